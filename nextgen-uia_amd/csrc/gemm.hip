@@ -1,0 +1,286 @@
+// gemm.hip — the one dense-contraction kernel of the library:
+//     C[M,N] = epilogue( A[M,K] · W[N,K]^T )            ("TN": both operands K-contiguous)
+//
+// Every Linear of the reference's hot path is an instance of it:
+//   forward   y = x·Wᵀ + b         W is the nn.Linear weight [out,in] as stored
+//                                  (timm Attention.qkv / proj, Mlp.fc1 / fc2; OpenAI CLIP
+//                                  in_proj / out_proj / c_fc / c_proj, src/third_party/openai_clip/model.py:181-188;
+//                                  Mona project1 / project2, src/adapters/mona.py:331,358;
+//                                  LoRA rank factors, src/adapters/lora.py:78-90)
+//   dgrad     dx = dy·W            run as TN against the host-cached transpose Wᵀ [in,out]
+//                                  (frozen weights: transposed once at setup; adapter weights: per step)
+//
+// gfx950 design:
+//   * BM×BN output tile per workgroup, 64-lane waves in a WAVES_M×WAVES_N grid, each wave owns
+//     (BM/WAVES_M)×(BN/WAVES_N) of C as 16×16 MFMA tiles (v_mfma_f32_16x16x32_bf16, or
+//     v_mfma_f32_16x16x4_f32 for the fp32-parity mode: gfx950 has no xf32).
+//   * one K-step = 128 bytes of every row (64 bf16 / 32 fp32), staged HBM→LDS with
+//     global_load_lds_dwordx4 (no VGPR round trip), double-buffered, one barrier per K-step.
+//   * LDS image is lane-linear (a glds requirement); bank conflicts are removed by an XOR
+//     swizzle applied to the per-lane SOURCE chunk and again on the ds_read_b128 address.
+//   * MFMA is issued "swapped" (W fragment as the A operand) with the W rows of a wave tile
+//     permuted so that each lane ends up owning 4·NT consecutive output columns of one row:
+//     the epilogue then loads bias/residual and stores C in 16-byte pieces.
+//   * workgroup ids are remapped so that each XCD (private L2) walks a contiguous run of tiles.
+#include "uia_common.h"
+#include "uia_kernels.h"
+
+namespace {
+
+template <typename T> struct MfmaTile;
+
+template <> struct MfmaTile<bf16_t> {
+    // 16-byte chunk = 8 bf16 = one 16x16x32 operand fragment
+    static __device__ __forceinline__ f32x4 mma(const uint4& w, const uint4& a, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w),
+                                                       __builtin_bit_cast(bf16x8, a), c, 0, 0, 0);
+    }
+};
+template <> struct MfmaTile<float> {
+    // 16-byte chunk = 4 fp32: lane (row, g) holds k = 4·chunk + e; the four 16x16x4 MFMAs each
+    // contract the e-th element of every lane group (the k order inside a chunk is free as long
+    // as both operands agree on it).
+    static __device__ __forceinline__ f32x4 mma(const uint4& w, const uint4& a, f32x4 c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, w.x), __builtin_bit_cast(float, a.x), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, w.y), __builtin_bit_cast(float, a.y), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, w.z), __builtin_bit_cast(float, a.z), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, w.w), __builtin_bit_cast(float, a.w), c, 0, 0, 0);
+        return c;
+    }
+};
+
+__device__ __forceinline__ float apply_act(float x, int act) {
+    switch (act) {
+        case UIA_ACT_GELU: return gelu_erf(x);
+        case UIA_ACT_QUICKGELU: return quick_gelu(x);
+        case UIA_ACT_RELU: return fmaxf(x, 0.0f);
+        default: return x;
+    }
+}
+__device__ __forceinline__ float apply_dact(float pre, int act) {
+    switch (act) {
+        case UIA_ACT_GELU: return dgelu_erf(pre);
+        case UIA_ACT_QUICKGELU: return dquick_gelu(pre);
+        case UIA_ACT_RELU: return pre > 0.0f ? 1.0f : 0.0f;
+        default: return 1.0f;
+    }
+}
+
+__device__ __forceinline__ void glds16(const char* gsrc, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_tn_kernel(const UiaGemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NW = WAVES_M * WAVES_N;
+    constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+    constexpr int MT = WTM / 16, NT = WTN / 16;
+    constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, BUF_BYTES = A_BYTES + W_BYTES;
+    constexpr int A_PER_WAVE = (BM / 8) / NW, W_PER_WAVE = (BN / 8) / NW;
+    static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "staging must divide over the waves");
+    static_assert(WTM % 16 == 0 && WTN % 16 == 0 && (NT % 2) == 0, "wave tile shape");
+    constexpr int ESZ = (int)sizeof(T);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+    // ---- XCD-aware (bijective) workgroup → tile map: blocks b and b+8 share an XCD, so give
+    //      each XCD one contiguous run of tiles; inside a run consecutive tiles share the A panel.
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // ---- per-lane staging sources (K offset added per step). Rows past M / N are clamped:
+    //      they feed accumulators that are never stored.
+    const char* srcA[A_PER_WAVE];
+    const char* srcW[W_PER_WAVE];
+#pragma unroll
+    for (int i = 0; i < A_PER_WAVE; ++i) {
+        const int r = 8 * (wave + NW * i) + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        int gm = m0 + r;
+        gm = gm < p.M ? gm : p.M - 1;
+        srcA[i] = (const char*)p.A + ((size_t)gm * (size_t)p.lda) * ESZ + c * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < W_PER_WAVE; ++i) {
+        const int r = 8 * (wave + NW * i) + (lane >> 3);
+        const int rl = r & (WTN - 1);
+        const int x = ((rl / (4 * NT)) << 1) | ((rl & 3) >> 1);
+        const int c = (lane & 7) ^ x;
+        int gn = n0 + r;
+        gn = gn < p.N ? gn : p.N - 1;
+        srcW[i] = (const char*)p.W + ((size_t)gn * (size_t)p.ldw) * ESZ + c * 16;
+    }
+
+    // ---- per-lane fragment read offsets inside one LDS buffer
+    const int li = lane & 15, g = lane >> 4;
+    // A tile (MFMA B operand): row = wm*WTM + 16*mt + li, chunk = g + 4*kk, swizzle (row>>1)&7
+    const int offA0 = (wm * WTM + li) * 128 + ((g ^ (li >> 1)) << 4);
+    // W tile (MFMA A operand): wave-local row = (li>>2)*4NT + 4*j + (li&3)
+    const int xw = ((li >> 2) << 1) | ((li & 3) >> 1);
+    const int offW0 = A_BYTES + (wn * WTN + (li >> 2) * (4 * NT) + (li & 3)) * 128 + ((g ^ xw) << 4);
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / (128 / ESZ);
+
+    auto stage = [&](int s, int buf) {
+        char* base = smem + buf * BUF_BYTES;
+        const size_t koff = (size_t)s * 128;
+#pragma unroll
+        for (int i = 0; i < A_PER_WAVE; ++i) glds16(srcA[i] + koff, base + (wave + NW * i) * 1024);
+#pragma unroll
+        for (int i = 0; i < W_PER_WAVE; ++i) glds16(srcW[i] + koff, base + A_BYTES + (wave + NW * i) * 1024);
+    };
+
+    stage(0, 0);
+    for (int s = 0; s < nk; ++s) {
+        // tile s has landed (own glds: vmcnt(0); everyone else's: the barrier), and every wave
+        // has finished reading the other buffer (its MFMAs of step s-1 precede the barrier).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (s + 1 < nk) stage(s + 1, (s + 1) & 1);
+        const char* buf = smem + (s & 1) * BUF_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            uint4 af[MT], wf[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) wf[j] = *(const uint4*)(buf + ((offW0 + j * 4 * 128) ^ (kk << 6)));
+#pragma unroll
+            for (int i = 0; i < MT; ++i) af[i] = *(const uint4*)(buf + ((offA0 + i * 16 * 128) ^ (kk << 6)));
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = MfmaTile<T>::mma(wf[j], af[i], acc[i][j]);
+        }
+    }
+
+    // ---- epilogue: lane owns row m, columns nb .. nb+4NT-1 (nb multiple of 16)
+    const int nb = n0 + wn * WTN + g * (4 * NT);
+    T* outT = (T*)p.outT;
+    const T* aux_in = (const T*)p.aux_in;
+    T* aux_out = (T*)p.aux_out;
+    const T* residT = (const T*)p.residT;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int m = m0 + wm * WTM + 16 * i + li;
+        if (m >= p.M) continue;
+        const size_t orow = p.out_group > 0 ? (size_t)(m + m / p.out_group + 1) : (size_t)m;
+        const size_t rrow = p.resid_mod > 0 ? (size_t)(m % p.resid_mod + p.resid_row_off) : orow;
+#pragma unroll
+        for (int jj = 0; jj < NT; jj += 2) {
+            const int n = nb + 4 * jj;
+            if (n >= p.N) continue;   // N is a multiple of 8 (checked on the host)
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = acc[i][jj][e] * p.alpha; v[4 + e] = acc[i][jj + 1][e] * p.alpha; }
+            if (p.bias) {
+                float b[8];
+                load8(p.bias + n, b);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += b[e];
+            }
+            if (aux_out) store8(aux_out + orow * p.ldaux_out + n, v);
+            if (p.act) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e], p.act);
+            }
+            if (p.dact) {
+                float a[8];
+                load8(aux_in + orow * p.ldaux_in + n, a);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= apply_dact(a[e], p.dact);
+            }
+            if (p.resid) {
+                float r[8];
+                load8(p.resid + rrow * p.ldr + n, r);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += r[e];
+            }
+            if (residT) {
+                float r[8];
+                load8(residT + orow * p.ldrT + n, r);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += r[e];
+            }
+            if (p.out32) store8(p.out32 + orow * p.ldo32 + n, v);
+            if (outT) store8(outT + orow * p.ldo + n, v);
+        }
+    }
+}
+
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
+int launch_cfg(hipStream_t stream, const UiaGemmParams& p) {
+    constexpr int LDS = 2 * (BM + BN) * 128;
+    auto kern = gemm_tn_kernel<T, BM, BN, WAVES_M, WAVES_N>;
+    static bool attr_set = false;   // one process per GPU, calls come from one host thread at a time
+    if (!attr_set) {
+        UIA_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_set = true;
+    }
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(64 * WAVES_M * WAVES_N), LDS, stream, p);
+    UIA_CHECK_LAUNCH();
+    return 0;
+}
+
+template <typename T>
+int launch_typed(hipStream_t stream, const UiaGemmParams& p, int cfg) {
+    // cfg: 0 = auto. Tile choice is a pure speed knob (results are identical for every config
+    // up to fp32 summation order inside a K-step, which does not depend on the tile).
+    if (cfg == 0) {
+        if (p.N <= 64) cfg = 4;
+        else if (p.M <= 2048) cfg = 3;
+        else if (p.N % 256 == 0 && p.N >= 2048) cfg = 1;
+        else cfg = 2;
+    }
+    switch (cfg) {
+        case 1: return launch_cfg<T, 256, 256, 2, 4>(stream, p);
+        case 2: return launch_cfg<T, 256, 128, 4, 2>(stream, p);
+        case 3: return launch_cfg<T, 128, 128, 2, 2>(stream, p);
+        case 4: return launch_cfg<T, 256, 64, 4, 1>(stream, p);
+        case 5: return launch_cfg<T, 128, 64, 2, 1>(stream, p);
+        default: uia_set_error("uia_gemm: unknown tile config %d", cfg); return -1;
+    }
+}
+
+}  // namespace
+
+int uia_gemm_launch(hipStream_t stream, int dtype, const UiaGemmParams& p, int cfg) {
+    const int esz = dtype == UIA_BF16 ? 2 : 4;
+    const int bk = 128 / esz;
+    UIA_CHECK_ARG(dtype == UIA_BF16 || dtype == UIA_F32, "uia_gemm: bad dtype %d", dtype);
+    UIA_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "uia_gemm: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
+    UIA_CHECK_ARG(p.K % bk == 0, "uia_gemm: K=%d must be a multiple of %d for this dtype", p.K, bk);
+    UIA_CHECK_ARG(p.N % 8 == 0, "uia_gemm: N=%d must be a multiple of 8", p.N);
+    UIA_CHECK_ARG(p.A && p.W, "uia_gemm: null operand");
+    UIA_CHECK_ARG(p.lda >= p.K && p.ldw >= p.K, "uia_gemm: leading dimension smaller than K");
+    UIA_CHECK_ARG((p.lda * esz) % 16 == 0 && (p.ldw * esz) % 16 == 0, "uia_gemm: rows must be 16-byte aligned");
+    UIA_CHECK_ARG(((uintptr_t)p.A % 16) == 0 && ((uintptr_t)p.W % 16) == 0, "uia_gemm: operands must be 16-byte aligned");
+    UIA_CHECK_ARG(p.outT || p.out32, "uia_gemm: no output");
+    UIA_CHECK_ARG(!p.outT || (p.ldo % 8 == 0 && (uintptr_t)p.outT % 16 == 0), "uia_gemm: outT alignment");
+    UIA_CHECK_ARG(!p.out32 || (p.ldo32 % 4 == 0 && (uintptr_t)p.out32 % 16 == 0), "uia_gemm: out32 alignment");
+    UIA_CHECK_ARG(!p.resid || (p.ldr % 4 == 0 && (uintptr_t)p.resid % 16 == 0), "uia_gemm: resid alignment");
+    UIA_CHECK_ARG(!p.residT || (p.ldrT % 8 == 0 && (uintptr_t)p.residT % 16 == 0), "uia_gemm: residT alignment");
+    UIA_CHECK_ARG(!p.bias || (uintptr_t)p.bias % 16 == 0, "uia_gemm: bias alignment");
+    UIA_CHECK_ARG(!p.dact || p.aux_in, "uia_gemm: dact needs aux_in");
+    UIA_CHECK_ARG(!p.aux_in || (p.ldaux_in % 8 == 0 && (uintptr_t)p.aux_in % 16 == 0), "uia_gemm: aux_in alignment");
+    UIA_CHECK_ARG(!p.aux_out || (p.ldaux_out % 8 == 0 && (uintptr_t)p.aux_out % 16 == 0), "uia_gemm: aux_out alignment");
+    UIA_CHECK_ARG(p.resid_mod == 0 || p.resid, "uia_gemm: resid_mod without resid");
+    if (dtype == UIA_BF16) return launch_typed<bf16_t>(stream, p, cfg);
+    return launch_typed<float>(stream, p, cfg);
+}

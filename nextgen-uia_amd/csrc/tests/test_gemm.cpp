@@ -1,0 +1,148 @@
+// test_gemm.cpp — on-device check + timing of gemm.hip against a float64 host reference.
+// Build: see csrc/Makefile (target tests/test_gemm). Run on the GPU box only.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "../uia_kernels.h"
+extern "C" const char* uia_last_error(void);
+
+#define HC(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(2); } } while (0)
+
+static uint32_t rng = 12345;
+static float frand() { rng = rng * 1664525u + 1013904223u; return ((rng >> 8) & 0xFFFF) / 32768.0f - 1.0f; }
+static uint16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); u = (u + 0x7FFF + ((u >> 16) & 1)) >> 16; return (uint16_t)u; }
+static float bf2f(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
+static double gelu(double x) { return 0.5 * x * (1.0 + erf(x / sqrt(2.0))); }
+static double dgelu(double x) { return 0.5 * (1.0 + erf(x / sqrt(2.0))) + x * exp(-0.5 * x * x) / sqrt(2.0 * M_PI); }
+
+struct Buf { void* d; size_t bytes; };
+template <typename H> static void* upload(const std::vector<H>& v) { void* d; HC(hipMalloc(&d, v.size() * sizeof(H))); HC(hipMemcpy(d, v.data(), v.size() * sizeof(H), hipMemcpyHostToDevice)); return d; }
+
+// returns max relative error (normalised by max|ref|)
+static int check(int dtype, int M, int N, int K, int cfg, int mode) {
+    const bool bf = dtype == UIA_BF16;
+    std::vector<float> A((size_t)M * K), W((size_t)N * K), bias(N), resid((size_t)M * N), aux((size_t)M * N);
+    for (auto& x : A) x = frand();
+    for (auto& x : W) x = frand() * 0.1f;
+    for (auto& x : bias) x = frand();
+    for (auto& x : resid) x = frand();
+    for (auto& x : aux) x = frand() * 2.0f;
+    if (bf) { for (auto& x : A) x = bf2f(f2bf(x)); for (auto& x : W) x = bf2f(f2bf(x)); for (auto& x : aux) x = bf2f(f2bf(x)); }
+    void *dA, *dW, *dAux;
+    if (bf) {
+        std::vector<uint16_t> a16(A.size()), w16(W.size()), x16(aux.size());
+        for (size_t i = 0; i < A.size(); ++i) a16[i] = f2bf(A[i]);
+        for (size_t i = 0; i < W.size(); ++i) w16[i] = f2bf(W[i]);
+        for (size_t i = 0; i < aux.size(); ++i) x16[i] = f2bf(aux[i]);
+        dA = upload(a16); dW = upload(w16); dAux = upload(x16);
+    } else { dA = upload(A); dW = upload(W); dAux = upload(aux); }
+    void* dBias = upload(bias); void* dRes = upload(resid);
+    const size_t esz = bf ? 2 : 4;
+    void *dOutT, *dAuxOut; float* dOut32;
+    HC(hipMalloc(&dOutT, (size_t)M * N * esz)); HC(hipMalloc(&dAuxOut, (size_t)M * N * esz)); HC(hipMalloc((void**)&dOut32, (size_t)M * N * 4));
+    HC(hipMemset(dOutT, 0xFF, (size_t)M * N * esz)); HC(hipMemset(dOut32, 0xFF, (size_t)M * N * 4));
+
+    UiaGemmParams p; memset(&p, 0, sizeof(p));
+    p.A = dA; p.lda = K; p.W = dW; p.ldw = K; p.M = M; p.N = N; p.K = K; p.alpha = 1.0f;
+    p.outT = dOutT; p.ldo = N; p.out32 = dOut32; p.ldo32 = N;
+    // mode 0: plain; 1: bias+gelu+aux_out; 2: bias+resid; 3: dact(gelu) from aux_in; 4: alpha
+    if (mode == 1) { p.bias = (float*)dBias; p.act = UIA_ACT_GELU; p.aux_out = dAuxOut; p.ldaux_out = N; }
+    if (mode == 2) { p.bias = (float*)dBias; p.resid = (float*)dRes; p.ldr = N; }
+    if (mode == 3) { p.dact = UIA_ACT_GELU; p.aux_in = dAux; p.ldaux_in = N; }
+    if (mode == 4) { p.alpha = 0.25f; }
+    if (uia_gemm_launch(0, dtype, p, cfg) != 0) { printf("launch failed: %s\n", uia_last_error()); return 1; }
+    HC(hipDeviceSynchronize());
+    std::vector<float> o32((size_t)M * N);
+    HC(hipMemcpy(o32.data(), dOut32, o32.size() * 4, hipMemcpyDeviceToHost));
+    std::vector<float> oT((size_t)M * N);
+    if (bf) { std::vector<uint16_t> t(oT.size()); HC(hipMemcpy(t.data(), dOutT, t.size() * 2, hipMemcpyDeviceToHost)); for (size_t i = 0; i < t.size(); ++i) oT[i] = bf2f(t[i]); }
+    else HC(hipMemcpy(oT.data(), dOutT, oT.size() * 4, hipMemcpyDeviceToHost));
+    std::vector<float> oAux;
+    if (mode == 1) { oAux.resize((size_t)M * N); if (bf) { std::vector<uint16_t> t(oAux.size()); HC(hipMemcpy(t.data(), dAuxOut, t.size() * 2, hipMemcpyDeviceToHost)); for (size_t i = 0; i < t.size(); ++i) oAux[i] = bf2f(t[i]); } else HC(hipMemcpy(oAux.data(), dAuxOut, oAux.size() * 4, hipMemcpyDeviceToHost)); }
+
+    double maxref = 0, maxerr32 = 0, maxerrT = 0, maxerrAux = 0;
+    // sample rows to keep the host reference cheap on big shapes
+    int step = M > 1024 ? M / 257 : 1;
+    for (int m = 0; m < M; m += step) for (int n = 0; n < N; ++n) {
+        double acc = 0; const float* a = &A[(size_t)m * K]; const float* w = &W[(size_t)n * K];
+        for (int k = 0; k < K; ++k) acc += (double)a[k] * (double)w[k];
+        double pre = acc * p.alpha + (p.bias ? bias[n] : 0.0), v = pre;
+        if (mode == 1) v = gelu(pre);
+        if (mode == 3) v = pre * dgelu(aux[(size_t)m * N + n]);
+        if (mode == 2) v += resid[(size_t)m * N + n];
+        maxref = fmax(maxref, fabs(v));
+        maxerr32 = fmax(maxerr32, fabs(v - o32[(size_t)m * N + n]));
+        maxerrT = fmax(maxerrT, fabs(v - oT[(size_t)m * N + n]));
+        if (mode == 1) maxerrAux = fmax(maxerrAux, fabs(pre - oAux[(size_t)m * N + n]));
+    }
+    const double tol32 = bf ? 2e-5 : 2e-6, tolT = bf ? 6e-3 : 2e-6;   // bf16 operands are exact here; only the T output rounds
+    const bool ok = maxerr32 / maxref < tol32 && maxerrT / maxref < tolT && maxerrAux / maxref < tolT;
+    printf("%s dtype=%s M=%d N=%d K=%d cfg=%d mode=%d  rel32=%.2e relT=%.2e relAux=%.2e (maxref %.3f)\n", ok ? "PASS" : "FAIL",
+           bf ? "bf16" : "f32", M, N, K, cfg, mode, maxerr32 / maxref, maxerrT / maxref, maxerrAux / maxref, maxref);
+    hipFree(dA); hipFree(dW); hipFree(dAux); hipFree(dBias); hipFree(dRes); hipFree(dOutT); hipFree(dAuxOut); hipFree(dOut32);
+    return ok ? 0 : 1;
+}
+
+static void bench(int dtype, int M, int N, int K, int cfg, int mode) {
+    const size_t esz = dtype == UIA_BF16 ? 2 : 4;
+    void *dA, *dW, *dO, *dAux; float *dRes, *dBias;
+    HC(hipMalloc(&dA, (size_t)M * K * esz)); HC(hipMalloc(&dW, (size_t)N * K * esz)); HC(hipMalloc(&dO, (size_t)M * N * esz));
+    HC(hipMalloc(&dAux, (size_t)M * N * esz)); HC(hipMalloc((void**)&dRes, (size_t)M * N * 4)); HC(hipMalloc((void**)&dBias, N * 4));
+    // random bf16 / fp32 bit patterns of sane magnitude
+    { std::vector<uint16_t> h((size_t)M * K * esz / 2); for (auto& x : h) x = f2bf(frand()); if (esz == 4) { float* f = (float*)h.data(); for (size_t i = 0; i < h.size() / 2; ++i) f[i] = frand(); } HC(hipMemcpy(dA, h.data(), h.size() * 2, hipMemcpyHostToDevice)); }
+    { std::vector<uint16_t> h((size_t)N * K * esz / 2); for (auto& x : h) x = f2bf(frand() * 0.05f); if (esz == 4) { float* f = (float*)h.data(); for (size_t i = 0; i < h.size() / 2; ++i) f[i] = frand() * 0.05f; } HC(hipMemcpy(dW, h.data(), h.size() * 2, hipMemcpyHostToDevice)); }
+    HC(hipMemset(dRes, 0, (size_t)M * N * 4)); HC(hipMemset(dBias, 0, N * 4)); HC(hipMemset(dAux, 0, (size_t)M * N * esz));
+    UiaGemmParams p; memset(&p, 0, sizeof(p));
+    p.A = dA; p.lda = K; p.W = dW; p.ldw = K; p.M = M; p.N = N; p.K = K; p.alpha = 1.0f;
+    if (mode == 0) { p.outT = dO; p.ldo = N; p.bias = dBias; }
+    if (mode == 1) { p.outT = dO; p.ldo = N; p.bias = dBias; p.act = UIA_ACT_GELU; p.aux_out = dAux; p.ldaux_out = N; }
+    if (mode == 2) { p.out32 = dRes; p.ldo32 = N; p.bias = dBias; p.resid = dRes; p.ldr = N; }
+    hipEvent_t e0, e1; HC(hipEventCreate(&e0)); HC(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) uia_gemm_launch(0, dtype, p, cfg);
+    HC(hipDeviceSynchronize());
+    const int iters = 20;
+    HC(hipEventRecord(e0, 0));
+    for (int i = 0; i < iters; ++i) uia_gemm_launch(0, dtype, p, cfg);
+    HC(hipEventRecord(e1, 0)); HC(hipEventSynchronize(e1));
+    float ms; HC(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
+    printf("BENCH dtype=%s M=%d N=%d K=%d cfg=%d mode=%d  %.3f ms  %.1f TFLOP/s\n", dtype == UIA_BF16 ? "bf16" : "f32", M, N, K, cfg, mode, ms, 2.0 * M * N * K / ms * 1e-9);
+    hipFree(dA); hipFree(dW); hipFree(dO); hipFree(dAux); hipFree(dRes); hipFree(dBias);
+}
+
+int main(int argc, char** argv) {
+    int fails = 0;
+    const int dts[2] = {UIA_BF16, UIA_F32};
+    for (int d = 0; d < 2; ++d) {
+        const int dt = dts[d];
+        for (int cfg = 1; cfg <= 5; ++cfg) {
+            const int N = (cfg >= 4) ? 64 : 384;
+            fails += check(dt, 300, N, 128, cfg, 0);          // ragged M, single N tile edge
+            fails += check(dt, 197 * 3, N, 256, cfg, 1);
+            fails += check(dt, 512, N, 64 , cfg, 2);           // single K step
+            fails += check(dt, 77, N, 192, cfg, 3);
+        }
+        fails += check(dt, 1000, 776, 320, 0, 4);   // N not a multiple of the tile
+        fails += check(dt, 4096, 768, 768, 0, 2);
+        fails += check(dt, 2500, 2304, 768, 0, 0);
+    }
+    printf("correctness: %d failures\n", fails);
+    if (argc > 1 && !strcmp(argv[1], "bench")) {
+        const int M = 50432;
+        for (int cfg = 1; cfg <= 3; ++cfg) {
+            bench(UIA_BF16, M, 2304, 768, cfg, 0);
+            bench(UIA_BF16, M, 768, 768, cfg, 2);
+            bench(UIA_BF16, M, 3072, 768, cfg, 1);
+            bench(UIA_BF16, M, 768, 3072, cfg, 2);
+        }
+        bench(UIA_BF16, M, 64, 768, 4, 0);
+        bench(UIA_BF16, M, 64, 768, 5, 0);
+        bench(UIA_BF16, M, 768, 64, 0, 2);
+        bench(UIA_BF16, 8192, 8192, 8192, 1, 0);
+        bench(UIA_F32, M, 2304, 768, 1, 0);
+        bench(UIA_F32, M, 768, 3072, 2, 2);
+    }
+    return fails ? 1 : 0;
+}

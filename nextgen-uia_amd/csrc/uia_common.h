@@ -1,0 +1,141 @@
+// uia_common.h — shared device/host helpers for libuia_hip.so (gfx950 / CDNA4 only).
+//
+// Conventions used by every kernel in this directory:
+//   * wavefront = 64 lanes, hard-coded.
+//   * "T" is the activation/operand element type: __bf16 (UIA_BF16) or float (UIA_F32).
+//     All arithmetic is fp32; T only decides how operands are stored in HBM/LDS.
+//   * the residual stream and every parameter gradient are fp32 in both modes.
+//   * all tensors are row-major contiguous unless a leading dimension is passed.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define UIA_WAVE 64
+
+// ---------------------------------------------------------------- error plumbing (host)
+void uia_set_error(const char* fmt, ...);
+#define UIA_CHECK_ARG(cond, ...)                 \
+    do {                                         \
+        if (!(cond)) {                           \
+            uia_set_error(__VA_ARGS__);          \
+            return -1;                           \
+        }                                        \
+    } while (0)
+#define UIA_CHECK_HIP(expr)                                                              \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess) {                                                          \
+            uia_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),         \
+                          __FILE__, __LINE__);                                           \
+            return -2;                                                                   \
+        }                                                                                \
+    } while (0)
+#define UIA_CHECK_LAUNCH() UIA_CHECK_HIP(hipGetLastError())
+
+// ---------------------------------------------------------------- element load/store
+__device__ __forceinline__ float to_f32(float x) { return x; }
+__device__ __forceinline__ float to_f32(bf16_t x) { return (float)x; }
+
+template <typename T> __device__ __forceinline__ T from_f32(float x);
+template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) { return (bf16_t)x; }
+
+// 4 consecutive elements <-> f32x4
+__device__ __forceinline__ f32x4 load4(const float* p) { return *(const f32x4*)p; }
+__device__ __forceinline__ f32x4 load4(const bf16_t* p) {
+    bf16x4 v = *(const bf16x4*)p;
+    f32x4 r = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    return r;
+}
+__device__ __forceinline__ void store4(float* p, f32x4 v) { *(f32x4*)p = v; }
+__device__ __forceinline__ void store4(bf16_t* p, f32x4 v) {
+    bf16x4 r = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+    *(bf16x4*)p = r;
+}
+// 8 consecutive elements (16 B of bf16 / 32 B of f32)
+__device__ __forceinline__ void load8(const float* p, float (&o)[8]) {
+    f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+    o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3];
+    o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
+}
+__device__ __forceinline__ void load8(const bf16_t* p, float (&o)[8]) {
+    bf16x8 v = *(const bf16x8*)p;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (float)v[i];
+}
+__device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
+    f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+    *(f32x4*)p = a;
+    *(f32x4*)(p + 4) = b;
+}
+__device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
+    bf16x8 r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = (bf16_t)v[i];
+    *(bf16x8*)p = r;
+}
+
+// ---------------------------------------------------------------- math
+// erf with |abs err| <= 1.5e-7 (Abramowitz & Stegun 7.1.26): one v_exp + one v_rcp.
+__device__ __forceinline__ float erf_as(float x) {
+    const float ax = fabsf(x);
+    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+    float y = fmaf(1.061405429f, t, -1.453152027f);
+    y = fmaf(y, t, 1.421413741f);
+    y = fmaf(y, t, -0.284496736f);
+    y = fmaf(y, t, 0.254829592f);
+    y = y * t * __expf(-ax * ax);
+    const float r = 1.0f - y;
+    return copysignf(r, x);
+}
+// exact-erf GELU (timm / HF BERT / F.gelu default) and its derivative
+__device__ __forceinline__ float gelu_erf(float x) {
+    return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f));
+}
+__device__ __forceinline__ float dgelu_erf(float x) {
+    const float cdf = 0.5f * (1.0f + erf_as(x * 0.70710678118654752f));
+    const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+    return fmaf(x, pdf, cdf);
+}
+// QuickGELU x*sigmoid(1.702x) (reference src/third_party/openai_clip/model.py:172-174)
+__device__ __forceinline__ float quick_gelu(float x) {
+    return x * __frcp_rn(1.0f + __expf(-1.702f * x));
+}
+__device__ __forceinline__ float dquick_gelu(float x) {
+    const float s = __frcp_rn(1.0f + __expf(-1.702f * x));
+    return s * fmaf(1.702f * x, 1.0f - s, 1.0f);
+}
+
+// ---------------------------------------------------------------- wave reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---------------------------------------------------------------- counter-based dropout RNG
+// keep(idx) is a pure function of (seed, idx): forward and backward regenerate the same mask,
+// so no mask tensor is stored.  (The reference uses torch's Philox stream,
+// src/adapters/mona.py:109,147; bit-matching that stream is a documented non-goal.)
+__device__ __forceinline__ uint32_t uia_hash32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU;
+    x ^= x >> 15; x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ bool dropout_keep(uint64_t seed, uint32_t idx, uint32_t thresh) {
+    // thresh = floor(p * 2^32); keep iff hash >= thresh
+    uint32_t h = uia_hash32(idx ^ (uint32_t)seed) ^ uia_hash32((idx * 0x9E3779B9U) + (uint32_t)(seed >> 32));
+    return uia_hash32(h) >= thresh;
+}
