@@ -1,0 +1,254 @@
+"""Generate tests/golden/*.npz from the IMPORTED reference.  Runs only in the build container
+(needs /root/reference); the fixtures it writes are committed, the reference code never is.
+
+    python oracle/gen_golden.py            # rewrites tests/golden/
+
+Each fixture holds inputs, deterministic formula-filled parameters, and the reference's outputs
+and autograd gradients, at toy dimensions (KBs).  fill(shape,a,b,scale,fn) = scale*fn(a*arange+b)
+evaluated in float64 and cast to fp32, so fixtures are reproducible bit for bit.
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+
+def fill(shape, a, b, scale=1.0, fn=np.sin):
+    n = int(np.prod(shape))
+    return torch.from_numpy((scale * fn(a * np.arange(n, dtype=np.float64) + b)).astype(np.float32).reshape(shape))
+
+
+def load_by_path(name, rel):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, rel))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def np_dict(d):
+    return {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in d.items()}
+
+
+def save(name, **arrays):
+    os.makedirs(OUT, exist_ok=True)
+    np.savez(os.path.join(OUT, name + ".npz"), **np_dict(arrays))
+    print("wrote", name, sum(np.asarray(v).size for v in np_dict(arrays).values()), "values")
+
+
+def fill_module(mod, a=0.37, scale=0.1):
+    with torch.no_grad():
+        for n, (_, p) in enumerate(mod.named_parameters()):
+            p.copy_(fill(tuple(p.shape), a, float(n), scale))
+
+
+def gen_mona(mona):
+    classes = {"baseline": mona.BaselineMona, "noise_aware": mona.NoiseAwareMona,
+               "freq_enhanced": mona.FreqEnhancedMona, "hybrid": mona.HybridNoiseFreqMona}
+    for variant, cls in classes.items():
+        torch.manual_seed(0)
+        m = cls(32, 8).eval()
+        fill_module(m)
+        # KAT2 input (sequence-first [N,B,D]) plus a second, larger-amplitude case with a dropout mask
+        x = fill((17, 2, 32), 0.11, 0.0).requires_grad_(True)
+        y = m(x, (4, 4))
+        (y.square().sum()).backward()
+        arrays = {"x_nbd": x, "y_nbd": y, "dx_nbd": x.grad}
+        for k, p in m.named_parameters():
+            arrays["p." + k] = p
+            arrays["g." + k] = p.grad
+        save(f"mona_{variant}", **arrays)
+
+        # training-mode case: deterministic keep mask injected by patching the module's dropout
+        m.zero_grad()
+        keep = (fill((2, 17, 8), 0.77, 1.0) > -0.6).float()      # ~80 % kept, batch-first [B,N,b]
+
+        class FixedDrop(torch.nn.Module):
+            def forward(self, g):
+                return g * keep / 0.9
+        m.dropout = FixedDrop()
+        x2 = (fill((17, 2, 32), 0.23, 1.0) * 3.0).requires_grad_(True)
+        y2 = m(x2, (4, 4))
+        (y2 * fill((17, 2, 32), 0.05, 2.0)).sum().backward()
+        arrays = {"x_nbd": x2, "y_nbd": y2, "dx_nbd": x2.grad, "keep_bnb": keep, "dy_nbd": fill((17, 2, 32), 0.05, 2.0)}
+        for k, p in m.named_parameters():
+            arrays["p." + k] = p
+            arrays["g." + k] = p.grad
+        save(f"mona_{variant}_drop", **arrays)
+
+
+def gen_lora(lora):
+    lin = torch.nn.Linear(8, 6)
+    with torch.no_grad():
+        lin.weight.copy_(fill((6, 8), 0.37, 0.0, 0.1))
+        lin.bias.copy_(fill((6,), 0.37, 1.0, 0.1))
+    ll = lora.LinearLoRA(lin, r=2, lora_alpha=4, dropout_rate=0.0)
+    with torch.no_grad():
+        ll.w_lora_A.copy_(fill((2, 8), 0.37, 2.0, 0.1))
+        ll.w_lora_B.copy_(fill((6, 2), 0.37, 3.0, 0.1))
+    x = fill((3, 8), 0.11, 0.0).requires_grad_(True)
+    y = ll(x)
+    y.square().sum().backward()
+    save("lora_linear", x=x, y=y, dx=x.grad, W=ll.weight, b=ll.bias, A=ll.w_lora_A, B=ll.w_lora_B,
+         dA=ll.w_lora_A.grad, dB=ll.w_lora_B.grad, db=ll.bias.grad, scaling=np.float32(ll.scaling))
+
+    mha = torch.nn.MultiheadAttention(16, 2)
+    fill_module(mha, 0.29, 0.2)
+    pm = lora.PlainMultiheadAttentionLoRA(mha, enable_lora=["q", "k", "v", "o"], r=4, lora_alpha=8, dropout_rate=0.0)
+    with torch.no_grad():
+        for n, (k, p) in enumerate(pm.named_parameters()):
+            if "lora" in k:
+                p.copy_(fill(tuple(p.shape), 0.41, float(n), 0.2))
+    x = fill((5, 3, 16), 0.13, 0.5).requires_grad_(True)
+    y, _ = pm(x, x, x)
+    y.square().sum().backward()
+    arrays = {"x_lbd": x, "y_lbd": y, "dx_lbd": x.grad}
+    for k, p in pm.named_parameters():
+        arrays["p." + k] = p
+        if p.grad is not None:
+            arrays["g." + k] = p.grad
+    save("lora_mha", **arrays)
+
+
+def gen_infonce(losses):
+    crit = losses.InfoNCELoss(0.07)
+    I = fill((4, 8), 0.37, 1.0).requires_grad_(True)
+    T = fill((4, 8), 0.23, 2.0, 1.0, np.cos).requires_grad_(True)
+    loss = crit(I, T)
+    loss.backward()
+    save("infonce_kat1", I=I, T=T, loss=loss, dI=I.grad, dT=T.grad)
+    I = (fill((6, 16), 0.91, 0.3) * 2).requires_grad_(True)
+    T = (fill((6, 16), 0.53, 1.1) * 0.5).requires_grad_(True)
+    loss = losses.InfoNCELoss(0.2)(I, T)
+    loss.backward()
+    save("infonce_b6", I=I, T=T, loss=loss, dI=I.grad, dT=T.grad, temperature=np.float32(0.2))
+
+
+def gen_openai_clip(model_mod, mona, lora):
+    torch.manual_seed(0)
+    clip = model_mod.CLIP(16, 32, 2, 128, 8, 8, 50, 64, 2, 2).float().eval()   # embed16 res32 2 layers vision w128 (2 heads) patch8; text ctx8 w64 2 heads
+    fill_module(clip, 0.31, 0.08)
+    with torch.no_grad():   # keep LN gains near 1 so activations stay O(1)
+        for k, p in clip.named_parameters():
+            if k.endswith(("ln_1.weight", "ln_2.weight", "ln_pre.weight", "ln_post.weight", "ln_final.weight")):
+                p.add_(1.0)
+    img = fill((3, 3, 32, 32), 0.017, 0.0) * 0.5 + 0.5
+    ids = torch.tensor([[49, 3, 7, 11, 2, 0, 0, 0], [5, 49, 1, 1, 1, 1, 1, 1], [4, 9, 8, 7, 6, 5, 3, 49]])
+    with torch.no_grad():
+        fi, ft = clip.encode_image(img), clip.encode_text(ids)
+    arrays = {"images": img, "ids": ids, "image_features": fi, "text_features": ft}
+    for k, v in clip.state_dict().items():
+        arrays["p." + k] = v
+    save("openai_clip_base", **arrays)
+
+    # + Mona (all four variants share the same backbone fill)
+    for variant in ("baseline", "noise_aware", "freq_enhanced", "hybrid"):
+        torch.manual_seed(0)
+        c2 = model_mod.CLIP(16, 32, 2, 128, 8, 8, 50, 64, 2, 2).float().eval()
+        c2.load_state_dict(clip.state_dict())
+        for p in c2.parameters():
+            p.requires_grad_(False)
+        c2, cnt = mona.inject_mona_variant_to_clip(c2, variant=variant, bottleneck_dim=8)
+        c2.eval()   # the injected adapters are built in training mode; parity vectors are dropout-free
+        mp = [(k, p) for k, p in c2.named_parameters() if "mona" in k]
+        with torch.no_grad():
+            for n, (k, p) in enumerate(mp):
+                p.copy_(fill(tuple(p.shape), 0.37, float(n), 0.1))
+                if k.endswith(("norm.weight", "gammax")):
+                    p.add_(1.0)
+        for k, p in mp:
+            p.requires_grad_(True)
+        fi = c2.encode_image(img)
+        with torch.no_grad():
+            ft = c2.encode_text(ids)
+        from_losses = load_by_path("ref_losses", "src/losses/losses.py")
+        loss = from_losses.InfoNCELoss(0.07)(fi, ft)
+        loss.backward()
+        arrays = {"image_features": fi, "loss": loss, "count": np.int32(cnt)}
+        for k, p in mp:
+            arrays["p." + k] = p
+            arrays["g." + k] = p.grad
+        save(f"openai_clip_mona_{variant}", **arrays)
+
+    # + LoRA r=4 on q,k,v,o
+    c3 = model_mod.CLIP(16, 32, 2, 128, 8, 8, 50, 64, 2, 2).float().eval()
+    c3.load_state_dict(clip.state_dict())
+    for p in c3.parameters():
+        p.requires_grad_(False)
+    c3, cnt = lora.inject_lora_to_clip(c3, lora_r=4, lora_alpha=8, lora_dropout=0.0)
+    c3.eval()
+    lp = [(k, p) for k, p in c3.named_parameters() if "lora" in k]
+    with torch.no_grad():
+        for n, (k, p) in enumerate(lp):
+            p.copy_(fill(tuple(p.shape), 0.43, float(n), 0.15))
+    for k, p in lp:
+        p.requires_grad_(True)
+    fi = c3.encode_image(img)
+    fi.square().sum().backward()
+    arrays = {"image_features": fi, "count": np.int32(cnt)}
+    for k, p in c3.named_parameters():
+        if "attn" in k and "visual" in k:
+            arrays["p." + k] = p
+        if "lora" in k:
+            arrays["g." + k] = p.grad
+    save("openai_clip_lora", **arrays)
+
+
+def gen_hf_crosschecks():
+    """Third-party towers: capture the installed transformers implementations (the reference pins
+    transformers 4.57.1; 5.15.0 is what is installed here) for the timm-ViT and BERT recipes."""
+    from transformers import BertConfig, BertModel, ViTConfig, ViTModel
+    torch.manual_seed(0)
+    vcfg = ViTConfig(hidden_size=32, num_hidden_layers=2, num_attention_heads=2, intermediate_size=64, image_size=32,
+                     patch_size=8, layer_norm_eps=1e-6, hidden_act="gelu", hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    vit = ViTModel(vcfg, add_pooling_layer=False).eval()
+    fill_module(vit, 0.27, 0.1)
+    with torch.no_grad():
+        for k, p in vit.named_parameters():
+            if "layernorm" in k and k.endswith("weight"):
+                p.add_(1.0)
+    img = fill((2, 3, 32, 32), 0.019, 0.3) * 0.5 + 0.5
+    with torch.no_grad():
+        out = vit(pixel_values=img).last_hidden_state            # includes final layernorm
+    arrays = {"images": img, "tokens_ln": out}
+    for k, v in vit.state_dict().items():
+        arrays["hf." + k] = v
+    save("hf_vit_tiny", **arrays)
+
+    bcfg = BertConfig(vocab_size=60, hidden_size=32, num_hidden_layers=2, num_attention_heads=2, intermediate_size=64,
+                      max_position_embeddings=16, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, layer_norm_eps=1e-12)
+    bert = BertModel(bcfg, add_pooling_layer=False).eval()
+    fill_module(bert, 0.33, 0.12)
+    with torch.no_grad():
+        for k, p in bert.named_parameters():
+            if "LayerNorm.weight" in k:
+                p.add_(1.0)
+    ids = torch.tensor([[2, 17, 33, 41, 3, 0, 0, 0, 0, 0, 0, 0], [2, 9, 8, 7, 6, 5, 4, 11, 12, 13, 14, 3], [2, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0]])
+    with torch.no_grad():
+        hs = bert(input_ids=ids, attention_mask=(ids != 0).long()).last_hidden_state
+    arrays = {"ids": ids, "last_hidden_state": hs}
+    for k, v in bert.state_dict().items():
+        arrays["hf." + k] = v
+    save("hf_bert_tiny", **arrays)
+
+
+def main():
+    sys.path.insert(0, REF)
+    mona = load_by_path("ref_mona", "src/adapters/mona.py")
+    lora = load_by_path("ref_lora", "src/adapters/lora.py")
+    losses = load_by_path("ref_losses", "src/losses/losses.py")
+    model_mod = load_by_path("ref_clip_model", "src/third_party/openai_clip/model.py")
+    gen_mona(mona)
+    gen_lora(lora)
+    gen_infonce(losses)
+    gen_openai_clip(model_mod, mona, lora)
+    gen_hf_crosschecks()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,212 @@
+"""Pin the CPU oracle (oracle/*.py) to the golden vectors captured from the imported reference
+(oracle/gen_golden.py) and to the known-answer values of SURVEY.md Appendix B.  CPU only."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import lora_ref, losses_ref, mona_ref, text_ref, vit_ref
+
+VARIANTS = ("baseline", "noise_aware", "freq_enhanced", "hybrid")
+
+
+def fill(shape, a, b, scale=1.0, fn=np.sin):
+    n = int(np.prod(shape))
+    return torch.from_numpy((scale * fn(a * np.arange(n, dtype=np.float64) + b)).astype(np.float32).reshape(shape))
+
+
+def params_of(g, prefix="p."):
+    return {k[len(prefix):]: v for k, v in g.items() if k.startswith(prefix)}
+
+
+def close(a, b, rtol=2e-5, atol=2e-6):
+    scale = float(b.abs().max()) + 1e-12
+    err = float((a - b).abs().max())
+    assert err <= atol + rtol * scale, f"max abs err {err:.3e} vs scale {scale:.3e}"
+
+
+# ----------------------------------------------------------------------------- Appendix B KATs
+def test_kat1_infonce():
+    I, T = fill((4, 8), 0.37, 1.0), fill((4, 8), 0.23, 2.0, 1.0, np.cos)
+    assert abs(float(losses_ref.info_nce(I, T, 0.07)) - 6.23591423) < 2e-6
+
+
+KAT2 = {  # variant: (#params, sum y, sum|y|, sum|dx|, sum|dtheta|)
+    "baseline": (1440, 6.6501746, 692.82996, 1385.7930, 336.73874),
+    "noise_aware": (1467, 6.6485100, 692.83026, 1385.7944, 337.98044),
+    "freq_enhanced": (1448, 6.7672405, 692.94092, 1385.9700, 342.51481),
+    "hybrid": (1475, 6.7654457, 692.92352, 1385.9294, 343.83231),
+}
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_kat2_mona(variant):
+    names = mona_ref.param_names(variant)
+    shapes = mona_ref.param_shapes(variant, 32, 8)
+    P = {k: fill(shapes[k], 0.37, float(n), 0.1).requires_grad_(True) for n, k in enumerate(names)}
+    nparam, sy, say, sdx, sdp = KAT2[variant]
+    assert sum(p.numel() for p in P.values()) == nparam
+    x = fill((17, 2, 32), 0.11, 0.0).permute(1, 0, 2).contiguous().requires_grad_(True)   # -> batch-first
+    y = mona_ref.forward(x, P, variant, (4, 4))
+    y.square().sum().backward()
+    assert abs(float(y.sum()) - sy) < 2e-4
+    assert abs(float(y.abs().sum()) - say) < 2e-3
+    assert abs(float(x.grad.abs().sum()) - sdx) < 5e-3
+    assert abs(sum(float(p.grad.abs().sum()) for p in P.values()) - sdp) < 5e-3
+
+
+def test_kat3_lora():
+    W, b = fill((6, 8), 0.37, 0.0, 0.1), fill((6,), 0.37, 1.0, 0.1)
+    A, B = fill((2, 8), 0.37, 2.0, 0.1), fill((6, 2), 0.37, 3.0, 0.1)
+    assert abs(lora_ref.scaling(2, 4) - 2.8284271) < 1e-6
+    y = lora_ref.linear_lora(fill((3, 8), 0.11, 0.0), W, b, A, B, 2, 4)
+    assert abs(float(y.sum()) - 1.86544621) < 2e-6
+    ref0 = torch.tensor([0.29604045, -0.13922282, 0.34197903, -0.12498981, 0.28950864, -0.15598631])
+    close(y[0], ref0, 1e-6, 1e-6)
+
+
+# ----------------------------------------------------------------------------- golden fixtures
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("drop", [False, True])
+def test_mona_matches_reference(golden, variant, drop):
+    g = golden(f"mona_{variant}" + ("_drop" if drop else ""))
+    P = {k: v.clone().requires_grad_(True) for k, v in params_of(g).items()}
+    assert list(P) == mona_ref.param_names(variant)
+    x = g["x_nbd"].permute(1, 0, 2).contiguous().requires_grad_(True)
+    keep = g["keep_bnb"] if drop else None
+    y = mona_ref.forward(x, P, variant, (4, 4), keep_mask=keep, p_drop=0.1)
+    dy = g["dy_nbd"].permute(1, 0, 2) if drop else 2 * y.detach()
+    y.backward(dy)
+    close(y, g["y_nbd"].permute(1, 0, 2))
+    close(x.grad, g["dx_nbd"].permute(1, 0, 2))
+    for k in P:
+        close(P[k].grad, g["g." + k], 5e-5, 1e-5)
+
+
+def test_mona_merged_stencil_identity(golden):
+    """rfft2*f_c*irfft2 == f_c scale, and (DW3+DW5+DW7)/3 == one merged 7x7."""
+    g = golden("mona_freq_enhanced")
+    P = params_of(g)
+    t = fill((3, 8, 4, 4), 0.19, 0.4)
+    want = mona_ref.spatial_op(t, P, "freq_enhanced")
+    k, kb = mona_ref.merged_stencil(P, "freq_enhanced")
+    xf = t * P["adapter_conv.freq_filter"].view(1, -1, 1, 1)
+    c = torch.nn.functional.conv2d(xf, k[:, None], kb, padding=3, groups=8) + t
+    got = c + torch.nn.functional.conv2d(c, P["adapter_conv.projector.weight"], P["adapter_conv.projector.bias"])
+    close(got, want, 1e-5, 1e-6)
+
+
+def test_lora_linear_matches_reference(golden):
+    g = golden("lora_linear")
+    x = g["x"].clone().requires_grad_(True)
+    A, B, b = (g[k].clone().requires_grad_(True) for k in ("A", "B", "b"))
+    y = lora_ref.linear_lora(x, g["W"], b, A, B, 2, 4)
+    y.square().sum().backward()
+    assert abs(lora_ref.scaling(2, 4) - float(g["scaling"])) < 1e-7
+    close(y, g["y"]); close(x.grad, g["dx"]); close(A.grad, g["dA"]); close(B.grad, g["dB"]); close(b.grad, g["db"])
+
+
+def test_lora_mha_matches_reference(golden):
+    g = golden("lora_mha")
+    P = {k: v.clone().requires_grad_("lora" in k) for k, v in params_of(g).items()}
+    x = g["x_lbd"].clone().requires_grad_(True)
+    y = lora_ref.mha_lora(x, P, 2, 4, 8)
+    y.square().sum().backward()
+    close(y, g["y_lbd"]); close(x.grad, g["dx_lbd"])
+    for k in P:
+        if "lora" in k:
+            close(P[k].grad, g["g." + k], 5e-5, 1e-5)
+
+
+@pytest.mark.parametrize("name,temp", [("infonce_kat1", 0.07), ("infonce_b6", 0.2)])
+def test_infonce_matches_reference(golden, name, temp):
+    g = golden(name)
+    I, T = g["I"].clone().requires_grad_(True), g["T"].clone().requires_grad_(True)
+    loss = losses_ref.info_nce(I, T, temp)
+    loss.backward()
+    close(loss, g["loss"]); close(I.grad, g["dI"]); close(T.grad, g["dT"])
+
+
+def test_openai_clip_towers_match_reference(golden):
+    g = golden("openai_clip_base")
+    P = params_of(g)
+    close(vit_ref.openai_vit_forward(g["images"], P, heads=2), g["image_features"], 1e-4, 1e-5)
+    close(text_ref.openai_text_forward(g["ids"], P, heads=2), g["text_features"], 1e-4, 1e-5)
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_openai_clip_mona_matches_reference(golden, variant):
+    base, g = golden("openai_clip_base"), golden(f"openai_clip_mona_{variant}")
+    P = params_of(base)
+    mp = {k: v.clone().requires_grad_(True) for k, v in params_of(g).items()}
+    assert int(g["count"]) == 2
+    P.update(mp)
+    fi = vit_ref.openai_vit_forward(base["images"], P, heads=2, mona=dict(variant=variant, hw=(4, 4)))
+    ft = text_ref.openai_text_forward(base["ids"], P, heads=2)
+    loss = losses_ref.info_nce(fi, ft, 0.07)
+    loss.backward()
+    close(fi, g["image_features"], 1e-4, 1e-5)
+    close(loss, g["loss"], 1e-5, 1e-6)
+    for k in mp:
+        close(mp[k].grad, g["g." + k], 2e-4, 1e-6)
+
+
+def test_openai_clip_lora_matches_reference(golden):
+    base, g = golden("openai_clip_base"), golden("openai_clip_lora")
+    P = params_of(base)
+    P = {k: v for k, v in P.items() if not (k.startswith("visual.") and ".attn." in k)}
+    lp = {k: v.clone().requires_grad_("lora" in k) for k, v in params_of(g).items()}
+    P.update(lp)
+    fi = vit_ref.openai_vit_forward(base["images"], P, heads=2, lora=dict(r=4, alpha=8))
+    fi.square().sum().backward()
+    close(fi, g["image_features"], 1e-4, 1e-5)
+    for k in lp:
+        if "lora" in k:
+            close(lp[k].grad, g["g." + k], 2e-4, 1e-6)
+
+
+# ----------------------------------------------------------------------------- third-party cross-checks
+def test_timm_vit_recipe_matches_hf_vit(golden):
+    """Appendix A.1 recipe == installed transformers ViTModel with mapped weights."""
+    g = golden("hf_vit_tiny")
+    hf = params_of(g, "hf.")
+    P = {"visual.trunk.cls_token": hf["embeddings.cls_token"], "visual.trunk.pos_embed": hf["embeddings.position_embeddings"],
+         "visual.trunk.patch_embed.proj.weight": hf["embeddings.patch_embeddings.projection.weight"],
+         "visual.trunk.patch_embed.proj.bias": hf["embeddings.patch_embeddings.projection.bias"],
+         "visual.trunk.norm.weight": hf["layernorm.weight"], "visual.trunk.norm.bias": hf["layernorm.bias"]}
+    lay = "encoder.layer." if any(k.startswith("encoder.layer.") for k in hf) else "layers."
+    for i in range(2):
+        s, d = f"{lay}{i}.", f"visual.trunk.blocks.{i}."
+        def pick(*cands):
+            for c in cands:
+                if s + c in hf:
+                    return hf[s + c]
+            raise KeyError(cands)
+        for wb in ("weight", "bias"):
+            q = pick(f"attention.attention.query.{wb}", f"attention.q_proj.{wb}")
+            k = pick(f"attention.attention.key.{wb}", f"attention.k_proj.{wb}")
+            v = pick(f"attention.attention.value.{wb}", f"attention.v_proj.{wb}")
+            P[d + f"attn.qkv.{wb}"] = torch.cat([q, k, v], 0)
+            P[d + f"attn.proj.{wb}"] = pick(f"attention.output.dense.{wb}", f"attention.o_proj.{wb}")
+            P[d + f"norm1.{wb}"] = pick(f"layernorm_before.{wb}")
+            P[d + f"norm2.{wb}"] = pick(f"layernorm_after.{wb}")
+            P[d + f"mlp.fc1.{wb}"] = pick(f"intermediate.dense.{wb}", f"mlp.fc1.{wb}")
+            P[d + f"mlp.fc2.{wb}"] = pick(f"output.dense.{wb}", f"mlp.fc2.{wb}")
+    x = vit_ref.timm_vit_forward(g["images"], P, heads=2, return_tokens=True)
+    x = torch.nn.functional.layer_norm(x, (32,), P["visual.trunk.norm.weight"], P["visual.trunk.norm.bias"], 1e-6)
+    close(x, g["tokens_ln"], 1e-4, 1e-5)
+
+
+def test_bert_recipe_matches_hf_bert(golden):
+    """Appendix A.2 recipe == installed transformers BertModel on non-pad rows; and truncating a
+    caption to its real length leaves the CLS vector unchanged (basis of the varlen text path)."""
+    g = golden("hf_bert_tiny")
+    P = {"text.transformer." + k: v for k, v in params_of(g, "hf.").items()}
+    ids = g["ids"]
+    hs = text_ref.bert_hidden(ids, P, heads=2)
+    keep = ids != 0
+    close(hs[keep], g["last_hidden_state"][keep], 1e-4, 1e-5)
+    L0 = int(keep[0].sum())
+    hs0 = text_ref.bert_hidden(ids[:1, :L0], P, heads=2)
+    close(hs0[0, 0], g["last_hidden_state"][0, 0], 1e-4, 1e-5)
