@@ -1,0 +1,378 @@
+// attention_bwd.hip — dQ, dK, dV of softmax(q kᵀ·scale + mask) v for short sequences, one
+// workgroup per (batch, head); probabilities are recomputed from the forward's log-sum-exp.
+//
+// The reference has no explicit backward (autograd through nn.MultiheadAttention / SDPA:
+// /root/reference/src/third_party/openai_clip/model.py:195-197, src/adapters/lora.py:188);
+// the equations are the standard ones:
+//     P = exp(S·scale − lse),  dP = dO·Vᵀ,  δ = rowsum(dO ⊙ O),  dS = P ⊙ (dP − δ)·scale,
+//     dV = Pᵀ·dO,  dK = dSᵀ·Q,  dQ = dS·K.
+//
+// bf16 path (MFMA): Q, K, V, dO of the head are staged once in LDS (row-major, XOR-swizzled).
+//   * S and dP are computed with the KEY on the MFMA lane (A = Q / dO rows, B = K / V rows), so a
+//     lane holds P[q = 16·qt + 4g + r][key]; two query tiles give the 8-element B fragment of
+//     dVᵀ += dOᵀ·P and dKᵀ += Qᵀ·dS with no lane movement.  The transposed A operands (dOᵀ, Qᵀ)
+//     are ds_read_b64_tr_b16 reads of the row-major tiles.
+//   * each wave owns key tiles {w, w+4, ...} and keeps their dKᵀ / dVᵀ in registers for the whole
+//     sweep over queries: no cross-workgroup (or cross-wave) reduction for dK, dV.
+//   * dS crosses LDS once per 32-query block (bf16, [32][keys]) for dQᵀ = Kᵀ·dSᵀ, whose Kᵀ operand
+//     is again a transpose read of the K tile.
+// fp32 path (parity mode): plain VALU, three sweeps (dQ per query, dV per key, dK per key).
+#include "uia_common.h"
+#include "uia_kernels.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+__device__ __forceinline__ void glds16(const char* gsrc, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ s16x4 lds_tr16(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+}
+__device__ __forceinline__ bf16x8 tr_pair(const char* lo_addr, const char* hi_addr) {
+    const s16x4 lo = lds_tr16(lo_addr), hi = lds_tr16(hi_addr);
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ f32x4 mma(const uint4& a, const uint4& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// All four tiles use the same image: [rows][128 B], 16-B chunk c of row r stored at chunk c ^ ((r>>1)&7).
+template <int LT_MAX>
+__global__ __launch_bounds__(256) void attn_bwd_bf16_kernel(const UiaAttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NP_MAX = (LT_MAX + 1) / 2;
+    constexpr int KTW = (LT_MAX + 3) / 4;          // key tiles owned by one wave
+    const int L = p.L;
+    const int LT = (L + 15) >> 4, NP = (LT + 1) >> 1, LPK = NP * 32;
+    const int DS_STRIDE = LPK * 2 + 16;            // bytes per dS row (keys bf16 + 16 B pad)
+    char* Ks = smem;
+    char* Vs = Ks + LPK * 128;
+    char* Qs = Vs + LPK * 128;
+    char* Gs = Qs + LPK * 128;                     // dO
+    char* dSs = Gs + LPK * 128;                    // [32][DS_STRIDE]
+    float* lse2 = (float*)(dSs + 32 * DS_STRIDE);  // [LPK] lse in base-2 units
+    float* delta = lse2 + LPK;                     // [LPK]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x / p.H, h = blockIdx.x - b * p.H;
+    const size_t row0 = (size_t)b * L;
+    const size_t rs = (size_t)p.ld_qkv * 2, rso = (size_t)p.lddo * 2;
+    const char* qb = (const char*)p.q + (row0 * p.ld_qkv + (size_t)h * 64) * 2;
+    const char* kb = (const char*)p.k + (row0 * p.ld_qkv + (size_t)h * 64) * 2;
+    const char* vb = (const char*)p.v + (row0 * p.ld_qkv + (size_t)h * 64) * 2;
+    const char* gb = (const char*)p.dout + (row0 * p.lddo + (size_t)h * 64) * 2;
+    const char* ob = (const char*)p.out + (row0 * p.ldo + (size_t)h * 64) * 2;
+
+    const int ninstr = LPK >> 3;
+    for (int q = wave; q < ninstr; q += 4) {
+        const int r = 8 * q + (lane >> 3);
+        const int gr = r < L ? r : L - 1;
+        const int c = ((lane & 7) ^ ((r >> 1) & 7)) * 16;
+        glds16(kb + gr * rs + c, Ks + q * 1024);
+        glds16(vb + gr * rs + c, Vs + q * 1024);
+        glds16(qb + gr * rs + c, Qs + q * 1024);
+        glds16(gb + gr * rso + c, Gs + q * 1024);
+    }
+    // δ and lse (plain loads, independent of the LDS image)
+    const float sc = p.scale * 1.44269504088896341f;
+    for (int r = tid; r < LPK; r += 256) {
+        float d = 0.f, l2 = 0.f;
+        if (r < L) {
+            const bf16_t* go = (const bf16_t*)(gb + r * rso);
+            const bf16_t* oo = (const bf16_t*)(ob + (size_t)r * p.ldo * 2);
+#pragma unroll
+            for (int c = 0; c < 64; c += 8) {
+                float a[8], bb[8];
+                load8(go + c, a);
+                load8(oo + c, bb);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) d = fmaf(a[e], bb[e], d);
+            }
+            l2 = p.lse[((size_t)b * p.H + h) * L + r] * 1.44269504088896341f;
+        }
+        delta[r] = d;
+        lse2[r] = l2;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int li = lane & 15, g = lane >> 4;
+    int klen = L;
+    if (p.mask_kind == UIA_MASK_KEYPAD && p.keylen) { klen = p.keylen[b]; klen = klen < 1 ? 1 : (klen > L ? L : klen); }
+
+    // row-read fragment offset: row (16·tile + li), chunk g (+4 for the second k-half via ^64)
+    const int offR = li * 128 + ((g ^ (li >> 1)) << 4);
+    // transpose-read (A operand with k = rows of the image): group g, lane (qq,pp) → row 4g+qq (+16 for hi),
+    // columns 16dt + 4pp  → byte 32dt + 8pp → chunk 2dt + (pp>>1)
+    const int qq = li >> 2, pp = li & 3;
+    const int trow = 4 * g + qq;                        // within a 32-row block (hi half: +16)
+    const int tsw = (trow >> 1) & 7;                    // (row>>1)&7; +16 adds 8 → same &7
+    // natural-order transpose read for dQ (k-slot (g,e) ↔ row 8g+e): rows 8g+qq and 8g+4+qq
+    const int nrow = 8 * g + qq;
+    const int nsw_lo = (nrow >> 1) & 7, nsw_hi = ((nrow + 4) >> 1) & 7;
+
+    f32x4 dVt[KTW][4], dKt[KTW][4];
+#pragma unroll
+    for (int a = 0; a < KTW; ++a)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) { dVt[a][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dKt[a][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+#pragma unroll 1
+    for (int u = 0; u < NP; ++u) {
+        // per-lane query rows of this 32-query block: q(hq, r) = 32u + 16hq + 4g + r
+        float ls[2][4], dl[2][4];
+#pragma unroll
+        for (int hq = 0; hq < 2; ++hq)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                ls[hq][r] = lse2[32 * u + 16 * hq + 4 * g + r];
+                dl[hq][r] = delta[32 * u + 16 * hq + 4 * g + r];
+            }
+        // A fragments of the two query tiles (Q and dO), both k-halves
+        uint4 qf[2][2], gf[2][2];
+#pragma unroll
+        for (int hq = 0; hq < 2; ++hq)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                qf[hq][kk] = *(const uint4*)(Qs + (2 * u + hq) * 2048 + (offR ^ (kk << 6)));
+                gf[hq][kk] = *(const uint4*)(Gs + (2 * u + hq) * 2048 + (offR ^ (kk << 6)));
+            }
+        // transposed A operands for dV / dK: dOᵀ and Qᵀ of this block, per d-tile
+        bf16x8 gT[4], qT[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const int off = (32 * u + trow) * 128 + (((2 * dt + (pp >> 1)) ^ tsw) << 4) + 8 * (pp & 1);
+            gT[dt] = tr_pair(Gs + off, Gs + off + 16 * 128);
+            qT[dt] = tr_pair(Qs + off, Qs + off + 16 * 128);
+        }
+#pragma unroll
+        for (int a = 0; a < KTW; ++a) {
+            const int kt = wave + 4 * a;
+            if (kt < LT) {
+                const uint4 kf0 = *(const uint4*)(Ks + kt * 2048 + offR), kf1 = *(const uint4*)(Ks + kt * 2048 + (offR ^ 64));
+                const uint4 vf0 = *(const uint4*)(Vs + kt * 2048 + offR), vf1 = *(const uint4*)(Vs + kt * 2048 + (offR ^ 64));
+                const int key = 16 * kt + li;
+                bf16x8 pf, sf;
+#pragma unroll
+                for (int hq = 0; hq < 2; ++hq) {
+                    f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+                    s = mma(qf[hq][0], kf0, s);
+                    s = mma(qf[hq][1], kf1, s);
+                    dp = mma(gf[hq][0], vf0, dp);
+                    dp = mma(gf[hq][1], vf1, dp);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int qrow = 32 * u + 16 * hq + 4 * g + r;
+                        const int kmax = p.mask_kind == UIA_MASK_CAUSAL ? (qrow < klen - 1 ? qrow : klen - 1) : klen - 1;
+                        const bool ok = qrow < L && key <= kmax;
+                        const float pv = ok ? exp2f(s[r] * sc - ls[hq][r]) : 0.f;
+                        const float dsv = pv * (dp[r] - dl[hq][r]) * p.scale;
+                        pf[4 * hq + r] = (bf16_t)pv;
+                        sf[4 * hq + r] = (bf16_t)dsv;
+                        // dS for dQ: row (16hq+4g+r) of the block, column key
+                        *(bf16_t*)(dSs + (16 * hq + 4 * g + r) * DS_STRIDE + key * 2) = (bf16_t)dsv;
+                    }
+                }
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    dVt[a][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gT[dt], pf, dVt[a][dt], 0, 0, 0);
+                    dKt[a][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT[dt], sf, dKt[a][dt], 0, 0, 0);
+                }
+            }
+        }
+        // key tiles LT..2NP-1 of dSs are never written by the loop above: zero them once (u == 0)
+        if (u == 0 && (LT & 1)) {
+            for (int i = tid; i < 32 * 16; i += 256) *(bf16_t*)(dSs + (i >> 4) * DS_STRIDE + (16 * LT + (i & 15)) * 2) = (bf16_t)0.f;
+        }
+        __syncthreads();
+        // ---- dQᵀ[d][q] = Σ_key Kᵀ[d][key] · dSᵀ[key][q]; wave w → query tile hq = w>>1, d-tiles 2(w&1), 2(w&1)+1
+        {
+            const int hq = wave >> 1;
+            f32x4 dq[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            for (int kbk = 0; kbk < NP; ++kbk) {
+                const uint4 dsf = *(const uint4*)(dSs + (16 * hq + li) * DS_STRIDE + (32 * kbk + 8 * g) * 2);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int dt = 2 * (wave & 1) + j;
+                    const int ch = 2 * dt + (pp >> 1);
+                    const char* lo = Ks + (32 * kbk + nrow) * 128 + ((ch ^ nsw_lo) << 4) + 8 * (pp & 1);
+                    const char* hi = Ks + (32 * kbk + nrow + 4) * 128 + ((ch ^ nsw_hi) << 4) + 8 * (pp & 1);
+                    dq[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_pair(lo, hi), __builtin_bit_cast(bf16x8, dsf), dq[j], 0, 0, 0);
+                }
+            }
+            const int qrow = 32 * u + 16 * hq + li;
+            if (qrow < L) {
+                bf16_t* drow = (bf16_t*)p.dq + (row0 + qrow) * p.ld_dqkv + (size_t)h * 64 + 4 * g;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) store4(drow + 16 * (2 * (wave & 1) + j), dq[j]);
+            }
+        }
+        __syncthreads();
+    }
+    // ---- dK, dV: lane owns key 16kt+li, d = 16dt + 4g + r
+#pragma unroll
+    for (int a = 0; a < KTW; ++a) {
+        const int kt = wave + 4 * a;
+        const int key = 16 * kt + li;
+        if (kt < LT && key < L) {
+            bf16_t* krow = (bf16_t*)p.dk + (row0 + key) * p.ld_dqkv + (size_t)h * 64 + 4 * g;
+            bf16_t* vrow = (bf16_t*)p.dv + (row0 + key) * p.ld_dqkv + (size_t)h * 64 + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) { store4(krow + 16 * dt, dKt[a][dt]); store4(vrow + 16 * dt, dVt[a][dt]); }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// fp32 parity path.  Sweep 0: dQ (thread per query; K,V in LDS).  Sweeps 1,2: dV then dK
+// (thread per key; Q,dO in LDS).
+__global__ __launch_bounds__(256) void attn_bwd_f32_kernel(const UiaAttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int L = p.L;
+    float* A = (float*)smem;                 // [L][64]
+    float* Bm = A + (size_t)L * 64;          // [L][64]
+    float* lse = Bm + (size_t)L * 64;        // [L]
+    float* delta = lse + L;                  // [L]
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x / p.H, h = blockIdx.x - b * p.H;
+    const size_t row0 = (size_t)b * L;
+    const float* qb = (const float*)p.q + row0 * p.ld_qkv + (size_t)h * 64;
+    const float* kb = (const float*)p.k + row0 * p.ld_qkv + (size_t)h * 64;
+    const float* vb = (const float*)p.v + row0 * p.ld_qkv + (size_t)h * 64;
+    const float* gb = (const float*)p.dout + row0 * p.lddo + (size_t)h * 64;
+    const float* ob = (const float*)p.out + row0 * p.ldo + (size_t)h * 64;
+    int klen = L;
+    if (p.mask_kind == UIA_MASK_KEYPAD && p.keylen) { klen = p.keylen[b]; klen = klen < 1 ? 1 : (klen > L ? L : klen); }
+
+    for (int r = tid; r < L; r += 256) {
+        float d = 0.f;
+        for (int c = 0; c < 64; ++c) d = fmaf(gb[(size_t)r * p.lddo + c], ob[(size_t)r * p.ldo + c], d);
+        delta[r] = d;
+        lse[r] = p.lse[((size_t)b * p.H + h) * L + r];
+    }
+    for (int i = tid; i < L * 16; i += 256) {
+        const int r = i >> 4, c = (i & 15) * 4;
+        *(f32x4*)(A + r * 64 + c) = *(const f32x4*)(kb + (size_t)r * p.ld_qkv + c);
+        *(f32x4*)(Bm + r * 64 + c) = *(const f32x4*)(vb + (size_t)r * p.ld_qkv + c);
+    }
+    __syncthreads();
+    // ---- sweep 0: dQ[q] = Σ_k ds·K[k]
+    for (int qi = tid; qi < L; qi += 256) {
+        float q[64], go[64], dq[64];
+#pragma unroll
+        for (int c = 0; c < 64; ++c) { q[c] = qb[(size_t)qi * p.ld_qkv + c]; go[c] = gb[(size_t)qi * p.lddo + c]; dq[c] = 0.f; }
+        const int kend = p.mask_kind == UIA_MASK_CAUSAL ? (qi + 1 < klen ? qi + 1 : klen) : klen;
+        const float lq = lse[qi], dq_delta = delta[qi];
+        for (int k = 0; k < kend; ++k) {
+            float s = 0.f, dp = 0.f;
+#pragma unroll
+            for (int c = 0; c < 64; ++c) { s = fmaf(q[c], A[k * 64 + c], s); dp = fmaf(go[c], Bm[k * 64 + c], dp); }
+            const float pv = expf(s * p.scale - lq);
+            const float ds = pv * (dp - dq_delta) * p.scale;
+#pragma unroll
+            for (int c = 0; c < 64; ++c) dq[c] = fmaf(ds, A[k * 64 + c], dq[c]);
+        }
+        float* drow = (float*)p.dq + (row0 + qi) * p.ld_dqkv + (size_t)h * 64;
+#pragma unroll
+        for (int c = 0; c < 64; ++c) drow[c] = dq[c];
+    }
+    __syncthreads();
+    for (int i = tid; i < L * 16; i += 256) {
+        const int r = i >> 4, c = (i & 15) * 4;
+        *(f32x4*)(A + r * 64 + c) = *(const f32x4*)(qb + (size_t)r * p.ld_qkv + c);
+        *(f32x4*)(Bm + r * 64 + c) = *(const f32x4*)(gb + (size_t)r * p.lddo + c);
+    }
+    __syncthreads();
+    // ---- sweeps 1,2: per key
+    for (int ki = tid; ki < L; ki += 256) {
+        float kv[64], acc[64];
+        float* vrow = (float*)p.dv + (row0 + ki) * p.ld_dqkv + (size_t)h * 64;
+        float* krow = (float*)p.dk + (row0 + ki) * p.ld_dqkv + (size_t)h * 64;
+        if (ki >= klen) {
+#pragma unroll
+            for (int c = 0; c < 64; ++c) { vrow[c] = 0.f; krow[c] = 0.f; }
+            continue;
+        }
+        const int qstart = p.mask_kind == UIA_MASK_CAUSAL ? ki : 0;
+#pragma unroll
+        for (int c = 0; c < 64; ++c) { kv[c] = kb[(size_t)ki * p.ld_qkv + c]; acc[c] = 0.f; }
+        for (int qi = qstart; qi < L; ++qi) {       // dV[k] = Σ_q p·dO[q]
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < 64; ++c) s = fmaf(A[qi * 64 + c], kv[c], s);
+            const float pv = expf(s * p.scale - lse[qi]);
+#pragma unroll
+            for (int c = 0; c < 64; ++c) acc[c] = fmaf(pv, Bm[qi * 64 + c], acc[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < 64; ++c) { vrow[c] = acc[c]; acc[c] = 0.f; }
+        float vv[64];
+#pragma unroll
+        for (int c = 0; c < 64; ++c) vv[c] = vb[(size_t)ki * p.ld_qkv + c];
+        for (int qi = qstart; qi < L; ++qi) {       // dK[k] = Σ_q ds·Q[q]
+            float s = 0.f, dp = 0.f;
+#pragma unroll
+            for (int c = 0; c < 64; ++c) { s = fmaf(A[qi * 64 + c], kv[c], s); dp = fmaf(Bm[qi * 64 + c], vv[c], dp); }
+            const float pv = expf(s * p.scale - lse[qi]);
+            const float ds = pv * (dp - delta[qi]) * p.scale;
+#pragma unroll
+            for (int c = 0; c < 64; ++c) acc[c] = fmaf(ds, A[qi * 64 + c], acc[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < 64; ++c) krow[c] = acc[c];
+    }
+}
+
+template <int LT_MAX>
+int launch_bf16(hipStream_t stream, const UiaAttnParams& p) {
+    const int LT = (p.L + 15) / 16, NP = (LT + 1) / 2, LPK = NP * 32;
+    const int lds = 4 * LPK * 128 + 32 * (LPK * 2 + 16) + 2 * LPK * 4;
+    auto kern = attn_bwd_bf16_kernel<LT_MAX>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        constexpr int LPKM = ((LT_MAX + 1) / 2) * 32;
+        UIA_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          4 * LPKM * 128 + 32 * (LPKM * 2 + 16) + 2 * LPKM * 4));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.B * p.H), dim3(256), lds, stream, p);
+    UIA_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace
+
+int uia_attn_bwd_launch(hipStream_t stream, int dtype, const UiaAttnParams& p) {
+    UIA_CHECK_ARG(dtype == UIA_BF16 || dtype == UIA_F32, "uia_attn_bwd: bad dtype %d", dtype);
+    UIA_CHECK_ARG(p.B > 0 && p.H > 0 && p.L > 0, "uia_attn_bwd: empty problem");
+    UIA_CHECK_ARG(p.dh == 64, "uia_attn_bwd: head dim %d unsupported (64 only)", p.dh);
+    UIA_CHECK_ARG(p.q && p.k && p.v && p.out && p.dout && p.lse && p.dq && p.dk && p.dv, "uia_attn_bwd: null tensor");
+    const int esz = dtype == UIA_BF16 ? 2 : 4;
+    UIA_CHECK_ARG((p.ld_qkv * esz) % 16 == 0 && (p.ldo * esz) % 16 == 0 && (p.lddo * esz) % 16 == 0 && (p.ld_dqkv * esz) % 8 == 0,
+                  "uia_attn_bwd: leading dimensions must keep 16-byte rows");
+    UIA_CHECK_ARG(((uintptr_t)p.q | (uintptr_t)p.k | (uintptr_t)p.v | (uintptr_t)p.out | (uintptr_t)p.dout) % 16 == 0, "uia_attn_bwd: alignment");
+    UIA_CHECK_ARG(((uintptr_t)p.dq | (uintptr_t)p.dk | (uintptr_t)p.dv) % 8 == 0, "uia_attn_bwd: output alignment");
+    UIA_CHECK_ARG(p.mask_kind != UIA_MASK_KEYPAD || p.keylen, "uia_attn_bwd: key-padding mask needs keylen");
+    if (dtype == UIA_F32) {
+        UIA_CHECK_ARG(p.L <= 272, "uia_attn_bwd: L=%d exceeds 272", p.L);
+        const int lds = (2 * p.L * 64 + 2 * p.L) * 4;
+        static bool attr_set = false;
+        if (!attr_set) {
+            UIA_CHECK_HIP(hipFuncSetAttribute((const void*)attn_bwd_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (2 * 272 * 64 + 2 * 272) * 4));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(attn_bwd_f32_kernel, dim3(p.B * p.H), dim3(256), lds, stream, p);
+        UIA_CHECK_LAUNCH();
+        return 0;
+    }
+    UIA_CHECK_ARG(p.L <= 224, "uia_attn_bwd: bf16 path keeps Q,K,V,dO of a head in LDS: L=%d exceeds 224", p.L);
+    const int LT = (p.L + 15) / 16;
+    if (LT <= 5) return launch_bf16<5>(stream, p);
+    return launch_bf16<14>(stream, p);
+}

@@ -1,0 +1,265 @@
+// attention_fwd.hip — softmax(q kᵀ·scale + mask) v for short sequences (L ≤ 272), one
+// workgroup per (batch, head); the whole K and V of a head live in LDS (single pass, no
+// online-softmax tiling).
+//
+// Replaces: timm Attention / F.scaled_dot_product_attention (BiomedCLIP vision tower),
+//           nn.MultiheadAttention in /root/reference/src/third_party/openai_clip/model.py:195-197,
+//           the SDPA call of /root/reference/src/adapters/lora.py:188,
+//           HF BertSelfAttention (key-padding mask) and the causal CLIP text blocks (model.py:346-352).
+//
+// Layout: q/k/v are read in place from the projection output: element (b, l, h, d) lives at
+// ptr[(b*L + l)*ld + h*64 + d]  (fused qkv → three base pointers 768 columns apart).  The output
+// uses the same convention with its own leading dimension.  Head dim is fixed at 64.
+//
+// bf16 path (MFMA, wave64):
+//   Sᵀ = K·Qᵀ is computed "swapped" so that each lane owns ONE query column and 4·LT of its keys:
+//   the row max / row sum are in-lane reductions plus two xor-shuffles (16, 32).  The exponentiated
+//   accumulator tiles are then, without any lane movement, the B operand of Oᵀ = Vᵀ·Pᵀ (k-slot
+//   (g,e) of a 32-key block ↔ key 32u + 16(e>>2) + 4g + (e&3)); the matching Vᵀ A-operand is
+//   fetched from the row-major V tile with ds_read_b64_tr_b16 (hardware transpose), so V is never
+//   transposed in memory.
+// fp32 path (parity mode): plain VALU two-pass softmax, one query per thread.
+#include "uia_common.h"
+#include "uia_kernels.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+__device__ __forceinline__ void glds16(const char* gsrc, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ s16x4 lds_tr16(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+}
+
+// ------------------------------------------------------------------------------------------
+// LT_MAX = max number of 16-key tiles (L ≤ 16·LT_MAX).  NP = 32-key blocks.
+template <int LT_MAX>
+__global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const UiaAttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NP_MAX = (LT_MAX + 1) / 2;
+    const int L = p.L;
+    const int LT = (L + 15) >> 4;           // key / query tiles in use
+    const int NP = (LT + 1) >> 1;
+    const int LPK = NP * 32;                // rows staged (multiple of 32)
+    char* Ks = smem;                        // [LPK][128 B], 16-B chunk swizzle (row>>1)&7
+    char* Vs = smem + LPK * 128;            // [LPK][128 B], 16-B chunk swizzle ((row>>1)&3)<<1
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x / p.H, h = blockIdx.x - b * p.H;
+    const size_t row0 = (size_t)b * L;
+    const char* qb = (const char*)p.q + (row0 * p.ld_qkv + (size_t)h * 64) * 2;
+    const char* kb = (const char*)p.k + (row0 * p.ld_qkv + (size_t)h * 64) * 2;
+    const char* vb = (const char*)p.v + (row0 * p.ld_qkv + (size_t)h * 64) * 2;
+    const size_t rs = (size_t)p.ld_qkv * 2;  // row stride in bytes
+
+    // ---- stage K and V (rows past L are clamped to row L-1: finite, and masked / multiplied by 0)
+    const int ninstr = LPK >> 3;             // 1 KiB wave-instructions per tensor
+    for (int q = wave; q < ninstr; q += 4) {
+        const int r = 8 * q + (lane >> 3);
+        const int gr = r < L ? r : L - 1;
+        const int ck = (lane & 7) ^ ((r >> 1) & 7);
+        const int cv = (lane & 7) ^ (((r >> 1) & 3) << 1);
+        glds16(kb + gr * rs + ck * 16, Ks + q * 1024);
+        glds16(vb + gr * rs + cv * 16, Vs + q * 1024);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int li = lane & 15, g = lane >> 4;
+    int klen = L;
+    if (p.mask_kind == UIA_MASK_KEYPAD && p.keylen) { klen = p.keylen[b]; klen = klen < 1 ? 1 : (klen > L ? L : klen); }
+    const float sc = p.scale * 1.44269504088896341f;   // softmax in base 2
+
+    // K fragment (MFMA A operand, rows = keys): row 16t+li, chunk g+4kk
+    const int offK0 = li * 128 + ((g ^ (li >> 1)) << 4);
+    // Vᵀ fragment via transpose read: group g reads rows 32u + 16hh + 4g + q', cols 16dt + 4pp
+    const int qq = li >> 2, pp = li & 3;
+    const int vrow0 = 4 * g + qq;                       // + 32u + 16hh  (multiples of 16 keep (row>>1)&3)
+    const int vsw = (vrow0 >> 1) & 3;
+
+    for (int qt = wave; qt < LT; qt += 4) {
+        const int qrow = 16 * qt + li;
+        const int qld = qrow < L ? qrow : L - 1;
+        const uint4 q0 = *(const uint4*)(qb + qld * rs + g * 16);
+        const uint4 q1 = *(const uint4*)(qb + qld * rs + (g + 4) * 16);
+
+        f32x4 s[LT_MAX];
+#pragma unroll
+        for (int t = 0; t < LT_MAX; ++t) {
+            s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (t < LT) {
+                const uint4 k0 = *(const uint4*)(Ks + t * 2048 + offK0);
+                const uint4 k1 = *(const uint4*)(Ks + t * 2048 + (offK0 ^ 64));
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, k0), __builtin_bit_cast(bf16x8, q0), s[t], 0, 0, 0);
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, k1), __builtin_bit_cast(bf16x8, q1), s[t], 0, 0, 0);
+            }
+        }
+        // ---- mask, row max (lane owns query qrow, keys 16t + 4g + r)
+        const int kmax = p.mask_kind == UIA_MASK_CAUSAL ? (qrow < klen - 1 ? qrow : klen - 1) : klen - 1;  // last valid key
+        float m = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < LT_MAX; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = 16 * t + 4 * g + r;
+                const float v = (t < LT && key <= kmax) ? s[t][r] * sc : -INFINITY;
+                s[t][r] = v;
+                m = fmaxf(m, v);
+            }
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < LT_MAX; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = exp2f(s[t][r] - m);      // exp2(-inf) = 0 for masked keys
+                s[t][r] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+
+        // ---- Oᵀ = Vᵀ · Pᵀ
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < NP_MAX; ++u) {
+            if (u < NP) {
+                bf16x8 pf;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    pf[e] = (bf16_t)s[2 * u][e];
+                    pf[4 + e] = (2 * u + 1 < LT_MAX) ? (bf16_t)s[(2 * u + 1 < LT_MAX) ? 2 * u + 1 : 0][e] : (bf16_t)0.f;
+                }
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const char* base = Vs + (32 * u + vrow0) * 128 + ((dt ^ vsw) << 5) + 8 * pp;
+                    const s16x4 lo = lds_tr16(base);
+                    const s16x4 hi = lds_tr16(base + 16 * 128);
+                    typedef __attribute__((ext_vector_type(8))) short s16x8;
+                    const s16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vf), pf, o[dt], 0, 0, 0);
+                }
+            }
+        }
+        // ---- store: lane owns query qrow, d = 16dt + 4g + r
+        if (qrow < L) {
+            bf16_t* orow = (bf16_t*)p.out + (row0 + qrow) * p.ldo + (size_t)h * 64 + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const f32x4 v = {o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv};
+                store4(orow + 16 * dt, v);
+            }
+            if (p.lse && g == 0) p.lse[((size_t)b * p.H + h) * L + qrow] = (m + log2f(sum)) * 0.69314718055994531f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// fp32 parity path: one query per thread, K/V rows broadcast from LDS.
+__global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const UiaAttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int L = p.L;
+    float* Ks = (float*)smem;               // [L][64]
+    float* Vs = Ks + (size_t)L * 64;
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x / p.H, h = blockIdx.x - b * p.H;
+    const size_t row0 = (size_t)b * L;
+    const float* qb = (const float*)p.q + row0 * p.ld_qkv + (size_t)h * 64;
+    const float* kb = (const float*)p.k + row0 * p.ld_qkv + (size_t)h * 64;
+    const float* vb = (const float*)p.v + row0 * p.ld_qkv + (size_t)h * 64;
+    for (int i = tid; i < L * 16; i += 256) {
+        const int r = i >> 4, c = (i & 15) * 4;
+        *(f32x4*)(Ks + r * 64 + c) = *(const f32x4*)(kb + (size_t)r * p.ld_qkv + c);
+        *(f32x4*)(Vs + r * 64 + c) = *(const f32x4*)(vb + (size_t)r * p.ld_qkv + c);
+    }
+    __syncthreads();
+    int klen = L;
+    if (p.mask_kind == UIA_MASK_KEYPAD && p.keylen) { klen = p.keylen[b]; klen = klen < 1 ? 1 : (klen > L ? L : klen); }
+    for (int qi = tid; qi < L; qi += 256) {
+        float q[64];
+#pragma unroll
+        for (int c = 0; c < 64; c += 4) {
+            const f32x4 v = *(const f32x4*)(qb + (size_t)qi * p.ld_qkv + c);
+            q[c] = v[0] * p.scale; q[c + 1] = v[1] * p.scale; q[c + 2] = v[2] * p.scale; q[c + 3] = v[3] * p.scale;
+        }
+        const int kend = p.mask_kind == UIA_MASK_CAUSAL ? (qi + 1 < klen ? qi + 1 : klen) : klen;
+        float m = -INFINITY;
+        for (int k = 0; k < kend; ++k) {
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < 64; ++c) s = fmaf(q[c], Ks[k * 64 + c], s);
+            m = fmaxf(m, s);
+        }
+        float o[64];
+#pragma unroll
+        for (int c = 0; c < 64; ++c) o[c] = 0.f;
+        float sum = 0.f;
+        for (int k = 0; k < kend; ++k) {
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < 64; ++c) s = fmaf(q[c], Ks[k * 64 + c], s);
+            const float e = expf(s - m);
+            sum += e;
+#pragma unroll
+            for (int c = 0; c < 64; ++c) o[c] = fmaf(e, Vs[k * 64 + c], o[c]);
+        }
+        const float inv = 1.0f / sum;
+        float* orow = (float*)p.out + (row0 + qi) * p.ldo + (size_t)h * 64;
+#pragma unroll
+        for (int c = 0; c < 64; c += 4) *(f32x4*)(orow + c) = f32x4{o[c] * inv, o[c + 1] * inv, o[c + 2] * inv, o[c + 3] * inv};
+        if (p.lse) p.lse[((size_t)b * p.H + h) * L + qi] = m + logf(sum);
+    }
+}
+
+template <int LT_MAX>
+int launch_bf16(hipStream_t stream, const UiaAttnParams& p) {
+    const int LT = (p.L + 15) / 16, NP = (LT + 1) / 2;
+    const int lds = 2 * NP * 32 * 128;
+    auto kern = attn_fwd_bf16_kernel<LT_MAX>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        UIA_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ((LT_MAX + 1) / 2) * 32 * 128));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.B * p.H), dim3(256), lds, stream, p);
+    UIA_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace
+
+int uia_attn_fwd_launch(hipStream_t stream, int dtype, const UiaAttnParams& p) {
+    UIA_CHECK_ARG(dtype == UIA_BF16 || dtype == UIA_F32, "uia_attn_fwd: bad dtype %d", dtype);
+    UIA_CHECK_ARG(p.B > 0 && p.H > 0 && p.L > 0, "uia_attn_fwd: empty problem");
+    UIA_CHECK_ARG(p.dh == 64, "uia_attn_fwd: head dim %d unsupported (64 only)", p.dh);
+    UIA_CHECK_ARG(p.L <= 272, "uia_attn_fwd: L=%d exceeds the single-pass limit 272", p.L);
+    UIA_CHECK_ARG(p.q && p.k && p.v && p.out, "uia_attn_fwd: null tensor");
+    const int esz = dtype == UIA_BF16 ? 2 : 4;
+    UIA_CHECK_ARG((p.ld_qkv * esz) % 16 == 0 && (p.ldo * esz) % 8 == 0, "uia_attn_fwd: leading dimensions must keep 16-byte rows");
+    UIA_CHECK_ARG(((uintptr_t)p.q | (uintptr_t)p.k | (uintptr_t)p.v) % 16 == 0 && (uintptr_t)p.out % 8 == 0, "uia_attn_fwd: alignment");
+    UIA_CHECK_ARG(p.mask_kind >= UIA_MASK_NONE && p.mask_kind <= UIA_MASK_KEYPAD, "uia_attn_fwd: bad mask kind");
+    UIA_CHECK_ARG(p.mask_kind != UIA_MASK_KEYPAD || p.keylen, "uia_attn_fwd: key-padding mask needs keylen");
+    if (dtype == UIA_F32) {
+        const int lds = 2 * p.L * 64 * 4;
+        static bool attr_set = false;
+        if (!attr_set) {
+            UIA_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 272 * 64 * 4));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(attn_fwd_f32_kernel, dim3(p.B * p.H), dim3(256), lds, stream, p);
+        UIA_CHECK_LAUNCH();
+        return 0;
+    }
+    const int LT = (p.L + 15) / 16;
+    if (LT <= 5) return launch_bf16<5>(stream, p);
+    if (LT <= 13) return launch_bf16<13>(stream, p);
+    return launch_bf16<17>(stream, p);
+}

@@ -1,0 +1,42 @@
+// capi.cpp — extern "C" entry points of libuia_hip.so (declared in include/uia_hip.h).
+// Thin: null checks on the descriptor, then the typed launcher.  No allocation, no sync.
+#include "uia_kernels.h"
+
+void uia_set_error(const char* fmt, ...);
+#define NEED(ptr, name) do { if (!(ptr)) { uia_set_error("%s: null descriptor", name); return -1; } } while (0)
+
+extern "C" {
+
+int uia_version(void) { return 100; }
+
+int uia_gemm(void* stream, int dtype, const uia_gemm_desc* d, int tile_cfg) {
+    NEED(d, "uia_gemm");
+    return uia_gemm_launch((hipStream_t)stream, dtype, *d, tile_cfg);
+}
+int uia_wgrad(void* stream, int dtype, int M, int I, int J, const void* A, int64_t lda, const void* B, int64_t ldb, float alpha, float* dW, float* dbias_A) {
+    return uia_wgrad_launch((hipStream_t)stream, dtype, M, I, J, A, lda, B, ldb, alpha, dW, dbias_A);
+}
+int uia_attn_fwd(void* stream, int dtype, const uia_attn_desc* d) {
+    NEED(d, "uia_attn_fwd");
+    return uia_attn_fwd_launch((hipStream_t)stream, dtype, *d);
+}
+int uia_attn_bwd(void* stream, int dtype, const uia_attn_desc* d) {
+    NEED(d, "uia_attn_bwd");
+    return uia_attn_bwd_launch((hipStream_t)stream, dtype, *d);
+}
+int uia_layernorm_fwd(void* stream, int dtype, int M, int D, int64_t ldx, const float* x, const float* gamma, const float* beta, float eps, void* yT, float* y32) {
+    return uia_layernorm_fwd_launch((hipStream_t)stream, dtype, M, D, ldx, x, gamma, beta, eps, yT, y32);
+}
+int uia_layernorm_bwd(void* stream, int dtype, int M, int D, int64_t ldx, const void* dy, const float* x, const float* gamma, float eps, const float* dres, float* dx32, void* dxT) {
+    return uia_layernorm_bwd_launch((hipStream_t)stream, dtype, M, D, ldx, dy, x, gamma, eps, dres, dx32, dxT);
+}
+int uia_cast(void* stream, int dtype, size_t n, const float* src, void* dst, float scale) { return uia_cast_launch((hipStream_t)stream, dtype, n, src, dst, scale); }
+int uia_transpose_cast(void* stream, int dtype, int rows, int cols, const float* src, void* dst) { return uia_transpose_cast_launch((hipStream_t)stream, dtype, rows, cols, src, dst); }
+int uia_im2col(void* stream, int dtype, int B, int C, int H, int W, int P, const float* img, void* out) { return uia_im2col_launch((hipStream_t)stream, dtype, B, C, H, W, P, img, out); }
+int uia_fill_cls(void* stream, int B, int N, int D, const float* cls, const float* pos0, float* x) { return uia_fill_cls_launch((hipStream_t)stream, B, N, D, cls, pos0, x); }
+int uia_embed(void* stream, int rows, int L, int D, const int64_t* ids, const float* table, const float* pos, const float* type0, float* out) {
+    return uia_embed_launch((hipStream_t)stream, rows, L, D, ids, table, pos, type0, out);
+}
+int uia_gather_rows(void* stream, int n, int D, const float* src, const int64_t* idx, float* dst) { return uia_gather_rows_launch((hipStream_t)stream, n, D, src, idx, dst); }
+
+}  // extern "C"

@@ -1,0 +1,150 @@
+// elementwise.hip — the small HBM-bound layout kernels around the GEMMs.
+//
+//   cast / transpose_cast : fp32 master weights → T operand copies, [out,in] and its transpose
+//                           (dgrad runs as a TN GEMM against Wᵀ, see gemm.hip)
+//   im2col                : Conv2d(3, D, k=P, s=P) patch embedding as a GEMM operand
+//                           (/root/reference/src/third_party/openai_clip/model.py:221,234; timm PatchEmbed)
+//   fill_cls              : x[b,0,:] = class_embedding + pos[0]   (model.py:237-245; timm _pos_embed)
+//   embed                 : x[b,l,:] = table[ids[b,l]] + pos[l] (+ type0)   (model.py:362-364; HF BertEmbeddings)
+//   gather_rows           : out[i,:] = src[idx[i],:]            (EOT / CLS pooling, model.py:372)
+//   scale                 : y = a*x (loss scaling of the incoming feature gradient)
+#include "uia_common.h"
+#include "uia_kernels.h"
+
+namespace {
+
+template <typename T>
+__global__ void cast_kernel(size_t n4, const float* __restrict__ src, T* __restrict__ dst) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
+        store4(dst + 4 * i, load4(src + 4 * i));
+}
+
+// dst[c][r] = src[r][c]; 32x32 tiles through LDS (padded), coalesced both ways
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_cast_kernel(int rows, int cols, const float* __restrict__ src, T* __restrict__ dst) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8) {
+        const int r = r0 + j, c = c0 + tx;
+        tile[j][tx] = (r < rows && c < cols) ? src[(size_t)r * cols + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j, r = r0 + tx;
+        if (c < cols && r < rows) dst[(size_t)c * rows + r] = from_f32<T>(tile[tx][j]);
+    }
+}
+
+// out[(b*gh+py)*gw+px][(c*P+ky)*P+kx] = img[b][c][py*P+ky][px*P+kx]; one thread = 4 consecutive kx
+template <typename T>
+__global__ void im2col_kernel(int B, int C, int H, int W, int P, const float* __restrict__ img, T* __restrict__ out) {
+    const int gh = H / P, gw = W / P, K = C * P * P, K4 = K >> 2;
+    const size_t total = (size_t)B * gh * gw * K4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int k4 = (int)(i % K4);
+        const size_t prow = i / K4;
+        const int px = (int)(prow % gw), py = (int)((prow / gw) % gh), b = (int)(prow / ((size_t)gw * gh));
+        const int k = k4 * 4, kx = k % P, ky = (k / P) % P, c = k / (P * P);
+        const float* s = img + (((size_t)b * C + c) * H + (size_t)py * P + ky) * W + (size_t)px * P + kx;
+        store4(out + prow * K + k, load4(s));
+    }
+}
+
+__global__ void fill_cls_kernel(int B, int N, int D, const float* __restrict__ cls, const float* __restrict__ pos0, float* __restrict__ x) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * D) return;
+    const int b = i / D, d = i - b * D;
+    x[(size_t)b * N * D + d] = cls[d] + (pos0 ? pos0[d] : 0.f);
+}
+
+__global__ void embed_kernel(int rows, int L, int D, const int64_t* __restrict__ ids, const float* __restrict__ table,
+                             const float* __restrict__ pos, const float* __restrict__ type0, float* __restrict__ out) {
+    const int D4 = D >> 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)rows * D4; i += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / D4), c = (int)(i % D4) * 4, l = r % L;
+        f32x4 v = load4(table + (size_t)ids[r] * D + c);
+        const f32x4 pv = load4(pos + (size_t)l * D + c);
+        v += pv;
+        if (type0) v += load4(type0 + c);
+        store4(out + (size_t)r * D + c, v);
+    }
+}
+
+__global__ void gather_rows_kernel(int n, int D, const float* __restrict__ src, const int64_t* __restrict__ idx, float* __restrict__ dst) {
+    const int D4 = D >> 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)n * D4; i += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / D4), c = (int)(i % D4) * 4;
+        store4(dst + (size_t)r * D + c, load4(src + (size_t)idx[r] * D + c));
+    }
+}
+
+template <typename T>
+__global__ void scale_cast_kernel(size_t n4, float a, const float* __restrict__ src, T* __restrict__ dst) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        f32x4 v = load4(src + 4 * i);
+        v *= a;
+        store4(dst + 4 * i, v);
+    }
+}
+
+inline int grid_for(size_t work, int block) {
+    size_t g = (work + block - 1) / block;
+    return (int)(g > 2048 ? 2048 : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+int uia_cast_launch(hipStream_t stream, int dtype, size_t n, const float* src, void* dst, float scale) {
+    UIA_CHECK_ARG(n % 4 == 0 && src && dst, "uia_cast: n=%zu must be a multiple of 4 and tensors non-null", n);
+    UIA_CHECK_ARG(((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 8) == 0, "uia_cast: alignment");
+    const int g = grid_for(n / 4, 256);
+    if (dtype == UIA_BF16) hipLaunchKernelGGL(scale_cast_kernel<bf16_t>, dim3(g), dim3(256), 0, stream, n / 4, scale, src, (bf16_t*)dst);
+    else if (dtype == UIA_F32) hipLaunchKernelGGL(scale_cast_kernel<float>, dim3(g), dim3(256), 0, stream, n / 4, scale, src, (float*)dst);
+    else { uia_set_error("uia_cast: bad dtype %d", dtype); return -1; }
+    UIA_CHECK_LAUNCH();
+    return 0;
+}
+
+int uia_transpose_cast_launch(hipStream_t stream, int dtype, int rows, int cols, const float* src, void* dst) {
+    UIA_CHECK_ARG(rows > 0 && cols > 0 && src && dst, "uia_transpose_cast: bad arguments");
+    const dim3 grid((cols + 31) / 32, (rows + 31) / 32);
+    if (dtype == UIA_BF16) hipLaunchKernelGGL(transpose_cast_kernel<bf16_t>, grid, dim3(256), 0, stream, rows, cols, src, (bf16_t*)dst);
+    else if (dtype == UIA_F32) hipLaunchKernelGGL(transpose_cast_kernel<float>, grid, dim3(256), 0, stream, rows, cols, src, (float*)dst);
+    else { uia_set_error("uia_transpose_cast: bad dtype %d", dtype); return -1; }
+    UIA_CHECK_LAUNCH();
+    return 0;
+}
+
+int uia_im2col_launch(hipStream_t stream, int dtype, int B, int C, int H, int W, int P, const float* img, void* out) {
+    UIA_CHECK_ARG(B > 0 && C > 0 && P > 0 && H % P == 0 && W % P == 0 && P % 4 == 0, "uia_im2col: unsupported geometry B=%d C=%d H=%d W=%d P=%d", B, C, H, W, P);
+    UIA_CHECK_ARG(img && out && (uintptr_t)img % 16 == 0 && W % 4 == 0, "uia_im2col: null or misaligned tensor");
+    const size_t work = (size_t)B * (H / P) * (W / P) * (C * P * P / 4);
+    const int g = grid_for(work, 256);
+    if (dtype == UIA_BF16) hipLaunchKernelGGL(im2col_kernel<bf16_t>, dim3(g), dim3(256), 0, stream, B, C, H, W, P, img, (bf16_t*)out);
+    else if (dtype == UIA_F32) hipLaunchKernelGGL(im2col_kernel<float>, dim3(g), dim3(256), 0, stream, B, C, H, W, P, img, (float*)out);
+    else { uia_set_error("uia_im2col: bad dtype %d", dtype); return -1; }
+    UIA_CHECK_LAUNCH();
+    return 0;
+}
+
+int uia_fill_cls_launch(hipStream_t stream, int B, int N, int D, const float* cls, const float* pos0, float* x) {
+    UIA_CHECK_ARG(B > 0 && N > 0 && D > 0 && cls && x, "uia_fill_cls: bad arguments");
+    hipLaunchKernelGGL(fill_cls_kernel, dim3((B * D + 255) / 256), dim3(256), 0, stream, B, N, D, cls, pos0, x);
+    UIA_CHECK_LAUNCH();
+    return 0;
+}
+
+int uia_embed_launch(hipStream_t stream, int rows, int L, int D, const int64_t* ids, const float* table, const float* pos, const float* type0, float* out) {
+    UIA_CHECK_ARG(rows > 0 && L > 0 && D % 4 == 0 && ids && table && pos && out, "uia_embed: bad arguments");
+    hipLaunchKernelGGL(embed_kernel, dim3(grid_for((size_t)rows * D / 4, 256)), dim3(256), 0, stream, rows, L, D, ids, table, pos, type0, out);
+    UIA_CHECK_LAUNCH();
+    return 0;
+}
+
+int uia_gather_rows_launch(hipStream_t stream, int n, int D, const float* src, const int64_t* idx, float* dst) {
+    UIA_CHECK_ARG(n > 0 && D % 4 == 0 && src && idx && dst, "uia_gather_rows: bad arguments");
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((size_t)n * D / 4, 256)), dim3(256), 0, stream, n, D, src, idx, dst);
+    UIA_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,148 @@
+// layernorm.hip — row LayerNorm over the fp32 residual stream, forward and (frozen-affine) backward.
+//
+// Replaces: the LayerNorm of /root/reference/src/third_party/openai_clip/model.py:163-169 (eps 1e-5:
+//           ln_1 / ln_2 / ln_pre / ln_post / ln_final), timm Block.norm1 / norm2 / trunk.norm
+//           (eps 1e-6), HF BERT LayerNorm (eps 1e-12), CLIPSeg decoder LayerNorms.
+// The Mona adapter's own (trainable) LayerNorm is fused elsewhere (mona.hip).
+//
+// HBM-bound: one wave per row, 16-byte loads, two-pass statistics held in registers; the backward
+// recomputes mean / rstd from x instead of storing them.  D ≤ 1024, D % 4 == 0.
+// x (and, in the backward, dres / dx) may be row-strided (ldx ≥ D): the final LayerNorm runs on the
+// CLS rows of the [B, N, D] stream in place; y / dy are compact [M, D].
+//   fwd:  y = (x - mean) * rstd * gamma + beta            → T copy (GEMM operand) and/or fp32 copy
+//   bwd:  dx = dres + rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy * gamma
+//         → fp32 (residual-gradient stream) and optional T copy (operand of the next dgrad GEMM)
+#include "uia_common.h"
+#include "uia_kernels.h"
+
+namespace {
+
+constexpr int LN_MAXV = 4;   // float4 per lane → D ≤ 64*4*4 = 1024
+
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(int M, int D, long ldx, const float* __restrict__ x, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float eps, T* __restrict__ yT, float* __restrict__ y32) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const int nv = D >> 2;
+    const float* xr = x + (size_t)row * ldx;
+    f32x4 v[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) {
+        const int c = lane + 64 * k;
+        v[k] = c < nv ? load4(xr + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        s += v[k][0] + v[k][1] + v[k][2] + v[k][3];
+    }
+    const float mean = wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) {
+        const int c = lane + 64 * k;
+        if (c < nv) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[k][e] - mean; q = fmaf(d, d, q); }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / D + eps);
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) {
+        const int c = lane + 64 * k;
+        if (c < nv) {
+            const f32x4 g = load4(gamma + 4 * c), b = load4(beta + 4 * c);
+            f32x4 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = fmaf((v[k][e] - mean) * rstd, g[e], b[e]);
+            if (yT) store4(yT + (size_t)row * D + 4 * c, y);
+            if (y32) store4(y32 + (size_t)row * D + 4 * c, y);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(int M, int D, long ldx, const T* __restrict__ dy, const float* __restrict__ x,
+                                                      const float* __restrict__ gamma, float eps, const float* __restrict__ dres,
+                                                      float* __restrict__ dx32, T* __restrict__ dxT) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const int nv = D >> 2;
+    const float* xr = x + (size_t)row * ldx;
+    const T* dyr = dy + (size_t)row * D;
+    f32x4 v[LN_MAXV], g[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) {
+        const int c = lane + 64 * k;
+        v[k] = c < nv ? load4(xr + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        g[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (c < nv) {
+            const f32x4 d = load4(dyr + 4 * c), w = load4(gamma + 4 * c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[k][e] = d[e] * w[e];
+        }
+        s += v[k][0] + v[k][1] + v[k][2] + v[k][3];
+    }
+    const float mean = wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) {
+        const int c = lane + 64 * k;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d = c < nv ? v[k][e] - mean : 0.f;
+            v[k][e] = d;
+            q = fmaf(d, d, q);
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / D + eps);
+    float sg = 0.f, sgx = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[k][e] *= rstd;   // xhat
+            sg += g[k][e];
+            sgx = fmaf(g[k][e], v[k][e], sgx);
+        }
+    const float mg = wave_sum(sg) / D, mgx = wave_sum(sgx) / D;
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) {
+        const int c = lane + 64 * k;
+        if (c < nv) {
+            f32x4 o = dres ? load4(dres + (size_t)row * ldx + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] += rstd * (g[k][e] - mg - v[k][e] * mgx);
+            if (dx32) store4(dx32 + (size_t)row * ldx + 4 * c, o);
+            if (dxT) store4(dxT + (size_t)row * ldx + 4 * c, o);
+        }
+    }
+}
+
+}  // namespace
+
+int uia_layernorm_fwd_launch(hipStream_t stream, int dtype, int M, int D, long ldx, const float* x, const float* gamma, const float* beta,
+                             float eps, void* yT, float* y32) {
+    UIA_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 1024, "uia_layernorm_fwd: unsupported shape M=%d D=%d", M, D);
+    UIA_CHECK_ARG(x && gamma && beta && (yT || y32), "uia_layernorm_fwd: null tensor");
+    UIA_CHECK_ARG(ldx >= D && ldx % 4 == 0, "uia_layernorm_fwd: row stride %ld", ldx);
+    UIA_CHECK_ARG(((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)yT | (uintptr_t)y32) % 8 == 0, "uia_layernorm_fwd: alignment");
+    const dim3 grid((M + 3) / 4), block(256);
+    if (dtype == UIA_BF16) hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, grid, block, 0, stream, M, D, ldx, x, gamma, beta, eps, (bf16_t*)yT, y32);
+    else if (dtype == UIA_F32) hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, block, 0, stream, M, D, ldx, x, gamma, beta, eps, (float*)yT, y32);
+    else { uia_set_error("uia_layernorm_fwd: bad dtype %d", dtype); return -1; }
+    UIA_CHECK_LAUNCH();
+    return 0;
+}
+
+int uia_layernorm_bwd_launch(hipStream_t stream, int dtype, int M, int D, long ldx, const void* dy, const float* x, const float* gamma, float eps,
+                             const float* dres, float* dx32, void* dxT) {
+    UIA_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 1024, "uia_layernorm_bwd: unsupported shape M=%d D=%d", M, D);
+    UIA_CHECK_ARG(dy && x && gamma && (dx32 || dxT), "uia_layernorm_bwd: null tensor");
+    UIA_CHECK_ARG(ldx >= D && ldx % 4 == 0, "uia_layernorm_bwd: row stride %ld", ldx);
+    const dim3 grid((M + 3) / 4), block(256);
+    if (dtype == UIA_BF16) hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, grid, block, 0, stream, M, D, ldx, (const bf16_t*)dy, x, gamma, eps, dres, dx32, (bf16_t*)dxT);
+    else if (dtype == UIA_F32) hipLaunchKernelGGL(ln_bwd_kernel<float>, grid, block, 0, stream, M, D, ldx, (const float*)dy, x, gamma, eps, dres, dx32, (float*)dxT);
+    else { uia_set_error("uia_layernorm_bwd: bad dtype %d", dtype); return -1; }
+    UIA_CHECK_LAUNCH();
+    return 0;
+}

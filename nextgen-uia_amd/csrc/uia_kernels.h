@@ -5,27 +5,22 @@
 #include <stddef.h>
 #include <stdint.h>
 
-enum { UIA_F32 = 0, UIA_BF16 = 1 };
-enum { UIA_ACT_NONE = 0, UIA_ACT_GELU = 1, UIA_ACT_QUICKGELU = 2, UIA_ACT_RELU = 3 };
-enum { UIA_MASK_NONE = 0, UIA_MASK_CAUSAL = 1, UIA_MASK_KEYPAD = 2 };
-enum { UIA_MONA_BASELINE = 0, UIA_MONA_NOISE_AWARE = 1, UIA_MONA_FREQ_ENHANCED = 2, UIA_MONA_HYBRID = 3 };
+#include "../../include/uia_hip.h"
 
-struct UiaGemmParams {
-    const void* A; long lda;        // [M,K] of T
-    const void* W; long ldw;        // [N,K] of T
-    int M, N, K;
-    float alpha;                    // scale on the accumulator (before bias)
-    const float* bias;              // [N] fp32 or null
-    int act;                        // UIA_ACT_* applied after bias
-    int dact;                       // UIA_ACT_*: multiply by act'(aux_in) (GELU backward fused into dgrad)
-    const void* aux_in; long ldaux_in;    // T [M,N]: pre-activation read by dact
-    void* aux_out; long ldaux_out;        // T [M,N]: pre-activation stash (value before act)
-    const float* resid; long ldr;   // fp32 residual added last, or null
-    int resid_mod, resid_row_off;   // if resid_mod>0: residual row = m % resid_mod + resid_row_off (pos-embed)
-    const void* residT; long ldrT;  // T residual (accumulate into a T tensor), or null
-    int out_group;                  // if >0: output row = m + m/out_group + 1 (patch rows → token rows)
-    void* outT; long ldo;           // T output or null
-    float* out32; long ldo32;       // fp32 output or null
-};
+typedef uia_gemm_desc UiaGemmParams;
+typedef uia_attn_desc UiaAttnParams;
 
 int uia_gemm_launch(hipStream_t stream, int dtype, const UiaGemmParams& p, int cfg);
+int uia_attn_fwd_launch(hipStream_t stream, int dtype, const UiaAttnParams& p);
+int uia_attn_bwd_launch(hipStream_t stream, int dtype, const UiaAttnParams& p);
+int uia_layernorm_fwd_launch(hipStream_t stream, int dtype, int M, int D, long ldx, const float* x, const float* gamma, const float* beta,
+                             float eps, void* yT, float* y32);
+int uia_layernorm_bwd_launch(hipStream_t stream, int dtype, int M, int D, long ldx, const void* dy, const float* x, const float* gamma, float eps,
+                             const float* dres, float* dx32, void* dxT);
+int uia_cast_launch(hipStream_t stream, int dtype, size_t n, const float* src, void* dst, float scale);
+int uia_transpose_cast_launch(hipStream_t stream, int dtype, int rows, int cols, const float* src, void* dst);
+int uia_im2col_launch(hipStream_t stream, int dtype, int B, int C, int H, int W, int P, const float* img, void* out);
+int uia_fill_cls_launch(hipStream_t stream, int B, int N, int D, const float* cls, const float* pos0, float* x);
+int uia_embed_launch(hipStream_t stream, int rows, int L, int D, const int64_t* ids, const float* table, const float* pos, const float* type0, float* out);
+int uia_gather_rows_launch(hipStream_t stream, int n, int D, const float* src, const int64_t* idx, float* dst);
+int uia_wgrad_launch(hipStream_t stream, int dtype, int M, int I, int J, const void* A, long lda, const void* B, long ldb, float alpha, float* dW, float* dbias);

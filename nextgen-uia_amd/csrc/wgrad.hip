@@ -1,0 +1,210 @@
+// wgrad.hip — parameter gradient of a Linear:  dW[I,J] += alpha · Σ_m A[m,I]ᵀ · B[m,J]
+//            (+ optional dbias[I] += Σ_m A[m,I]).   I and J multiples of 64.
+//
+// The reference gets these from autograd; only ADAPTER weights are trainable on the hot path, so
+// one of I, J is always the bottleneck / rank (64):
+//     Mona  dW2 = dYᵀ·d, db2 = Σ dY     (project2, /root/reference/src/adapters/mona.py:148,358)
+//     Mona  dW1 = dtᵀ·u, db1 = Σ dt     (project1, mona.py:127,331)
+//     LoRA  dB = s·dyᵀ·t, dA = s·qᵀ·x̃, db = Σ dy    (src/adapters/lora.py:87)
+//
+// The contraction runs over the ROW index of both row-major operands, so both MFMA fragments
+// need "k = rows": they are fetched from 128-row LDS slabs with ds_read_b64_tr_b16 (bf16) or with
+// plain 4-byte reads for the 16x16x4 fp32 MFMA.  A workgroup owns one 64×64 tile of dW and one
+// chunk of rows; its four waves split each slab by rows, are summed through LDS, and the tile is
+// accumulated into the (caller-zeroed) fp32 gradient with one atomic add per element per chunk.
+// HBM-bound (reads A once per J-tile and B once per I-tile).
+#include "uia_common.h"
+#include "uia_kernels.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+__device__ __forceinline__ void glds16(const char* gsrc, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ s16x4 lds_tr16(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+}
+
+constexpr int SLAB = 128;            // rows per LDS slab (32 per wave)
+constexpr int CHUNK_SLABS = 4;       // slabs per workgroup → 512 rows per chunk
+
+// ---- bf16: slabs are [128][128 B] images, 32-B column groups swizzled by (row>>1)&3
+__global__ __launch_bounds__(256) void wgrad_bf16_kernel(int M, int I, int J, const bf16_t* __restrict__ A, long lda,
+                                                          const bf16_t* __restrict__ B, long ldb, float alpha,
+                                                          float* __restrict__ dW, float* __restrict__ dbias) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* As = smem;                  // 16 KiB
+    char* Bs = smem + SLAB * 128;     // 16 KiB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tj = blockIdx.x % (J / 64), ti = blockIdx.x / (J / 64);
+    const int m_begin = blockIdx.y * (SLAB * CHUNK_SLABS);
+    const int li = lane & 15, g = lane >> 4, qq = li >> 2, pp = li & 3;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+
+    const int trow = 32 * wave + 4 * g + qq;          // lo rows; hi rows = +16
+    const int tsw = (trow >> 1) & 3;                  // (+16 keeps (row>>1)&3)
+    for (int sl = 0; sl < CHUNK_SLABS; ++sl) {
+        const int m0 = m_begin + sl * SLAB;
+        if (m0 >= M) break;
+        __syncthreads();                               // previous slab fully consumed
+        for (int q = wave; q < SLAB / 8; q += 4) {
+            const int r = 8 * q + (lane >> 3);
+            int gm = m0 + r;
+            gm = gm < M ? gm : M - 1;
+            const int c = ((lane & 7) ^ (((r >> 1) & 3) << 1)) * 16;
+            glds16((const char*)(A + (size_t)gm * lda + (size_t)ti * 64) + c, As + q * 1024);
+            glds16((const char*)(B + (size_t)gm * ldb + (size_t)tj * 64) + c, Bs + q * 1024);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // this wave's 32 rows: k-slot (g,e) ↔ row 32w + 16(e>>2) + 4g + (e&3)
+        const bool tail = m0 + SLAB > M;
+        bf16x8 af[4], bfr[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int off = trow * 128 + ((t ^ tsw) << 5) + 8 * pp;
+            s16x4 alo = lds_tr16(As + off), ahi = lds_tr16(As + off + 16 * 128);
+            const s16x4 blo = lds_tr16(Bs + off), bhi = lds_tr16(Bs + off + 16 * 128);
+            if (tail) {   // rows past M were clamped duplicates: zero their A contribution
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (m0 + 32 * wave + 4 * g + e >= M) alo[e] = 0;
+                    if (m0 + 32 * wave + 16 + 4 * g + e >= M) ahi[e] = 0;
+                }
+            }
+            const s16x8 av = {alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
+            const s16x8 bv = {blo[0], blo[1], blo[2], blo[3], bhi[0], bhi[1], bhi[2], bhi[3]};
+            af[t] = __builtin_bit_cast(bf16x8, av);
+            bfr[t] = __builtin_bit_cast(bf16x8, bv);
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+        if (dbias && tj == 0) {   // column sums of A: thread = (column tid&63, row quarter tid>>6)
+            const int col = tid & 63, r0 = 32 * (tid >> 6);
+            for (int r = r0; r < r0 + 32; ++r) {
+                if (m0 + r < M) {
+                    const int ch = (col >> 3) ^ (((r >> 1) & 3) << 1);
+                    bsum += (float)*(const bf16_t*)(As + r * 128 + ch * 16 + (col & 7) * 2);
+                }
+            }
+        }
+    }
+    // ---- reduce the four waves through LDS, then one atomic per element
+    __syncthreads();
+    float* red = (float*)smem;                         // [4 waves][64*64] fp32 = 64 KiB
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)                // D[row = i = 16a + 4g + r][col = j = 16b + li]
+                red[wave * 4096 + (16 * a + 4 * g + r) * 64 + 16 * b + li] = acc[a][b][r];
+    __syncthreads();
+    for (int e = tid; e < 4096; e += 256) {
+        const float v = red[e] + red[4096 + e] + red[8192 + e] + red[12288 + e];
+        atomicAdd(dW + (size_t)(ti * 64 + (e >> 6)) * J + tj * 64 + (e & 63), v * alpha);
+    }
+    if (dbias && tj == 0) {
+        __syncthreads();
+        red[tid] = bsum;
+        __syncthreads();
+        if (tid < 64) atomicAdd(dbias + ti * 64 + tid, red[tid] + red[64 + tid] + red[128 + tid] + red[192 + tid]);
+    }
+}
+
+// ---- fp32: 16x16x4 MFMA straight from global (parity path; not tuned)
+__global__ __launch_bounds__(256) void wgrad_f32_kernel(int M, int I, int J, const float* __restrict__ A, long lda,
+                                                         const float* __restrict__ B, long ldb, float alpha,
+                                                         float* __restrict__ dW, float* __restrict__ dbias) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tj = blockIdx.x % (J / 64), ti = blockIdx.x / (J / 64);
+    const int m_begin = blockIdx.y * (SLAB * CHUNK_SLABS);
+    const int m_end = min(M, m_begin + SLAB * CHUNK_SLABS);
+    const int li = lane & 15, g = lane >> 4;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    for (int m = m_begin + 4 * wave; m < m_end; m += 16) {
+        const int row = m + g;
+        const bool ok = row < m_end;
+        const int rr = ok ? row : m_end - 1;
+        float av[4], bv[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            av[t] = ok ? A[(size_t)rr * lda + ti * 64 + 16 * t + li] : 0.f;
+            bv[t] = B[(size_t)rr * ldb + tj * 64 + 16 * t + li];
+            bsum += av[t];    // lane (li,g) accumulates columns 16t+li over its rows: summed per column below
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+        (void)bsum;
+    }
+    __syncthreads();
+    float* red = (float*)smem;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave * 4096 + (16 * a + 4 * g + r) * 64 + 16 * b + li] = acc[a][b][r];
+    __syncthreads();
+    for (int e = tid; e < 4096; e += 256) {
+        const float v = red[e] + red[4096 + e] + red[8192 + e] + red[12288 + e];
+        atomicAdd(dW + (size_t)(ti * 64 + (e >> 6)) * J + tj * 64 + (e & 63), v * alpha);
+    }
+    if (dbias && tj == 0) {   // separate simple pass: thread = column, quarter of the chunk's rows
+        const int col = tid & 63, part = tid >> 6;
+        float s = 0.f;
+        for (int m = m_begin + part; m < m_end; m += 4) s += A[(size_t)m * lda + ti * 64 + col];
+        __syncthreads();
+        red[tid] = s;
+        __syncthreads();
+        if (tid < 64) atomicAdd(dbias + ti * 64 + tid, red[tid] + red[64 + tid] + red[128 + tid] + red[192 + tid]);
+    }
+}
+
+}  // namespace
+
+int uia_wgrad_launch(hipStream_t stream, int dtype, int M, int I, int J, const void* A, long lda, const void* B, long ldb, float alpha,
+                     float* dW, float* dbias) {
+    UIA_CHECK_ARG(dtype == UIA_BF16 || dtype == UIA_F32, "uia_wgrad: bad dtype %d", dtype);
+    UIA_CHECK_ARG(M > 0 && I > 0 && J > 0 && I % 64 == 0 && J % 64 == 0, "uia_wgrad: I=%d and J=%d must be multiples of 64 (M=%d)", I, J, M);
+    UIA_CHECK_ARG(A && B && dW, "uia_wgrad: null tensor");
+    const int esz = dtype == UIA_BF16 ? 2 : 4;
+    UIA_CHECK_ARG((lda * esz) % 16 == 0 && (ldb * esz) % 16 == 0 && (uintptr_t)A % 16 == 0 && (uintptr_t)B % 16 == 0, "uia_wgrad: alignment");
+    UIA_CHECK_ARG(lda >= I && ldb >= J, "uia_wgrad: leading dimension too small");
+    const dim3 grid((I / 64) * (J / 64), (M + SLAB * CHUNK_SLABS - 1) / (SLAB * CHUNK_SLABS));
+    const int lds = 4 * 4096 * 4;   // reduction buffer (covers the 32 KiB of slabs)
+    static bool attr_set = false;
+    if (!attr_set) {
+        UIA_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        UIA_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    if (dtype == UIA_BF16)
+        hipLaunchKernelGGL(wgrad_bf16_kernel, grid, dim3(256), lds, stream, M, I, J, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, alpha, dW, dbias);
+    else
+        hipLaunchKernelGGL(wgrad_f32_kernel, grid, dim3(256), lds, stream, M, I, J, (const float*)A, lda, (const float*)B, ldb, alpha, dW, dbias);
+    UIA_CHECK_LAUNCH();
+    return 0;
+}

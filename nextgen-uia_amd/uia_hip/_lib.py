@@ -1,0 +1,87 @@
+"""ctypes binding of libuia_hip.so (C ABI in include/uia_hip.h).
+
+The product path has no CPU fallback: loading fails loudly if the library has not been built
+(`make -C nextgen-uia_amd/csrc` or `python -c "import __graft_entry__ as g; g.build()"`), and every
+wrapper raises if handed a non-CUDA tensor.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libuia_hip.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_GELU, ACT_QUICKGELU, ACT_RELU = 0, 1, 2, 3
+MASK_NONE, MASK_CAUSAL, MASK_KEYPAD = 0, 1, 2
+MONA_VARIANTS = {"baseline": 0, "noise_aware": 1, "freq_enhanced": 2, "hybrid": 3}
+
+vp, i32, i64, f32, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("A", vp), ("lda", i64), ("W", vp), ("ldw", i64), ("M", i32), ("N", i32), ("K", i32), ("alpha", f32),
+                ("bias", vp), ("act", i32), ("dact", i32), ("aux_in", vp), ("ldaux_in", i64), ("aux_out", vp), ("ldaux_out", i64),
+                ("resid", vp), ("ldr", i64), ("resid_mod", i32), ("resid_row_off", i32), ("residT", vp), ("ldrT", i64),
+                ("out_group", i32), ("outT", vp), ("ldo", i64), ("out32", vp), ("ldo32", i64)]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [("q", vp), ("k", vp), ("v", vp), ("ld_qkv", i64), ("out", vp), ("ldo", i64), ("lse", vp), ("keylen", vp),
+                ("B", i32), ("H", i32), ("L", i32), ("dh", i32), ("mask_kind", i32), ("scale", f32),
+                ("dout", vp), ("lddo", i64), ("dq", vp), ("dk", vp), ("dv", vp), ("ld_dqkv", i64)]
+
+
+class MonaSpatialDesc(C.Structure):
+    _fields_ = [("variant", i32), ("B", i32), ("h", i32), ("w", i32), ("bott", i32),
+                ("t", vp), ("d", vp),
+                ("conv1_w", vp), ("conv1_b", vp), ("conv2_w", vp), ("conv2_b", vp), ("conv3_w", vp), ("conv3_b", vp),
+                ("proj_w", vp), ("proj_b", vp), ("freq", vp), ("ne1_w", vp), ("ne1_b", vp), ("ne3_w", vp), ("ne3_b", vp),
+                ("p_drop", f32), ("seed", C.c_uint64), ("keep_mask", vp),
+                ("dd", vp), ("dt", vp),
+                ("g_conv1_w", vp), ("g_conv1_b", vp), ("g_conv2_w", vp), ("g_conv2_b", vp), ("g_conv3_w", vp), ("g_conv3_b", vp),
+                ("g_proj_w", vp), ("g_proj_b", vp), ("g_freq", vp), ("g_ne1_w", vp), ("g_ne1_b", vp), ("g_ne3_w", vp), ("g_ne3_b", vp)]
+
+
+# name -> (restype, argtypes).  tests/test_capi_symbols.py checks this table against include/uia_hip.h.
+PROTOTYPES = {
+    "uia_last_error": (C.c_char_p, []),
+    "uia_version": (C.c_int, []),
+    "uia_gemm": (C.c_int, [vp, C.c_int, C.POINTER(GemmDesc), C.c_int]),
+    "uia_wgrad": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, vp, i64, f32, vp, vp]),
+    "uia_attn_fwd": (C.c_int, [vp, C.c_int, C.POINTER(AttnDesc)]),
+    "uia_attn_bwd": (C.c_int, [vp, C.c_int, C.POINTER(AttnDesc)]),
+    "uia_layernorm_fwd": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, i64, vp, vp, vp, f32, vp, vp]),
+    "uia_layernorm_bwd": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, i64, vp, vp, vp, f32, vp, vp, vp]),
+    "uia_cast": (C.c_int, [vp, C.c_int, sz, vp, vp, f32]),
+    "uia_transpose_cast": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "uia_im2col": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "uia_fill_cls": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
+    "uia_embed": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
+    "uia_gather_rows": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp]),
+}
+
+_lib = None
+
+
+class UiaError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the shared library with prototypes applied."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise UiaError(f"{LIB_PATH} not built: run `make -C nextgen-uia_amd/csrc` (hipcc --offload-arch=gfx950). "
+                           "There is no CPU fallback for the uia hot path.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise UiaError(f"{what} failed (rc={rc}): {lib().uia_last_error().decode()}")

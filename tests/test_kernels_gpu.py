@@ -1,0 +1,171 @@
+"""-m gpu: each HIP kernel (through the C ABI / ctypes) against a plain PyTorch fp32 reference of
+the same op, on seeded inputs.  Tolerances: fp32 mode 1e-4 rel (exact-fp32 MFMA, different
+summation order); bf16 mode 1e-2 rel of max|ref| unless a test states otherwise."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from uia_hip import ops as o
+    return o
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rel(a, b):
+    return float((a.float() - b.float()).abs().max() / (b.float().abs().max() + 1e-12))
+
+
+TOL = {torch.float32: 2e-5, torch.bfloat16: 1.2e-2}
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_gemm_epilogues(ops, dt):
+    torch.manual_seed(0)
+    M, N, K = 197 * 3, 384, 256
+    a = torch.randn(M, K, device=dev()).to(dt)
+    w = (torch.randn(N, K, device=dev()) * 0.1).to(dt)
+    bias = torch.randn(N, device=dev())
+    resid = torch.randn(M, N, device=dev())
+    pre_ref = a.float() @ w.float().T + bias
+    out_t, aux = torch.empty(M, N, device=dev(), dtype=dt), torch.empty(M, N, device=dev(), dtype=dt)
+    ops.gemm(a, w, bias=bias, act="gelu", aux_out=aux, out_t=out_t)
+    assert rel(aux, pre_ref) < TOL[dt] and rel(out_t, torch.nn.functional.gelu(pre_ref)) < TOL[dt]
+    out32 = torch.empty(M, N, device=dev())
+    ops.gemm(a, w, bias=bias, resid=resid, out32=out32)
+    assert rel(out32, pre_ref + resid) < 1e-5 if dt == torch.float32 else 1e-5 + 1.0  # operands exact: fp32 out is exact-ish
+    assert rel(out32, pre_ref + resid) < 2e-5
+    ops.gemm(a, w, dact="quick_gelu", aux_in=aux, out32=out32)
+    x = aux.float()
+    s = torch.sigmoid(1.702 * x)
+    assert rel(out32, (a.float() @ w.float().T) * (s * (1 + 1.702 * x * (1 - s)))) < 2e-5
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_gemm_patch_embed_epilogue(ops, dt):
+    torch.manual_seed(1)
+    B, G, K, D = 3, 16, 192, 128          # 3 images, 16 patches each
+    a = torch.randn(B * G, K, device=dev()).to(dt)
+    w = (torch.randn(D, K, device=dev()) * 0.1).to(dt)
+    bias = torch.randn(D, device=dev())
+    pos = torch.randn(G + 1, D, device=dev())
+    x = torch.zeros(B, G + 1, D, device=dev())
+    ops.gemm(a, w, bias=bias, resid=pos, resid_mod=G, resid_row_off=1, out_group=G, out32=x.view(-1, D))
+    ref = (a.float() @ w.float().T + bias).view(B, G, D) + pos[1:]
+    assert rel(x[:, 1:], ref) < 2e-5 and float(x[:, 0].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("L,mask", [(197, "none"), (77, "causal"), (256, "keypad"), (17, "none"), (50, "keypad")])
+def test_attention_fwd_bwd(ops, dt, L, mask):
+    torch.manual_seed(2)
+    B, H, D = 3, 4, 256
+    qkv = (torch.randn(B * L, 3 * D, device=dev()) * 1.5).to(dt)
+    q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+    keylen = torch.tensor([L, max(1, L // 3), max(2, L - 5)], device=dev(), dtype=torch.int32) if mask == "keypad" else None
+    out = torch.empty(B * L, D, device=dev(), dtype=dt)
+    lse = torch.empty(B, H, L, device=dev())
+    ops.attn_fwd(q, k, v, out, B, H, L, lse=lse, mask=mask, keylen=keylen)
+
+    qf = qkv.float().view(B, L, 3, H, 64).permute(2, 0, 3, 1, 4).contiguous().requires_grad_(True)   # [3,B,H,L,64]
+    s = qf[0] @ qf[1].transpose(-1, -2) / 8.0
+    if mask == "causal":
+        s = s + torch.full((L, L), float("-inf"), device=dev()).triu_(1)
+    if mask == "keypad":
+        ar = torch.arange(L, device=dev())
+        s = s.masked_fill(ar[None, None, None, :] >= keylen[:, None, None, None], float("-inf"))
+    ref = torch.softmax(s, -1) @ qf[2]                                   # [B,H,L,64]
+    ref_o = ref.permute(0, 2, 1, 3).reshape(B * L, D)
+    assert rel(out, ref_o) < TOL[dt]
+    assert rel(lse, torch.logsumexp(s, -1)) < (1e-5 if dt == torch.float32 else 2e-2)
+
+    if L > 224 and dt == torch.bfloat16:
+        return                                                           # bf16 backward keeps the head in LDS: L <= 224
+    dout = torch.randn(B * L, D, device=dev()).to(dt)
+    ref.backward(dout.float().view(B, L, H, 64).permute(0, 2, 1, 3))
+    dqkv = torch.zeros(B * L, 3 * D, device=dev(), dtype=dt)
+    ops.attn_bwd(q, k, v, out, dout, lse, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], B, H, L, mask=mask, keylen=keylen)
+    g = qf.grad.permute(1, 3, 0, 2, 4).reshape(B * L, 3 * D)              # back to [B*L, (3,H,64)]
+    tol = 1e-4 if dt == torch.float32 else 2.5e-2
+    for i, name in enumerate("qkv"):
+        assert rel(dqkv[:, i * D:(i + 1) * D], g[:, i * D:(i + 1) * D]) < tol, name
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("D", [768, 64, 1024])
+def test_layernorm_fwd_bwd(ops, dt, D):
+    torch.manual_seed(3)
+    M = 37
+    x = (torch.randn(M, D, device=dev()) * 2 + 0.5).requires_grad_(True)
+    g, b = torch.randn(D, device=dev()), torch.randn(D, device=dev())
+    y_t, y32 = torch.empty(M, D, device=dev(), dtype=dt), torch.empty(M, D, device=dev())
+    ops.layernorm_fwd(x.detach(), g, b, 1e-6, y_t=y_t, y32=y32)
+    ref = torch.nn.functional.layer_norm(x, (D,), g, b, 1e-6)
+    assert rel(y32, ref) < 1e-5 and rel(y_t, ref) < TOL[dt]
+    dy = torch.randn(M, D, device=dev()).to(dt)
+    dres = torch.randn(M, D, device=dev())
+    ref.backward(dy.float())
+    dx32, dx_t = torch.empty(M, D, device=dev()), torch.empty(M, D, device=dev(), dtype=dt)
+    ops.layernorm_bwd(dy, x.detach(), g, 1e-6, dres=dres, dx32=dx32, dx_t=dx_t)
+    assert rel(dx32, x.grad + dres) < 2e-5 and rel(dx_t, x.grad + dres) < TOL[dt]
+
+
+def test_layernorm_strided_rows(ops):
+    torch.manual_seed(4)
+    B, N, D = 5, 7, 128
+    x = torch.randn(B, N, D, device=dev())
+    g, b = torch.randn(D, device=dev()), torch.randn(D, device=dev())
+    y = torch.empty(B, D, device=dev())
+    ops.layernorm_fwd(x, g, b, 1e-5, y32=y, rows=B, ldx=N * D)
+    assert rel(y, torch.nn.functional.layer_norm(x[:, 0], (D,), g, b, 1e-5)) < 1e-5
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,I,J", [(1000, 128, 64), (197 * 5, 64, 192), (513, 64, 64)])
+def test_wgrad(ops, dt, M, I, J):
+    torch.manual_seed(5)
+    a = torch.randn(M, I, device=dev()).to(dt)
+    b = torch.randn(M, J, device=dev()).to(dt)
+    dw = torch.zeros(I, J, device=dev())
+    db = torch.zeros(I, device=dev())
+    ops.wgrad(a, b, dw, db, alpha=0.5)
+    assert rel(dw, 0.5 * a.float().T @ b.float()) < 2e-5
+    assert rel(db, a.float().sum(0)) < 2e-5
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_layout_helpers(ops, dt):
+    torch.manual_seed(6)
+    w = torch.randn(70, 130, device=dev())
+    wt = torch.empty(130, 70, device=dev(), dtype=dt)
+    ops.transpose_cast(w, wt)
+    assert torch.equal(wt, w.T.to(dt))
+    c = torch.empty(70, 132, device=dev(), dtype=dt)
+    src = torch.randn(70, 132, device=dev())
+    ops.cast(src, c, 0.5)
+    assert torch.equal(c, (src * 0.5).to(dt))
+    img = torch.rand(2, 3, 32, 32, device=dev())
+    cols = torch.empty(2 * 16, 3 * 64, device=dev(), dtype=dt)
+    ops.im2col(img, cols, 8)
+    ref = torch.nn.functional.unfold(img, 8, stride=8).transpose(1, 2).reshape(32, 192)
+    assert torch.equal(cols, ref.to(dt))
+    x = torch.zeros(2, 5, 64, device=dev())
+    cls, pos0 = torch.randn(64, device=dev()), torch.randn(64, device=dev())
+    ops.fill_cls(x, cls, pos0)
+    assert torch.equal(x[:, 0], (cls + pos0).expand(2, -1)) and float(x[:, 1:].abs().max()) == 0
+    ids = torch.randint(0, 50, (3, 9), device=dev())
+    table, pos, ty = torch.randn(50, 64, device=dev()), torch.randn(9, 64, device=dev()), torch.randn(64, device=dev())
+    e = torch.empty(27, 64, device=dev())
+    ops.embed(ids, table, pos, ty, e)
+    assert rel(e.view(3, 9, 64), table[ids] + pos + ty) < 1e-6
+    idx = torch.tensor([26, 0, 13], device=dev())
+    gth = torch.empty(3, 64, device=dev())
+    ops.gather_rows(e, idx, gth)
+    assert torch.equal(gth, e[idx])
