@@ -99,6 +99,38 @@ int uia_layernorm_bwd(void* stream, int dtype, int M, int D, int64_t ldx, const 
                       float eps, const float* dres, float* dx32, void* dxT);
 
 /* ---------------------------------------------------------------------------------------------
+ * Mona adapter, all four variants (src/adapters/mona.py:75-487; equations SURVEY.md Appendix E.1).
+ * The two projections run on uia_gemm, their weight gradients on uia_wgrad; these are the stages
+ * in between.  bottleneck must be 64.
+ *   pre_fwd      u = LN(x; norm.w, norm.b, eps)*gamma + x*gammax                  (mona.py:125,227,328,461)
+ *   spatial_fwd  t [B,1+h*w,64] -> d = dropout(gelu([t_cls ; op(t_spatial)]))      (mona.py:129-147 + *MonaOp.forward)
+ *   spatial_bwd  dd -> dt and += gradients of every adapter_conv parameter (fp32 atomics, caller zeroes)
+ *   pre_bwd      dx = dy + du*gammax + LN'(du*gamma*norm.w); += d gamma, gammax, norm.w, norm.b
+ * Dropout: keep_mask (uint8 [B,1+h*w,64]) if non-null, else the counter hash of (seed, element index)
+ * when p_drop > 0; kept values are scaled by 1/(1-p_drop).  Pass the same seed / mask to fwd and bwd. */
+typedef struct uia_mona_spatial_desc {
+    int32_t variant, B, h, w, bott;
+    const void* t;                /* T [B, 1+h*w, bott] output of project1 */
+    void* d;                      /* T [B, 1+h*w, bott] forward output (input of project2) */
+    const float *conv1_w, *conv1_b, *conv2_w, *conv2_b, *conv3_w, *conv3_b;   /* depth-wise 3x3 / 5x5 / 7x7 */
+    const float *proj_w, *proj_b;                                             /* 1x1 projector [64,64] */
+    const float* freq;                                                        /* freq_filter [64] (freq_enhanced, hybrid) */
+    const float *ne1_w, *ne1_b, *ne3_w, *ne3_b;                               /* noise_estimator.{1,3} (noise_aware, hybrid) */
+    float p_drop; uint64_t seed; const uint8_t* keep_mask;
+    const void* dd;               /* backward: T grad wrt d */
+    void* dt;                     /* backward: T grad wrt t */
+    float *g_conv1_w, *g_conv1_b, *g_conv2_w, *g_conv2_b, *g_conv3_w, *g_conv3_b, *g_proj_w, *g_proj_b, *g_freq,
+          *g_ne1_w, *g_ne1_b, *g_ne3_w, *g_ne3_b;
+} uia_mona_spatial_desc;
+int uia_mona_pre_fwd(void* stream, int dtype, int M, int D, const float* x, const float* norm_w, const float* norm_b,
+                     const float* gamma, const float* gammax, float eps, void* u);
+int uia_mona_pre_bwd(void* stream, int dtype, int M, int D, const void* du, const float* x, const float* dy,
+                     const float* norm_w, const float* norm_b, const float* gamma, const float* gammax, float eps,
+                     float* dx32, void* dxT, float* g_gamma, float* g_gammax, float* g_norm_w, float* g_norm_b);
+int uia_mona_spatial_fwd(void* stream, int dtype, const uia_mona_spatial_desc* d);
+int uia_mona_spatial_bwd(void* stream, int dtype, const uia_mona_spatial_desc* d);
+
+/* ---------------------------------------------------------------------------------------------
  * Layout helpers around the GEMMs. */
 int uia_cast(void* stream, int dtype, size_t n, const float* src, void* dst, float scale);          /* dst = T(scale*src) */
 int uia_transpose_cast(void* stream, int dtype, int rows, int cols, const float* src, void* dst);   /* dst[c][r] = T(src[r][c]) */
@@ -107,6 +139,36 @@ int uia_fill_cls(void* stream, int B, int N, int D, const float* cls, const floa
 int uia_embed(void* stream, int rows, int L, int D, const int64_t* ids, const float* table, const float* pos,
               const float* type0, float* out);                                                          /* model.py:362-364 */
 int uia_gather_rows(void* stream, int n, int D, const float* src, const int64_t* idx, float* dst);  /* model.py:372 */
+/* dst = (accumulate ? dst : 0) + src*keep/(1-p), keep from the counter hash of (seed, index): LoRA input dropout
+ * (src/adapters/lora.py:82-83) and its backward (same seed). */
+int uia_dropout(void* stream, int dtype, size_t n, const void* src, void* dst, float p, uint64_t seed, int accumulate);
+/* out[N] += column sums of A[M,N] (bias gradients; LinearLoRA biases train: SURVEY Appendix C-4). */
+int uia_colsum(void* stream, int dtype, int M, int N, const void* A, int64_t lda, float* out);
+
+/* ---------------------------------------------------------------------------------------------
+ * Symmetric InfoNCE (src/losses/losses.py:23-47), forward + gradients of both feature matrices, fp32.
+ * loss (1 float, device) is overwritten; dimg/dtxt (both or neither) receive grad_scale * dLoss/dfeat.
+ * workspace: uia_infonce_workspace_bytes(B, E). */
+size_t uia_infonce_workspace_bytes(int B, int E);
+int uia_infonce_fwd_bwd(void* stream, int B, int E, const float* img, const float* txt, float inv_temp, float grad_scale,
+                        float* loss, float* dimg, float* dtxt, void* workspace, size_t workspace_bytes);
+
+/* ---------------------------------------------------------------------------------------------
+ * One optimiser update on the flat fp32 adapter buffer: clip_grad_norm_(max_norm) + AdamW
+ * (src/models/biomedclip/finetune.py:244-249,297-302).  g is read as grad_scale*g (1/world after the
+ * all-reduce SUM).  ws2: 2 floats of device scratch; ws2[0] returns the squared gradient norm. */
+int uia_adamw_clip_step(void* stream, size_t n, float* p, const float* g, float* m, float* v, float lr, float beta1, float beta2,
+                        float eps, float weight_decay, float max_norm, int step, float grad_scale, float* ws2);
+
+/* ---------------------------------------------------------------------------------------------
+ * Data-parallel exchange (new: the reference is single-process, finetune.py:287-302 accumulates
+ * instead).  RCCL all-reduce on the caller's stream; the unique id travels through the host. */
+int uia_comm_unique_id_bytes(void);
+int uia_comm_get_unique_id(void* out, int bytes);
+int uia_comm_init(int rank, int world, const void* unique_id, int bytes);
+int uia_comm_world(void);
+int uia_allreduce_sum(void* stream, int dtype, void* buf, size_t n);
+int uia_comm_destroy(void);
 
 #ifdef __cplusplus
 }

@@ -39,4 +39,40 @@ int uia_embed(void* stream, int rows, int L, int D, const int64_t* ids, const fl
 }
 int uia_gather_rows(void* stream, int n, int D, const float* src, const int64_t* idx, float* dst) { return uia_gather_rows_launch((hipStream_t)stream, n, D, src, idx, dst); }
 
+int uia_mona_pre_fwd(void* stream, int dtype, int M, int D, const float* x, const float* norm_w, const float* norm_b, const float* gamma,
+                     const float* gammax, float eps, void* u) {
+    return uia_mona_pre_fwd_launch((hipStream_t)stream, dtype, M, D, x, norm_w, norm_b, gamma, gammax, eps, u);
+}
+int uia_mona_pre_bwd(void* stream, int dtype, int M, int D, const void* du, const float* x, const float* dy, const float* norm_w,
+                     const float* norm_b, const float* gamma, const float* gammax, float eps, float* dx32, void* dxT, float* g_gamma,
+                     float* g_gammax, float* g_norm_w, float* g_norm_b) {
+    return uia_mona_pre_bwd_launch((hipStream_t)stream, dtype, M, D, du, x, dy, norm_w, norm_b, gamma, gammax, eps, dx32, dxT, g_gamma, g_gammax,
+                                   g_norm_w, g_norm_b);
+}
+int uia_mona_spatial_fwd(void* stream, int dtype, const uia_mona_spatial_desc* d) {
+    NEED(d, "uia_mona_spatial_fwd");
+    return uia_mona_spatial_fwd_launch((hipStream_t)stream, dtype, *d);
+}
+int uia_mona_spatial_bwd(void* stream, int dtype, const uia_mona_spatial_desc* d) {
+    NEED(d, "uia_mona_spatial_bwd");
+    return uia_mona_spatial_bwd_launch((hipStream_t)stream, dtype, *d);
+}
+
+size_t uia_infonce_workspace_bytes(int B, int E) { return uia_infonce_workspace_floats(B, E) * sizeof(float); }
+int uia_infonce_fwd_bwd(void* stream, int B, int E, const float* img, const float* txt, float inv_temp, float grad_scale, float* loss,
+                        float* dimg, float* dtxt, void* workspace, size_t workspace_bytes) {
+    return uia_infonce_launch((hipStream_t)stream, B, E, img, txt, inv_temp, grad_scale, loss, dimg, dtxt, (float*)workspace, workspace_bytes / sizeof(float));
+}
+int uia_adamw_clip_step(void* stream, size_t n, float* p, const float* g, float* m, float* v, float lr, float beta1, float beta2, float eps,
+                        float weight_decay, float max_norm, int step, float grad_scale, float* ws2) {
+    return uia_adamw_clip_launch((hipStream_t)stream, n, p, g, m, v, lr, beta1, beta2, eps, weight_decay, max_norm, step, grad_scale, ws2);
+}
+
+int uia_dropout(void* stream, int dtype, size_t n, const void* src, void* dst, float p, uint64_t seed, int accumulate) {
+    return uia_dropout_launch((hipStream_t)stream, dtype, n, src, dst, p, seed, accumulate);
+}
+int uia_colsum(void* stream, int dtype, int M, int N, const void* A, int64_t lda, float* out) {
+    return uia_colsum_launch((hipStream_t)stream, dtype, M, N, A, lda, out);
+}
+
 }  // extern "C"

@@ -88,6 +88,36 @@ __global__ void scale_cast_kernel(size_t n4, float a, const float* __restrict__ 
     }
 }
 
+// dst = (accumulate ? dst : 0) + src * keep(seed, idx) / (1 - p)      (LoRA input dropout, lora.py:82-83, and its backward)
+template <typename T>
+__global__ void dropout_kernel(size_t n8, const T* __restrict__ src, T* __restrict__ dst, float inv_keep, uint32_t thresh, uint64_t seed, int accumulate) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        float v[8], o[8];
+        load8(src + 8 * i, v);
+        if (accumulate) load8(dst + 8 * i, o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float k = dropout_keep(seed, (uint32_t)(8 * i + e), thresh) ? inv_keep : 0.f;
+            o[e] = (accumulate ? o[e] : 0.f) + v[e] * k;
+        }
+        store8(dst + 8 * i, o);
+    }
+}
+
+// out[n] += Σ_m A[m][n]: block = 64 columns x 4 row-quarters of a 1024-row chunk
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(int M, int N, const T* __restrict__ A, long lda, float* __restrict__ out) {
+    __shared__ float red[256];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+    const int m0 = blockIdx.y * 1024, m1 = min(M, m0 + 1024);
+    float s = 0.f;
+    if (col < N)
+        for (int m = m0 + part; m < m1; m += 4) s += to_f32(A[(size_t)m * lda + col]);
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < 64 && col < N) atomicAdd(out + col, red[threadIdx.x] + red[64 + threadIdx.x] + red[128 + threadIdx.x] + red[192 + threadIdx.x]);
+}
+
 inline int grid_for(size_t work, int block) {
     size_t g = (work + block - 1) / block;
     return (int)(g > 2048 ? 2048 : (g < 1 ? 1 : g));
@@ -145,6 +175,28 @@ int uia_embed_launch(hipStream_t stream, int rows, int L, int D, const int64_t* 
 int uia_gather_rows_launch(hipStream_t stream, int n, int D, const float* src, const int64_t* idx, float* dst) {
     UIA_CHECK_ARG(n > 0 && D % 4 == 0 && src && idx && dst, "uia_gather_rows: bad arguments");
     hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((size_t)n * D / 4, 256)), dim3(256), 0, stream, n, D, src, idx, dst);
+    UIA_CHECK_LAUNCH();
+    return 0;
+}
+
+int uia_dropout_launch(hipStream_t stream, int dtype, size_t n, const void* src, void* dst, float p, uint64_t seed, int accumulate) {
+    UIA_CHECK_ARG(n % 8 == 0 && src && dst && p >= 0.f && p < 1.f, "uia_dropout: bad arguments (n=%zu, p=%f)", n, p);
+    const float inv_keep = 1.0f / (1.0f - p);
+    const uint32_t thresh = (uint32_t)fminf(p * 4294967296.0f, 4294967295.0f);
+    const int g = grid_for(n / 8, 256);
+    if (dtype == UIA_BF16) hipLaunchKernelGGL(dropout_kernel<bf16_t>, dim3(g), dim3(256), 0, stream, n / 8, (const bf16_t*)src, (bf16_t*)dst, inv_keep, thresh, seed, accumulate);
+    else if (dtype == UIA_F32) hipLaunchKernelGGL(dropout_kernel<float>, dim3(g), dim3(256), 0, stream, n / 8, (const float*)src, (float*)dst, inv_keep, thresh, seed, accumulate);
+    else { uia_set_error("uia_dropout: bad dtype %d", dtype); return -1; }
+    UIA_CHECK_LAUNCH();
+    return 0;
+}
+
+int uia_colsum_launch(hipStream_t stream, int dtype, int M, int N, const void* A, long lda, float* out) {
+    UIA_CHECK_ARG(M > 0 && N > 0 && A && out && lda >= N, "uia_colsum: bad arguments");
+    const dim3 grid((N + 63) / 64, (M + 1023) / 1024);
+    if (dtype == UIA_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, stream, M, N, (const bf16_t*)A, lda, out);
+    else if (dtype == UIA_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, stream, M, N, (const float*)A, lda, out);
+    else { uia_set_error("uia_colsum: bad dtype %d", dtype); return -1; }
     UIA_CHECK_LAUNCH();
     return 0;
 }

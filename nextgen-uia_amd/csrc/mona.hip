@@ -1,0 +1,575 @@
+// mona.hip — the Mona adapter's non-GEMM stages, all four variants, forward and backward.
+//
+// Reference: /root/reference/src/adapters/mona.py
+//   BaselineMona :96-151 (op :75-93)         NoiseAwareMona :198-253 (op :159-195)
+//   FreqEnhancedMona :298-362 (op :261-295)  HybridNoiseFreqMona :427-487 (op :370-424)
+// Equations: SURVEY.md Appendix E.1.  The adapter is split around its two skinny GEMMs
+// (project1 768→64 and project2 64→768 run on gemm.hip, their weight gradients on wgrad.hip):
+//
+//   mona_pre      u = LN(x)·γ + x·γx                       [M,D] fp32 → T      (mona.py:125)
+//   mona_spatial  t → z → d = drop(gelu(z))                per image, [1+hw, 64] tile in LDS
+//                 · rfft2·f_c·irfft2 ≡ per-channel scale f_c (freq_filter multiplies every bin of a channel)
+//                 · (DW3+DW5+DW7)/3 — or the per-image softmax-weighted sum of the noise variants —
+//                   is evaluated as ONE merged 7×7 depth-wise stencil built per image
+//                 · 1×1 projector 64×64 with residual, CLS token bypasses the spatial op, exact-erf GELU,
+//                   dropout p=0.1 from a counter-based hash (or an explicit keep mask for parity tests)
+//   mona_spatial_bwd recomputes c and z from t (no stash), then back-propagates to dt and to every
+//                 adapter_conv parameter (atomic fp32 accumulation, one add per parameter per image)
+//   mona_pre_bwd  dX = dY + du·γx + LN'(du·γ·w_n);  dγ, dγx, dw_n, db_n column sums
+//
+// All of it is HBM/LDS-bound VALU work: thread = (channel = lane, pixel group = wave) so that every
+// LDS access of a wave is 64 consecutive floats (conflict-free) and boundary tests are wave-uniform.
+#include "uia_common.h"
+#include "uia_kernels.h"
+
+namespace {
+
+constexpr int BOTT = 64;
+constexpr int LN_MAXV = 4;
+
+// ======================================================================================= pre
+template <typename T>
+__global__ __launch_bounds__(256) void mona_pre_fwd_kernel(int M, int D, const float* __restrict__ x, const float* __restrict__ nw,
+                                                            const float* __restrict__ nb, const float* __restrict__ gamma,
+                                                            const float* __restrict__ gammax, float eps, T* __restrict__ u) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const int nv = D >> 2;
+    const float* xr = x + (size_t)row * D;
+    f32x4 v[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) {
+        const int c = lane + 64 * k;
+        v[k] = c < nv ? load4(xr + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        s += v[k][0] + v[k][1] + v[k][2] + v[k][3];
+    }
+    const float mean = wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) {
+        const int c = lane + 64 * k;
+        if (c < nv) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[k][e] - mean; q = fmaf(d, d, q); }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / D + eps);
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) {
+        const int c = lane + 64 * k;
+        if (c < nv) {
+            const f32x4 w = load4(nw + 4 * c), b = load4(nb + 4 * c), g = load4(gamma + 4 * c), gx = load4(gammax + 4 * c);
+            f32x4 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float n = fmaf((v[k][e] - mean) * rstd, w[e], b[e]);
+                y[e] = fmaf(n, g[e], v[k][e] * gx[e]);
+            }
+            store4(u + (size_t)row * D + 4 * c, y);
+        }
+    }
+}
+
+// rows are dealt to waves in a grid-stride loop so that every wave keeps per-column partial sums of
+// the four parameter gradients in registers; one LDS reduction + one atomic per column per block.
+template <typename T>
+__global__ __launch_bounds__(256) void mona_pre_bwd_kernel(int M, int D, const T* __restrict__ du, const float* __restrict__ x,
+                                                            const float* __restrict__ dy, const float* __restrict__ nw,
+                                                            const float* __restrict__ nb, const float* __restrict__ gamma,
+                                                            const float* __restrict__ gammax, float eps, float* __restrict__ dx32,
+                                                            T* __restrict__ dxT, float* __restrict__ g_gamma, float* __restrict__ g_gammax,
+                                                            float* __restrict__ g_nw, float* __restrict__ g_nb) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nv = D >> 2;
+    f32x4 a_g[LN_MAXV], a_gx[LN_MAXV], a_w[LN_MAXV], a_b[LN_MAXV];
+    f32x4 pw[LN_MAXV], pb[LN_MAXV], pg[LN_MAXV], pgx[LN_MAXV];
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) {
+        a_g[k] = a_gx[k] = a_w[k] = a_b[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int c = lane + 64 * k;
+        const bool ok = c < nv;
+        pw[k] = ok ? load4(nw + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        pb[k] = ok ? load4(nb + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        pg[k] = ok ? load4(gamma + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        pgx[k] = ok ? load4(gammax + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+        const float* xr = x + (size_t)row * D;
+        f32x4 v[LN_MAXV], d[LN_MAXV];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < LN_MAXV; ++k) {
+            const int c = lane + 64 * k;
+            const bool ok = c < nv;
+            v[k] = ok ? load4(xr + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+            d[k] = ok ? load4(du + (size_t)row * D + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+            s += v[k][0] + v[k][1] + v[k][2] + v[k][3];
+        }
+        const float mean = wave_sum(s) / D;
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < LN_MAXV; ++k) {
+            const int c = lane + 64 * k;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float t = c < nv ? v[k][e] - mean : 0.f; q = fmaf(t, t, q); }
+        }
+        const float rstd = rsqrtf(wave_sum(q) / D + eps);
+        // g = dn·w_n with dn = du·γ ; parameter partial sums
+        f32x4 xh[LN_MAXV], g[LN_MAXV];
+        float sg = 0.f, sgx = 0.f;
+#pragma unroll
+        for (int k = 0; k < LN_MAXV; ++k) {
+            const int c = lane + 64 * k;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xhat = c < nv ? (v[k][e] - mean) * rstd : 0.f;
+                const float dn = d[k][e] * pg[k][e];
+                const float n = fmaf(xhat, pw[k][e], pb[k][e]);
+                a_g[k][e] = fmaf(d[k][e], n, a_g[k][e]);            // dγ  = Σ du·n
+                a_gx[k][e] = fmaf(d[k][e], v[k][e], a_gx[k][e]);    // dγx = Σ du·x
+                a_w[k][e] = fmaf(dn, xhat, a_w[k][e]);              // dw_n = Σ dn·x̂
+                a_b[k][e] += dn;                                    // db_n = Σ dn
+                xh[k][e] = xhat;
+                g[k][e] = dn * pw[k][e];
+                sg += g[k][e];
+                sgx = fmaf(g[k][e], xhat, sgx);
+            }
+        }
+        const float mg = wave_sum(sg) / D, mgx = wave_sum(sgx) / D;
+        if (dx32 || dxT) {
+#pragma unroll
+            for (int k = 0; k < LN_MAXV; ++k) {
+                const int c = lane + 64 * k;
+                if (c < nv) {
+                    f32x4 o = load4(dy + (size_t)row * D + 4 * c);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] += fmaf(d[k][e], pgx[k][e], rstd * (g[k][e] - mg - xh[k][e] * mgx));
+                    if (dx32) store4(dx32 + (size_t)row * D + 4 * c, o);
+                    if (dxT) store4(dxT + (size_t)row * D + 4 * c, o);
+                }
+            }
+        }
+    }
+    // block reduction: [4 waves][4 quantities][D]
+    float* red = (float*)smem;
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) {
+        const int c = lane + 64 * k;
+        if (c < nv) {
+            store4(red + ((wave * 4 + 0) * D) + 4 * c, a_g[k]);
+            store4(red + ((wave * 4 + 1) * D) + 4 * c, a_gx[k]);
+            store4(red + ((wave * 4 + 2) * D) + 4 * c, a_w[k]);
+            store4(red + ((wave * 4 + 3) * D) + 4 * c, a_b[k]);
+        }
+    }
+    __syncthreads();
+    float* outs[4] = {g_gamma, g_gammax, g_nw, g_nb};
+    for (int i = threadIdx.x; i < 4 * D; i += 256) {
+        const int qn = i / D, c = i - qn * D;
+        const float v = red[(0 * 4 + qn) * D + c] + red[(1 * 4 + qn) * D + c] + red[(2 * 4 + qn) * D + c] + red[(3 * 4 + qn) * D + c];
+        atomicAdd(outs[qn] + c, v);
+    }
+}
+
+// ======================================================================================= spatial
+struct NoiseState {   // per-image noise-estimator activations kept for the backward
+    float w[3];
+};
+
+// merged-tap weight of stencil position (i,j) in the 7×7 frame
+#define KM(i, j) (w3 * k3[(i) * 7 + (j)] + (((i) >= 1 && (i) <= 5 && (j) >= 1 && (j) <= 5) ? w2 * k2[((i) - 1) * 5 + ((j) - 1)] : 0.f) + \
+                  (((i) >= 2 && (i) <= 4 && (j) >= 2 && (j) <= 4) ? w1 * k1[((i) - 2) * 3 + ((j) - 2)] : 0.f))
+
+template <typename T>
+__device__ __forceinline__ void load_tokens(const T* __restrict__ src, float* __restrict__ dst, int ntok, int tid) {
+    for (int i = tid; i < ntok * 8; i += 256) {
+        float v[8];
+        load8(src + (size_t)i * 8, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dst[i * 8 + e] = v[e];
+    }
+}
+
+// Noise estimator forward (mona.py:170-176,187 / :393-399,416): pool → 1×1 (64→16) → ReLU → 1×1 (16→3) → softmax.
+// scr: ≥ 4*64 + 64 + 16 + 16 + 4 floats.  Returns w1,w2,w3 in scr[W_OFF..].
+constexpr int SCR_PART = 0, SCR_POOL = 256, SCR_HPRE = 320, SCR_HID = 336, SCR_W = 352, SCR_DPOOL = 360, SCR_RED = 424, SCR_SIZE = 448;
+constexpr int RED_FLOATS = 3 * 64 * 50;   // pass-A partials of pixel groups 1..3 (group 0 keeps its own in registers)
+
+__device__ __forceinline__ void noise_forward(const uia_mona_spatial_desc& p, const float* tS, float f, int hw, int ppg, int c, int grp,
+                                              int tid, float* scr) {
+    float s = 0.f;
+    const int p0 = grp * ppg, p1 = min(hw, p0 + ppg);
+    for (int px = p0; px < p1; ++px) s += tS[(1 + px) * BOTT + c];
+    scr[SCR_PART + grp * 64 + c] = s;
+    __syncthreads();
+    if (tid < 64) scr[SCR_POOL + tid] = f * (scr[SCR_PART + tid] + scr[SCR_PART + 64 + tid] + scr[SCR_PART + 128 + tid] + scr[SCR_PART + 192 + tid]) / hw;
+    __syncthreads();
+    if (tid < 16) {
+        float a = p.ne1_b[tid];
+        for (int k = 0; k < 64; ++k) a = fmaf(p.ne1_w[tid * 64 + k], scr[SCR_POOL + k], a);
+        scr[SCR_HPRE + tid] = a;
+        scr[SCR_HID + tid] = fmaxf(a, 0.f);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float l[3];
+        for (int k = 0; k < 3; ++k) {
+            float a = p.ne3_b[k];
+            for (int j = 0; j < 16; ++j) a = fmaf(p.ne3_w[k * 16 + j], scr[SCR_HID + j], a);
+            l[k] = a;
+        }
+        const float m = fmaxf(l[0], fmaxf(l[1], l[2]));
+        const float e0 = expf(l[0] - m), e1 = expf(l[1] - m), e2 = expf(l[2] - m), inv = 1.f / (e0 + e1 + e2);
+        scr[SCR_W + 0] = e0 * inv; scr[SCR_W + 1] = e1 * inv; scr[SCR_W + 2] = e2 * inv;
+    }
+    __syncthreads();
+}
+
+// c[pix][ch] = f·Σ K·t[nbr] + Σ w_k b_k + t[pix]   for this thread's channel and pixel group
+__device__ __forceinline__ void conv_forward(const float* tS, float* cS, const float* k1, const float* k2, const float* k3, float w1,
+                                             float w2, float w3, float bm, float f, int h, int w, int p0, int p1, int c) {
+    for (int px = p0; px < p1; ++px) {
+        const int y = px / w, x = px - y * w;
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const int yy = y + i - 3;
+            if (yy < 0 || yy >= h) continue;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                const int xx = x + j - 3;
+                if (xx < 0 || xx >= w) continue;
+                acc = fmaf(KM(i, j), tS[(1 + yy * w + xx) * BOTT + c], acc);
+            }
+        }
+        cS[px * BOTT + c] = fmaf(f, acc, bm) + tS[(1 + px) * BOTT + c];
+    }
+}
+
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void mona_spatial_kernel(const uia_mona_spatial_desc p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int h = p.h, w = p.w, hw = h * w, ntok = hw + 1;
+    float* tS = (float*)smem;                 // [ntok][64]
+    float* cS = tS + ntok * BOTT;             // [hw][64]   (+64 slack)
+    const int cs_floats = BWD ? max(ntok * BOTT, RED_FLOATS) : ntok * BOTT;
+    float* gS = cS + cs_floats;               // [ntok][64] backward only
+    float* scr = BWD ? gS + ntok * BOTT : cS + cs_floats;
+    const int tid = threadIdx.x, c = tid & 63, grp = tid >> 6;
+    const int b = blockIdx.x;
+    const bool has_freq = p.variant == UIA_MONA_FREQ_ENHANCED || p.variant == UIA_MONA_HYBRID;
+    const bool has_noise = p.variant == UIA_MONA_NOISE_AWARE || p.variant == UIA_MONA_HYBRID;
+    const int ppg = (hw + 3) >> 2, p0 = grp * ppg, p1 = min(hw, p0 + ppg);
+    const size_t tok0 = (size_t)b * ntok;
+
+    load_tokens((const T*)p.t + tok0 * BOTT, tS, ntok, tid);
+    __syncthreads();
+    const float f = has_freq ? p.freq[c] : 1.0f;
+    float w1 = 1.f / 3.f, w2 = 1.f / 3.f, w3 = 1.f / 3.f;
+    if (has_noise) {
+        noise_forward(p, tS, f, hw, ppg, c, grp, tid, scr);
+        w1 = scr[SCR_W]; w2 = scr[SCR_W + 1]; w3 = scr[SCR_W + 2];
+    }
+    float k1[9], k2[25], k3[49];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) k1[i] = p.conv1_w[c * 9 + i];
+#pragma unroll
+    for (int i = 0; i < 25; ++i) k2[i] = p.conv2_w[c * 25 + i];
+#pragma unroll
+    for (int i = 0; i < 49; ++i) k3[i] = p.conv3_w[c * 49 + i];
+    const float b1 = p.conv1_b[c], b2 = p.conv2_b[c], b3 = p.conv3_b[c];
+    const float bm = w1 * b1 + w2 * b2 + w3 * b3;
+    conv_forward(tS, cS, k1, k2, k3, w1, w2, w3, bm, f, h, w, p0, p1, c);
+    __syncthreads();
+
+    // ---- projector + GELU (+dropout): thread = (out channel c, pixel group)
+    const float inv_keep = p.p_drop > 0.f ? 1.0f / (1.0f - p.p_drop) : 1.0f;
+    const uint32_t thresh = p.p_drop > 0.f ? (uint32_t)fminf(p.p_drop * 4294967296.0f, 4294967295.0f) : 0u;
+    auto keep_scale = [&](int tok) -> float {
+        const size_t idx = (tok0 + tok) * BOTT + c;
+        if (p.keep_mask) return p.keep_mask[idx] ? inv_keep : 0.f;
+        if (p.p_drop > 0.f) return dropout_keep(p.seed, (uint32_t)idx, thresh) ? inv_keep : 0.f;
+        return 1.0f;
+    };
+    {
+        float prow[64];
+#pragma unroll
+        for (int k = 0; k < 64; k += 4) {
+            const f32x4 v = load4(p.proj_w + c * 64 + k);
+            prow[k] = v[0]; prow[k + 1] = v[1]; prow[k + 2] = v[2]; prow[k + 3] = v[3];
+        }
+        const float pb = p.proj_b[c];
+        for (int px = p0; px < p1; ++px) {
+            float s = pb;
+#pragma unroll
+            for (int k = 0; k < 64; k += 4) {
+                const f32x4 v = *(const f32x4*)(cS + px * BOTT + k);     // broadcast read
+                s = fmaf(prow[k], v[0], s); s = fmaf(prow[k + 1], v[1], s); s = fmaf(prow[k + 2], v[2], s); s = fmaf(prow[k + 3], v[3], s);
+            }
+            const float z = cS[px * BOTT + c] + s;
+            const float ks = keep_scale(1 + px);
+            if (!BWD) {
+                ((T*)p.d)[(tok0 + 1 + px) * BOTT + c] = from_f32<T>(gelu_erf(z) * ks);
+            } else {
+                const float dd = to_f32(((const T*)p.dd)[(tok0 + 1 + px) * BOTT + c]);
+                gS[(1 + px) * BOTT + c] = dd * ks * dgelu_erf(z);         // dz = dp
+            }
+        }
+        if (grp == 0) {   // CLS token bypasses the spatial op (mona.py:132,139)
+            const float z = tS[c], ks = keep_scale(0);
+            if (!BWD) ((T*)p.d)[tok0 * BOTT + c] = from_f32<T>(gelu_erf(z) * ks);
+            else gS[c] = to_f32(((const T*)p.dd)[tok0 * BOTT + c]) * ks * dgelu_erf(z);
+        }
+    }
+    if (!BWD) return;
+
+    // ======================================================================== backward
+    __syncthreads();
+    // ---- dP[co][ci] += Σ_pix dp[pix][co]·c[pix][ci];  db_p[co] += Σ_pix dp[pix][co]
+    {
+        const int co = tid >> 2, cb = (tid & 3) * 16;
+        float a[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a[k] = 0.f;
+        float sb = 0.f;
+        for (int px = 0; px < hw; ++px) {
+            const float dpv = gS[(1 + px) * BOTT + co];
+            sb += dpv;
+#pragma unroll
+            for (int k = 0; k < 16; k += 4) {
+                const f32x4 v = *(const f32x4*)(cS + px * BOTT + cb + k);
+                a[k] = fmaf(dpv, v[0], a[k]); a[k + 1] = fmaf(dpv, v[1], a[k + 1]); a[k + 2] = fmaf(dpv, v[2], a[k + 2]); a[k + 3] = fmaf(dpv, v[3], a[k + 3]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) atomicAdd(p.g_proj_w + co * 64 + cb + k, a[k]);
+        if ((tid & 3) == 0) atomicAdd(p.g_proj_b + co, sb);
+    }
+    __syncthreads();
+    // ---- dc = dp + Pᵀ·dp, in place (rows of a pixel group belong to one wave)
+    {
+        float pcol[64];
+#pragma unroll
+        for (int k = 0; k < 64; ++k) pcol[k] = p.proj_w[k * 64 + c];
+        for (int px = p0; px < p1; ++px) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < 64; k += 4) {
+                const f32x4 v = *(const f32x4*)(gS + (1 + px) * BOTT + k);
+                s = fmaf(pcol[k], v[0], s); s = fmaf(pcol[k + 1], v[1], s); s = fmaf(pcol[k + 2], v[2], s); s = fmaf(pcol[k + 3], v[3], s);
+            }
+            const float dcv = gS[(1 + px) * BOTT + c] + s;
+            __builtin_amdgcn_wave_barrier();
+            gS[(1 + px) * BOTT + c] = dcv;
+        }
+    }
+    __syncthreads();
+    // ---- pass A: stencil weight gradients (and the mixing-weight gradients of the noise variants)
+    float dkm[49];
+#pragma unroll
+    for (int i = 0; i < 49; ++i) dkm[i] = 0.f;
+    float sdc = 0.f, dwm1 = 0.f, dwm2 = 0.f, dwm3 = 0.f;
+    for (int px = p0; px < p1; ++px) {
+        const int y = px / w, x = px - y * w;
+        const float dcv = gS[(1 + px) * BOTT + c];
+        sdc += dcv;
+        float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const int yy = y + i - 3;
+            if (yy < 0 || yy >= h) continue;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                const int xx = x + j - 3;
+                if (xx < 0 || xx >= w) continue;
+                const float tv = tS[(1 + yy * w + xx) * BOTT + c];
+                dkm[i * 7 + j] = fmaf(dcv, tv, dkm[i * 7 + j]);
+                s3 = fmaf(k3[i * 7 + j], tv, s3);
+                if (i >= 1 && i <= 5 && j >= 1 && j <= 5) s2 = fmaf(k2[(i - 1) * 5 + (j - 1)], tv, s2);
+                if (i >= 2 && i <= 4 && j >= 2 && j <= 4) s1 = fmaf(k1[(i - 2) * 3 + (j - 2)], tv, s1);
+            }
+        }
+        dwm1 = fmaf(dcv, fmaf(f, s1, b1), dwm1);     // Σ dc·conv_k  (conv_k = f·(k_k*t) + b_k)
+        dwm2 = fmaf(dcv, fmaf(f, s2, b2), dwm2);
+        dwm3 = fmaf(dcv, fmaf(f, s3, b3), dwm3);
+    }
+    // reduce over the 4 pixel groups through LDS (the c tile is free now): groups 1..3 → [3][64][50]
+    float* red = cS;
+    if (grp > 0) {
+#pragma unroll
+        for (int i = 0; i < 49; ++i) red[((grp - 1) * 64 + c) * 50 + i] = dkm[i];
+        red[((grp - 1) * 64 + c) * 50 + 49] = sdc;
+    }
+    __syncthreads();
+    if (grp == 0) {
+#pragma unroll
+        for (int i = 0; i < 49; ++i) dkm[i] = f * (dkm[i] + red[c * 50 + i] + red[(64 + c) * 50 + i] + red[(128 + c) * 50 + i]);   // Σ dc·xf[nbr]
+        sdc += red[c * 50 + 49] + red[(64 + c) * 50 + 49] + red[(128 + c) * 50 + 49];
+#pragma unroll
+        for (int i = 0; i < 7; ++i)
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                atomicAdd(p.g_conv3_w + c * 49 + i * 7 + j, w3 * dkm[i * 7 + j]);
+                if (i >= 1 && i <= 5 && j >= 1 && j <= 5) atomicAdd(p.g_conv2_w + c * 25 + (i - 1) * 5 + (j - 1), w2 * dkm[i * 7 + j]);
+                if (i >= 2 && i <= 4 && j >= 2 && j <= 4) atomicAdd(p.g_conv1_w + c * 9 + (i - 2) * 3 + (j - 2), w1 * dkm[i * 7 + j]);
+            }
+        atomicAdd(p.g_conv1_b + c, w1 * sdc);
+        atomicAdd(p.g_conv2_b + c, w2 * sdc);
+        atomicAdd(p.g_conv3_b + c, w3 * sdc);
+    }
+    float dpool_c = 0.f;
+    if (has_noise) {
+        // block-wide sums of dwm_k over channels and pixel groups
+        __syncthreads();
+        float r1 = wave_sum(dwm1), r2 = wave_sum(dwm2), r3 = wave_sum(dwm3);
+        if (c == 0) { scr[SCR_RED + grp * 4] = r1; scr[SCR_RED + grp * 4 + 1] = r2; scr[SCR_RED + grp * 4 + 2] = r3; }
+        __syncthreads();
+        if (tid < 16) {
+            // softmax backward → logits → hidden (each of the 16 threads recomputes the 3-vector)
+            float dwv[3], wv[3] = {w1, w2, w3}, dl[3];
+            for (int k = 0; k < 3; ++k) dwv[k] = scr[SCR_RED + k] + scr[SCR_RED + 4 + k] + scr[SCR_RED + 8 + k] + scr[SCR_RED + 12 + k];
+            const float dot = dwv[0] * wv[0] + dwv[1] * wv[1] + dwv[2] * wv[2];
+            for (int k = 0; k < 3; ++k) dl[k] = wv[k] * (dwv[k] - dot);
+            const float hid = scr[SCR_HID + tid], hpre = scr[SCR_HPRE + tid];
+            float dh = 0.f;
+            for (int k = 0; k < 3; ++k) {
+                atomicAdd(p.g_ne3_w + k * 16 + tid, dl[k] * hid);
+                dh = fmaf(dl[k], p.ne3_w[k * 16 + tid], dh);
+            }
+            if (tid < 3) atomicAdd(p.g_ne3_b + tid, dl[tid]);
+            dh = hpre > 0.f ? dh : 0.f;
+            scr[SCR_HPRE + tid] = dh;                       // reuse as dh
+            atomicAdd(p.g_ne1_b + tid, dh);
+        }
+        __syncthreads();
+        if (tid < 64) {
+            float dp = 0.f;
+            for (int j = 0; j < 16; ++j) dp = fmaf(scr[SCR_HPRE + j], p.ne1_w[j * 64 + tid], dp);
+            scr[SCR_DPOOL + tid] = dp / hw;                 // gradient reaching every xf[c][pix] through the pool
+        }
+        for (int i = tid; i < 16 * 64; i += 256) atomicAdd(p.g_ne1_w + i, scr[SCR_HPRE + (i >> 6)] * scr[SCR_POOL + (i & 63)]);
+        __syncthreads();
+        dpool_c = scr[SCR_DPOOL + c];
+    }
+    // ---- pass B: dxf = Kᵀ ⋆ dc (+ pool path);  dt = dc + f·dxf;  df = Σ dxf·t
+    float dfc = 0.f;
+    T* dt = (T*)p.dt;
+    for (int px = p0; px < p1; ++px) {
+        const int y = px / w, x = px - y * w;
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const int yy = y - (i - 3);
+            if (yy < 0 || yy >= h) continue;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                const int xx = x - (j - 3);
+                if (xx < 0 || xx >= w) continue;
+                acc = fmaf(KM(i, j), gS[(1 + yy * w + xx) * BOTT + c], acc);
+            }
+        }
+        const float dxf = acc + dpool_c;
+        dfc = fmaf(dxf, tS[(1 + px) * BOTT + c], dfc);
+        dt[(tok0 + 1 + px) * BOTT + c] = from_f32<T>(fmaf(f, dxf, gS[(1 + px) * BOTT + c]));
+    }
+    if (grp == 0) dt[tok0 * BOTT + c] = from_f32<T>(gS[c]);
+    if (has_freq) {
+        __syncthreads();
+        scr[SCR_PART + grp * 64 + c] = dfc;
+        __syncthreads();
+        if (tid < 64) atomicAdd(p.g_freq + tid, scr[SCR_PART + tid] + scr[SCR_PART + 64 + tid] + scr[SCR_PART + 128 + tid] + scr[SCR_PART + 192 + tid]);
+    }
+}
+
+size_t spatial_lds(int hw, bool bwd) {
+    const size_t tile = (size_t)(hw + 1) * BOTT;
+    const size_t cs = bwd ? (tile > (size_t)RED_FLOATS ? tile : (size_t)RED_FLOATS) : tile;
+    return (tile * (bwd ? 2 : 1) + cs + SCR_SIZE) * sizeof(float);
+}
+
+template <typename T, bool BWD>
+int launch_spatial(hipStream_t stream, const uia_mona_spatial_desc& p) {
+    const size_t lds = spatial_lds(p.h * p.w, BWD);
+    auto kern = mona_spatial_kernel<T, BWD>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        UIA_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.B), dim3(256), lds, stream, p);
+    UIA_CHECK_LAUNCH();
+    return 0;
+}
+
+int check_spatial(const uia_mona_spatial_desc& p, bool bwd) {
+    UIA_CHECK_ARG(p.variant >= 0 && p.variant <= 3, "uia_mona_spatial: bad variant %d", p.variant);
+    UIA_CHECK_ARG(p.bott == BOTT, "uia_mona_spatial: bottleneck %d unsupported (64 only)", p.bott);
+    UIA_CHECK_ARG(p.B > 0 && p.h > 0 && p.w > 0, "uia_mona_spatial: empty problem");
+    UIA_CHECK_ARG(spatial_lds(p.h * p.w, bwd) <= 160 * 1024, "uia_mona_spatial: %dx%d grid does not fit the 160 KiB LDS tile", p.h, p.w);
+    UIA_CHECK_ARG(p.t && p.conv1_w && p.conv1_b && p.conv2_w && p.conv2_b && p.conv3_w && p.conv3_b && p.proj_w && p.proj_b, "uia_mona_spatial: null parameter");
+    const bool has_freq = p.variant == UIA_MONA_FREQ_ENHANCED || p.variant == UIA_MONA_HYBRID;
+    const bool has_noise = p.variant == UIA_MONA_NOISE_AWARE || p.variant == UIA_MONA_HYBRID;
+    UIA_CHECK_ARG(!has_freq || p.freq, "uia_mona_spatial: variant needs freq_filter");
+    UIA_CHECK_ARG(!has_noise || (p.ne1_w && p.ne1_b && p.ne3_w && p.ne3_b), "uia_mona_spatial: variant needs noise_estimator parameters");
+    UIA_CHECK_ARG(p.p_drop >= 0.f && p.p_drop < 1.f, "uia_mona_spatial: p_drop %f", p.p_drop);
+    if (!bwd) { UIA_CHECK_ARG(p.d, "uia_mona_spatial_fwd: null output"); }
+    else {
+        UIA_CHECK_ARG(p.dd && p.dt && p.g_conv1_w && p.g_conv1_b && p.g_conv2_w && p.g_conv2_b && p.g_conv3_w && p.g_conv3_b && p.g_proj_w && p.g_proj_b,
+                      "uia_mona_spatial_bwd: null gradient buffer");
+        UIA_CHECK_ARG(!has_freq || p.g_freq, "uia_mona_spatial_bwd: variant needs g_freq");
+        UIA_CHECK_ARG(!has_noise || (p.g_ne1_w && p.g_ne1_b && p.g_ne3_w && p.g_ne3_b), "uia_mona_spatial_bwd: variant needs noise_estimator gradient buffers");
+    }
+    return 0;
+}
+
+}  // namespace
+
+int uia_mona_pre_fwd_launch(hipStream_t stream, int dtype, int M, int D, const float* x, const float* nw, const float* nb, const float* gamma,
+                            const float* gammax, float eps, void* u) {
+    UIA_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 1024, "uia_mona_pre_fwd: unsupported shape M=%d D=%d", M, D);
+    UIA_CHECK_ARG(x && nw && nb && gamma && gammax && u, "uia_mona_pre_fwd: null tensor");
+    const dim3 grid((M + 3) / 4), block(256);
+    if (dtype == UIA_BF16) hipLaunchKernelGGL(mona_pre_fwd_kernel<bf16_t>, grid, block, 0, stream, M, D, x, nw, nb, gamma, gammax, eps, (bf16_t*)u);
+    else if (dtype == UIA_F32) hipLaunchKernelGGL(mona_pre_fwd_kernel<float>, grid, block, 0, stream, M, D, x, nw, nb, gamma, gammax, eps, (float*)u);
+    else { uia_set_error("uia_mona_pre_fwd: bad dtype %d", dtype); return -1; }
+    UIA_CHECK_LAUNCH();
+    return 0;
+}
+
+int uia_mona_pre_bwd_launch(hipStream_t stream, int dtype, int M, int D, const void* du, const float* x, const float* dy, const float* nw,
+                            const float* nb, const float* gamma, const float* gammax, float eps, float* dx32, void* dxT, float* g_gamma,
+                            float* g_gammax, float* g_nw, float* g_nb) {
+    UIA_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 1024, "uia_mona_pre_bwd: unsupported shape M=%d D=%d", M, D);
+    UIA_CHECK_ARG(du && x && nw && nb && gamma && gammax && g_gamma && g_gammax && g_nw && g_nb, "uia_mona_pre_bwd: null tensor");
+    UIA_CHECK_ARG(dy || !(dx32 || dxT), "uia_mona_pre_bwd: dx requested without dy");
+    int blocks = (M + 3) / 4;
+    blocks = blocks > 512 ? 512 : blocks;
+    const size_t lds = (size_t)16 * D * sizeof(float);
+    if (dtype == UIA_BF16)
+        hipLaunchKernelGGL(mona_pre_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), lds, stream, M, D, (const bf16_t*)du, x, dy, nw, nb, gamma, gammax, eps,
+                           dx32, (bf16_t*)dxT, g_gamma, g_gammax, g_nw, g_nb);
+    else if (dtype == UIA_F32)
+        hipLaunchKernelGGL(mona_pre_bwd_kernel<float>, dim3(blocks), dim3(256), lds, stream, M, D, (const float*)du, x, dy, nw, nb, gamma, gammax, eps,
+                           dx32, (float*)dxT, g_gamma, g_gammax, g_nw, g_nb);
+    else { uia_set_error("uia_mona_pre_bwd: bad dtype %d", dtype); return -1; }
+    UIA_CHECK_LAUNCH();
+    return 0;
+}
+
+int uia_mona_spatial_fwd_launch(hipStream_t stream, int dtype, const uia_mona_spatial_desc& p) {
+    if (int rc = check_spatial(p, false)) return rc;
+    if (dtype == UIA_BF16) return launch_spatial<bf16_t, false>(stream, p);
+    if (dtype == UIA_F32) return launch_spatial<float, false>(stream, p);
+    uia_set_error("uia_mona_spatial_fwd: bad dtype %d", dtype);
+    return -1;
+}
+
+int uia_mona_spatial_bwd_launch(hipStream_t stream, int dtype, const uia_mona_spatial_desc& p) {
+    if (int rc = check_spatial(p, true)) return rc;
+    if (dtype == UIA_BF16) return launch_spatial<bf16_t, true>(stream, p);
+    if (dtype == UIA_F32) return launch_spatial<float, true>(stream, p);
+    uia_set_error("uia_mona_spatial_bwd: bad dtype %d", dtype);
+    return -1;
+}

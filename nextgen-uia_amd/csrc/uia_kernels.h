@@ -24,3 +24,17 @@ int uia_fill_cls_launch(hipStream_t stream, int B, int N, int D, const float* cl
 int uia_embed_launch(hipStream_t stream, int rows, int L, int D, const int64_t* ids, const float* table, const float* pos, const float* type0, float* out);
 int uia_gather_rows_launch(hipStream_t stream, int n, int D, const float* src, const int64_t* idx, float* dst);
 int uia_wgrad_launch(hipStream_t stream, int dtype, int M, int I, int J, const void* A, long lda, const void* B, long ldb, float alpha, float* dW, float* dbias);
+int uia_mona_pre_fwd_launch(hipStream_t stream, int dtype, int M, int D, const float* x, const float* nw, const float* nb, const float* gamma,
+                            const float* gammax, float eps, void* u);
+int uia_mona_pre_bwd_launch(hipStream_t stream, int dtype, int M, int D, const void* du, const float* x, const float* dy, const float* nw,
+                            const float* nb, const float* gamma, const float* gammax, float eps, float* dx32, void* dxT, float* g_gamma,
+                            float* g_gammax, float* g_nw, float* g_nb);
+int uia_mona_spatial_fwd_launch(hipStream_t stream, int dtype, const uia_mona_spatial_desc& p);
+int uia_mona_spatial_bwd_launch(hipStream_t stream, int dtype, const uia_mona_spatial_desc& p);
+size_t uia_infonce_workspace_floats(int B, int E);
+int uia_infonce_launch(hipStream_t stream, int B, int E, const float* img, const float* txt, float inv_temp, float grad_scale, float* loss,
+                       float* dimg, float* dtxt, float* ws, size_t ws_floats);
+int uia_adamw_clip_launch(hipStream_t stream, size_t n, float* p, const float* g, float* m, float* v, float lr, float beta1, float beta2,
+                          float eps, float weight_decay, float max_norm, int step, float grad_scale, float* ws);
+int uia_dropout_launch(hipStream_t stream, int dtype, size_t n, const void* src, void* dst, float p, uint64_t seed, int accumulate);
+int uia_colsum_launch(hipStream_t stream, int dtype, int M, int N, const void* A, long lda, float* out);

@@ -52,6 +52,21 @@ PROTOTYPES = {
     "uia_attn_bwd": (C.c_int, [vp, C.c_int, C.POINTER(AttnDesc)]),
     "uia_layernorm_fwd": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, i64, vp, vp, vp, f32, vp, vp]),
     "uia_layernorm_bwd": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, i64, vp, vp, vp, f32, vp, vp, vp]),
+    "uia_mona_pre_fwd": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, f32, vp]),
+    "uia_mona_pre_bwd": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp]),
+    "uia_mona_spatial_fwd": (C.c_int, [vp, C.c_int, C.POINTER(MonaSpatialDesc)]),
+    "uia_mona_spatial_bwd": (C.c_int, [vp, C.c_int, C.POINTER(MonaSpatialDesc)]),
+    "uia_infonce_workspace_bytes": (sz, [C.c_int, C.c_int]),
+    "uia_infonce_fwd_bwd": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, f32, f32, vp, vp, vp, vp, sz]),
+    "uia_adamw_clip_step": (C.c_int, [vp, sz, vp, vp, vp, vp, f32, f32, f32, f32, f32, f32, C.c_int, f32, vp]),
+    "uia_comm_unique_id_bytes": (C.c_int, []),
+    "uia_comm_get_unique_id": (C.c_int, [vp, C.c_int]),
+    "uia_comm_init": (C.c_int, [C.c_int, C.c_int, vp, C.c_int]),
+    "uia_comm_world": (C.c_int, []),
+    "uia_allreduce_sum": (C.c_int, [vp, C.c_int, vp, sz]),
+    "uia_comm_destroy": (C.c_int, []),
+    "uia_dropout": (C.c_int, [vp, C.c_int, sz, vp, vp, f32, C.c_uint64, C.c_int]),
+    "uia_colsum": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, i64, vp]),
     "uia_cast": (C.c_int, [vp, C.c_int, sz, vp, vp, f32]),
     "uia_transpose_cast": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp]),
     "uia_im2col": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),

@@ -1,0 +1,530 @@
+"""Autograd-level building blocks on top of uia_hip.ops (one process per GPU, current stream).
+
+What lives here is orchestration only — which kernel runs on which buffer, what is stashed for the
+backward — mirroring what PyTorch autograd does for the reference's modules:
+
+  MonaFn        all four Mona variants                        (/root/reference/src/adapters/mona.py:96-487)
+  VitBlockFn    pre-LN transformer block, dgrad-only backward  (src/third_party/openai_clip/model.py:177-202; timm Block)
+                with optional LoRA on the attention projections (src/adapters/lora.py:54-199)
+  post_ln_layer HF BERT layer, forward only (frozen text tower)
+  patch_embed / head helpers
+
+Residual stream, parameter gradients: fp32.  GEMM / attention operands: `T` = the compute dtype
+(torch.bfloat16, or torch.float32 for the parity mode).
+"""
+import math
+import weakref
+
+import torch
+
+from . import ops
+
+_STATE = {"dtype": torch.bfloat16, "seed": 0x5EED, "calls": 0}
+
+
+def set_compute_dtype(dt):
+    assert dt in (torch.bfloat16, torch.float32)
+    _STATE["dtype"] = dt
+
+
+def compute_dtype():
+    return _STATE["dtype"]
+
+
+def set_dropout_seed(seed):
+    _STATE["seed"], _STATE["calls"] = int(seed), 0
+
+
+def _next_seed():
+    _STATE["calls"] += 1
+    return (_STATE["seed"] * 0x9E3779B97F4A7C15 + _STATE["calls"] * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+
+
+# ------------------------------------------------------------------------------------------------
+# T copies of fp32 gradient tensors travel beside autograd: the kernel that produces a residual
+# gradient also writes its T copy (operand of the consumer's first dgrad GEMM); the consumer looks
+# it up by storage address instead of re-reading 4 bytes/element to cast.
+_T_COPIES = {}
+
+
+def publish_t_copy(g32, g_t):
+    if g_t is not None and g_t.dtype != torch.float32:
+        _T_COPIES[g32.data_ptr()] = (g32.shape, g_t)
+
+
+def t_copy_of(g32, dt):
+    """Return a T copy of the fp32 gradient `g32` (cached one if its producer published it)."""
+    if dt == torch.float32:
+        return g32
+    hit = _T_COPIES.pop(g32.data_ptr(), None)
+    if hit is not None and hit[0] == g32.shape and hit[1].dtype == dt:
+        return hit[1]
+    out = torch.empty(g32.shape, device=g32.device, dtype=dt)
+    ops.cast(g32.contiguous(), out)
+    return out
+
+
+def clear_t_copies():
+    _T_COPIES.clear()
+
+
+# ------------------------------------------------------------------------------------------------
+class WeightCache:
+    """T copies (and transposes, for dgrad-as-TN) of fp32 parameters, refreshed when the parameter's
+    version counter changes (frozen weights are converted exactly once)."""
+
+    def __init__(self):
+        self._c = {}
+
+    def get(self, p, dt, transpose=False, pad_rows_to=None):
+        key = (id(p), dt, transpose, pad_rows_to)
+        hit = self._c.get(key)
+        if hit is not None and hit[0] == p._version and hit[1]() is p and hit[2].device == p.device:
+            return hit[2]
+        src = p.detach()
+        if src.dim() != 2:
+            src = src.reshape(src.shape[0], -1)
+        src = src.contiguous().float()
+        if pad_rows_to is not None and src.shape[0] < pad_rows_to:      # LoRA rank → 64 (zero rows change nothing)
+            src = torch.cat([src, src.new_zeros(pad_rows_to - src.shape[0], src.shape[1])], 0)
+        if transpose:
+            out = torch.empty(src.shape[1], src.shape[0], device=src.device, dtype=dt)
+            ops.transpose_cast(src, out)
+        elif dt == torch.float32:
+            out = src
+        else:
+            out = torch.empty(src.shape, device=src.device, dtype=dt)
+            ops.cast(src, out)
+        self._c[key] = (p._version, weakref.ref(p), out)
+        return out
+
+
+WEIGHTS = WeightCache()
+
+
+def _empty(shape, dt, like):
+    return torch.empty(shape, device=like.device, dtype=dt)
+
+
+# ================================================================================================ Mona
+MONA_PARAM_ORDER = ("gamma", "gammax", "project1.weight", "project1.bias", "project2.weight", "project2.bias", "norm.weight", "norm.bias",
+                    "adapter_conv.conv1.weight", "adapter_conv.conv1.bias", "adapter_conv.conv2.weight", "adapter_conv.conv2.bias",
+                    "adapter_conv.conv3.weight", "adapter_conv.conv3.bias", "adapter_conv.projector.weight", "adapter_conv.projector.bias",
+                    "adapter_conv.freq_filter", "adapter_conv.noise_estimator.1.weight", "adapter_conv.noise_estimator.1.bias",
+                    "adapter_conv.noise_estimator.3.weight", "adapter_conv.noise_estimator.3.bias")
+_SPATIAL_MAP = {"adapter_conv.conv1.weight": "conv1_w", "adapter_conv.conv1.bias": "conv1_b", "adapter_conv.conv2.weight": "conv2_w",
+                "adapter_conv.conv2.bias": "conv2_b", "adapter_conv.conv3.weight": "conv3_w", "adapter_conv.conv3.bias": "conv3_b",
+                "adapter_conv.projector.weight": "proj_w", "adapter_conv.projector.bias": "proj_b", "adapter_conv.freq_filter": "freq",
+                "adapter_conv.noise_estimator.1.weight": "ne1_w", "adapter_conv.noise_estimator.1.bias": "ne1_b",
+                "adapter_conv.noise_estimator.3.weight": "ne3_w", "adapter_conv.noise_estimator.3.bias": "ne3_b"}
+
+
+class MonaFn(torch.autograd.Function):
+    """y = x + project2(drop(gelu(spatial(project1(LN(x)·γ + x·γx)))))  on batch-first x [B, N, D] fp32."""
+
+    @staticmethod
+    def forward(ctx, x, variant, hw, p_drop, keep_mask, names, *params):
+        P = dict(zip(names, params))
+        B, N, D = x.shape
+        h, w = hw
+        assert N == 1 + h * w, f"Mona expects 1+h*w tokens, got N={N}, hw={hw}"
+        dt = compute_dtype()
+        x = x.contiguous()
+        M = B * N
+        bott = P["project1.weight"].shape[0]
+        u = _empty((M, D), dt, x)
+        ops.mona_pre_fwd(x, P["norm.weight"], P["norm.bias"], P["gamma"], P["gammax"], u)
+        w1 = WEIGHTS.get(P["project1.weight"], dt)
+        t = _empty((M, bott), dt, x)
+        ops.gemm(u, w1, bias=P["project1.bias"], out_t=t)
+        sp = {_SPATIAL_MAP[k]: v.detach().contiguous() for k, v in P.items() if k in _SPATIAL_MAP}
+        d = _empty((M, bott), dt, x)
+        seed = _next_seed() if (p_drop > 0 and keep_mask is None) else 0
+        ops.mona_spatial_fwd(variant, B, h, w, t, sp, d, p_drop=p_drop, seed=seed, keep_mask=keep_mask)
+        w2 = WEIGHTS.get(P["project2.weight"], dt)
+        y = torch.empty_like(x)
+        ops.gemm(d, w2, bias=P["project2.bias"], resid=x.view(M, D), out32=y.view(M, D))
+        ctx.save_for_backward(x, u, t, d, keep_mask if keep_mask is not None else x.new_empty(0), *params)
+        ctx.meta = (variant, hw, p_drop, seed, names, keep_mask is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        variant, hw, p_drop, seed, names, has_mask = ctx.meta
+        x, u, t, d, keep_mask, *params = ctx.saved_tensors
+        keep_mask = keep_mask if has_mask else None
+        P = dict(zip(names, params))
+        B, N, D = x.shape
+        h, w = hw
+        M, dt = B * N, u.dtype
+        bott = t.shape[1]
+        dy = dy.contiguous()
+        dy_t = t_copy_of(dy, dt).view(M, D)
+        G = {k: torch.zeros_like(v, dtype=torch.float32) for k, v in P.items()}
+        # project2: dd = dy·W2 ; dW2 = dyᵀ·d ; db2 = Σ dy
+        w2t = WEIGHTS.get(P["project2.weight"], dt, transpose=True)          # [bott, D]
+        dd = _empty((M, bott), dt, x)
+        ops.gemm(dy_t, w2t, out_t=dd)
+        ops.wgrad(dy_t, d, G["project2.weight"], G["project2.bias"])
+        # spatial
+        sp = {_SPATIAL_MAP[k]: v.detach().contiguous() for k, v in P.items() if k in _SPATIAL_MAP}
+        sg = {_SPATIAL_MAP[k]: G[k] for k in P if k in _SPATIAL_MAP}
+        dtt = _empty((M, bott), dt, x)
+        ops.mona_spatial_bwd(variant, B, h, w, t, sp, dd, dtt, sg, p_drop=p_drop, seed=seed, keep_mask=keep_mask)
+        # project1: du = dt·W1 ; dW1 = dtᵀ·u ; db1 = Σ dt
+        w1t = WEIGHTS.get(P["project1.weight"], dt, transpose=True)          # [D, bott]
+        du = _empty((M, D), dt, x)
+        ops.gemm(dtt, w1t, out_t=du)
+        ops.wgrad(dtt, u, G["project1.weight"], G["project1.bias"])
+        need_dx = ctx.needs_input_grad[0]
+        dx = torch.empty_like(x) if need_dx else None
+        dx_t = _empty((M, D), dt, x) if (need_dx and dt != torch.float32) else None
+        ops.mona_pre_bwd(du, x, dy if need_dx else None, P["norm.weight"], P["norm.bias"], P["gamma"], P["gammax"], dx, dx_t,
+                         G["gamma"], G["gammax"], G["norm.weight"], G["norm.bias"])
+        if need_dx:
+            publish_t_copy(dx, dx_t)
+        grads = tuple(G[k] if ctx.needs_input_grad[6 + i] else None for i, k in enumerate(names))
+        return (dx, None, None, None, None, None) + grads
+
+
+def mona_apply(x_bnd, module_params, variant, hw, p_drop, training, keep_mask=None):
+    """module_params: ordered {relative name: Parameter}."""
+    names = tuple(k for k in MONA_PARAM_ORDER if k in module_params)
+    pd = p_drop if (training or keep_mask is not None) else 0.0
+    return MonaFn.apply(x_bnd, variant, tuple(hw), pd, keep_mask, names, *[module_params[k] for k in names])
+
+
+# ================================================================================================ ViT block
+class BlockSpec:
+    """Static description of a pre-LN block: which parameters play which role."""
+
+    def __init__(self, heads, eps, act, ln1, qkv, proj, ln2, fc1, fc2, mask=None):
+        self.heads, self.eps, self.act, self.mask = heads, eps, act, mask
+        self.ln1, self.qkv, self.proj, self.ln2, self.fc1, self.fc2 = ln1, qkv, proj, ln2, fc1, fc2   # each: (weight, bias)
+
+
+class VitBlockFn(torch.autograd.Function):
+    """x + attn(LN1 x);  · + mlp(LN2 ·)   with frozen weights: the backward is dgrad only."""
+
+    @staticmethod
+    def forward(ctx, x, spec):
+        B, N, D = x.shape
+        M, dt = B * N, compute_dtype()
+        x = x.contiguous()
+        x2d = x.view(M, D)
+        train = ctx.needs_input_grad[0]
+        h1 = _empty((M, D), dt, x)
+        ops.layernorm_fwd(x2d, spec.ln1[0], spec.ln1[1], spec.eps, y_t=h1)
+        qkv = _empty((M, 3 * D), dt, x)
+        ops.gemm(h1, WEIGHTS.get(spec.qkv[0], dt), bias=spec.qkv[1], out_t=qkv)
+        a = _empty((M, D), dt, x)
+        lse = torch.empty(B, spec.heads, N, device=x.device, dtype=torch.float32) if train else None
+        ops.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], a, B, spec.heads, N, lse=lse, mask=spec.mask)
+        x1 = torch.empty_like(x2d)
+        ops.gemm(a, WEIGHTS.get(spec.proj[0], dt), bias=spec.proj[1], resid=x2d, out32=x1)
+        ops.layernorm_fwd(x1, spec.ln2[0], spec.ln2[1], spec.eps, y_t=h1)          # h1 buffer reused as h2
+        F = spec.fc1[0].shape[0]
+        f = _empty((M, F), dt, x)
+        pre = _empty((M, F), dt, x) if train else None
+        ops.gemm(h1, WEIGHTS.get(spec.fc1[0], dt), bias=spec.fc1[1], act=spec.act, aux_out=pre, out_t=f)
+        x2 = torch.empty_like(x)
+        ops.gemm(f, WEIGHTS.get(spec.fc2[0], dt), bias=spec.fc2[1], resid=x1, out32=x2.view(M, D))
+        if train:
+            ctx.save_for_backward(x, qkv, a, lse, x1, pre)
+            ctx.spec = spec
+        return x2
+
+    @staticmethod
+    def backward(ctx, dx2):
+        x, qkv, a, lse, x1, pre = ctx.saved_tensors
+        spec = ctx.spec
+        B, N, D = x.shape
+        M, dt = B * N, qkv.dtype
+        F = pre.shape[1]
+        dx2 = dx2.contiguous()
+        dx2_t = t_copy_of(dx2, dt).view(M, D)
+        # fc2 dgrad fused with act'(pre)
+        dpre = _empty((M, F), dt, x)
+        ops.gemm(dx2_t, WEIGHTS.get(spec.fc2[0], dt, transpose=True), dact=spec.act, aux_in=pre, out_t=dpre)
+        dh = _empty((M, D), dt, x)
+        ops.gemm(dpre, WEIGHTS.get(spec.fc1[0], dt, transpose=True), out_t=dh)
+        del dpre
+        dx1 = torch.empty_like(x1)
+        dx1_t = _empty((M, D), dt, x) if dt != torch.float32 else dx1
+        ops.layernorm_bwd(dh, x1, spec.ln2[0], spec.eps, dres=dx2.view(M, D), dx32=dx1, dx_t=dx1_t if dt != torch.float32 else None)
+        da = dh                                                                     # reuse
+        ops.gemm(dx1_t, WEIGHTS.get(spec.proj[0], dt, transpose=True), out_t=da)
+        dqkv = _empty((M, 3 * D), dt, x)
+        ops.attn_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], a, da, lse, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], B, spec.heads, N, mask=spec.mask)
+        ops.gemm(dqkv, WEIGHTS.get(spec.qkv[0], dt, transpose=True), out_t=da)       # dh1 into the same buffer
+        dx = torch.empty_like(x)
+        dx_t = _empty((M, D), dt, x) if dt != torch.float32 else None
+        ops.layernorm_bwd(da, x.view(M, D), spec.ln1[0], spec.eps, dres=dx1, dx32=dx.view(M, D), dx_t=dx_t)
+        publish_t_copy(dx, dx_t)
+        return dx, None
+
+
+def vit_block(x, spec):
+    return VitBlockFn.apply(x, spec)
+
+
+# ================================================================================================ forward-only pieces
+@torch.no_grad()
+def post_ln_layer(x32, x_t, L, B, heads, P, keylen, eps=1e-12):
+    """HF BertLayer (post-LN), frozen: returns the new (fp32, T) residual pair.  P: dict of Parameters with the HF
+    names relative to `encoder.layer.{i}.`; q/k/v weights are used as one fused [3D, D] matrix."""
+    M, D = x32.shape
+    dt = x_t.dtype
+    qkv = _empty((M, 3 * D), dt, x32)
+    ops.gemm(x_t, P["_qkv_w"](dt), bias=P["_qkv_b"], out_t=qkv)
+    a = _empty((M, D), dt, x32)
+    ops.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], a, B, heads, L, mask="keypad", keylen=keylen)
+    s = torch.empty_like(x32)
+    ops.gemm(a, WEIGHTS.get(P["attention.output.dense.weight"], dt), bias=P["attention.output.dense.bias"], resid=x32, out32=s)
+    ops.layernorm_fwd(s, P["attention.output.LayerNorm.weight"], P["attention.output.LayerNorm.bias"], eps, y_t=x_t, y32=x32)
+    F = P["intermediate.dense.weight"].shape[0]
+    f = _empty((M, F), dt, x32)
+    ops.gemm(x_t, WEIGHTS.get(P["intermediate.dense.weight"], dt), bias=P["intermediate.dense.bias"], act="gelu", out_t=f)
+    ops.gemm(f, WEIGHTS.get(P["output.dense.weight"], dt), bias=P["output.dense.bias"], resid=x32, out32=s)
+    ops.layernorm_fwd(s, P["output.LayerNorm.weight"], P["output.LayerNorm.bias"], eps, y_t=x_t, y32=x32)
+    return x32, x_t
+
+
+class PatchEmbedFn(torch.autograd.Function):
+    """images [B,3,H,W] → tokens [B, 1+gh*gw, D] fp32 (= cat(cls, conv(x)) + pos); frozen → no backward."""
+
+    @staticmethod
+    def forward(ctx, images, conv_w, conv_b, cls, pos, patch):
+        dt = compute_dtype()
+        B, C, H, W = images.shape
+        G = (H // patch) * (W // patch)
+        D = conv_w.shape[0]
+        cols = _empty((B * G, C * patch * patch), dt, images)
+        ops.im2col(images.contiguous().float(), cols, patch)
+        x = torch.empty(B, G + 1, D, device=images.device, dtype=torch.float32)
+        pos2d = pos.detach().reshape(G + 1, D).contiguous()
+        ops.gemm(cols, WEIGHTS.get(conv_w, dt), bias=conv_b, resid=pos2d, resid_mod=G, resid_row_off=1, out_group=G, out32=x.view(-1, D))
+        ops.fill_cls(x, cls.detach().reshape(D).contiguous(), pos2d[0])
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        return None, None, None, None, None, None
+
+
+class ClsHeadFn(torch.autograd.Function):
+    """feat = LN(x[:,0]) @ Wᵀ  (final norm + CLS pool + bias-free projection); frozen weights, dgrad to x."""
+
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, eps, w_out_in):
+        B, N, D = x.shape
+        dt = compute_dtype()
+        x = x.contiguous()
+        h = _empty((B, D), dt, x)
+        ops.layernorm_fwd(x, ln_w, ln_b, eps, y_t=h, rows=B, ldx=N * D)
+        E = w_out_in.shape[0]
+        feat = torch.empty(B, E, device=x.device, dtype=torch.float32)
+        ops.gemm(h, WEIGHTS.get(w_out_in, dt), out32=feat)
+        ctx.save_for_backward(x, ln_w)
+        ctx.meta = (eps, w_out_in)
+        return feat
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        x, ln_w = ctx.saved_tensors
+        eps, w = ctx.meta
+        B, N, D = x.shape
+        dt = compute_dtype()
+        df = t_copy_of(dfeat.contiguous(), dt)
+        dh = _empty((B, D), dt, x)
+        ops.gemm(df, WEIGHTS.get(w, dt, transpose=True), out_t=dh)
+        dx = torch.zeros_like(x)
+        dx_t = torch.zeros(B * N, D, device=x.device, dtype=dt) if dt != torch.float32 else None
+        ops.layernorm_bwd(dh, x, ln_w, eps, dx32=dx, dx_t=dx_t, rows=B, ldx=N * D)
+        publish_t_copy(dx, dx_t)
+        return dx, None, None, None, None
+
+
+# ================================================================================================ op-level functions
+# Used where a block cannot take the fully fused frozen path (LoRA on the attention projections).
+class LayerNormFn(torch.autograd.Function):
+    """fp32 rows → T operand; frozen affine.  backward returns the LN branch of dx only (autograd adds the residual branch)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        D = x.shape[-1]
+        x2 = x.contiguous().view(-1, D)
+        y = _empty(x2.shape, compute_dtype(), x)
+        ops.layernorm_fwd(x2, w, b, eps, y_t=y)
+        ctx.save_for_backward(x2, w)
+        ctx.meta = (eps, x.shape)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        eps, shape = ctx.meta
+        dx = torch.empty_like(x2)
+        ops.layernorm_bwd(dy.contiguous().view(x2.shape), x2, w, eps, dx32=dx)
+        return dx.view(shape), None, None, None
+
+
+class AttentionFn(torch.autograd.Function):
+    """q,k,v: [M, D] T tensors (rows ordered (b, l), row stride shared) → [M, D]."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, B, H, L, mask):
+        out = _empty((B * L, H * 64), q.dtype, q)
+        need = any(ctx.needs_input_grad[:3])
+        lse = torch.empty(B, H, L, device=q.device, dtype=torch.float32) if need else None
+        ops.attn_fwd(q, k, v, out, B, H, L, lse=lse, mask=mask)
+        if need:
+            ctx.save_for_backward(q, k, v, out, lse)
+            ctx.meta = (B, H, L, mask)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, out, lse = ctx.saved_tensors
+        B, H, L, mask = ctx.meta
+        D = H * 64
+        dqkv = _empty((B * L, 3 * D), q.dtype, q)
+        ops.attn_bwd(q, k, v, out, dout.contiguous(), lse, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], B, H, L, mask=mask)
+        return dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], None, None, None, None
+
+
+class MlpHalfFn(torch.autograd.Function):
+    """x + fc2(act(fc1(LN2 x))) with frozen weights (second half of VitBlockFn)."""
+
+    @staticmethod
+    def forward(ctx, x1, spec):
+        shape = x1.shape
+        D = shape[-1]
+        x1 = x1.contiguous().view(-1, D)
+        M, dt = x1.shape[0], compute_dtype()
+        train = ctx.needs_input_grad[0]
+        h = _empty((M, D), dt, x1)
+        ops.layernorm_fwd(x1, spec.ln2[0], spec.ln2[1], spec.eps, y_t=h)
+        F = spec.fc1[0].shape[0]
+        f = _empty((M, F), dt, x1)
+        pre = _empty((M, F), dt, x1) if train else None
+        ops.gemm(h, WEIGHTS.get(spec.fc1[0], dt), bias=spec.fc1[1], act=spec.act, aux_out=pre, out_t=f)
+        x2 = torch.empty_like(x1)
+        ops.gemm(f, WEIGHTS.get(spec.fc2[0], dt), bias=spec.fc2[1], resid=x1, out32=x2)
+        if train:
+            ctx.save_for_backward(x1, pre)
+            ctx.meta = (spec, shape)
+        return x2.view(shape)
+
+    @staticmethod
+    def backward(ctx, dx2):
+        x1, pre = ctx.saved_tensors
+        spec, shape = ctx.meta
+        M, D = x1.shape
+        dt = pre.dtype
+        dx2 = dx2.contiguous().view(M, D)
+        dx2_t = t_copy_of(dx2, dt)
+        dpre = _empty(pre.shape, dt, x1)
+        ops.gemm(dx2_t, WEIGHTS.get(spec.fc2[0], dt, transpose=True), dact=spec.act, aux_in=pre, out_t=dpre)
+        dh = _empty((M, D), dt, x1)
+        ops.gemm(dpre, WEIGHTS.get(spec.fc1[0], dt, transpose=True), out_t=dh)
+        dx1 = torch.empty_like(x1)
+        ops.layernorm_bwd(dh, x1, spec.ln2[0], spec.eps, dres=dx2, dx32=dx1)
+        return dx1.view(shape), None
+
+
+LORA_PAD = 64     # rank is zero-padded to the GEMM's K granule; padded rows/columns contribute exactly 0
+
+
+class LoraLinearFn(torch.autograd.Function):
+    """y = x·Wᵀ + b + s·drop(x)·Aᵀ·Bᵀ (+ resid32)  in RANK form (never materialises B·A; reference lora.py:78-90 does).
+    x: [M, in] T.  Output: T, or fp32 when an fp32 residual is fused in.  W frozen; A, B (and the bias, reference quirk
+    SURVEY Appendix C-4) trainable."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, A, Bm, scaling, p_drop, resid32):
+        dt = x.dtype
+        M, K = x.shape
+        N = weight.shape[0]
+        r = A.shape[0]
+        y32 = torch.empty(M, N, device=x.device, dtype=torch.float32) if resid32 is not None else None
+        y_t = _empty((M, N), dt, x) if resid32 is None else None
+        ops.gemm(x, WEIGHTS.get(weight, dt), bias=bias, resid=resid32, out32=y32, out_t=y_t)
+        seed = 0
+        xd = x
+        if p_drop > 0:
+            seed = _next_seed()
+            xd = torch.empty_like(x)
+            ops.dropout(x, xd, p_drop, seed)
+        if r > 0:
+            t = _empty((M, LORA_PAD), dt, x)
+            ops.gemm(xd, WEIGHTS.get(A, dt, pad_rows_to=LORA_PAD), out_t=t)
+            bpad = WEIGHTS.get(Bm, dt, transpose=True, pad_rows_to=None)            # [r, N] → need [N, LORA_PAD]
+            bmat = _pad_cols(Bm, dt)
+            if y32 is not None:
+                ops.gemm(t, bmat, alpha=scaling, resid=y32, out32=y32)
+            else:
+                ops.gemm(t, bmat, alpha=scaling, resid_t=y_t, out_t=y_t)
+            del bpad
+        else:
+            t = None
+        ctx.save_for_backward(xd, t if t is not None else x.new_empty(0), weight, A, Bm)
+        ctx.meta = (scaling, p_drop, seed, r, bias is not None, resid32 is not None)
+        return y32 if y32 is not None else y_t
+
+    @staticmethod
+    def backward(ctx, dy):
+        xd, t, weight, A, Bm = ctx.saved_tensors
+        scaling, p_drop, seed, r, has_bias, has_resid = ctx.meta
+        dt = xd.dtype
+        M, K = xd.shape
+        N = weight.shape[0]
+        dy = dy.contiguous()
+        dy_t = t_copy_of(dy, dt) if dy.dtype == torch.float32 else dy
+        dx = _empty((M, K), dt, xd)
+        ops.gemm(dy_t, WEIGHTS.get(weight, dt, transpose=True), out_t=dx)
+        dA = dB = db = None
+        if r > 0:
+            q = _empty((M, LORA_PAD), dt, xd)
+            ops.gemm(dy_t, _pad_cols(Bm, dt, transpose=True), out_t=q)              # q = dy·B   [M, 64]
+            at = _pad_cols(A, dt, transpose=True, rows=True)                        # Aᵀ padded: [K, 64]
+            if p_drop > 0:
+                dxd = _empty((M, K), dt, xd)
+                ops.gemm(q, at, alpha=scaling, out_t=dxd)
+                ops.dropout(dxd, dx, p_drop, seed, accumulate=True)
+            else:
+                ops.gemm(q, at, alpha=scaling, resid_t=dx, out_t=dx)
+            gB = torch.zeros(N, LORA_PAD, device=xd.device, dtype=torch.float32)
+            ops.wgrad(dy_t, t, gB, alpha=scaling)
+            gA = torch.zeros(LORA_PAD, K, device=xd.device, dtype=torch.float32)
+            ops.wgrad(q, xd, gA, alpha=scaling)
+            dB, dA = gB[:, :r].contiguous(), gA[:r].contiguous()
+        if has_bias and ctx.needs_input_grad[2]:
+            db = torch.zeros(N, device=xd.device, dtype=torch.float32)
+            ops.colsum(dy_t, db)
+        return dx, None, db, dA, dB, None, None, (dy if has_resid else None)
+
+
+def _pad_cols(p, dt, transpose=False, rows=False):
+    """T copy of a LoRA factor zero-padded to LORA_PAD along its rank dimension.
+    B [out, r]  -> [out, 64] (transpose=False)  or  Bᵀ -> [64, out] (transpose=True)
+    A [r, in]   -> Aᵀ padded [in, 64] (transpose=True, rows=True)"""
+    src = p.detach().float()
+    if rows:                                   # A: rank is the row dim
+        if src.shape[0] < LORA_PAD:
+            src = torch.cat([src, src.new_zeros(LORA_PAD - src.shape[0], src.shape[1])], 0)
+        out = torch.empty(src.shape[1], LORA_PAD, device=src.device, dtype=dt)
+        ops.transpose_cast(src.contiguous(), out)
+        return out
+    if src.shape[1] < LORA_PAD:                # B: rank is the column dim
+        src = torch.cat([src, src.new_zeros(src.shape[0], LORA_PAD - src.shape[1])], 1)
+    src = src.contiguous()
+    if transpose:
+        out = torch.empty(LORA_PAD, src.shape[0], device=src.device, dtype=dt)
+        ops.transpose_cast(src, out)
+        return out
+    if dt == torch.float32:
+        return src
+    out = torch.empty(src.shape, device=src.device, dtype=dt)
+    ops.cast(src, out)
+    return out

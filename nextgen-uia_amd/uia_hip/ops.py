@@ -9,7 +9,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import AttnDesc, GemmDesc, UiaError, check, lib
+from ._lib import AttnDesc, GemmDesc, MonaSpatialDesc, UiaError, check, lib
 
 _ACT = {None: 0, "none": 0, "gelu": 1, "quick_gelu": 2, "relu": 3}
 
@@ -159,3 +159,107 @@ def embed(ids, table, pos, type0, out):
 def gather_rows(src, idx, dst):
     assert idx.dtype == torch.int64
     check(lib().uia_gather_rows(_stream(), idx.numel(), src.shape[-1], _p(src), _p(idx), _p(dst)), "uia_gather_rows")
+
+
+# ------------------------------------------------------------------------------------------- Mona
+_SPATIAL_KEYS = ("conv1_w", "conv1_b", "conv2_w", "conv2_b", "conv3_w", "conv3_b", "proj_w", "proj_b", "freq", "ne1_w", "ne1_b", "ne3_w", "ne3_b")
+
+
+def mona_pre_fwd(x, norm_w, norm_b, gamma, gammax, u, eps=1e-5):
+    D = gamma.numel()
+    check(lib().uia_mona_pre_fwd(_stream(), _code(u.dtype), x.numel() // D, D, _p(x), _p(norm_w), _p(norm_b), _p(gamma), _p(gammax), eps, _p(u)), "uia_mona_pre_fwd")
+
+
+def mona_pre_bwd(du, x, dy, norm_w, norm_b, gamma, gammax, dx32, dx_t, g_gamma, g_gammax, g_norm_w, g_norm_b, eps=1e-5):
+    D = gamma.numel()
+    check(lib().uia_mona_pre_bwd(_stream(), _code(du.dtype), x.numel() // D, D, _p(du), _p(x), _p(dy), _p(norm_w), _p(norm_b), _p(gamma), _p(gammax),
+                                 eps, _p(dx32), _p(dx_t), _p(g_gamma), _p(g_gammax), _p(g_norm_w), _p(g_norm_b)), "uia_mona_pre_bwd")
+
+
+def _spatial_desc(variant, B, h, w, t, params, p_drop, seed, keep_mask):
+    d = MonaSpatialDesc()
+    d.variant = _lib.MONA_VARIANTS[variant]
+    d.B, d.h, d.w, d.bott = B, h, w, t.shape[-1]
+    d.t = _p(t)
+    for k in _SPATIAL_KEYS:
+        v = params.get(k)
+        if v is not None:
+            assert v.dtype == torch.float32 and v.is_contiguous()
+            setattr(d, k, _p(v))
+    d.p_drop, d.seed = float(p_drop), int(seed) & 0xFFFFFFFFFFFFFFFF
+    if keep_mask is not None:
+        assert keep_mask.dtype == torch.uint8 and keep_mask.is_contiguous()
+        d.keep_mask = _p(keep_mask)
+    return d
+
+
+def mona_spatial_fwd(variant, B, h, w, t, params, d_out, p_drop=0.0, seed=0, keep_mask=None):
+    """params: dict with keys of _SPATIAL_KEYS (fp32, contiguous; absent ones for variants without them)."""
+    d = _spatial_desc(variant, B, h, w, t, params, p_drop, seed, keep_mask)
+    d.d = _p(d_out)
+    check(lib().uia_mona_spatial_fwd(_stream(), _code(t.dtype), C.byref(d)), "uia_mona_spatial_fwd")
+
+
+def mona_spatial_bwd(variant, B, h, w, t, params, dd, dt, grads, p_drop=0.0, seed=0, keep_mask=None):
+    """grads: dict keyed like params with fp32 accumulators (caller-zeroed)."""
+    d = _spatial_desc(variant, B, h, w, t, params, p_drop, seed, keep_mask)
+    d.dd, d.dt = _p(dd), _p(dt)
+    for k in _SPATIAL_KEYS:
+        v = grads.get(k)
+        if v is not None:
+            setattr(d, "g_" + k, _p(v))
+    check(lib().uia_mona_spatial_bwd(_stream(), _code(t.dtype), C.byref(d)), "uia_mona_spatial_bwd")
+
+
+# ------------------------------------------------------------------------------------------- loss / optimiser / comm
+def infonce(img, txt, temperature, grad_scale=1.0, want_grads=True):
+    """Returns (loss[1] fp32 device tensor, dimg, dtxt).  img/txt fp32 [B,E] contiguous."""
+    assert img.dtype == torch.float32 and txt.dtype == torch.float32 and img.is_contiguous() and txt.is_contiguous()
+    B, E = img.shape
+    nbytes = lib().uia_infonce_workspace_bytes(B, E)
+    ws = torch.empty(nbytes // 4, device=img.device, dtype=torch.float32)
+    loss = torch.empty(1, device=img.device, dtype=torch.float32)
+    dimg = torch.empty_like(img) if want_grads else None
+    dtxt = torch.empty_like(txt) if want_grads else None
+    check(lib().uia_infonce_fwd_bwd(_stream(), B, E, _p(img), _p(txt), 1.0 / temperature, grad_scale, _p(loss), _p(dimg), _p(dtxt), _p(ws), nbytes), "uia_infonce_fwd_bwd")
+    return loss, dimg, dtxt
+
+
+def adamw_clip_step(p, g, m, v, lr, betas, eps, weight_decay, max_norm, step, grad_scale, ws2):
+    for t in (p, g, m, v):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == p.numel()
+    check(lib().uia_adamw_clip_step(_stream(), p.numel(), _p(p), _p(g), _p(m), _p(v), lr, betas[0], betas[1], eps, weight_decay, max_norm, step, grad_scale, _p(ws2)), "uia_adamw_clip_step")
+
+
+def comm_unique_id():
+    n = lib().uia_comm_unique_id_bytes()
+    buf = C.create_string_buffer(n)
+    check(lib().uia_comm_get_unique_id(buf, n), "uia_comm_get_unique_id")
+    return bytes(buf.raw)
+
+
+def comm_init(rank, world, uid):
+    check(lib().uia_comm_init(rank, world, C.c_char_p(uid), len(uid)), "uia_comm_init")
+
+
+def comm_world():
+    return lib().uia_comm_world()
+
+
+def allreduce_sum(buf):
+    check(lib().uia_allreduce_sum(_stream(), _code(buf.dtype), _p(buf), buf.numel()), "uia_allreduce_sum")
+
+
+def comm_destroy():
+    check(lib().uia_comm_destroy(), "uia_comm_destroy")
+
+
+def dropout(src, dst, p, seed, accumulate=False):
+    assert src.dtype == dst.dtype and src.is_contiguous() and dst.is_contiguous() and src.numel() == dst.numel()
+    check(lib().uia_dropout(_stream(), _code(src.dtype), src.numel(), _p(src), _p(dst), p, int(seed) & 0xFFFFFFFFFFFFFFFF, int(accumulate)), "uia_dropout")
+
+
+def colsum(a, out):
+    lda = _rowmajor(a, "a")
+    assert out.dtype == torch.float32 and out.numel() == a.shape[1]
+    check(lib().uia_colsum(_stream(), _code(a.dtype), a.shape[0], a.shape[1], _p(a), lda, _p(out)), "uia_colsum")

@@ -1,0 +1,214 @@
+"""-m gpu: the product modules (HIP path, through the C ABI) against the CPU oracle on identical seeded inputs.
+Tolerances (north_star): fp32 mode 1e-3 relative, bf16 mode 1e-2 relative, both measured as max|Δ| / max|ref|
+per tensor; parameter gradients in bf16 mode get 3e-2 (they are sums of bf16-rounded products over all tokens)."""
+import math
+
+import pytest
+import torch
+
+from oracle import lora_ref, losses_ref, mona_ref, text_ref, train_ref, vit_ref
+
+pytestmark = pytest.mark.gpu
+VARIANTS = ("baseline", "noise_aware", "freq_enhanced", "hybrid")
+DT = {"fp32": torch.float32, "bf16": torch.bfloat16}
+TOL = {"fp32": 1e-3, "bf16": 1e-2}
+GTOL = {"fp32": 1e-3, "bf16": 3e-2}
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+@pytest.fixture(autouse=True)
+def _mode():
+    from uia_hip import functional as UF
+    yield
+    UF.set_compute_dtype(torch.bfloat16)
+    UF.clear_t_copies()
+
+
+def randomize(module, gen, scale=0.2):
+    with torch.no_grad():
+        for k, p in module.named_parameters():
+            if k.endswith(("norm.weight", "gammax", "freq_filter")) or ("norm" in k.lower() and k.endswith("weight")) or "LayerNorm.weight" in k:
+                p.copy_(1.0 + 0.3 * torch.randn(p.shape, generator=gen))
+            elif k.endswith("gamma"):
+                p.copy_(0.5 * torch.randn(p.shape, generator=gen))
+            else:
+                p.copy_(scale * torch.randn(p.shape, generator=gen))
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("drop", [False, True])
+def test_mona_module_vs_oracle(mode, variant, drop):
+    from uia_hip import functional as UF
+    from src.adapters import mona as M
+    UF.set_compute_dtype(DT[mode])
+    g = torch.Generator().manual_seed(11)
+    B, hw, D = 3, (5, 4), 128
+    N = 1 + hw[0] * hw[1]
+    mod = M._VARIANTS[variant](D, 64)
+    randomize(mod, g)
+    P = {k: v.detach().clone().requires_grad_(True) for k, v in mod.named_parameters()}
+    x = torch.randn(B, N, D, generator=g) * 1.5
+    dy = torch.randn(B, N, D, generator=g)
+    keep = (torch.rand(B, N, 64, generator=g) > 0.1) if drop else None
+    xr = x.clone().requires_grad_(True)
+    yr = mona_ref.forward(xr, P, variant, hw, keep_mask=None if keep is None else keep.float(), p_drop=0.1)
+    yr.backward(dy)
+
+    mod = mod.to(dev())
+    mod.train(drop)
+    mod.keep_mask = keep.to(torch.uint8).to(dev()).contiguous() if drop else None
+    xg = x.to(dev()).requires_grad_(True)
+    y = mod(xg.permute(1, 0, 2), hw).permute(1, 0, 2)              # sequence-first API of the reference
+    y.backward(dy.to(dev()))
+    assert rel(y, yr) < TOL[mode]
+    assert rel(xg.grad, xr.grad) < TOL[mode]
+    for k, p in mod.named_parameters():
+        assert rel(p.grad, P[k].grad) < GTOL[mode], k
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_infonce_module_vs_oracle(mode):
+    from src.losses import InfoNCELoss
+    g = torch.Generator().manual_seed(5)
+    I, T = torch.randn(24, 64, generator=g), torch.randn(24, 64, generator=g) * 3
+    Ir, Tr = I.clone().requires_grad_(True), T.clone().requires_grad_(True)
+    lr_ = losses_ref.info_nce(Ir, Tr, 0.07)
+    lr_.backward()
+    Ig, Tg = I.to(dev()).requires_grad_(True), T.to(dev()).requires_grad_(True)
+    loss = InfoNCELoss(0.07)(Ig, Tg)
+    (2.0 * loss).backward()
+    assert abs(float(loss) - float(lr_)) < 1e-4 * abs(float(lr_))
+    assert rel(Ig.grad, 2 * Ir.grad) < 1e-4 and rel(Tg.grad, 2 * Tr.grad) < 1e-4
+
+
+TOY = dict(embed_dim=64, vision_cfg=dict(img_size=32, patch_size=8, embed_dim=128, depth=3, num_heads=2),
+           text_cfg=dict(vocab_size=120, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                         max_position_embeddings=40))
+
+
+def toy_batch(g, B=6, L=24):
+    images = torch.rand(B, 3, 32, 32, generator=g)
+    ids = torch.zeros(B, L, dtype=torch.long)
+    for b in range(B):
+        n = int(torch.randint(4, L, (1,), generator=g))
+        ids[b, :n] = torch.randint(5, 120, (n,), generator=g)
+        ids[b, 0], ids[b, n - 1] = 2, 3
+    return images, ids
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("variant", ["freq_enhanced", "hybrid"])
+def test_biomedclip_mona_train_step_vs_oracle(mode, variant):
+    """encode_image / encode_text / InfoNCE / backward of the BiomedCLIP-shaped model with Mona in every block."""
+    from uia_hip import functional as UF
+    from src.adapters import inject_mona_variant_to_open_clip
+    from src.losses import InfoNCELoss
+    from src.third_party.biomedclip.model import create_biomedclip
+    UF.set_compute_dtype(DT[mode])
+    g = torch.Generator().manual_seed(3)
+    model = create_biomedclip(config=TOY, seed=1)
+    randomize(model, g, 0.08)
+    for p in model.parameters():
+        p.requires_grad_(False)
+    inject_mona_variant_to_open_clip(model, variant=variant, bottleneck_dim=64)
+    randomize(torch.nn.ModuleList([b.mona for b in model.visual.trunk.blocks]), g, 0.15)
+    for k, p in model.named_parameters():
+        p.requires_grad_("mona" in k)
+    model.eval()
+    images, ids = toy_batch(g)
+    P = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    trainable = [k for k in P if "mona" in k]
+    mona = dict(variant=variant, hw=(4, 4))
+    gref, lref = train_ref.grads_of(lambda Pq, im, tk: train_ref.biomedclip_loss(Pq, im, tk, mona=mona), P, trainable, [(images, ids)])
+    fref = vit_ref.timm_vit_forward(images, P, heads=2, mona=mona)
+    tref = text_ref.bert_text_forward(ids, P, heads=2)
+
+    model = model.to(dev())
+    fi = model.encode_image(images.to(dev()))
+    ft = model.encode_text(ids.to(dev()))
+    loss = InfoNCELoss(0.07)(fi, ft)
+    loss.backward()
+    assert rel(fi, fref) < TOL[mode], "image features"
+    assert rel(ft, tref) < TOL[mode], "text features"
+    assert abs(float(loss) - lref) < (2e-3 if mode == "fp32" else 3e-2) * max(1.0, abs(lref))
+    worst = max(rel(p.grad, gref[k]) for k, p in model.named_parameters() if "mona" in k)
+    assert worst < GTOL[mode], f"worst relative gradient error {worst}"
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_biomedclip_lora_vs_oracle(mode):
+    from uia_hip import functional as UF
+    from src.adapters import inject_lora_to_biomedclip
+    from src.third_party.biomedclip.model import create_biomedclip
+    UF.set_compute_dtype(DT[mode])
+    g = torch.Generator().manual_seed(9)
+    model = create_biomedclip(config=TOY, seed=2)
+    randomize(model, g, 0.08)
+    for p in model.parameters():
+        p.requires_grad_(False)
+    inject_lora_to_biomedclip(model, lora_r=8, lora_alpha=16, lora_dropout=0.0)
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            if "lora" in k:
+                p.copy_(0.2 * torch.randn(p.shape, generator=g))
+    for k, p in model.named_parameters():
+        if "lora" in k:
+            p.requires_grad_(True)
+    model.eval()
+    images, _ = toy_batch(g)
+    P = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    trainable = [k for k, p in model.named_parameters() if p.requires_grad]          # lora factors + the (quirk) trainable biases
+    assert any(k.endswith("attn.qkv.bias") for k in trainable)
+    leaves = {k: P[k].clone().requires_grad_(True) for k in trainable}
+    Pq = dict(P); Pq.update(leaves)
+    fr = vit_ref.timm_vit_forward(images, Pq, heads=2, lora=dict(r=8, alpha=16))
+    fr.square().sum().backward()
+    model = model.to(dev())
+    fi = model.encode_image(images.to(dev()))
+    fi.square().sum().backward()
+    assert rel(fi, fr) < TOL[mode]
+    for k, p in model.named_parameters():
+        if p.requires_grad:
+            assert rel(p.grad, leaves[k].grad) < GTOL[mode], k
+
+
+def test_lora_zero_init_is_identity():
+    """SURVEY §4 invariant: LoRA injection at init (B = 0) leaves encode_image bit-identical."""
+    from uia_hip import functional as UF
+    from src.adapters import inject_lora_to_biomedclip
+    from src.third_party.biomedclip.model import create_biomedclip
+    UF.set_compute_dtype(torch.float32)
+    model = create_biomedclip(config=TOY, seed=4).to(dev()).eval()
+    images = torch.rand(4, 3, 32, 32, device=dev())
+    with torch.no_grad():
+        a = model.encode_image(images)
+        inject_lora_to_biomedclip(model, lora_r=8, lora_alpha=16, lora_dropout=0.1)
+        model.eval()
+        b = model.encode_image(images)
+    assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("max_norm", [1.0, 0.0])
+def test_adamw_clip_step_vs_oracle(max_norm):
+    from uia_hip import ops
+    g = torch.Generator().manual_seed(1)
+    n = 10007 * 4
+    p, gr = torch.randn(n, generator=g), torch.randn(n, generator=g) * 0.05
+    m, v = torch.zeros(n), torch.zeros(n)
+    pr, mr, vr = {"w": p.clone()}, {"w": m.clone()}, {"w": v.clone()}
+    pg, gg, mg, vg = (t.to(dev()) for t in (p, gr, m, v))
+    ws = torch.zeros(2, device=dev())
+    for step in (1, 2, 3):
+        total = train_ref.clip_and_adamw(pr, {"w": gr.clone() * 0.5}, mr, vr, step, 1e-3, (0.9, 0.95), 1e-8, 0.01, max_norm)
+        ops.adamw_clip_step(pg, gg, mg, vg, 1e-3, (0.9, 0.95), 1e-8, 0.01, max_norm, step, 0.5, ws)
+        assert abs(math.sqrt(float(ws[0])) - total) < 1e-4 * total
+    assert rel(pg, pr["w"]) < 1e-5 and rel(mg, mr["w"]) < 1e-5 and rel(vg, vr["w"]) < 1e-5
