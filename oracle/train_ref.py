@@ -13,9 +13,9 @@ import torch
 from . import losses_ref, vit_ref, text_ref
 
 
-def biomedclip_loss(P, images, ids, mona=None, lora=None, temperature=0.07):
-    img = vit_ref.timm_vit_forward(images, P, mona=mona, lora=lora)
-    txt = text_ref.bert_text_forward(ids, P)
+def biomedclip_loss(P, images, ids, mona=None, lora=None, temperature=0.07, heads=12, text_heads=12):
+    img = vit_ref.timm_vit_forward(images, P, heads=heads, mona=mona, lora=lora)
+    txt = text_ref.bert_text_forward(ids, P, heads=text_heads)
     return losses_ref.info_nce(img, txt, temperature)
 
 
