@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py — the headline measurement of BASELINE.json:
+
+    images/sec, forward + backward + optimiser, BiomedCLIP ViT-B/16 + Mona fine-tune step,
+    synthetic 224x224 image-text pairs, bs = 256 per GPU, bf16 operands  (BASELINE configs[1]; configs[2] at N=8)
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One process per GPU; every rank runs the same per-GPU workload (weak scaling) on its own synthetic batch and the
+flat adapter-gradient buffer (1.34 M fp32) is all-reduced once per step with RCCL.  A "step" = encode_image (ViT-B/16,
+12 blocks each followed by a Mona adapter) + encode_text (frozen BERT-base, dense L = 256, no padded-token skipping) +
+InfoNCE + backward through blocks 11..1 and all 12 adapters + gradient clipping + AdamW.  Inputs are resident in HBM
+before the timed region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "nextgen-uia_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+# algorithmic work per image-caption pair: 69.95 GF image tower fwd+bwd (+Mona) + 45.90 GF text fwd
+GFLOP_PER_PAIR = 115.86
+PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="pairs per GPU")
+    ap.add_argument("--variant", default="freq_enhanced", help="Mona variant (reference default: biomedclip/finetune.py:76)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    return ap.parse_args()
+
+
+def synthetic_batch(batch, rank, device):
+    import torch
+    g = torch.Generator().manual_seed(1 + rank)                     # --seed default 1 (finetune.py:93), offset per rank
+    images = torch.rand(batch, 3, 224, 224, generator=g)            # U[0,1), no mean/std normalisation (datasets/finetune.py:17-24)
+    ids = torch.zeros(batch, 256, dtype=torch.long)
+    lens = torch.randint(24, 129, (batch,), generator=g)
+    for b in range(batch):
+        n = int(lens[b])
+        ids[b, 1:n - 1] = torch.randint(1000, 30000, (n - 2,), generator=g)
+        ids[b, 0], ids[b, n - 1] = 2, 3                              # [CLS] / [SEP]; pad = 0
+    return images.to(device), ids.to(device)
+
+
+def cpu_baseline(state, variant, batch, steps):
+    """The oracle (CPU restatement of the reference path) timed on this host's cores: the reported CPU baseline."""
+    import torch
+    from oracle import train_ref
+    torch.set_num_threads(min(16, os.cpu_count()))                  # more threads than this only adds contention at micro-batch 8
+    g = torch.Generator().manual_seed(1)
+    images = torch.rand(batch, 3, 224, 224, generator=g)
+    ids = torch.zeros(batch, 256, dtype=torch.long)
+    for b in range(batch):
+        n = 24 + (b * 13) % 105
+        ids[b, 1:n - 1] = torch.randint(1000, 30000, (n - 2,), generator=g)
+        ids[b, 0], ids[b, n - 1] = 2, 3
+    names = [k for k in state if "mona" in k]
+    mona = dict(variant=variant, hw=(14, 14))
+    times, budget = [], 30.0                                        # bounded sample: stop once ~30 s of CPU work are spent
+    for i in range(steps + 1):
+        t0 = time.perf_counter()
+        train_ref.grads_of(lambda Pq, im, tk: train_ref.biomedclip_loss(Pq, im, tk, mona=mona), state, names, [(images, ids)])
+        times.append(time.perf_counter() - t0)
+        if sum(times) > budget:
+            break
+    timed = times[1:] if len(times) > 1 else times
+    dt = sum(timed) / len(timed)
+    return {"value": round(batch / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{len(timed)} fwd+bwd step(s){' after 1 warm-up' if len(times) > 1 else ' (no warm-up: first step exceeded the 30 s budget)'} "
+                      f"of the same model at micro-batch {batch}, fp32, oracle/train_ref.py",
+            "s_per_step": round(dt, 3)}
+
+
+def main():
+    args = parse()
+    import torch
+    from uia_hip import functional as UF
+    from uia_hip import ops
+    from uia_hip.engine import FlatAdapterOptimizer, contrastive_step, init_data_parallel
+    from src.adapters import inject_mona_variant_to_open_clip
+    from src.losses import InfoNCELoss
+    from src.third_party.biomedclip.model import create_biomedclip
+
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    UF.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+
+    model = create_biomedclip(seed=0)                                # same weights on every rank (random init: no network for checkpoints)
+    for p in model.parameters():
+        p.requires_grad_(False)
+    inject_mona_variant_to_open_clip(model, variant=args.variant, bottleneck_dim=64)
+    for k, p in model.named_parameters():
+        p.requires_grad_("mona" in k.lower())                        # finetune.py:173-175
+    cpu_state = {k: v.detach().clone() for k, v in model.state_dict().items()} if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
+    model = model.to(device)
+    model.train()                                                    # Mona dropout p=0.1 active (finetune.py:218)
+    opt = FlatAdapterOptimizer([(k, p) for k, p in model.named_parameters() if p.requires_grad], lr=1e-4, betas=(0.9, 0.95),
+                               weight_decay=0.01, max_norm=1.0)
+    init_data_parallel(opt)
+    criterion = InfoNCELoss(0.07)
+    images, ids = synthetic_batch(args.batch, rank, device)
+    UF.set_dropout_seed(1234 + rank)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    loss = None
+    for _ in range(args.warmup):
+        loss = contrastive_step(model, criterion, opt, images, ids)
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        if s == args.steps - 1:
+            ops.GEMM_PROFILE = []                                    # live per-launch events on the last timed step
+        loss = contrastive_step(model, criterion, opt, images, ids)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t[0])
+    final_loss = float(loss)
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = world * args.batch * args.steps / elapsed
+        # ---- roofline of the dominant kernel: the 256x256-tile bf16 GEMM instantiation (QKV / fc1 / their dgrads)
+        by_cfg = {}
+        for e0, e1, M, N, K, dt, cfg in prof:
+            d = by_cfg.setdefault(cfg, [0.0, 0.0, 0])
+            d[0] += e0.elapsed_time(e1) * 1e-3
+            d[1] += 2.0 * M * N * K
+            d[2] += 1
+        dom = max(by_cfg, key=lambda c: by_cfg[c][0]) if by_cfg else None
+        roof = None
+        if dom is not None:
+            tsec, flops, n = by_cfg[dom]
+            achieved = flops / tsec * 1e-12
+            peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
+            roof = {"bound": "mfma", "kernel": f"gemm_tn_kernel<{args.dtype}, tile cfg {dom}>", "achieved": round(achieved, 1), "peak": peak,
+                    "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None, "launches_per_step": n,
+                    "avg_launch_us": round(tsec / n * 1e6, 2), "gemm_share_of_step": round(sum(v[0] for v in by_cfg.values()) / (ms * 1e-3), 3),
+                    "whole_step_frac_of_peak": round(value / world * GFLOP_PER_PAIR * 1e-3 / peak, 4)}
+        out = {"metric": "images/sec fwd+bwd BiomedCLIP+Mona bs=256", "value": round(value, 2), "unit": "images/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+               "config": {"workload": "BiomedCLIP ViT-B/16 + Mona fine-tune step (BASELINE configs[1]): image tower fwd+bwd with 12 Mona adapters, "
+                                      "frozen BERT-base text tower fwd (dense L=256), InfoNCE, clip+AdamW; random-init weights",
+                          "mona_variant": args.variant, "batch_per_gpu": args.batch, "global_batch": args.batch * world, "image": "3x224x224",
+                          "text_len": 256, "parallelism": f"dp{world}", "mona_dropout": 0.1, "bert_dropout_emulated": False,
+                          "gflop_per_pair_algorithmic": GFLOP_PER_PAIR},
+               "loss": round(final_loss, 5), "roofline": roof}
+        if cpu_state is not None:
+            out["cpu_baseline"] = cpu_baseline(cpu_state, args.variant, args.cpu_batch, args.cpu_steps)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        ops.comm_destroy()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -7,6 +7,8 @@ wrapper raises if handed a non-CUDA tensor.
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- must come first: libuia_hip.so has to bind to the SAME libamdhip64 that PyTorch loaded
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libuia_hip.so")
 

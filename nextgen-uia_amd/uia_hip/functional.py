@@ -75,11 +75,18 @@ class WeightCache:
 
     def __init__(self):
         self._c = {}
+        self.epoch = 0
+
+    def bump(self):
+        """Trainable parameters were updated behind autograd's back (fused optimiser kernel)."""
+        self.epoch += 1
+        if len(self._c) > 8192:
+            self._c = {k: v for k, v in self._c.items() if v[1]() is not None}
 
     def get(self, p, dt, transpose=False, pad_rows_to=None):
         key = (id(p), dt, transpose, pad_rows_to)
         hit = self._c.get(key)
-        if hit is not None and hit[0] == p._version and hit[1]() is p and hit[2].device == p.device:
+        if hit is not None and hit[0] == p._version and hit[1]() is p and hit[2].device == p.device and (not p.requires_grad or hit[3] == self.epoch):
             return hit[2]
         src = p.detach()
         if src.dim() != 2:
@@ -95,7 +102,7 @@ class WeightCache:
         else:
             out = torch.empty(src.shape, device=src.device, dtype=dt)
             ops.cast(src, out)
-        self._c[key] = (p._version, weakref.ref(p), out)
+        self._c[key] = (p._version, weakref.ref(p), out, self.epoch)
         return out
 
 

@@ -13,6 +13,21 @@ from ._lib import AttnDesc, GemmDesc, MonaSpatialDesc, UiaError, check, lib
 
 _ACT = {None: 0, "none": 0, "gelu": 1, "quick_gelu": 2, "relu": 3}
 
+# When set to a list, every uia_gemm launch is bracketed by two events on the launch stream and
+# (start, end, M, N, K, dtype, tile_cfg) is appended: bench.py's live per-kernel roofline measurement.
+GEMM_PROFILE = None
+
+
+def auto_tile_cfg(M, N):
+    """Mirror of launch_typed() in csrc/gemm.hip (which kernel instantiation a shape runs on)."""
+    if N <= 64:
+        return 4
+    if M <= 2048:
+        return 3
+    if N % 256 == 0 and N >= 2048:
+        return 1
+    return 2
+
 
 def _code(dt):
     if dt == torch.bfloat16:
@@ -71,6 +86,13 @@ def gemm(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None, res
         d.outT, d.ldo = _p(out_t), _rowmajor(out_t, "out_t")
     if out32 is not None:
         d.out32, d.ldo32 = _p(out32), _rowmajor(out32, "out32")
+    if GEMM_PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib().uia_gemm(_stream(), _code(a.dtype), C.byref(d), tile_cfg), "uia_gemm")
+        e1.record()
+        GEMM_PROFILE.append((e0, e1, d.M, d.N, d.K, a.dtype, tile_cfg or auto_tile_cfg(d.M, d.N)))
+        return
     check(lib().uia_gemm(_stream(), _code(a.dtype), C.byref(d), tile_cfg), "uia_gemm")
 
 
