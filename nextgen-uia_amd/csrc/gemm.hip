@@ -25,6 +25,10 @@
 #include "uia_common.h"
 #include "uia_kernels.h"
 
+#ifdef UIA_GEMM_STAMPS
+__device__ unsigned long long* uia_stamp_buf = nullptr;   // diagnostic build only (tests/test_gemm_stamps)
+#endif
+
 namespace {
 
 template <typename T> struct MfmaTile;
@@ -49,17 +53,19 @@ template <> struct MfmaTile<float> {
     }
 };
 
+template <bool FAST>
 __device__ __forceinline__ float apply_act(float x, int act) {
     switch (act) {
-        case UIA_ACT_GELU: return gelu_erf(x);
+        case UIA_ACT_GELU: return gelu_erf_t<FAST>(x);
         case UIA_ACT_QUICKGELU: return quick_gelu(x);
         case UIA_ACT_RELU: return fmaxf(x, 0.0f);
         default: return x;
     }
 }
+template <bool FAST>
 __device__ __forceinline__ float apply_dact(float pre, int act) {
     switch (act) {
-        case UIA_ACT_GELU: return dgelu_erf(pre);
+        case UIA_ACT_GELU: return dgelu_erf_t<FAST>(pre);
         case UIA_ACT_QUICKGELU: return dquick_gelu(pre);
         case UIA_ACT_RELU: return pre > 0.0f ? 1.0f : 0.0f;
         default: return 1.0f;
@@ -69,6 +75,134 @@ __device__ __forceinline__ float apply_dact(float pre, int act) {
 __device__ __forceinline__ void glds16(const char* gsrc, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <typename T, int MT, int NT, int WTM, int WTN>
+__device__ __forceinline__ void gemm_epilogue(const UiaGemmParams& p, f32x4 (&acc)[MT][NT], int m0, int n0, int wm, int wn, int li, int g) {
+    // ---- epilogue: lane owns row m, columns nb .. nb+4NT-1 (nb multiple of 16)
+    const int nb = n0 + wn * WTN + g * (4 * NT);
+    T* outT = (T*)p.outT;
+    const T* aux_in = (const T*)p.aux_in;
+    T* aux_out = (T*)p.aux_out;
+    const T* residT = (const T*)p.residT;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int m = m0 + wm * WTM + 16 * i + li;
+        if (m >= p.M) continue;
+        const size_t orow = p.out_group > 0 ? (size_t)(m + m / p.out_group + 1) : (size_t)m;
+        const size_t rrow = p.resid_mod > 0 ? (size_t)(m % p.resid_mod + p.resid_row_off) : orow;
+#pragma unroll
+        for (int jj = 0; jj < NT; jj += 2) {
+            const int n = nb + 4 * jj;
+            if (n >= p.N) continue;   // N is a multiple of 8 (checked on the host)
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = acc[i][jj][e] * p.alpha; v[4 + e] = acc[i][jj + 1][e] * p.alpha; }
+            if (p.bias) {
+                float b[8];
+                load8(p.bias + n, b);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += b[e];
+            }
+            if (aux_out) store8(aux_out + orow * p.ldaux_out + n, v);
+            if (p.act) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = apply_act<sizeof(T) == 2>(v[e], p.act);
+            }
+            if (p.dact) {
+                float a[8];
+                load8(aux_in + orow * p.ldaux_in + n, a);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= apply_dact<sizeof(T) == 2>(a[e], p.dact);
+            }
+            if (p.resid) {
+                float r[8];
+                load8(p.resid + rrow * p.ldr + n, r);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += r[e];
+            }
+            if (residT) {
+                float r[8];
+                load8(residT + orow * p.ldrT + n, r);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += r[e];
+            }
+            if (p.out32) store8(p.out32 + orow * p.ldo32 + n, v);
+            if (outT) store8(outT + orow * p.ldo + n, v);
+        }
+    }
+}
+
+
+// Epilogue of the ping-pong kernel: every wave bounces its accumulators, 16 rows at a time, through a private LDS
+// patch so that the bias/residual/aux loads and the C stores are issued with one lane per 8 consecutive columns
+// and consecutive lanes on consecutive 16/32-byte pieces of a row — whole 128/256-byte row segments per wave
+// instruction instead of 16 rows × 16-byte pieces.  (Measured before: 17K-49K cycles per 256×256 tile, as long as
+// the K loop itself; the MFMA-layout stores were issue-bound.)
+template <typename T, int MT, int NT, int WTM, int WTN>
+__device__ __forceinline__ void gemm_epilogue_lds(const UiaGemmParams& p, f32x4 (&acc)[MT][NT], char* smem, int wave, int lane, int m0, int n0,
+                                                  int wm, int wn) {
+    constexpr int LDW = WTN + 4;                    // floats per staged row (+4 keeps the b128 writes conflict-free)
+    constexpr int LPR = WTN / 8;                    // lanes per row when reading back
+    constexpr int RPP = 64 / LPR;                   // rows per read pass
+    float* stg = (float*)(smem + wave * (16 * LDW * 4));
+    const int li = lane & 15, g = lane >> 4;
+    const int rr = lane / LPR, rc = (lane % LPR) * 8;
+    const int n = n0 + wn * WTN + rc;
+    T* outT = (T*)p.outT;
+    const T* aux_in = (const T*)p.aux_in;
+    T* aux_out = (T*)p.aux_out;
+    const T* residT = (const T*)p.residT;
+    float bias[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias[e] = 0.f;
+    if (p.bias && n < p.N) load8(p.bias + n, bias);
+#pragma clang loop unroll(full)
+    for (int i = 0; i < MT; ++i) {
+#pragma clang loop unroll(full)
+        for (int j = 0; j < NT; ++j) *(f32x4*)(stg + li * LDW + g * (4 * NT) + 4 * j) = acc[i][j];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int ps = 0; ps < 16 / RPP; ++ps) {
+            const int row = ps * RPP + rr;
+            const f32x4 lo = *(const f32x4*)(stg + row * LDW + rc), hi = *(const f32x4*)(stg + row * LDW + rc + 4);
+            const int m = m0 + wm * WTM + 16 * i + row;
+            if (m < p.M && n < p.N) {
+                float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                const size_t orow = p.out_group > 0 ? (size_t)(m + m / p.out_group + 1) : (size_t)m;
+                const size_t rrow = p.resid_mod > 0 ? (size_t)(m % p.resid_mod + p.resid_row_off) : orow;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], p.alpha, bias[e]);
+                if (aux_out) store8(aux_out + orow * p.ldaux_out + n, v);
+                if (p.act) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = apply_act<sizeof(T) == 2>(v[e], p.act);
+                }
+                if (p.dact) {
+                    float a[8];
+                    load8(aux_in + orow * p.ldaux_in + n, a);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] *= apply_dact<sizeof(T) == 2>(a[e], p.dact);
+                }
+                if (p.resid) {
+                    float r[8];
+                    load8(p.resid + rrow * p.ldr + n, r);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += r[e];
+                }
+                if (residT) {
+                    float r[8];
+                    load8(residT + orow * p.ldrT + n, r);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += r[e];
+                }
+                if (p.out32) store8(p.out32 + orow * p.ldo32 + n, v);
+                if (outT) store8(outT + orow * p.ldo + n, v);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
 }
 
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
@@ -169,58 +303,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_tn_kernel(const U
         }
     }
 
-    // ---- epilogue: lane owns row m, columns nb .. nb+4NT-1 (nb multiple of 16)
-    const int nb = n0 + wn * WTN + g * (4 * NT);
-    T* outT = (T*)p.outT;
-    const T* aux_in = (const T*)p.aux_in;
-    T* aux_out = (T*)p.aux_out;
-    const T* residT = (const T*)p.residT;
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        const int m = m0 + wm * WTM + 16 * i + li;
-        if (m >= p.M) continue;
-        const size_t orow = p.out_group > 0 ? (size_t)(m + m / p.out_group + 1) : (size_t)m;
-        const size_t rrow = p.resid_mod > 0 ? (size_t)(m % p.resid_mod + p.resid_row_off) : orow;
-#pragma unroll
-        for (int jj = 0; jj < NT; jj += 2) {
-            const int n = nb + 4 * jj;
-            if (n >= p.N) continue;   // N is a multiple of 8 (checked on the host)
-            float v[8];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] = acc[i][jj][e] * p.alpha; v[4 + e] = acc[i][jj + 1][e] * p.alpha; }
-            if (p.bias) {
-                float b[8];
-                load8(p.bias + n, b);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += b[e];
-            }
-            if (aux_out) store8(aux_out + orow * p.ldaux_out + n, v);
-            if (p.act) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e], p.act);
-            }
-            if (p.dact) {
-                float a[8];
-                load8(aux_in + orow * p.ldaux_in + n, a);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] *= apply_dact(a[e], p.dact);
-            }
-            if (p.resid) {
-                float r[8];
-                load8(p.resid + rrow * p.ldr + n, r);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += r[e];
-            }
-            if (residT) {
-                float r[8];
-                load8(residT + orow * p.ldrT + n, r);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += r[e];
-            }
-            if (p.out32) store8(p.out32 + orow * p.ldo32 + n, v);
-            if (outT) store8(outT + orow * p.ldo + n, v);
-        }
-    }
+    gemm_epilogue<T, MT, NT, WTM, WTN>(p, acc, m0, n0, wm, wn, li, g);
 }
 
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
@@ -238,6 +321,336 @@ int launch_cfg(hipStream_t stream, const UiaGemmParams& p) {
     return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Ping-pong variant (tile cfg 6/7): the workgroup's waves form two groups (wave < NW/2, wave ≥ NW/2), one
+// wave of each group per SIMD.  Group 1 runs ONE barrier slot behind group 0, so in every slot one group
+// issues its MFMA cluster while the other reads its next fragments from LDS: the matrix pipe sees
+// back-to-back clusters instead of [LDS phase | MFMA phase] lockstep.  Per K-tile each wave runs
+//     LOAD(kk=0) | COMPUTE(kk=0) | LOAD(kk=1) | COMPUTE(kk=1)        (one raw s_barrier after each)
+// Staging: at wall-clock slot 4s every wave issues its global_load_lds for tile s+1 (group 0 at the top of
+// LOAD(s,0), group 1 at the top of COMPUTE(s-1,1)); every wave retires them with vmcnt(0) at the end of
+// wall-clock slot 4s+3, so the loads stay in flight across four barrier slots.  Hazards:
+//   RAW  tile s+1 is first read in slot 4s+4, after the barrier that follows every wave's vmcnt(0);
+//   WAR  buffer (s+1)&1 held tile s-1, last read in slot 4s-1 by group 1 whose ds_reads were retired
+//        (lgkmcnt(0)) before that slot's barrier.
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_tn_pp_kernel(const UiaGemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NW = WAVES_M * WAVES_N;
+    constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+    constexpr int MT = WTM / 16, NT = WTN / 16;
+    constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, BUF_BYTES = A_BYTES + W_BYTES;
+    constexpr int A_PER_WAVE = (BM / 8) / NW, W_PER_WAVE = (BN / 8) / NW;
+    static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0 && NW % 2 == 0 && (NT % 2) == 0, "tile shape");
+    constexpr int ESZ = (int)sizeof(T);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int grp = wave >= NW / 2 ? 1 : 0;
+
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const char* srcA[A_PER_WAVE];
+    const char* srcW[W_PER_WAVE];
+#pragma unroll
+    for (int i = 0; i < A_PER_WAVE; ++i) {
+        const int r = 8 * (wave + NW * i) + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        int gm = m0 + r;
+        gm = gm < p.M ? gm : p.M - 1;
+        srcA[i] = (const char*)p.A + ((size_t)gm * (size_t)p.lda) * ESZ + c * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < W_PER_WAVE; ++i) {
+        const int r = 8 * (wave + NW * i) + (lane >> 3);
+        const int rl = r & (WTN - 1);
+        const int x = ((rl / (4 * NT)) << 1) | ((rl & 3) >> 1);
+        const int c = (lane & 7) ^ x;
+        int gn = n0 + r;
+        gn = gn < p.N ? gn : p.N - 1;
+        srcW[i] = (const char*)p.W + ((size_t)gn * (size_t)p.ldw) * ESZ + c * 16;
+    }
+    const int li = lane & 15, g = lane >> 4;
+    const int offA0 = (wm * WTM + li) * 128 + ((g ^ (li >> 1)) << 4);
+    const int xw = ((li >> 2) << 1) | ((li & 3) >> 1);
+    const int offW0 = A_BYTES + (wn * WTN + (li >> 2) * (4 * NT) + (li & 3)) * 128 + ((g ^ xw) << 4);
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / (128 / ESZ);
+    auto stage = [&](int s) {
+        char* base = smem + (s & 1) * BUF_BYTES;
+        const size_t koff = (size_t)s * 128;
+#pragma unroll
+        for (int i = 0; i < A_PER_WAVE; ++i) glds16(srcA[i] + koff, base + (wave + NW * i) * 1024);
+#pragma unroll
+        for (int i = 0; i < W_PER_WAVE; ++i) glds16(srcW[i] + koff, base + A_BYTES + (wave + NW * i) * 1024);
+    };
+    uint4 af[MT], wf[NT];
+    auto load_frags = [&](const char* buf, int kk) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) wf[j] = *(const uint4*)(buf + ((offW0 + j * 4 * 128) ^ (kk << 6)));
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af[i] = *(const uint4*)(buf + ((offA0 + i * 16 * 128) ^ (kk << 6)));
+    };
+    auto compute = [&]() {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = MfmaTile<T>::mma(wf[j], af[i], acc[i][j]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+#define UIA_SLOT_END()                                         \
+    do {                                                       \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     \
+        __builtin_amdgcn_s_barrier();                          \
+        __builtin_amdgcn_sched_barrier(0);                     \
+    } while (0)
+
+#ifdef UIA_GEMM_STAMPS
+    unsigned long long t_start = __builtin_amdgcn_s_memtime(), t_pro = 0, t_loop = 0;
+#endif
+    stage(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                 // tile 0 resident
+    __builtin_amdgcn_sched_barrier(0);
+#ifdef UIA_GEMM_STAMPS
+    t_pro = __builtin_amdgcn_s_memtime();
+#endif
+    if (grp == 1) {                               // wall-clock slot 0 from group 1's side: prefetch tile 1, then fall one slot behind
+        if (nk > 1) stage(1);
+        UIA_SLOT_END();
+    }
+    for (int s = 0; s < nk; ++s) {
+        const char* buf = smem + (s & 1) * BUF_BYTES;
+        // ---- LOAD(s,0)
+        if (grp == 0 && s + 1 < nk) stage(s + 1);
+        load_frags(buf, 0);
+        UIA_SLOT_END();
+        // ---- COMPUTE(s,0)
+        compute();
+        UIA_SLOT_END();
+        // ---- LOAD(s,1)
+        load_frags(buf, 1);
+        if (grp == 1 && s + 1 < nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // wall-clock slot 4s+3
+        UIA_SLOT_END();
+        // ---- COMPUTE(s,1)
+        if (grp == 1 && s + 2 < nk) stage(s + 2);                                      // wall-clock slot 4(s+1)
+        compute();
+        if (grp == 0 && s + 1 < nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // wall-clock slot 4s+3
+        UIA_SLOT_END();
+    }
+    if (grp == 0) {                               // balance group 1's extra slot
+        UIA_SLOT_END();
+    }
+#undef UIA_SLOT_END
+#ifdef UIA_GEMM_STAMPS
+    t_loop = __builtin_amdgcn_s_memtime();
+#endif
+    gemm_epilogue_lds<T, MT, NT, WTM, WTN>(p, acc, smem, wave, lane, m0, n0, wm, wn);
+#ifdef UIA_GEMM_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0 && uia_stamp_buf) {
+        unsigned long long t_end = __builtin_amdgcn_s_memtime();
+        unsigned long long* o = uia_stamp_buf + ((size_t)blockIdx.x * NW + wave) * 4;
+        o[0] = t_start; o[1] = t_pro; o[2] = t_loop; o[3] = t_end;
+    }
+#endif
+}
+
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
+int launch_pp(hipStream_t stream, const UiaGemmParams& p) {
+    constexpr int LDS = 2 * (BM + BN) * 128;
+    auto kern = gemm_tn_pp_kernel<T, BM, BN, WAVES_M, WAVES_N>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        UIA_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_set = true;
+    }
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(64 * WAVES_M * WAVES_N), LDS, stream, p);
+    UIA_CHECK_LAUNCH();
+    return 0;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Ring variant (tile cfg 8/9): ping-pong schedule as above, but the staging loads form a CONTINUOUS stream.
+// The K dimension is cut into sub-tiles of BKB bytes per row (64 or 128); NBUF sub-tile buffers form a ring in
+// LDS and PD = NBUF-1 sub-tiles are kept in flight behind a COUNTED s_waitcnt vmcnt((PD-1)·GPT): the loop never
+// drains its loads.  (Measured on the 2-buffer kernel: 15 B/clk/CU from L2 = one 64 KB burst in flight for ~half
+// the time at ~2000 cycles latency; the ring keeps 64-96 KB in flight all the time.)
+//   step u = one (LOAD, COMPUTE) slot pair = 64 bytes of K per row; sub-tile t = u / SPT, SPT = BKB/64.
+//   wall slot 2·t·SPT     : every wave issues sub-tile t+PD   (group 0: top of LOAD(t·SPT); group 1: top of COMPUTE(t·SPT-1))
+//   wall slot 2·t·SPT - 1 : every wave retires sub-tile t     (group 0: end of COMPUTE;     group 1: end of LOAD)
+//   RAW: sub-tile t is first read in wall slot 2·t·SPT, after that barrier.   WAR: buffer (t+PD)%NBUF last held
+//   sub-tile t-1, whose final ds_reads (group 1, wall slot 2·t·SPT-1) were retired before that slot's barrier.
+// 64-byte rows use the 4-entry swizzle table {0,3,2,1} indexed by (row>>2)&3 (A) / the 16-row block of the
+// permuted W rows: conflict-free ds_read_b128 for both fragment patterns.
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int NBUF>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_tn_ring_kernel(const UiaGemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NW = WAVES_M * WAVES_N;
+    constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+    constexpr int MT = WTM / 16, NT = WTN / 16;
+    constexpr int A_BYTES = BM * BKB, W_BYTES = BN * BKB, BUF_BYTES = A_BYTES + W_BYTES;
+    constexpr int RPI = 1024 / BKB;                              // rows per 1 KiB wave-instruction (8 or 16)
+    constexpr int CPR = BKB / 16;                                // 16-byte chunks per row (8 or 4)
+    constexpr int A_PER_WAVE = (BM / RPI) / NW, W_PER_WAVE = (BN / RPI) / NW;
+    constexpr int GPT = A_PER_WAVE + W_PER_WAVE;                 // glds per sub-tile per wave
+    constexpr int SPT = BKB / 64;                                // (LOAD, COMPUTE) steps per sub-tile
+    constexpr int PD = NBUF - 1;                                 // sub-tiles in flight
+    static_assert((BM / RPI) % NW == 0 && (BN / RPI) % NW == 0 && NW % 2 == 0 && NT == 4, "tile shape");
+    static_assert(BKB == 64 || BKB == 128, "sub-tile rows are 64 or 128 bytes");
+    constexpr int ESZ = (int)sizeof(T);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int grp = wave >= NW / 2 ? 1 : 0;
+
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // swizzle of the 16-byte chunk index: 128-byte rows: (row>>1)&7 / 2a|(b>>1) as in the 2-buffer kernels;
+    // 64-byte rows: table {0,3,2,1}[(row>>2)&3] for A, [(row_local>>4)&3] for the permuted W rows.
+    auto swzA = [](int r) -> int { return BKB == 128 ? ((r >> 1) & 7) : ((0x1230 >> (4 * ((r >> 2) & 3))) & 3); };
+    auto swzW = [](int rl) -> int { return BKB == 128 ? ((((rl >> 4) & 3) << 1) | ((rl & 3) >> 1)) : ((0x1230 >> (4 * ((rl >> 4) & 3))) & 3); };
+
+    const char* srcA[A_PER_WAVE];
+    const char* srcW[W_PER_WAVE];
+#pragma unroll
+    for (int i = 0; i < A_PER_WAVE; ++i) {
+        const int r = RPI * (wave + NW * i) + lane / CPR;
+        const int c = (lane % CPR) ^ swzA(r);
+        int gm = m0 + r;
+        gm = gm < p.M ? gm : p.M - 1;
+        srcA[i] = (const char*)p.A + ((size_t)gm * (size_t)p.lda) * ESZ + c * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < W_PER_WAVE; ++i) {
+        const int r = RPI * (wave + NW * i) + lane / CPR;
+        const int c = (lane % CPR) ^ swzW(r & (WTN - 1));
+        int gn = n0 + r;
+        gn = gn < p.N ? gn : p.N - 1;
+        srcW[i] = (const char*)p.W + ((size_t)gn * (size_t)p.ldw) * ESZ + c * 16;
+    }
+    const int li = lane & 15, g = lane >> 4;
+    const int rowA = wm * WTM + li;                                         // + 16·mt  (keeps (row>>1)&7 and (row>>2)&3)
+    const int rowW = wn * WTN + (li >> 2) * 16 + (li & 3);                  // + 4·j
+    const int offA0 = rowA * BKB + ((g ^ swzA(li)) << 4);
+    const int offW0 = A_BYTES + rowW * BKB + ((g ^ swzW((li >> 2) * 16 + (li & 3))) << 4);
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int ntl = (p.K * ESZ) / BKB;                                       // sub-tiles
+    auto stage = [&](int t) {
+        char* base = smem + (t % NBUF) * BUF_BYTES;
+        const size_t koff = (size_t)t * BKB;
+#pragma unroll
+        for (int i = 0; i < A_PER_WAVE; ++i) glds16(srcA[i] + koff, base + (wave + NW * i) * 1024);
+#pragma unroll
+        for (int i = 0; i < W_PER_WAVE; ++i) glds16(srcW[i] + koff, base + A_BYTES + (wave + NW * i) * 1024);
+    };
+    uint4 af[MT], wf[NT];
+    auto load_frags = [&](const char* buf, int kk) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) wf[j] = *(const uint4*)(buf + ((offW0 + j * 4 * BKB) ^ (kk << 6)));
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af[i] = *(const uint4*)(buf + ((offA0 + i * 16 * BKB) ^ (kk << 6)));
+    };
+    auto compute = [&]() {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = MfmaTile<T>::mma(wf[j], af[i], acc[i][j]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    // retire sub-tile t: everything this wave issued except the (PD-1) newer sub-tiles (fewer near the tail → drain)
+    auto retire = [&](int t) {
+        if (t + PD - 1 < ntl) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PD - 1) * GPT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+#define UIA_SLOT_END()                                         \
+    do {                                                       \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     \
+        __builtin_amdgcn_s_barrier();                          \
+        __builtin_amdgcn_sched_barrier(0);                     \
+    } while (0)
+
+    for (int t = 0; t < PD && t < ntl; ++t) stage(t);
+    retire(0);
+    __builtin_amdgcn_s_barrier();                 // sub-tile 0 resident
+    __builtin_amdgcn_sched_barrier(0);
+    if (grp == 1) {                               // wall slot 0 seen from group 1: issue sub-tile PD, fall one slot behind
+        if (PD < ntl) stage(PD);
+        UIA_SLOT_END();
+    }
+    const int nu = ntl * SPT;
+    for (int u = 0; u < nu; ++u) {
+        const int t = u / SPT, kk = u % SPT;
+        const char* buf = smem + (t % NBUF) * BUF_BYTES;
+        const bool last_of_tile = kk == SPT - 1;
+        // ---- LOAD(u)
+        if (grp == 0 && kk == 0 && t + PD < ntl) stage(t + PD);                   // wall slot 2·t·SPT
+        load_frags(buf, kk);
+        if (grp == 1 && last_of_tile && t + 1 < ntl) retire(t + 1);               // wall slot 2·(t+1)·SPT - 1
+        UIA_SLOT_END();
+        // ---- COMPUTE(u)
+        if (grp == 1 && last_of_tile && t + 1 + PD < ntl) stage(t + 1 + PD);      // wall slot 2·(t+1)·SPT
+        compute();
+        if (grp == 0 && last_of_tile && t + 1 < ntl) retire(t + 1);               // wall slot 2·(t+1)·SPT - 1
+        UIA_SLOT_END();
+    }
+    if (grp == 0) {
+        UIA_SLOT_END();
+    }
+#undef UIA_SLOT_END
+    gemm_epilogue_lds<T, MT, NT, WTM, WTN>(p, acc, smem, wave, lane, m0, n0, wm, wn);
+}
+
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int NBUF>
+int launch_ring(hipStream_t stream, const UiaGemmParams& p) {
+    constexpr int LDS = NBUF * (BM + BN) * BKB;
+    auto kern = gemm_tn_ring_kernel<T, BM, BN, WAVES_M, WAVES_N, BKB, NBUF>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        UIA_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_set = true;
+    }
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(64 * WAVES_M * WAVES_N), LDS, stream, p);
+    UIA_CHECK_LAUNCH();
+    return 0;
+}
+
 template <typename T>
 int launch_typed(hipStream_t stream, const UiaGemmParams& p, int cfg) {
     // cfg: 0 = auto. Tile choice is a pure speed knob (results are identical for every config
@@ -245,8 +658,7 @@ int launch_typed(hipStream_t stream, const UiaGemmParams& p, int cfg) {
     if (cfg == 0) {
         if (p.N <= 64) cfg = 4;
         else if (p.M <= 2048) cfg = 3;
-        else if (p.N % 256 == 0 && p.N >= 2048) cfg = 1;
-        else cfg = 2;
+        else cfg = 6;            // 256x256 ping-pong + LDS-staged epilogue: best measured on every large shape (N = 768 included)
     }
     switch (cfg) {
         case 1: return launch_cfg<T, 256, 256, 2, 4>(stream, p);
@@ -254,6 +666,11 @@ int launch_typed(hipStream_t stream, const UiaGemmParams& p, int cfg) {
         case 3: return launch_cfg<T, 128, 128, 2, 2>(stream, p);
         case 4: return launch_cfg<T, 256, 64, 4, 1>(stream, p);
         case 5: return launch_cfg<T, 128, 64, 2, 1>(stream, p);
+        case 6: return launch_pp<T, 256, 256, 2, 4>(stream, p);
+        case 7: return launch_pp<T, 256, 128, 4, 2>(stream, p);
+        case 8: return launch_ring<T, 256, 256, 2, 4, 64, 4>(stream, p);
+        case 9: return launch_ring<T, 256, 128, 4, 2, 128, 3>(stream, p);
+        case 10: return launch_ring<T, 256, 256, 2, 4, 64, 5>(stream, p);
         default: uia_set_error("uia_gemm: unknown tile config %d", cfg); return -1;
     }
 }

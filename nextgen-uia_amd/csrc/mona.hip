@@ -73,7 +73,8 @@ __global__ __launch_bounds__(256) void mona_pre_fwd_kernel(int M, int D, const f
 
 // rows are dealt to waves in a grid-stride loop so that every wave keeps per-column partial sums of
 // the four parameter gradients in registers; one LDS reduction + one atomic per column per block.
-template <typename T>
+// NV = float4 per lane (D ≤ 256·NV): the common D = 768 runs with NV = 3 and ~3 waves/SIMD.
+template <typename T, int NV>
 __global__ __launch_bounds__(256) void mona_pre_bwd_kernel(int M, int D, const T* __restrict__ du, const float* __restrict__ x,
                                                             const float* __restrict__ dy, const float* __restrict__ nw,
                                                             const float* __restrict__ nb, const float* __restrict__ gamma,
@@ -83,24 +84,15 @@ __global__ __launch_bounds__(256) void mona_pre_bwd_kernel(int M, int D, const T
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int nv = D >> 2;
-    f32x4 a_g[LN_MAXV], a_gx[LN_MAXV], a_w[LN_MAXV], a_b[LN_MAXV];
-    f32x4 pw[LN_MAXV], pb[LN_MAXV], pg[LN_MAXV], pgx[LN_MAXV];
+    f32x4 a_g[NV], a_gx[NV], a_w[NV], a_b[NV];
 #pragma unroll
-    for (int k = 0; k < LN_MAXV; ++k) {
-        a_g[k] = a_gx[k] = a_w[k] = a_b[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int c = lane + 64 * k;
-        const bool ok = c < nv;
-        pw[k] = ok ? load4(nw + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
-        pb[k] = ok ? load4(nb + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
-        pg[k] = ok ? load4(gamma + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
-        pgx[k] = ok ? load4(gammax + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+    for (int k = 0; k < NV; ++k) a_g[k] = a_gx[k] = a_w[k] = a_b[k] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
         const float* xr = x + (size_t)row * D;
-        f32x4 v[LN_MAXV], d[LN_MAXV];
+        f32x4 v[NV], d[NV];
         float s = 0.f;
 #pragma unroll
-        for (int k = 0; k < LN_MAXV; ++k) {
+        for (int k = 0; k < NV; ++k) {
             const int c = lane + 64 * k;
             const bool ok = c < nv;
             v[k] = ok ? load4(xr + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -110,29 +102,32 @@ __global__ __launch_bounds__(256) void mona_pre_bwd_kernel(int M, int D, const T
         const float mean = wave_sum(s) / D;
         float q = 0.f;
 #pragma unroll
-        for (int k = 0; k < LN_MAXV; ++k) {
+        for (int k = 0; k < NV; ++k) {
             const int c = lane + 64 * k;
 #pragma unroll
             for (int e = 0; e < 4; ++e) { const float t = c < nv ? v[k][e] - mean : 0.f; q = fmaf(t, t, q); }
         }
         const float rstd = rsqrtf(wave_sum(q) / D + eps);
-        // g = dn·w_n with dn = du·γ ; parameter partial sums
-        f32x4 xh[LN_MAXV], g[LN_MAXV];
+        // g = dn·w_n with dn = du·γ ; parameter partial sums.  xh/g overwrite v/d-independent temporaries.
+        f32x4 xh[NV], g[NV];
         float sg = 0.f, sgx = 0.f;
 #pragma unroll
-        for (int k = 0; k < LN_MAXV; ++k) {
+        for (int k = 0; k < NV; ++k) {
             const int c = lane + 64 * k;
+            const bool ok = c < nv;
+            const f32x4 pw = ok ? load4(nw + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f}, pb = ok ? load4(nb + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 pg = ok ? load4(gamma + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float xhat = c < nv ? (v[k][e] - mean) * rstd : 0.f;
-                const float dn = d[k][e] * pg[k][e];
-                const float n = fmaf(xhat, pw[k][e], pb[k][e]);
+                const float xhat = ok ? (v[k][e] - mean) * rstd : 0.f;
+                const float dn = d[k][e] * pg[e];
+                const float n = fmaf(xhat, pw[e], pb[e]);
                 a_g[k][e] = fmaf(d[k][e], n, a_g[k][e]);            // dγ  = Σ du·n
                 a_gx[k][e] = fmaf(d[k][e], v[k][e], a_gx[k][e]);    // dγx = Σ du·x
                 a_w[k][e] = fmaf(dn, xhat, a_w[k][e]);              // dw_n = Σ dn·x̂
                 a_b[k][e] += dn;                                    // db_n = Σ dn
                 xh[k][e] = xhat;
-                g[k][e] = dn * pw[k][e];
+                g[k][e] = dn * pw[e];
                 sg += g[k][e];
                 sgx = fmaf(g[k][e], xhat, sgx);
             }
@@ -140,12 +135,13 @@ __global__ __launch_bounds__(256) void mona_pre_bwd_kernel(int M, int D, const T
         const float mg = wave_sum(sg) / D, mgx = wave_sum(sgx) / D;
         if (dx32 || dxT) {
 #pragma unroll
-            for (int k = 0; k < LN_MAXV; ++k) {
+            for (int k = 0; k < NV; ++k) {
                 const int c = lane + 64 * k;
                 if (c < nv) {
                     f32x4 o = load4(dy + (size_t)row * D + 4 * c);
+                    const f32x4 pgx = load4(gammax + 4 * c);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] += fmaf(d[k][e], pgx[k][e], rstd * (g[k][e] - mg - xh[k][e] * mgx));
+                    for (int e = 0; e < 4; ++e) o[e] += fmaf(d[k][e], pgx[e], rstd * (g[k][e] - mg - xh[k][e] * mgx));
                     if (dx32) store4(dx32 + (size_t)row * D + 4 * c, o);
                     if (dxT) store4(dxT + (size_t)row * D + 4 * c, o);
                 }
@@ -155,7 +151,7 @@ __global__ __launch_bounds__(256) void mona_pre_bwd_kernel(int M, int D, const T
     // block reduction: [4 waves][4 quantities][D]
     float* red = (float*)smem;
 #pragma unroll
-    for (int k = 0; k < LN_MAXV; ++k) {
+    for (int k = 0; k < NV; ++k) {
         const int c = lane + 64 * k;
         if (c < nv) {
             store4(red + ((wave * 4 + 0) * D) + 4 * c, a_g[k]);
@@ -184,7 +180,7 @@ struct NoiseState {   // per-image noise-estimator activations kept for the back
 
 template <typename T>
 __device__ __forceinline__ void load_tokens(const T* __restrict__ src, float* __restrict__ dst, int ntok, int tid) {
-    for (int i = tid; i < ntok * 8; i += 256) {
+    for (int i = tid; i < ntok * 8; i += 512) {
         float v[8];
         load8(src + (size_t)i * 8, v);
 #pragma unroll
@@ -194,8 +190,9 @@ __device__ __forceinline__ void load_tokens(const T* __restrict__ src, float* __
 
 // Noise estimator forward (mona.py:170-176,187 / :393-399,416): pool → 1×1 (64→16) → ReLU → 1×1 (16→3) → softmax.
 // scr: ≥ 4*64 + 64 + 16 + 16 + 4 floats.  Returns w1,w2,w3 in scr[W_OFF..].
-constexpr int SCR_PART = 0, SCR_POOL = 256, SCR_HPRE = 320, SCR_HID = 336, SCR_W = 352, SCR_DPOOL = 360, SCR_RED = 424, SCR_SIZE = 448;
-constexpr int RED_FLOATS = 3 * 64 * 50;   // pass-A partials of pixel groups 1..3 (group 0 keeps its own in registers)
+constexpr int NGRP = 8;                   // pixel groups = waves per image (512 threads)
+constexpr int SCR_PART = 0, SCR_POOL = 512, SCR_HPRE = 576, SCR_HID = 592, SCR_W = 608, SCR_DPOOL = 616, SCR_RED = 680, SCR_SIZE = 720;
+constexpr int RED_FLOATS = 64 * 50;       // pass-A per-channel accumulators (LDS atomics from the 8 pixel groups)
 
 __device__ __forceinline__ void noise_forward(const uia_mona_spatial_desc& p, const float* tS, float f, int hw, int ppg, int c, int grp,
                                               int tid, float* scr) {
@@ -204,7 +201,12 @@ __device__ __forceinline__ void noise_forward(const uia_mona_spatial_desc& p, co
     for (int px = p0; px < p1; ++px) s += tS[(1 + px) * BOTT + c];
     scr[SCR_PART + grp * 64 + c] = s;
     __syncthreads();
-    if (tid < 64) scr[SCR_POOL + tid] = f * (scr[SCR_PART + tid] + scr[SCR_PART + 64 + tid] + scr[SCR_PART + 128 + tid] + scr[SCR_PART + 192 + tid]) / hw;
+    if (tid < 64) {
+        float a = 0.f;
+#pragma unroll
+        for (int q = 0; q < NGRP; ++q) a += scr[SCR_PART + q * 64 + tid];
+        scr[SCR_POOL + tid] = f * a / hw;
+    }
     __syncthreads();
     if (tid < 16) {
         float a = p.ne1_b[tid];
@@ -236,12 +238,13 @@ __device__ __forceinline__ void conv_forward(const float* tS, float* cS, const f
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
             const int yy = y + i - 3;
-            if (yy < 0 || yy >= h) continue;
+            const bool vy = yy >= 0 && yy < h;
 #pragma unroll
             for (int j = 0; j < 7; ++j) {
                 const int xx = x + j - 3;
-                if (xx < 0 || xx >= w) continue;
-                acc = fmaf(KM(i, j), tS[(1 + yy * w + xx) * BOTT + c], acc);
+                const bool ok = vy && xx >= 0 && xx < w;                   // wave-uniform: no branch, out-of-range taps read token 0 and are zeroed
+                const float tv = tS[(ok ? 1 + yy * w + xx : 0) * BOTT + c];
+                acc = fmaf(KM(i, j), ok ? tv : 0.f, acc);
             }
         }
         cS[px * BOTT + c] = fmaf(f, acc, bm) + tS[(1 + px) * BOTT + c];
@@ -249,7 +252,7 @@ __device__ __forceinline__ void conv_forward(const float* tS, float* cS, const f
 }
 
 template <typename T, bool BWD>
-__global__ __launch_bounds__(256) void mona_spatial_kernel(const uia_mona_spatial_desc p) {
+__global__ __launch_bounds__(512) void mona_spatial_kernel(const uia_mona_spatial_desc p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int h = p.h, w = p.w, hw = h * w, ntok = hw + 1;
     float* tS = (float*)smem;                 // [ntok][64]
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(256) void mona_spatial_kernel(const uia_mona_spatia
     const int b = blockIdx.x;
     const bool has_freq = p.variant == UIA_MONA_FREQ_ENHANCED || p.variant == UIA_MONA_HYBRID;
     const bool has_noise = p.variant == UIA_MONA_NOISE_AWARE || p.variant == UIA_MONA_HYBRID;
-    const int ppg = (hw + 3) >> 2, p0 = grp * ppg, p1 = min(hw, p0 + ppg);
+    const int ppg = (hw + NGRP - 1) / NGRP, p0 = grp * ppg, p1 = min(hw, p0 + ppg);
     const size_t tok0 = (size_t)b * ntok;
 
     load_tokens((const T*)p.t + tok0 * BOTT, tS, ntok, tid);
@@ -329,23 +332,23 @@ __global__ __launch_bounds__(256) void mona_spatial_kernel(const uia_mona_spatia
     __syncthreads();
     // ---- dP[co][ci] += Σ_pix dp[pix][co]·c[pix][ci];  db_p[co] += Σ_pix dp[pix][co]
     {
-        const int co = tid >> 2, cb = (tid & 3) * 16;
-        float a[16];
+        const int co = tid >> 3, cb = (tid & 7) * 8;
+        float a[8];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) a[k] = 0.f;
+        for (int k = 0; k < 8; ++k) a[k] = 0.f;
         float sb = 0.f;
         for (int px = 0; px < hw; ++px) {
             const float dpv = gS[(1 + px) * BOTT + co];
             sb += dpv;
 #pragma unroll
-            for (int k = 0; k < 16; k += 4) {
+            for (int k = 0; k < 8; k += 4) {
                 const f32x4 v = *(const f32x4*)(cS + px * BOTT + cb + k);
                 a[k] = fmaf(dpv, v[0], a[k]); a[k + 1] = fmaf(dpv, v[1], a[k + 1]); a[k + 2] = fmaf(dpv, v[2], a[k + 2]); a[k + 3] = fmaf(dpv, v[3], a[k + 3]);
             }
         }
 #pragma unroll
-        for (int k = 0; k < 16; ++k) atomicAdd(p.g_proj_w + co * 64 + cb + k, a[k]);
-        if ((tid & 3) == 0) atomicAdd(p.g_proj_b + co, sb);
+        for (int k = 0; k < 8; ++k) atomicAdd(p.g_proj_w + co * 64 + cb + k, a[k]);
+        if ((tid & 7) == 0) atomicAdd(p.g_proj_b + co, sb);
     }
     __syncthreads();
     // ---- dc = dp + Pᵀ·dp, in place (rows of a pixel group belong to one wave)
@@ -379,12 +382,13 @@ __global__ __launch_bounds__(256) void mona_spatial_kernel(const uia_mona_spatia
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
             const int yy = y + i - 3;
-            if (yy < 0 || yy >= h) continue;
+            const bool vy = yy >= 0 && yy < h;
 #pragma unroll
             for (int j = 0; j < 7; ++j) {
                 const int xx = x + j - 3;
-                if (xx < 0 || xx >= w) continue;
-                const float tv = tS[(1 + yy * w + xx) * BOTT + c];
+                const bool ok = vy && xx >= 0 && xx < w;
+                const float tr = tS[(ok ? 1 + yy * w + xx : 0) * BOTT + c];
+                const float tv = ok ? tr : 0.f;
                 dkm[i * 7 + j] = fmaf(dcv, tv, dkm[i * 7 + j]);
                 s3 = fmaf(k3[i * 7 + j], tv, s3);
                 if (i >= 1 && i <= 5 && j >= 1 && j <= 5) s2 = fmaf(k2[(i - 1) * 5 + (j - 1)], tv, s2);
@@ -395,18 +399,18 @@ __global__ __launch_bounds__(256) void mona_spatial_kernel(const uia_mona_spatia
         dwm2 = fmaf(dcv, fmaf(f, s2, b2), dwm2);
         dwm3 = fmaf(dcv, fmaf(f, s3, b3), dwm3);
     }
-    // reduce over the 4 pixel groups through LDS (the c tile is free now): groups 1..3 → [3][64][50]
+    // reduce over the pixel groups with LDS atomics into [64][50] (the c tile is free now)
     float* red = cS;
-    if (grp > 0) {
+    for (int i = tid; i < RED_FLOATS; i += 512) red[i] = 0.f;
+    __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 49; ++i) red[((grp - 1) * 64 + c) * 50 + i] = dkm[i];
-        red[((grp - 1) * 64 + c) * 50 + 49] = sdc;
-    }
+    for (int i = 0; i < 49; ++i) atomicAdd(red + c * 50 + i, dkm[i]);
+    atomicAdd(red + c * 50 + 49, sdc);
     __syncthreads();
     if (grp == 0) {
 #pragma unroll
-        for (int i = 0; i < 49; ++i) dkm[i] = f * (dkm[i] + red[c * 50 + i] + red[(64 + c) * 50 + i] + red[(128 + c) * 50 + i]);   // Σ dc·xf[nbr]
-        sdc += red[c * 50 + 49] + red[(64 + c) * 50 + 49] + red[(128 + c) * 50 + 49];
+        for (int i = 0; i < 49; ++i) dkm[i] = f * red[c * 50 + i];      // Σ dc·xf[nbr]
+        sdc = red[c * 50 + 49];
 #pragma unroll
         for (int i = 0; i < 7; ++i)
 #pragma unroll
@@ -429,7 +433,10 @@ __global__ __launch_bounds__(256) void mona_spatial_kernel(const uia_mona_spatia
         if (tid < 16) {
             // softmax backward → logits → hidden (each of the 16 threads recomputes the 3-vector)
             float dwv[3], wv[3] = {w1, w2, w3}, dl[3];
-            for (int k = 0; k < 3; ++k) dwv[k] = scr[SCR_RED + k] + scr[SCR_RED + 4 + k] + scr[SCR_RED + 8 + k] + scr[SCR_RED + 12 + k];
+            for (int k = 0; k < 3; ++k) {
+                dwv[k] = 0.f;
+                for (int q = 0; q < NGRP; ++q) dwv[k] += scr[SCR_RED + 4 * q + k];
+            }
             const float dot = dwv[0] * wv[0] + dwv[1] * wv[1] + dwv[2] * wv[2];
             for (int k = 0; k < 3; ++k) dl[k] = wv[k] * (dwv[k] - dot);
             const float hid = scr[SCR_HID + tid], hpre = scr[SCR_HPRE + tid];
@@ -449,7 +456,7 @@ __global__ __launch_bounds__(256) void mona_spatial_kernel(const uia_mona_spatia
             for (int j = 0; j < 16; ++j) dp = fmaf(scr[SCR_HPRE + j], p.ne1_w[j * 64 + tid], dp);
             scr[SCR_DPOOL + tid] = dp / hw;                 // gradient reaching every xf[c][pix] through the pool
         }
-        for (int i = tid; i < 16 * 64; i += 256) atomicAdd(p.g_ne1_w + i, scr[SCR_HPRE + (i >> 6)] * scr[SCR_POOL + (i & 63)]);
+        for (int i = tid; i < 16 * 64; i += 512) atomicAdd(p.g_ne1_w + i, scr[SCR_HPRE + (i >> 6)] * scr[SCR_POOL + (i & 63)]);
         __syncthreads();
         dpool_c = scr[SCR_DPOOL + c];
     }
@@ -462,12 +469,13 @@ __global__ __launch_bounds__(256) void mona_spatial_kernel(const uia_mona_spatia
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
             const int yy = y - (i - 3);
-            if (yy < 0 || yy >= h) continue;
+            const bool vy = yy >= 0 && yy < h;
 #pragma unroll
             for (int j = 0; j < 7; ++j) {
                 const int xx = x - (j - 3);
-                if (xx < 0 || xx >= w) continue;
-                acc = fmaf(KM(i, j), gS[(1 + yy * w + xx) * BOTT + c], acc);
+                const bool ok = vy && xx >= 0 && xx < w;
+                const float gv = gS[(ok ? 1 + yy * w + xx : 0) * BOTT + c];
+                acc = fmaf(KM(i, j), ok ? gv : 0.f, acc);
             }
         }
         const float dxf = acc + dpool_c;
@@ -479,7 +487,12 @@ __global__ __launch_bounds__(256) void mona_spatial_kernel(const uia_mona_spatia
         __syncthreads();
         scr[SCR_PART + grp * 64 + c] = dfc;
         __syncthreads();
-        if (tid < 64) atomicAdd(p.g_freq + tid, scr[SCR_PART + tid] + scr[SCR_PART + 64 + tid] + scr[SCR_PART + 128 + tid] + scr[SCR_PART + 192 + tid]);
+        if (tid < 64) {
+            float a = 0.f;
+#pragma unroll
+            for (int q = 0; q < NGRP; ++q) a += scr[SCR_PART + q * 64 + tid];
+            atomicAdd(p.g_freq + tid, a);
+        }
     }
 }
 
@@ -498,7 +511,7 @@ int launch_spatial(hipStream_t stream, const uia_mona_spatial_desc& p) {
         UIA_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(p.B), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL(kern, dim3(p.B), dim3(512), lds, stream, p);
     UIA_CHECK_LAUNCH();
     return 0;
 }
@@ -545,15 +558,15 @@ int uia_mona_pre_bwd_launch(hipStream_t stream, int dtype, int M, int D, const v
     UIA_CHECK_ARG(du && x && nw && nb && gamma && gammax && g_gamma && g_gammax && g_nw && g_nb, "uia_mona_pre_bwd: null tensor");
     UIA_CHECK_ARG(dy || !(dx32 || dxT), "uia_mona_pre_bwd: dx requested without dy");
     int blocks = (M + 3) / 4;
-    blocks = blocks > 512 ? 512 : blocks;
+    blocks = blocks > 1024 ? 1024 : blocks;
     const size_t lds = (size_t)16 * D * sizeof(float);
-    if (dtype == UIA_BF16)
-        hipLaunchKernelGGL(mona_pre_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), lds, stream, M, D, (const bf16_t*)du, x, dy, nw, nb, gamma, gammax, eps,
-                           dx32, (bf16_t*)dxT, g_gamma, g_gammax, g_nw, g_nb);
-    else if (dtype == UIA_F32)
-        hipLaunchKernelGGL(mona_pre_bwd_kernel<float>, dim3(blocks), dim3(256), lds, stream, M, D, (const float*)du, x, dy, nw, nb, gamma, gammax, eps,
-                           dx32, (float*)dxT, g_gamma, g_gammax, g_nw, g_nb);
+    const int nvsel = D <= 256 ? 1 : (D <= 768 ? 3 : 4);
+#define UIA_PRE_BWD(TT, NVV) hipLaunchKernelGGL((mona_pre_bwd_kernel<TT, NVV>), dim3(blocks), dim3(256), lds, stream, M, D, (const TT*)du, x, dy, nw, nb, \
+                                                gamma, gammax, eps, dx32, (TT*)dxT, g_gamma, g_gammax, g_nw, g_nb)
+    if (dtype == UIA_BF16) { if (nvsel == 1) UIA_PRE_BWD(bf16_t, 1); else if (nvsel == 3) UIA_PRE_BWD(bf16_t, 3); else UIA_PRE_BWD(bf16_t, 4); }
+    else if (dtype == UIA_F32) { if (nvsel == 1) UIA_PRE_BWD(float, 1); else if (nvsel == 3) UIA_PRE_BWD(float, 3); else UIA_PRE_BWD(float, 4); }
     else { uia_set_error("uia_mona_pre_bwd: bad dtype %d", dtype); return -1; }
+#undef UIA_PRE_BWD
     UIA_CHECK_LAUNCH();
     return 0;
 }

@@ -82,27 +82,41 @@ __device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
 }
 
 // ---------------------------------------------------------------- math
-// erf with |abs err| <= 1.5e-7 (Abramowitz & Stegun 7.1.26): one v_exp + one v_rcp.
-__device__ __forceinline__ float erf_as(float x) {
-    const float ax = fabsf(x);
-    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
-    float y = fmaf(1.061405429f, t, -1.453152027f);
-    y = fmaf(y, t, 1.421413741f);
-    y = fmaf(y, t, -0.284496736f);
-    y = fmaf(y, t, 0.254829592f);
-    y = y * t * __expf(-ax * ax);
-    const float r = 1.0f - y;
-    return copysignf(r, x);
+// Φ(x) (standard normal CDF) and E = exp(-x²/2) from ONE v_exp + ONE v_rcp (Abramowitz & Stegun 7.1.25/26):
+//   FAST = false: 5-term form, |Δerf| ≤ 1.5e-7  (fp32 parity mode)
+//   FAST = true : 3-term form, |Δerf| ≤ 2.5e-5 → |Δgelu| ≤ 2.6e-5, an order below bf16 rounding (bf16 mode)
+// gelu(x) = x·Φ, gelu'(x) = Φ + x·E/√(2π): the backward reuses the same exponential.
+template <bool FAST>
+__device__ __forceinline__ void gelu_parts(float x, float& Phi, float& E) {
+    const float ax = fabsf(x) * 0.70710678118654752f;
+    E = __expf(-ax * ax);
+    float y;
+    if (FAST) {
+        const float t = __frcp_rn(fmaf(0.47047f, ax, 1.0f));
+        y = fmaf(fmaf(0.7478556f, t, -0.0958798f), t, 0.3480242f) * t;
+    } else {
+        const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+        y = fmaf(1.061405429f, t, -1.453152027f);
+        y = fmaf(y, t, 1.421413741f);
+        y = fmaf(y, t, -0.284496736f);
+        y = fmaf(y, t, 0.254829592f) * t;
+    }
+    const float half_erfc = 0.5f * y * E;                 // 0.5·erfc(|x|/√2)
+    Phi = x >= 0.f ? 1.0f - half_erfc : half_erfc;
 }
-// exact-erf GELU (timm / HF BERT / F.gelu default) and its derivative
-__device__ __forceinline__ float gelu_erf(float x) {
-    return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f));
+template <bool FAST = false> __device__ __forceinline__ float gelu_erf_t(float x) {
+    float P, E;
+    gelu_parts<FAST>(x, P, E);
+    return x * P;
 }
-__device__ __forceinline__ float dgelu_erf(float x) {
-    const float cdf = 0.5f * (1.0f + erf_as(x * 0.70710678118654752f));
-    const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
-    return fmaf(x, pdf, cdf);
+template <bool FAST = false> __device__ __forceinline__ float dgelu_erf_t(float x) {
+    float P, E;
+    gelu_parts<FAST>(x, P, E);
+    return fmaf(x * 0.39894228040143268f, E, P);
 }
+// exact-erf GELU (timm / HF BERT / F.gelu default) and its derivative, accurate form
+__device__ __forceinline__ float gelu_erf(float x) { return gelu_erf_t<false>(x); }
+__device__ __forceinline__ float dgelu_erf(float x) { return dgelu_erf_t<false>(x); }
 // QuickGELU x*sigmoid(1.702x) (reference src/third_party/openai_clip/model.py:172-174)
 __device__ __forceinline__ float quick_gelu(float x) {
     return x * __frcp_rn(1.0f + __expf(-1.702f * x));

@@ -99,16 +99,38 @@ def init_data_parallel(opt=None):
     return rank, local, world
 
 
-def contrastive_step(model, criterion, opt, images, ids, micro_batches=1, lr=None):
-    """One optimiser update: encode → InfoNCE → backward (→ all-reduce) → clip+AdamW.  Returns the loss tensor (device)."""
+_SIDE_STREAM = {}
+
+
+def _side_stream(device):
+    if device not in _SIDE_STREAM:
+        _SIDE_STREAM[device] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAM[device]
+
+
+def contrastive_step(model, criterion, opt, images, ids, micro_batches=1, lr=None, overlap_text=True):
+    """One optimiser update: encode → InfoNCE → backward (→ all-reduce) → clip+AdamW.  Returns the loss tensor (device).
+
+    overlap_text: the frozen text tower does not depend on the image tower, so it runs on a second HIP stream beside
+    encode_image (same kernels, same results); the streams join before the loss."""
     UF.clear_t_copies()
     opt.zero_grad()
     total = None
     mb = images.shape[0] // micro_batches
+    cur = torch.cuda.current_stream()
     for i in range(micro_batches):
         im, tk = images[i * mb:(i + 1) * mb], ids[i * mb:(i + 1) * mb]
-        fi = model.encode_image(im)
-        ft = model.encode_text(tk)
+        if overlap_text:
+            side = _side_stream(images.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                ft = model.encode_text(tk)
+            fi = model.encode_image(im)
+            cur.wait_stream(side)
+            ft.record_stream(cur)
+        else:
+            fi = model.encode_image(im)
+            ft = model.encode_text(tk)
         loss = criterion(fi, ft)
         (loss / micro_batches).backward()
         total = loss.detach() if total is None else total + loss.detach()

@@ -130,7 +130,7 @@ class MonaFn(torch.autograd.Function):
     """y = x + project2(drop(gelu(spatial(project1(LN(x)·γ + x·γx)))))  on batch-first x [B, N, D] fp32."""
 
     @staticmethod
-    def forward(ctx, x, variant, hw, p_drop, keep_mask, names, *params):
+    def forward(ctx, x, variant, hw, p_drop, keep_mask, names, grad_bufs, *params):
         P = dict(zip(names, params))
         B, N, D = x.shape
         h, w = hw
@@ -153,6 +153,7 @@ class MonaFn(torch.autograd.Function):
         ops.gemm(d, w2, bias=P["project2.bias"], resid=x.view(M, D), out32=y.view(M, D))
         ctx.save_for_backward(x, u, t, d, keep_mask if keep_mask is not None else x.new_empty(0), *params)
         ctx.meta = (variant, hw, p_drop, seed, names, keep_mask is not None)
+        ctx.grad_bufs = grad_bufs
         return y
 
     @staticmethod
@@ -167,7 +168,8 @@ class MonaFn(torch.autograd.Function):
         bott = t.shape[1]
         dy = dy.contiguous()
         dy_t = t_copy_of(dy, dt).view(M, D)
-        G = {k: torch.zeros_like(v, dtype=torch.float32) for k, v in P.items()}
+        direct = ctx.grad_bufs is not None          # accumulate straight into the (flat-buffer) .grad views: no fills, no adds
+        G = dict(zip(names, ctx.grad_bufs)) if direct else {k: torch.zeros_like(v, dtype=torch.float32) for k, v in P.items()}
         # project2: dd = dy·W2 ; dW2 = dyᵀ·d ; db2 = Σ dy
         w2t = WEIGHTS.get(P["project2.weight"], dt, transpose=True)          # [bott, D]
         dd = _empty((M, bott), dt, x)
@@ -190,15 +192,19 @@ class MonaFn(torch.autograd.Function):
                          G["gamma"], G["gammax"], G["norm.weight"], G["norm.bias"])
         if need_dx:
             publish_t_copy(dx, dx_t)
-        grads = tuple(G[k] if ctx.needs_input_grad[6 + i] else None for i, k in enumerate(names))
-        return (dx, None, None, None, None, None) + grads
+        grads = tuple(None if direct else (G[k] if ctx.needs_input_grad[7 + i] else None) for i, k in enumerate(names))
+        return (dx, None, None, None, None, None, None) + grads
 
 
 def mona_apply(x_bnd, module_params, variant, hw, p_drop, training, keep_mask=None):
     """module_params: ordered {relative name: Parameter}."""
     names = tuple(k for k in MONA_PARAM_ORDER if k in module_params)
     pd = p_drop if (training or keep_mask is not None) else 0.0
-    return MonaFn.apply(x_bnd, variant, tuple(hw), pd, keep_mask, names, *[module_params[k] for k in names])
+    params = [module_params[k] for k in names]
+    bufs = [p.grad for p in params]
+    direct = torch.is_grad_enabled() and all(p.requires_grad and g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.shape == p.shape
+                                             for p, g in zip(params, bufs))
+    return MonaFn.apply(x_bnd, variant, tuple(hw), pd, keep_mask, names, bufs if direct else None, *params)
 
 
 # ================================================================================================ ViT block

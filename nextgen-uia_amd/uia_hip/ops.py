@@ -24,9 +24,7 @@ def auto_tile_cfg(M, N):
         return 4
     if M <= 2048:
         return 3
-    if N % 256 == 0 and N >= 2048:
-        return 1
-    return 2
+    return 6
 
 
 def _code(dt):
