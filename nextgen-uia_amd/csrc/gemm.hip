@@ -77,6 +77,21 @@ __device__ __forceinline__ void glds16(const char* gsrc, char* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// LDS-DMA issued through inline asm: hipcc models the builtin as an LDS store and drains it (s_waitcnt vmcnt(0)) in front
+// of the next ds_read, which serialises the whole staging pipeline (seen in the .s of the first ping-pong build: the slot
+// that issued the pieces took 2444 cycles against 600-730 for the others).  The asm form is invisible to that pass; the
+// kernels that use it retire their pieces with their own counted s_waitcnt vmcnt(N) + barrier before any read.
+// M0 carries the wave-uniform LDS byte address of the 1 KiB piece (lane i lands at +16·i); it is saved/restored around.
+__device__ __forceinline__ void glds16_asm(const char* gsrc, char* lds_wave_base) {
+    const unsigned dst = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds_wave_base;
+    const unsigned dst_u = __builtin_amdgcn_readfirstlane(dst);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(dst_u)
+                 : "memory");
+}
+
 template <typename T, int MT, int NT, int WTM, int WTN>
 __device__ __forceinline__ void gemm_epilogue(const UiaGemmParams& p, f32x4 (&acc)[MT][NT], int m0, int n0, int wm, int wn, int li, int g) {
     // ---- epilogue: lane owns row m, columns nb .. nb+4NT-1 (nb multiple of 16)
@@ -396,9 +411,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_tn_pp_kernel(cons
         char* base = smem + (s & 1) * BUF_BYTES;
         const size_t koff = (size_t)s * 128;
 #pragma unroll
-        for (int i = 0; i < A_PER_WAVE; ++i) glds16(srcA[i] + koff, base + (wave + NW * i) * 1024);
+        for (int i = 0; i < A_PER_WAVE; ++i) glds16_asm(srcA[i] + koff, base + (wave + NW * i) * 1024);
 #pragma unroll
-        for (int i = 0; i < W_PER_WAVE; ++i) glds16(srcW[i] + koff, base + A_BYTES + (wave + NW * i) * 1024);
+        for (int i = 0; i < W_PER_WAVE; ++i) glds16_asm(srcW[i] + koff, base + A_BYTES + (wave + NW * i) * 1024);
     };
     uint4 af[MT], wf[NT];
     auto load_frags = [&](const char* buf, int kk) {
@@ -436,25 +451,41 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_tn_pp_kernel(cons
         if (nk > 1) stage(1);
         UIA_SLOT_END();
     }
+#ifdef UIA_GEMM_STAMPS
+    unsigned long long sl[4] = {0, 0, 0, 0}, tp = __builtin_amdgcn_s_memtime(), tq;
+#define UIA_SLOT_STAMP(i) do { tq = __builtin_amdgcn_s_memtime(); sl[i] += tq - tp; tp = tq; } while (0)
+#else
+#define UIA_SLOT_STAMP(i)
+#endif
     for (int s = 0; s < nk; ++s) {
         const char* buf = smem + (s & 1) * BUF_BYTES;
         // ---- LOAD(s,0)
         if (grp == 0 && s + 1 < nk) stage(s + 1);
         load_frags(buf, 0);
         UIA_SLOT_END();
+        UIA_SLOT_STAMP(0);
         // ---- COMPUTE(s,0)
         compute();
         UIA_SLOT_END();
+        UIA_SLOT_STAMP(1);
         // ---- LOAD(s,1)
         load_frags(buf, 1);
         if (grp == 1 && s + 1 < nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // wall-clock slot 4s+3
         UIA_SLOT_END();
+        UIA_SLOT_STAMP(2);
         // ---- COMPUTE(s,1)
         if (grp == 1 && s + 2 < nk) stage(s + 2);                                      // wall-clock slot 4(s+1)
         compute();
         if (grp == 0 && s + 1 < nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // wall-clock slot 4s+3
         UIA_SLOT_END();
+        UIA_SLOT_STAMP(3);
     }
+#ifdef UIA_GEMM_STAMPS
+    if (lane == 0 && uia_stamp_buf && wave == 0) {
+        unsigned long long* o = uia_stamp_buf + (size_t)gridDim.x * NW * 4 + (size_t)blockIdx.x * 4;
+        o[0] = sl[0]; o[1] = sl[1]; o[2] = sl[2]; o[3] = sl[3];
+    }
+#endif
     if (grp == 0) {                               // balance group 1's extra slot
         UIA_SLOT_END();
     }
@@ -496,14 +527,17 @@ int launch_pp(hipStream_t stream, const UiaGemmParams& p) {
 // drains its loads.  (Measured on the 2-buffer kernel: 15 B/clk/CU from L2 = one 64 KB burst in flight for ~half
 // the time at ~2000 cycles latency; the ring keeps 64-96 KB in flight all the time.)
 //   step u = one (LOAD, COMPUTE) slot pair = 64 bytes of K per row; sub-tile t = u / SPT, SPT = BKB/64.
-//   wall slot 2·t·SPT     : every wave issues sub-tile t+PD   (group 0: top of LOAD(t·SPT); group 1: top of COMPUTE(t·SPT-1))
-//   wall slot 2·t·SPT - 1 : every wave retires sub-tile t     (group 0: end of COMPUTE;     group 1: end of LOAD)
+//   LOAD(u) of sub-tile t  : the wave issues its share of sub-tile t+PD (1/SPT of its pieces per LOAD slot), so in every
+//                            wall slot the loading group's DMA pieces run beside the other group's MFMA cluster
+//                            (measured on the 2-buffer kernel: 64 pieces issued in ONE slot made that slot 2444 cycles
+//                            against 600-730 for the other three)
+//   wall slot 2·t·SPT - 1  : every wave retires sub-tile t     (group 0: end of COMPUTE;     group 1: end of LOAD)
 //   RAW: sub-tile t is first read in wall slot 2·t·SPT, after that barrier.   WAR: buffer (t+PD)%NBUF last held
 //   sub-tile t-1, whose final ds_reads (group 1, wall slot 2·t·SPT-1) were retired before that slot's barrier.
 // 64-byte rows use the 4-entry swizzle table {0,3,2,1} indexed by (row>>2)&3 (A) / the 16-row block of the
 // permuted W rows: conflict-free ds_read_b128 for both fragment patterns.
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int NBUF>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_tn_ring_kernel(const UiaGemmParams p) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_tn_ring_kernel(const UiaGemmParams p, const int stagger_cycles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
@@ -533,6 +567,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_tn_ring_kernel(co
     }
     const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
+
+    // De-phase the chip: all first-round workgroups start together and, with equal tiles, would reach their epilogues
+    // together (HBM saturated for that phase, idle during the K loops).  Half of the first-round workgroups of every XCD
+    // start half a tile period late, so one half's store/residual traffic overlaps the other half's K loop for the
+    // rest of the launch (later workgroups inherit the offset of the CU they land on).
+    if (stagger_cycles > 0 && blockIdx.x < 256 && ((blockIdx.x >> 3) & 1)) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)stagger_cycles) __builtin_amdgcn_s_sleep(32);
+    }
 
     // swizzle of the 16-byte chunk index: 128-byte rows: (row>>1)&7 / 2a|(b>>1) as in the 2-buffer kernels;
     // 64-byte rows: table {0,3,2,1}[(row>>2)&3] for A, [(row_local>>4)&3] for the permuted W rows.
@@ -570,13 +613,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_tn_ring_kernel(co
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int ntl = (p.K * ESZ) / BKB;                                       // sub-tiles
-    auto stage = [&](int t) {
+    // part = which 1/SPT of this wave's pieces of sub-tile t (the DMA issue is spread over the wave's LOAD slots)
+    auto stage = [&](int t, int part) {
         char* base = smem + (t % NBUF) * BUF_BYTES;
         const size_t koff = (size_t)t * BKB;
 #pragma unroll
-        for (int i = 0; i < A_PER_WAVE; ++i) glds16(srcA[i] + koff, base + (wave + NW * i) * 1024);
-#pragma unroll
-        for (int i = 0; i < W_PER_WAVE; ++i) glds16(srcW[i] + koff, base + A_BYTES + (wave + NW * i) * 1024);
+        for (int i = 0; i < GPT; ++i) {
+            if (i * SPT / GPT != part && SPT > 1) continue;
+            if (i < A_PER_WAVE) glds16_asm(srcA[i] + koff, base + (wave + NW * i) * 1024);
+            else glds16_asm(srcW[i - A_PER_WAVE] + koff, base + A_BYTES + (wave + NW * (i - A_PER_WAVE)) * 1024);
+        }
     };
     uint4 af[MT], wf[NT];
     auto load_frags = [&](const char* buf, int kk) {
@@ -605,12 +651,19 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_tn_ring_kernel(co
         __builtin_amdgcn_sched_barrier(0);                     \
     } while (0)
 
-    for (int t = 0; t < PD && t < ntl; ++t) stage(t);
+#ifdef UIA_GEMM_STAMPS
+    unsigned long long t_start = __builtin_amdgcn_s_memtime(), t_pro = 0, t_loop = 0;
+#endif
+    for (int t = 0; t < PD && t < ntl; ++t)
+#pragma unroll
+        for (int part = 0; part < SPT; ++part) stage(t, part);
     retire(0);
     __builtin_amdgcn_s_barrier();                 // sub-tile 0 resident
     __builtin_amdgcn_sched_barrier(0);
-    if (grp == 1) {                               // wall slot 0 seen from group 1: issue sub-tile PD, fall one slot behind
-        if (PD < ntl) stage(PD);
+#ifdef UIA_GEMM_STAMPS
+    t_pro = __builtin_amdgcn_s_memtime();
+#endif
+    if (grp == 1) {                               // fall one slot behind group 0
         UIA_SLOT_END();
     }
     const int nu = ntl * SPT;
@@ -618,26 +671,37 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_tn_ring_kernel(co
         const int t = u / SPT, kk = u % SPT;
         const char* buf = smem + (t % NBUF) * BUF_BYTES;
         const bool last_of_tile = kk == SPT - 1;
-        // ---- LOAD(u)
-        if (grp == 0 && kk == 0 && t + PD < ntl) stage(t + PD);                   // wall slot 2·t·SPT
+        // ---- LOAD(u): this group's DMA pieces of sub-tile t+PD ride beside the other group's MFMA cluster
+        if (t + PD < ntl) stage(t + PD, kk);
         load_frags(buf, kk);
-        if (grp == 1 && last_of_tile && t + 1 < ntl) retire(t + 1);               // wall slot 2·(t+1)·SPT - 1
+        if (grp == 1 && last_of_tile && t + 1 < ntl) retire(t + 1);
         UIA_SLOT_END();
         // ---- COMPUTE(u)
-        if (grp == 1 && last_of_tile && t + 1 + PD < ntl) stage(t + 1 + PD);      // wall slot 2·(t+1)·SPT
         compute();
-        if (grp == 0 && last_of_tile && t + 1 < ntl) retire(t + 1);               // wall slot 2·(t+1)·SPT - 1
+        if (grp == 0 && last_of_tile && t + 1 < ntl) retire(t + 1);
         UIA_SLOT_END();
     }
     if (grp == 0) {
         UIA_SLOT_END();
     }
 #undef UIA_SLOT_END
+#ifdef UIA_GEMM_STAMPS
+    t_loop = __builtin_amdgcn_s_memtime();
+#endif
     gemm_epilogue_lds<T, MT, NT, WTM, WTN>(p, acc, smem, wave, lane, m0, n0, wm, wn);
+#ifdef UIA_GEMM_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0 && uia_stamp_buf) {
+        unsigned long long t_end = __builtin_amdgcn_s_memtime();
+        unsigned long long* o = uia_stamp_buf + ((size_t)blockIdx.x * NW + wave) * 4;
+        o[0] = t_start; o[1] = t_pro; o[2] = t_loop; o[3] = t_end;
+        if (wave == 0) { unsigned long long* q = uia_stamp_buf + (size_t)gridDim.x * NW * 4 + (size_t)blockIdx.x * 4; q[0] = q[1] = q[2] = q[3] = 0; }
+    }
+#endif
 }
 
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int NBUF>
-int launch_ring(hipStream_t stream, const UiaGemmParams& p) {
+int launch_ring(hipStream_t stream, const UiaGemmParams& p, bool stagger = false) {
     constexpr int LDS = NBUF * (BM + BN) * BKB;
     auto kern = gemm_tn_ring_kernel<T, BM, BN, WAVES_M, WAVES_N, BKB, NBUF>;
     static bool attr_set = false;
@@ -646,7 +710,14 @@ int launch_ring(hipStream_t stream, const UiaGemmParams& p) {
         attr_set = true;
     }
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(64 * WAVES_M * WAVES_N), LDS, stream, p);
+    // half of an estimated tile period (cycles): K loop ~3000 per 64-deep step + epilogue ~ proportional to the bytes it moves
+    int stag = 0;
+    if (stagger && tiles > 256) {
+        const int ksteps = (p.K * (int)sizeof(T)) / 128;
+        const int epi = 8000 + (p.outT ? 7000 : 0) + (p.aux_out ? 25000 : 0) + (p.out32 ? 14000 : 0) + (p.resid ? 14000 : 0) + (p.aux_in ? 7000 : 0);
+        stag = (ksteps * 3000 + epi) / 2;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(64 * WAVES_M * WAVES_N), LDS, stream, p, stag);
     UIA_CHECK_LAUNCH();
     return 0;
 }
@@ -658,7 +729,7 @@ int launch_typed(hipStream_t stream, const UiaGemmParams& p, int cfg) {
     if (cfg == 0) {
         if (p.N <= 64) cfg = 4;
         else if (p.M <= 2048) cfg = 3;
-        else cfg = 6;            // 256x256 ping-pong + LDS-staged epilogue: best measured on every large shape (N = 768 included)
+        else cfg = 8;            // 256x256 ping-pong, 4-deep 64-byte ring, LDS-staged epilogue: best measured on every large shape
     }
     switch (cfg) {
         case 1: return launch_cfg<T, 256, 256, 2, 4>(stream, p);
@@ -671,6 +742,7 @@ int launch_typed(hipStream_t stream, const UiaGemmParams& p, int cfg) {
         case 8: return launch_ring<T, 256, 256, 2, 4, 64, 4>(stream, p);
         case 9: return launch_ring<T, 256, 128, 4, 2, 128, 3>(stream, p);
         case 10: return launch_ring<T, 256, 256, 2, 4, 64, 5>(stream, p);
+        case 11: return launch_ring<T, 256, 256, 2, 4, 64, 4>(stream, p, true);
         default: uia_set_error("uia_gemm: unknown tile config %d", cfg); return -1;
     }
 }

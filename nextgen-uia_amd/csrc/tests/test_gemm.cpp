@@ -115,18 +115,21 @@ static void bench(int dtype, int M, int N, int K, int cfg, int mode) {
 #ifdef UIA_GEMM_STAMPS
 extern __device__ unsigned long long* uia_stamp_buf;
 static void stamps(int cfg, int M, int N, int K, int mode) {
-    const int BM = 256, BN = cfg == 6 ? 256 : 128, NW = 8;
+    const int BM = 256, BN = (cfg == 7 || cfg == 9) ? 128 : 256, NW = 8;
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-    unsigned long long* d; HC(hipMalloc(&d, (size_t)tiles * NW * 4 * 8));
+    unsigned long long* d; HC(hipMalloc(&d, ((size_t)tiles * NW * 4 + (size_t)tiles * 4) * 8));
     HC(hipMemcpyToSymbol(HIP_SYMBOL(uia_stamp_buf), &d, sizeof(d)));
     bench(UIA_BF16, M, N, K, cfg, mode);
-    std::vector<unsigned long long> h((size_t)tiles * NW * 4);
+    std::vector<unsigned long long> h((size_t)tiles * NW * 4 + (size_t)tiles * 4);
     HC(hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost));
     double pro = 0, loop = 0, epi = 0, tot = 0; unsigned long long t0 = ~0ull, t1 = 0;
     for (int i = 0; i < tiles * NW; ++i) { pro += h[4*i+1]-h[4*i]; loop += h[4*i+2]-h[4*i+1]; epi += h[4*i+3]-h[4*i+2]; tot += h[4*i+3]-h[4*i]; if (h[4*i] < t0) t0 = h[4*i]; if (h[4*i+3] > t1) t1 = h[4*i+3]; }
     const double n = (double)tiles * NW;
     printf("STAMPS cfg=%d M=%d N=%d K=%d mode=%d: per-wave ticks (100MHz s_memtime? see ratio) prologue %.0f  k-loop %.0f (%.0f per K-step)  epilogue %.0f  total %.0f ; kernel span %llu ticks\n",
            cfg, M, N, K, mode, pro / n, loop / n, loop / n / (K / 64), epi / n, tot / n, t1 - t0);
+    { double sl[4] = {0,0,0,0}; const unsigned long long* q = h.data() + (size_t)tiles * NW * 4;
+      for (int i = 0; i < tiles; ++i) for (int k = 0; k < 4; ++k) sl[k] += q[4*i+k];
+      printf("   group-0 wave-0 slot cycles per K-step: LOAD0(+8 glds) %.0f | COMPUTE0 %.0f | LOAD1 %.0f | COMPUTE1(+vmcnt) %.0f\n", sl[0]/tiles/(K/64), sl[1]/tiles/(K/64), sl[2]/tiles/(K/64), sl[3]/tiles/(K/64)); }
     unsigned long long z = 0; HC(hipMemcpyToSymbol(HIP_SYMBOL(uia_stamp_buf), &z, sizeof(z))); hipFree(d);
 }
 #endif
@@ -134,9 +137,10 @@ static void stamps(int cfg, int M, int N, int K, int mode) {
 int main(int argc, char** argv) {
 #ifdef UIA_GEMM_STAMPS
     stamps(6, 50432, 2304, 768, 0);
-    stamps(6, 50432, 3072, 768, 1);
-    stamps(7, 50432, 768, 3072, 2);
-    stamps(7, 50432, 768, 768, 2);
+    stamps(8, 50432, 2304, 768, 0);
+    stamps(8, 50432, 3072, 768, 1);
+    stamps(8, 50432, 768, 3072, 2);
+    stamps(8, 50432, 768, 768, 2);
     stamps(6, 8192, 8192, 8192, 0);
     return 0;
 #endif
@@ -150,7 +154,7 @@ int main(int argc, char** argv) {
     const int dts[2] = {UIA_BF16, UIA_F32};
     for (int d = 0; d < 2; ++d) {
         const int dt = dts[d];
-        for (int cfg = 1; cfg <= 10; ++cfg) {
+        for (int cfg = 1; cfg <= 11; ++cfg) {
             const int N = (cfg == 4 || cfg == 5) ? 64 : 384;
             fails += check(dt, 300, N, 128, cfg, 0);          // ragged M, single N tile edge
             fails += check(dt, 197 * 3, N, 256, cfg, 1);
@@ -164,7 +168,7 @@ int main(int argc, char** argv) {
     printf("correctness: %d failures\n", fails);
     if (argc > 1 && !strcmp(argv[1], "bench")) {
         const int M = 50432;
-        for (int cfg : {6, 7, 8, 9, 10}) {
+        for (int cfg : {8, 11}) {
             bench(UIA_BF16, M, 2304, 768, cfg, 0);
             bench(UIA_BF16, M, 768, 768, cfg, 2);
             bench(UIA_BF16, M, 3072, 768, cfg, 1);

@@ -24,7 +24,7 @@ def auto_tile_cfg(M, N):
         return 4
     if M <= 2048:
         return 3
-    return 6
+    return 8
 
 
 def _code(dt):
