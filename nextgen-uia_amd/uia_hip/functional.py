@@ -329,33 +329,34 @@ class ClsHeadFn(torch.autograd.Function):
     """feat = LN(x[:,0]) @ Wᵀ  (final norm + CLS pool + bias-free projection); frozen weights, dgrad to x."""
 
     @staticmethod
-    def forward(ctx, x, ln_w, ln_b, eps, w_out_in):
+    def forward(ctx, x, ln_w, ln_b, eps, w, w_is_in_out=False):
+        """w: [out, in] (nn.Linear weight, timm head.proj) or, with w_is_in_out, [in, out] (OpenAI `x @ proj`)."""
         B, N, D = x.shape
         dt = compute_dtype()
         x = x.contiguous()
         h = _empty((B, D), dt, x)
         ops.layernorm_fwd(x, ln_w, ln_b, eps, y_t=h, rows=B, ldx=N * D)
-        E = w_out_in.shape[0]
+        E = w.shape[1] if w_is_in_out else w.shape[0]
         feat = torch.empty(B, E, device=x.device, dtype=torch.float32)
-        ops.gemm(h, WEIGHTS.get(w_out_in, dt), out32=feat)
+        ops.gemm(h, WEIGHTS.get(w, dt, transpose=w_is_in_out), out32=feat)
         ctx.save_for_backward(x, ln_w)
-        ctx.meta = (eps, w_out_in)
+        ctx.meta = (eps, w, w_is_in_out)
         return feat
 
     @staticmethod
     def backward(ctx, dfeat):
         x, ln_w = ctx.saved_tensors
-        eps, w = ctx.meta
+        eps, w, w_is_in_out = ctx.meta
         B, N, D = x.shape
         dt = compute_dtype()
         df = t_copy_of(dfeat.contiguous(), dt)
         dh = _empty((B, D), dt, x)
-        ops.gemm(df, WEIGHTS.get(w, dt, transpose=True), out_t=dh)
+        ops.gemm(df, WEIGHTS.get(w, dt, transpose=not w_is_in_out), out_t=dh)
         dx = torch.zeros_like(x)
         dx_t = torch.zeros(B * N, D, device=x.device, dtype=dt) if dt != torch.float32 else None
         ops.layernorm_bwd(dh, x, ln_w, eps, dx32=dx, dx_t=dx_t, rows=B, ldx=N * D)
         publish_t_copy(dx, dx_t)
-        return dx, None, None, None, None
+        return dx, None, None, None, None, None
 
 
 # ================================================================================================ op-level functions
