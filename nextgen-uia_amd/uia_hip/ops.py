@@ -44,6 +44,8 @@ def _p(t):
 
 
 def _stream():
+    if not torch.cuda.is_available():
+        raise UiaError("uia ops need an MI355X (HIP) device: there is no CPU fallback for the hot path")
     return torch.cuda.current_stream().cuda_stream
 
 

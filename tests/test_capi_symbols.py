@@ -1,0 +1,60 @@
+"""CPU: libuia_hip.so loads and exports exactly the entry points include/uia_hip.h declares, and the ctypes prototype table
+covers all of them (no compute calls: there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "uia_hip.h")
+
+
+def declared():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(uia_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_functions():
+    names = declared()
+    assert len(names) >= 29 and "uia_gemm" in names and "uia_mona_spatial_bwd" in names and "uia_allreduce_sum" in names
+
+
+def test_library_exports_every_declared_symbol():
+    from uia_hip import _lib
+    assert os.path.exists(_lib.LIB_PATH), "run `python -c 'import __graft_entry__ as g; g.build()'` first"
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [n for n in declared() if not hasattr(handle, n)]
+    assert not missing, f"declared in include/uia_hip.h but not exported: {missing}"
+
+
+def test_ctypes_table_matches_header():
+    from uia_hip import _lib
+    names = set(declared())
+    table = set(_lib.PROTOTYPES)
+    assert table == names, f"only in header: {sorted(names - table)}; only in ctypes table: {sorted(table - names)}"
+
+
+def test_descriptor_struct_sizes_match_c_layout():
+    """The ctypes mirrors of uia_gemm_desc / uia_attn_desc / uia_mona_spatial_desc must have the C layout (LP64)."""
+    from uia_hip import _lib
+    assert ctypes.sizeof(_lib.GemmDesc) == 176
+    assert ctypes.sizeof(_lib.AttnDesc) == 136
+    assert ctypes.sizeof(_lib.MonaSpatialDesc) % 8 == 0 and ctypes.sizeof(_lib.MonaSpatialDesc) == 288
+
+
+def test_error_path_without_gpu():
+    from uia_hip import _lib
+    lib = _lib.lib()
+    assert lib.uia_version() >= 100
+    assert lib.uia_gemm(None, 1, None, 0) != 0                       # null descriptor is rejected before any launch
+    assert b"null descriptor" in lib.uia_last_error()
+
+
+def test_header_is_plain_c(tmp_path):
+    """The boundary is a C ABI: the header must compile as C (gcc), with no C++ or torch types."""
+    import subprocess
+    src = tmp_path / "t.c"
+    src.write_text('#include "uia_hip.h"\nint main(void){ return (int)sizeof(uia_gemm_desc) == 0; }\n')
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-fsyntax-only", str(src)], check=True)

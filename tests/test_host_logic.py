@@ -1,0 +1,149 @@
+"""CPU: host-side logic of the drop-in surface — names (the checkpoint wire format), injector behaviour, parameter counts,
+error behaviour, and the absence of any CPU fallback on the product path."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+TOY = dict(embed_dim=128, vision_cfg=dict(img_size=32, patch_size=8, embed_dim=128, depth=3, num_heads=2),
+           text_cfg=dict(vocab_size=120, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                         max_position_embeddings=40))
+VARIANTS = ("baseline", "noise_aware", "freq_enhanced", "hybrid")
+
+
+def test_adapters_package_exports():
+    import src.adapters as A
+    for name in ("BaselineMona", "NoiseAwareMona", "FreqEnhancedMona", "FreqEnhancedMonaOp", "inject_mona_variant_to_clip",
+                 "inject_mona_variant_to_open_clip", "inject_lora_to_clip", "inject_lora_to_biomedclip"):
+        assert hasattr(A, name)                                       # reference __init__.py:21-34, minus the names that do not exist
+    for missing in ("FractionalMona", "SimplePromptTuner", "create_simple_prompt_tuner"):
+        with pytest.raises(NotImplementedError):
+            getattr(A, missing)
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_mona_parameter_names_match_reference(golden, variant):
+    """named_parameters() order and shapes == the reference module's (captured in the golden fixture)."""
+    from src.adapters import mona as M
+    g = golden(f"mona_{variant}")
+    want = [k[2:] for k in g if k.startswith("p.")]
+    mod = M._VARIANTS[variant](32, 8)
+    got = [k for k, _ in mod.named_parameters()]
+    assert got == want
+    for k, p in mod.named_parameters():
+        assert tuple(p.shape) == tuple(g["p." + k].shape), k
+    assert float(mod.gamma[0]) == pytest.approx(1e-6) and float(mod.gammax[0]) == 1.0 and mod.dropout.p == 0.1
+
+
+@pytest.mark.parametrize("variant,count", [("baseline", 1342464), ("freq_enhanced", 1343232), ("hybrid", 1356324)])
+def test_mona_trainable_count_full_size(variant, count):
+    """trainable elements of 12 Mona layers (b=64) on ViT-B/16 — the all-reduce payload."""
+    from src.adapters import mona as M
+    per_layer = sum(p.numel() for p in M._VARIANTS[variant](768, 64).parameters())
+    assert 12 * per_layer == count
+
+
+def test_inject_mona_open_clip_layout_and_names():
+    from src.adapters import inject_mona_variant_to_open_clip, BatchFirstMonaWrapper
+    from src.third_party.biomedclip.model import create_biomedclip
+    model = create_biomedclip(config=TOY)
+    text_before = {k: v.clone() for k, v in model.text.state_dict().items()}
+    model, n = inject_mona_variant_to_open_clip(model, variant="freq_enhanced", bottleneck_dim=64, num_layers=2)
+    assert n == 2
+    blocks = model.visual.trunk.blocks
+    assert isinstance(blocks[0].mona, BatchFirstMonaWrapper) and not hasattr(blocks[2], "mona")
+    names = [k for k, _ in model.named_parameters() if "mona" in k]
+    assert names[0] == "visual.trunk.blocks.0.mona.clip_mona.gamma"
+    assert "visual.trunk.blocks.1.mona.clip_mona.adapter_conv.freq_filter" in names
+    assert "forward" in blocks[0].__dict__ and "forward" not in blocks[2].__dict__   # instance-level patch, as the reference does
+    for k, v in model.text.state_dict().items():
+        assert torch.equal(v, text_before[k])                                         # the text tower is never touched
+    with pytest.raises(ValueError):
+        inject_mona_variant_to_open_clip(model, variant="fractional")                 # accepted by the CLI, rejected by the injector (reference :604-605)
+
+
+def test_inject_mona_clip_layout_and_names():
+    from src.adapters import inject_mona_variant_to_clip
+    from src.third_party.openai_clip.model import CLIP
+    model = CLIP(64, 32, 2, 128, 8, 16, 100, 128, 2, 2)
+    model, n = inject_mona_variant_to_clip(model, variant="hybrid", bottleneck_dim=64)
+    assert n == 2
+    names = [k for k, _ in model.named_parameters() if "mona" in k]
+    assert names[0] == "visual.transformer.resblocks.0.mona.gamma"                    # no wrapper on the sequence-first layout
+    assert any(k.endswith("mona.adapter_conv.noise_estimator.3.bias") for k in names)
+    with pytest.raises(ValueError):
+        inject_mona_variant_to_clip(model, variant="nope")
+
+
+def test_lora_modules_names_init_and_quirks():
+    from src.adapters.lora import LinearLoRA, PlainMultiheadAttentionLoRA, inject_lora_to_biomedclip, inject_lora_to_clip
+    from src.third_party.biomedclip.model import create_biomedclip
+    from src.third_party.openai_clip.model import CLIP
+    lin = torch.nn.Linear(8, 6)
+    ll = LinearLoRA(lin, r=2, lora_alpha=4, dropout_rate=0.1)
+    assert [k for k, _ in ll.named_parameters()] == ["weight", "bias", "w_lora_A", "w_lora_B"]
+    assert tuple(ll.w_lora_A.shape) == (2, 8) and tuple(ll.w_lora_B.shape) == (6, 2)
+    assert ll.scaling == pytest.approx(4 / math.sqrt(2)) and float(ll.w_lora_B.abs().max()) == 0.0 and float(ll.w_lora_A.abs().max()) > 0
+    assert not ll.weight.requires_grad and ll.bias.requires_grad                      # reference quirk: the copied bias stays trainable (SURVEY C-4)
+    assert torch.equal(ll.weight, lin.weight) and torch.allclose(ll.merge_BA("weight"), torch.zeros(6, 8))
+
+    model = create_biomedclip(config=TOY)
+    model, n = inject_lora_to_biomedclip(model, lora_r=4, lora_alpha=8, lora_dropout=0.1, num_layers=2)
+    assert n == 2 and isinstance(model.visual.trunk.blocks[1].attn.qkv, LinearLoRA) and not isinstance(model.visual.trunk.blocks[2].attn.qkv, LinearLoRA)
+    assert "visual.trunk.blocks.0.attn.qkv.w_lora_A" in dict(model.named_parameters())
+    model, n = inject_lora_to_biomedclip(create_biomedclip(config=TOY), lora_r=4, tune_text_encoder=True)
+    assert n == 3 + 2 and isinstance(model.text.transformer.encoder.layer[0].attention.self.query, LinearLoRA)
+
+    clip = CLIP(64, 32, 2, 128, 8, 16, 100, 128, 2, 2)
+    w = clip.visual.transformer.resblocks[0].attn.in_proj_weight.detach().clone()
+    clip, n = inject_lora_to_clip(clip, lora_r=4, lora_alpha=8)
+    attn = clip.visual.transformer.resblocks[0].attn
+    assert n == 2 and isinstance(attn, PlainMultiheadAttentionLoRA)
+    assert torch.equal(attn.k_proj.weight, w[128:256]) and isinstance(clip.transformer.resblocks[0].attn, torch.nn.MultiheadAttention)
+    assert sorted(k for k, _ in attn.named_parameters())[:4] == ["k_proj.bias", "k_proj.w_lora_A", "k_proj.w_lora_B", "k_proj.weight"]
+
+
+def test_no_cpu_fallback_on_product_path():
+    """CPU tensors must be refused loudly: the hot path exists only in libuia_hip.so."""
+    from uia_hip._lib import UiaError
+    from src.adapters import FreqEnhancedMona
+    from src.losses import InfoNCELoss
+    m = FreqEnhancedMona(128, 64)
+    with pytest.raises(UiaError):
+        m(torch.randn(17, 2, 128), (4, 4))
+    with pytest.raises(UiaError):
+        InfoNCELoss()(torch.randn(4, 8), torch.randn(4, 8))
+    with pytest.raises(RuntimeError):
+        m.adapter_conv(torch.randn(2, 64, 4, 4))                                      # the spatial op never runs un-fused
+
+
+def test_product_does_not_import_oracle():
+    import os
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "nextgen-uia_amd")
+    for d, _, files in os.walk(root):
+        for f in files:
+            if f.endswith(".py"):
+                text = open(os.path.join(d, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f"{f} imports the oracle"
+
+
+def test_cosine_lr_matches_torch_scheduler():
+    from uia_hip.engine import cosine_lr
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([p], lr=1e-4)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=50, eta_min=1e-8)
+    for t in range(1, 51):
+        opt.step()
+        sched.step()
+        assert opt.param_groups[0]["lr"] == pytest.approx(cosine_lr(1e-4, 1e-8, t, 50), rel=1e-6, abs=1e-12)
+
+
+def test_synthetic_tokenizer_shape_and_padding():
+    from src.third_party.biomedclip.model import SyntheticTokenizer
+    tok = SyntheticTokenizer(256)
+    ids = tok(["breast ultrasound image with a benign tumor", "x"])
+    assert tuple(ids.shape) == (2, 256) and ids.dtype == torch.long
+    assert int(ids[0, 0]) == 2 and int(ids[0, 8]) == 3 and int(ids[0, 9:].abs().sum()) == 0 and int((ids[1] != 0).sum()) == 3
+    assert torch.equal(ids, tok(["breast ultrasound image with a benign tumor", "x"]))
