@@ -1,0 +1,190 @@
+"""BiomedCLIP contrastive fine-tuning on the MI355X HIP path — drop-in for /root/reference/src/models/biomedclip/finetune.py.
+
+Same command line (every flag and default of reference :32-111), same loop semantics (:211-361): micro-batch InfoNCE,
+(loss / accumulation_steps).backward(), non-finite batches skipped, clip_grad_norm_ → AdamW → cosine LR once per cycle,
+validation each epoch, best-val checkpoint of the adapter parameters only (names containing "mona"/"lora", :200-208),
+early stopping, runs/<exp>/{log.log,best_model.pth}.  Added, non-breaking: --dtype {bf16,fp32}, --synthetic / --data_pt,
+--ckpt_path (an open_clip BiomedCLIP state dict; without it the towers are randomly initialised because the build image
+has no network), and data parallelism when launched under torch.distributed.run (one process per GPU, one RCCL
+all-reduce of the flat adapter-gradient buffer per optimiser update ≡ the reference's accumulation).
+
+What differs underneath: encode_image / encode_text / loss / backward / optimiser run in libuia_hip.so (uia_hip.*).
+`--method full` (the reference's default, which trains every backbone weight) needs weight gradients of the frozen-path
+kernels and is not on this path: it raises.
+"""
+import argparse
+import logging
+import math
+import os
+import random
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[3]))
+
+import numpy as np
+import torch
+
+from src.adapters import inject_lora_to_biomedclip, inject_mona_variant_to_open_clip
+from src.datasets import finetune as dataset_finetune
+from src.losses import InfoNCELoss
+from src.third_party.biomedclip.model import SyntheticTokenizer, create_biomedclip
+from src.utils.tools import model_summary, setup_logging
+from uia_hip import functional as UF
+from uia_hip.engine import FlatAdapterOptimizer, cosine_lr, init_data_parallel
+
+
+def get_args(argv=None):
+    p = argparse.ArgumentParser("BiomedCLIP Fine-tuning")
+    p.add_argument("--img_size", type=int, default=224)
+    p.add_argument("--num_workers", type=int, default=8)
+    p.add_argument("--strong_augs", default=False, action=argparse.BooleanOptionalAction)
+    p.add_argument("--weak_augs", default=False, action=argparse.BooleanOptionalAction)
+    p.add_argument("--exp", type=str, default="biomedclip_finetune")
+    p.add_argument("--in_channels", type=int, default=3)
+    p.add_argument("--ckpt", type=str, default=None, help="Path to finetuned model checkpoint")
+    p.add_argument("--method", type=str, default="full", choices=["full", "mona", "lora"])
+    p.add_argument("--tune_text_encoder", default=False, action="store_true")
+    p.add_argument("--tune_layers", type=str, default="all", choices=["last3", "last6", "last9", "all"])
+    p.add_argument("--mona_variant", type=str, default="freq_enhanced", choices=["baseline", "fractional", "noise_aware", "freq_enhanced", "hybrid"])
+    p.add_argument("--mona_bottleneck", type=int, default=64)
+    p.add_argument("--mona_layers", type=int, default=None)
+    p.add_argument("--lora_r", type=int, default=16)
+    p.add_argument("--lora_alpha", type=int, default=32)
+    p.add_argument("--lora_dropout", type=float, default=0.1)
+    p.add_argument("--lora_layers", type=int, default=None)
+    p.add_argument("--temperature", type=float, default=0.07)
+    p.add_argument("--seed", type=int, default=1)
+    p.add_argument("--epochs", type=int, default=32)
+    p.add_argument("--batch_size", type=int, default=64)
+    p.add_argument("--lr", type=float, default=1e-4)
+    p.add_argument("--lr_min", type=float, default=1e-8)
+    p.add_argument("--weight_decay", type=float, default=0.01)
+    p.add_argument("--beta1_adam", type=float, default=0.9)
+    p.add_argument("--beta2_adam", type=float, default=0.95)
+    p.add_argument("--device", type=str, default="cuda:0" if torch.cuda.is_available() else "cpu")
+    p.add_argument("--patience", type=int, default=10)
+    p.add_argument("--accumulation_steps", type=int, default=4)
+    p.add_argument("--grad_clip", type=float, default=1.0)
+    # additions of this build
+    p.add_argument("--dtype", type=str, default="bf16", choices=["bf16", "fp32"], help="operand precision of the HIP kernels")
+    p.add_argument("--synthetic", action="store_true", help="synthetic image-caption pairs (no dataset files needed)")
+    p.add_argument("--synthetic_train", type=int, default=512)
+    p.add_argument("--synthetic_val", type=int, default=128)
+    p.add_argument("--data_pt", type=str, default=None, help=".pt with {'images': [N,3,S,S], 'texts': [str]}")
+    p.add_argument("--ckpt_path", type=str, default=None, help="open_clip BiomedCLIP state dict (.pt); random init if absent")
+    p.add_argument("--model_config", type=str, default=None, help="python dict literal overriding the BiomedCLIP geometry (tests)")
+    return p.parse_args(argv)
+
+
+def prepare_model(args):
+    cfg = eval(args.model_config) if args.model_config else None
+    state = torch.load(args.ckpt_path, map_location="cpu") if args.ckpt_path else None
+    model = create_biomedclip(state_dict=state, config=cfg, seed=args.seed)
+    tokenizer = SyntheticTokenizer(256 if cfg is None else cfg["text_cfg"]["max_position_embeddings"])
+    model.float()
+    if args.method == "full":
+        raise NotImplementedError("--method full trains the backbone weights; the HIP path implements the adapter methods "
+                                  "(--method mona | lora) named by the fine-tune hot path")
+    for p in model.parameters():
+        p.requires_grad = False
+    if args.method == "mona":
+        inject_mona_variant_to_open_clip(model, variant=args.mona_variant, bottleneck_dim=args.mona_bottleneck, num_layers=args.mona_layers)
+        key = "mona"
+        logging.info(f"MONA variant: {args.mona_variant}, bottleneck: {args.mona_bottleneck}")
+    else:
+        inject_lora_to_biomedclip(model, lora_r=args.lora_r, lora_alpha=args.lora_alpha, lora_dropout=args.lora_dropout,
+                                  num_layers=args.lora_layers, tune_text_encoder=args.tune_text_encoder)
+        key = "lora"
+        logging.info(f"LoRA rank: {args.lora_r}, alpha: {args.lora_alpha}, dropout: {args.lora_dropout}")
+    for name, p in model.named_parameters():
+        if key in name.lower():
+            p.requires_grad = True
+    model.to(args.device)
+    tr = sum(p.numel() for p in model.parameters() if p.requires_grad)
+    tot = sum(p.numel() for p in model.parameters())
+    logging.info(f"Trainable parameters: {tr:,} / {tot:,} ({100 * tr / tot:.2f}%)")
+    return model, tokenizer
+
+
+def _save_checkpoint(model, args, save_path):
+    key = "mona" if args.method == "mona" else "lora"
+    torch.save({n: p.data.clone() for n, p in model.named_parameters() if key in n.lower()}, save_path)
+
+
+def train(args):
+    UF.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+    UF.set_dropout_seed(args.seed)
+    model, tokenizer = prepare_model(args)
+    model.train()
+    logging.info(model_summary({"model": model}))
+    dm = dataset_finetune.DataModule(args)
+    trainloader, valloader = dm.train_dataloader(), dm.val_dataloader()
+    criterion = InfoNCELoss(temperature=args.temperature)
+    opt = FlatAdapterOptimizer([(n, p) for n, p in model.named_parameters() if p.requires_grad], lr=args.lr,
+                               betas=(args.beta1_adam, args.beta2_adam), weight_decay=args.weight_decay, max_norm=args.grad_clip)
+    rank, _, world = init_data_parallel(opt) if int(os.environ.get("WORLD_SIZE", 1)) > 1 else (0, 0, 1)
+    updates_per_epoch = math.ceil(len(trainloader) / args.accumulation_steps)
+    total_updates = updates_per_epoch * args.epochs
+    logging.info(f"Gradient accumulation steps: {args.accumulation_steps}; updates per epoch: {updates_per_epoch}; world: {world}")
+
+    update_count, best_loss, best_epoch, patience = 0, float("inf"), 0, 0
+    opt.zero_grad()
+    for epoch in range(args.epochs):
+        model.train()
+        ep_loss, ep_n, in_cycle = 0.0, 0, 0
+        for batch_idx, (images, texts) in enumerate(trainloader):
+            images = images.to(args.device)
+            tokens = tokenizer(list(texts)).to(args.device)
+            loss = criterion(model.encode_image(images), model.encode_text(tokens))
+            if not torch.isfinite(loss):
+                logging.warning(f"Non-finite loss detected at batch {batch_idx} in epoch {epoch + 1}, skipping batch")
+                continue
+            (loss / args.accumulation_steps).backward()
+            ep_loss += loss.item()
+            ep_n += 1
+            in_cycle += 1
+            if ((batch_idx + 1) % args.accumulation_steps == 0) or (batch_idx + 1 == len(trainloader)):
+                opt.all_reduce()
+                update_count += 1
+                opt.step(lr=cosine_lr(args.lr, args.lr_min, update_count - 1, total_updates))
+                opt.zero_grad()
+                UF.clear_t_copies()
+                in_cycle = 0
+        model.eval()
+        val_loss, val_n = 0.0, 0
+        with torch.no_grad():
+            for images, texts in valloader:
+                loss = criterion(model.encode_image(images.to(args.device)), model.encode_text(tokenizer(list(texts)).to(args.device)))
+                if torch.isfinite(loss):
+                    val_loss += loss.item()
+                    val_n += 1
+        avg_val, avg_train = (val_loss / val_n if val_n else 0.0), (ep_loss / ep_n if ep_n else 0.0)
+        if avg_val < best_loss:
+            best_loss, patience, best_epoch = avg_val, 0, epoch
+            if rank == 0:
+                _save_checkpoint(model, args, os.path.join(args.train_snapshot_path, "best_model.pth"))
+            logging.info(f"\nBest model saved at epoch {epoch + 1} with validation loss {best_loss:.4f}")
+        else:
+            patience += 1
+        logging.info(f"Epoch {epoch + 1}: Train={avg_train:.4f}, Val={avg_val:.4f}, Best={best_loss:.4f}")
+        if patience >= args.patience:
+            logging.info(f"\nEarly stopping at epoch {epoch + 1} as validation loss did not improve for {args.patience} epochs.")
+            break
+    logging.info(f"\n✓ Training completed! Best validation loss: {best_loss:.4f} at epoch {best_epoch + 1}")
+    return {"best_val": best_loss, "updates": update_count, "last_train": avg_train}
+
+
+def main(argv=None):
+    args = get_args(argv)
+    random.seed(args.seed)
+    np.random.seed(args.seed)
+    torch.manual_seed(args.seed)
+    args.train_snapshot_path = f"runs/{args.exp}"
+    os.makedirs(args.train_snapshot_path, exist_ok=True)
+    setup_logging(args, args.train_snapshot_path)
+    return train(args)
+
+
+if __name__ == "__main__":
+    main()

@@ -147,3 +147,17 @@ def test_synthetic_tokenizer_shape_and_padding():
     assert tuple(ids.shape) == (2, 256) and ids.dtype == torch.long
     assert int(ids[0, 0]) == 2 and int(ids[0, 8]) == 3 and int(ids[0, 9:].abs().sum()) == 0 and int((ids[1] != 0).sum()) == 3
     assert torch.equal(ids, tok(["breast ultrasound image with a benign tumor", "x"]))
+
+
+def test_finetune_cli_matches_reference_flags():
+    """Flag names and defaults of reference biomedclip/finetune.py:32-111 (the CLI is part of the drop-in contract)."""
+    from src.models.biomedclip.finetune import get_args
+    a = get_args([])
+    ref = dict(img_size=224, num_workers=8, exp="biomedclip_finetune", in_channels=3, ckpt=None, method="full", tune_text_encoder=False,
+               tune_layers="all", mona_variant="freq_enhanced", mona_bottleneck=64, mona_layers=None, lora_r=16, lora_alpha=32,
+               lora_dropout=0.1, lora_layers=None, temperature=0.07, seed=1, epochs=32, batch_size=64, lr=1e-4, lr_min=1e-8,
+               weight_decay=0.01, beta1_adam=0.9, beta2_adam=0.95, patience=10, accumulation_steps=4, grad_clip=1.0,
+               strong_augs=False, weak_augs=False)
+    for k, v in ref.items():
+        assert getattr(a, k) == v, k
+    assert get_args(["--mona_variant", "fractional"]).mona_variant == "fractional"     # accepted here, rejected by the injector

@@ -353,3 +353,17 @@ def test_openai_clip_lora_vs_oracle(mode):
     fi.square().sum().backward()
     assert rel(fi, fr) < TOL[mode]
     check_grads(model, leaves, mode)
+
+
+def test_finetune_entry_point_runs_and_saves_adapter_checkpoint(tmp_path, monkeypatch):
+    """python -m src.models.biomedclip.finetune --method mona --synthetic: loss goes down, best_model.pth holds only adapter names."""
+    from src.models.biomedclip import finetune
+    monkeypatch.chdir(tmp_path)
+    cfg = ("dict(embed_dim=128, vision_cfg=dict(img_size=32, patch_size=8, embed_dim=128, depth=2, num_heads=2), "
+           "text_cfg=dict(vocab_size=30000, hidden_size=128, num_hidden_layers=1, num_attention_heads=2, intermediate_size=256, max_position_embeddings=64))")
+    out = finetune.main(["--method", "mona", "--mona_variant", "hybrid", "--synthetic", "--synthetic_train", "64", "--synthetic_val", "16",
+                         "--img_size", "32", "--batch_size", "16", "--accumulation_steps", "2", "--epochs", "3", "--lr", "2e-3",
+                         "--dtype", "fp32", "--exp", "t", "--model_config", cfg])
+    ck = torch.load(tmp_path / "runs" / "t" / "best_model.pth")
+    assert ck and all("mona" in k for k in ck) and "visual.trunk.blocks.0.mona.clip_mona.gamma" in ck
+    assert out["updates"] == 3 * 2 and math.isfinite(out["best_val"]) and (tmp_path / "runs" / "t" / "log.log").exists()
