@@ -25,4 +25,4 @@ Pinning (how we know the oracle is right) — see ``oracle/gen_golden.py`` and `
     PARITY UNPINNED.
 """
 
-from . import mona_ref, lora_ref, losses_ref, vit_ref, text_ref, train_ref  # noqa: F401
+from . import mona_ref, lora_ref, losses_ref, vit_ref, text_ref, train_ref, clipseg_ref  # noqa: F401

@@ -237,6 +237,45 @@ def gen_hf_crosschecks():
     save("hf_bert_tiny", **arrays)
 
 
+def gen_clipseg(model_mod):
+    """Reference CLIPSegAdapter (built with __new__: its __init__ downloads weights) around the installed HF decoder."""
+    adapter_mod = load_by_path("ref_clipseg_adapter", "src/third_party/openai_clip/clipseg_adapter.py")
+    from transformers import CLIPSegConfig
+    from transformers.models.clipseg.modeling_clipseg import CLIPSegDecoder
+    torch.manual_seed(0)
+    clip = model_mod.CLIP(64, 64, 3, 64, 16, 8, 50, 64, 2, 2).float().eval()         # image 64, patch 16 -> 4x4 grid; 3 vision layers, width 64 (1 head)
+    fill_module(clip, 0.31, 0.08)
+    with torch.no_grad():
+        for k, p in clip.named_parameters():
+            if k.endswith(("ln_1.weight", "ln_2.weight", "ln_pre.weight", "ln_post.weight", "ln_final.weight")):
+                p.add_(1.0)
+    cfg = CLIPSegConfig(use_complex_transposed_convolution=True, reduce_dim=64, extract_layers=[0, 1, 2], conditional_layer=0,
+                        decoder_num_attention_heads=4, decoder_intermediate_size=128, projection_dim=64,
+                        vision_config={"patch_size": 16, "image_size": 64, "hidden_size": 64, "num_attention_heads": 1, "intermediate_size": 256, "num_hidden_layers": 3})
+    dec = CLIPSegDecoder(cfg).eval()
+    fill_module(dec, 0.29, 0.15)
+    with torch.no_grad():
+        for k, p in dec.named_parameters():
+            if "layer_norm" in k and k.endswith("weight"):
+                p.add_(1.0)
+    ad = adapter_mod.CLIPSegAdapter.__new__(adapter_mod.CLIPSegAdapter)
+    torch.nn.Module.__init__(ad)
+    ad.clip_model, ad.decoder, ad.extract_layers = clip, dec, cfg.extract_layers
+    ad.freeze_clip_backbone()
+    img = fill((2, 3, 64, 64), 0.013, 0.2) * 0.5 + 0.5
+    ids = torch.tensor([[49, 3, 7, 11, 2, 0, 0, 0], [5, 9, 49, 1, 1, 1, 1, 1]])
+    out = ad(img, input_ids=ids)
+    (out * fill(tuple(out.shape), 0.007, 0.4)).sum().backward()
+    arrays = {"images": img, "ids": ids, "logits": out, "dlogits": fill(tuple(out.shape), 0.007, 0.4)}
+    for k, v in ad.state_dict().items():
+        arrays["p." + k] = v
+    for k, p in ad.named_parameters():
+        if p.grad is not None:
+            arrays["g." + k] = p.grad
+    assert all(k.startswith("decoder.") for k, p in ad.named_parameters() if p.requires_grad)
+    save("clipseg_adapter", **arrays)
+
+
 def main():
     sys.path.insert(0, REF)
     mona = load_by_path("ref_mona", "src/adapters/mona.py")
@@ -248,6 +287,7 @@ def main():
     gen_infonce(losses)
     gen_openai_clip(model_mod, mona, lora)
     gen_hf_crosschecks()
+    gen_clipseg(model_mod)
 
 
 if __name__ == "__main__":

@@ -210,3 +210,21 @@ def test_bert_recipe_matches_hf_bert(golden):
     L0 = int(keep[0].sum())
     hs0 = text_ref.bert_hidden(ids[:1, :L0], P, heads=2)
     close(hs0[0, 0], g["last_hidden_state"][0, 0], 1e-4, 1e-5)
+
+
+def test_clipseg_adapter_matches_reference(golden):
+    """reference CLIPSegAdapter.forward (clipseg_adapter.py:73-98) around the installed HF CLIPSegDecoder: logits [B,2,H,W]
+    and every decoder gradient (the CLIP backbone is frozen, :100-110)."""
+    from oracle import clipseg_ref
+    g = golden("clipseg_adapter")
+    P = {k: v.clone() for k, v in params_of(g).items()}
+    names = [k for k in P if k.startswith("decoder.")]
+    leaves = {k: P[k].clone().requires_grad_(True) for k in names}
+    Pq = dict(P); Pq.update(leaves)
+    out = clipseg_ref.adapter_forward(g["images"], g["ids"], Pq, vit_heads=1, text_heads=2, extract_layers=(0, 1, 2))
+    assert tuple(out.shape) == (2, 2, 64, 64)
+    (out * g["dlogits"]).sum().backward()
+    close(out, g["logits"], 1e-4, 1e-5)
+    assert sorted("g." + k for k in names) == sorted(k for k in g if k.startswith("g."))
+    for k in names:
+        close(leaves[k].grad, g["g." + k], 2e-3, 1e-6)     # fp32 summation order differs from HF's eager attention / conv kernels
