@@ -146,6 +146,23 @@ int uia_dropout(void* stream, int dtype, size_t n, const void* src, void* dst, f
 int uia_colsum(void* stream, int dtype, int M, int N, const void* A, int64_t lda, float* out);
 
 /* ---------------------------------------------------------------------------------------------
+ * CLIPSeg decoder pieces (src/third_party/openai_clip/clipseg_adapter.py:73-98 → transformers CLIPSegDecoder [third-party],
+ * SURVEY Appendix A.3).  Its Linear / convolution contractions are uia_gemm + uia_wgrad; uia_attn_* accepts head dim 16 / 32
+ * (plain-VALU path) besides 64.  These are the remaining stages; the decoder is trainable, so all have backwards. */
+int uia_layernorm_bwd_affine(void* stream, int dtype, int M, int D, const void* dy, const float* x, const float* gamma, float eps,
+                             const float* dres, float* dx32, float* g_gamma, float* g_beta);   /* dx and += dgamma, dbeta */
+int uia_film_fwd(void* stream, int B, int N, int C, const float* x, const float* mul, const float* add, float* y);   /* y = mul[b]*x + add[b] */
+int uia_film_bwd(void* stream, int B, int N, int C, const float* dy, const float* x, const float* mul, float* dx, float* dmul, float* dadd);
+/* 3x3 / pad-1 patches of the token grid: cols[(b*h*w+p)][(ky*3+kx)*C + c] = x[b][tok_off + nbr][c]; col2im is its adjoint
+ * (rows < tok_off of dx are zeroed). */
+int uia_im2col3x3(void* stream, int dtype, int B, int h, int w, int C, int ntok, int tok_off, const float* x, void* cols);
+int uia_col2im3x3(void* stream, int dtype, int B, int h, int w, int C, int ntok, int tok_off, const void* dcols, float* dx);
+/* two stacked kernel=stride transposed convolutions leave [B*h*w*k1*k1, >=k2*k2]; unshuffle writes logits [B, h*k1*k2, w*k1*k2] (+bias). */
+int uia_unshuffle(void* stream, int dtype, int B, int h, int w, int k1, int k2, const void* tmp, int64_t ld, float bias, float* out);
+int uia_shuffle(void* stream, int dtype, int B, int h, int w, int k1, int k2, const float* dout, void* dtmp, int64_t ld);
+int uia_act_bwd(void* stream, int dtype, size_t n, const void* dy, const void* y, int act, void* out);   /* ReLU from the post-activation */
+
+/* ---------------------------------------------------------------------------------------------
  * Symmetric InfoNCE (src/losses/losses.py:23-47), forward + gradients of both feature matrices, fp32.
  * loss (1 float, device) is overwritten; dimg/dtxt (both or neither) receive grad_scale * dLoss/dfeat.
  * workspace: uia_infonce_workspace_bytes(B, E). */

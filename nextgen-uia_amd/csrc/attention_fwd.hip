@@ -239,7 +239,7 @@ int launch_bf16(hipStream_t stream, const UiaAttnParams& p) {
 int uia_attn_fwd_launch(hipStream_t stream, int dtype, const UiaAttnParams& p) {
     UIA_CHECK_ARG(dtype == UIA_BF16 || dtype == UIA_F32, "uia_attn_fwd: bad dtype %d", dtype);
     UIA_CHECK_ARG(p.B > 0 && p.H > 0 && p.L > 0, "uia_attn_fwd: empty problem");
-    UIA_CHECK_ARG(p.dh == 64, "uia_attn_fwd: head dim %d unsupported (64 only)", p.dh);
+    if (p.dh != 64) return uia_attn_small_launch(stream, dtype, p, false);   // CLIPSeg decoder heads (d_h = 16)
     UIA_CHECK_ARG(p.L <= 272, "uia_attn_fwd: L=%d exceeds the single-pass limit 272", p.L);
     UIA_CHECK_ARG(p.q && p.k && p.v && p.out, "uia_attn_fwd: null tensor");
     const int esz = dtype == UIA_BF16 ? 2 : 4;

@@ -75,4 +75,26 @@ int uia_colsum(void* stream, int dtype, int M, int N, const void* A, int64_t lda
     return uia_colsum_launch((hipStream_t)stream, dtype, M, N, A, lda, out);
 }
 
+int uia_layernorm_bwd_affine(void* stream, int dtype, int M, int D, const void* dy, const float* x, const float* gamma, float eps, const float* dres,
+                             float* dx32, float* g_gamma, float* g_beta) {
+    return uia_layernorm_bwd_affine_launch((hipStream_t)stream, dtype, M, D, dy, x, gamma, eps, dres, dx32, g_gamma, g_beta);
+}
+int uia_film_fwd(void* stream, int B, int N, int C, const float* x, const float* mul, const float* add, float* y) { return uia_film_fwd_launch((hipStream_t)stream, B, N, C, x, mul, add, y); }
+int uia_film_bwd(void* stream, int B, int N, int C, const float* dy, const float* x, const float* mul, float* dx, float* dmul, float* dadd) {
+    return uia_film_bwd_launch((hipStream_t)stream, B, N, C, dy, x, mul, dx, dmul, dadd);
+}
+int uia_im2col3x3(void* stream, int dtype, int B, int h, int w, int C, int ntok, int tok_off, const float* x, void* cols) {
+    return uia_im2col3x3_launch((hipStream_t)stream, dtype, B, h, w, C, ntok, tok_off, x, cols);
+}
+int uia_col2im3x3(void* stream, int dtype, int B, int h, int w, int C, int ntok, int tok_off, const void* dcols, float* dx) {
+    return uia_col2im3x3_launch((hipStream_t)stream, dtype, B, h, w, C, ntok, tok_off, dcols, dx);
+}
+int uia_unshuffle(void* stream, int dtype, int B, int h, int w, int k1, int k2, const void* tmp, int64_t ld, float bias, float* out) {
+    return uia_unshuffle_launch((hipStream_t)stream, dtype, B, h, w, k1, k2, tmp, ld, bias, out);
+}
+int uia_shuffle(void* stream, int dtype, int B, int h, int w, int k1, int k2, const float* dout, void* dtmp, int64_t ld) {
+    return uia_shuffle_launch((hipStream_t)stream, dtype, B, h, w, k1, k2, dout, dtmp, ld);
+}
+int uia_act_bwd(void* stream, int dtype, size_t n, const void* dy, const void* y, int act, void* out) { return uia_act_bwd_launch((hipStream_t)stream, dtype, n, dy, y, act, out); }
+
 }  // extern "C"

@@ -38,3 +38,13 @@ int uia_adamw_clip_launch(hipStream_t stream, size_t n, float* p, const float* g
                           float eps, float weight_decay, float max_norm, int step, float grad_scale, float* ws);
 int uia_dropout_launch(hipStream_t stream, int dtype, size_t n, const void* src, void* dst, float p, uint64_t seed, int accumulate);
 int uia_colsum_launch(hipStream_t stream, int dtype, int M, int N, const void* A, long lda, float* out);
+int uia_attn_small_launch(hipStream_t stream, int dtype, const UiaAttnParams& p, bool bwd);
+int uia_layernorm_bwd_affine_launch(hipStream_t stream, int dtype, int M, int D, const void* dy, const float* x, const float* gamma, float eps,
+                                    const float* dres, float* dx32, float* g_gamma, float* g_beta);
+int uia_film_fwd_launch(hipStream_t stream, int B, int N, int C, const float* x, const float* mul, const float* add, float* y);
+int uia_film_bwd_launch(hipStream_t stream, int B, int N, int C, const float* dy, const float* x, const float* mul, float* dx, float* dmul, float* dadd);
+int uia_im2col3x3_launch(hipStream_t stream, int dtype, int B, int h, int w, int C, int ntok, int tok_off, const float* x, void* cols);
+int uia_col2im3x3_launch(hipStream_t stream, int dtype, int B, int h, int w, int C, int ntok, int tok_off, const void* dcols, float* dx);
+int uia_unshuffle_launch(hipStream_t stream, int dtype, int B, int h, int w, int k1, int k2, const void* tmp, long ld, float bias, float* out);
+int uia_shuffle_launch(hipStream_t stream, int dtype, int B, int h, int w, int k1, int k2, const float* dout, void* dtmp, long ld);
+int uia_act_bwd_launch(hipStream_t stream, int dtype, size_t n, const void* dy, const void* y, int act, void* out);

@@ -69,6 +69,14 @@ PROTOTYPES = {
     "uia_comm_destroy": (C.c_int, []),
     "uia_dropout": (C.c_int, [vp, C.c_int, sz, vp, vp, f32, C.c_uint64, C.c_int]),
     "uia_colsum": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, i64, vp]),
+    "uia_layernorm_bwd_affine": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, f32, vp, vp, vp, vp]),
+    "uia_film_fwd": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
+    "uia_film_bwd": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]),
+    "uia_im2col3x3": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "uia_col2im3x3": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "uia_unshuffle": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, f32, vp]),
+    "uia_shuffle": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, i64]),
+    "uia_act_bwd": (C.c_int, [vp, C.c_int, sz, vp, vp, C.c_int, vp]),
     "uia_cast": (C.c_int, [vp, C.c_int, sz, vp, vp, f32]),
     "uia_transpose_cast": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp]),
     "uia_im2col": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),

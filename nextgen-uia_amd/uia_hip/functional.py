@@ -542,3 +542,167 @@ def _pad_cols(p, dt, transpose=False, rows=False):
     out = torch.empty(src.shape, device=src.device, dtype=dt)
     ops.cast(src, out)
     return out
+
+
+# ================================================================================================ trainable op-level functions
+# (CLIPSeg decoder: every weight trains, so these produce dx, dW and db.  wgrad needs both GEMM dimensions to be
+#  multiples of 64: callers zero-pad narrow outputs, e.g. the last transposed convolution's 16 columns.)
+class CastFn(torch.autograd.Function):
+    """fp32 → compute dtype (operand copy); the backward is the plain upcast."""
+
+    @staticmethod
+    def forward(ctx, x):
+        dt = compute_dtype()
+        if dt == torch.float32:
+            return x.contiguous()
+        out = torch.empty(x.shape, device=x.device, dtype=dt)
+        ops.cast(x.contiguous(), out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.float()
+
+
+class LinearTrainFn(torch.autograd.Function):
+    """y = act(x·Wᵀ + b) (+ resid32), x [M,K] in T, W [N,K] / b [N] fp32 trainable.  Output T, or fp32 when `out32` / a residual."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act, resid32, out32):
+        dt = x.dtype
+        M, K = x.shape
+        N = weight.shape[0]
+        want32 = out32 or resid32 is not None
+        assert not (act and want32), "activation + fp32 output is not used by any caller"
+        y = torch.empty(M, N, device=x.device, dtype=torch.float32 if want32 else dt)
+        w_t = WEIGHTS.get(weight, dt)
+        if want32:
+            ops.gemm(x, w_t, bias=bias, resid=resid32, out32=y)
+        else:
+            ops.gemm(x, w_t, bias=bias, act=act, out_t=y)
+        ctx.save_for_backward(x, weight, y if act else x.new_empty(0))
+        ctx.meta = (act, bias is not None, resid32 is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        act, has_bias, has_resid = ctx.meta
+        dt = x.dtype
+        M, K = x.shape
+        N = weight.shape[0]
+        dy = dy.contiguous()
+        dy_t = t_copy_of(dy, dt) if dy.dtype == torch.float32 else dy
+        if act:
+            dpre = torch.empty_like(dy_t)
+            ops.act_bwd(dy_t, y, act, dpre)
+            dy_t = dpre
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _empty((M, K), dt, x)
+            ops.gemm(dy_t, WEIGHTS.get(weight, dt, transpose=True), out_t=dx)
+        dW = torch.zeros(N, K, device=x.device, dtype=torch.float32)
+        db = torch.zeros(N, device=x.device, dtype=torch.float32) if has_bias else None
+        ops.wgrad(dy_t, x, dW, db)
+        return dx, dW, db, None, (dy if has_resid else None), None
+
+
+class LayerNormAffineFn(torch.autograd.Function):
+    """fp32 rows → fp32 rows, trainable γ/β (CLIPSeg decoder layer_norm1/2)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        D = x.shape[-1]
+        x2 = x.contiguous().view(-1, D)
+        y = torch.empty_like(x2)
+        ops.layernorm_fwd(x2, w, b, eps, y32=y)
+        ctx.save_for_backward(x2, w)
+        ctx.meta = (eps, x.shape)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        eps, shape = ctx.meta
+        dx = torch.empty_like(x2)
+        gw, gb = torch.zeros_like(w, dtype=torch.float32), torch.zeros_like(w, dtype=torch.float32)
+        ops.layernorm_bwd_affine(dy.contiguous().view(x2.shape).float(), x2, w, eps, dx, gw, gb)
+        return dx.view(shape), gw, gb, None
+
+
+class SmallAttentionFn(torch.autograd.Function):
+    """q,k,v [M, H·dh] (strided views of one fused buffer), dh ∈ {16, 32, 64} → [M, H·dh]."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, B, H, L, dh):
+        out = _empty((B * L, H * dh), q.dtype, q)
+        lse = torch.empty(B, H, L, device=q.device, dtype=torch.float32)
+        ops.attn_fwd(q, k, v, out, B, H, L, lse=lse, dh=dh)
+        ctx.save_for_backward(q, k, v, out, lse)
+        ctx.meta = (B, H, L, dh)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, out, lse = ctx.saved_tensors
+        B, H, L, dh = ctx.meta
+        D = H * dh
+        dqkv = _empty((B * L, 3 * D), q.dtype, q)
+        ops.attn_bwd(q, k, v, out, dout.contiguous(), lse, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], B, H, L, dh=dh)
+        return dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], None, None, None, None
+
+
+class FilmFn(torch.autograd.Function):
+    """y[b,n,:] = mul[b,:]·x[b,n,:] + add[b,:]   (fp32)."""
+
+    @staticmethod
+    def forward(ctx, x, mul, add):
+        x, mul, add = x.contiguous(), mul.contiguous(), add.contiguous()
+        y = torch.empty_like(x)
+        ops.film_fwd(x, mul, add, y)
+        ctx.save_for_backward(x, mul)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mul = ctx.saved_tensors
+        dx, dmul, dadd = torch.empty_like(x), torch.empty_like(mul), torch.empty_like(mul)
+        ops.film_bwd(dy.contiguous(), x, mul, dx, dmul, dadd)
+        return dx, dmul, dadd
+
+
+class Im2col3x3Fn(torch.autograd.Function):
+    """tokens [B, 1+h·w, C] fp32 → 3×3 zero-padded patches [B·h·w, 9C] in T (CLS token dropped, as decoder.forward does)."""
+
+    @staticmethod
+    def forward(ctx, x, h, w):
+        B, N, C = x.shape
+        cols = _empty((B * h * w, 9 * C), compute_dtype(), x)
+        ops.im2col3x3(x.contiguous(), cols, h, w, tok_off=N - h * w)
+        ctx.meta = (x.shape, h, w)
+        return cols
+
+    @staticmethod
+    def backward(ctx, dcols):
+        shape, h, w = ctx.meta
+        dx = torch.empty(shape, device=dcols.device, dtype=torch.float32)
+        ops.col2im3x3(dcols.contiguous(), dx, h, w, tok_off=shape[1] - h * w)
+        return dx, None, None
+
+
+class UnshuffleFn(torch.autograd.Function):
+    """[B·h·w·k1², ≥k2²] (output of the two stacked kernel=stride transposed convolutions) → logits [B, h·k1·k2, w·k1·k2] fp32."""
+
+    @staticmethod
+    def forward(ctx, tmp, B, h, w, k1, k2):
+        out = torch.empty(B, h * k1 * k2, w * k1 * k2, device=tmp.device, dtype=torch.float32)
+        ops.unshuffle(tmp, out, B, h, w, k1, k2)
+        ctx.meta = (tmp.shape, tmp.dtype, B, h, w, k1, k2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        shape, dt, B, h, w, k1, k2 = ctx.meta
+        dtmp = torch.empty(shape, device=dout.device, dtype=dt)
+        ops.shuffle(dout.contiguous().float(), dtmp, B, h, w, k1, k2)
+        return dtmp, None, None, None, None, None

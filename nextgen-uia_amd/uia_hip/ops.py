@@ -104,7 +104,7 @@ def wgrad(a, b, dw, dbias=None, alpha=1.0):
     check(lib().uia_wgrad(_stream(), _code(a.dtype), a.shape[0], a.shape[1], b.shape[1], _p(a), lda, _p(b), ldb, alpha, _p(dw), _p(dbias)), "uia_wgrad")
 
 
-def _attn_desc(q, k, v, out, lse, B, H, L, mask, keylen, scale):
+def _attn_desc(q, k, v, out, lse, B, H, L, mask, keylen, scale, dh=64):
     d = AttnDesc()
     for t in (q, k, v):
         if t.stride(-1) != 1 or t.dtype != q.dtype:
@@ -114,20 +114,20 @@ def _attn_desc(q, k, v, out, lse, B, H, L, mask, keylen, scale):
     d.out, d.ldo = _p(out), out.stride(-2)
     d.lse = _p(lse)
     d.keylen = _p(keylen)
-    d.B, d.H, d.L, d.dh = B, H, L, 64
+    d.B, d.H, d.L, d.dh = B, H, L, dh
     d.mask_kind = {"none": 0, None: 0, "causal": 1, "keypad": 2}[mask]
-    d.scale = scale if scale is not None else 64 ** -0.5
+    d.scale = scale if scale is not None else dh ** -0.5
     return d
 
 
-def attn_fwd(q, k, v, out, B, H, L, lse=None, mask=None, keylen=None, scale=None):
-    """q,k,v: views whose element (b,l,h,d) is at base[(b*L+l)*ld + h*64 + d] (e.g. slices of the fused qkv)."""
-    d = _attn_desc(q, k, v, out, lse, B, H, L, mask, keylen, scale)
+def attn_fwd(q, k, v, out, B, H, L, lse=None, mask=None, keylen=None, scale=None, dh=64):
+    """q,k,v: views whose element (b,l,h,d) is at base[(b*L+l)*ld + h*dh + d] (e.g. slices of the fused qkv)."""
+    d = _attn_desc(q, k, v, out, lse, B, H, L, mask, keylen, scale, dh)
     check(lib().uia_attn_fwd(_stream(), _code(q.dtype), C.byref(d)), "uia_attn_fwd")
 
 
-def attn_bwd(q, k, v, out, dout, lse, dq, dk, dv, B, H, L, mask=None, keylen=None, scale=None):
-    d = _attn_desc(q, k, v, out, lse, B, H, L, mask, keylen, scale)
+def attn_bwd(q, k, v, out, dout, lse, dq, dk, dv, B, H, L, mask=None, keylen=None, scale=None, dh=64):
+    d = _attn_desc(q, k, v, out, lse, B, H, L, mask, keylen, scale, dh)
     d.dout, d.lddo = _p(dout), dout.stride(-2)
     d.dq, d.dk, d.dv, d.ld_dqkv = _p(dq), _p(dk), _p(dv), dq.stride(-2)
     assert dk.stride(-2) == dq.stride(-2) == dv.stride(-2)
@@ -285,3 +285,42 @@ def colsum(a, out):
     lda = _rowmajor(a, "a")
     assert out.dtype == torch.float32 and out.numel() == a.shape[1]
     check(lib().uia_colsum(_stream(), _code(a.dtype), a.shape[0], a.shape[1], _p(a), lda, _p(out)), "uia_colsum")
+
+
+# ------------------------------------------------------------------------------------------- CLIPSeg decoder pieces
+def layernorm_bwd_affine(dy, x, gamma, eps, dx32, g_gamma, g_beta, dres=None):
+    D = gamma.numel()
+    check(lib().uia_layernorm_bwd_affine(_stream(), _code(dy.dtype), dy.numel() // D, D, _p(dy), _p(x), _p(gamma), eps, _p(dres), _p(dx32), _p(g_gamma), _p(g_beta)),
+          "uia_layernorm_bwd_affine")
+
+
+def film_fwd(x, mul, add, y):
+    B, N, Cc = x.shape
+    check(lib().uia_film_fwd(_stream(), B, N, Cc, _p(x), _p(mul), _p(add), _p(y)), "uia_film_fwd")
+
+
+def film_bwd(dy, x, mul, dx, dmul, dadd):
+    B, N, Cc = x.shape
+    check(lib().uia_film_bwd(_stream(), B, N, Cc, _p(dy), _p(x), _p(mul), _p(dx), _p(dmul), _p(dadd)), "uia_film_bwd")
+
+
+def im2col3x3(x, cols, h, w, tok_off=1):
+    B, N, Cc = x.shape
+    check(lib().uia_im2col3x3(_stream(), _code(cols.dtype), B, h, w, Cc, N, tok_off, _p(x), _p(cols)), "uia_im2col3x3")
+
+
+def col2im3x3(dcols, dx, h, w, tok_off=1):
+    B, N, Cc = dx.shape
+    check(lib().uia_col2im3x3(_stream(), _code(dcols.dtype), B, h, w, Cc, N, tok_off, _p(dcols), _p(dx)), "uia_col2im3x3")
+
+
+def unshuffle(tmp, out, B, h, w, k1, k2, bias=0.0):
+    check(lib().uia_unshuffle(_stream(), _code(tmp.dtype), B, h, w, k1, k2, _p(tmp), tmp.stride(0), bias, _p(out)), "uia_unshuffle")
+
+
+def shuffle(dout, dtmp, B, h, w, k1, k2):
+    check(lib().uia_shuffle(_stream(), _code(dtmp.dtype), B, h, w, k1, k2, _p(dout), _p(dtmp), dtmp.stride(0)), "uia_shuffle")
+
+
+def act_bwd(dy, y, act, out):
+    check(lib().uia_act_bwd(_stream(), _code(dy.dtype), dy.numel(), _p(dy), _p(y), _ACT[act], _p(out)), "uia_act_bwd")

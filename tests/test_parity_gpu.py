@@ -367,3 +367,51 @@ def test_finetune_entry_point_runs_and_saves_adapter_checkpoint(tmp_path, monkey
     ck = torch.load(tmp_path / "runs" / "t" / "best_model.pth")
     assert ck and all("mona" in k for k in ck) and "visual.trunk.blocks.0.mona.clip_mona.gamma" in ck
     assert out["updates"] == 3 * 2 and math.isfinite(out["best_val"]) and (tmp_path / "runs" / "t" / "log.log").exists()
+
+
+# ------------------------------------------------------------------------------------------------ CLIPSeg
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_clipseg_adapter_vs_oracle(mode):
+    """CLIPSegAdapter.forward → [B,2,H,W] and every decoder-parameter gradient vs the oracle (itself pinned to the reference
+    adapter + HF decoder by tests/golden/clipseg_adapter.npz)."""
+    from oracle import clipseg_ref
+    from uia_hip import functional as UF
+    from src.third_party.openai_clip.model import CLIP
+    from src.third_party.openai_clip.clipseg_adapter import CLIPSegAdapter, CLIPSegDecoder
+    UF.set_compute_dtype(DT[mode])
+    g = torch.Generator().manual_seed(31)
+    torch.manual_seed(31)
+    clip = CLIP(64, 64, 3, 128, 16, 16, 100, 128, 2, 2).eval()       # image 64, patch 16 → 4×4 grid; 3 vision blocks, width 128
+    dec = CLIPSegDecoder(vision_hidden=128, projection_dim=64, extract_layers=(0, 1, 2), intermediate=128, patch_size=16)
+    model = CLIPSegAdapter(clip, decoder=dec)
+    randomize(model, g, 0.1)
+    model.freeze_clip_backbone()
+    images = torch.rand(3, 3, 64, 64, generator=g)
+    ids = clip_text_batch(g, B=3, L=16)
+    ids[2] = ids[0]                                                   # repeated prompt rows (segmentation.py:142)
+    dl = torch.randn(3, 2, 64, 64, generator=g) * 0.01
+    P = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    names = [k for k in P if k.startswith("decoder.")]
+    leaves = {k: P[k].clone().requires_grad_(True) for k in names}
+    Pq = dict(P); Pq.update(leaves)
+    ref = clipseg_ref.adapter_forward(images, ids, Pq, vit_heads=2, text_heads=2, extract_layers=(0, 1, 2))
+    (ref * dl).sum().backward()
+    model = model.to(dev())
+    out = model(images.to(dev()), input_ids=ids.to(dev()))
+    (out * dl.to(dev())).sum().backward()
+    assert tuple(out.shape) == (3, 2, 64, 64)
+    assert rel(out, ref) < TOL[mode]
+    # masks: argmax agrees wherever the logit margin is not tiny (SURVEY §8d "Dice parity")
+    agree = (out.argmax(1).cpu() == ref.argmax(1)) | ((ref[:, 1] - ref[:, 0]).abs() < (1e-3 if mode == "fp32" else 2e-2) * float(ref.abs().max()))
+    assert bool(agree.all())
+    gmax = max(float(v.grad.abs().max()) for v in leaves.values())
+    if mode == "fp32":
+        for k, p in model.named_parameters():
+            if k.startswith("decoder."):
+                err = float((p.grad.detach().float().cpu() - leaves[k].grad).abs().max())
+                tol = GTOL[mode] * float(leaves[k].grad.abs().max())
+                assert err < tol or err < 1e-1 * GTOL[mode] * gmax, (k, err, tol)
+    else:   # bf16: whole-gradient direction and size (per-tensor exactness is the fp32 case above)
+        got = torch.cat([p.grad.detach().float().cpu().flatten() for k, p in model.named_parameters() if k.startswith("decoder.")])
+        want = torch.cat([leaves[k].grad.flatten() for k, _ in model.named_parameters() if k.startswith("decoder.")])
+        assert float(torch.dot(got, want) / (got.norm() * want.norm())) > 0.995 and float((got - want).norm() / want.norm()) < 0.1
