@@ -415,3 +415,12 @@ def test_clipseg_adapter_vs_oracle(mode):
         got = torch.cat([p.grad.detach().float().cpu().flatten() for k, p in model.named_parameters() if k.startswith("decoder.")])
         want = torch.cat([leaves[k].grad.flatten() for k, _ in model.named_parameters() if k.startswith("decoder.")])
         assert float(torch.dot(got, want) / (got.norm() * want.norm())) > 0.995 and float((got - want).norm() / want.norm()) < 0.1
+
+
+def test_clipseg_entry_point_trains_and_saves_decoder_checkpoint(tmp_path, monkeypatch):
+    from src.models.clipseg import segmentation
+    monkeypatch.chdir(tmp_path)
+    out = segmentation.main(["--synthetic", "--iters", "12", "--batch_size", "8", "--img_size", "64", "--lr", "1e-3", "--dtype", "fp32", "--exp", "t"])
+    ck = torch.load(tmp_path / "runs" / "t" / "BUSI" / "train" / "best_model.pth")
+    assert set(ck) == {"decoder"} and "layers.0.self_attn.q_proj.weight" in ck["decoder"] and "transposed_convolution.4.bias" in ck["decoder"]
+    assert out["iters"] == 12 and math.isfinite(out["loss"])
