@@ -121,7 +121,11 @@ typedef struct uia_mona_spatial_desc {
     void* dt;                     /* backward: T grad wrt t */
     float *g_conv1_w, *g_conv1_b, *g_conv2_w, *g_conv2_b, *g_conv3_w, *g_conv3_b, *g_proj_w, *g_proj_b, *g_freq,
           *g_ne1_w, *g_ne1_b, *g_ne3_w, *g_ne3_b;
+    float* ws;                    /* backward, optional: uia_mona_spatial_workspace_bytes(B) of scratch. With it every image writes one
+                                     partial-gradient row and a second kernel adds the column sums into g_* in a fixed order
+                                     (deterministic, no atomic contention); without it the kernel uses float atomics. */
 } uia_mona_spatial_desc;
+size_t uia_mona_spatial_workspace_bytes(int B);
 int uia_mona_pre_fwd(void* stream, int dtype, int M, int D, const float* x, const float* norm_w, const float* norm_b,
                      const float* gamma, const float* gammax, float eps, void* u);
 int uia_mona_pre_bwd(void* stream, int dtype, int M, int D, const void* du, const float* x, const float* dy,

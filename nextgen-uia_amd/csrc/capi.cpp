@@ -97,4 +97,6 @@ int uia_shuffle(void* stream, int dtype, int B, int h, int w, int k1, int k2, co
 }
 int uia_act_bwd(void* stream, int dtype, size_t n, const void* dy, const void* y, int act, void* out) { return uia_act_bwd_launch((hipStream_t)stream, dtype, n, dy, y, act, out); }
 
+size_t uia_mona_spatial_workspace_bytes(int B) { return uia_mona_spatial_ws_floats(B) * sizeof(float); }
+
 }  // extern "C"

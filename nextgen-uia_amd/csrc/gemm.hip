@@ -62,6 +62,37 @@ __device__ __forceinline__ float apply_act(float x, int act) {
         default: return x;
     }
 }
+// 8 values at a time: bf16-mode GELU goes through the packed polynomial, everything else through the scalar forms
+template <bool FAST>
+__device__ __forceinline__ void apply_act8(float (&v)[8], int act) {
+    if (FAST && act == UIA_ACT_GELU) {
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            const f32x2 x = {v[e], v[e + 1]}, y = gelu_poly2(x);
+            v[e] = y[0];
+            v[e + 1] = y[1];
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = apply_act<FAST>(v[e], act);
+    }
+}
+template <bool FAST>
+__device__ __forceinline__ float apply_dact(float pre, int act);
+template <bool FAST>
+__device__ __forceinline__ void apply_dact8(float (&v)[8], const float (&a)[8], int act) {
+    if (FAST && act == UIA_ACT_GELU) {
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            const f32x2 x = {a[e], a[e + 1]}, d = dgelu_poly2(x);
+            v[e] *= d[0];
+            v[e + 1] *= d[1];
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= apply_dact<FAST>(a[e], act);
+    }
+}
 template <bool FAST>
 __device__ __forceinline__ float apply_dact(float pre, int act) {
     switch (act) {
@@ -121,14 +152,12 @@ __device__ __forceinline__ void gemm_epilogue(const UiaGemmParams& p, f32x4 (&ac
             }
             if (aux_out) store8(aux_out + orow * p.ldaux_out + n, v);
             if (p.act) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = apply_act<sizeof(T) == 2>(v[e], p.act);
+                apply_act8<sizeof(T) == 2>(v, p.act);
             }
             if (p.dact) {
                 float a[8];
                 load8(aux_in + orow * p.ldaux_in + n, a);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] *= apply_dact<sizeof(T) == 2>(a[e], p.dact);
+                apply_dact8<sizeof(T) == 2>(v, a, p.dact);
             }
             if (p.resid) {
                 float r[8];
@@ -191,14 +220,12 @@ __device__ __forceinline__ void gemm_epilogue_lds(const UiaGemmParams& p, f32x4 
                 for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], p.alpha, bias[e]);
                 if (aux_out) store8(aux_out + orow * p.ldaux_out + n, v);
                 if (p.act) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = apply_act<sizeof(T) == 2>(v[e], p.act);
+                    apply_act8<sizeof(T) == 2>(v, p.act);
                 }
                 if (p.dact) {
                     float a[8];
                     load8(aux_in + orow * p.ldaux_in + n, a);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] *= apply_dact<sizeof(T) == 2>(a[e], p.dact);
+                    apply_dact8<sizeof(T) == 2>(v, a, p.dact);
                 }
                 if (p.resid) {
                     float r[8];

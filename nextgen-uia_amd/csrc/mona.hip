@@ -192,7 +192,10 @@ __device__ __forceinline__ void load_tokens(const T* __restrict__ src, float* __
 // scr: ≥ 4*64 + 64 + 16 + 16 + 4 floats.  Returns w1,w2,w3 in scr[W_OFF..].
 constexpr int NGRP = 8;                   // pixel groups = waves per image (512 threads)
 constexpr int SCR_PART = 0, SCR_POOL = 512, SCR_HPRE = 576, SCR_HID = 592, SCR_W = 608, SCR_DPOOL = 616, SCR_RED = 680, SCR_SIZE = 720;
-constexpr int RED_FLOATS = 64 * 50;       // pass-A per-channel accumulators (LDS atomics from the 8 pixel groups)
+constexpr int RED_FLOATS = 64 * 50;
+// layout of one per-image partial-gradient row in the workspace (floats)
+constexpr int WS_PROJ_W = 0, WS_PROJ_B = 4096, WS_C1W = 4160, WS_C1B = 4736, WS_C2W = 4800, WS_C2B = 6400, WS_C3W = 6464, WS_C3B = 9600,
+              WS_FREQ = 9664, WS_NE1W = 9728, WS_NE1B = 10752, WS_NE3W = 10768, WS_NE3B = 10816, WS_ROW = 10880;       // pass-A per-channel accumulators (LDS atomics from the 8 pixel groups)
 
 __device__ __forceinline__ void noise_forward(const uia_mona_spatial_desc& p, const float* tS, float f, int hw, int ppg, int c, int grp,
                                               int tid, float* scr) {
@@ -251,6 +254,11 @@ __device__ __forceinline__ void conv_forward(const float* tS, float* cS, const f
     }
 }
 
+__device__ __forceinline__ void grad_out(float* wsrow, int ws_off, float* gptr, int idx, float v) {
+    if (wsrow) wsrow[ws_off + idx] = v;           // one writer per element: plain store, summed over images by mona_ws_reduce_kernel
+    else atomicAdd(gptr + idx, v);
+}
+
 template <typename T, bool BWD>
 __global__ __launch_bounds__(512) void mona_spatial_kernel(const uia_mona_spatial_desc p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -266,6 +274,7 @@ __global__ __launch_bounds__(512) void mona_spatial_kernel(const uia_mona_spatia
     const bool has_noise = p.variant == UIA_MONA_NOISE_AWARE || p.variant == UIA_MONA_HYBRID;
     const int ppg = (hw + NGRP - 1) / NGRP, p0 = grp * ppg, p1 = min(hw, p0 + ppg);
     const size_t tok0 = (size_t)b * ntok;
+    float* wsrow = (BWD && p.ws) ? p.ws + (size_t)b * WS_ROW : nullptr;
 
     load_tokens((const T*)p.t + tok0 * BOTT, tS, ntok, tid);
     __syncthreads();
@@ -347,8 +356,9 @@ __global__ __launch_bounds__(512) void mona_spatial_kernel(const uia_mona_spatia
             }
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) atomicAdd(p.g_proj_w + co * 64 + cb + k, a[k]);
-        if ((tid & 7) == 0) atomicAdd(p.g_proj_b + co, sb);
+        for (int k = 0; k < 8; ++k) grad_out(wsrow, WS_PROJ_W, p.g_proj_w, co * 64 + cb + k, a[k]);
+        // db_p: the 8 threads of a `co` hold the same sum
+        if ((tid & 7) == 0) grad_out(wsrow, WS_PROJ_B, p.g_proj_b, co, sb);
     }
     __syncthreads();
     // ---- dc = dp + Pᵀ·dp, in place (rows of a pixel group belong to one wave)
@@ -415,13 +425,13 @@ __global__ __launch_bounds__(512) void mona_spatial_kernel(const uia_mona_spatia
         for (int i = 0; i < 7; ++i)
 #pragma unroll
             for (int j = 0; j < 7; ++j) {
-                atomicAdd(p.g_conv3_w + c * 49 + i * 7 + j, w3 * dkm[i * 7 + j]);
-                if (i >= 1 && i <= 5 && j >= 1 && j <= 5) atomicAdd(p.g_conv2_w + c * 25 + (i - 1) * 5 + (j - 1), w2 * dkm[i * 7 + j]);
-                if (i >= 2 && i <= 4 && j >= 2 && j <= 4) atomicAdd(p.g_conv1_w + c * 9 + (i - 2) * 3 + (j - 2), w1 * dkm[i * 7 + j]);
+                grad_out(wsrow, WS_C3W, p.g_conv3_w, c * 49 + i * 7 + j, w3 * dkm[i * 7 + j]);
+                if (i >= 1 && i <= 5 && j >= 1 && j <= 5) grad_out(wsrow, WS_C2W, p.g_conv2_w, c * 25 + (i - 1) * 5 + (j - 1), w2 * dkm[i * 7 + j]);
+                if (i >= 2 && i <= 4 && j >= 2 && j <= 4) grad_out(wsrow, WS_C1W, p.g_conv1_w, c * 9 + (i - 2) * 3 + (j - 2), w1 * dkm[i * 7 + j]);
             }
-        atomicAdd(p.g_conv1_b + c, w1 * sdc);
-        atomicAdd(p.g_conv2_b + c, w2 * sdc);
-        atomicAdd(p.g_conv3_b + c, w3 * sdc);
+        grad_out(wsrow, WS_C1B, p.g_conv1_b, c, w1 * sdc);
+        grad_out(wsrow, WS_C2B, p.g_conv2_b, c, w2 * sdc);
+        grad_out(wsrow, WS_C3B, p.g_conv3_b, c, w3 * sdc);
     }
     float dpool_c = 0.f;
     if (has_noise) {
@@ -442,13 +452,13 @@ __global__ __launch_bounds__(512) void mona_spatial_kernel(const uia_mona_spatia
             const float hid = scr[SCR_HID + tid], hpre = scr[SCR_HPRE + tid];
             float dh = 0.f;
             for (int k = 0; k < 3; ++k) {
-                atomicAdd(p.g_ne3_w + k * 16 + tid, dl[k] * hid);
+                grad_out(wsrow, WS_NE3W, p.g_ne3_w, k * 16 + tid, dl[k] * hid);
                 dh = fmaf(dl[k], p.ne3_w[k * 16 + tid], dh);
             }
-            if (tid < 3) atomicAdd(p.g_ne3_b + tid, dl[tid]);
+            if (tid < 3) grad_out(wsrow, WS_NE3B, p.g_ne3_b, tid, dl[tid]);
             dh = hpre > 0.f ? dh : 0.f;
             scr[SCR_HPRE + tid] = dh;                       // reuse as dh
-            atomicAdd(p.g_ne1_b + tid, dh);
+            grad_out(wsrow, WS_NE1B, p.g_ne1_b, tid, dh);
         }
         __syncthreads();
         if (tid < 64) {
@@ -456,7 +466,7 @@ __global__ __launch_bounds__(512) void mona_spatial_kernel(const uia_mona_spatia
             for (int j = 0; j < 16; ++j) dp = fmaf(scr[SCR_HPRE + j], p.ne1_w[j * 64 + tid], dp);
             scr[SCR_DPOOL + tid] = dp / hw;                 // gradient reaching every xf[c][pix] through the pool
         }
-        for (int i = tid; i < 16 * 64; i += 512) atomicAdd(p.g_ne1_w + i, scr[SCR_HPRE + (i >> 6)] * scr[SCR_POOL + (i & 63)]);
+        for (int i = tid; i < 16 * 64; i += 512) grad_out(wsrow, WS_NE1W, p.g_ne1_w, i, scr[SCR_HPRE + (i >> 6)] * scr[SCR_POOL + (i & 63)]);
         __syncthreads();
         dpool_c = scr[SCR_DPOOL + c];
     }
@@ -491,9 +501,49 @@ __global__ __launch_bounds__(512) void mona_spatial_kernel(const uia_mona_spatia
             float a = 0.f;
 #pragma unroll
             for (int q = 0; q < NGRP; ++q) a += scr[SCR_PART + q * 64 + tid];
-            atomicAdd(p.g_freq + tid, a);
+            grad_out(wsrow, WS_FREQ, p.g_freq, tid, a);
         }
     }
+}
+
+// g[param][i] += Σ_b ws[b][off + i]   (fixed summation order: deterministic, no atomics)
+// 64 columns per block × 4 image phases: every phase walks its images with 8 independent loads in flight.
+__global__ __launch_bounds__(256) void mona_ws_reduce_kernel(int B, const float* __restrict__ ws, uia_mona_spatial_desc p, int has_freq, int has_noise) {
+    __shared__ float part[4][64];
+    const int cx = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + cx;
+    float s = 0.f;
+    if (col < WS_ROW) {
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int b = ph;
+        for (; b + 28 < B; b += 32) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[k] += ws[(size_t)(b + 4 * k) * WS_ROW + col];
+        }
+        for (; b < B; b += 4) a[0] += ws[(size_t)b * WS_ROW + col];
+        s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    }
+    part[ph][cx] = s;
+    __syncthreads();
+    if (ph != 0 || col >= WS_ROW) return;
+    s = (part[0][cx] + part[1][cx]) + (part[2][cx] + part[3][cx]);
+    float* dst = nullptr;
+    int idx = 0;
+    if (col < WS_PROJ_B) { dst = p.g_proj_w; idx = col - WS_PROJ_W; }
+    else if (col < WS_C1W) { dst = p.g_proj_b; idx = col - WS_PROJ_B; }
+    else if (col < WS_C1B) { dst = p.g_conv1_w; idx = col - WS_C1W; }
+    else if (col < WS_C2W) { dst = p.g_conv1_b; idx = col - WS_C1B; }
+    else if (col < WS_C2B) { dst = p.g_conv2_w; idx = col - WS_C2W; }
+    else if (col < WS_C3W) { dst = p.g_conv2_b; idx = col - WS_C2B; }
+    else if (col < WS_C3B) { dst = p.g_conv3_w; idx = col - WS_C3W; }
+    else if (col < WS_FREQ) { dst = p.g_conv3_b; idx = col - WS_C3B; }
+    else if (col < WS_NE1W) { if (!has_freq) return; dst = p.g_freq; idx = col - WS_FREQ; }
+    else if (!has_noise) return;
+    else if (col < WS_NE1B) { dst = p.g_ne1_w; idx = col - WS_NE1W; }
+    else if (col < WS_NE3W) { dst = p.g_ne1_b; idx = col - WS_NE1B; }
+    else if (col < WS_NE3B) { dst = p.g_ne3_w; idx = col - WS_NE3W; if (idx >= 48) return; }
+    else { dst = p.g_ne3_b; idx = col - WS_NE3B; if (idx >= 3) return; }
+    dst[idx] += s;
 }
 
 size_t spatial_lds(int hw, bool bwd) {
@@ -512,6 +562,11 @@ int launch_spatial(hipStream_t stream, const uia_mona_spatial_desc& p) {
         attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3(p.B), dim3(512), lds, stream, p);
+    if (BWD && p.ws) {
+        const bool has_freq = p.variant == UIA_MONA_FREQ_ENHANCED || p.variant == UIA_MONA_HYBRID;
+        const bool has_noise = p.variant == UIA_MONA_NOISE_AWARE || p.variant == UIA_MONA_HYBRID;
+        hipLaunchKernelGGL(mona_ws_reduce_kernel, dim3((WS_ROW + 63) / 64), dim3(256), 0, stream, p.B, p.ws, p, (int)has_freq, (int)has_noise);
+    }
     UIA_CHECK_LAUNCH();
     return 0;
 }
@@ -570,6 +625,8 @@ int uia_mona_pre_bwd_launch(hipStream_t stream, int dtype, int M, int D, const v
     UIA_CHECK_LAUNCH();
     return 0;
 }
+
+size_t uia_mona_spatial_ws_floats(int B) { return (size_t)B * WS_ROW; }
 
 int uia_mona_spatial_fwd_launch(hipStream_t stream, int dtype, const uia_mona_spatial_desc& p) {
     if (int rc = check_spatial(p, false)) return rc;

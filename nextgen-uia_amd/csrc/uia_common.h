@@ -126,6 +126,33 @@ __device__ __forceinline__ float dquick_gelu(float x) {
     return s * fmaf(1.702f * x, 1.0f - s, 1.0f);
 }
 
+// bf16-mode GELU for the GEMM epilogues, two values per instruction and no transcendental:
+//   Φ(x)     ≈ ½ + xc·P(xc²)    gelu'(x) = Φ(x) + x·φ(x) ≈ ½ + xc·Q(xc²),    xc = clamp(x, -4, 4)
+// P, Q are degree-7 minimax fits on [-4, 4] (tools/fit_gelu_poly.py): |ΔΦ| ≤ 5.3e-5, |Δgelu'| ≤ 5e-4 (incl. the clamp at 4),
+// both an order below bf16 rounding (2^-9 = 2e-3).  The A&S form above costs a v_exp and a v_rcp per value (quarter-rate:
+// 32 of its ≈90 issue cycles per wave); this is 8 packed FMAs per PAIR of values (v_pk_fma_f32), ≈4× cheaper, and the
+// fc1/fc2-dgrad epilogues were VALU-bound on exactly that (45K cycles per 256×256 tile against 15K without GELU).
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ f32x2 uia_clamp4(f32x2 x) {
+    f32x2 r = {__builtin_amdgcn_fmed3f(x[0], -4.0f, 4.0f), __builtin_amdgcn_fmed3f(x[1], -4.0f, 4.0f)};
+    return r;
+}
+__device__ __forceinline__ f32x2 uia_odd_poly8(f32x2 xc, const float (&c)[8]) {
+    const f32x2 u = xc * xc;
+    f32x2 a = {c[7], c[7]};
+#pragma unroll
+    for (int k = 6; k >= 0; --k) a = a * u + c[k];
+    return xc * a + 0.5f;
+}
+__device__ __forceinline__ f32x2 gelu_poly2(f32x2 x) {
+    const float c[8] = {3.988475093e-01f, -6.617537764e-02f, 9.664873136e-03f, -1.048204087e-03f, 8.066734772e-05f, -4.100862563e-06f, 1.217109478e-07f, -1.580783585e-09f};
+    return x * uia_odd_poly8(uia_clamp4(x), c);
+}
+__device__ __forceinline__ f32x2 dgelu_poly2(f32x2 x) {
+    const float c[8] = {7.967216367e-01f, -2.620298342e-01f, 5.591481834e-02f, -7.687439325e-03f, 6.876450573e-04f, -3.845953927e-05f, 1.213804812e-06f, -1.641976469e-08f};
+    return uia_odd_poly8(uia_clamp4(x), c);
+}
+
 // ---------------------------------------------------------------- wave reductions
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

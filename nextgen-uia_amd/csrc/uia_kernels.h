@@ -48,3 +48,4 @@ int uia_col2im3x3_launch(hipStream_t stream, int dtype, int B, int h, int w, int
 int uia_unshuffle_launch(hipStream_t stream, int dtype, int B, int h, int w, int k1, int k2, const void* tmp, long ld, float bias, float* out);
 int uia_shuffle_launch(hipStream_t stream, int dtype, int B, int h, int w, int k1, int k2, const float* dout, void* dtmp, long ld);
 int uia_act_bwd_launch(hipStream_t stream, int dtype, size_t n, const void* dy, const void* y, int act, void* out);
+size_t uia_mona_spatial_ws_floats(int B);

@@ -41,7 +41,7 @@ class MonaSpatialDesc(C.Structure):
                 ("p_drop", f32), ("seed", C.c_uint64), ("keep_mask", vp),
                 ("dd", vp), ("dt", vp),
                 ("g_conv1_w", vp), ("g_conv1_b", vp), ("g_conv2_w", vp), ("g_conv2_b", vp), ("g_conv3_w", vp), ("g_conv3_b", vp),
-                ("g_proj_w", vp), ("g_proj_b", vp), ("g_freq", vp), ("g_ne1_w", vp), ("g_ne1_b", vp), ("g_ne3_w", vp), ("g_ne3_b", vp)]
+                ("g_proj_w", vp), ("g_proj_b", vp), ("g_freq", vp), ("g_ne1_w", vp), ("g_ne1_b", vp), ("g_ne3_w", vp), ("g_ne3_b", vp), ("ws", vp)]
 
 
 # name -> (restype, argtypes).  tests/test_capi_symbols.py checks this table against include/uia_hip.h.
@@ -58,6 +58,7 @@ PROTOTYPES = {
     "uia_mona_pre_bwd": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp]),
     "uia_mona_spatial_fwd": (C.c_int, [vp, C.c_int, C.POINTER(MonaSpatialDesc)]),
     "uia_mona_spatial_bwd": (C.c_int, [vp, C.c_int, C.POINTER(MonaSpatialDesc)]),
+    "uia_mona_spatial_workspace_bytes": (sz, [C.c_int]),
     "uia_infonce_workspace_bytes": (sz, [C.c_int, C.c_int]),
     "uia_infonce_fwd_bwd": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, f32, f32, vp, vp, vp, vp, sz]),
     "uia_adamw_clip_step": (C.c_int, [vp, sz, vp, vp, vp, vp, f32, f32, f32, f32, f32, f32, C.c_int, f32, vp]),

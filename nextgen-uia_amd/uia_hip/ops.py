@@ -226,6 +226,8 @@ def mona_spatial_bwd(variant, B, h, w, t, params, dd, dt, grads, p_drop=0.0, see
     """grads: dict keyed like params with fp32 accumulators (caller-zeroed)."""
     d = _spatial_desc(variant, B, h, w, t, params, p_drop, seed, keep_mask)
     d.dd, d.dt = _p(dd), _p(dt)
+    ws = torch.empty(lib().uia_mona_spatial_workspace_bytes(B) // 4, device=t.device, dtype=torch.float32)
+    d.ws = _p(ws)
     for k in _SPATIAL_KEYS:
         v = grads.get(k)
         if v is not None:

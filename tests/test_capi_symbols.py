@@ -41,7 +41,7 @@ def test_descriptor_struct_sizes_match_c_layout():
     from uia_hip import _lib
     assert ctypes.sizeof(_lib.GemmDesc) == 176
     assert ctypes.sizeof(_lib.AttnDesc) == 136
-    assert ctypes.sizeof(_lib.MonaSpatialDesc) % 8 == 0 and ctypes.sizeof(_lib.MonaSpatialDesc) == 288
+    assert ctypes.sizeof(_lib.MonaSpatialDesc) % 8 == 0 and ctypes.sizeof(_lib.MonaSpatialDesc) == 296
 
 
 def test_error_path_without_gpu():
