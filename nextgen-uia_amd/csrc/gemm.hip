@@ -27,6 +27,12 @@
 
 #ifdef UIA_GEMM_STAMPS
 __device__ unsigned long long* uia_stamp_buf = nullptr;   // diagnostic build only (tests/test_gemm_stamps)
+__device__ int uia_epi_diag = 0;                          // 1: epilogue without its stores, 2: without stores and operand loads
+#define UIA_EPI_STORES (uia_epi_diag == 0)
+#define UIA_EPI_LOADS (uia_epi_diag < 2)
+#else
+#define UIA_EPI_STORES true
+#define UIA_EPI_LOADS true
 #endif
 
 namespace {
@@ -178,18 +184,49 @@ __device__ __forceinline__ void gemm_epilogue(const UiaGemmParams& p, f32x4 (&ac
 }
 
 
-// Epilogue of the ping-pong kernel: every wave bounces its accumulators, 16 rows at a time, through a private LDS
-// patch so that the bias/residual/aux loads and the C stores are issued with one lane per 8 consecutive columns
-// and consecutive lanes on consecutive 16/32-byte pieces of a row — whole 128/256-byte row segments per wave
-// instruction instead of 16 rows × 16-byte pieces.  (Measured before: 17K-49K cycles per 256×256 tile, as long as
-// the K loop itself; the MFMA-layout stores were issue-bound.)
-template <typename T, int MT, int NT, int WTM, int WTN>
+// Epilogue of the ping-pong / ring kernels.  Every wave bounces its accumulators through a private LDS patch so that
+// the bias/residual/aux loads and the C stores are issued with one lane per 8 consecutive columns and consecutive
+// lanes on consecutive 16/32-byte pieces of a row: whole 128/256-byte row segments per wave instruction instead of
+// 16 rows × 16-byte pieces in the MFMA layout (those stores were issue-bound: 17K-49K cycles per 256×256 tile).
+//
+// The patch holds 64 rows (4 MFMA row groups) at a time and the read-back/compute/store body is a ROLLED loop over
+// those rows.  It used to be unrolled over all 16 passes of a tile with every runtime option inlined in each copy:
+// ~18K instructions, >100 KB of straight-line code against a 64 KB instruction cache, and the stamps showed the
+// epilogue taking 20K cycles per tile with its loads AND stores disabled (tests/test_gemm_stamps, diag 2) — it was
+// instruction-fetch bound.  The K-loop's LDS buffers are dead by now, so the bigger patch costs nothing.
+template <int MT, int WTN> struct EpiPatch {
+    static constexpr int LDW = WTN + 4;                 // floats per staged row (+4 keeps the b128 accesses conflict-free)
+    static constexpr int GPP = MT < 4 ? MT : 4;         // MFMA row groups per phase
+    static constexpr int ROWS = GPP * 16;
+    static constexpr int BYTES_PER_WAVE = ROWS * LDW * 4;
+};
+
+// EPI selects the epilogue's feature set at COMPILE time (bit mask of EPI_*; the launcher picks the instantiation that
+// matches the descriptor) or, when EPI_GENERIC, at run time from the descriptor.  One training step uses six masks
+// for >99% of its GEMM time (tools/gemm_census.py); with the features folded the body is branch-free and the
+// compiler interleaves two read-back passes.  Specialised masks imply alpha == 1, no row remapping and GELU as the
+// activation; anything else takes the generic instantiation.
+enum : int { EPI_BIAS = 1, EPI_AUX_OUT = 2, EPI_GELU = 4, EPI_DGELU = 8, EPI_RESID = 16, EPI_RESIDT = 32, EPI_OUT32 = 64, EPI_OUTT = 128,
+             EPI_GENERIC = -1 };
+
+template <typename T, int MT, int NT, int WTM, int WTN, int EPI = EPI_GENERIC>
 __device__ __forceinline__ void gemm_epilogue_lds(const UiaGemmParams& p, f32x4 (&acc)[MT][NT], char* smem, int wave, int lane, int m0, int n0,
                                                   int wm, int wn) {
-    constexpr int LDW = WTN + 4;                    // floats per staged row (+4 keeps the b128 writes conflict-free)
+    constexpr bool GEN = EPI == EPI_GENERIC;
+    const bool f_bias = GEN ? p.bias != nullptr : (EPI & EPI_BIAS) != 0;
+    const bool f_aux_out = GEN ? p.aux_out != nullptr : (EPI & EPI_AUX_OUT) != 0;
+    const bool f_resid = GEN ? p.resid != nullptr : (EPI & EPI_RESID) != 0;
+    const bool f_residT = GEN ? p.residT != nullptr : (EPI & EPI_RESIDT) != 0;
+    const bool f_out32 = GEN ? p.out32 != nullptr : (EPI & EPI_OUT32) != 0;
+    const bool f_outT = GEN ? p.outT != nullptr : (EPI & EPI_OUTT) != 0;
+    const int act = GEN ? p.act : ((EPI & EPI_GELU) ? UIA_ACT_GELU : UIA_ACT_NONE);
+    const int dact = GEN ? p.dact : ((EPI & EPI_DGELU) ? UIA_ACT_GELU : UIA_ACT_NONE);
+    using EP = EpiPatch<MT, WTN>;
+    constexpr int LDW = EP::LDW, GPP = EP::GPP, ROWS = EP::ROWS;
     constexpr int LPR = WTN / 8;                    // lanes per row when reading back
     constexpr int RPP = 64 / LPR;                   // rows per read pass
-    float* stg = (float*)(smem + wave * (16 * LDW * 4));
+    static_assert(MT % GPP == 0, "row groups must split evenly into phases");
+    float* stg = (float*)(smem + wave * EP::BYTES_PER_WAVE);
     const int li = lane & 15, g = lane >> 4;
     const int rr = lane / LPR, rc = (lane % LPR) * 8;
     const int n = n0 + wn * WTN + rc;
@@ -200,47 +237,54 @@ __device__ __forceinline__ void gemm_epilogue_lds(const UiaGemmParams& p, f32x4 
     float bias[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) bias[e] = 0.f;
-    if (p.bias && n < p.N) load8(p.bias + n, bias);
+    if (f_bias && n < p.N) load8(p.bias + n, bias);
+    const bool col_ok = n < p.N;
 #pragma clang loop unroll(full)
-    for (int i = 0; i < MT; ++i) {
+    for (int ph = 0; ph < MT / GPP; ++ph) {
 #pragma clang loop unroll(full)
-        for (int j = 0; j < NT; ++j) *(f32x4*)(stg + li * LDW + g * (4 * NT) + 4 * j) = acc[i][j];
+        for (int gi = 0; gi < GPP; ++gi)
+#pragma clang loop unroll(full)
+            for (int j = 0; j < NT; ++j) *(f32x4*)(stg + (gi * 16 + li) * LDW + g * (4 * NT) + 4 * j) = acc[ph * GPP + gi][j];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int ps = 0; ps < 16 / RPP; ++ps) {
-            const int row = ps * RPP + rr;
+        const int mbase = m0 + wm * WTM + ph * ROWS + rr;
+#pragma clang loop unroll_count(2)
+        for (int q = 0; q < ROWS / RPP; ++q) {
+            const int row = q * RPP + rr;
             const f32x4 lo = *(const f32x4*)(stg + row * LDW + rc), hi = *(const f32x4*)(stg + row * LDW + rc + 4);
-            const int m = m0 + wm * WTM + 16 * i + row;
-            if (m < p.M && n < p.N) {
+            const int m = mbase + q * RPP;
+            if (m < p.M && col_ok) {
                 float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                const size_t orow = p.out_group > 0 ? (size_t)(m + m / p.out_group + 1) : (size_t)m;
-                const size_t rrow = p.resid_mod > 0 ? (size_t)(m % p.resid_mod + p.resid_row_off) : orow;
+                const size_t orow = GEN && p.out_group > 0 ? (size_t)(m + m / p.out_group + 1) : (size_t)m;
+                const size_t rrow = GEN && p.resid_mod > 0 ? (size_t)(m % p.resid_mod + p.resid_row_off) : orow;
+                if (GEN) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], p.alpha, bias[e]);
-                if (aux_out) store8(aux_out + orow * p.ldaux_out + n, v);
-                if (p.act) {
-                    apply_act8<sizeof(T) == 2>(v, p.act);
+                    for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], p.alpha, bias[e]);
+                } else if (f_bias) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += bias[e];
                 }
-                if (p.dact) {
+                if (f_aux_out && UIA_EPI_STORES) store8(aux_out + orow * p.ldaux_out + n, v);
+                if (act) apply_act8<sizeof(T) == 2>(v, act);
+                if (dact && UIA_EPI_LOADS) {
                     float a[8];
                     load8(aux_in + orow * p.ldaux_in + n, a);
-                    apply_dact8<sizeof(T) == 2>(v, a, p.dact);
+                    apply_dact8<sizeof(T) == 2>(v, a, dact);
                 }
-                if (p.resid) {
+                if (f_resid && UIA_EPI_LOADS) {
                     float r[8];
                     load8(p.resid + rrow * p.ldr + n, r);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += r[e];
                 }
-                if (residT) {
+                if (f_residT && UIA_EPI_LOADS) {
                     float r[8];
                     load8(residT + orow * p.ldrT + n, r);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += r[e];
                 }
-                if (p.out32) store8(p.out32 + orow * p.ldo32 + n, v);
-                if (outT) store8(outT + orow * p.ldo + n, v);
+                if (f_out32 && UIA_EPI_STORES) store8(p.out32 + orow * p.ldo32 + n, v);
+                if (f_outT && UIA_EPI_STORES) store8(outT + orow * p.ldo + n, v);
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -533,7 +577,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_tn_pp_kernel(cons
 
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
 int launch_pp(hipStream_t stream, const UiaGemmParams& p) {
-    constexpr int LDS = 2 * (BM + BN) * 128;
+    constexpr int EPI = WAVES_M * WAVES_N * EpiPatch<BM / WAVES_M / 16, BN / WAVES_N>::BYTES_PER_WAVE;
+    constexpr int LDS = 2 * (BM + BN) * 128 > EPI ? 2 * (BM + BN) * 128 : EPI;
     auto kern = gemm_tn_pp_kernel<T, BM, BN, WAVES_M, WAVES_N>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -563,8 +608,8 @@ int launch_pp(hipStream_t stream, const UiaGemmParams& p) {
 //   sub-tile t-1, whose final ds_reads (group 1, wall slot 2·t·SPT-1) were retired before that slot's barrier.
 // 64-byte rows use the 4-entry swizzle table {0,3,2,1} indexed by (row>>2)&3 (A) / the 16-row block of the
 // permuted W rows: conflict-free ds_read_b128 for both fragment patterns.
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int NBUF>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_tn_ring_kernel(const UiaGemmParams p, const int stagger_cycles) {
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int NBUF, int EPI>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_tn_ring_kernel(const UiaGemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
@@ -594,15 +639,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_tn_ring_kernel(co
     }
     const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
-
-    // De-phase the chip: all first-round workgroups start together and, with equal tiles, would reach their epilogues
-    // together (HBM saturated for that phase, idle during the K loops).  Half of the first-round workgroups of every XCD
-    // start half a tile period late, so one half's store/residual traffic overlaps the other half's K loop for the
-    // rest of the launch (later workgroups inherit the offset of the CU they land on).
-    if (stagger_cycles > 0 && blockIdx.x < 256 && ((blockIdx.x >> 3) & 1)) {
-        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-        while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)stagger_cycles) __builtin_amdgcn_s_sleep(32);
-    }
 
     // swizzle of the 16-byte chunk index: 128-byte rows: (row>>1)&7 / 2a|(b>>1) as in the 2-buffer kernels;
     // 64-byte rows: table {0,3,2,1}[(row>>2)&3] for A, [(row_local>>4)&3] for the permuted W rows.
@@ -715,38 +751,59 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_tn_ring_kernel(co
 #ifdef UIA_GEMM_STAMPS
     t_loop = __builtin_amdgcn_s_memtime();
 #endif
-    gemm_epilogue_lds<T, MT, NT, WTM, WTN>(p, acc, smem, wave, lane, m0, n0, wm, wn);
+    gemm_epilogue_lds<T, MT, NT, WTM, WTN, EPI>(p, acc, smem, wave, lane, m0, n0, wm, wn);
 #ifdef UIA_GEMM_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0 && uia_stamp_buf) {
         unsigned long long t_end = __builtin_amdgcn_s_memtime();
         unsigned long long* o = uia_stamp_buf + ((size_t)blockIdx.x * NW + wave) * 4;
         o[0] = t_start; o[1] = t_pro; o[2] = t_loop; o[3] = t_end;
-        if (wave == 0) { unsigned long long* q = uia_stamp_buf + (size_t)gridDim.x * NW * 4 + (size_t)blockIdx.x * 4; q[0] = q[1] = q[2] = q[3] = 0; }
+        if (wave == 0) { unsigned long long* q = uia_stamp_buf + (size_t)gridDim.x * NW * 4 + (size_t)blockIdx.x * 4; q[0] = __builtin_amdgcn_s_getreg(63492); q[1] = __builtin_amdgcn_s_getreg(63508); q[2] = q[3] = 0; }
     }
 #endif
 }
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int NBUF>
-int launch_ring(hipStream_t stream, const UiaGemmParams& p, bool stagger = false) {
-    constexpr int LDS = NBUF * (BM + BN) * BKB;
-    auto kern = gemm_tn_ring_kernel<T, BM, BN, WAVES_M, WAVES_N, BKB, NBUF>;
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int NBUF, int EPI>
+int launch_ring_epi(hipStream_t stream, const UiaGemmParams& p) {
+    constexpr int EPB = WAVES_M * WAVES_N * EpiPatch<BM / WAVES_M / 16, BN / WAVES_N>::BYTES_PER_WAVE;
+    constexpr int LDS = NBUF * (BM + BN) * BKB > EPB ? NBUF * (BM + BN) * BKB : EPB;
+    static_assert(LDS <= 160 * 1024, "LDS budget");
+    auto kern = gemm_tn_ring_kernel<T, BM, BN, WAVES_M, WAVES_N, BKB, NBUF, EPI>;
     static bool attr_set = false;
     if (!attr_set) {
         UIA_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr_set = true;
     }
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    // half of an estimated tile period (cycles): K loop ~3000 per 64-deep step + epilogue ~ proportional to the bytes it moves
-    int stag = 0;
-    if (stagger && tiles > 256) {
-        const int ksteps = (p.K * (int)sizeof(T)) / 128;
-        const int epi = 8000 + (p.outT ? 7000 : 0) + (p.aux_out ? 25000 : 0) + (p.out32 ? 14000 : 0) + (p.resid ? 14000 : 0) + (p.aux_in ? 7000 : 0);
-        stag = (ksteps * 3000 + epi) / 2;
-    }
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(64 * WAVES_M * WAVES_N), LDS, stream, p, stag);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(64 * WAVES_M * WAVES_N), LDS, stream, p);
     UIA_CHECK_LAUNCH();
     return 0;
+}
+
+// feature mask of a descriptor, or EPI_GENERIC when it uses something the specialised epilogues leave out
+inline int epi_mask_of(const UiaGemmParams& p) {
+    if (p.alpha != 1.0f || p.out_group > 0 || p.resid_mod > 0) return EPI_GENERIC;
+    if ((p.act && p.act != UIA_ACT_GELU) || (p.dact && p.dact != UIA_ACT_GELU)) return EPI_GENERIC;
+    return (p.bias ? EPI_BIAS : 0) | (p.aux_out ? EPI_AUX_OUT : 0) | (p.act ? EPI_GELU : 0) | (p.dact ? EPI_DGELU : 0) | (p.resid ? EPI_RESID : 0) |
+           (p.residT ? EPI_RESIDT : 0) | (p.out32 ? EPI_OUT32 : 0) | (p.outT ? EPI_OUTT : 0);
+}
+
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int NBUF>
+int launch_ring(hipStream_t stream, const UiaGemmParams& p, bool specialise) {
+    if (specialise) {
+        switch (epi_mask_of(p)) {    // the six masks of a training step, by time spent (tools/gemm_census.py)
+#define UIA_EPI_CASE(MASK) case (MASK): return launch_ring_epi<T, BM, BN, WAVES_M, WAVES_N, BKB, NBUF, (MASK)>(stream, p)
+            UIA_EPI_CASE(EPI_BIAS | EPI_RESID | EPI_OUT32);                    // proj / fc2 / Mona project2 forward
+            UIA_EPI_CASE(EPI_OUTT);                                            // dgrads
+            UIA_EPI_CASE(EPI_BIAS | EPI_OUTT);                                 // QKV
+            UIA_EPI_CASE(EPI_BIAS | EPI_GELU | EPI_OUTT);                      // fc1, frozen tower
+            UIA_EPI_CASE(EPI_DGELU | EPI_OUTT);                                // fc2 dgrad through GELU'
+            UIA_EPI_CASE(EPI_BIAS | EPI_GELU | EPI_AUX_OUT | EPI_OUTT);        // fc1 with the pre-activation stashed
+#undef UIA_EPI_CASE
+            default: break;
+        }
+    }
+    return launch_ring_epi<T, BM, BN, WAVES_M, WAVES_N, BKB, NBUF, EPI_GENERIC>(stream, p);
 }
 
 template <typename T>
@@ -766,10 +823,9 @@ int launch_typed(hipStream_t stream, const UiaGemmParams& p, int cfg) {
         case 5: return launch_cfg<T, 128, 64, 2, 1>(stream, p);
         case 6: return launch_pp<T, 256, 256, 2, 4>(stream, p);
         case 7: return launch_pp<T, 256, 128, 4, 2>(stream, p);
-        case 8: return launch_ring<T, 256, 256, 2, 4, 64, 4>(stream, p);
-        case 9: return launch_ring<T, 256, 128, 4, 2, 128, 3>(stream, p);
-        case 10: return launch_ring<T, 256, 256, 2, 4, 64, 5>(stream, p);
-        case 11: return launch_ring<T, 256, 256, 2, 4, 64, 4>(stream, p, true);
+        case 8: return launch_ring<T, 256, 256, 2, 4, 64, 4>(stream, p, true);
+        case 9: return launch_ring<T, 256, 128, 4, 2, 128, 3>(stream, p, false);
+        case 10: return launch_ring<T, 256, 256, 2, 4, 64, 4>(stream, p, false);   // cfg 8 with the run-time (generic) epilogue: parity cross-check
         default: uia_set_error("uia_gemm: unknown tile config %d", cfg); return -1;
     }
 }

@@ -6,6 +6,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
+#include <map>
+#include <algorithm>
 #include "../uia_kernels.h"
 extern "C" const char* uia_last_error(void);
 
@@ -114,7 +116,10 @@ static void bench(int dtype, int M, int N, int K, int cfg, int mode) {
 
 #ifdef UIA_GEMM_STAMPS
 extern __device__ unsigned long long* uia_stamp_buf;
-static void stamps(int cfg, int M, int N, int K, int mode) {
+extern __device__ int uia_epi_diag;
+static void stamps(int cfg, int M, int N, int K, int mode, int diag = 0) {
+    HC(hipMemcpyToSymbol(HIP_SYMBOL(uia_epi_diag), &diag, sizeof(diag)));
+    if (diag) printf("-- epilogue diag %d (1: no stores, 2: no stores, no operand loads)\n", diag);
     const int BM = 256, BN = (cfg == 7 || cfg == 9) ? 128 : 256, NW = 8;
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     unsigned long long* d; HC(hipMalloc(&d, ((size_t)tiles * NW * 4 + (size_t)tiles * 4) * 8));
@@ -127,6 +132,25 @@ static void stamps(int cfg, int M, int N, int K, int mode) {
     const double n = (double)tiles * NW;
     printf("STAMPS cfg=%d M=%d N=%d K=%d mode=%d: per-wave ticks (100MHz s_memtime? see ratio) prologue %.0f  k-loop %.0f (%.0f per K-step)  epilogue %.0f  total %.0f ; kernel span %llu ticks\n",
            cfg, M, N, K, mode, pro / n, loop / n, loop / n / (K / 64), epi / n, tot / n, t1 - t0);
+    if (cfg >= 8) {   // ring kernel: q[0] = HW_ID, q[1] = XCC_ID of wave 0.  Group blocks by CU and look at the gaps between consecutive blocks.
+        const unsigned long long* q = h.data() + (size_t)tiles * NW * 4;
+        std::map<unsigned, std::vector<std::pair<unsigned long long, unsigned long long>>> per_cu;
+        for (int b = 0; b < tiles; ++b) {
+            const unsigned hw = (unsigned)q[4*b], xcc = (unsigned)q[4*b+1] & 0xf;
+            const unsigned cu = (hw >> 8) & 0xf, sh = (hw >> 12) & 1, se = (hw >> 13) & 7;
+            unsigned long long s = ~0ull, e = 0;
+            for (int w = 0; w < NW; ++w) { s = std::min(s, h[4*((size_t)b*NW+w)]); e = std::max(e, h[4*((size_t)b*NW+w)+3]); }
+            per_cu[(xcc << 12) | (se << 8) | (sh << 4) | cu].push_back({s, e});
+        }
+        double gap = 0, busy = 0; int ngap = 0; unsigned long long span = 0;
+        for (auto& kv : per_cu) {
+            auto& v = kv.second; std::sort(v.begin(), v.end());
+            for (size_t i = 0; i < v.size(); ++i) { busy += v[i].second - v[i].first; if (i) { gap += (double)v[i].first - (double)v[i-1].second; ++ngap; } }
+            span = std::max(span, v.back().second - v.front().first);
+        }
+        printf("   %zu CUs seen, blocks/CU %.2f, block busy %.0f cycles avg, gap between consecutive blocks on a CU %.0f cycles avg, longest CU span %llu cycles\n",
+               per_cu.size(), (double)tiles / per_cu.size(), busy / tiles, ngap ? gap / ngap : 0.0, span);
+    }
     { double sl[4] = {0,0,0,0}; const unsigned long long* q = h.data() + (size_t)tiles * NW * 4;
       for (int i = 0; i < tiles; ++i) for (int k = 0; k < 4; ++k) sl[k] += q[4*i+k];
       printf("   group-0 wave-0 slot cycles per K-step: LOAD0(+8 glds) %.0f | COMPUTE0 %.0f | LOAD1 %.0f | COMPUTE1(+vmcnt) %.0f\n", sl[0]/tiles/(K/64), sl[1]/tiles/(K/64), sl[2]/tiles/(K/64), sl[3]/tiles/(K/64)); }
@@ -136,12 +160,11 @@ static void stamps(int cfg, int M, int N, int K, int mode) {
 
 int main(int argc, char** argv) {
 #ifdef UIA_GEMM_STAMPS
-    stamps(6, 50432, 2304, 768, 0);
-    stamps(8, 50432, 2304, 768, 0);
-    stamps(8, 50432, 3072, 768, 1);
-    stamps(8, 50432, 768, 3072, 2);
-    stamps(8, 50432, 768, 768, 2);
-    stamps(6, 8192, 8192, 8192, 0);
+    for (int diag = 0; diag < 3; diag += 2) {
+        stamps(8, 50432, 2304, 768, 0, diag);
+        stamps(8, 50432, 3072, 768, 1, diag);
+        stamps(8, 50432, 768, 768, 2, diag);
+    }
     return 0;
 #endif
     if (argc > 2 && !strcmp(argv[1], "one")) {      // ./test_gemm one <cfg> [M N K]: a single shape, for PMC runs

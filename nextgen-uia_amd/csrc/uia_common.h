@@ -92,10 +92,10 @@ __device__ __forceinline__ void gelu_parts(float x, float& Phi, float& E) {
     E = __expf(-ax * ax);
     float y;
     if (FAST) {
-        const float t = __frcp_rn(fmaf(0.47047f, ax, 1.0f));
+        const float t = __builtin_amdgcn_rcpf(fmaf(0.47047f, ax, 1.0f));
         y = fmaf(fmaf(0.7478556f, t, -0.0958798f), t, 0.3480242f) * t;
     } else {
-        const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+        const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
         y = fmaf(1.061405429f, t, -1.453152027f);
         y = fmaf(y, t, 1.421413741f);
         y = fmaf(y, t, -0.284496736f);
@@ -119,10 +119,10 @@ __device__ __forceinline__ float gelu_erf(float x) { return gelu_erf_t<false>(x)
 __device__ __forceinline__ float dgelu_erf(float x) { return dgelu_erf_t<false>(x); }
 // QuickGELU x*sigmoid(1.702x) (reference src/third_party/openai_clip/model.py:172-174)
 __device__ __forceinline__ float quick_gelu(float x) {
-    return x * __frcp_rn(1.0f + __expf(-1.702f * x));
+    return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
 }
 __device__ __forceinline__ float dquick_gelu(float x) {
-    const float s = __frcp_rn(1.0f + __expf(-1.702f * x));
+    const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
     return s * fmaf(1.702f * x, 1.0f - s, 1.0f);
 }
 

@@ -49,6 +49,44 @@ def test_gemm_epilogues(ops, dt):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
+def test_gemm_every_tile_config_and_epilogue_mask(ops, dt, cfg):
+    """Every tile instantiation (lockstep 1-5, ping-pong 6-7, ring 8-10) against torch on a ragged shape, through
+    the six compile-time epilogue masks of the ring kernel (cfg 8) and the run-time epilogue (everything else)."""
+    torch.manual_seed(10 + cfg)
+    M, N, K = 2 * 256 + 77, 264, 192          # ragged in M and N for every tile size
+    a = torch.randn(M, K, device=dev()).to(dt)
+    w = (torch.randn(N, K, device=dev()) * 0.1).to(dt)
+    bias, resid = torch.randn(N, device=dev()), torch.randn(M, N, device=dev())
+    pre = a.float() @ w.float().T
+    gelu = torch.nn.functional.gelu
+    tol = TOL[dt]
+    o_t = lambda: torch.full((M, N), float("nan"), device=dev(), dtype=dt)
+    o32 = lambda: torch.full((M, N), float("nan"), device=dev())
+
+    y = o32(); ops.gemm(a, w, bias=bias, resid=resid, out32=y, tile_cfg=cfg)                       # proj / fc2
+    assert rel(y, pre + bias + resid) < 2e-5 and bool(torch.isfinite(y).all())
+    y = o_t(); ops.gemm(a, w, out_t=y, tile_cfg=cfg)                                               # dgrad
+    assert rel(y, pre) < tol
+    y = o_t(); ops.gemm(a, w, bias=bias, out_t=y, tile_cfg=cfg)                                    # QKV
+    assert rel(y, pre + bias) < tol
+    y = o_t(); ops.gemm(a, w, bias=bias, act="gelu", out_t=y, tile_cfg=cfg)                        # fc1 (frozen tower)
+    assert rel(y, gelu(pre + bias)) < tol
+    y, aux = o_t(), o_t(); ops.gemm(a, w, bias=bias, act="gelu", aux_out=aux, out_t=y, tile_cfg=cfg)   # fc1 + stash
+    assert rel(y, gelu(pre + bias)) < tol and rel(aux, pre + bias) < tol
+    x = aux.float().requires_grad_(True)
+    gelu(x).sum().backward()
+    y = o_t(); ops.gemm(a, w, dact="gelu", aux_in=aux, out_t=y, tile_cfg=cfg)                      # fc2 dgrad through GELU'
+    assert rel(y, pre * x.grad) < tol
+    # combinations outside the specialised masks take the run-time epilogue
+    rt = torch.randn(M, N, device=dev()).to(dt)
+    y, y2 = o32(), o_t(); ops.gemm(a, w, bias=bias, resid=resid, resid_t=rt, out32=y, out_t=y2, alpha=0.5, tile_cfg=cfg)
+    assert rel(y, 0.5 * pre + bias + resid + rt.float()) < 2e-5 and rel(y2, 0.5 * pre + bias + resid + rt.float()) < tol
+    y = o_t(); ops.gemm(a, w, bias=bias, act="quick_gelu", out_t=y, tile_cfg=cfg)
+    assert rel(y, (pre + bias) * torch.sigmoid(1.702 * (pre + bias))) < tol
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_gemm_patch_embed_epilogue(ops, dt):
     torch.manual_seed(1)
     B, G, K, D = 3, 16, 192, 128          # 3 images, 16 patches each
