@@ -28,11 +28,20 @@
 #ifdef UIA_GEMM_STAMPS
 __device__ unsigned long long* uia_stamp_buf = nullptr;   // diagnostic build only (tests/test_gemm_stamps)
 __device__ int uia_epi_diag = 0;                          // 1: epilogue without its stores, 2: without stores and operand loads
-#define UIA_EPI_STORES (uia_epi_diag == 0)
-#define UIA_EPI_LOADS (uia_epi_diag < 2)
+#define UIA_EPI_STORES ((uia_epi_diag & 3) == 0)
+#define UIA_EPI_LOADS ((uia_epi_diag & 3) < 2)
+#ifndef UIA_KDIAG
+#define UIA_KDIAG 0                                // compile-time: a run-time test inside the K loop disturbs its schedule
+#endif
+#define UIA_DIAG_NO_FRAGS ((UIA_KDIAG & 4) != 0)   // K loop without its ds_reads
+#define UIA_DIAG_NO_DMA ((UIA_KDIAG & 8) != 0)     // K loop without its LDS-DMA (after the prologue)
+#define UIA_DIAG_NO_MFMA ((UIA_KDIAG & 16) != 0)   // K loop without its MFMAs
 #else
 #define UIA_EPI_STORES true
 #define UIA_EPI_LOADS true
+#define UIA_DIAG_NO_FRAGS false
+#define UIA_DIAG_NO_DMA false
+#define UIA_DIAG_NO_MFMA false
 #endif
 
 namespace {
@@ -735,12 +744,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_tn_ring_kernel(co
         const char* buf = smem + (t % NBUF) * BUF_BYTES;
         const bool last_of_tile = kk == SPT - 1;
         // ---- LOAD(u): this group's DMA pieces of sub-tile t+PD ride beside the other group's MFMA cluster
-        if (t + PD < ntl) stage(t + PD, kk);
-        load_frags(buf, kk);
+        if (t + PD < ntl && !UIA_DIAG_NO_DMA) stage(t + PD, kk);
+        if (!UIA_DIAG_NO_FRAGS) load_frags(buf, kk);
         if (grp == 1 && last_of_tile && t + 1 < ntl) retire(t + 1);
         UIA_SLOT_END();
         // ---- COMPUTE(u)
-        compute();
+        if (!UIA_DIAG_NO_MFMA) compute();
         if (grp == 0 && last_of_tile && t + 1 < ntl) retire(t + 1);
         UIA_SLOT_END();
     }

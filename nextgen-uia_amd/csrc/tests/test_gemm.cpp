@@ -119,7 +119,7 @@ extern __device__ unsigned long long* uia_stamp_buf;
 extern __device__ int uia_epi_diag;
 static void stamps(int cfg, int M, int N, int K, int mode, int diag = 0) {
     HC(hipMemcpyToSymbol(HIP_SYMBOL(uia_epi_diag), &diag, sizeof(diag)));
-    if (diag) printf("-- epilogue diag %d (1: no stores, 2: no stores, no operand loads)\n", diag);
+    if (diag) printf("-- diag %d (1: no stores, 2: no stores/operand loads, +4 no ds_reads, +8 no DMA, +16 no MFMA)\n", diag);
     const int BM = 256, BN = (cfg == 7 || cfg == 9) ? 128 : 256, NW = 8;
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     unsigned long long* d; HC(hipMalloc(&d, ((size_t)tiles * NW * 4 + (size_t)tiles * 4) * 8));
@@ -160,11 +160,7 @@ static void stamps(int cfg, int M, int N, int K, int mode, int diag = 0) {
 
 int main(int argc, char** argv) {
 #ifdef UIA_GEMM_STAMPS
-    for (int diag = 0; diag < 3; diag += 2) {
-        stamps(8, 50432, 2304, 768, 0, diag);
-        stamps(8, 50432, 3072, 768, 1, diag);
-        stamps(8, 50432, 768, 768, 2, diag);
-    }
+    stamps(8, 50432, 2304, 768, 0, 0);
     return 0;
 #endif
     if (argc > 2 && !strcmp(argv[1], "one")) {      // ./test_gemm one <cfg> [M N K]: a single shape, for PMC runs
