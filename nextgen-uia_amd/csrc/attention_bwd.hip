@@ -7,15 +7,19 @@
 //     P = exp(S·scale − lse),  dP = dO·Vᵀ,  δ = rowsum(dO ⊙ O),  dS = P ⊙ (dP − δ)·scale,
 //     dV = Pᵀ·dO,  dK = dSᵀ·Q,  dQ = dS·K.
 //
-// bf16 path (MFMA): Q, K, V, dO of the head are staged once in LDS (row-major, XOR-swizzled).
+// bf16 path (MFMA), 8 waves: Q, K, dO of the head are staged once in LDS (row-major, XOR-swizzled); V goes straight
+// to the registers of the wave that owns the key tile.
 //   * S and dP are computed with the KEY on the MFMA lane (A = Q / dO rows, B = K / V rows), so a
 //     lane holds P[q = 16·qt + 4g + r][key]; two query tiles give the 8-element B fragment of
 //     dVᵀ += dOᵀ·P and dKᵀ += Qᵀ·dS with no lane movement.  The transposed A operands (dOᵀ, Qᵀ)
 //     are ds_read_b64_tr_b16 reads of the row-major tiles.
-//   * each wave owns key tiles {w, w+4, ...} and keeps their dKᵀ / dVᵀ in registers for the whole
-//     sweep over queries: no cross-workgroup (or cross-wave) reduction for dK, dV.
-//   * dS crosses LDS once per 32-query block (bf16, [32][keys]) for dQᵀ = Kᵀ·dSᵀ, whose Kᵀ operand
-//     is again a transpose read of the K tile.
+//   * each wave owns key tiles {w, w+8, ...} and keeps their K/V fragments and dKᵀ / dVᵀ in registers for the
+//     whole sweep over queries: no cross-workgroup (or cross-wave) reduction for dK, dV.
+//   * dS crosses LDS once per 32-query block as dSᵀ (bf16, [keys][32 queries], one 8-byte store per query tile)
+//     for dQᵀ = Kᵀ·dSᵀ; both of its operands are transpose reads.
+//   * interior tiles of an unmasked head take a path with no per-element tests; exp2 is the raw v_exp_f32.
+//     (The first version was VALU-bound at one wave per SIMD: ~20 VALU instructions and 8 two-byte LDS stores per
+//     element group, 424 us per ViT-B layer at B=256 against an MFMA floor of ~50.)
 // fp32 path (parity mode): plain VALU, three sweeps (dQ per query, dV per key, dK per key).
 #include "uia_common.h"
 #include "uia_kernels.h"
@@ -41,22 +45,23 @@ __device__ __forceinline__ f32x4 mma(const uint4& a, const uint4& b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-// All four tiles use the same image: [rows][128 B], 16-B chunk c of row r stored at chunk c ^ ((r>>1)&7).
+// K, Q, dO tiles share one image: [rows][128 B], 16-B chunk c of row r stored at chunk c ^ ((r>>1)&7).
+// dSᵀ tile: [keys][64 B] (32 queries of the current block), 8-B chunk c of row r stored at chunk c ^ ((r>>1)&7).
+constexpr int BWD_WAVES = 8;
+__host__ __device__ constexpr int bwd_lds_bytes(int LPK) { return 3 * LPK * 128 + LPK * 64 + 2 * LPK * 4; }
+
 template <int LT_MAX>
-__global__ __launch_bounds__(256) void attn_bwd_bf16_kernel(const UiaAttnParams p) {
+__global__ __launch_bounds__(64 * BWD_WAVES) void attn_bwd_bf16_kernel(const UiaAttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NP_MAX = (LT_MAX + 1) / 2;
-    constexpr int KTW = (LT_MAX + 3) / 4;          // key tiles owned by one wave
+    constexpr int KTW = (LT_MAX + BWD_WAVES - 1) / BWD_WAVES;   // key tiles owned by one wave
     const int L = p.L;
     const int LT = (L + 15) >> 4, NP = (LT + 1) >> 1, LPK = NP * 32;
-    const int DS_STRIDE = LPK * 2 + 16;            // bytes per dS row (keys bf16 + 16 B pad)
     char* Ks = smem;
-    char* Vs = Ks + LPK * 128;
-    char* Qs = Vs + LPK * 128;
+    char* Qs = Ks + LPK * 128;
     char* Gs = Qs + LPK * 128;                     // dO
-    char* dSs = Gs + LPK * 128;                    // [32][DS_STRIDE]
-    float* lse2 = (float*)(dSs + 32 * DS_STRIDE);  // [LPK] lse in base-2 units
-    float* delta = lse2 + LPK;                     // [LPK]
+    char* dST = Gs + LPK * 128;                    // [LPK keys][32 queries] bf16
+    float* lse2 = (float*)(dST + LPK * 64);        // [LPK] lse in base-2 units
+    float* dls = lse2 + LPK;                       // [LPK] δ·scale
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -68,41 +73,52 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16_kernel(const UiaAttnParams 
     const char* vb = (const char*)p.v + (row0 * p.ld_qkv + (size_t)h * 64) * 2;
     const char* gb = (const char*)p.dout + (row0 * p.lddo + (size_t)h * 64) * 2;
     const char* ob = (const char*)p.out + (row0 * p.ldo + (size_t)h * 64) * 2;
+    const int li = lane & 15, g = lane >> 4;
 
     const int ninstr = LPK >> 3;
-    for (int q = wave; q < ninstr; q += 4) {
+    for (int q = wave; q < ninstr; q += BWD_WAVES) {
         const int r = 8 * q + (lane >> 3);
         const int gr = r < L ? r : L - 1;
         const int c = ((lane & 7) ^ ((r >> 1) & 7)) * 16;
         glds16(kb + gr * rs + c, Ks + q * 1024);
-        glds16(vb + gr * rs + c, Vs + q * 1024);
         glds16(qb + gr * rs + c, Qs + q * 1024);
         glds16(gb + gr * rso + c, Gs + q * 1024);
     }
-    // δ and lse (plain loads, independent of the LDS image)
+    // V is only ever a B operand of the wave that owns the key tile: its fragments go straight from HBM to registers
+    // (row 16kt+li, 16-B chunks g and g+4), for the whole sweep over queries.
+    uint4 vf[KTW][2];
+#pragma unroll
+    for (int a = 0; a < KTW; ++a) {
+        const int kt = wave + BWD_WAVES * a;
+        int r = 16 * kt + li;
+        r = r < L ? r : L - 1;
+        vf[a][0] = *(const uint4*)(vb + r * rs + g * 16);
+        vf[a][1] = *(const uint4*)(vb + r * rs + (g + 4) * 16);
+    }
+    // δ·scale and lse (plain loads, independent of the LDS image); dSᵀ rows of the key tiles nobody owns are zeroed once
     const float sc = p.scale * 1.44269504088896341f;
-    for (int r = tid; r < LPK; r += 256) {
+    for (int r = tid; r < LPK; r += 64 * BWD_WAVES) {
         float d = 0.f, l2 = 0.f;
         if (r < L) {
             const bf16_t* go = (const bf16_t*)(gb + r * rso);
             const bf16_t* oo = (const bf16_t*)(ob + (size_t)r * p.ldo * 2);
 #pragma unroll
             for (int c = 0; c < 64; c += 8) {
-                float a[8], bb[8];
-                load8(go + c, a);
-                load8(oo + c, bb);
+                float x[8], y[8];
+                load8(go + c, x);
+                load8(oo + c, y);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) d = fmaf(a[e], bb[e], d);
+                for (int e = 0; e < 8; ++e) d = fmaf(x[e], y[e], d);
             }
             l2 = p.lse[((size_t)b * p.H + h) * L + r] * 1.44269504088896341f;
         }
-        delta[r] = d;
+        dls[r] = d * p.scale;
         lse2[r] = l2;
     }
+    for (int i = tid; i < (LPK - 16 * LT) * 4; i += 64 * BWD_WAVES) *(uint4*)(dST + 16 * LT * 64 + i * 16) = uint4{0u, 0u, 0u, 0u};
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    const int li = lane & 15, g = lane >> 4;
     int klen = L;
     if (p.mask_kind == UIA_MASK_KEYPAD && p.keylen) { klen = p.keylen[b]; klen = klen < 1 ? 1 : (klen > L ? L : klen); }
 
@@ -113,10 +129,19 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16_kernel(const UiaAttnParams 
     const int qq = li >> 2, pp = li & 3;
     const int trow = 4 * g + qq;                        // within a 32-row block (hi half: +16)
     const int tsw = (trow >> 1) & 7;                    // (row>>1)&7; +16 adds 8 → same &7
-    // natural-order transpose read for dQ (k-slot (g,e) ↔ row 8g+e): rows 8g+qq and 8g+4+qq
+    // natural-order transpose reads for dQ (k-slot (g,e) ↔ key 8g+e): rows 8g+qq (lo) and 8g+4+qq (hi)
     const int nrow = 8 * g + qq;
     const int nsw_lo = (nrow >> 1) & 7, nsw_hi = ((nrow + 4) >> 1) & 7;
 
+    // K fragments of the owned key tiles (B operand of S = Q·Kᵀ), kept for the whole sweep
+    uint4 kf[KTW][2];
+#pragma unroll
+    for (int a = 0; a < KTW; ++a) {
+        const int kt = wave + BWD_WAVES * a;
+        const int ktc = kt < 2 * NP ? kt : 0;
+        kf[a][0] = *(const uint4*)(Ks + ktc * 2048 + offR);
+        kf[a][1] = *(const uint4*)(Ks + ktc * 2048 + (offR ^ 64));
+    }
     f32x4 dVt[KTW][4], dKt[KTW][4];
 #pragma unroll
     for (int a = 0; a < KTW; ++a)
@@ -126,14 +151,12 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16_kernel(const UiaAttnParams 
 #pragma unroll 1
     for (int u = 0; u < NP; ++u) {
         // per-lane query rows of this 32-query block: q(hq, r) = 32u + 16hq + 4g + r
-        float ls[2][4], dl[2][4];
+        f32x4 ls[2], dl[2];
 #pragma unroll
-        for (int hq = 0; hq < 2; ++hq)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                ls[hq][r] = lse2[32 * u + 16 * hq + 4 * g + r];
-                dl[hq][r] = delta[32 * u + 16 * hq + 4 * g + r];
-            }
+        for (int hq = 0; hq < 2; ++hq) {
+            ls[hq] = *(const f32x4*)(lse2 + 32 * u + 16 * hq + 4 * g);
+            dl[hq] = *(const f32x4*)(dls + 32 * u + 16 * hq + 4 * g);
+        }
         // A fragments of the two query tiles (Q and dO), both k-halves
         uint4 qf[2][2], gf[2][2];
 #pragma unroll
@@ -151,33 +174,55 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16_kernel(const UiaAttnParams 
             gT[dt] = tr_pair(Gs + off, Gs + off + 16 * 128);
             qT[dt] = tr_pair(Qs + off, Qs + off + 16 * 128);
         }
+        const bool full_q = p.mask_kind == UIA_MASK_NONE && 32 * u + 32 <= L;
 #pragma unroll
         for (int a = 0; a < KTW; ++a) {
-            const int kt = wave + 4 * a;
+            const int kt = wave + BWD_WAVES * a;
             if (kt < LT) {
-                const uint4 kf0 = *(const uint4*)(Ks + kt * 2048 + offR), kf1 = *(const uint4*)(Ks + kt * 2048 + (offR ^ 64));
-                const uint4 vf0 = *(const uint4*)(Vs + kt * 2048 + offR), vf1 = *(const uint4*)(Vs + kt * 2048 + (offR ^ 64));
                 const int key = 16 * kt + li;
                 bf16x8 pf, sf;
+                f32x4 s[2], dp[2];
 #pragma unroll
                 for (int hq = 0; hq < 2; ++hq) {
-                    f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
-                    s = mma(qf[hq][0], kf0, s);
-                    s = mma(qf[hq][1], kf1, s);
-                    dp = mma(gf[hq][0], vf0, dp);
-                    dp = mma(gf[hq][1], vf1, dp);
+                    s[hq] = mma(qf[hq][0], kf[a][0], f32x4{0.f, 0.f, 0.f, 0.f});
+                    dp[hq] = mma(gf[hq][0], vf[a][0], f32x4{0.f, 0.f, 0.f, 0.f});
+                }
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int qrow = 32 * u + 16 * hq + 4 * g + r;
-                        const int kmax = p.mask_kind == UIA_MASK_CAUSAL ? (qrow < klen - 1 ? qrow : klen - 1) : klen - 1;
-                        const bool ok = qrow < L && key <= kmax;
-                        const float pv = ok ? exp2f(s[r] * sc - ls[hq][r]) : 0.f;
-                        const float dsv = pv * (dp[r] - dl[hq][r]) * p.scale;
-                        pf[4 * hq + r] = (bf16_t)pv;
-                        sf[4 * hq + r] = (bf16_t)dsv;
-                        // dS for dQ: row (16hq+4g+r) of the block, column key
-                        *(bf16_t*)(dSs + (16 * hq + 4 * g + r) * DS_STRIDE + key * 2) = (bf16_t)dsv;
-                    }
+                for (int hq = 0; hq < 2; ++hq) {
+                    s[hq] = mma(qf[hq][1], kf[a][1], s[hq]);
+                    dp[hq] = mma(gf[hq][1], vf[a][1], dp[hq]);
+                }
+                if (full_q && 16 * kt + 16 <= L) {       // interior tile, no mask: no per-element tests
+#pragma unroll
+                    for (int hq = 0; hq < 2; ++hq)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float pv = __builtin_amdgcn_exp2f(fmaf(s[hq][r], sc, -ls[hq][r]));
+                            const float dsv = pv * fmaf(dp[hq][r], p.scale, -dl[hq][r]);
+                            pf[4 * hq + r] = (bf16_t)pv;
+                            sf[4 * hq + r] = (bf16_t)dsv;
+                        }
+                } else {
+#pragma unroll
+                    for (int hq = 0; hq < 2; ++hq)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int qrow = 32 * u + 16 * hq + 4 * g + r;
+                            const int kmax = p.mask_kind == UIA_MASK_CAUSAL ? (qrow < klen - 1 ? qrow : klen - 1) : klen - 1;
+                            const bool ok = qrow < L && key <= kmax;
+                            const float pv = ok ? __builtin_amdgcn_exp2f(fmaf(s[hq][r], sc, -ls[hq][r])) : 0.f;
+                            const float dsv = pv * fmaf(dp[hq][r], p.scale, -dl[hq][r]);
+                            pf[4 * hq + r] = (bf16_t)pv;
+                            sf[4 * hq + r] = (bf16_t)dsv;
+                        }
+                }
+                // dSᵀ row `key`, queries 16hq + 4g .. +3 of the block: one 8-byte store per query tile
+                {
+                    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+                    char* rowp = dST + key * 64;
+                    const int sw = (key >> 1) & 7;
+                    *(bf16x4_t*)(rowp + (((0 + g) ^ sw) << 3)) = bf16x4_t{sf[0], sf[1], sf[2], sf[3]};
+                    *(bf16x4_t*)(rowp + (((4 + g) ^ sw) << 3)) = bf16x4_t{sf[4], sf[5], sf[6], sf[7]};
                 }
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
@@ -186,31 +231,26 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16_kernel(const UiaAttnParams 
                 }
             }
         }
-        // key tiles LT..2NP-1 of dSs are never written by the loop above: zero them once (u == 0)
-        if (u == 0 && (LT & 1)) {
-            for (int i = tid; i < 32 * 16; i += 256) *(bf16_t*)(dSs + (i >> 4) * DS_STRIDE + (16 * LT + (i & 15)) * 2) = (bf16_t)0.f;
-        }
         __syncthreads();
-        // ---- dQᵀ[d][q] = Σ_key Kᵀ[d][key] · dSᵀ[key][q]; wave w → query tile hq = w>>1, d-tiles 2(w&1), 2(w&1)+1
+        // ---- dQᵀ[d][q] = Σ_key Kᵀ[d][key] · dSᵀ[key][q]; wave w → query tile hq = w>>2, d-tile w&3.
+        //      Both operands are transpose reads: Kᵀ from the K tile, dSᵀ columns from the [key][query] tile.
         {
-            const int hq = wave >> 1;
-            f32x4 dq[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            const int hq = wave >> 2, dt = wave & 3;
+            f32x4 dq = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int ch = 2 * dt + (pp >> 1);
+            const int c8 = 4 * hq + pp;
+#pragma unroll 2
             for (int kbk = 0; kbk < NP; ++kbk) {
-                const uint4 dsf = *(const uint4*)(dSs + (16 * hq + li) * DS_STRIDE + (32 * kbk + 8 * g) * 2);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int dt = 2 * (wave & 1) + j;
-                    const int ch = 2 * dt + (pp >> 1);
-                    const char* lo = Ks + (32 * kbk + nrow) * 128 + ((ch ^ nsw_lo) << 4) + 8 * (pp & 1);
-                    const char* hi = Ks + (32 * kbk + nrow + 4) * 128 + ((ch ^ nsw_hi) << 4) + 8 * (pp & 1);
-                    dq[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_pair(lo, hi), __builtin_bit_cast(bf16x8, dsf), dq[j], 0, 0, 0);
-                }
+                const char* klo = Ks + (32 * kbk + nrow) * 128 + ((ch ^ nsw_lo) << 4) + 8 * (pp & 1);
+                const char* khi = Ks + (32 * kbk + nrow + 4) * 128 + ((ch ^ nsw_hi) << 4) + 8 * (pp & 1);
+                const char* slo = dST + (32 * kbk + nrow) * 64 + ((c8 ^ nsw_lo) << 3);
+                const char* shi = dST + (32 * kbk + nrow + 4) * 64 + ((c8 ^ nsw_hi) << 3);
+                dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_pair(klo, khi), tr_pair(slo, shi), dq, 0, 0, 0);
             }
             const int qrow = 32 * u + 16 * hq + li;
             if (qrow < L) {
                 bf16_t* drow = (bf16_t*)p.dq + (row0 + qrow) * p.ld_dqkv + (size_t)h * 64 + 4 * g;
-#pragma unroll
-                for (int j = 0; j < 2; ++j) store4(drow + 16 * (2 * (wave & 1) + j), dq[j]);
+                store4(drow + 16 * dt, dq);
             }
         }
         __syncthreads();
@@ -218,7 +258,7 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16_kernel(const UiaAttnParams 
     // ---- dK, dV: lane owns key 16kt+li, d = 16dt + 4g + r
 #pragma unroll
     for (int a = 0; a < KTW; ++a) {
-        const int kt = wave + 4 * a;
+        const int kt = wave + BWD_WAVES * a;
         const int key = 16 * kt + li;
         if (kt < LT && key < L) {
             bf16_t* krow = (bf16_t*)p.dk + (row0 + key) * p.ld_dqkv + (size_t)h * 64 + 4 * g;
@@ -332,16 +372,16 @@ __global__ __launch_bounds__(256) void attn_bwd_f32_kernel(const UiaAttnParams p
 template <int LT_MAX>
 int launch_bf16(hipStream_t stream, const UiaAttnParams& p) {
     const int LT = (p.L + 15) / 16, NP = (LT + 1) / 2, LPK = NP * 32;
-    const int lds = 4 * LPK * 128 + 32 * (LPK * 2 + 16) + 2 * LPK * 4;
+    const int lds = bwd_lds_bytes(LPK);
     auto kern = attn_bwd_bf16_kernel<LT_MAX>;
     static bool attr_set = false;
     if (!attr_set) {
         constexpr int LPKM = ((LT_MAX + 1) / 2) * 32;
-        UIA_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          4 * LPKM * 128 + 32 * (LPKM * 2 + 16) + 2 * LPKM * 4));
+        static_assert(bwd_lds_bytes(LPKM) <= 160 * 1024, "LDS budget");
+        UIA_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bwd_lds_bytes(LPKM)));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(p.B * p.H), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL(kern, dim3(p.B * p.H), dim3(64 * BWD_WAVES), lds, stream, p);
     UIA_CHECK_LAUNCH();
     return 0;
 }
@@ -371,8 +411,9 @@ int uia_attn_bwd_launch(hipStream_t stream, int dtype, const UiaAttnParams& p) {
         UIA_CHECK_LAUNCH();
         return 0;
     }
-    UIA_CHECK_ARG(p.L <= 224, "uia_attn_bwd: bf16 path keeps Q,K,V,dO of a head in LDS: L=%d exceeds 224", p.L);
+    UIA_CHECK_ARG(p.L <= 288, "uia_attn_bwd: bf16 path keeps Q, K, dO of a head in LDS: L=%d exceeds 288", p.L);
     const int LT = (p.L + 15) / 16;
-    if (LT <= 5) return launch_bf16<5>(stream, p);
-    return launch_bf16<14>(stream, p);
+    if (LT <= 8) return launch_bf16<8>(stream, p);
+    if (LT <= 16) return launch_bf16<16>(stream, p);
+    return launch_bf16<18>(stream, p);
 }

@@ -56,8 +56,16 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const UiaAttnParams 
     const char* vb = (const char*)p.v + (row0 * p.ld_qkv + (size_t)h * 64) * 2;
     const size_t rs = (size_t)p.ld_qkv * 2;  // row stride in bytes
 
+    // Keys past the last valid one contribute exactly 0: with a key-padding mask only the 16-key tiles that hold a valid
+    // key are staged, multiplied and exponentiated (BERT captions fill 24-128 of 256 positions); a causal mask stops
+    // each query tile at its own diagonal tile.
+    int klen = L;
+    if (p.mask_kind == UIA_MASK_KEYPAD && p.keylen) { klen = p.keylen[b]; klen = klen < 1 ? 1 : (klen > L ? L : klen); }
+    const int LTk = (klen + 15) >> 4;        // key tiles in use (wave-uniform: depends on the batch row only)
+    const int NPk = (LTk + 1) >> 1;
+
     // ---- stage K and V (rows past L are clamped to row L-1: finite, and masked / multiplied by 0)
-    const int ninstr = LPK >> 3;             // 1 KiB wave-instructions per tensor
+    const int ninstr = (NPk * 32) >> 3;      // 1 KiB wave-instructions per tensor
     for (int q = wave; q < ninstr; q += 4) {
         const int r = 8 * q + (lane >> 3);
         const int gr = r < L ? r : L - 1;
@@ -70,8 +78,6 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const UiaAttnParams 
     __syncthreads();
 
     const int li = lane & 15, g = lane >> 4;
-    int klen = L;
-    if (p.mask_kind == UIA_MASK_KEYPAD && p.keylen) { klen = p.keylen[b]; klen = klen < 1 ? 1 : (klen > L ? L : klen); }
     const float sc = p.scale * 1.44269504088896341f;   // softmax in base 2
 
     // K fragment (MFMA A operand, rows = keys): row 16t+li, chunk g+4kk
@@ -87,40 +93,57 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const UiaAttnParams 
         const uint4 q0 = *(const uint4*)(qb + qld * rs + g * 16);
         const uint4 q1 = *(const uint4*)(qb + qld * rs + (g + 4) * 16);
 
-        f32x4 s[LT_MAX];
-#pragma unroll
-        for (int t = 0; t < LT_MAX; ++t) {
-            s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (t < LT) {
-                const uint4 k0 = *(const uint4*)(Ks + t * 2048 + offK0);
-                const uint4 k1 = *(const uint4*)(Ks + t * 2048 + (offK0 ^ 64));
-                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, k0), __builtin_bit_cast(bf16x8, q0), s[t], 0, 0, 0);
-                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, k1), __builtin_bit_cast(bf16x8, q1), s[t], 0, 0, 0);
-            }
-        }
-        // ---- mask, row max (lane owns query qrow, keys 16t + 4g + r)
+        const int LTq = (p.mask_kind == UIA_MASK_CAUSAL && qt + 1 < LTk) ? qt + 1 : LTk;   // key tiles this query tile can see
+        const int NPq = (LTq + 1) >> 1;
+        // Tiles are skipped in chunks of 4 (one wave-uniform branch per chunk keeps 4 tiles of independent work in a
+        // basic block; a branch per tile cost more than the skipped work).  A chunk may run past LTq: its extra tiles
+        // read K rows that were never staged, and the select below discards whatever they produce.
+        constexpr int NCH = (LT_MAX + 3) / 4;
         const int kmax = p.mask_kind == UIA_MASK_CAUSAL ? (qrow < klen - 1 ? qrow : klen - 1) : klen - 1;  // last valid key
+        f32x4 s[4 * NCH];
         float m = -INFINITY;
 #pragma unroll
-        for (int t = 0; t < LT_MAX; ++t)
+        for (int c = 0; c < NCH; ++c) {
+            if (4 * c < LTq) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = 16 * t + 4 * g + r;
-                const float v = (t < LT && key <= kmax) ? s[t][r] * sc : -INFINITY;
-                s[t][r] = v;
-                m = fmaxf(m, v);
+                for (int t = 4 * c; t < 4 * c + 4; ++t) {
+                    const int tl = t < 2 * NP ? t : 2 * NP - 1;              // stay inside the LDS allocation
+                    const uint4 k0 = *(const uint4*)(Ks + tl * 2048 + offK0);
+                    const uint4 k1 = *(const uint4*)(Ks + tl * 2048 + (offK0 ^ 64));
+                    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, k0), __builtin_bit_cast(bf16x8, q0), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, k1), __builtin_bit_cast(bf16x8, q1), acc, 0, 0, 0);
+                    // ---- mask, row max (lane owns query qrow, keys 16t + 4g + r)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = 16 * t + 4 * g + r;
+                        const float v = key <= kmax ? acc[r] * sc : -INFINITY;
+                        acc[r] = v;
+                        m = fmaxf(m, v);
+                    }
+                    s[t] = acc;
+                }
+            } else {
+#pragma unroll
+                for (int t = 4 * c; t < 4 * c + 4; ++t) s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
+        }
         m = fmaxf(m, __shfl_xor(m, 16, 64));
         m = fmaxf(m, __shfl_xor(m, 32, 64));
         float sum = 0.f;
 #pragma unroll
-        for (int t = 0; t < LT_MAX; ++t)
+        for (int c = 0; c < NCH; ++c) {
+            if (4 * c < LTq) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float e = exp2f(s[t][r] - m);      // exp2(-inf) = 0 for masked keys
-                s[t][r] = e;
-                sum += e;
+                for (int t = 4 * c; t < 4 * c + 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float e = __builtin_amdgcn_exp2f(s[t][r] - m);      // exp2(-inf) = 0 for masked keys
+                        s[t][r] = e;
+                        sum += e;
+                    }
             }
+        }
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
         const float inv = 1.0f / sum;
@@ -131,12 +154,12 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const UiaAttnParams 
         for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int u = 0; u < NP_MAX; ++u) {
-            if (u < NP) {
+            if (u < NPq) {
                 bf16x8 pf;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     pf[e] = (bf16_t)s[2 * u][e];
-                    pf[4 + e] = (2 * u + 1 < LT_MAX) ? (bf16_t)s[(2 * u + 1 < LT_MAX) ? 2 * u + 1 : 0][e] : (bf16_t)0.f;
+                    pf[4 + e] = (bf16_t)s[2 * u + 1][e];
                 }
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
