@@ -1,0 +1,158 @@
+"""MetaCLIP contrastive fine-tuning with Mona adapters on the MI355X HIP path — drop-in for
+/root/reference/src/models/metaclip/finetune.py (the clip/ and unimedclip/ entry points of the reference share this loop).
+
+Same command line (every flag and default of reference :26-64; default --mona_variant noise_aware, batch 64, no gradient
+accumulation) and loop semantics (:92-218): per batch InfoNCE on L2-normalised features, non-finite batches skipped,
+clip_grad_norm_(1.0) → AdamW → cosine LR every iteration, a validation pass per epoch in eval mode, best-val checkpoint of
+the parameters whose name contains "mona", early stopping by --patience, runs/<exp>/{log.log,best_model.pth}.
+Added, non-breaking: --dtype, --synthetic / --data_pt, --ckpt_path, --model_config, data parallelism under
+torch.distributed.run.  The post-training zero-shot subprocess (:220-268) is outside the hot path and not launched.
+"""
+import argparse
+import logging
+import os
+import random
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[3]))
+
+import numpy as np
+import torch
+
+from src.adapters import inject_mona_variant_to_open_clip
+from src.datasets import finetune as dataset_finetune
+from src.losses import InfoNCELoss
+from src.third_party.open_clip.model import SyntheticClipTokenizer, create_metaclip
+from src.utils.tools import model_summary, setup_logging
+from uia_hip import functional as UF
+from uia_hip.engine import FlatAdapterOptimizer, cosine_lr, init_data_parallel
+
+
+def get_args(argv=None):
+    p = argparse.ArgumentParser("MetaCLIP Fine-tuning with Frequency-Enhanced MONA")
+    p.add_argument("--img_size", type=int, default=224)
+    p.add_argument("--num_workers", type=int, default=8)
+    p.add_argument("--strong_augs", default=False, action=argparse.BooleanOptionalAction)
+    p.add_argument("--weak_augs", default=False, action=argparse.BooleanOptionalAction)
+    p.add_argument("--exp", type=str, default="metaclip_finetune")
+    p.add_argument("--in_channels", type=int, default=3)
+    p.add_argument("--mona_variant", type=str, default="noise_aware")
+    p.add_argument("--mona_bottleneck", type=int, default=64)
+    p.add_argument("--mona_layers", type=int, default=None)
+    p.add_argument("--temperature", type=float, default=0.07)
+    p.add_argument("--uniformity_weight", type=float, default=0)
+    p.add_argument("--seed", type=int, default=1)
+    p.add_argument("--epochs", type=int, default=1000)
+    p.add_argument("--batch_size", type=int, default=64)
+    p.add_argument("--lr", type=float, default=1e-4)
+    p.add_argument("--lr_min", type=float, default=1e-8)
+    p.add_argument("--weight_decay", type=float, default=0.01)
+    p.add_argument("--beta1_adam", type=float, default=0.9)
+    p.add_argument("--beta2_adam", type=float, default=0.95)
+    p.add_argument("--device", type=str, default="cuda:0" if torch.cuda.is_available() else "cpu")
+    p.add_argument("--patience", type=int, default=10)
+    # additions of this build
+    p.add_argument("--dtype", type=str, default="bf16", choices=["bf16", "fp32"])
+    p.add_argument("--synthetic", action="store_true")
+    p.add_argument("--synthetic_train", type=int, default=512)
+    p.add_argument("--synthetic_val", type=int, default=128)
+    p.add_argument("--data_pt", type=str, default=None)
+    p.add_argument("--ckpt_path", type=str, default=None, help="open_clip state dict (.pt); random init if absent")
+    p.add_argument("--model_config", type=str, default=None, help="python dict literal overriding the model geometry (tests)")
+    return p.parse_args(argv)
+
+
+def prepare_model(args):
+    cfg = eval(args.model_config) if args.model_config else None
+    state = torch.load(args.ckpt_path, map_location="cpu") if args.ckpt_path else None
+    model = create_metaclip(state_dict=state, config=cfg, seed=args.seed)
+    tc = (cfg or {}).get("text_cfg", {})
+    tokenizer = SyntheticClipTokenizer(tc.get("context_length", 77), tc.get("vocab_size", 49408))
+    for p in model.parameters():
+        p.requires_grad = False
+    model, mona_count = inject_mona_variant_to_open_clip(model, variant=args.mona_variant, bottleneck_dim=args.mona_bottleneck,
+                                                         num_layers=args.mona_layers)
+    for name, p in model.named_parameters():
+        if "mona" in name.lower():
+            p.requires_grad = True
+    model.float()
+    model.to(args.device)
+    return model, tokenizer
+
+
+def _features(model, tokenizer, images, texts, device):
+    fi = model.encode_image(images.to(device))
+    ft = model.encode_text(tokenizer(list(texts)).to(device))
+    return fi / fi.norm(dim=-1, keepdim=True), ft / ft.norm(dim=-1, keepdim=True)
+
+
+def train(args):
+    UF.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+    UF.set_dropout_seed(args.seed)
+    model, tokenizer = prepare_model(args)
+    model.train()
+    logging.info(model_summary({"model": model}))
+    dm = dataset_finetune.DataModule(args)
+    trainloader, valloader = dm.train_dataloader(), dm.val_dataloader()
+    criterion = InfoNCELoss(temperature=args.temperature)
+    opt = FlatAdapterOptimizer([(n, p) for n, p in model.named_parameters() if p.requires_grad], lr=args.lr,
+                               betas=(args.beta1_adam, args.beta2_adam), weight_decay=args.weight_decay, max_norm=1.0)
+    rank, _, world = init_data_parallel(opt) if int(os.environ.get("WORLD_SIZE", 1)) > 1 else (0, 0, 1)
+    max_iters = len(trainloader) * args.epochs
+    iter_num, best_loss, best_epoch, patience = 0, float("inf"), 0, 0
+    train_loss = 0.0
+    for epoch in range(args.epochs):
+        model.train()
+        train_loss = 0.0
+        for images, texts in trainloader:
+            fi, ft = _features(model, tokenizer, images, texts, args.device)
+            loss = criterion(fi, ft)
+            if not torch.isfinite(loss):
+                logging.warning(f"Non-finite loss detected at iteration {iter_num}, skipping batch")
+                continue
+            opt.zero_grad()
+            loss.backward()
+            opt.all_reduce()
+            opt.step(lr=cosine_lr(args.lr, args.lr_min, iter_num, max_iters))
+            UF.clear_t_copies()
+            train_loss += loss.item()
+            iter_num += 1
+        train_loss /= max(1, len(trainloader))
+        model.eval()
+        val_loss = 0.0
+        with torch.no_grad():
+            for images, texts in valloader:
+                loss = criterion(*_features(model, tokenizer, images, texts, args.device))
+                if torch.isfinite(loss):
+                    val_loss += loss.item()
+        val_loss /= max(1, len(valloader))
+        logging.info(f"Epoch {epoch + 1}/{args.epochs}: Train={train_loss:.4f}, Val={val_loss:.4f}, Best={best_loss:.4f}")
+        if val_loss < best_loss:
+            best_loss, best_epoch, patience = val_loss, epoch, 0
+            if rank == 0:
+                torch.save({n: p.data.clone() for n, p in model.named_parameters() if "mona" in n.lower()},
+                           os.path.join(args.train_snapshot_path, "best_model.pth"))
+            logging.info(f"Best model saved at epoch {epoch + 1}")
+        else:
+            patience += 1
+        if patience >= args.patience:
+            logging.info(f"Early stopping triggered at epoch {epoch + 1}")
+            break
+    logging.info(f"\n✓ Training completed! Best loss: {best_loss:.4f} (epoch {best_epoch + 1})")
+    return {"best_val": best_loss, "iters": iter_num, "last_train": train_loss}
+
+
+def main(argv=None):
+    args = get_args(argv)
+    random.seed(args.seed)
+    np.random.seed(args.seed)
+    torch.manual_seed(args.seed)
+    args.train_snapshot_path = f"runs/{args.exp}"
+    os.makedirs(args.train_snapshot_path, exist_ok=True)
+    setup_logging(args, args.train_snapshot_path)
+    return train(args)
+
+
+if __name__ == "__main__":
+    main()

@@ -48,8 +48,9 @@ def _maybe_lora_linear(x, P, name, lora):
     return F.linear(x, P[f"{name}.weight"], P.get(f"{name}.bias"))
 
 
-def timm_block(x, P, heads, eps=1e-6, lora=None):
-    """timm Block: x + attn(norm1 x); x + mlp(norm2 x).  P keys relative to 'blocks.{i}.'."""
+def timm_block(x, P, heads, eps=1e-6, lora=None, act="gelu"):
+    """timm Block: x + attn(norm1 x); x + mlp(norm2 x).  P keys relative to 'blocks.{i}.'.
+    act="quick_gelu": x·σ(1.702x), the `vit_*_clip_quickgelu_*` variants (same form as reference model.py:172-174)."""
     D = x.shape[-1]
     h = F.layer_norm(x, (D,), P["norm1.weight"], P["norm1.bias"], eps)
     qkv = _maybe_lora_linear(h, P, "attn.qkv", lora)
@@ -57,29 +58,32 @@ def timm_block(x, P, heads, eps=1e-6, lora=None):
     a = _attention(q, k, v, heads)
     x = x + _maybe_lora_linear(a, P, "attn.proj", lora)
     h = F.layer_norm(x, (D,), P["norm2.weight"], P["norm2.bias"], eps)
-    h = F.gelu(F.linear(h, P["mlp.fc1.weight"], P["mlp.fc1.bias"]))
+    h = F.linear(h, P["mlp.fc1.weight"], P["mlp.fc1.bias"])
+    h = F.gelu(h) if act == "gelu" else h * torch.sigmoid(1.702 * h)
     return x + F.linear(h, P["mlp.fc2.weight"], P["mlp.fc2.bias"])
 
 
 def timm_vit_tokens(images, P, prefix="visual.trunk."):
     W = P[prefix + "patch_embed.proj.weight"]
-    x = F.conv2d(images, W, P[prefix + "patch_embed.proj.bias"], stride=W.shape[-1])
+    x = F.conv2d(images, W, P.get(prefix + "patch_embed.proj.bias"), stride=W.shape[-1])
     x = x.flatten(2).transpose(1, 2)                                  # [B, 196, D]
     cls = P[prefix + "cls_token"].expand(x.shape[0], -1, -1)
     return torch.cat([cls, x], dim=1) + P[prefix + "pos_embed"]
 
 
-def timm_vit_forward(images, P, heads=12, mona=None, lora=None, prefix="visual.trunk.", return_tokens=False):
+def timm_vit_forward(images, P, heads=12, mona=None, lora=None, prefix="visual.trunk.", return_tokens=False, eps=1e-6, act="gelu"):
     """images [B,3,H,W] -> features [B, embed].  P: flat state dict with open_clip key names.
 
     mona: None or dict(variant=..., hw=(h,w), keep_masks=None|list, p_drop=0.1); Mona parameters
     are read from '<prefix>blocks.{i}.mona.clip_mona.<p>' (wrapper attribute, mona.py:52).
     """
     x = timm_vit_tokens(images, P, prefix)
+    if prefix + "norm_pre.weight" in P:                               # timm `pre_norm=True` (vit_*_clip_* family); PARITY UNPINNED
+        x = F.layer_norm(x, (x.shape[-1],), P[prefix + "norm_pre.weight"], P[prefix + "norm_pre.bias"], eps)
     depth = 1 + max(int(k[len(prefix) + 7:].split(".")[0]) for k in P if k.startswith(prefix + "blocks."))
     for i in range(depth):
         bp = _sub(P, f"{prefix}blocks.{i}.")
-        x = timm_block(x, bp, heads, 1e-6, lora)
+        x = timm_block(x, bp, heads, eps, lora, act)
         mp = _sub(bp, "mona.clip_mona.")
         if mona is not None and mp:
             km = None if mona.get("keep_masks") is None else mona["keep_masks"][i]
@@ -87,7 +91,7 @@ def timm_vit_forward(images, P, heads=12, mona=None, lora=None, prefix="visual.t
     if return_tokens:
         return x
     D = x.shape[-1]
-    x = F.layer_norm(x, (D,), P[prefix + "norm.weight"], P[prefix + "norm.bias"], 1e-6)
+    x = F.layer_norm(x, (D,), P[prefix + "norm.weight"], P[prefix + "norm.bias"], eps)
     head = prefix.replace("trunk.", "head.") + "proj.weight"           # visual.head.proj.weight
     return F.linear(x[:, 0], P[head])
 

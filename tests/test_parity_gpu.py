@@ -369,6 +369,57 @@ def test_finetune_entry_point_runs_and_saves_adapter_checkpoint(tmp_path, monkey
     assert out["updates"] == 3 * 2 and math.isfinite(out["best_val"]) and (tmp_path / "runs" / "t" / "log.log").exists()
 
 
+METACLIP_TOY = ("dict(embed_dim=128, vision_cfg=dict(img_size=32, patch_size=8, embed_dim=128, depth=2, num_heads=2, eps=1e-5, "
+                "act='quick_gelu', pre_norm=True, patch_bias=False), "
+                "text_cfg=dict(context_length=16, vocab_size=4000, width=128, heads=2, layers=2, act='quick_gelu'))")
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_metaclip_family_towers_vs_oracle(mode):
+    """open_clip CLIP with a timm trunk (norm_pre, eps 1e-5, QuickGELU, bias-free patch projection) + Mona, and the native causal
+    text tower, against the oracle restatements; every Mona gradient of a contrastive loss as well."""
+    from oracle import text_ref, vit_ref
+    from uia_hip import functional as UF
+    from src.adapters import inject_mona_variant_to_open_clip
+    from src.third_party.open_clip.model import create_metaclip
+    UF.set_compute_dtype(DT[mode])
+    g = torch.Generator().manual_seed(41)
+    model = create_metaclip(config=eval(METACLIP_TOY), seed=3)
+    inject_mona_variant_to_open_clip(model, variant="noise_aware", bottleneck_dim=64)
+    randomize(model, g, 0.08)
+    model.eval()
+    for k, p in model.named_parameters():
+        p.requires_grad_("mona" in k)
+    images = torch.rand(4, 3, 32, 32, generator=g)
+    ids = clip_text_batch(g, B=4, L=16)
+    dfi = torch.randn(4, 128, generator=g)
+    P = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    names = [k for k in P if "mona" in k]
+    leaves = {k: P[k].clone().requires_grad_(True) for k in names}
+    Pq = dict(P); Pq.update(leaves)
+    fr = vit_ref.timm_vit_forward(images, Pq, heads=2, mona=dict(variant="noise_aware", hw=(4, 4), keep_masks=None, p_drop=0.0), eps=1e-5, act="quick_gelu")
+    tr = text_ref.openai_text_forward(ids, P, heads=2)
+    (fr * dfi).sum().backward()
+    model = model.to(dev())
+    fi = model.encode_image(images.to(dev()))
+    ft = model.encode_text(ids.to(dev()))
+    assert rel(fi, fr) < TOL[mode] and rel(ft, tr) < TOL[mode]
+    (fi * dfi.to(dev())).sum().backward()
+    check_grads(model, leaves, mode)
+
+
+def test_metaclip_entry_point_trains_validates_and_saves(tmp_path, monkeypatch):
+    """src.models.metaclip.finetune (reference CLI, default noise_aware Mona): per-iteration updates, eval-mode validation,
+    best_model.pth with the timm-trunk Mona key names."""
+    from src.models.metaclip import finetune
+    monkeypatch.chdir(tmp_path)
+    out = finetune.main(["--synthetic", "--synthetic_train", "64", "--synthetic_val", "16", "--img_size", "32", "--batch_size", "16",
+                         "--epochs", "2", "--lr", "2e-3", "--dtype", "bf16", "--exp", "m", "--model_config", METACLIP_TOY])
+    ck = torch.load(tmp_path / "runs" / "m" / "best_model.pth")
+    assert ck and all("mona" in k for k in ck) and "visual.trunk.blocks.1.mona.clip_mona.adapter_conv.noise_estimator.1.weight" in ck
+    assert out["iters"] == 2 * 4 and math.isfinite(out["best_val"]) and math.isfinite(out["last_train"])
+
+
 # ------------------------------------------------------------------------------------------------ CLIPSeg
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
 def test_clipseg_adapter_vs_oracle(mode):
