@@ -369,6 +369,46 @@ def test_finetune_entry_point_runs_and_saves_adapter_checkpoint(tmp_path, monkey
     assert out["updates"] == 3 * 2 and math.isfinite(out["best_val"]) and (tmp_path / "runs" / "t" / "log.log").exists()
 
 
+def test_checkpoint_round_trip_into_zero_shot_vs_oracle(tmp_path, monkeypatch):
+    """fine-tune entry point → best_model.pth → zero-shot entry point loads it BY NAME (reference zero_shot.py:136-147) into a
+    freshly built model; ensemble logits (:204-222) equal the oracle's on the same weights, and the loaded adapter tensors are
+    the checkpoint's, not the fresh initialisation."""
+    from oracle import text_ref, vit_ref
+    from src.models.biomedclip import finetune, zero_shot
+    monkeypatch.chdir(tmp_path)
+    cfg = ("dict(embed_dim=128, vision_cfg=dict(img_size=32, patch_size=8, embed_dim=128, depth=2, num_heads=2), "
+           "text_cfg=dict(vocab_size=30000, hidden_size=128, num_hidden_layers=1, num_attention_heads=2, intermediate_size=256, max_position_embeddings=64))")
+    finetune.main(["--method", "mona", "--mona_variant", "hybrid", "--synthetic", "--synthetic_train", "32", "--synthetic_val", "16",
+                   "--img_size", "32", "--batch_size", "16", "--accumulation_steps", "1", "--epochs", "2", "--lr", "5e-3",
+                   "--dtype", "fp32", "--exp", "ft", "--model_config", cfg])
+    ck_path = str(tmp_path / "runs" / "ft" / "best_model.pth")
+    ck = torch.load(ck_path, map_location="cpu")
+    zs = ["--mona_weights", ck_path, "--mona_variant", "hybrid", "--synthetic", "--synthetic_test", "24", "--img_size", "32",
+          "--batch_size", "8", "--dtype", "fp32", "--exp", "zs", "--model_config", cfg]
+    args = zero_shot.get_args(zs)
+    args.test_snapshot_path = str(tmp_path)
+    stats, logits = zero_shot.test(args)
+    assert stats["n"] == 24 and 0.0 <= stats["acc"] <= 1.0 and math.isfinite(stats["loss"])
+    # what was loaded is what was saved
+    model, tokenizer = zero_shot.prepare_model(args)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    assert all(torch.equal(sd[k], ck[k]) for k in ck) and len(ck) > 0
+    assert float((sd["visual.trunk.blocks.0.mona.clip_mona.project2.weight"]).abs().max()) > 0       # trained away from the zero init
+    # oracle logits on the same weights
+    images = torch.cat([im for im, _ in zero_shot._test_batches(args)])
+    fi = vit_ref.timm_vit_forward(images, sd, heads=2, mona=dict(variant="hybrid", hw=(4, 4), keep_masks=None, p_drop=0.0))
+    fi = fi / fi.norm(dim=-1, keepdim=True)
+    cols = []
+    for c in zero_shot.LESION_TYPES:
+        ft = text_ref.bert_text_forward(tokenizer(zero_shot.DEFAULT_PROMPTS[c]), sd, heads=2)
+        ft = ft / ft.norm(dim=-1, keepdim=True)
+        cols.append((100.0 * fi @ ft.T).mean(dim=1))
+    ref = torch.stack(cols, dim=1)
+    assert float((logits - ref).abs().max()) < 1e-3 * float(ref.abs().max())
+    out = zero_shot.main(zs)
+    assert (tmp_path / "runs" / "zs" / "LN-INT" / "test" / "results.json").exists() and out["n"] == 24
+
+
 METACLIP_TOY = ("dict(embed_dim=128, vision_cfg=dict(img_size=32, patch_size=8, embed_dim=128, depth=2, num_heads=2, eps=1e-5, "
                 "act='quick_gelu', pre_norm=True, patch_bias=False), "
                 "text_cfg=dict(context_length=16, vocab_size=4000, width=128, heads=2, layers=2, act='quick_gelu'))")
