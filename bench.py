@@ -155,24 +155,36 @@ def main():
         # ---- roofline of the dominant kernel: the 256x256-tile bf16 GEMM instantiation (QKV / fc1 / their dgrads)
         def by_cfg_of(events):
             acc = {}
-            for e0, e1, M, N, K, dt, cfg in events:
-                d = acc.setdefault(cfg, [0.0, 0.0, 0])
+            for e0, e1, M, N, K, dt, cfg, nbytes in events:
+                d = acc.setdefault(cfg, [0.0, 0.0, 0, 0.0])
                 d[0] += e0.elapsed_time(e1) * 1e-3
                 d[1] += 2.0 * M * N * K
                 d[2] += 1
+                d[3] += nbytes
             return acc
         by_cfg, by_cfg_serial = by_cfg_of(prof), by_cfg_of(prof_serial)
         dom = max(by_cfg, key=lambda c: by_cfg[c][0]) if by_cfg else None
         roof = None
-        names = {8: "gemm_tn_ring_kernel<T,256,256,2,4,64,4>", 6: "gemm_tn_pp_kernel<T,256,256,2,4>", 4: "gemm_tn_kernel<T,256,64,4,1>",
+        names = {8: "gemm_tn_ring_kernel<T,256,256,2,4,64,4,EPI> (six epilogue masks + generic)", 6: "gemm_tn_pp_kernel<T,256,256,2,4>", 4: "gemm_tn_kernel<T,256,64,4,1>",
                  3: "gemm_tn_kernel<T,128,128,2,2>"}
         if dom is not None:
-            tsec, flops, n = by_cfg[dom]
+            tsec, flops, n, algo_bytes = by_cfg[dom]
             achieved = flops / tsec * 1e-12
             peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
-            ts, fs, ns = by_cfg_serial.get(dom, (tsec, flops, n))
+            ts, fs, ns, _ = by_cfg_serial.get(dom, (tsec, flops, n, algo_bytes))
+            traffic, traffic_src = None, None
+            tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_e_traffic_pmc.json")
+            if dom == 8 and args.dtype == "bf16" and args.batch == 256 and os.path.exists(tpath):
+                # HBM bytes per launch of this kernel family from rocprofv3 PMC passes of the same workload (tools/pmc_traffic.sh):
+                # FETCH_SIZE and WRITE_SIZE are reported in KiB; FETCH_SIZE counts 128-B requests at 64 B on gfx950 for wide
+                # coalesced reads, so it is doubled (MI355X_MICROARCH.md, HBM section).
+                pm = json.load(open(tpath))
+                f, w = pm["FETCH_SIZE"]["ring_gemm"], pm["WRITE_SIZE"]["ring_gemm"]
+                traffic = round((2.0 * f["sum"] / f["launches"] + w["sum"] / w["launches"]) * 1024)
+                traffic_src = "profiles/r01_e_traffic_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x2 per the gfx950 note)"
             roof = {"bound": "mfma", "kernel": names.get(dom, f"tile cfg {dom}").replace("T", args.dtype), "achieved": round(achieved, 1), "peak": peak,
-                    "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None, "launches_per_step": n,
+                    "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "bytes per launch (HBM, PMC)",
+                    "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(algo_bytes / n), "launches_per_step": n,
                     "avg_launch_us": round(tsec / n * 1e6, 2), "flop_per_launch_avg": round(flops / n),
                     "note": "measured with HIP events on each launch stream during the last timed step; the text tower runs concurrently on a "
                             "second stream, so a launch's duration includes time shared with the other stream's kernels",
@@ -183,7 +195,8 @@ def main():
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                "config": {"workload": "BiomedCLIP ViT-B/16 + Mona fine-tune step (BASELINE configs[1]): image tower fwd+bwd with 12 Mona adapters, "
-                                      "frozen BERT-base text tower fwd (dense L=256), InfoNCE, clip+AdamW; random-init weights",
+                                      "frozen BERT-base text tower fwd (all 256 positions through every GEMM; attention skips key tiles that are entirely padding), "
+                                      "InfoNCE, clip+AdamW; random-init weights",
                           "mona_variant": args.variant, "batch_per_gpu": args.batch, "global_batch": args.batch * world, "image": "3x224x224",
                           "text_len": 256, "parallelism": f"dp{world}", "mona_dropout": 0.1, "bert_dropout_emulated": False,
                           "gflop_per_pair_algorithmic": GFLOP_PER_PAIR},

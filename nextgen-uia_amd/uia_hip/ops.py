@@ -91,7 +91,10 @@ def gemm(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None, res
         e0.record()
         check(lib().uia_gemm(_stream(), _code(a.dtype), C.byref(d), tile_cfg), "uia_gemm")
         e1.record()
-        GEMM_PROFILE.append((e0, e1, d.M, d.N, d.K, a.dtype, tile_cfg or auto_tile_cfg(d.M, d.N)))
+        esz = a.element_size()                  # algorithmic HBM bytes of this launch: every operand and result once
+        nbytes = esz * (d.M * d.K + d.N * d.K) + d.M * d.N * (esz * sum(t is not None for t in (aux_in, aux_out, resid_t, out_t))
+                                                             + 4 * sum(t is not None for t in (resid, out32)))
+        GEMM_PROFILE.append((e0, e1, d.M, d.N, d.K, a.dtype, tile_cfg or auto_tile_cfg(d.M, d.N), nbytes))
         return
     check(lib().uia_gemm(_stream(), _code(a.dtype), C.byref(d), tile_cfg), "uia_gemm")
 
