@@ -205,3 +205,21 @@ def test_layout_helpers(ops, dt):
     gth = torch.empty(3, 64, device=dev())
     ops.gather_rows(e, idx, gth)
     assert torch.equal(gth, e[idx])
+
+
+def test_rccl_communicator_single_rank_allreduce(ops):
+    """The library's own RCCL path (unique id -> ncclCommInitRank -> ncclAllReduce on the compute stream -> destroy) with a
+    world of one rank: the sum over one rank is the buffer itself.  (world_size 2 semantics are covered on CPU by
+    tests/test_dp_gloo.py; multi-GPU boxes are not available to the test run.)"""
+    uid = ops.comm_unique_id()
+    assert isinstance(uid, bytes) and len(uid) >= 128
+    ops.comm_init(0, 1, uid)
+    try:
+        assert ops.comm_world() == 1
+        g = torch.randn(1343232, device=dev())
+        ref = g.clone()
+        ops.allreduce_sum(g)
+        torch.cuda.synchronize()
+        assert torch.equal(g, ref)
+    finally:
+        ops.comm_destroy()
