@@ -152,44 +152,55 @@ def main():
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = world * args.batch * args.steps / elapsed
-        # ---- roofline of the dominant kernel: the 256x256-tile bf16 GEMM instantiation (QKV / fc1 / their dgrads)
-        def by_cfg_of(events):
+        # ---- roofline of the dominant kernel.  Launches are grouped by the kernel instantiation they run on (tile config,
+        #      compile-time epilogue mask) — the same granularity as a row of rocprofv3's kernel_stats.csv — and the
+        #      instantiation with the largest share of the step is reported; the whole GEMM family is given beside it.
+        def group(events, key):
             acc = {}
-            for e0, e1, M, N, K, dt, cfg, nbytes in events:
-                d = acc.setdefault(cfg, [0.0, 0.0, 0, 0.0])
+            for e0, e1, M, N, K, dt, cfg, nbytes, mask in events:
+                d = acc.setdefault(key(cfg, mask), [0.0, 0.0, 0, 0.0])
                 d[0] += e0.elapsed_time(e1) * 1e-3
                 d[1] += 2.0 * M * N * K
                 d[2] += 1
                 d[3] += nbytes
             return acc
-        by_cfg, by_cfg_serial = by_cfg_of(prof), by_cfg_of(prof_serial)
-        dom = max(by_cfg, key=lambda c: by_cfg[c][0]) if by_cfg else None
+        per_kernel = lambda c, m: (c, m if m in ops._SPECIALISED else ops.EPI_GENERIC)
+        by_k, by_k_serial = group(prof, per_kernel), group(prof_serial, per_kernel)
+        fam, fam_serial = group(prof, lambda c, m: c in (8, 12)), group(prof_serial, lambda c, m: c in (8, 12))
+        dom = max(by_k, key=lambda k: by_k[k][0]) if by_k else None
         roof = None
-        names = {8: "gemm_tn_ring_kernel<T,256,256,2,4,64,4,EPI> (six epilogue masks + generic)", 6: "gemm_tn_pp_kernel<T,256,256,2,4>", 4: "gemm_tn_kernel<T,256,64,4,1>",
-                 3: "gemm_tn_kernel<T,128,128,2,2>"}
         if dom is not None:
-            tsec, flops, n, algo_bytes = by_cfg[dom]
+            tsec, flops, n, algo_bytes = by_k[dom]
             achieved = flops / tsec * 1e-12
             peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
-            ts, fs, ns, _ = by_cfg_serial.get(dom, (tsec, flops, n, algo_bytes))
+            ts, fs, ns, _ = by_k_serial.get(dom, (tsec, flops, n, algo_bytes))
+            kname, kmangled = ops.gemm_kernel_name(dom[0], dom[1], torch.bfloat16 if args.dtype == "bf16" else torch.float32)
             traffic, traffic_src = None, None
-            tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_e_traffic_pmc.json")
-            if dom == 8 and args.dtype == "bf16" and args.batch == 256 and os.path.exists(tpath):
-                # HBM bytes per launch of this kernel family from rocprofv3 PMC passes of the same workload (tools/pmc_traffic.sh):
-                # FETCH_SIZE and WRITE_SIZE are reported in KiB; FETCH_SIZE counts 128-B requests at 64 B on gfx950 for wide
-                # coalesced reads, so it is doubled (MI355X_MICROARCH.md, HBM section).
+            tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_g_traffic_pmc.json")
+            if args.dtype == "bf16" and args.batch == 256 and os.path.exists(tpath):
+                # HBM bytes per launch of this kernel from rocprofv3 PMC passes over the same workload (tools/pmc_traffic.sh):
+                # FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies the 128-B requests of wide coalesced
+                # reads at 64 B, so it is doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact for 16-B stores.
                 pm = json.load(open(tpath))
-                f, w = pm["FETCH_SIZE"]["ring_gemm"], pm["WRITE_SIZE"]["ring_gemm"]
-                traffic = round((2.0 * f["sum"] / f["launches"] + w["sum"] / w["launches"]) * 1024)
-                traffic_src = "profiles/r01_e_traffic_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x2 per the gfx950 note)"
-            roof = {"bound": "mfma", "kernel": names.get(dom, f"tile cfg {dom}").replace("T", args.dtype), "achieved": round(achieved, 1), "peak": peak,
+                f, w = pm["FETCH_SIZE"].get(kmangled), pm["WRITE_SIZE"].get(kmangled)
+                if f and w:
+                    traffic = round((2.0 * f["sum"] / f["launches"] + w["sum"] / w["launches"]) * 1024)
+                    traffic_src = ("profiles/r01_g_traffic_pmc.json (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, same "
+                                   "workload; FETCH_SIZE doubled per the gfx950 note of the microarchitecture guide)")
+            ft, ff, fn, _ = fam.get(True, (tsec, flops, n, 0.0))
+            fts, ffs, fns, _ = fam_serial.get(True, (ts, fs, ns, 0.0))
+            roof = {"bound": "mfma", "kernel": kname, "kernel_in_rocprof_csv": kmangled, "achieved": round(achieved, 1), "peak": peak,
                     "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "bytes per launch (HBM, PMC)",
                     "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(algo_bytes / n), "launches_per_step": n,
                     "avg_launch_us": round(tsec / n * 1e6, 2), "flop_per_launch_avg": round(flops / n),
-                    "note": "measured with HIP events on each launch stream during the last timed step; the text tower runs concurrently on a "
-                            "second stream, so a launch's duration includes time shared with the other stream's kernels",
+                    "share_of_step": round(tsec / (elapsed / args.steps), 3),
+                    "note": "HIP events on each launch stream during the last timed step; the text tower runs concurrently on a second "
+                            "stream, so a launch's duration includes time shared with the other stream's kernels (see standalone)",
                     "standalone": {"achieved": round(fs / ts * 1e-12, 1), "frac": round(fs / ts * 1e-12 / peak, 4), "avg_launch_us": round(ts / ns * 1e6, 2),
                                    "how": "one extra untimed step with both towers serialised on one stream"},
+                    "gemm_family": {"kernels": "gemm_tn_ring_kernel<...,EPI> + gemm_tn_persist_kernel<...,EPI>, all epilogue masks",
+                                    "launches_per_step": fn, "achieved": round(ff / ft * 1e-12, 1), "standalone_achieved": round(ffs / fts * 1e-12, 1),
+                                    "standalone_frac": round(ffs / fts * 1e-12 / peak, 4)},
                     "whole_step_frac_of_peak": round(value / world * GFLOP_PER_PAIR * 1e-3 / peak, 4)}
         out = {"metric": "images/sec fwd+bwd BiomedCLIP+Mona bs=256", "value": round(value, 2), "unit": "images/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",

@@ -218,7 +218,7 @@ template <int MT, int WTN> struct EpiPatch {
 enum : int { EPI_BIAS = 1, EPI_AUX_OUT = 2, EPI_GELU = 4, EPI_DGELU = 8, EPI_RESID = 16, EPI_RESIDT = 32, EPI_OUT32 = 64, EPI_OUTT = 128,
              EPI_GENERIC = -1 };
 
-template <typename T, int MT, int NT, int WTM, int WTN, int EPI = EPI_GENERIC>
+template <typename T, int MT, int NT, int WTM, int WTN, int EPI = EPI_GENERIC, bool PATCH16 = false>
 __device__ __forceinline__ void gemm_epilogue_lds(const UiaGemmParams& p, f32x4 (&acc)[MT][NT], char* smem, int wave, int lane, int m0, int n0,
                                                   int wm, int wn) {
     constexpr bool GEN = EPI == EPI_GENERIC;
@@ -235,7 +235,6 @@ __device__ __forceinline__ void gemm_epilogue_lds(const UiaGemmParams& p, f32x4 
     constexpr int LPR = WTN / 8;                    // lanes per row when reading back
     constexpr int RPP = 64 / LPR;                   // rows per read pass
     static_assert(MT % GPP == 0, "row groups must split evenly into phases");
-    float* stg = (float*)(smem + wave * EP::BYTES_PER_WAVE);
     const int li = lane & 15, g = lane >> 4;
     const int rr = lane / LPR, rc = (lane % LPR) * 8;
     const int n = n0 + wn * WTN + rc;
@@ -248,55 +247,85 @@ __device__ __forceinline__ void gemm_epilogue_lds(const UiaGemmParams& p, f32x4 
     for (int e = 0; e < 8; ++e) bias[e] = 0.f;
     if (f_bias && n < p.N) load8(p.bias + n, bias);
     const bool col_ok = n < p.N;
-#pragma clang loop unroll(full)
-    for (int ph = 0; ph < MT / GPP; ++ph) {
-#pragma clang loop unroll(full)
-        for (int gi = 0; gi < GPP; ++gi)
-#pragma clang loop unroll(full)
-            for (int j = 0; j < NT; ++j) *(f32x4*)(stg + (gi * 16 + li) * LDW + g * (4 * NT) + 4 * j) = acc[ph * GPP + gi][j];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-        const int mbase = m0 + wm * WTM + ph * ROWS + rr;
-#pragma clang loop unroll_count(2)
-        for (int q = 0; q < ROWS / RPP; ++q) {
-            const int row = q * RPP + rr;
-            const f32x4 lo = *(const f32x4*)(stg + row * LDW + rc), hi = *(const f32x4*)(stg + row * LDW + rc + 4);
-            const int m = mbase + q * RPP;
-            if (m < p.M && col_ok) {
-                float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                const size_t orow = GEN && p.out_group > 0 ? (size_t)(m + m / p.out_group + 1) : (size_t)m;
-                const size_t rrow = GEN && p.resid_mod > 0 ? (size_t)(m % p.resid_mod + p.resid_row_off) : orow;
-                if (GEN) {
+
+    // one row segment of 8 columns: bias / activation / residuals / stores
+    auto apply = [&](const f32x4& lo, const f32x4& hi, int m) {
+        if (!(m < p.M && col_ok)) return;
+        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        const size_t orow = GEN && p.out_group > 0 ? (size_t)(m + m / p.out_group + 1) : (size_t)m;
+        const size_t rrow = GEN && p.resid_mod > 0 ? (size_t)(m % p.resid_mod + p.resid_row_off) : orow;
+        if (GEN) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], p.alpha, bias[e]);
-                } else if (f_bias) {
+            for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], p.alpha, bias[e]);
+        } else if (f_bias) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += bias[e];
-                }
-                if (f_aux_out && UIA_EPI_STORES) store8(aux_out + orow * p.ldaux_out + n, v);
-                if (act) apply_act8<sizeof(T) == 2>(v, act);
-                if (dact && UIA_EPI_LOADS) {
-                    float a[8];
-                    load8(aux_in + orow * p.ldaux_in + n, a);
-                    apply_dact8<sizeof(T) == 2>(v, a, dact);
-                }
-                if (f_resid && UIA_EPI_LOADS) {
-                    float r[8];
-                    load8(p.resid + rrow * p.ldr + n, r);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += r[e];
-                }
-                if (f_residT && UIA_EPI_LOADS) {
-                    float r[8];
-                    load8(residT + orow * p.ldrT + n, r);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += r[e];
-                }
-                if (f_out32 && UIA_EPI_STORES) store8(p.out32 + orow * p.ldo32 + n, v);
-                if (f_outT && UIA_EPI_STORES) store8(outT + orow * p.ldo + n, v);
-            }
+            for (int e = 0; e < 8; ++e) v[e] += bias[e];
         }
-        __builtin_amdgcn_wave_barrier();
+        if (f_aux_out && UIA_EPI_STORES) store8(aux_out + orow * p.ldaux_out + n, v);
+        if (act) apply_act8<sizeof(T) == 2>(v, act);
+        if (dact && UIA_EPI_LOADS) {
+            float a[8];
+            load8(aux_in + orow * p.ldaux_in + n, a);
+            apply_dact8<sizeof(T) == 2>(v, a, dact);
+        }
+        if (f_resid && UIA_EPI_LOADS) {
+            float r[8];
+            load8(p.resid + rrow * p.ldr + n, r);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += r[e];
+        }
+        if (f_residT && UIA_EPI_LOADS) {
+            float r[8];
+            load8(residT + orow * p.ldrT + n, r);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += r[e];
+        }
+        if (f_out32 && UIA_EPI_STORES) store8(p.out32 + orow * p.ldo32 + n, v);
+        if (f_outT && UIA_EPI_STORES) store8(outT + orow * p.ldo + n, v);
+    };
+
+    if constexpr (PATCH16) {
+        // Persistent kernel: the next tile's first sub-tiles are already landing in ring buffers 0..2, so the patch is
+        // 16 rows × WTN floats per wave (8 waves = one 32 KiB ring buffer, the caller passes its base), un-padded, with the
+        // 16-byte chunk c of row r stored at chunk c ^ (r & 15): conflict-free for the b128 writes (8 rows × one chunk
+        // column) and for both b128 reads of a pass (rows r, r+1 take disjoint chunk sets).
+        static_assert(WTN == 64 && NT == 4, "swizzled 16-row patch is laid out for 64-column wave tiles");
+        float* stg = (float*)(smem + wave * (16 * WTN * 4));
+        const int c0 = (lane % LPR) * 2;
+#pragma clang loop unroll(full)
+        for (int i = 0; i < MT; ++i) {
+#pragma clang loop unroll(full)
+            for (int j = 0; j < NT; ++j) *(f32x4*)(stg + li * WTN + (((g * NT + j) ^ li) << 2)) = acc[i][j];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int ps = 0; ps < 16 / RPP; ++ps) {
+                const int row = ps * RPP + rr;
+                const f32x4 lo = *(const f32x4*)(stg + row * WTN + ((c0 ^ row) << 2));
+                const f32x4 hi = *(const f32x4*)(stg + row * WTN + (((c0 + 1) ^ row) << 2));
+                apply(lo, hi, m0 + wm * WTM + 16 * i + row);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    } else {
+        float* stg = (float*)(smem + wave * EP::BYTES_PER_WAVE);
+#pragma clang loop unroll(full)
+        for (int ph = 0; ph < MT / GPP; ++ph) {
+#pragma clang loop unroll(full)
+            for (int gi = 0; gi < GPP; ++gi)
+#pragma clang loop unroll(full)
+                for (int j = 0; j < NT; ++j) *(f32x4*)(stg + (gi * 16 + li) * LDW + g * (4 * NT) + 4 * j) = acc[ph * GPP + gi][j];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            const int mbase = m0 + wm * WTM + ph * ROWS + rr;
+#pragma clang loop unroll_count(2)
+            for (int q = 0; q < ROWS / RPP; ++q) {
+                const int row = q * RPP + rr;
+                const f32x4 lo = *(const f32x4*)(stg + row * LDW + rc), hi = *(const f32x4*)(stg + row * LDW + rc + 4);
+                apply(lo, hi, mbase + q * RPP);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
     }
 }
 
@@ -789,6 +818,181 @@ int launch_ring_epi(hipStream_t stream, const UiaGemmParams& p) {
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Persistent ring kernel (tile cfg 12): one workgroup per CU walks its share of the 256×256 tiles.  Same K loop as the
+// ring kernel (64-byte sub-tiles, 4-deep ring, two wave groups one barrier slot apart); what changes is the seam
+// between tiles: right after the last barrier of a tile's K loop the workgroup issues the LDS-DMA of the NEXT tile's
+// first three sub-tiles into ring buffers 0..2 and runs the epilogue out of buffer 3 (16-row swizzled patches), so the
+// prologue's HBM/L2 latency (3-6 K cycles per tile in the stamps) and the workgroup hand-over (≈1.5 K) hide under the
+// epilogue.  Tile order: the blocks of one XCD (blockIdx & 7) own a contiguous range of tiles and take them
+// round-robin, so at any time an XCD's CUs work on neighbouring tiles that share A row panels in its L2.
+// vmcnt bookkeeping at the seam: the epilogue's loads/stores are younger than the three prefetched sub-tiles, so the
+// counted wait for sub-tile 0 (all but the 2·GPT youngest operations) also waits for them — correct, slightly early.
+template <typename T, int EPI>
+__global__ __launch_bounds__(512) void gemm_tn_persist_kernel(const UiaGemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BM = 256, BN = 256, WAVES_M = 2, WAVES_N = 4, BKB = 64, NBUF = 4;
+    constexpr int NW = WAVES_M * WAVES_N;
+    constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+    constexpr int MT = WTM / 16, NT = WTN / 16;
+    constexpr int A_BYTES = BM * BKB, W_BYTES = BN * BKB, BUF_BYTES = A_BYTES + W_BYTES;
+    constexpr int RPI = 1024 / BKB, CPR = BKB / 16;
+    constexpr int A_PER_WAVE = (BM / RPI) / NW, W_PER_WAVE = (BN / RPI) / NW;
+    constexpr int GPT = A_PER_WAVE + W_PER_WAVE;
+    constexpr int PD = NBUF - 1;
+    constexpr int ESZ = (int)sizeof(T);
+    static_assert(NW * 16 * WTN * 4 <= BUF_BYTES, "epilogue patches must fit one ring buffer");
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int grp = wave >= NW / 2 ? 1 : 0;
+
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tiles = ((p.M + BM - 1) / BM) * tiles_n;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int nslots = ((int)gridDim.x - xcd + 7) >> 3;                      // workgroups that share this XCD
+    const int tq = tiles >> 3, tr = tiles & 7;
+    const int t_lo = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
+    const int t_hi = t_lo + (xcd < tr ? tq + 1 : tq);
+    int tile = t_lo + slot;
+    if (tile >= t_hi) return;
+
+    auto swzA = [](int r) -> int { return (0x1230 >> (4 * ((r >> 2) & 3))) & 3; };
+    auto swzW = [](int rl) -> int { return (0x1230 >> (4 * ((rl >> 4) & 3))) & 3; };
+    const char* srcA[A_PER_WAVE];
+    const char* srcW[W_PER_WAVE];
+    int m0 = 0, n0 = 0;
+    auto point_at = [&](int tl) {
+        const int tm = tl / tiles_n, tn = tl - tm * tiles_n;
+        m0 = tm * BM;
+        n0 = tn * BN;
+#pragma unroll
+        for (int i = 0; i < A_PER_WAVE; ++i) {
+            const int r = RPI * (wave + NW * i) + lane / CPR;
+            const int c = (lane % CPR) ^ swzA(r);
+            int gm = m0 + r;
+            gm = gm < p.M ? gm : p.M - 1;
+            srcA[i] = (const char*)p.A + ((size_t)gm * (size_t)p.lda) * ESZ + c * 16;
+        }
+#pragma unroll
+        for (int i = 0; i < W_PER_WAVE; ++i) {
+            const int r = RPI * (wave + NW * i) + lane / CPR;
+            const int c = (lane % CPR) ^ swzW(r & (WTN - 1));
+            int gn = n0 + r;
+            gn = gn < p.N ? gn : p.N - 1;
+            srcW[i] = (const char*)p.W + ((size_t)gn * (size_t)p.ldw) * ESZ + c * 16;
+        }
+    };
+    const int li = lane & 15, g = lane >> 4;
+    const int rowA = wm * WTM + li;
+    const int rowW = wn * WTN + (li >> 2) * 16 + (li & 3);
+    const int offA0 = rowA * BKB + ((g ^ swzA(li)) << 4);
+    const int offW0 = A_BYTES + rowW * BKB + ((g ^ swzW((li >> 2) * 16 + (li & 3))) << 4);
+    const int ntl = (p.K * ESZ) / BKB;
+
+    auto stage = [&](int t) {
+        char* base = smem + (t % NBUF) * BUF_BYTES;
+        const size_t koff = (size_t)t * BKB;
+#pragma unroll
+        for (int i = 0; i < A_PER_WAVE; ++i) glds16_asm(srcA[i] + koff, base + (wave + NW * i) * 1024);
+#pragma unroll
+        for (int i = 0; i < W_PER_WAVE; ++i) glds16_asm(srcW[i] + koff, base + A_BYTES + (wave + NW * i) * 1024);
+    };
+    uint4 af[MT], wf[NT];
+    auto load_frags = [&](const char* buf) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) wf[j] = *(const uint4*)(buf + offW0 + j * 4 * BKB);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af[i] = *(const uint4*)(buf + offA0 + i * 16 * BKB);
+    };
+    f32x4 acc[MT][NT];
+    auto compute = [&]() {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = MfmaTile<T>::mma(wf[j], af[i], acc[i][j]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto retire = [&](int t) {
+        if (t + PD - 1 < ntl) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PD - 1) * GPT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+#define UIA_SLOT_END()                                         \
+    do {                                                       \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     \
+        __builtin_amdgcn_s_barrier();                          \
+        __builtin_amdgcn_sched_barrier(0);                     \
+    } while (0)
+
+    point_at(tile);
+    for (int t = 0; t < PD && t < ntl; ++t) stage(t);
+    while (true) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        retire(0);
+        __builtin_amdgcn_s_barrier();                 // sub-tile 0 resident; every wave is out of the previous epilogue
+        __builtin_amdgcn_sched_barrier(0);
+        if (grp == 1) {                               // fall one slot behind group 0
+            UIA_SLOT_END();
+        }
+        for (int t = 0; t < ntl; ++t) {
+            const char* buf = smem + (t % NBUF) * BUF_BYTES;
+            if (t + PD < ntl) stage(t + PD);
+            load_frags(buf);
+            if (grp == 1 && t + 1 < ntl) retire(t + 1);
+            UIA_SLOT_END();
+            compute();
+            if (grp == 0 && t + 1 < ntl) retire(t + 1);
+            UIA_SLOT_END();
+        }
+        if (grp == 0) {
+            UIA_SLOT_END();
+        }
+        const int cm0 = m0, cn0 = n0;
+        const int next = tile + nslots;
+        const bool more = next < t_hi;
+        if (more) {                                   // next tile's head rides under this tile's epilogue
+            point_at(next);
+            for (int t = 0; t < PD && t < ntl; ++t) stage(t);
+        }
+        gemm_epilogue_lds<T, MT, NT, WTM, WTN, EPI, true>(p, acc, smem + (NBUF - 1) * BUF_BYTES, wave, lane, cm0, cn0, wm, wn);
+        if (!more) break;
+        tile = next;
+    }
+#undef UIA_SLOT_END
+}
+
+inline int uia_num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                ? prop.multiProcessorCount : 256;
+    }
+    return n;
+}
+
+template <typename T, int EPI>
+int launch_persist_epi(hipStream_t stream, const UiaGemmParams& p) {
+    constexpr int LDS = 4 * 512 * 64;
+    auto kern = gemm_tn_persist_kernel<T, EPI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        UIA_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_set = true;
+    }
+    const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+    const int ncu = uia_num_cus();
+    hipLaunchKernelGGL(kern, dim3(tiles < ncu ? tiles : ncu), dim3(512), LDS, stream, p);
+    UIA_CHECK_LAUNCH();
+    return 0;
+}
+
 // feature mask of a descriptor, or EPI_GENERIC when it uses something the specialised epilogues leave out
 inline int epi_mask_of(const UiaGemmParams& p) {
     if (p.alpha != 1.0f || p.out_group > 0 || p.resid_mod > 0) return EPI_GENERIC;
@@ -816,13 +1020,31 @@ int launch_ring(hipStream_t stream, const UiaGemmParams& p, bool specialise) {
 }
 
 template <typename T>
+int launch_persist(hipStream_t stream, const UiaGemmParams& p) {
+    switch (epi_mask_of(p)) {
+#define UIA_EPI_CASE(MASK) case (MASK): return launch_persist_epi<T, (MASK)>(stream, p)
+        UIA_EPI_CASE(EPI_BIAS | EPI_RESID | EPI_OUT32);
+        UIA_EPI_CASE(EPI_OUTT);
+        UIA_EPI_CASE(EPI_BIAS | EPI_OUTT);
+        UIA_EPI_CASE(EPI_BIAS | EPI_GELU | EPI_OUTT);
+        UIA_EPI_CASE(EPI_DGELU | EPI_OUTT);
+        UIA_EPI_CASE(EPI_BIAS | EPI_GELU | EPI_AUX_OUT | EPI_OUTT);
+#undef UIA_EPI_CASE
+        default: break;
+    }
+    return launch_persist_epi<T, EPI_GENERIC>(stream, p);
+}
+
+template <typename T>
 int launch_typed(hipStream_t stream, const UiaGemmParams& p, int cfg) {
     // cfg: 0 = auto. Tile choice is a pure speed knob (results are identical for every config
     // up to fp32 summation order inside a K-step, which does not depend on the tile).
     if (cfg == 0) {
         if (p.N <= 64) cfg = 4;
         else if (p.M <= 2048) cfg = 3;
-        else cfg = 8;            // 256x256 ping-pong, 4-deep 64-byte ring, LDS-staged epilogue: best measured on every large shape
+        else cfg = 8;            // 256x256 ping-pong, 4-deep 64-byte ring, LDS-staged epilogue: best measured on every large shape.
+                                 // (cfg 12, the persistent variant, is +2-3.5 % on store-only epilogues in isolation, -15-25 % on the
+                                 //  fp32-residual ones, and a net loss inside the two-stream training step: opt-in only.)
     }
     switch (cfg) {
         case 1: return launch_cfg<T, 256, 256, 2, 4>(stream, p);
@@ -835,6 +1057,7 @@ int launch_typed(hipStream_t stream, const UiaGemmParams& p, int cfg) {
         case 8: return launch_ring<T, 256, 256, 2, 4, 64, 4>(stream, p, true);
         case 9: return launch_ring<T, 256, 128, 4, 2, 128, 3>(stream, p, false);
         case 10: return launch_ring<T, 256, 256, 2, 4, 64, 4>(stream, p, false);   // cfg 8 with the run-time (generic) epilogue: parity cross-check
+        case 12: return launch_persist<T>(stream, p);
         default: uia_set_error("uia_gemm: unknown tile config %d", cfg); return -1;
     }
 }

@@ -163,6 +163,12 @@ int main(int argc, char** argv) {
     stamps(8, 50432, 2304, 768, 0, 0);
     return 0;
 #endif
+    if (argc > 1 && !strcmp(argv[1], "cmp")) {      // ./test_gemm cmp: ring (8) vs persistent (12) on the training step's shapes
+        const int shapes[][4] = {{50432, 2304, 768, 0}, {65536, 2304, 768, 0}, {50432, 3072, 768, 1}, {50432, 768, 3072, 2}, {65536, 768, 3072, 2},
+                                 {50432, 768, 768, 2}, {65536, 768, 768, 2}, {50432, 768, 2304, 0}, {50432, 768, 64, 2}};
+        for (auto& sh : shapes) for (int cfg : {8, 12}) bench(UIA_BF16, sh[0], sh[1], sh[2], cfg, sh[3]);
+        return 0;
+    }
     if (argc > 2 && !strcmp(argv[1], "one")) {      // ./test_gemm one <cfg> [M N K]: a single shape, for PMC runs
         const int cfg = atoi(argv[2]);
         const int M = argc > 5 ? atoi(argv[3]) : 8192, N = argc > 5 ? atoi(argv[4]) : 8192, K = argc > 5 ? atoi(argv[5]) : 8192;

@@ -18,13 +18,45 @@ _ACT = {None: 0, "none": 0, "gelu": 1, "quick_gelu": 2, "relu": 3}
 GEMM_PROFILE = None
 
 
-def auto_tile_cfg(M, N):
+EPI_BIAS, EPI_AUX_OUT, EPI_GELU, EPI_DGELU, EPI_RESID, EPI_RESIDT, EPI_OUT32, EPI_OUTT, EPI_GENERIC = 1, 2, 4, 8, 16, 32, 64, 128, -1
+_SPECIALISED = {EPI_BIAS | EPI_RESID | EPI_OUT32, EPI_OUTT, EPI_BIAS | EPI_OUTT, EPI_BIAS | EPI_GELU | EPI_OUTT, EPI_DGELU | EPI_OUTT,
+                EPI_BIAS | EPI_GELU | EPI_AUX_OUT | EPI_OUTT}
+
+
+def epi_mask_of(d):
+    """Mirror of epi_mask_of() in csrc/gemm.hip: the compile-time epilogue instantiation a descriptor lands on."""
+    if d.alpha != 1.0 or d.out_group > 0 or d.resid_mod > 0:
+        return EPI_GENERIC
+    if (d.act and d.act != _ACT["gelu"]) or (d.dact and d.dact != _ACT["gelu"]):
+        return EPI_GENERIC
+    m = ((EPI_BIAS if d.bias else 0) | (EPI_AUX_OUT if d.aux_out else 0) | (EPI_GELU if d.act else 0) | (EPI_DGELU if d.dact else 0) |
+         (EPI_RESID if d.resid else 0) | (EPI_RESIDT if d.residT else 0) | (EPI_OUT32 if d.out32 else 0) | (EPI_OUTT if d.outT else 0))
+    return m
+
+
+def auto_tile_cfg(M, N, K=None, esz=2, mask=EPI_GENERIC):
     """Mirror of launch_typed() in csrc/gemm.hip (which kernel instantiation a shape runs on)."""
     if N <= 64:
         return 4
     if M <= 2048:
         return 3
     return 8
+
+
+def gemm_kernel_name(cfg, mask, dtype):
+    """(readable name, mangled fragment) of the instantiation a launch runs on.  rocprofv3 prints these kernels mangled
+    (its demangler does not know the bf16 type code), so the fragment is what to grep for in profiles/*.csv."""
+    m = mask if mask in _SPECIALISED else EPI_GENERIC
+    tn, tc = ("bf16", "DF16b") if dtype == torch.bfloat16 else ("float", "f")
+    mi = lambda v: f"Li{v}E" if v >= 0 else f"Lin{-v}E"
+    if cfg == 12:
+        return f"gemm_tn_persist_kernel<{tn},{m}>", f"gemm_tn_persist_kernelI{tc}{mi(m)}E"
+    if cfg == 8:
+        return f"gemm_tn_ring_kernel<{tn},256,256,2,4,64,4,{m}>", "gemm_tn_ring_kernelI" + tc + "".join(mi(v) for v in (256, 256, 2, 4, 64, 4, m)) + "E"
+    shape = {1: (256, 256, 2, 4), 2: (256, 128, 4, 2), 3: (128, 128, 2, 2), 4: (256, 64, 4, 1), 5: (128, 64, 2, 1)}.get(cfg)
+    if shape:
+        return f"gemm_tn_kernel<{tn},{','.join(map(str, shape))}>", "gemm_tn_kernelI" + tc + "".join(mi(v) for v in shape) + "E"
+    return f"tile cfg {cfg}", f"cfg{cfg}"
 
 
 def _code(dt):
@@ -94,7 +126,8 @@ def gemm(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None, res
         esz = a.element_size()                  # algorithmic HBM bytes of this launch: every operand and result once
         nbytes = esz * (d.M * d.K + d.N * d.K) + d.M * d.N * (esz * sum(t is not None for t in (aux_in, aux_out, resid_t, out_t))
                                                              + 4 * sum(t is not None for t in (resid, out32)))
-        GEMM_PROFILE.append((e0, e1, d.M, d.N, d.K, a.dtype, tile_cfg or auto_tile_cfg(d.M, d.N), nbytes))
+        mask = epi_mask_of(d)
+        GEMM_PROFILE.append((e0, e1, d.M, d.N, d.K, a.dtype, tile_cfg or auto_tile_cfg(d.M, d.N, d.K, esz, mask), nbytes, mask))
         return
     check(lib().uia_gemm(_stream(), _code(a.dtype), C.byref(d), tile_cfg), "uia_gemm")
 

@@ -49,7 +49,7 @@ def test_gemm_epilogues(ops, dt):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12])
 def test_gemm_every_tile_config_and_epilogue_mask(ops, dt, cfg):
     """Every tile instantiation (lockstep 1-5, ping-pong 6-7, ring 8-10) against torch on a ragged shape, through
     the six compile-time epilogue masks of the ring kernel (cfg 8) and the run-time epilogue (everything else)."""
@@ -84,6 +84,32 @@ def test_gemm_every_tile_config_and_epilogue_mask(ops, dt, cfg):
     assert rel(y, 0.5 * pre + bias + resid + rt.float()) < 2e-5 and rel(y2, 0.5 * pre + bias + resid + rt.float()) < tol
     y = o_t(); ops.gemm(a, w, bias=bias, act="quick_gelu", out_t=y, tile_cfg=cfg)
     assert rel(y, (pre + bias) * torch.sigmoid(1.702 * (pre + bias))) < tol
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_gemm_persistent_kernel_walks_many_tiles(ops, dt):
+    """cfg 12 (persistent): more tiles than CUs, ragged edges, so every workgroup crosses the tile seam (next tile's
+    LDS-DMA issued under the epilogue) at least once; checked against torch and, bit for bit, against cfg 8."""
+    torch.manual_seed(5)
+    M, N, K = 20 * 256 - 19, 17 * 256 - 40, 192          # 340 tiles on 256 CUs
+    a = torch.randn(M, K, device=dev()).to(dt)
+    w = (torch.randn(N, K, device=dev()) * 0.1).to(dt)
+    bias, resid = torch.randn(N, device=dev()), torch.randn(M, N, device=dev())
+    pre = a.float() @ w.float().T
+    y12, y8 = torch.full((M, N), float("nan"), device=dev()), torch.full((M, N), float("nan"), device=dev())
+    ops.gemm(a, w, bias=bias, resid=resid, out32=y12, tile_cfg=12)
+    ops.gemm(a, w, bias=bias, resid=resid, out32=y8, tile_cfg=8)
+    assert rel(y12, pre + bias + resid) < 2e-5 and torch.equal(y12, y8)
+    z12, z8 = torch.empty(M, N, device=dev(), dtype=dt), torch.empty(M, N, device=dev(), dtype=dt)
+    x12, x8 = torch.empty_like(z12), torch.empty_like(z8)
+    ops.gemm(a, w, bias=bias, act="gelu", aux_out=x12, out_t=z12, tile_cfg=12)
+    ops.gemm(a, w, bias=bias, act="gelu", aux_out=x8, out_t=z8, tile_cfg=8)
+    assert rel(z12, torch.nn.functional.gelu(pre + bias)) < TOL[dt] and torch.equal(z12, z8) and torch.equal(x12, x8)
+    # K shorter than the ring (2 sub-tiles): the Mona project2 shape
+    a2, w2 = a[:, :64].contiguous() if dt == torch.bfloat16 else a[:, :32].contiguous(), None
+    w2 = w[:, :a2.shape[1]].contiguous()
+    ops.gemm(a2, w2, bias=bias, resid=resid, out32=y12, tile_cfg=12)
+    assert rel(y12, a2.float() @ w2.float().T + bias + resid) < 2e-5
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
