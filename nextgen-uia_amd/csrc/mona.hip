@@ -19,6 +19,7 @@
 //
 // All of it is HBM/LDS-bound VALU work: thread = (channel = lane, pixel group = wave) so that every
 // LDS access of a wave is 64 consecutive floats (conflict-free) and boundary tests are wave-uniform.
+#include <stdlib.h>
 #include "uia_common.h"
 #include "uia_kernels.h"
 
@@ -506,6 +507,353 @@ __global__ __launch_bounds__(512) void mona_spatial_kernel(const uia_mona_spatia
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// bf16 fast path of the spatial op (grid width W known at compile time: 14 for ViT-B/16 at 224, 4 in the unit tests).
+// Same arithmetic, same LDS residency, restructured for the machine:
+//   * 7×7 stencils (forward, transposed, and the weight-gradient correlation) are ROW STRIPS: a wave owns image rows
+//     y = wave, wave+8, …; a lane owns one channel and holds the W outputs of the row in registers; each source row is
+//     read from LDS once (W loads) into a zero-padded register strip and feeds 7·W FMAs with compile-time indices.
+//     (The per-pixel form spent ~4 VALU instructions of bounds logic and one LDS load per FMA.)
+//   * the 1×1 projector, its data gradient and its weight gradient run on the matrix cores
+//     (v_mfma_f32_16x16x32_bf16, operands converted from the fp32 LDS tiles on the way into the registers).
+//     c and dz tiles use a row stride of 68 floats so that row-per-lane fragment reads are conflict-free.
+constexpr int FLD = 68;
+__host__ __device__ constexpr size_t spatial_fast_lds(int hw, bool bwd) {
+    return ((size_t)(hw + 1) * BOTT + (size_t)((hw * FLD > RED_FLOATS) ? hw * FLD : RED_FLOATS) + (bwd ? (size_t)(hw + 1) * FLD : 0) + SCR_SIZE) * sizeof(float);
+}
+__device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
+    bf16x8 r = {(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3], (bf16_t)b[0], (bf16_t)b[1], (bf16_t)b[2], (bf16_t)b[3]};
+    return r;
+}
+
+// acc[x] += Σ_j km[i][j] · src(row yy)[x + (j-3)·sgn]  for the 7 source rows of output row y.  FLIP = transposed stencil.
+template <int W, bool FLIP>
+__device__ __forceinline__ void stencil_row(const float* __restrict__ src, int ld, int h, int y, int c, const float (&km)[49], float (&acc)[W]) {
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        const int yy = FLIP ? y - (i - 3) : y + (i - 3);
+        if (yy < 0 || yy >= h) continue;                       // wave-uniform
+        float row[W + 6];
+#pragma unroll
+        for (int x = 0; x < W + 6; ++x) row[x] = 0.f;
+#pragma unroll
+        for (int x = 0; x < W; ++x) row[3 + x] = src[(size_t)(yy * W + x) * ld + c];
+#pragma unroll
+        for (int x = 0; x < W; ++x)
+#pragma unroll
+            for (int j = 0; j < 7; ++j) acc[x] = fmaf(km[i * 7 + j], row[3 + x + (FLIP ? -(j - 3) : (j - 3))], acc[x]);
+    }
+}
+
+template <int W, bool BWD>
+__global__ __launch_bounds__(512) void mona_spatial_fast_kernel(const uia_mona_spatial_desc p) {
+    typedef bf16_t T;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int h = p.h, hw = h * W, ntok = hw + 1;
+    float* tS = (float*)smem;                                   // [ntok][64]      t (token 0 = CLS)
+    float* cS = tS + ntok * BOTT;                               // [hw][FLD]       c = conv + identity  (later: reduction scratch)
+    const int cs_floats = (hw * FLD > RED_FLOATS) ? hw * FLD : RED_FLOATS;
+    float* gS = cS + cs_floats;                                 // [ntok][FLD]     dz, then dc (backward only)
+    float* scr = BWD ? gS + ntok * FLD : cS + cs_floats;
+    const int tid = threadIdx.x, lane = tid & 63, c = lane, grp = tid >> 6;
+    const int li = lane & 15, g = lane >> 4;
+    const int b = blockIdx.x;
+    const bool has_freq = p.variant == UIA_MONA_FREQ_ENHANCED || p.variant == UIA_MONA_HYBRID;
+    const bool has_noise = p.variant == UIA_MONA_NOISE_AWARE || p.variant == UIA_MONA_HYBRID;
+    const int ppg = (hw + NGRP - 1) / NGRP;
+    const size_t tok0 = (size_t)b * ntok;
+    float* wsrow = (BWD && p.ws) ? p.ws + (size_t)b * WS_ROW : nullptr;
+
+    load_tokens((const T*)p.t + tok0 * BOTT, tS, ntok, tid);
+    __syncthreads();
+    const float f = has_freq ? p.freq[c] : 1.0f;
+    float w1 = 1.f / 3.f, w2 = 1.f / 3.f, w3 = 1.f / 3.f;
+    if (has_noise) {
+        noise_forward(p, tS, f, hw, ppg, c, grp, tid, scr);
+        w1 = scr[SCR_W]; w2 = scr[SCR_W + 1]; w3 = scr[SCR_W + 2];
+    }
+    float km[49];
+    {
+        float k1[9], k2[25], k3[49];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) k1[i] = p.conv1_w[c * 9 + i];
+#pragma unroll
+        for (int i = 0; i < 25; ++i) k2[i] = p.conv2_w[c * 25 + i];
+#pragma unroll
+        for (int i = 0; i < 49; ++i) k3[i] = p.conv3_w[c * 49 + i];
+#pragma unroll
+        for (int i = 0; i < 7; ++i)
+#pragma unroll
+            for (int j = 0; j < 7; ++j) km[i * 7 + j] = KM(i, j);
+    }
+    const float b1 = p.conv1_b[c], b2 = p.conv2_b[c], b3 = p.conv3_b[c];
+    const float bm = w1 * b1 + w2 * b2 + w3 * b3;
+    // ---- c[px][ch] = f·(K ⋆ t) + Σ w_k b_k + t
+    for (int y = grp; y < h; y += NGRP) {
+        float acc[W];
+#pragma unroll
+        for (int x = 0; x < W; ++x) acc[x] = 0.f;
+        stencil_row<W, false>(tS + BOTT, BOTT, h, y, c, km, acc);
+#pragma unroll
+        for (int x = 0; x < W; ++x) cS[(y * W + x) * FLD + c] = fmaf(f, acc[x], bm) + tS[(1 + y * W + x) * BOTT + c];
+    }
+    __syncthreads();
+
+    // ---- projector on the matrix cores: z[px][co] = c[px][co] + Σ_ci c[px][ci]·P[co][ci] + pb[co]
+    const float inv_keep = p.p_drop > 0.f ? 1.0f / (1.0f - p.p_drop) : 1.0f;
+    const uint32_t thresh = p.p_drop > 0.f ? (uint32_t)fminf(p.p_drop * 4294967296.0f, 4294967295.0f) : 0u;
+    auto keep_scale = [&](int tok, int ch) -> float {
+        const size_t idx = (tok0 + tok) * BOTT + ch;
+        if (p.keep_mask) return p.keep_mask[idx] ? inv_keep : 0.f;
+        if (p.p_drop > 0.f) return dropout_keep(p.seed, (uint32_t)idx, thresh) ? inv_keep : 0.f;
+        return 1.0f;
+    };
+    const int mtiles = (hw + 15) >> 4;
+    {
+        bf16x8 pw[4][2];                                        // B fragments: P rows co = 16nt + li, k = ci = 32kk + 8g .. +7
+        float pb[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const float* src = p.proj_w + (16 * nt + li) * 64 + 32 * kk + 8 * g;
+                pw[nt][kk] = pack8(load4(src), load4(src + 4));
+            }
+            pb[nt] = p.proj_b[16 * nt + li];
+        }
+        for (int mt = grp; mt < mtiles; mt += NGRP) {
+            int arow = 16 * mt + li;
+            arow = arow < hw ? arow : hw - 1;
+            bf16x8 af[2];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const float* src = cS + arow * FLD + 32 * kk + 8 * g;
+                af[kk] = pack8(*(const f32x4*)src, *(const f32x4*)(src + 4));
+            }
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], pw[nt][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], pw[nt][1], acc, 0, 0, 0);
+                const int co = 16 * nt + li;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int px = 16 * mt + 4 * g + r;
+                    if (px < hw) {
+                        const float z = cS[px * FLD + co] + acc[r] + pb[nt];
+                        const float ks = keep_scale(1 + px, co);
+                        if (!BWD) ((T*)p.d)[(tok0 + 1 + px) * BOTT + co] = (T)(gelu_erf(z) * ks);
+                        else gS[(1 + px) * FLD + co] = to_f32(((const T*)p.dd)[(tok0 + 1 + px) * BOTT + co]) * ks * dgelu_erf(z);    // dz
+                    }
+                }
+            }
+        }
+        if (grp == NGRP - 1) {   // CLS token bypasses the spatial op (mona.py:132,139)
+            const float z = tS[c], ks = keep_scale(0, c);
+            if (!BWD) ((T*)p.d)[tok0 * BOTT + c] = (T)(gelu_erf(z) * ks);
+            else gS[c] = to_f32(((const T*)p.dd)[tok0 * BOTT + c]) * ks * dgelu_erf(z);
+        }
+    }
+    if (!BWD) return;
+
+    // ======================================================================== backward
+    __syncthreads();
+    // ---- dP[co][ci] = Σ_px dz[px][co]·c[px][ci] on the matrix cores (k = pixels, zero beyond hw); db_p[co] = Σ_px dz[px][co]
+    {
+        const int mt = grp & 3, nt0 = 2 * (grp >> 2);
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        const int ksteps = (hw + 31) >> 5;
+        for (int ks = 0; ks < ksteps; ++ks) {
+            bf16x8 a, bb[2];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int px = 32 * ks + 8 * g + e;
+                const int pc = px < hw ? px : hw - 1;
+                const float av = gS[(1 + pc) * FLD + 16 * mt + li];
+                a[e] = (bf16_t)(px < hw ? av : 0.f);
+                bb[0][e] = (bf16_t)cS[pc * FLD + 16 * nt0 + li];
+                bb[1][e] = (bf16_t)cS[pc * FLD + 16 * (nt0 + 1) + li];
+            }
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bb[0], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bb[1], acc[1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) grad_out(wsrow, WS_PROJ_W, p.g_proj_w, (16 * mt + 4 * g + r) * 64 + 16 * (nt0 + q) + li, acc[q][r]);
+        if (tid < 64) {
+            float sb = 0.f;
+            for (int px = 0; px < hw; ++px) sb += gS[(1 + px) * FLD + tid];
+            grad_out(wsrow, WS_PROJ_B, p.g_proj_b, tid, sb);
+        }
+    }
+    __syncthreads();
+    // ---- dc = dz + dz·P, in place (the rows of an m-tile belong to one wave)
+    {
+        bf16x8 pt[4][2];                                        // B fragments: k = co = 32kk + 8g + e, n = ci = 16nt + li  →  P[co][ci]
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pt[nt][kk][e] = (bf16_t)p.proj_w[(32 * kk + 8 * g + e) * 64 + 16 * nt + li];
+        for (int mt = grp; mt < mtiles; mt += NGRP) {
+            int arow = 16 * mt + li;
+            arow = arow < hw ? arow : hw - 1;
+            bf16x8 af[2];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const float* src = gS + (1 + arow) * FLD + 32 * kk + 8 * g;
+                af[kk] = pack8(*(const f32x4*)src, *(const f32x4*)(src + 4));
+            }
+            f32x4 acc[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], pt[nt][0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], pt[nt][1], acc[nt], 0, 0, 0);
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int px = 16 * mt + 4 * g + r;
+                    if (px < hw) gS[(1 + px) * FLD + 16 * nt + li] += acc[nt][r];
+                }
+        }
+    }
+    __syncthreads();
+    // ---- pass A: stencil weight gradients dK[i][j] = Σ_px dc[px]·t[px + off]  (and the mixing-weight gradients of the noise variants)
+    float dkm[49];
+#pragma unroll
+    for (int i = 0; i < 49; ++i) dkm[i] = 0.f;
+    float sdc = 0.f, dwm1 = 0.f, dwm2 = 0.f, dwm3 = 0.f;
+    for (int y = grp; y < h; y += NGRP) {
+        float dcr[W];
+#pragma unroll
+        for (int x = 0; x < W; ++x) { dcr[x] = gS[(1 + y * W + x) * FLD + c]; sdc += dcr[x]; }
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const int yy = y + i - 3;
+            if (yy < 0 || yy >= h) continue;
+            float row[W + 6];
+#pragma unroll
+            for (int x = 0; x < W + 6; ++x) row[x] = 0.f;
+#pragma unroll
+            for (int x = 0; x < W; ++x) row[3 + x] = tS[(1 + yy * W + x) * BOTT + c];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                float a = 0.f;
+#pragma unroll
+                for (int x = 0; x < W; ++x) a = fmaf(dcr[x], row[x + j], a);
+                dkm[i * 7 + j] += a;
+            }
+        }
+    }
+    if (has_noise) {
+        // Σ_px dc·conv_k = f·Σ_taps k_k[tap]·dK[tap] (restricted to the sub-stencil) + b_k·Σ dc   — no second sweep needed
+        float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 7; ++i)
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                s3 = fmaf(p.conv3_w[c * 49 + i * 7 + j], dkm[i * 7 + j], s3);
+                if (i >= 1 && i <= 5 && j >= 1 && j <= 5) s2 = fmaf(p.conv2_w[c * 25 + (i - 1) * 5 + (j - 1)], dkm[i * 7 + j], s2);
+                if (i >= 2 && i <= 4 && j >= 2 && j <= 4) s1 = fmaf(p.conv1_w[c * 9 + (i - 2) * 3 + (j - 2)], dkm[i * 7 + j], s1);
+            }
+        dwm1 = fmaf(f, s1, b1 * sdc);
+        dwm2 = fmaf(f, s2, b2 * sdc);
+        dwm3 = fmaf(f, s3, b3 * sdc);
+    }
+    // reduce over the waves with LDS atomics into [64][50] (the c tile is free now)
+    float* red = cS;
+    for (int i = tid; i < RED_FLOATS; i += 512) red[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 49; ++i) atomicAdd(red + c * 50 + i, dkm[i]);
+    atomicAdd(red + c * 50 + 49, sdc);
+    __syncthreads();
+    if (grp == 0) {
+#pragma unroll
+        for (int i = 0; i < 49; ++i) dkm[i] = f * red[c * 50 + i];      // Σ dc·xf[nbr]
+        sdc = red[c * 50 + 49];
+#pragma unroll
+        for (int i = 0; i < 7; ++i)
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                grad_out(wsrow, WS_C3W, p.g_conv3_w, c * 49 + i * 7 + j, w3 * dkm[i * 7 + j]);
+                if (i >= 1 && i <= 5 && j >= 1 && j <= 5) grad_out(wsrow, WS_C2W, p.g_conv2_w, c * 25 + (i - 1) * 5 + (j - 1), w2 * dkm[i * 7 + j]);
+                if (i >= 2 && i <= 4 && j >= 2 && j <= 4) grad_out(wsrow, WS_C1W, p.g_conv1_w, c * 9 + (i - 2) * 3 + (j - 2), w1 * dkm[i * 7 + j]);
+            }
+        grad_out(wsrow, WS_C1B, p.g_conv1_b, c, w1 * sdc);
+        grad_out(wsrow, WS_C2B, p.g_conv2_b, c, w2 * sdc);
+        grad_out(wsrow, WS_C3B, p.g_conv3_b, c, w3 * sdc);
+    }
+    float dpool_c = 0.f;
+    if (has_noise) {
+        __syncthreads();
+        float r1 = wave_sum(dwm1), r2 = wave_sum(dwm2), r3 = wave_sum(dwm3);
+        if (c == 0) { scr[SCR_RED + grp * 4] = r1; scr[SCR_RED + grp * 4 + 1] = r2; scr[SCR_RED + grp * 4 + 2] = r3; }
+        __syncthreads();
+        if (tid < 16) {
+            float dwv[3], wv[3] = {w1, w2, w3}, dl[3];
+            for (int k = 0; k < 3; ++k) {
+                dwv[k] = 0.f;
+                for (int q = 0; q < NGRP; ++q) dwv[k] += scr[SCR_RED + 4 * q + k];
+            }
+            const float dot = dwv[0] * wv[0] + dwv[1] * wv[1] + dwv[2] * wv[2];
+            for (int k = 0; k < 3; ++k) dl[k] = wv[k] * (dwv[k] - dot);
+            const float hid = scr[SCR_HID + tid], hpre = scr[SCR_HPRE + tid];
+            float dh = 0.f;
+            for (int k = 0; k < 3; ++k) {
+                grad_out(wsrow, WS_NE3W, p.g_ne3_w, k * 16 + tid, dl[k] * hid);
+                dh = fmaf(dl[k], p.ne3_w[k * 16 + tid], dh);
+            }
+            if (tid < 3) grad_out(wsrow, WS_NE3B, p.g_ne3_b, tid, dl[tid]);
+            dh = hpre > 0.f ? dh : 0.f;
+            scr[SCR_HPRE + tid] = dh;
+            grad_out(wsrow, WS_NE1B, p.g_ne1_b, tid, dh);
+        }
+        __syncthreads();
+        if (tid < 64) {
+            float dp = 0.f;
+            for (int j = 0; j < 16; ++j) dp = fmaf(scr[SCR_HPRE + j], p.ne1_w[j * 64 + tid], dp);
+            scr[SCR_DPOOL + tid] = dp / hw;
+        }
+        for (int i = tid; i < 16 * 64; i += 512) grad_out(wsrow, WS_NE1W, p.g_ne1_w, i, scr[SCR_HPRE + (i >> 6)] * scr[SCR_POOL + (i & 63)]);
+        __syncthreads();
+        dpool_c = scr[SCR_DPOOL + c];
+    }
+    // ---- pass B: dxf = Kᵀ ⋆ dc (+ pool path);  dt = dc + f·dxf;  df = Σ dxf·t
+    float dfc = 0.f;
+    T* dt = (T*)p.dt;
+    for (int y = grp; y < h; y += NGRP) {
+        float acc[W];
+#pragma unroll
+        for (int x = 0; x < W; ++x) acc[x] = 0.f;
+        stencil_row<W, true>(gS + FLD, FLD, h, y, c, km, acc);
+#pragma unroll
+        for (int x = 0; x < W; ++x) {
+            const int px = y * W + x;
+            const float dxf = acc[x] + dpool_c;
+            dfc = fmaf(dxf, tS[(1 + px) * BOTT + c], dfc);
+            dt[(tok0 + 1 + px) * BOTT + c] = (T)fmaf(f, dxf, gS[(1 + px) * FLD + c]);
+        }
+    }
+    if (grp == NGRP - 1) dt[tok0 * BOTT + c] = (T)gS[c];
+    if (has_freq) {
+        __syncthreads();
+        scr[SCR_PART + grp * 64 + c] = dfc;
+        __syncthreads();
+        if (tid < 64) {
+            float a = 0.f;
+#pragma unroll
+            for (int q = 0; q < NGRP; ++q) a += scr[SCR_PART + q * 64 + tid];
+            grad_out(wsrow, WS_FREQ, p.g_freq, tid, a);
+        }
+    }
+}
+
 // g[param][i] += Σ_b ws[b][off + i]   (fixed summation order: deterministic, no atomics)
 // 64 columns per block × 4 image phases: every phase walks its images with 8 independent loads in flight.
 __global__ __launch_bounds__(256) void mona_ws_reduce_kernel(int B, const float* __restrict__ ws, uia_mona_spatial_desc p, int has_freq, int has_noise) {
@@ -552,9 +900,31 @@ size_t spatial_lds(int hw, bool bwd) {
     return (tile * (bwd ? 2 : 1) + cs + SCR_SIZE) * sizeof(float);
 }
 
+template <int W, bool BWD>
+int launch_spatial_fast(hipStream_t stream, const uia_mona_spatial_desc& p) {
+    auto kern = mona_spatial_fast_kernel<W, BWD>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        UIA_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.B), dim3(512), spatial_fast_lds(p.h * W, BWD), stream, p);
+    return 0;
+}
+
 template <typename T, bool BWD>
 int launch_spatial(hipStream_t stream, const uia_mona_spatial_desc& p) {
     const size_t lds = spatial_lds(p.h * p.w, BWD);
+    bool fast = false;
+    if (sizeof(T) == 2 && (p.w == 14 || p.w == 4) && spatial_fast_lds(p.h * p.w, BWD) <= 160 * 1024) {
+        static int allow = -1;                       // UIA_MONA_FAST=0 selects the per-pixel kernel (cross-checks)
+        if (allow < 0) { const char* e = getenv("UIA_MONA_FAST"); allow = (e && e[0] == '0') ? 0 : 1; }
+        fast = allow != 0;
+    }
+    if (fast) {
+        if (p.w == 14) launch_spatial_fast<14, BWD>(stream, p);
+        else launch_spatial_fast<4, BWD>(stream, p);
+    } else {
     auto kern = mona_spatial_kernel<T, BWD>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -562,6 +932,7 @@ int launch_spatial(hipStream_t stream, const uia_mona_spatial_desc& p) {
         attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3(p.B), dim3(512), lds, stream, p);
+    }
     if (BWD && p.ws) {
         const bool has_freq = p.variant == UIA_MONA_FREQ_ENHANCED || p.variant == UIA_MONA_HYBRID;
         const bool has_noise = p.variant == UIA_MONA_NOISE_AWARE || p.variant == UIA_MONA_HYBRID;

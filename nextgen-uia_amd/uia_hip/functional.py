@@ -48,17 +48,24 @@ _T_COPIES = {}
 
 
 def publish_t_copy(g32, g_t):
+    """The entry keeps a STRONG reference to the fp32 gradient: while it is registered its storage cannot be freed, so no
+    later tensor can appear at the same address and pick up a stale copy (a registry keyed by address alone did exactly that
+    when two backward passes ran without clear_t_copies() in between).  Entries are consumed by the first lookup; the
+    training loops clear what was never looked up once per step, and the registry is bounded besides."""
     if g_t is not None and g_t.dtype != torch.float32:
-        _T_COPIES[g32.data_ptr()] = (g32.shape, g_t)
+        if len(_T_COPIES) >= 256:
+            _T_COPIES.clear()
+        _T_COPIES[g32.data_ptr()] = (g32, g32._version, g_t)
 
 
 def t_copy_of(g32, dt):
-    """Return a T copy of the fp32 gradient `g32` (cached one if its producer published it)."""
+    """Return a T copy of the fp32 gradient `g32` (the one its producer published, if it is still that tensor's content)."""
     if dt == torch.float32:
         return g32
     hit = _T_COPIES.pop(g32.data_ptr(), None)
-    if hit is not None and hit[0] == g32.shape and hit[1].dtype == dt:
-        return hit[1]
+    if (hit is not None and hit[0].shape == g32.shape and hit[0].stride() == g32.stride() and hit[1] == g32._version
+            and hit[0].untyped_storage().data_ptr() == g32.untyped_storage().data_ptr() and hit[2].dtype == dt):
+        return hit[2]
     out = torch.empty(g32.shape, device=g32.device, dtype=dt)
     ops.cast(g32.contiguous(), out)
     return out

@@ -47,12 +47,15 @@ def randomize(module, gen, scale=0.2):
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
 @pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("drop", [False, True])
-def test_mona_module_vs_oracle(mode, variant, drop):
+@pytest.mark.parametrize("hw", [(5, 4), (14, 14), (3, 7)])
+def test_mona_module_vs_oracle(mode, variant, drop, hw):
+    """hw (5,4) and (14,14) take the row-strip / MFMA spatial kernel in bf16 (grid widths 4 and 14), (3,7) the per-pixel one;
+    fp32 always runs the per-pixel kernel."""
     from uia_hip import functional as UF
     from src.adapters import mona as M
     UF.set_compute_dtype(DT[mode])
     g = torch.Generator().manual_seed(11)
-    B, hw, D = 3, (5, 4), 128
+    B, D = 3, 128
     N = 1 + hw[0] * hw[1]
     mod = M._VARIANTS[variant](D, 64)
     randomize(mod, g)
@@ -75,7 +78,36 @@ def test_mona_module_vs_oracle(mode, variant, drop):
     for k, p in mod.named_parameters():
         # the 3-way softmax mixing weights turn O(1e3)-term sums into O(1) differences: give their tiny estimator 2x headroom in bf16
         tol = GTOL[mode] * (2.0 if (mode == "bf16" and "noise_estimator" in k) else 1.0)
+        if mode == "bf16" and hw == (14, 14) and variant == "hybrid":
+            # 196-pixel sums through the softmax mixing weights AND the frequency scale: the per-pixel kernel shows the same
+            # errors (gamma 0.058, norm.bias 0.069, estimator 0.081 against the fp32 oracle); exactness is held in fp32 mode
+            tol = 0.15 if "noise_estimator" in k else 0.1
         assert rel(p.grad, P[k].grad) < tol, k
+
+
+def test_gradient_operand_copies_survive_address_reuse():
+    """Two independent backward passes in one process with NO clear_t_copies() in between: the second pass's upstream
+    gradient lands on the address the first one used (caching allocator) and must not pick up the first pass's published
+    bf16 copy.  (Found with exactly this sequence: dx was off by 4.7x.)"""
+    from uia_hip import functional as UF
+    from src.adapters import mona as M
+    UF.set_compute_dtype(torch.bfloat16)
+    for variant in ("hybrid", "noise_aware", "hybrid"):
+        g = torch.Generator().manual_seed(11)
+        B, hw, D = 3, (14, 14), 128
+        N = 1 + hw[0] * hw[1]
+        mod = M._VARIANTS[variant](D, 64)
+        randomize(mod, g)
+        P = {k: v.detach().clone().requires_grad_(True) for k, v in mod.named_parameters()}
+        x = torch.randn(B, N, D, generator=g) * 1.5
+        dy = torch.randn(B, N, D, generator=g)
+        xr = x.clone().requires_grad_(True)
+        mona_ref.forward(xr, P, variant, hw, keep_mask=None, p_drop=0.1).backward(dy)
+        mod = mod.to(dev()).eval()
+        mod.keep_mask = None
+        xg = x.to(dev()).requires_grad_(True)
+        mod(xg.permute(1, 0, 2), hw).permute(1, 0, 2).backward(dy.to(dev()))
+        assert rel(xg.grad, xr.grad) < GTOL["bf16"], variant
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
