@@ -13,6 +13,7 @@ What differs underneath: encode_image / encode_text / loss / backward / optimise
 kernels and is not on this path: it raises.
 """
 import argparse
+import ast
 import logging
 import math
 import os
@@ -78,7 +79,7 @@ def get_args(argv=None):
 
 
 def prepare_model(args):
-    cfg = eval(args.model_config) if args.model_config else None
+    cfg = ast.literal_eval(args.model_config) if args.model_config else None
     state = torch.load(args.ckpt_path, map_location="cpu") if args.ckpt_path else None
     model = create_biomedclip(state_dict=state, config=cfg, seed=args.seed)
     tokenizer = SyntheticTokenizer(256 if cfg is None else cfg["text_cfg"]["max_position_embeddings"])

@@ -9,6 +9,7 @@ Added, non-breaking: --dtype, --synthetic / --data_pt, --ckpt_path, --model_conf
 torch.distributed.run.  The post-training zero-shot subprocess (:220-268) is outside the hot path and not launched.
 """
 import argparse
+import ast
 import logging
 import os
 import random
@@ -64,7 +65,7 @@ def get_args(argv=None):
 
 
 def prepare_model(args):
-    cfg = eval(args.model_config) if args.model_config else None
+    cfg = ast.literal_eval(args.model_config) if args.model_config else None
     state = torch.load(args.ckpt_path, map_location="cpu") if args.ckpt_path else None
     model = create_metaclip(state_dict=state, config=cfg, seed=args.seed)
     tc = (cfg or {}).get("text_cfg", {})

@@ -456,7 +456,8 @@ def test_metaclip_family_towers_vs_oracle(mode):
     from src.third_party.open_clip.model import create_metaclip
     UF.set_compute_dtype(DT[mode])
     g = torch.Generator().manual_seed(41)
-    model = create_metaclip(config=eval(METACLIP_TOY), seed=3)
+    import ast
+    model = create_metaclip(config=ast.literal_eval(METACLIP_TOY), seed=3)
     inject_mona_variant_to_open_clip(model, variant="noise_aware", bottleneck_dim=64)
     randomize(model, g, 0.08)
     model.eval()
