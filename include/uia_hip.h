@@ -135,6 +135,18 @@ int uia_mona_spatial_fwd(void* stream, int dtype, const uia_mona_spatial_desc* d
 int uia_mona_spatial_bwd(void* stream, int dtype, const uia_mona_spatial_desc* d);
 
 /* ---------------------------------------------------------------------------------------------
+ * Task heads of the feature-pyramid adapter (reference src/third_party/timm/clip_adapter.py:47-57, 118-160).
+ * uia_upsample_bilinear_fwd: nn.Upsample((H,W), mode="bilinear", align_corners=False) of a token-major map
+ *   src[(b*h*w + y*w + x)*ld + c] -> dst[b][c][Y][X] (NCHW fp32).  _bwd: dsrc (token-major, overwritten) from ddst (NCHW),
+ *   as a gather (fixed summation order).  The reference's Conv1x1 after the upsample is applied BEFORE it by the caller
+ *   (it commutes with the interpolation), so C here is the number of classes.
+ * uia_segment_mean_fwd: out[b][c] = mean_i x[(b*n + i)*ld + c]  (AdaptiveAvgPool2d(1) + Flatten); _bwd broadcasts dout/n. */
+int uia_upsample_bilinear_fwd(void* stream, int B, int C, int h, int w, int H, int W, const float* src, int64_t ld, float* dst);
+int uia_upsample_bilinear_bwd(void* stream, int B, int C, int h, int w, int H, int W, const float* ddst, float* dsrc, int64_t ld);
+int uia_segment_mean_fwd(void* stream, int B, int n, int C, const float* x, int64_t ld, float* out);
+int uia_segment_mean_bwd(void* stream, int B, int n, int C, const float* dout, float* dx, int64_t ld);
+
+/* ---------------------------------------------------------------------------------------------
  * Layout helpers around the GEMMs. */
 int uia_cast(void* stream, int dtype, size_t n, const float* src, void* dst, float scale);          /* dst = T(scale*src) */
 int uia_transpose_cast(void* stream, int dtype, int rows, int cols, const float* src, void* dst);   /* dst[c][r] = T(src[r][c]) */
@@ -164,7 +176,8 @@ int uia_col2im3x3(void* stream, int dtype, int B, int h, int w, int C, int ntok,
 /* two stacked kernel=stride transposed convolutions leave [B*h*w*k1*k1, >=k2*k2]; unshuffle writes logits [B, h*k1*k2, w*k1*k2] (+bias). */
 int uia_unshuffle(void* stream, int dtype, int B, int h, int w, int k1, int k2, const void* tmp, int64_t ld, float bias, float* out);
 int uia_shuffle(void* stream, int dtype, int B, int h, int w, int k1, int k2, const float* dout, void* dtmp, int64_t ld);
-int uia_act_bwd(void* stream, int dtype, size_t n, const void* dy, const void* y, int act, void* out);   /* ReLU from the post-activation */
+/* out = dy * act'(.) where y is the stored POST-activation for ReLU and the stored PRE-activation for GELU / QuickGELU */
+int uia_act_bwd(void* stream, int dtype, size_t n, const void* dy, const void* y, int act, void* out);
 
 /* ---------------------------------------------------------------------------------------------
  * Symmetric InfoNCE (src/losses/losses.py:23-47), forward + gradients of both feature matrices, fp32.

@@ -239,7 +239,6 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void attn_bwd_bf16_kernel(const Uia
             f32x4 dq = f32x4{0.f, 0.f, 0.f, 0.f};
             const int ch = 2 * dt + (pp >> 1);
             const int c8 = 4 * hq + pp;
-#pragma unroll 2
             for (int kbk = 0; kbk < NP; ++kbk) {
                 const char* klo = Ks + (32 * kbk + nrow) * 128 + ((ch ^ nsw_lo) << 4) + 8 * (pp & 1);
                 const char* khi = Ks + (32 * kbk + nrow + 4) * 128 + ((ch ^ nsw_hi) << 4) + 8 * (pp & 1);

@@ -99,4 +99,17 @@ int uia_act_bwd(void* stream, int dtype, size_t n, const void* dy, const void* y
 
 size_t uia_mona_spatial_workspace_bytes(int B) { return uia_mona_spatial_ws_floats(B) * sizeof(float); }
 
+int uia_upsample_bilinear_fwd(void* stream, int B, int C, int h, int w, int H, int W, const float* src, int64_t ld, float* dst) {
+    return uia_upsample_bilinear_launch((hipStream_t)stream, false, B, C, h, w, H, W, src, dst, (long)ld);
+}
+int uia_upsample_bilinear_bwd(void* stream, int B, int C, int h, int w, int H, int W, const float* ddst, float* dsrc, int64_t ld) {
+    return uia_upsample_bilinear_launch((hipStream_t)stream, true, B, C, h, w, H, W, ddst, dsrc, (long)ld);
+}
+int uia_segment_mean_fwd(void* stream, int B, int n, int C, const float* x, int64_t ld, float* out) {
+    return uia_segment_mean_launch((hipStream_t)stream, false, B, n, C, x, out, (long)ld);
+}
+int uia_segment_mean_bwd(void* stream, int B, int n, int C, const float* dout, float* dx, int64_t ld) {
+    return uia_segment_mean_launch((hipStream_t)stream, true, B, n, C, dout, dx, (long)ld);
+}
+
 }  // extern "C"

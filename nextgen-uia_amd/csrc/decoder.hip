@@ -11,7 +11,7 @@
 //   film_{fwd,bwd}         y = mul[b]·x + add[b]                         (CLIPSegDecoder.forward, conditional_layer)
 //   im2col3x3 / col2im3x3  token-major [B,1+hw,C] ↔ [B·hw, 9C] patches of the 3×3 convolution (zero padding 1)
 //   unshuffle / shuffle    [B·hw·k², k²(+pad)] GEMM output of the two k=4,s=4 transposed convolutions ↔ [B, hk², wk²]
-//   act_bwd                dpre = dy · act′ from the stored post-activation (ReLU)
+//   act_bwd                dpre = dy · act′ from the stored post-activation (ReLU) or pre-activation (GELU, QuickGELU)
 #include "uia_common.h"
 #include "uia_kernels.h"
 
@@ -339,8 +339,12 @@ __global__ void shuffle_kernel(int B, int h, int w, int k1, int k2, const float*
 template <typename T>
 __global__ void act_bwd_kernel(size_t n, const T* __restrict__ dy, const T* __restrict__ y, int act, T* __restrict__ out) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const float yv = to_f32(y[i]);
-        out[i] = from_f32<T>(act == UIA_ACT_RELU ? (yv > 0.f ? to_f32(dy[i]) : 0.f) : to_f32(dy[i]));
+        const float yv = to_f32(y[i]), g = to_f32(dy[i]);
+        float r = g;
+        if (act == UIA_ACT_RELU) r = yv > 0.f ? g : 0.f;                 // y = post-activation
+        else if (act == UIA_ACT_GELU) r = g * dgelu_erf(yv);              // y = pre-activation
+        else if (act == UIA_ACT_QUICKGELU) r = g * dquick_gelu(yv);       // y = pre-activation
+        out[i] = from_f32<T>(r);
     }
 }
 
@@ -444,7 +448,7 @@ int uia_shuffle_launch(hipStream_t stream, int dtype, int B, int h, int w, int k
 }
 
 int uia_act_bwd_launch(hipStream_t stream, int dtype, size_t n, const void* dy, const void* y, int act, void* out) {
-    UIA_CHECK_ARG(n > 0 && dy && y && out && (act == UIA_ACT_RELU || act == UIA_ACT_NONE), "uia_act_bwd: bad arguments (only ReLU has a post-activation backward)");
+    UIA_CHECK_ARG(n > 0 && dy && y && out && act >= UIA_ACT_NONE && act <= UIA_ACT_RELU, "uia_act_bwd: bad arguments");
     const int g = grid_for(n, 256);
     if (dtype == UIA_BF16) hipLaunchKernelGGL(act_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, stream, n, (const bf16_t*)dy, (const bf16_t*)y, act, (bf16_t*)out);
     else if (dtype == UIA_F32) hipLaunchKernelGGL(act_bwd_kernel<float>, dim3(g), dim3(256), 0, stream, n, (const float*)dy, (const float*)y, act, (float*)out);

@@ -49,3 +49,5 @@ int uia_unshuffle_launch(hipStream_t stream, int dtype, int B, int h, int w, int
 int uia_shuffle_launch(hipStream_t stream, int dtype, int B, int h, int w, int k1, int k2, const float* dout, void* dtmp, long ld);
 int uia_act_bwd_launch(hipStream_t stream, int dtype, size_t n, const void* dy, const void* y, int act, void* out);
 size_t uia_mona_spatial_ws_floats(int B);
+int uia_upsample_bilinear_launch(hipStream_t stream, bool bwd, int B, int C, int h, int w, int H, int W, const float* in, float* out, long ld);
+int uia_segment_mean_launch(hipStream_t stream, bool bwd, int B, int n, int C, const float* in, float* out, long ld);

@@ -583,11 +583,17 @@ class LinearTrainFn(torch.autograd.Function):
         assert not (act and want32), "activation + fp32 output is not used by any caller"
         y = torch.empty(M, N, device=x.device, dtype=torch.float32 if want32 else dt)
         w_t = WEIGHTS.get(weight, dt)
+        stash = x.new_empty(0)
         if want32:
             ops.gemm(x, w_t, bias=bias, resid=resid32, out32=y)
+        elif act in ("gelu", "quick_gelu"):                     # smooth activations need the pre-activation in the backward
+            stash = torch.empty_like(y)
+            ops.gemm(x, w_t, bias=bias, act=act, aux_out=stash, out_t=y)
         else:
             ops.gemm(x, w_t, bias=bias, act=act, out_t=y)
-        ctx.save_for_backward(x, weight, y if act else x.new_empty(0))
+            if act:
+                stash = y                                       # ReLU: the post-activation is enough
+        ctx.save_for_backward(x, weight, stash)
         ctx.meta = (act, bias is not None, resid32 is not None)
         return y
 
@@ -713,3 +719,63 @@ class UnshuffleFn(torch.autograd.Function):
         dtmp = torch.empty(shape, device=dout.device, dtype=dt)
         ops.shuffle(dout.contiguous().float(), dtmp, B, h, w, k1, k2)
         return dtmp, None, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------ FPN task heads
+class UpsampleBilinearFn(torch.autograd.Function):
+    """token-major fp32 [B*h*w, C] → [B, C, H, W] (nn.Upsample(size, mode="bilinear", align_corners=False))."""
+
+    @staticmethod
+    def forward(ctx, tok, B, h, w, H, W):
+        tok = tok.contiguous()
+        C = tok.shape[1]
+        out = torch.empty(B, C, H, W, device=tok.device, dtype=torch.float32)
+        ops.upsample_bilinear(tok, B, C, h, w, H, W, out)
+        ctx.meta = (B, C, h, w, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, C, h, w, H, W = ctx.meta
+        dtok = torch.empty(B * h * w, C, device=dout.device, dtype=torch.float32)
+        ops.upsample_bilinear(dout.contiguous().float(), B, C, h, w, H, W, dtok, backward=True)
+        return dtok, None, None, None, None, None
+
+
+class SegmentMeanFn(torch.autograd.Function):
+    """fp32 [B*n, C] → [B, C]: mean over each image's n tokens (AdaptiveAvgPool2d(1) + Flatten)."""
+
+    @staticmethod
+    def forward(ctx, x, B, n):
+        x = x.contiguous()
+        out = torch.empty(B, x.shape[1], device=x.device, dtype=torch.float32)
+        ops.segment_mean(x, B, n, out)
+        ctx.meta = (B, n, x.shape[1])
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, n, C = ctx.meta
+        dx = torch.empty(B * n, C, device=dout.device, dtype=torch.float32)
+        ops.segment_mean(dout.contiguous().float(), B, n, dx, backward=True)
+        return dx, None, None
+
+
+class DropoutFn(torch.autograd.Function):
+    """Inverted dropout with the library's counter-hash mask (regenerated, not stored, in the backward)."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        ops.dropout(x, y, p, seed)
+        ctx.meta = (p, seed)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, seed = ctx.meta
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        ops.dropout(dy, dx, p, seed)
+        return dx, None, None

@@ -362,3 +362,28 @@ def shuffle(dout, dtmp, B, h, w, k1, k2):
 
 def act_bwd(dy, y, act, out):
     check(lib().uia_act_bwd(_stream(), _code(dy.dtype), dy.numel(), _p(dy), _p(y), _ACT[act], _p(out)), "uia_act_bwd")
+
+
+# ------------------------------------------------------------------------------------------- FPN task heads
+def upsample_bilinear(src, B, C, h, w, H, W, dst, backward=False):
+    """forward: src token-major fp32 [B*h*w, ld>=C] -> dst [B,C,H,W]; backward: src = d(dst) [B,C,H,W] -> dst token-major (overwritten)."""
+    tok = dst if backward else src
+    assert tok.dtype == torch.float32 and tok.dim() == 2 and tok.stride(1) == 1 and tok.shape[0] == B * h * w and tok.shape[1] >= C
+    img = src if backward else dst
+    assert img.dtype == torch.float32 and img.is_contiguous() and tuple(img.shape) == (B, C, H, W)
+    if backward:
+        check(lib().uia_upsample_bilinear_bwd(_stream(), B, C, h, w, H, W, _p(src), _p(dst), dst.stride(0)), "uia_upsample_bilinear_bwd")
+    else:
+        check(lib().uia_upsample_bilinear_fwd(_stream(), B, C, h, w, H, W, _p(src), src.stride(0), _p(dst)), "uia_upsample_bilinear_fwd")
+
+
+def segment_mean(x, B, n, out, backward=False):
+    """forward: x fp32 [B*n, C] -> out [B, C] (mean over each image's n tokens); backward: x = d(out) [B, C] -> out [B*n, C]."""
+    tok = out if backward else x
+    vec = x if backward else out
+    Cc = vec.shape[1]
+    assert tok.dtype == vec.dtype == torch.float32 and tok.stride(1) == 1 and vec.is_contiguous() and tok.shape[0] == B * n and tok.shape[1] == Cc
+    if backward:
+        check(lib().uia_segment_mean_bwd(_stream(), B, n, Cc, _p(x), _p(out), out.stride(0)), "uia_segment_mean_bwd")
+    else:
+        check(lib().uia_segment_mean_fwd(_stream(), B, n, Cc, _p(x), x.stride(0), _p(out)), "uia_segment_mean_fwd")

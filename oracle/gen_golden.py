@@ -276,6 +276,62 @@ def gen_clipseg(model_mod):
     save("clipseg_adapter", **arrays)
 
 
+def gen_fpn():
+    """TimmCLIPAdapter (seg and cls heads) of the imported reference over a torch trunk with formula-filled weights."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from oracle import fpn_ref, vit_ref
+    ca = load_by_path("ref_timm_clip_adapter", "src/third_party/timm/clip_adapter.py")
+    import torch.nn as nn
+    P = fpn_ref.toy_trunk_params()
+    pre = "visual.trunk."
+
+    class Block(nn.Module):                     # timm Block arithmetic via the (separately pinned) functional restatement
+        def __init__(self, i):
+            super().__init__()
+            self.i = i
+
+        def forward(self, x):
+            return vit_ref.timm_block(x, vit_ref._sub(P, f"{pre}blocks.{self.i}."), heads=12)
+
+    class PatchEmbed(nn.Module):
+        def forward(self, x):
+            W = P[pre + "patch_embed.proj.weight"]
+            return torch.nn.functional.conv2d(x, W, P[pre + "patch_embed.proj.bias"], stride=W.shape[-1]).flatten(2).transpose(1, 2)
+
+    trunk = nn.Module()
+    trunk.patch_embed, trunk.pos_drop, trunk.norm = PatchEmbed(), nn.Identity(), nn.LayerNorm(768, eps=1e-6)
+    trunk.cls_token, trunk.pos_embed = nn.Parameter(P[pre + "cls_token"].clone()), nn.Parameter(P[pre + "pos_embed"].clone())
+    trunk.blocks = nn.ModuleList([Block(i) for i in range(3)])
+    with torch.no_grad():
+        trunk.norm.weight.copy_(P[pre + "norm.weight"]); trunk.norm.bias.copy_(P[pre + "norm.bias"])
+    clip = nn.Module(); clip.visual = nn.Module(); clip.visual.trunk = trunk
+    images = torch.from_numpy(np.random.RandomState(11).uniform(0, 1, (3, 3, 32, 32)).astype(np.float32))
+    out = {}
+    for task in ("seg", "cls"):
+        ad = ca.TimmCLIPAdapter(clip, extract_layers=[0, 1, 2], reduce_dim=64, num_classes=2, img_size=32, patch_size=8, task=task)
+        rs = np.random.RandomState(7)                                    # seeded Gaussian adapter weights (stored in the fixture)
+        with torch.no_grad():
+            for k, p_ in torch.nn.ModuleList([ad.reduces, ad.blocks, ad.seg_head, ad.cls_head]).named_parameters():
+                p_.copy_(torch.from_numpy((rs.standard_normal(p_.numel()) * 0.08).astype(np.float32).reshape(tuple(p_.shape))))
+            for blk in ad.blocks:                                        # keep LayerNorm scales near one
+                blk[0].weight.add_(1.0)
+        ad.eval()
+        ad.freeze_clip_backbone()
+        A = {k: v.detach().clone() for k, v in ad.state_dict().items() if not k.startswith("clip_model.")}
+        y = ad(images)
+        dy = torch.from_numpy(np.random.RandomState(13).standard_normal(tuple(y.shape)).astype(np.float32))
+        (y * dy).sum().backward()
+        yo = fpn_ref.adapter_forward(images, P, A, task=task)
+        assert float((yo - y).abs().max()) < 1e-4 * float(y.abs().max()), "oracle restatement deviates from the reference"
+        if task == "seg":
+            out.update({f"A.{k}": v for k, v in A.items()})
+        out[f"{task}.y"] = y.detach(); out[f"{task}.dy"] = dy
+        for k, p in ad.named_parameters():
+            if p.requires_grad and p.grad is not None and not k.startswith("clip_model."):
+                out[f"{task}.g.{k}"] = p.grad.detach()
+    save("fpn_adapter", images=images, **out)
+
+
 def main():
     sys.path.insert(0, REF)
     mona = load_by_path("ref_mona", "src/adapters/mona.py")
@@ -287,6 +343,7 @@ def main():
     gen_infonce(losses)
     gen_openai_clip(model_mod, mona, lora)
     gen_hf_crosschecks()
+    gen_fpn()
     gen_clipseg(model_mod)
 
 

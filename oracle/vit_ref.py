@@ -71,7 +71,7 @@ def timm_vit_tokens(images, P, prefix="visual.trunk."):
     return torch.cat([cls, x], dim=1) + P[prefix + "pos_embed"]
 
 
-def timm_vit_forward(images, P, heads=12, mona=None, lora=None, prefix="visual.trunk.", return_tokens=False, eps=1e-6, act="gelu"):
+def timm_vit_forward(images, P, heads=12, mona=None, lora=None, prefix="visual.trunk.", return_tokens=False, eps=1e-6, act="gelu", taps=None):
     """images [B,3,H,W] -> features [B, embed].  P: flat state dict with open_clip key names.
 
     mona: None or dict(variant=..., hw=(h,w), keep_masks=None|list, p_drop=0.1); Mona parameters
@@ -88,6 +88,8 @@ def timm_vit_forward(images, P, heads=12, mona=None, lora=None, prefix="visual.t
         if mona is not None and mp:
             km = None if mona.get("keep_masks") is None else mona["keep_masks"][i]
             x = mona_ref.forward(x, mp, mona["variant"], mona["hw"], keep_mask=km, p_drop=mona.get("p_drop", 0.1))
+        if taps is not None and i in taps["layers"]:
+            taps["acts"].append(x)          # tokens after block i (timm/clip_adapter.py:104-107)
     if return_tokens:
         return x
     D = x.shape[-1]

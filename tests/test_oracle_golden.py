@@ -228,3 +228,22 @@ def test_clipseg_adapter_matches_reference(golden):
     assert sorted("g." + k for k in names) == sorted(k for k in g if k.startswith("g."))
     for k in names:
         close(leaves[k].grad, g["g." + k], 2e-3, 1e-6)     # fp32 summation order differs from HF's eager attention / conv kernels
+
+
+@pytest.mark.parametrize("task", ["seg", "cls"])
+def test_fpn_adapter_matches_reference(golden, task):
+    """reference TimmCLIPAdapter.forward (timm/clip_adapter.py:118-160), seg and cls heads, over a torch trunk with
+    formula-filled weights that the generator and this test rebuild identically (oracle/fpn_ref.py::toy_trunk_params):
+    outputs and every adapter-parameter gradient."""
+    from oracle import fpn_ref
+    g = golden("fpn_adapter")
+    P = fpn_ref.toy_trunk_params()
+    A = {k[2:]: v.clone().requires_grad_(True) for k, v in g.items() if k.startswith("A.")}
+    out = fpn_ref.adapter_forward(g["images"], P, A, task=task)
+    assert tuple(out.shape) == ((3, 2, 32, 32) if task == "seg" else (3, 2))
+    (out * g[f"{task}.dy"]).sum().backward()
+    close(out, g[f"{task}.y"], 1e-4, 1e-5)
+    gnames = [k[len(task) + 3:] for k in g if k.startswith(f"{task}.g.")]
+    assert gnames and all(n.startswith(("reduces.", "blocks.", "seg_head." if task == "seg" else "cls_head.")) for n in gnames)
+    for n in gnames:
+        close(A[n].grad, g[f"{task}.g.{n}"], 2e-3, 1e-6)
