@@ -13,7 +13,6 @@ What differs underneath: encode_image / encode_text / loss / backward / optimise
 kernels and is not on this path: it raises.
 """
 import argparse
-import ast
 import logging
 import math
 import os
@@ -30,7 +29,7 @@ from src.adapters import inject_lora_to_biomedclip, inject_mona_variant_to_open_
 from src.datasets import finetune as dataset_finetune
 from src.losses import InfoNCELoss
 from src.third_party.biomedclip.model import SyntheticTokenizer, create_biomedclip
-from src.utils.tools import model_summary, setup_logging
+from src.utils.tools import model_summary, parse_config, setup_logging
 from uia_hip import functional as UF
 from uia_hip.engine import FlatAdapterOptimizer, cosine_lr, init_data_parallel
 
@@ -79,7 +78,7 @@ def get_args(argv=None):
 
 
 def prepare_model(args):
-    cfg = ast.literal_eval(args.model_config) if args.model_config else None
+    cfg = parse_config(args.model_config) if args.model_config else None
     state = torch.load(args.ckpt_path, map_location="cpu") if args.ckpt_path else None
     model = create_biomedclip(state_dict=state, config=cfg, seed=args.seed)
     tokenizer = SyntheticTokenizer(256 if cfg is None else cfg["text_cfg"]["max_position_embeddings"])

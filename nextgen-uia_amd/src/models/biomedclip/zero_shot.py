@@ -10,7 +10,6 @@ with a few torch ops.  The prompt ensembles are this build's own short lists (th
 are data of that project); pass --prompts_json to use others.  Data: --synthetic or --data_pt {"images","labels"}.
 """
 import argparse
-import ast
 import json
 import logging
 import os
@@ -23,7 +22,7 @@ import torch
 
 from src.adapters import inject_lora_to_biomedclip, inject_mona_variant_to_open_clip
 from src.third_party.biomedclip.model import SyntheticTokenizer, create_biomedclip
-from src.utils.tools import setup_logging
+from src.utils.tools import parse_config, setup_logging
 from uia_hip import functional as UF
 
 LESION_TYPES = ("benign", "malignant")
@@ -80,7 +79,7 @@ def load_adapter_by_name(model, path, wrapper_key):
 
 
 def prepare_model(args):
-    cfg = ast.literal_eval(args.model_config) if args.model_config else None
+    cfg = parse_config(args.model_config) if args.model_config else None
     state = torch.load(args.ckpt_path, map_location="cpu") if args.ckpt_path else None
     model = create_biomedclip(state_dict=state, config=cfg, seed=args.seed)
     tokenizer = SyntheticTokenizer(256 if cfg is None else cfg["text_cfg"]["max_position_embeddings"])

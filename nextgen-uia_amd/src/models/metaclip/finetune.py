@@ -9,7 +9,6 @@ Added, non-breaking: --dtype, --synthetic / --data_pt, --ckpt_path, --model_conf
 torch.distributed.run.  The post-training zero-shot subprocess (:220-268) is outside the hot path and not launched.
 """
 import argparse
-import ast
 import logging
 import os
 import random
@@ -25,7 +24,7 @@ from src.adapters import inject_mona_variant_to_open_clip
 from src.datasets import finetune as dataset_finetune
 from src.losses import InfoNCELoss
 from src.third_party.open_clip.model import SyntheticClipTokenizer, create_metaclip
-from src.utils.tools import model_summary, setup_logging
+from src.utils.tools import model_summary, parse_config, setup_logging
 from uia_hip import functional as UF
 from uia_hip.engine import FlatAdapterOptimizer, cosine_lr, init_data_parallel
 
@@ -65,7 +64,7 @@ def get_args(argv=None):
 
 
 def prepare_model(args):
-    cfg = ast.literal_eval(args.model_config) if args.model_config else None
+    cfg = parse_config(args.model_config) if args.model_config else None
     state = torch.load(args.ckpt_path, map_location="cpu") if args.ckpt_path else None
     model = create_metaclip(state_dict=state, config=cfg, seed=args.seed)
     tc = (cfg or {}).get("text_cfg", {})

@@ -161,3 +161,13 @@ def test_finetune_cli_matches_reference_flags():
     for k, v in ref.items():
         assert getattr(a, k) == v, k
     assert get_args(["--mona_variant", "fractional"]).mona_variant == "fractional"     # accepted here, rejected by the injector
+
+
+def test_model_config_parser_accepts_dict_calls_and_nothing_executable():
+    from src.utils.tools import parse_config
+    cfg = parse_config("dict(embed_dim=128, vision_cfg=dict(img_size=32, act='quick_gelu', pre_norm=True), layers=[1, 2], t=(3, 4.5))")
+    assert cfg == {"embed_dim": 128, "vision_cfg": {"img_size": 32, "act": "quick_gelu", "pre_norm": True}, "layers": [1, 2], "t": (3, 4.5)}
+    assert parse_config("{'a': 1}") == {"a": 1}
+    for bad in ("__import__('os').system('true')", "dict(a=open('x'))", "dict(**{'a': 1})", "[x for x in (1,)]"):
+        with pytest.raises((ValueError, TypeError, SyntaxError)):
+            parse_config(bad)

@@ -456,8 +456,8 @@ def test_metaclip_family_towers_vs_oracle(mode):
     from src.third_party.open_clip.model import create_metaclip
     UF.set_compute_dtype(DT[mode])
     g = torch.Generator().manual_seed(41)
-    import ast
-    model = create_metaclip(config=ast.literal_eval(METACLIP_TOY), seed=3)
+    from src.utils.tools import parse_config
+    model = create_metaclip(config=parse_config(METACLIP_TOY), seed=3)
     inject_mona_variant_to_open_clip(model, variant="noise_aware", bottleneck_dim=64)
     randomize(model, g, 0.08)
     model.eval()
@@ -644,3 +644,25 @@ def test_fpn_adapter_vs_oracle(golden, mode, task, with_mona):
         a, b = torch.cat(mona_got), torch.cat(mona_want)
         assert float(torch.dot(a, b) / (a.norm() * b.norm())) > 0.99 and float((a - b).norm() / b.norm()) < 0.15
     assert seen >= 20
+
+
+def test_biomedclip_segmentation_entry_point(tmp_path, monkeypatch):
+    """src.models.biomedclip.segmentation (reference CLI): Mona checkpoint loaded by name, FPN seg adapter trained with DiceCE,
+    validation Dice, and the reference's checkpoint dict layout."""
+    from src.models.biomedclip import finetune, segmentation
+    monkeypatch.chdir(tmp_path)
+    cfg = ("dict(embed_dim=128, vision_cfg=dict(img_size=32, patch_size=8, embed_dim=128, depth=3, num_heads=2), "
+           "text_cfg=dict(vocab_size=30000, hidden_size=128, num_hidden_layers=1, num_attention_heads=2, intermediate_size=256, max_position_embeddings=64))")
+    finetune.main(["--method", "mona", "--mona_variant", "hybrid", "--synthetic", "--synthetic_train", "32", "--synthetic_val", "16", "--img_size", "32",
+                   "--batch_size", "16", "--accumulation_steps", "1", "--epochs", "1", "--dtype", "bf16", "--exp", "ft", "--model_config", cfg])
+    out = segmentation.main(["--synthetic", "--synthetic_train", "32", "--synthetic_val", "16", "--img_size", "32", "--patch_size", "8", "--batch_size", "8",
+                             "--epochs", "3", "--val_every", "1", "--lr", "2e-3", "--reduce_dim", "64", "--extract_layers", "0,1,2", "--dtype", "bf16",
+                             "--mona_weights", str(tmp_path / "runs" / "ft" / "best_model.pth"), "--exp", "seg", "--model_config", cfg])
+    assert out["iters"] == 3 * 4 and math.isfinite(out["last_loss"]) and 0.0 <= out["best_val_dice"] <= 1.0
+    saved = tmp_path / "runs" / "seg" / "LN-INT" / "train" / "best_model.pth"
+    assert saved.exists() == (out["best_val_dice"] > 0.0)                  # reference: saved only when the validation Dice improves on 0
+    args = segmentation.get_args(["--synthetic", "--img_size", "32", "--patch_size", "8", "--reduce_dim", "64", "--extract_layers", "0,1,2",
+                                  "--mona_weights", str(tmp_path / "runs" / "ft" / "best_model.pth"), "--model_config", cfg])
+    ck = segmentation.checkpoint_dict(segmentation.prepare_model(args))
+    assert set(ck) == {"reduces", "blocks", "seg_head", "mona"} and "1.weight" in ck["seg_head"] and "0.weight" in ck["reduces"]
+    assert ck["mona"] and all("mona" in k for k in ck["mona"])
