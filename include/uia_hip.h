@@ -145,6 +145,13 @@ int uia_upsample_bilinear_fwd(void* stream, int B, int C, int h, int w, int H, i
 int uia_upsample_bilinear_bwd(void* stream, int B, int C, int h, int w, int H, int W, const float* ddst, float* dsrc, int64_t ld);
 int uia_segment_mean_fwd(void* stream, int B, int n, int C, const float* x, int64_t ld, float* out);
 int uia_segment_mean_bwd(void* stream, int B, int n, int C, const float* dout, float* dx, int64_t ld);
+/* MONAI DiceCELoss(to_onehot_y=True, softmax=True, squared_pred=True, smooth_nr, smooth_dr) of the segmentation entry points
+ * (reference src/models/clipseg/segmentation.py:84, biomedclip/segmentation.py:75): loss (one float) and d loss / d logits in
+ * one call.  logits, dlogits fp32 [B,C,H*W] (NCHW), label fp32 [B,H*W] holding class indices, 2 <= C <= 8;
+ * ws: uia_dicece_workspace_bytes(B) of scratch. */
+size_t uia_dicece_workspace_bytes(int B);
+int uia_dicece_fwd_bwd(void* stream, int B, int C, int HW, const float* logits, const float* label, float smooth_nr, float smooth_dr,
+                       float* ws, float* loss, float* dlogits);
 
 /* ---------------------------------------------------------------------------------------------
  * Layout helpers around the GEMMs. */

@@ -112,4 +112,10 @@ int uia_segment_mean_bwd(void* stream, int B, int n, int C, const float* dout, f
     return uia_segment_mean_launch((hipStream_t)stream, true, B, n, C, dout, dx, (long)ld);
 }
 
+size_t uia_dicece_workspace_bytes(int B) { return uia_dicece_ws_floats(B) * sizeof(float); }
+int uia_dicece_fwd_bwd(void* stream, int B, int C, int HW, const float* logits, const float* label, float smooth_nr, float smooth_dr,
+                       float* ws, float* loss, float* dlogits) {
+    return uia_dicece_launch((hipStream_t)stream, B, C, HW, logits, label, smooth_nr, smooth_dr, ws, loss, dlogits);
+}
+
 }  // extern "C"

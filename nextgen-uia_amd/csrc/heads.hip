@@ -90,6 +90,109 @@ __global__ __launch_bounds__(256) void segment_bcast_kernel(int B, int n, int C,
     }
 }
 
+// ------------------------------------------------------------------------------------------ DiceCE
+// MONAI DiceCELoss(to_onehot_y=True, softmax=True, squared_pred=True, smooth_nr, smooth_dr) as the segmentation entry points use
+// it (reference src/models/clipseg/segmentation.py:84, biomedclip/segmentation.py:75):
+//   p = softmax_c(z);  dice[b,c] = 1 − (2·Σ p·t + nr) / (Σ p² + Σ t + dr);  loss = mean_{b,c} dice + mean_{b,pix}(−log p[label])
+// Pass 1 (one workgroup per image, fixed-order tree reduction): I, P2, T per class and the CE sum → ws[b][3C+1].
+// Pass 2: dz_k = p_k·(g_k − Σ_c g_c p_c) + (p_k − t_k)/(B·HW),  g_c = (2/(B·C))·((2I_c+nr)·p_c/D_c² − t_c/D_c);  block 0 also
+// reduces the loss.  C ≤ 8.
+constexpr int DICE_MAXC = 8;
+
+__device__ __forceinline__ void softmax_c(const float* __restrict__ z, size_t stride, int C, float (&p)[DICE_MAXC], float& lse) {
+    float m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < DICE_MAXC; ++c) if (c < C) { p[c] = z[c * stride]; m = fmaxf(m, p[c]); }
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < DICE_MAXC; ++c) if (c < C) { p[c] = __expf(p[c] - m); s += p[c]; }
+    const float inv = 1.0f / s;
+#pragma unroll
+    for (int c = 0; c < DICE_MAXC; ++c) if (c < C) p[c] *= inv;
+    lse = m + __logf(s);
+}
+
+__global__ __launch_bounds__(1024) void dicece_sums_kernel(int C, int HW, const float* __restrict__ logits, const float* __restrict__ label,
+                                                           float* __restrict__ ws) {
+    __shared__ float red[16][3 * DICE_MAXC + 1];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* z = logits + (size_t)b * C * HW;
+    const float* y = label + (size_t)b * HW;
+    float acc[3 * DICE_MAXC + 1];
+#pragma unroll
+    for (int i = 0; i < 3 * DICE_MAXC + 1; ++i) acc[i] = 0.f;
+    for (int px = tid; px < HW; px += 1024) {
+        float p[DICE_MAXC], lse;
+        softmax_c(z + px, (size_t)HW, C, p, lse);
+        const int cls = (int)y[px];
+#pragma unroll
+        for (int c = 0; c < DICE_MAXC; ++c)
+            if (c < C) {
+                const float t = c == cls ? 1.f : 0.f;
+                acc[c] += p[c] * t;
+                acc[DICE_MAXC + c] += p[c] * p[c];
+                acc[2 * DICE_MAXC + c] += t;
+                if (c == cls) acc[3 * DICE_MAXC] += lse - z[(size_t)c * HW + px];
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < 3 * DICE_MAXC + 1; ++i) {
+        const float v = wave_sum(acc[i]);
+        if (lane == 0) red[wave][i] = v;
+    }
+    __syncthreads();
+    if (tid < 3 * DICE_MAXC + 1) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) v += red[w][tid];
+        ws[(size_t)b * (3 * DICE_MAXC + 1) + tid] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void dicece_grad_kernel(int B, int C, int HW, const float* __restrict__ logits, const float* __restrict__ label,
+                                                          const float* __restrict__ ws, float nr, float dr, float* __restrict__ loss,
+                                                          float* __restrict__ dlogits) {
+    const int b = blockIdx.y;
+    const float* w = ws + (size_t)b * (3 * DICE_MAXC + 1);
+    float a1[DICE_MAXC], a2[DICE_MAXC];                 // g_c = a1_c·p_c − a2_c·t_c
+    const float k = 2.0f / ((float)B * C);
+#pragma unroll
+    for (int c = 0; c < DICE_MAXC; ++c)
+        if (c < C) {
+            const float D = w[DICE_MAXC + c] + w[2 * DICE_MAXC + c] + dr;
+            a1[c] = k * (2.f * w[c] + nr) / (D * D);
+            a2[c] = k / D;
+        }
+    const float ce_scale = 1.0f / ((float)B * HW);
+    const float* z = logits + (size_t)b * C * HW;
+    float* dz = dlogits + (size_t)b * C * HW;
+    for (int px = blockIdx.x * 256 + threadIdx.x; px < HW; px += gridDim.x * 256) {
+        float p[DICE_MAXC], lse;
+        softmax_c(z + px, (size_t)HW, C, p, lse);
+        const int cls = (int)label[(size_t)b * HW + px];
+        float gp = 0.f;
+        float g[DICE_MAXC];
+#pragma unroll
+        for (int c = 0; c < DICE_MAXC; ++c)
+            if (c < C) {
+                g[c] = a1[c] * p[c] - (c == cls ? a2[c] : 0.f);
+                gp = fmaf(g[c], p[c], gp);
+            }
+#pragma unroll
+        for (int c = 0; c < DICE_MAXC; ++c)
+            if (c < C) dz[(size_t)c * HW + px] = p[c] * (g[c] - gp) + ce_scale * (p[c] - (c == cls ? 1.f : 0.f));
+    }
+    if (b == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+        float dice = 0.f, ce = 0.f;
+        for (int i = 0; i < B; ++i) {
+            const float* wi = ws + (size_t)i * (3 * DICE_MAXC + 1);
+            for (int c = 0; c < C; ++c) dice += 1.0f - (2.f * wi[c] + nr) / (wi[DICE_MAXC + c] + wi[2 * DICE_MAXC + c] + dr);
+            ce += wi[3 * DICE_MAXC];
+        }
+        *loss = dice / ((float)B * C) + ce * ce_scale;
+    }
+}
+
 int grid_for(size_t n) {
     size_t g = (n + 255) / 256;
     return (int)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
@@ -111,6 +214,20 @@ int uia_segment_mean_launch(hipStream_t stream, bool bwd, int B, int n, int C, c
     UIA_CHECK_ARG(in && out, "uia_segment_mean: null tensor");
     if (!bwd) hipLaunchKernelGGL(segment_sum_kernel, dim3((C + 255) / 256, B), dim3(256), 0, stream, B, n, C, in, ld, 1.0f / n, out);
     else hipLaunchKernelGGL(segment_bcast_kernel, dim3(grid_for((size_t)B * n * C)), dim3(256), 0, stream, B, n, C, in, 1.0f / n, out, ld);
+    UIA_CHECK_LAUNCH();
+    return 0;
+}
+
+size_t uia_dicece_ws_floats(int B) { return (size_t)B * (3 * DICE_MAXC + 1); }
+
+int uia_dicece_launch(hipStream_t stream, int B, int C, int HW, const float* logits, const float* label, float nr, float dr, float* ws, float* loss,
+                      float* dlogits) {
+    UIA_CHECK_ARG(B > 0 && C >= 2 && C <= DICE_MAXC && HW > 0, "uia_dicece: bad shape B=%d C=%d HW=%d (2 <= C <= %d)", B, C, HW, DICE_MAXC);
+    UIA_CHECK_ARG(logits && label && ws && loss && dlogits, "uia_dicece: null tensor");
+    hipLaunchKernelGGL(dicece_sums_kernel, dim3(B), dim3(1024), 0, stream, C, HW, logits, label, ws);
+    int gx = (HW + 255) / 256;
+    gx = gx > 64 ? 64 : gx;
+    hipLaunchKernelGGL(dicece_grad_kernel, dim3(gx, B), dim3(256), 0, stream, B, C, HW, logits, label, ws, nr, dr, loss, dlogits);
     UIA_CHECK_LAUNCH();
     return 0;
 }

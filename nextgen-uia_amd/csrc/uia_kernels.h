@@ -51,3 +51,5 @@ int uia_act_bwd_launch(hipStream_t stream, int dtype, size_t n, const void* dy, 
 size_t uia_mona_spatial_ws_floats(int B);
 int uia_upsample_bilinear_launch(hipStream_t stream, bool bwd, int B, int C, int h, int w, int H, int W, const float* in, float* out, long ld);
 int uia_segment_mean_launch(hipStream_t stream, bool bwd, int B, int n, int C, const float* in, float* out, long ld);
+size_t uia_dicece_ws_floats(int B);
+int uia_dicece_launch(hipStream_t stream, int B, int C, int HW, const float* logits, const float* label, float nr, float dr, float* ws, float* loss, float* dlogits);

@@ -1,10 +1,24 @@
 """DiceCE loss and Dice metric with MONAI 1.5.1 semantics (reference: /root/reference/src/models/clipseg/segmentation.py:84,
 `DiceCELoss(to_onehot_y=True, softmax=True, squared_pred=True, smooth_nr=1e-8, smooth_dr=1e-8)`; metric src/utils/tools.py:185-206).
-SURVEY §8(f)-3 lists an on-device fused kernel as a follow-up; for now these are plain device-side torch ops at the edge of the
-hot path (the decoder gradient enters libuia_hip.so through `logits.grad`)."""
+The loss runs fused on the device (`uia_dicece_fwd_bwd`: loss and d loss / d logits in one call); the Dice metric
+is a handful of torch reductions on the validation path."""
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
+
+from uia_hip import ops
+
+
+class _DiceCEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, label, nr, dr):
+        loss, dl = ops.dicece_fwd_bwd(logits.contiguous().float(), label, nr, dr)
+        ctx.save_for_backward(dl)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        return dl * g, None, None, None
 
 
 class DiceCELoss(nn.Module):
@@ -14,12 +28,7 @@ class DiceCELoss(nn.Module):
 
     def forward(self, logits, label):
         """logits [B, C, H, W]; label [B, 1, H, W] with class indices."""
-        p = torch.softmax(logits, dim=1)
-        t = F.one_hot(label[:, 0].long(), logits.shape[1]).permute(0, 3, 1, 2).to(p.dtype)
-        inter = (p * t).sum(dim=(2, 3))
-        den = (p * p).sum(dim=(2, 3)) + (t * t).sum(dim=(2, 3))
-        dice = 1.0 - (2.0 * inter + self.smooth_nr) / (den + self.smooth_dr)
-        return dice.mean() + F.cross_entropy(logits, label[:, 0].long())
+        return _DiceCEFn.apply(logits, label, self.smooth_nr, self.smooth_dr)
 
 
 def dice_per_image(logits, label):

@@ -63,6 +63,8 @@ PROTOTYPES = {
     "uia_upsample_bilinear_bwd": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int64]),
     "uia_segment_mean_fwd": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int64, vp]),
     "uia_segment_mean_bwd": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int64]),
+    "uia_dicece_workspace_bytes": (sz, [C.c_int]),
+    "uia_dicece_fwd_bwd": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_float, C.c_float, vp, vp, vp]),
     "uia_infonce_workspace_bytes": (sz, [C.c_int, C.c_int]),
     "uia_infonce_fwd_bwd": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, f32, f32, vp, vp, vp, vp, sz]),
     "uia_adamw_clip_step": (C.c_int, [vp, sz, vp, vp, vp, vp, f32, f32, f32, f32, f32, f32, C.c_int, f32, vp]),

@@ -387,3 +387,15 @@ def segment_mean(x, B, n, out, backward=False):
         check(lib().uia_segment_mean_bwd(_stream(), B, n, Cc, _p(x), _p(out), out.stride(0)), "uia_segment_mean_bwd")
     else:
         check(lib().uia_segment_mean_fwd(_stream(), B, n, Cc, _p(x), x.stride(0), _p(out)), "uia_segment_mean_fwd")
+
+
+def dicece_fwd_bwd(logits, label, smooth_nr=1e-8, smooth_dr=1e-8):
+    """logits fp32 [B,C,H,W], label [B,1,H,W] (class indices) -> (loss 0-dim fp32, dlogits fp32 [B,C,H,W])."""
+    assert logits.dtype == torch.float32 and logits.is_contiguous() and logits.dim() == 4
+    B, Cc, H, W = logits.shape
+    lab = label.reshape(B, H * W).to(torch.float32).contiguous()
+    ws = torch.empty(lib().uia_dicece_workspace_bytes(B) // 4, device=logits.device, dtype=torch.float32)
+    loss = torch.empty((), device=logits.device, dtype=torch.float32)
+    dl = torch.empty_like(logits)
+    check(lib().uia_dicece_fwd_bwd(_stream(), B, Cc, H * W, _p(logits), _p(lab), smooth_nr, smooth_dr, _p(ws), _p(loss), _p(dl)), "uia_dicece_fwd_bwd")
+    return loss, dl

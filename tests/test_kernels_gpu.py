@@ -249,3 +249,24 @@ def test_rccl_communicator_single_rank_allreduce(ops):
         assert torch.equal(g, ref)
     finally:
         ops.comm_destroy()
+
+
+@pytest.mark.parametrize("C", [2, 3])
+def test_dicece_fused_loss_and_gradient(ops, C):
+    """uia_dicece_fwd_bwd against the oracle's DiceCE restatement (MONAI semantics) and its autograd gradient, incl. an image
+    with an empty foreground (the smooth terms carry it)."""
+    from oracle import losses_ref
+    g = torch.Generator().manual_seed(8)
+    B, H, W = 5, 24, 40
+    logits = torch.randn(B, C, H, W, generator=g) * 2
+    label = torch.randint(0, C, (B, 1, H, W), generator=g).float()
+    label[1] = 0
+    lr_ = logits.clone().requires_grad_(True)
+    ref = losses_ref.dice_ce(lr_, label)
+    (3.0 * ref).backward()
+    from src.losses.dice import DiceCELoss
+    lg = logits.to(dev()).requires_grad_(True)
+    loss = DiceCELoss()(lg, label.to(dev()))
+    (3.0 * loss).backward()
+    assert abs(float(loss) - float(ref)) < 1e-5 * abs(float(ref))
+    assert rel(lg.grad.cpu(), lr_.grad) < 1e-4
