@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--no-overlap-text", action="store_true", help="run the text tower on the main stream instead of a side stream")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--global-loss", action="store_true", help="opt-in: InfoNCE over the global batch (all-gathered features) instead of "
+                    "the reference-equivalent local loss; changes the objective, not the headline configuration")
     return ap.parse_args()
 
 
@@ -127,20 +129,20 @@ def main():
 
     loss = None
     for _ in range(args.warmup):
-        loss = contrastive_step(model, criterion, opt, images, ids, overlap_text=not args.no_overlap_text)
+        loss = contrastive_step(model, criterion, opt, images, ids, overlap_text=not args.no_overlap_text, global_loss=args.global_loss)
     barrier()
     t0 = time.perf_counter()
     for s in range(args.steps):
         if s == args.steps - 1:
             ops.GEMM_PROFILE = []                                    # live per-launch events on the last timed step
-        loss = contrastive_step(model, criterion, opt, images, ids, overlap_text=not args.no_overlap_text)
+        loss = contrastive_step(model, criterion, opt, images, ids, overlap_text=not args.no_overlap_text, global_loss=args.global_loss)
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
     prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
     # one extra, untimed step with the two towers serialised on one stream: the dominant kernel's standalone rate
     ops.GEMM_PROFILE = []
-    contrastive_step(model, criterion, opt, images, ids, overlap_text=False)
+    contrastive_step(model, criterion, opt, images, ids, overlap_text=False, global_loss=args.global_loss)
     torch.cuda.synchronize()
     prof_serial, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
     if world > 1:
@@ -209,7 +211,7 @@ def main():
                                       "frozen BERT-base text tower fwd (all 256 positions through every GEMM; attention skips key tiles that are entirely padding), "
                                       "InfoNCE, clip+AdamW; random-init weights",
                           "mona_variant": args.variant, "batch_per_gpu": args.batch, "global_batch": args.batch * world, "image": "3x224x224",
-                          "text_len": 256, "parallelism": f"dp{world}", "mona_dropout": 0.1, "bert_dropout_emulated": False,
+                          "text_len": 256, "parallelism": f"dp{world}", "contrastive_batch": "global (opt-in)" if args.global_loss else "per-rank (reference-equivalent)", "mona_dropout": 0.1, "bert_dropout_emulated": False,
                           "gflop_per_pair_algorithmic": GFLOP_PER_PAIR},
                "loss": round(final_loss, 5), "roofline": roof}
         if cpu_state is not None:

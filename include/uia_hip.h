@@ -209,6 +209,8 @@ int uia_comm_get_unique_id(void* out, int bytes);
 int uia_comm_init(int rank, int world, const void* unique_id, int bytes);
 int uia_comm_world(void);
 int uia_allreduce_sum(void* stream, int dtype, void* buf, size_t n);
+/* opt-in global-batch contrastive loss: recv[r*n_per_rank ...] = rank r's send buffer (RCCL all-gather). */
+int uia_allgather(void* stream, int dtype, const void* send, void* recv, size_t n_per_rank);
 int uia_comm_destroy(void);
 
 #ifdef __cplusplus

@@ -56,6 +56,14 @@ int uia_allreduce_sum(void* stream, int dtype, void* buf, size_t n) {
     return 0;
 }
 
+int uia_allgather(void* stream, int dtype, const void* send, void* recv, size_t n_per_rank) {
+    if (!g_comm) { uia_set_error("uia_allgather: communicator not initialised"); return -1; }
+    if (!send || !recv || n_per_rank == 0) { uia_set_error("uia_allgather: empty buffer"); return -1; }
+    const ncclDataType_t t = dtype == UIA_BF16 ? ncclBfloat16 : ncclFloat32;
+    NCCL_TRY(ncclAllGather(send, recv, n_per_rank, t, g_comm, (hipStream_t)stream));
+    return 0;
+}
+
 int uia_comm_destroy(void) {
     if (g_comm) { NCCL_TRY(ncclCommDestroy(g_comm)); g_comm = nullptr; g_world = 1; }
     return 0;

@@ -73,6 +73,7 @@ PROTOTYPES = {
     "uia_comm_init": (C.c_int, [C.c_int, C.c_int, vp, C.c_int]),
     "uia_comm_world": (C.c_int, []),
     "uia_allreduce_sum": (C.c_int, [vp, C.c_int, vp, sz]),
+    "uia_allgather": (C.c_int, [vp, C.c_int, vp, vp, sz]),
     "uia_comm_destroy": (C.c_int, []),
     "uia_dropout": (C.c_int, [vp, C.c_int, sz, vp, vp, f32, C.c_uint64, C.c_int]),
     "uia_colsum": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, i64, vp]),

@@ -99,6 +99,28 @@ def init_data_parallel(opt=None):
     return rank, local, world
 
 
+class GatherFeaturesFn(torch.autograd.Function):
+    """[B, E] local features → [world·B, E] in rank order (RCCL all-gather on the compute stream).  Every rank then evaluates the
+    SAME global-batch loss, so the gradient of that loss with respect to this rank's rows is simply the local slice of the
+    gathered gradient — no collective in the backward; the parameter gradients of the ranks add up in the usual all-reduce."""
+
+    @staticmethod
+    def forward(ctx, x, rank, world):
+        x = x.contiguous()
+        out = torch.empty(world * x.shape[0], x.shape[1], device=x.device, dtype=x.dtype)
+        if world > 1:
+            ops.allgather(x, out)
+        else:
+            out.copy_(x)
+        ctx.meta = (rank, x.shape[0])
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        rank, B = ctx.meta
+        return g[rank * B:(rank + 1) * B].contiguous(), None, None
+
+
 _SIDE_STREAM = {}
 
 
@@ -108,8 +130,13 @@ def _side_stream(device):
     return _SIDE_STREAM[device]
 
 
-def contrastive_step(model, criterion, opt, images, ids, micro_batches=1, lr=None, overlap_text=True):
+def contrastive_step(model, criterion, opt, images, ids, micro_batches=1, lr=None, overlap_text=True, global_loss=False):
     """One optimiser update: encode → InfoNCE → backward (→ all-reduce) → clip+AdamW.  Returns the loss tensor (device).
+
+    global_loss (opt-in, not the reference's semantics): the InfoNCE batch is the GLOBAL batch — features are all-gathered,
+    every rank evaluates the same world·B × world·B loss, back-propagates the rows it owns, and the all-reduced parameter
+    gradient is the gradient of that one loss (no 1/world scaling).  Default: each rank's local loss, averaged (≡ the
+    reference's gradient accumulation).
 
     overlap_text: the frozen text tower does not depend on the image tower, so it runs on a second HIP stream beside
     encode_image (same kernels, same results); the streams join before the loss."""
@@ -131,9 +158,12 @@ def contrastive_step(model, criterion, opt, images, ids, micro_batches=1, lr=Non
         else:
             fi = model.encode_image(im)
             ft = model.encode_text(tk)
+        if global_loss:
+            rank, _, _ = dist_env()
+            fi, ft = GatherFeaturesFn.apply(fi, rank, opt.world), GatherFeaturesFn.apply(ft, rank, opt.world)
         loss = criterion(fi, ft)
         (loss / micro_batches).backward()
         total = loss.detach() if total is None else total + loss.detach()
     opt.all_reduce()
-    opt.step(lr=lr)
+    opt.step(lr=lr, grad_scale=1.0 if global_loss else None)
     return total / micro_batches

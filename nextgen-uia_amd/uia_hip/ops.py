@@ -310,6 +310,12 @@ def allreduce_sum(buf):
     check(lib().uia_allreduce_sum(_stream(), _code(buf.dtype), _p(buf), buf.numel()), "uia_allreduce_sum")
 
 
+def allgather(send, recv):
+    """recv [world * n] = concatenation over ranks of send [n] (same dtype, contiguous)."""
+    assert send.is_contiguous() and recv.is_contiguous() and send.dtype == recv.dtype and recv.numel() == send.numel() * comm_world()
+    check(lib().uia_allgather(_stream(), _code(send.dtype), _p(send), _p(recv), send.numel()), "uia_allgather")
+
+
 def comm_destroy():
     check(lib().uia_comm_destroy(), "uia_comm_destroy")
 

@@ -75,6 +75,60 @@ def test_dp2_equals_accumulation(tmp_path):
         assert torch.allclose(r0["params"][k], params[k], rtol=1e-5, atol=1e-7), k  # == accumulation (fp32 summation order aside)
 
 
+# ---- opt-in global-batch loss: all-gather the features, every rank evaluates the same global InfoNCE and
+#      back-propagates only the rows it owns; the all-reduced parameter gradient (NOT divided by world) is the gradient of that loss.
+class _Gather(torch.autograd.Function):            # the protocol of uia_hip.engine.GatherFeaturesFn, with gloo in place of RCCL
+    @staticmethod
+    def forward(ctx, x, rank, world):
+        parts = [torch.empty_like(x) for _ in range(world)]
+        dist.all_gather(parts, x.contiguous())
+        ctx.meta = (rank, x.shape[0])
+        return torch.cat(parts, 0)
+
+    @staticmethod
+    def backward(ctx, g):
+        rank, B = ctx.meta
+        return g[rank * B:(rank + 1) * B].contiguous(), None, None
+
+
+def _features(Pq, x, head, hw=(3, 3)):
+    return mona_ref.forward(x, Pq, "hybrid", hw)[:, 0] @ head.T
+
+
+def _global_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    P, _, batches = _problem()
+    head = torch.randn(16, 32, generator=torch.Generator().manual_seed(99)) * 0.2
+    Pq = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    x, txt = batches[rank]
+    fi = _Gather.apply(_features(Pq, x, head), rank, world)
+    ft = _Gather.apply(txt, rank, world)
+    loss = losses_ref.info_nce(fi, ft, 0.07)
+    loss.backward()
+    flat = _flatten({k: v.grad for k, v in Pq.items()}, list(P))
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)                                    # no 1/world: the ranks' contributions add up
+    torch.save({"flat": flat, "loss": loss.detach()}, os.path.join(out, f"g{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_dp2_global_batch_loss_protocol(tmp_path):
+    world, port = 2, 29811 + os.getpid() % 200
+    mp.spawn(_global_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    P, _, batches = _problem()
+    head = torch.randn(16, 32, generator=torch.Generator().manual_seed(99)) * 0.2
+    Pq = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    fi = torch.cat([_features(Pq, x, head) for x, _ in batches], 0)                 # one process, the concatenated batch
+    ft = torch.cat([t for _, t in batches], 0)
+    loss = losses_ref.info_nce(fi, ft, 0.07)
+    loss.backward()
+    want = _flatten({k: v.grad for k, v in Pq.items()}, list(P))
+    r0, r1 = (torch.load(os.path.join(tmp_path, f"g{r}.pt")) for r in range(2))
+    assert torch.equal(r0["flat"], r1["flat"]) and abs(float(r0["loss"]) - float(loss)) < 1e-6
+    assert torch.allclose(r0["flat"], want, rtol=1e-5, atol=1e-7)
+
+
 def test_dist_env_parsing(monkeypatch):
     from uia_hip.engine import dist_env
     monkeypatch.setenv("RANK", "3"); monkeypatch.setenv("LOCAL_RANK", "1"); monkeypatch.setenv("WORLD_SIZE", "8")

@@ -666,3 +666,30 @@ def test_biomedclip_segmentation_entry_point(tmp_path, monkeypatch):
     ck = segmentation.checkpoint_dict(segmentation.prepare_model(args))
     assert set(ck) == {"reduces", "blocks", "seg_head", "mona"} and "1.weight" in ck["seg_head"] and "0.weight" in ck["reduces"]
     assert ck["mona"] and all("mona" in k for k in ck["mona"])
+
+
+def test_global_batch_loss_with_one_rank_equals_local_loss():
+    """engine.contrastive_step(global_loss=True) on a world of one rank: the gather is a copy, grad_scale is 1 — same loss,
+    same updated adapter weights as the default local-loss step (the two-rank protocol itself is tests/test_dp_gloo.py)."""
+    from uia_hip import functional as UF
+    from uia_hip.engine import FlatAdapterOptimizer, contrastive_step
+    from src.adapters import inject_mona_variant_to_open_clip
+    from src.losses import InfoNCELoss
+    from src.third_party.biomedclip.model import create_biomedclip
+    UF.set_compute_dtype(torch.float32)
+    outs = []
+    for flag in (False, True):
+        model = create_biomedclip(config=TOY, seed=5)
+        for p in model.parameters():
+            p.requires_grad_(False)
+        inject_mona_variant_to_open_clip(model, variant="baseline", bottleneck_dim=64)
+        randomize(torch.nn.ModuleList([b.mona for b in model.visual.trunk.blocks]), torch.Generator().manual_seed(2), 0.05)
+        for k, p in model.named_parameters():
+            p.requires_grad_("mona" in k)
+        model = model.to(dev()).eval()
+        opt = FlatAdapterOptimizer([(k, p) for k, p in model.named_parameters() if p.requires_grad], lr=1e-3)
+        images, ids = toy_batch(torch.Generator().manual_seed(4))
+        loss = contrastive_step(model, InfoNCELoss(0.07), opt, images.to(dev()), ids.to(dev()), overlap_text=False, global_loss=flag)
+        outs.append((float(loss), opt.p.clone()))
+    # float atomics in the loss / weight-gradient reductions make two runs differ in the last bits
+    assert abs(outs[0][0] - outs[1][0]) < 1e-6 * abs(outs[0][0]) and torch.allclose(outs[0][1], outs[1][1], rtol=1e-5, atol=1e-7)
