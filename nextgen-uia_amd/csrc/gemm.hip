@@ -1007,6 +1007,7 @@ int launch_ring(hipStream_t stream, const UiaGemmParams& p, bool specialise) {
         switch (epi_mask_of(p)) {    // the six masks of a training step, by time spent (tools/gemm_census.py)
 #define UIA_EPI_CASE(MASK) case (MASK): return launch_ring_epi<T, BM, BN, WAVES_M, WAVES_N, BKB, NBUF, (MASK)>(stream, p)
             UIA_EPI_CASE(EPI_BIAS | EPI_RESID | EPI_OUT32);                    // proj / fc2 / Mona project2 forward
+            UIA_EPI_CASE(EPI_BIAS | EPI_RESIDT | EPI_OUT32);                   // post-LN (BERT) sub-layer sums on the T residual
             UIA_EPI_CASE(EPI_OUTT);                                            // dgrads
             UIA_EPI_CASE(EPI_BIAS | EPI_OUTT);                                 // QKV
             UIA_EPI_CASE(EPI_BIAS | EPI_GELU | EPI_OUTT);                      // fc1, frozen tower
@@ -1024,6 +1025,7 @@ int launch_persist(hipStream_t stream, const UiaGemmParams& p) {
     switch (epi_mask_of(p)) {
 #define UIA_EPI_CASE(MASK) case (MASK): return launch_persist_epi<T, (MASK)>(stream, p)
         UIA_EPI_CASE(EPI_BIAS | EPI_RESID | EPI_OUT32);
+        UIA_EPI_CASE(EPI_BIAS | EPI_RESIDT | EPI_OUT32);
         UIA_EPI_CASE(EPI_OUTT);
         UIA_EPI_CASE(EPI_BIAS | EPI_OUTT);
         UIA_EPI_CASE(EPI_BIAS | EPI_GELU | EPI_OUTT);

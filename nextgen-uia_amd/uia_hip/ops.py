@@ -19,7 +19,7 @@ GEMM_PROFILE = None
 
 
 EPI_BIAS, EPI_AUX_OUT, EPI_GELU, EPI_DGELU, EPI_RESID, EPI_RESIDT, EPI_OUT32, EPI_OUTT, EPI_GENERIC = 1, 2, 4, 8, 16, 32, 64, 128, -1
-_SPECIALISED = {EPI_BIAS | EPI_RESID | EPI_OUT32, EPI_OUTT, EPI_BIAS | EPI_OUTT, EPI_BIAS | EPI_GELU | EPI_OUTT, EPI_DGELU | EPI_OUTT,
+_SPECIALISED = {EPI_BIAS | EPI_RESID | EPI_OUT32, EPI_BIAS | EPI_RESIDT | EPI_OUT32, EPI_OUTT, EPI_BIAS | EPI_OUTT, EPI_BIAS | EPI_GELU | EPI_OUTT, EPI_DGELU | EPI_OUTT,
                 EPI_BIAS | EPI_GELU | EPI_AUX_OUT | EPI_OUTT}
 
 
