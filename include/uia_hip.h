@@ -158,6 +158,8 @@ int uia_dicece_fwd_bwd(void* stream, int B, int C, int HW, const float* logits, 
 int uia_cast(void* stream, int dtype, size_t n, const float* src, void* dst, float scale);          /* dst = T(scale*src) */
 int uia_transpose_cast(void* stream, int dtype, int rows, int cols, const float* src, void* dst);   /* dst[c][r] = T(src[r][c]) */
 int uia_im2col(void* stream, int dtype, int B, int C, int H, int W, int P, const float* img, void* out); /* model.py:221,234 */
+/* same for any patch size (P need not be a multiple of 4), rows padded with zeros to ldo >= C*P*P columns (ViT-L/14: 588 -> 640) */
+int uia_im2col_padded(void* stream, int dtype, int B, int C, int H, int W, int P, const float* img, void* cols, int64_t ldo);
 int uia_fill_cls(void* stream, int B, int N, int D, const float* cls, const float* pos0, float* x);   /* model.py:237-245 */
 int uia_embed(void* stream, int rows, int L, int D, const int64_t* ids, const float* table, const float* pos,
               const float* type0, float* out);                                                          /* model.py:362-364 */

@@ -118,4 +118,8 @@ int uia_dicece_fwd_bwd(void* stream, int B, int C, int HW, const float* logits, 
     return uia_dicece_launch((hipStream_t)stream, B, C, HW, logits, label, smooth_nr, smooth_dr, ws, loss, dlogits);
 }
 
+int uia_im2col_padded(void* stream, int dtype, int B, int C, int H, int W, int P, const float* img, void* cols, int64_t ldo) {
+    return uia_im2col_padded_launch((hipStream_t)stream, dtype, B, C, H, W, P, img, cols, (long)ldo);
+}
+
 }  // extern "C"

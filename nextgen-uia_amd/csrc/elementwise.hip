@@ -51,6 +51,24 @@ __global__ void im2col_kernel(int B, int C, int H, int W, int P, const float* __
     }
 }
 
+// any patch size, output rows padded to `ldo` columns (zeros beyond C·P·P): ViT-L/14's 588-wide patches → 640 for the GEMM's K granule
+template <typename T>
+__global__ void im2col_padded_kernel(int B, int C, int H, int W, int P, const float* __restrict__ img, T* __restrict__ out, long ldo) {
+    const int gh = H / P, gw = W / P, K = C * P * P;
+    const size_t total = (size_t)B * gh * gw * ldo;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % ldo);
+        const size_t prow = i / ldo;
+        float v = 0.f;
+        if (k < K) {
+            const int px = (int)(prow % gw), py = (int)((prow / gw) % gh), b = (int)(prow / ((size_t)gw * gh));
+            const int kx = k % P, ky = (k / P) % P, c = k / (P * P);
+            v = img[(((size_t)b * C + c) * H + (size_t)py * P + ky) * W + (size_t)px * P + kx];
+        }
+        out[i] = from_f32<T>(v);
+    }
+}
+
 __global__ void fill_cls_kernel(int B, int N, int D, const float* __restrict__ cls, const float* __restrict__ pos0, float* __restrict__ x) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * D) return;
@@ -154,6 +172,17 @@ int uia_im2col_launch(hipStream_t stream, int dtype, int B, int C, int H, int W,
     if (dtype == UIA_BF16) hipLaunchKernelGGL(im2col_kernel<bf16_t>, dim3(g), dim3(256), 0, stream, B, C, H, W, P, img, (bf16_t*)out);
     else if (dtype == UIA_F32) hipLaunchKernelGGL(im2col_kernel<float>, dim3(g), dim3(256), 0, stream, B, C, H, W, P, img, (float*)out);
     else { uia_set_error("uia_im2col: bad dtype %d", dtype); return -1; }
+    UIA_CHECK_LAUNCH();
+    return 0;
+}
+
+int uia_im2col_padded_launch(hipStream_t stream, int dtype, int B, int C, int H, int W, int P, const float* img, void* out, long ldo) {
+    UIA_CHECK_ARG(B > 0 && C > 0 && P > 0 && H % P == 0 && W % P == 0 && ldo >= (long)C * P * P, "uia_im2col_padded: unsupported geometry B=%d C=%d H=%d W=%d P=%d ldo=%ld", B, C, H, W, P, ldo);
+    UIA_CHECK_ARG(img && out, "uia_im2col_padded: null tensor");
+    const int g = grid_for((size_t)B * (H / P) * (W / P) * ldo, 256);
+    if (dtype == UIA_BF16) hipLaunchKernelGGL(im2col_padded_kernel<bf16_t>, dim3(g), dim3(256), 0, stream, B, C, H, W, P, img, (bf16_t*)out, ldo);
+    else if (dtype == UIA_F32) hipLaunchKernelGGL(im2col_padded_kernel<float>, dim3(g), dim3(256), 0, stream, B, C, H, W, P, img, (float*)out, ldo);
+    else { uia_set_error("uia_im2col_padded: bad dtype %d", dtype); return -1; }
     UIA_CHECK_LAUNCH();
     return 0;
 }

@@ -88,6 +88,7 @@ PROTOTYPES = {
     "uia_cast": (C.c_int, [vp, C.c_int, sz, vp, vp, f32]),
     "uia_transpose_cast": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp]),
     "uia_im2col": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "uia_im2col_padded": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int64]),
     "uia_fill_cls": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     "uia_embed": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
     "uia_gather_rows": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp]),

@@ -90,8 +90,8 @@ class WeightCache:
         if len(self._c) > 8192:
             self._c = {k: v for k, v in self._c.items() if v[1]() is not None}
 
-    def get(self, p, dt, transpose=False, pad_rows_to=None):
-        key = (id(p), dt, transpose, pad_rows_to)
+    def get(self, p, dt, transpose=False, pad_rows_to=None, pad_cols_to=None):
+        key = (id(p), dt, transpose, pad_rows_to, pad_cols_to)
         hit = self._c.get(key)
         if hit is not None and hit[0] == p._version and hit[1]() is p and hit[2].device == p.device and (not p.requires_grad or hit[3] == self.epoch):
             return hit[2]
@@ -101,6 +101,8 @@ class WeightCache:
         src = src.contiguous().float()
         if pad_rows_to is not None and src.shape[0] < pad_rows_to:      # LoRA rank → 64 (zero rows change nothing)
             src = torch.cat([src, src.new_zeros(pad_rows_to - src.shape[0], src.shape[1])], 0)
+        if pad_cols_to is not None and src.shape[1] < pad_cols_to:      # contraction dim → the GEMM's K granule (zero columns change nothing)
+            src = torch.cat([src, src.new_zeros(src.shape[0], pad_cols_to - src.shape[1])], 1)
         if transpose:
             out = torch.empty(src.shape[1], src.shape[0], device=src.device, dtype=dt)
             ops.transpose_cast(src, out)
@@ -326,11 +328,14 @@ class PatchEmbedFn(torch.autograd.Function):
         B, C, H, W = images.shape
         G = (H // patch) * (W // patch)
         D = conv_w.shape[0]
-        cols = _empty((B * G, C * patch * patch), dt, images)
+        K = C * patch * patch
+        gran = 64 if dt == torch.bfloat16 else 32                                    # uia_gemm's K granule (128 bytes)
+        Kp = (K + gran - 1) // gran * gran                                           # ViT-L/14: 588 → 640, zero-padded on both operands
+        cols = _empty((B * G, Kp), dt, images)
         ops.im2col(images.contiguous().float(), cols, patch)
         x = torch.empty(B, G + 1, D, device=images.device, dtype=torch.float32)
         pos2d = pos.detach().reshape(G + 1, D).contiguous()
-        ops.gemm(cols, WEIGHTS.get(conv_w, dt), bias=conv_b, resid=pos2d, resid_mod=G, resid_row_off=1, out_group=G, out32=x.view(-1, D))
+        ops.gemm(cols, WEIGHTS.get(conv_w, dt, pad_cols_to=Kp), bias=conv_b, resid=pos2d, resid_mod=G, resid_row_off=1, out_group=G, out32=x.view(-1, D))
         ops.fill_cls(x, cls.detach().reshape(D).contiguous(), pos2d[0])
         return x
 

@@ -198,9 +198,14 @@ def transpose_cast(src, dst):
 
 
 def im2col(img, out, patch):
+    """out [B*gh*gw, ld]: ld == C*patch^2 with patch % 4 == 0 takes the vectorised kernel, anything else the padded one
+    (columns beyond C*patch^2 are zero-filled, e.g. ViT-L/14: 588 -> 640 for the GEMM's K granule)."""
     B, Cc, H, W = img.shape
     assert img.dtype == torch.float32 and img.is_contiguous() and out.is_contiguous()
-    check(lib().uia_im2col(_stream(), _code(out.dtype), B, Cc, H, W, patch, _p(img), _p(out)), "uia_im2col")
+    if patch % 4 == 0 and out.shape[1] == Cc * patch * patch and W % 4 == 0:
+        check(lib().uia_im2col(_stream(), _code(out.dtype), B, Cc, H, W, patch, _p(img), _p(out)), "uia_im2col")
+    else:
+        check(lib().uia_im2col_padded(_stream(), _code(out.dtype), B, Cc, H, W, patch, _p(img), _p(out), out.shape[1]), "uia_im2col_padded")
 
 
 def fill_cls(x, cls, pos0):

@@ -270,3 +270,18 @@ def test_dicece_fused_loss_and_gradient(ops, C):
     (3.0 * loss).backward()
     assert abs(float(loss) - float(ref)) < 1e-5 * abs(float(ref))
     assert rel(lg.grad.cpu(), lr_.grad) < 1e-4
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_patch_embed_patch14(dt):
+    """ViT-L/14 stem: 14x14 patches (588 values, not a multiple of the GEMM's K granule) through the zero-padded im2col + GEMM."""
+    from uia_hip import functional as UF
+    UF.set_compute_dtype(dt)
+    g = torch.Generator().manual_seed(14)
+    B, D, P, S = 2, 128, 14, 56
+    img = torch.rand(B, 3, S, S, generator=g)
+    w, cls, pos = torch.randn(D, 3, P, P, generator=g) * 0.05, torch.randn(D, generator=g), torch.randn((S // P) ** 2 + 1, D, generator=g)
+    ref = torch.nn.functional.conv2d(img, w, None, stride=P).flatten(2).transpose(1, 2)
+    ref = torch.cat([cls.expand(B, 1, D), ref], 1) + pos
+    x = UF.PatchEmbedFn.apply(img.to(dev()), w.to(dev()), None, cls.to(dev()), pos.to(dev()), P)
+    assert rel(x.cpu(), ref) < (2e-5 if dt == torch.float32 else 1e-2)
