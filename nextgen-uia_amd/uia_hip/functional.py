@@ -407,22 +407,24 @@ class AttentionFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, q, k, v, B, H, L, mask):
+        """mask: None | "causal" | ("keypad", keylen int32 [B])."""
+        kind, keylen = (mask[0], mask[1]) if isinstance(mask, tuple) else (mask, None)
         out = _empty((B * L, H * 64), q.dtype, q)
         need = any(ctx.needs_input_grad[:3])
         lse = torch.empty(B, H, L, device=q.device, dtype=torch.float32) if need else None
-        ops.attn_fwd(q, k, v, out, B, H, L, lse=lse, mask=mask)
+        ops.attn_fwd(q, k, v, out, B, H, L, lse=lse, mask=kind, keylen=keylen)
         if need:
             ctx.save_for_backward(q, k, v, out, lse)
-            ctx.meta = (B, H, L, mask)
+            ctx.meta = (B, H, L, kind, keylen)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         q, k, v, out, lse = ctx.saved_tensors
-        B, H, L, mask = ctx.meta
+        B, H, L, kind, keylen = ctx.meta
         D = H * 64
         dqkv = _empty((B * L, 3 * D), q.dtype, q)
-        ops.attn_bwd(q, k, v, out, dout.contiguous(), lse, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], B, H, L, mask=mask)
+        ops.attn_bwd(q, k, v, out, dout.contiguous(), lse, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], B, H, L, mask=kind, keylen=keylen)
         return dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], None, None, None, None
 
 
@@ -791,3 +793,91 @@ class DropoutFn(torch.autograd.Function):
         dx = torch.empty_like(dy)
         ops.dropout(dy, dx, p, seed)
         return dx, None, None
+
+
+# ------------------------------------------------------------------------------------------------ trainable post-LN (BERT) path
+class FrozenLinearFn(torch.autograd.Function):
+    """y = act(x·Wᵀ + b) (+ resid32) with FROZEN W, b: forward like LinearTrainFn, backward is the data gradient only."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act, resid32):
+        dt = x.dtype
+        M, K = x.shape
+        N = weight.shape[0]
+        need = ctx.needs_input_grad[0] or (resid32 is not None and ctx.needs_input_grad[4])
+        if resid32 is not None:
+            assert not act
+            y = torch.empty(M, N, device=x.device, dtype=torch.float32)
+            ops.gemm(x, WEIGHTS.get(weight, dt), bias=bias, resid=resid32, out32=y)
+            pre = None
+        else:
+            y = _empty((M, N), dt, x)
+            pre = _empty((M, N), dt, x) if (act and need) else None
+            ops.gemm(x, WEIGHTS.get(weight, dt), bias=bias, act=act, aux_out=pre, out_t=y)
+        ctx.save_for_backward(weight, pre if pre is not None else x.new_empty(0))
+        ctx.meta = (act, resid32 is not None, dt, K)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        weight, pre = ctx.saved_tensors
+        act, has_resid, dt, K = ctx.meta
+        dy = dy.contiguous()
+        dy_t = t_copy_of(dy, dt) if dy.dtype == torch.float32 else dy
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _empty((dy.shape[0], K), dt, dy)
+            if act:
+                dpre = torch.empty_like(dy_t)
+                ops.act_bwd(dy_t, pre, act, dpre)
+                ops.gemm(dpre, WEIGHTS.get(weight, dt, transpose=True), out_t=dx)
+            else:
+                ops.gemm(dy_t, WEIGHTS.get(weight, dt, transpose=True), out_t=dx)
+        return dx, None, None, None, (dy if has_resid else None)
+
+
+class PostLayerNormFn(torch.autograd.Function):
+    """Post-LN sub-layer output: LayerNorm(s) with frozen affine, returned both as the fp32 residual and as the T operand.
+    Backward: LN backward of the SUM of the two incoming gradients, in fp32."""
+
+    @staticmethod
+    def forward(ctx, s32, w, b, eps):
+        s32 = s32.contiguous()
+        y32 = torch.empty_like(s32)
+        y_t = _empty(s32.shape, compute_dtype(), s32) if compute_dtype() != torch.float32 else None
+        ops.layernorm_fwd(s32, w, b, eps, y_t=y_t, y32=y32)
+        ctx.save_for_backward(s32, w)
+        ctx.eps = eps
+        return y32, (y_t if y_t is not None else y32)
+
+    @staticmethod
+    def backward(ctx, g32, g_t):
+        s32, w = ctx.saved_tensors
+        g = None
+        for t in (g32, g_t):
+            if t is not None:
+                g = t.float() if g is None else g + t.float()
+        ds = torch.empty_like(s32)
+        ops.layernorm_bwd(g.contiguous(), s32, w, ctx.eps, dx32=ds)
+        return ds, None, None, None
+
+
+def post_ln_layer_train(x32, x_t, L, B, heads, layer, keylen, eps=1e-12):
+    """HF BertLayer (post-LN) with autograd: q/k/v/attention.output.dense may be LinearLoRA modules (reference
+    lora.py:317-367, --tune_text_encoder), everything else is frozen.  Returns the new (fp32, T) residual pair."""
+    from src.adapters.lora import LinearLoRA
+    sa, ao = layer.attention.self, layer.attention.output
+
+    def lin(mod, rows, resid32=None, act=None):
+        if isinstance(mod, LinearLoRA):
+            assert act is None
+            return mod.apply_rows(rows, resid32)
+        return FrozenLinearFn.apply(rows, mod.weight, mod.bias, act, resid32)
+
+    q, k, v = lin(sa.query, x_t), lin(sa.key, x_t), lin(sa.value, x_t)
+    a = AttentionFn.apply(q, k, v, B, heads, L, ("keypad", keylen))
+    s = lin(ao.dense, a, resid32=x32)
+    x32, x_t = PostLayerNormFn.apply(s, ao.LayerNorm.weight, ao.LayerNorm.bias, eps)
+    f = lin(layer.intermediate.dense, x_t, act="gelu")
+    s = lin(layer.output.dense, f, resid32=x32)
+    return PostLayerNormFn.apply(s, layer.output.LayerNorm.weight, layer.output.LayerNorm.bias, eps)

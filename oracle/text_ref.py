@@ -16,21 +16,23 @@ import torch.nn.functional as F
 from .vit_ref import _attention, _sub, openai_block
 
 
-def bert_layer(x, P, heads, key_mask_add, eps=1e-12):
-    """HF BertLayer, post-LN.  P keys relative to 'encoder.layer.{i}.'."""
+def bert_layer(x, P, heads, key_mask_add, eps=1e-12, lora=None):
+    """HF BertLayer, post-LN.  P keys relative to 'encoder.layer.{i}.'.  lora = dict(r, alpha): query/key/value/attention.output.dense
+    carry LinearLoRA factors `<name>.w_lora_A/B` where present (reference src/adapters/lora.py:317-367, --tune_text_encoder)."""
+    from .vit_ref import _maybe_lora_linear
     D = x.shape[-1]
-    q = F.linear(x, P["attention.self.query.weight"], P["attention.self.query.bias"])
-    k = F.linear(x, P["attention.self.key.weight"], P["attention.self.key.bias"])
-    v = F.linear(x, P["attention.self.value.weight"], P["attention.self.value.bias"])
+    q = _maybe_lora_linear(x, P, "attention.self.query", lora)
+    k = _maybe_lora_linear(x, P, "attention.self.key", lora)
+    v = _maybe_lora_linear(x, P, "attention.self.value", lora)
     a = _attention(q, k, v, heads, key_mask_add)
-    a = F.linear(a, P["attention.output.dense.weight"], P["attention.output.dense.bias"])
+    a = _maybe_lora_linear(a, P, "attention.output.dense", lora)
     x = F.layer_norm(x + a, (D,), P["attention.output.LayerNorm.weight"], P["attention.output.LayerNorm.bias"], eps)
     h = F.gelu(F.linear(x, P["intermediate.dense.weight"], P["intermediate.dense.bias"]))
     h = F.linear(h, P["output.dense.weight"], P["output.dense.bias"])
     return F.layer_norm(x + h, (D,), P["output.LayerNorm.weight"], P["output.LayerNorm.bias"], eps)
 
 
-def bert_hidden(ids, P, heads=12, prefix="text.transformer.", pad_id=0):
+def bert_hidden(ids, P, heads=12, prefix="text.transformer.", pad_id=0, lora=None):
     B, L = ids.shape
     e = P[prefix + "embeddings.word_embeddings.weight"][ids]
     e = e + P[prefix + "embeddings.position_embeddings.weight"][:L][None]
@@ -42,12 +44,12 @@ def bert_hidden(ids, P, heads=12, prefix="text.transformer.", pad_id=0):
     lp = prefix + "encoder.layer."
     depth = 1 + max(int(k[len(lp):].split(".")[0]) for k in P if k.startswith(lp))
     for i in range(depth):
-        x = bert_layer(x, _sub(P, f"{lp}{i}."), heads, mask_add)
+        x = bert_layer(x, _sub(P, f"{lp}{i}."), heads, mask_add, lora=lora)
     return x
 
 
-def bert_text_forward(ids, P, heads=12, prefix="text."):
-    x = bert_hidden(ids, P, heads, prefix + "transformer.")
+def bert_text_forward(ids, P, heads=12, prefix="text.", lora=None):
+    x = bert_hidden(ids, P, heads, prefix + "transformer.", lora=lora)
     pooled = x[:, 0]                                                   # cls_last_hidden_state_pooler
     h = F.gelu(F.linear(pooled, P[prefix + "proj.0.weight"]))
     return F.linear(h, P[prefix + "proj.2.weight"])

@@ -15,7 +15,7 @@ from . import losses_ref, vit_ref, text_ref
 
 def biomedclip_loss(P, images, ids, mona=None, lora=None, temperature=0.07, heads=12, text_heads=12):
     img = vit_ref.timm_vit_forward(images, P, heads=heads, mona=mona, lora=lora)
-    txt = text_ref.bert_text_forward(ids, P, heads=text_heads)
+    txt = text_ref.bert_text_forward(ids, P, heads=text_heads, lora=lora)      # LoRA factors in the text tower are used where present
     return losses_ref.info_nce(img, txt, temperature)
 
 

@@ -693,3 +693,56 @@ def test_global_batch_loss_with_one_rank_equals_local_loss():
         outs.append((float(loss), opt.p.clone()))
     # float atomics in the loss / weight-gradient reductions make two runs differ in the last bits
     assert abs(outs[0][0] - outs[1][0]) < 1e-6 * abs(outs[0][0]) and torch.allclose(outs[0][1], outs[1][1], rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_biomedclip_lora_in_both_towers_vs_oracle(mode):
+    """inject_lora_to_biomedclip(tune_text_encoder=True) (reference lora.py:317-367): LinearLoRA on BERT query/key/value/
+    attention.output.dense as well as the timm qkv/proj.  Tower features and every LoRA-factor gradient of a linear probe loss
+    against the oracle (text tower on the autograd-composed post-LN path)."""
+    from oracle import text_ref, vit_ref
+    from uia_hip import functional as UF
+    from src.adapters import inject_lora_to_biomedclip
+    from src.third_party.biomedclip.model import create_biomedclip
+    UF.set_compute_dtype(DT[mode])
+    g = torch.Generator().manual_seed(23)
+    model = create_biomedclip(config=TOY, seed=9)
+    for p in model.parameters():
+        p.requires_grad_(False)
+    model, n = inject_lora_to_biomedclip(model, lora_r=4, lora_alpha=8, lora_dropout=0.0, tune_text_encoder=True)
+    assert n == TOY["vision_cfg"]["depth"] + TOY["text_cfg"]["num_hidden_layers"]
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            if "lora" in k:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+            p.requires_grad_("lora" in k)                              # finetune.py:173-175 (the injected linears come back trainable)
+    model.eval()
+    images, ids = toy_batch(g)
+    di, dtx = torch.randn(images.shape[0], 128, generator=g), torch.randn(images.shape[0], 128, generator=g)
+    P = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    names = [k for k in P if "lora" in k]
+    assert any(k.startswith("text.transformer.encoder.layer.0.attention.self.query.w_lora_A") for k in names)
+    leaves = {k: P[k].clone().requires_grad_(True) for k in names}
+    Pq = dict(P); Pq.update(leaves)
+    lora = dict(r=4, alpha=8)
+    fr = vit_ref.timm_vit_forward(images, Pq, heads=2, lora=lora)
+    tr = text_ref.bert_text_forward(ids, Pq, heads=2, lora=lora)
+    ((fr * di).sum() + (tr * dtx).sum()).backward()
+    model = model.to(dev())
+    fi, ft = model.encode_image(images.to(dev())), model.encode_text(ids.to(dev()))
+    assert rel(fi, fr) < TOL[mode] and rel(ft, tr) < TOL[mode]
+    ((fi * di.to(dev())).sum() + (ft * dtx.to(dev())).sum()).backward()
+    check_grads(model, leaves, mode)
+
+
+def test_finetune_entry_point_with_text_lora(tmp_path, monkeypatch):
+    from src.models.biomedclip import finetune
+    monkeypatch.chdir(tmp_path)
+    cfg = ("dict(embed_dim=128, vision_cfg=dict(img_size=32, patch_size=8, embed_dim=128, depth=2, num_heads=2), "
+           "text_cfg=dict(vocab_size=30000, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, max_position_embeddings=64))")
+    out = finetune.main(["--method", "lora", "--tune_text_encoder", "--lora_r", "4", "--lora_alpha", "8", "--synthetic", "--synthetic_train", "32",
+                         "--synthetic_val", "16", "--img_size", "32", "--batch_size", "16", "--accumulation_steps", "1", "--epochs", "2", "--lr", "2e-3",
+                         "--dtype", "bf16", "--exp", "tl", "--model_config", cfg])
+    ck = torch.load(tmp_path / "runs" / "tl" / "best_model.pth", map_location="cpu")
+    assert any(k.startswith("text.transformer.encoder.layer.1.attention.output.dense.w_lora_B") for k in ck) and all("lora" in k for k in ck)
+    assert out["updates"] == 4 and math.isfinite(out["best_val"])
