@@ -9,8 +9,9 @@ has no network), and data parallelism when launched under torch.distributed.run 
 all-reduce of the flat adapter-gradient buffer per optimiser update ≡ the reference's accumulation).
 
 What differs underneath: encode_image / encode_text / loss / backward / optimiser run in libuia_hip.so (uia_hip.*).
-`--method full` (the reference's default, which trains every backbone weight) needs weight gradients of the frozen-path
-kernels and is not on this path: it raises.
+`--method full` (the reference's default): the image tower trains through op-level functions with `uia_wgrad` weight gradients
+(all blocks or --tune_layers last3/6/9, lr forced to 1e-6 as in reference :153-155, whole state dict checkpointed); together with
+--tune_text_encoder it would train the BERT weights, which this path does not do (raises; LoRA in the text tower is supported).
 """
 import argparse
 import logging
@@ -83,9 +84,32 @@ def prepare_model(args):
     model = create_biomedclip(state_dict=state, config=cfg, seed=args.seed)
     tokenizer = SyntheticTokenizer(256 if cfg is None else cfg["text_cfg"]["max_position_embeddings"])
     model.float()
-    if args.method == "full":
-        raise NotImplementedError("--method full trains the backbone weights; the HIP path implements the adapter methods "
-                                  "(--method mona | lora) named by the fine-tune hot path")
+    if args.method == "full":                                    # reference :134-157
+        if args.tune_text_encoder:
+            raise NotImplementedError("--method full --tune_text_encoder trains the BERT weights and embeddings; on the HIP path the text "
+                                      "tower trains LoRA factors only (--method lora --tune_text_encoder)")
+        for p in model.text.parameters():
+            p.requires_grad = False
+        logging.info("Text encoder frozen")
+        if args.tune_layers != "all":
+            blocks = model.visual.trunk.blocks
+            for p in model.visual.parameters():
+                p.requires_grad = False
+            layers = {"last3": 3, "last6": 6, "last9": 9}.get(args.tune_layers, 0)
+            for i in range(len(blocks) - layers, len(blocks)):
+                for p in blocks[i].parameters():
+                    p.requires_grad = True
+            logging.info(f"Tuning ViT layers {len(blocks) - layers}-{len(blocks) - 1} ({layers}/{len(blocks)} layers)")
+        if args.lr > 1e-5:
+            args.lr = 1e-6
+            logging.info(f"Adjusted learning rate to {args.lr} for full fine-tuning")
+        if hasattr(model, "logit_scale"):
+            model.logit_scale.requires_grad = False              # not used by the InfoNCE loss (fixed temperature): no gradient ever reaches it
+        model.to(args.device)
+        tr = sum(p.numel() for p in model.parameters() if p.requires_grad)
+        tot = sum(p.numel() for p in model.parameters())
+        logging.info(f"Trainable parameters: {tr:,} / {tot:,} ({100 * tr / tot:.2f}%)")
+        return model, tokenizer
     for p in model.parameters():
         p.requires_grad = False
     if args.method == "mona":
@@ -108,6 +132,9 @@ def prepare_model(args):
 
 
 def _save_checkpoint(model, args, save_path):
+    if args.method == "full":                                    # reference :200-208: the whole state dict
+        torch.save(model.state_dict(), save_path)
+        return
     key = "mona" if args.method == "mona" else "lora"
     torch.save({n: p.data.clone() for n, p in model.named_parameters() if key in n.lower()}, save_path)
 

@@ -881,3 +881,96 @@ def post_ln_layer_train(x32, x_t, L, B, heads, layer, keylen, eps=1e-12):
     f = lin(layer.intermediate.dense, x_t, act="gelu")
     s = lin(layer.output.dense, f, resid32=x32)
     return PostLayerNormFn.apply(s, layer.output.LayerNorm.weight, layer.output.LayerNorm.bias, eps)
+
+
+# ------------------------------------------------------------------------------------------------ full fine-tuning of the image tower
+# (reference biomedclip/finetune.py:134-157, --method full — its argparse default).  Frozen-backbone blocks keep the fused
+# VitBlockFn; a block with trainable weights is the same arithmetic composed of the trainable op-level functions
+# (LayerNormAffineFn, LinearTrainFn with uia_wgrad, attention): correct first, not tuned — the headline path is the adapters.
+class AttentionQkvFn(torch.autograd.Function):
+    """Fused-projection attention: qkv [M, 3D] T → [M, D]; the backward writes dq | dk | dv into one [M, 3D] tensor."""
+
+    @staticmethod
+    def forward(ctx, qkv, B, H, L, mask):
+        D = H * 64
+        out = _empty((B * L, D), qkv.dtype, qkv)
+        need = ctx.needs_input_grad[0]
+        lse = torch.empty(B, H, L, device=qkv.device, dtype=torch.float32) if need else None
+        ops.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], out, B, H, L, lse=lse, mask=mask)
+        if need:
+            ctx.save_for_backward(qkv, out, lse)
+            ctx.meta = (B, H, L, mask)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, lse = ctx.saved_tensors
+        B, H, L, mask = ctx.meta
+        D = H * 64
+        dqkv = torch.empty_like(qkv)
+        ops.attn_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], out, dout.contiguous(), lse, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], B, H, L, mask=mask)
+        return dqkv, None, None, None, None
+
+
+def trainable_vit_block(x, heads, eps, act, ln1, qkv, proj, ln2, fc1, fc2, mask=None):
+    """x [B, N, D] fp32 → [B, N, D]; every (weight, bias) pair may require grad."""
+    B, N, D = x.shape
+    M = B * N
+    xr = x.contiguous().view(M, D)
+    h = LayerNormAffineFn.apply(xr, ln1[0], ln1[1], eps)
+    q = LinearTrainFn.apply(CastFn.apply(h), qkv[0], qkv[1], None, None, False)
+    a = AttentionQkvFn.apply(q, B, heads, N, mask)
+    x1 = LinearTrainFn.apply(a, proj[0], proj[1], None, xr, True)
+    h2 = LayerNormAffineFn.apply(x1, ln2[0], ln2[1], eps)
+    f = LinearTrainFn.apply(CastFn.apply(h2), fc1[0], fc1[1], act, None, False)
+    x2 = LinearTrainFn.apply(f, fc2[0], fc2[1], None, x1, True)
+    return x2.view(B, N, D)
+
+
+class PatchEmbedTrainFn(torch.autograd.Function):
+    """PatchEmbedFn with gradients for the projection weight/bias, the class token and the position embedding."""
+
+    @staticmethod
+    def forward(ctx, images, conv_w, conv_b, cls, pos, patch):
+        dt = compute_dtype()
+        B, C, H, W = images.shape
+        G = (H // patch) * (W // patch)
+        D = conv_w.shape[0]
+        K = C * patch * patch
+        gran = 64                                               # uia_wgrad needs both extents in multiples of 64
+        Kp = (K + gran - 1) // gran * gran
+        cols = _empty((B * G, Kp), dt, images)
+        ops.im2col(images.contiguous().float(), cols, patch)
+        x = torch.empty(B, G + 1, D, device=images.device, dtype=torch.float32)
+        pos2d = pos.detach().reshape(G + 1, D).contiguous()
+        ops.gemm(cols, WEIGHTS.get(conv_w, dt, pad_cols_to=Kp), bias=conv_b, resid=pos2d, resid_mod=G, resid_row_off=1, out_group=G, out32=x.view(-1, D))
+        ops.fill_cls(x, cls.detach().reshape(D).contiguous(), pos2d[0])
+        ctx.save_for_backward(cols)
+        ctx.meta = (conv_w.shape, conv_b is not None, cls.shape, pos.shape, K, Kp)
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        (cols,) = ctx.saved_tensors
+        wshape, has_bias, cshape, pshape, K, Kp = ctx.meta
+        B, N, D = dx.shape
+        G = N - 1
+        dt = cols.dtype
+        dx = dx.contiguous()
+        dtok = dx[:, 1:, :].contiguous().view(B * G, D)
+        dtok_t = dtok if dt == torch.float32 else torch.empty(B * G, D, device=dx.device, dtype=dt)
+        if dt != torch.float32:
+            ops.cast(dtok, dtok_t)
+        dW = torch.zeros(D, Kp, device=dx.device, dtype=torch.float32)
+        db = torch.zeros(D, device=dx.device, dtype=torch.float32) if has_bias else None
+        ops.wgrad(dtok_t, cols, dW, db)
+        dpos = torch.zeros(N * D, device=dx.device, dtype=torch.float32)
+        ops.colsum(dx.view(B, N * D), dpos)                      # Σ over the batch: position-embedding gradient; row 0 is also d cls
+        return None, dW[:, :K].contiguous().view(wshape), db, dpos[:D].clone().view(cshape), dpos.view(pshape), None
+
+
+def trainable_cls_head(tokens, ln_w, ln_b, eps, proj_w):
+    """feat = LN(tokens[:, 0]) @ proj_wᵀ with trainable norm and projection (timm head)."""
+    cls = tokens[:, 0, :].contiguous()
+    h = LayerNormAffineFn.apply(cls, ln_w, ln_b, eps)
+    return LinearTrainFn.apply(CastFn.apply(h), proj_w, None, None, None, True)

@@ -746,3 +746,55 @@ def test_finetune_entry_point_with_text_lora(tmp_path, monkeypatch):
     ck = torch.load(tmp_path / "runs" / "tl" / "best_model.pth", map_location="cpu")
     assert any(k.startswith("text.transformer.encoder.layer.1.attention.output.dense.w_lora_B") for k in ck) and all("lora" in k for k in ck)
     assert out["updates"] == 4 and math.isfinite(out["best_val"])
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("tune", ["all", "last1"])
+def test_full_finetune_image_tower_vs_oracle(mode, tune):
+    """--method full (reference finetune.py:134-157): every image-tower parameter (or only the last block's) trains; features and
+    all those gradients — patch projection, class token, position embedding, LayerNorm affines, qkv/proj/fc1/fc2, final norm,
+    head — against the oracle's autograd.  Blocks that stay frozen keep the fused path."""
+    from oracle import vit_ref
+    from uia_hip import functional as UF
+    from src.third_party.biomedclip.model import create_biomedclip
+    UF.set_compute_dtype(DT[mode])
+    g = torch.Generator().manual_seed(29)
+    model = create_biomedclip(config=TOY, seed=13)
+    randomize(model.visual, g, 0.05)
+    for k, p in model.named_parameters():
+        if tune == "all":
+            p.requires_grad_(k.startswith("visual."))
+        else:
+            p.requires_grad_(k.startswith(f"visual.trunk.blocks.{TOY['vision_cfg']['depth'] - 1}."))
+    model.eval()
+    images, _ = toy_batch(g)
+    di = torch.randn(images.shape[0], 128, generator=g)
+    P = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    names = [k for k, p in model.named_parameters() if p.requires_grad]
+    assert (len(names) > 30) if tune == "all" else all(".blocks.2." in k for k in names)
+    leaves = {k: P[k].clone().requires_grad_(True) for k in names}
+    Pq = dict(P); Pq.update(leaves)
+    fr = vit_ref.timm_vit_forward(images, Pq, heads=2)
+    (fr * di).sum().backward()
+    model = model.to(dev())
+    fi = model.encode_image(images.to(dev()))
+    assert rel(fi, fr) < TOL[mode]
+    (fi * di.to(dev())).sum().backward()
+    if mode == "fp32":
+        check_grads(model, leaves, mode)
+    else:   # bf16 operands through three blocks: direction and size of the whole gradient (per-tensor exactness is the fp32 case)
+        a = torch.cat([p.grad.detach().float().cpu().flatten() for k, p in model.named_parameters() if p.requires_grad])
+        b = torch.cat([leaves[k].grad.flatten() for k, p in model.named_parameters() if p.requires_grad])
+        assert float(torch.dot(a, b) / (a.norm() * b.norm())) > 0.995 and float((a - b).norm() / b.norm()) < 0.1
+
+
+def test_finetune_entry_point_default_method_full(tmp_path, monkeypatch):
+    """`finetune.py` with the reference's default --method full: lr forced to 1e-6, text frozen, whole state dict saved."""
+    from src.models.biomedclip import finetune
+    monkeypatch.chdir(tmp_path)
+    cfg = ("dict(embed_dim=128, vision_cfg=dict(img_size=32, patch_size=8, embed_dim=128, depth=2, num_heads=2), "
+           "text_cfg=dict(vocab_size=30000, hidden_size=128, num_hidden_layers=1, num_attention_heads=2, intermediate_size=256, max_position_embeddings=64))")
+    out = finetune.main(["--tune_layers", "last3", "--synthetic", "--synthetic_train", "32", "--synthetic_val", "16", "--img_size", "32", "--batch_size", "16",
+                         "--accumulation_steps", "2", "--epochs", "1", "--dtype", "bf16", "--exp", "full", "--model_config", cfg])
+    ck = torch.load(tmp_path / "runs" / "full" / "best_model.pth", map_location="cpu")
+    assert "visual.trunk.blocks.0.attn.qkv.weight" in ck and "text.proj.0.weight" in ck and out["updates"] == 1
