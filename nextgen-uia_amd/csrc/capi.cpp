@@ -122,4 +122,8 @@ int uia_im2col_padded(void* stream, int dtype, int B, int C, int H, int W, int P
     return uia_im2col_padded_launch((hipStream_t)stream, dtype, B, C, H, W, P, img, cols, (long)ldo);
 }
 
+int uia_embed_bwd(void* stream, int rows, int D, const int64_t* ids, const float* dx, float* dtable, int64_t pad_id) {
+    return uia_embed_bwd_launch((hipStream_t)stream, rows, D, ids, dx, dtable, (long)pad_id);
+}
+
 }  // extern "C"

@@ -89,6 +89,15 @@ __global__ void embed_kernel(int rows, int L, int D, const int64_t* __restrict__
     }
 }
 
+// d table[ids[r]] += dx[r]   (nn.Embedding backward; rows whose id is `pad_id` contribute nothing: padding_idx semantics)
+__global__ void embed_bwd_kernel(int rows, int D, const int64_t* __restrict__ ids, const float* __restrict__ dx, float* __restrict__ dtable, long pad_id) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)rows * D; i += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / D), c = (int)(i % D);
+        const int64_t id = ids[r];
+        if (id != pad_id) atomicAdd(dtable + (size_t)id * D + c, dx[i]);
+    }
+}
+
 __global__ void gather_rows_kernel(int n, int D, const float* __restrict__ src, const int64_t* __restrict__ idx, float* __restrict__ dst) {
     const int D4 = D >> 2;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)n * D4; i += (size_t)gridDim.x * blockDim.x) {
@@ -197,6 +206,13 @@ int uia_fill_cls_launch(hipStream_t stream, int B, int N, int D, const float* cl
 int uia_embed_launch(hipStream_t stream, int rows, int L, int D, const int64_t* ids, const float* table, const float* pos, const float* type0, float* out) {
     UIA_CHECK_ARG(rows > 0 && L > 0 && D % 4 == 0 && ids && table && pos && out, "uia_embed: bad arguments");
     hipLaunchKernelGGL(embed_kernel, dim3(grid_for((size_t)rows * D / 4, 256)), dim3(256), 0, stream, rows, L, D, ids, table, pos, type0, out);
+    UIA_CHECK_LAUNCH();
+    return 0;
+}
+
+int uia_embed_bwd_launch(hipStream_t stream, int rows, int D, const int64_t* ids, const float* dx, float* dtable, long pad_id) {
+    UIA_CHECK_ARG(rows > 0 && D > 0 && ids && dx && dtable, "uia_embed_bwd: bad arguments");
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid_for((size_t)rows * D, 256)), dim3(256), 0, stream, rows, D, ids, dx, dtable, pad_id);
     UIA_CHECK_LAUNCH();
     return 0;
 }

@@ -10,8 +10,8 @@ all-reduce of the flat adapter-gradient buffer per optimiser update ≡ the refe
 
 What differs underneath: encode_image / encode_text / loss / backward / optimiser run in libuia_hip.so (uia_hip.*).
 `--method full` (the reference's default): the image tower trains through op-level functions with `uia_wgrad` weight gradients
-(all blocks or --tune_layers last3/6/9, lr forced to 1e-6 as in reference :153-155, whole state dict checkpointed); together with
---tune_text_encoder it would train the BERT weights, which this path does not do (raises; LoRA in the text tower is supported).
+(all blocks or --tune_layers last3/6/9, lr forced to 1e-6 as in reference :153-155, whole state dict checkpointed); with
+--tune_text_encoder the BERT weights, LayerNorms and embedding tables train as well (`uia_embed_bwd`).
 """
 import argparse
 import logging
@@ -85,12 +85,10 @@ def prepare_model(args):
     tokenizer = SyntheticTokenizer(256 if cfg is None else cfg["text_cfg"]["max_position_embeddings"])
     model.float()
     if args.method == "full":                                    # reference :134-157
-        if args.tune_text_encoder:
-            raise NotImplementedError("--method full --tune_text_encoder trains the BERT weights and embeddings; on the HIP path the text "
-                                      "tower trains LoRA factors only (--method lora --tune_text_encoder)")
-        for p in model.text.parameters():
-            p.requires_grad = False
-        logging.info("Text encoder frozen")
+        if not args.tune_text_encoder:
+            for p in model.text.parameters():
+                p.requires_grad = False
+            logging.info("Text encoder frozen")
         if args.tune_layers != "all":
             blocks = model.visual.trunk.blocks
             for p in model.visual.parameters():

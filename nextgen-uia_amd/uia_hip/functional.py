@@ -862,25 +862,65 @@ class PostLayerNormFn(torch.autograd.Function):
         return ds, None, None, None
 
 
-def post_ln_layer_train(x32, x_t, L, B, heads, layer, keylen, eps=1e-12):
-    """HF BertLayer (post-LN) with autograd: q/k/v/attention.output.dense may be LinearLoRA modules (reference
-    lora.py:317-367, --tune_text_encoder), everything else is frozen.  Returns the new (fp32, T) residual pair."""
+class EmbedFn(torch.autograd.Function):
+    """BERT embedding sum word[ids] + position[:L] + token_type[0] → fp32 rows [B·L, D], with gradients for the three tables
+    (nn.Embedding padding_idx semantics for the word table)."""
+
+    @staticmethod
+    def forward(ctx, ids, word, pos, typ, pad_id):
+        B, L = ids.shape
+        D = word.shape[1]
+        x = torch.empty(B * L, D, device=ids.device, dtype=torch.float32)
+        ops.embed(ids, word.detach(), pos.detach(), typ.detach()[0].contiguous(), x)
+        ctx.save_for_backward(ids)
+        ctx.meta = (word.shape, pos.shape, typ.shape, pad_id, B, L, D)
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        (ids,) = ctx.saved_tensors
+        wshape, pshape, tshape, pad_id, B, L, D = ctx.meta
+        dx = dx.contiguous()
+        dword = torch.zeros(wshape, device=dx.device, dtype=torch.float32)
+        ops.embed_bwd(ids, dx, dword, pad_id)
+        dpos = torch.zeros(pshape, device=dx.device, dtype=torch.float32)
+        ops.colsum(dx.view(B, L * D), dpos.view(-1)[:L * D])             # Σ over the batch per position
+        dtyp = torch.zeros(tshape, device=dx.device, dtype=torch.float32)
+        ops.colsum(dx, dtyp[0])                                            # every token has type 0
+        return None, dword, dpos, dtyp, None
+
+
+def _train_lin(mod, rows, resid32=None, act=None):
+    """One Linear of the trainable text path: LoRA module, trainable plain Linear, or frozen."""
     from src.adapters.lora import LinearLoRA
+    if isinstance(mod, LinearLoRA):
+        assert act is None
+        return mod.apply_rows(rows, resid32)
+    if mod.weight.requires_grad or (mod.bias is not None and mod.bias.requires_grad):
+        return LinearTrainFn.apply(rows, mod.weight, mod.bias, act, resid32, False)
+    return FrozenLinearFn.apply(rows, mod.weight, mod.bias, act, resid32)
+
+
+def _train_post_ln(s32, ln, eps):
+    """LayerNorm of a post-LN sub-layer → (fp32 residual, T operand); trainable affine when it requires grad."""
+    if ln.weight.requires_grad or ln.bias.requires_grad:
+        y32 = LayerNormAffineFn.apply(s32, ln.weight, ln.bias, eps)
+        return y32, CastFn.apply(y32)
+    return PostLayerNormFn.apply(s32, ln.weight, ln.bias, eps)
+
+
+def post_ln_layer_train(x32, x_t, L, B, heads, layer, keylen, eps=1e-12):
+    """HF BertLayer (post-LN) with autograd: q/k/v/attention.output.dense may be LinearLoRA modules (reference lora.py:317-367,
+    --tune_text_encoder) and any Linear / LayerNorm may itself be trainable (--method full --tune_text_encoder); the rest is
+    frozen.  Returns the new (fp32, T) residual pair."""
     sa, ao = layer.attention.self, layer.attention.output
-
-    def lin(mod, rows, resid32=None, act=None):
-        if isinstance(mod, LinearLoRA):
-            assert act is None
-            return mod.apply_rows(rows, resid32)
-        return FrozenLinearFn.apply(rows, mod.weight, mod.bias, act, resid32)
-
-    q, k, v = lin(sa.query, x_t), lin(sa.key, x_t), lin(sa.value, x_t)
+    q, k, v = _train_lin(sa.query, x_t), _train_lin(sa.key, x_t), _train_lin(sa.value, x_t)
     a = AttentionFn.apply(q, k, v, B, heads, L, ("keypad", keylen))
-    s = lin(ao.dense, a, resid32=x32)
-    x32, x_t = PostLayerNormFn.apply(s, ao.LayerNorm.weight, ao.LayerNorm.bias, eps)
-    f = lin(layer.intermediate.dense, x_t, act="gelu")
-    s = lin(layer.output.dense, f, resid32=x32)
-    return PostLayerNormFn.apply(s, layer.output.LayerNorm.weight, layer.output.LayerNorm.bias, eps)
+    s = _train_lin(ao.dense, a, resid32=x32)
+    x32, x_t = _train_post_ln(s, ao.LayerNorm, eps)
+    f = _train_lin(layer.intermediate.dense, x_t, act="gelu")
+    s = _train_lin(layer.output.dense, f, resid32=x32)
+    return _train_post_ln(s, layer.output.LayerNorm, eps)
 
 
 # ------------------------------------------------------------------------------------------------ full fine-tuning of the image tower

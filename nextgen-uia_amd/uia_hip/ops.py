@@ -219,6 +219,12 @@ def embed(ids, table, pos, type0, out):
     check(lib().uia_embed(_stream(), rows, L, table.shape[1], _p(ids), _p(table), _p(pos), _p(type0), _p(out)), "uia_embed")
 
 
+def embed_bwd(ids, dx, dtable, pad_id=-1):
+    """dtable[ids[r]] += dx[r] for every row r with ids[r] != pad_id (dtable fp32, caller-zeroed or accumulating)."""
+    assert ids.dtype == torch.int64 and ids.is_contiguous() and dx.dtype == dtable.dtype == torch.float32 and dx.is_contiguous() and dtable.is_contiguous()
+    check(lib().uia_embed_bwd(_stream(), ids.numel(), dx.shape[-1], _p(ids), _p(dx), _p(dtable), pad_id), "uia_embed_bwd")
+
+
 def gather_rows(src, idx, dst):
     assert idx.dtype == torch.int64
     check(lib().uia_gather_rows(_stream(), idx.numel(), src.shape[-1], _p(src), _p(idx), _p(dst)), "uia_gather_rows")

@@ -34,7 +34,7 @@ def bert_layer(x, P, heads, key_mask_add, eps=1e-12, lora=None):
 
 def bert_hidden(ids, P, heads=12, prefix="text.transformer.", pad_id=0, lora=None):
     B, L = ids.shape
-    e = P[prefix + "embeddings.word_embeddings.weight"][ids]
+    e = F.embedding(ids, P[prefix + "embeddings.word_embeddings.weight"], padding_idx=pad_id)   # HF: nn.Embedding(..., padding_idx=pad_token_id)
     e = e + P[prefix + "embeddings.position_embeddings.weight"][:L][None]
     e = e + P[prefix + "embeddings.token_type_embeddings.weight"][0][None, None]
     D = e.shape[-1]

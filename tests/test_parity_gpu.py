@@ -798,3 +798,54 @@ def test_finetune_entry_point_default_method_full(tmp_path, monkeypatch):
                          "--accumulation_steps", "2", "--epochs", "1", "--dtype", "bf16", "--exp", "full", "--model_config", cfg])
     ck = torch.load(tmp_path / "runs" / "full" / "best_model.pth", map_location="cpu")
     assert "visual.trunk.blocks.0.attn.qkv.weight" in ck and "text.proj.0.weight" in ck and out["updates"] == 1
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_full_finetune_text_tower_vs_oracle(mode):
+    """--method full --tune_text_encoder: every text-tower parameter trains — word / position / token-type embeddings (word row 0
+    is the padding index: zero gradient), embedding and sub-layer LayerNorms, all BERT linears, the MLP projection — against the
+    oracle's autograd."""
+    from oracle import text_ref
+    from uia_hip import functional as UF
+    from src.third_party.biomedclip.model import create_biomedclip
+    UF.set_compute_dtype(DT[mode])
+    g = torch.Generator().manual_seed(37)
+    model = create_biomedclip(config=TOY, seed=17)
+    randomize(model.text, g, 0.05)
+    for k, p in model.named_parameters():
+        p.requires_grad_(k.startswith("text."))
+    model.eval()
+    _, ids = toy_batch(g)
+    dtx = torch.randn(ids.shape[0], 128, generator=g)
+    P = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    names = [k for k, p in model.named_parameters() if p.requires_grad]
+    assert "text.transformer.embeddings.word_embeddings.weight" in names and len(names) > 30
+    leaves = {k: P[k].clone().requires_grad_(True) for k in names}
+    Pq = dict(P); Pq.update(leaves)
+    tr = text_ref.bert_text_forward(ids, Pq, heads=2)
+    (tr * dtx).sum().backward()
+    for k in names:
+        if leaves[k].grad is None:                         # token_type row 1, unused position rows: zero by construction
+            leaves[k].grad = torch.zeros_like(leaves[k])
+    model = model.to(dev())
+    ft = model.encode_text(ids.to(dev()))
+    assert rel(ft, tr) < TOL[mode]
+    (ft * dtx.to(dev())).sum().backward()
+    wg = model.text.transformer.embeddings.word_embeddings.weight.grad
+    assert float(wg[0].abs().max()) == 0.0                 # padding_idx row
+    if mode == "fp32":
+        check_grads(model, leaves, mode)
+    else:
+        a = torch.cat([p.grad.detach().float().cpu().flatten() for k, p in model.named_parameters() if p.requires_grad])
+        b = torch.cat([leaves[k].grad.flatten() for k, p in model.named_parameters() if p.requires_grad])
+        assert float(torch.dot(a, b) / (a.norm() * b.norm())) > 0.995 and float((a - b).norm() / b.norm()) < 0.1
+
+
+def test_finetune_entry_point_full_with_text_encoder(tmp_path, monkeypatch):
+    from src.models.biomedclip import finetune
+    monkeypatch.chdir(tmp_path)
+    cfg = ("dict(embed_dim=128, vision_cfg=dict(img_size=32, patch_size=8, embed_dim=128, depth=2, num_heads=2), "
+           "text_cfg=dict(vocab_size=30000, hidden_size=128, num_hidden_layers=1, num_attention_heads=2, intermediate_size=256, max_position_embeddings=64))")
+    out = finetune.main(["--method", "full", "--tune_text_encoder", "--synthetic", "--synthetic_train", "32", "--synthetic_val", "16", "--img_size", "32",
+                         "--batch_size", "16", "--accumulation_steps", "1", "--epochs", "1", "--dtype", "bf16", "--exp", "fullt", "--model_config", cfg])
+    assert out["updates"] == 2 and math.isfinite(out["best_val"])
