@@ -285,3 +285,42 @@ def test_patch_embed_patch14(dt):
     ref = torch.cat([cls.expand(B, 1, D), ref], 1) + pos
     x = UF.PatchEmbedFn.apply(img.to(dev()), w.to(dev()), None, cls.to(dev()), pos.to(dev()), P)
     assert rel(x.cpu(), ref) < (2e-5 if dt == torch.float32 else 1e-2)
+
+
+def test_error_behaviour_is_loud_and_specific(ops):
+    """The C ABI returns a negative code with a message, surfaced as UiaError: misaligned K, empty problems, CPU tensors, a tile
+    config that does not exist, an unsupported attention length — none of them falls back to anything."""
+    from uia_hip._lib import UiaError
+    a = torch.randn(64, 48, device=dev()).bfloat16()          # K = 48 is not a multiple of 64 for bf16
+    w = torch.randn(64, 48, device=dev()).bfloat16()
+    y = torch.empty(64, 64, device=dev(), dtype=torch.bfloat16)
+    with pytest.raises(UiaError, match="K=48"):
+        ops.gemm(a, w, out_t=y)
+    a, w = torch.randn(64, 64, device=dev()).bfloat16(), torch.randn(64, 64, device=dev()).bfloat16()
+    with pytest.raises(UiaError, match="unknown tile config"):
+        ops.gemm(a, w, out_t=y, tile_cfg=99)
+    with pytest.raises(UiaError, match="no output"):
+        ops.gemm(a, w)
+    with pytest.raises(UiaError):
+        ops.gemm(a.cpu(), w.cpu(), out_t=y.cpu())
+    qkv = torch.randn(2 * 300, 3 * 64, device=dev()).bfloat16()
+    out = torch.empty(2 * 300, 64, device=dev(), dtype=torch.bfloat16)
+    with pytest.raises(UiaError, match="L=300"):
+        ops.attn_fwd(qkv[:, :64], qkv[:, 64:128], qkv[:, 128:], out, 2, 1, 300)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_single_row_and_single_image_edges(ops, dt):
+    """M = 1 GEMM row, one image with one head and a one-token key-padding length."""
+    torch.manual_seed(3)
+    a = torch.randn(1, 128, device=dev()).to(dt)
+    w = (torch.randn(72, 128, device=dev()) * 0.1).to(dt)
+    y = torch.empty(1, 72, device=dev())
+    ops.gemm(a, w, out32=y)
+    assert rel(y, a.float() @ w.float().T) < (2e-5 if dt == torch.float32 else 2e-5)
+    L = 9
+    qkv = torch.randn(L, 192, device=dev()).to(dt)
+    out = torch.empty(L, 64, device=dev(), dtype=dt)
+    keylen = torch.tensor([1], device=dev(), dtype=torch.int32)
+    ops.attn_fwd(qkv[:, :64], qkv[:, 64:128], qkv[:, 128:], out, 1, 1, L, mask="keypad", keylen=keylen)
+    assert rel(out, qkv[:1, 128:].float().expand(L, 64)) < TOL[dt]      # every query attends to the single valid key
