@@ -48,7 +48,7 @@ __device__ __forceinline__ f32x4 mma(const uint4& a, const uint4& b, f32x4 c) {
 // K, Q, dO tiles share one image: [rows][128 B], 16-B chunk c of row r stored at chunk c ^ ((r>>1)&7).
 // dSᵀ tile: [keys][64 B] (32 queries of the current block), 8-B chunk c of row r stored at chunk c ^ ((r>>1)&7).
 constexpr int BWD_WAVES = 8;
-__host__ __device__ constexpr int bwd_lds_bytes(int LPK) { return 3 * LPK * 128 + LPK * 64 + 2 * LPK * 4; }
+__host__ __device__ constexpr int bwd_lds_bytes(int LPK) { return 3 * LPK * 128 + 2 * LPK * 64 + 2 * LPK * 4; }
 
 template <int LT_MAX>
 __global__ __launch_bounds__(64 * BWD_WAVES) void attn_bwd_bf16_kernel(const UiaAttnParams p) {
@@ -59,8 +59,8 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void attn_bwd_bf16_kernel(const Uia
     char* Ks = smem;
     char* Qs = Ks + LPK * 128;
     char* Gs = Qs + LPK * 128;                     // dO
-    char* dST = Gs + LPK * 128;                    // [LPK keys][32 queries] bf16
-    float* lse2 = (float*)(dST + LPK * 64);        // [LPK] lse in base-2 units
+    char* dST0 = Gs + LPK * 128;                   // 2 × [LPK keys][32 queries] bf16: block u writes buffer u&1 while dQ of block u-1 reads the other
+    float* lse2 = (float*)(dST0 + 2 * LPK * 64);   // [LPK] lse in base-2 units
     float* dls = lse2 + LPK;                       // [LPK] δ·scale
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -115,7 +115,10 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void attn_bwd_bf16_kernel(const Uia
         dls[r] = d * p.scale;
         lse2[r] = l2;
     }
-    for (int i = tid; i < (LPK - 16 * LT) * 4; i += 64 * BWD_WAVES) *(uint4*)(dST + 16 * LT * 64 + i * 16) = uint4{0u, 0u, 0u, 0u};
+    for (int i = tid; i < (LPK - 16 * LT) * 4; i += 64 * BWD_WAVES) {
+        *(uint4*)(dST0 + 16 * LT * 64 + i * 16) = uint4{0u, 0u, 0u, 0u};
+        *(uint4*)(dST0 + LPK * 64 + 16 * LT * 64 + i * 16) = uint4{0u, 0u, 0u, 0u};
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -148,8 +151,13 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void attn_bwd_bf16_kernel(const Uia
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) { dVt[a][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dKt[a][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
+    // Software pipeline over the 32-query blocks: iteration u computes S/dP/dS (and dV, dK) of block u into dSᵀ buffer u&1 and, in the
+    // same barrier interval, dQ of block u-1 from the other buffer: one barrier per block, and the two kinds of work interleave.
 #pragma unroll 1
-    for (int u = 0; u < NP; ++u) {
+    for (int u = 0; u <= NP; ++u) {
+        char* dST = dST0 + (u & 1) * LPK * 64;
+        const char* dSTr = dST0 + ((u + 1) & 1) * LPK * 64;
+        if (u < NP) {
         // per-lane query rows of this 32-query block: q(hq, r) = 32u + 16hq + 4g + r
         f32x4 ls[2], dl[2];
 #pragma unroll
@@ -192,6 +200,12 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void attn_bwd_bf16_kernel(const Uia
                     s[hq] = mma(qf[hq][1], kf[a][1], s[hq]);
                     dp[hq] = mma(gf[hq][1], vf[a][1], dp[hq]);
                 }
+#ifdef ABWD_NO_VALU
+                if (true) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { pf[e] = (bf16_t)s[e >> 2][e & 3]; sf[e] = (bf16_t)dp[e >> 2][e & 3]; }
+                } else
+#endif
                 if (full_q && 16 * kt + 16 <= L) {       // interior tile, no mask: no per-element tests
 #pragma unroll
                     for (int hq = 0; hq < 2; ++hq)
@@ -224,17 +238,23 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void attn_bwd_bf16_kernel(const Uia
                     *(bf16x4_t*)(rowp + (((0 + g) ^ sw) << 3)) = bf16x4_t{sf[0], sf[1], sf[2], sf[3]};
                     *(bf16x4_t*)(rowp + (((4 + g) ^ sw) << 3)) = bf16x4_t{sf[4], sf[5], sf[6], sf[7]};
                 }
+#ifndef ABWD_NO_DVDK
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
                     dVt[a][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gT[dt], pf, dVt[a][dt], 0, 0, 0);
                     dKt[a][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT[dt], sf, dKt[a][dt], 0, 0, 0);
                 }
+#endif
             }
         }
-        __syncthreads();
-        // ---- dQᵀ[d][q] = Σ_key Kᵀ[d][key] · dSᵀ[key][q]; wave w → query tile hq = w>>2, d-tile w&3.
+        }
+        // ---- dQᵀ[d][q] = Σ_key Kᵀ[d][key] · dSᵀ[key][q] of the PREVIOUS block; wave w → query tile hq = w>>2, d-tile w&3.
         //      Both operands are transpose reads: Kᵀ from the K tile, dSᵀ columns from the [key][query] tile.
-        {
+#ifndef ABWD_NO_DQ
+        if (u > 0) {
+#else
+        if (false) {
+#endif
             const int hq = wave >> 2, dt = wave & 3;
             f32x4 dq = f32x4{0.f, 0.f, 0.f, 0.f};
             const int ch = 2 * dt + (pp >> 1);
@@ -242,11 +262,11 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void attn_bwd_bf16_kernel(const Uia
             for (int kbk = 0; kbk < NP; ++kbk) {
                 const char* klo = Ks + (32 * kbk + nrow) * 128 + ((ch ^ nsw_lo) << 4) + 8 * (pp & 1);
                 const char* khi = Ks + (32 * kbk + nrow + 4) * 128 + ((ch ^ nsw_hi) << 4) + 8 * (pp & 1);
-                const char* slo = dST + (32 * kbk + nrow) * 64 + ((c8 ^ nsw_lo) << 3);
-                const char* shi = dST + (32 * kbk + nrow + 4) * 64 + ((c8 ^ nsw_hi) << 3);
+                const char* slo = dSTr + (32 * kbk + nrow) * 64 + ((c8 ^ nsw_lo) << 3);
+                const char* shi = dSTr + (32 * kbk + nrow + 4) * 64 + ((c8 ^ nsw_hi) << 3);
                 dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_pair(klo, khi), tr_pair(slo, shi), dq, 0, 0, 0);
             }
-            const int qrow = 32 * u + 16 * hq + li;
+            const int qrow = 32 * (u - 1) + 16 * hq + li;
             if (qrow < L) {
                 bf16_t* drow = (bf16_t*)p.dq + (row0 + qrow) * p.ld_dqkv + (size_t)h * 64 + 4 * g;
                 store4(drow + 16 * dt, dq);

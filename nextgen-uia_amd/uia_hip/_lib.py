@@ -10,7 +10,7 @@ import os
 import torch  # noqa: F401  -- must come first: libuia_hip.so has to bind to the SAME libamdhip64 that PyTorch loaded
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libuia_hip.so")
+LIB_PATH = os.environ.get("UIA_HIP_LIB") or os.path.join(_HERE, "libuia_hip.so")     # UIA_HIP_LIB: diagnostic builds (tools/abwd_variants.sh)
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_QUICKGELU, ACT_RELU = 0, 1, 2, 3
