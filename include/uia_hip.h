@@ -85,6 +85,8 @@ typedef struct uia_attn_desc {
     float scale;
     const void* dout; int64_t lddo;              /* backward only */
     void *dq, *dk, *dv; int64_t ld_dqkv;         /* backward only */
+    const int32_t* cu_seqlens; /* forward only, optional: [B+1] row offsets of PACKED (un-padded) sequences; sequence b then has
+                                  cu[b+1]-cu[b] <= L tokens at rows cu[b].. and every key is valid (L is the maximum length) */
 } uia_attn_desc;
 int uia_attn_fwd(void* stream, int dtype, const uia_attn_desc* d);
 int uia_attn_bwd(void* stream, int dtype, const uia_attn_desc* d);
@@ -163,6 +165,9 @@ int uia_im2col_padded(void* stream, int dtype, int B, int C, int H, int W, int P
 int uia_fill_cls(void* stream, int B, int N, int D, const float* cls, const float* pos0, float* x);   /* model.py:237-245 */
 int uia_embed(void* stream, int rows, int L, int D, const int64_t* ids, const float* table, const float* pos,
               const float* type0, float* out);                                                          /* model.py:362-364 */
+/* un-padded text tower (opt-in): rows are the valid tokens only; pos_idx[r] is the token's position inside its caption */
+int uia_embed_packed(void* stream, int rows, int D, const int64_t* ids, const int64_t* pos_idx, const float* table, const float* pos,
+                     const float* type0, float* out);
 /* nn.Embedding backward for --method full --tune_text_encoder: dtable[ids[r]] += dx[r] (fp32 atomics into a caller-zeroed table);
  * rows whose id equals pad_id are skipped (padding_idx). */
 int uia_embed_bwd(void* stream, int rows, int D, const int64_t* ids, const float* dx, float* dtable, int64_t pad_id);

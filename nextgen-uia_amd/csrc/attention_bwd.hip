@@ -410,6 +410,7 @@ int launch_bf16(hipStream_t stream, const UiaAttnParams& p) {
 int uia_attn_bwd_launch(hipStream_t stream, int dtype, const UiaAttnParams& p) {
     UIA_CHECK_ARG(dtype == UIA_BF16 || dtype == UIA_F32, "uia_attn_bwd: bad dtype %d", dtype);
     UIA_CHECK_ARG(p.B > 0 && p.H > 0 && p.L > 0, "uia_attn_bwd: empty problem");
+    UIA_CHECK_ARG(!p.cu_seqlens, "uia_attn_bwd: packed sequences (cu_seqlens) are a forward-only layout");
     if (p.dh != 64) return uia_attn_small_launch(stream, dtype, p, true);   // CLIPSeg decoder heads (d_h = 16)
     UIA_CHECK_ARG(p.q && p.k && p.v && p.out && p.dout && p.lse && p.dq && p.dk && p.dv, "uia_attn_bwd: null tensor");
     const int esz = dtype == UIA_BF16 ? 2 : 4;

@@ -40,7 +40,9 @@ template <int LT_MAX>
 __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const UiaAttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NP_MAX = (LT_MAX + 1) / 2;
-    const int L = p.L;
+    const int bb = blockIdx.x / p.H;
+    // packed (un-padded) sequences: this head's rows start at cu_seqlens[b] and there are cu[b+1]-cu[b] of them, all valid
+    const int L = p.cu_seqlens ? p.cu_seqlens[bb + 1] - p.cu_seqlens[bb] : p.L;
     const int LT = (L + 15) >> 4;           // key / query tiles in use
     const int NP = (LT + 1) >> 1;
     const int LPK = NP * 32;                // rows staged (multiple of 32)
@@ -49,8 +51,8 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const UiaAttnParams 
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.x / p.H, h = blockIdx.x - b * p.H;
-    const size_t row0 = (size_t)b * L;
+    const int b = bb, h = blockIdx.x - b * p.H;
+    const size_t row0 = p.cu_seqlens ? (size_t)p.cu_seqlens[b] : (size_t)b * L;
     const char* qb = (const char*)p.q + (row0 * p.ld_qkv + (size_t)h * 64) * 2;
     const char* kb = (const char*)p.k + (row0 * p.ld_qkv + (size_t)h * 64) * 2;
     const char* vb = (const char*)p.v + (row0 * p.ld_qkv + (size_t)h * 64) * 2;
@@ -189,12 +191,12 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const UiaAttnParams 
 // fp32 parity path: one query per thread, K/V rows broadcast from LDS.
 __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const UiaAttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int L = p.L;
+    const int b = blockIdx.x / p.H, h = blockIdx.x - b * p.H;
+    const int L = p.cu_seqlens ? p.cu_seqlens[b + 1] - p.cu_seqlens[b] : p.L;       // packed sequences: see the bf16 kernel
     float* Ks = (float*)smem;               // [L][64]
     float* Vs = Ks + (size_t)L * 64;
     const int tid = threadIdx.x;
-    const int b = blockIdx.x / p.H, h = blockIdx.x - b * p.H;
-    const size_t row0 = (size_t)b * L;
+    const size_t row0 = p.cu_seqlens ? (size_t)p.cu_seqlens[b] : (size_t)b * L;
     const float* qb = (const float*)p.q + row0 * p.ld_qkv + (size_t)h * 64;
     const float* kb = (const float*)p.k + row0 * p.ld_qkv + (size_t)h * 64;
     const float* vb = (const float*)p.v + row0 * p.ld_qkv + (size_t)h * 64;
@@ -270,6 +272,8 @@ int uia_attn_fwd_launch(hipStream_t stream, int dtype, const UiaAttnParams& p) {
     UIA_CHECK_ARG(((uintptr_t)p.q | (uintptr_t)p.k | (uintptr_t)p.v) % 16 == 0 && (uintptr_t)p.out % 8 == 0, "uia_attn_fwd: alignment");
     UIA_CHECK_ARG(p.mask_kind >= UIA_MASK_NONE && p.mask_kind <= UIA_MASK_KEYPAD, "uia_attn_fwd: bad mask kind");
     UIA_CHECK_ARG(p.mask_kind != UIA_MASK_KEYPAD || p.keylen, "uia_attn_fwd: key-padding mask needs keylen");
+    UIA_CHECK_ARG(!p.cu_seqlens || (p.mask_kind != UIA_MASK_KEYPAD && !p.lse),
+                  "uia_attn_fwd: packed sequences (cu_seqlens) take no key-padding mask and write no lse (forward-only path)");
     if (dtype == UIA_F32) {
         const int lds = 2 * p.L * 64 * 4;
         static bool attr_set = false;

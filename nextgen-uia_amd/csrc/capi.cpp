@@ -126,4 +126,9 @@ int uia_embed_bwd(void* stream, int rows, int D, const int64_t* ids, const float
     return uia_embed_bwd_launch((hipStream_t)stream, rows, D, ids, dx, dtable, (long)pad_id);
 }
 
+int uia_embed_packed(void* stream, int rows, int D, const int64_t* ids, const int64_t* pos_idx, const float* table, const float* pos,
+                     const float* type0, float* out) {
+    return uia_embed_packed_launch((hipStream_t)stream, rows, D, ids, pos_idx, table, pos, type0, out);
+}
+
 }  // extern "C"

@@ -358,6 +358,7 @@ inline int grid_for(size_t work, int block) {
 // ---- launchers ---------------------------------------------------------------------------------------------------------
 int uia_attn_small_launch(hipStream_t stream, int dtype, const UiaAttnParams& p, bool bwd) {
     UIA_CHECK_ARG(p.dh == 16 || p.dh == 32, "uia_attn: head dim %d unsupported (16, 32 or 64)", p.dh);
+    UIA_CHECK_ARG(!p.cu_seqlens, "uia_attn: packed sequences (cu_seqlens) need head dim 64");
     UIA_CHECK_ARG(p.L > 0 && p.L <= 1024 && p.B > 0 && p.H > 0, "uia_attn: bad shape");
     const size_t lds = bwd ? ((size_t)2 * p.L * p.dh + 2 * p.L) * 4 : (size_t)2 * p.L * p.dh * 4;
     UIA_CHECK_ARG(lds <= 160 * 1024, "uia_attn: L=%d too long for the small-head path", p.L);

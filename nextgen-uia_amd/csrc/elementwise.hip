@@ -89,6 +89,20 @@ __global__ void embed_kernel(int rows, int L, int D, const int64_t* __restrict__
     }
 }
 
+// packed rows: out[r] = table[ids[r]] + pos[pos_idx[r]] (+ type0)   (un-padded text tower: r runs over the valid tokens only)
+__global__ void embed_packed_kernel(int rows, int D, const int64_t* __restrict__ ids, const int64_t* __restrict__ pos_idx,
+                                    const float* __restrict__ table, const float* __restrict__ pos, const float* __restrict__ type0,
+                                    float* __restrict__ out) {
+    const int D4 = D >> 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)rows * D4; i += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / D4), c = (int)(i % D4) * 4;
+        f32x4 v = load4(table + (size_t)ids[r] * D + c);
+        v += load4(pos + (size_t)pos_idx[r] * D + c);
+        if (type0) v += load4(type0 + c);
+        store4(out + (size_t)r * D + c, v);
+    }
+}
+
 // d table[ids[r]] += dx[r]   (nn.Embedding backward; rows whose id is `pad_id` contribute nothing: padding_idx semantics)
 __global__ void embed_bwd_kernel(int rows, int D, const int64_t* __restrict__ ids, const float* __restrict__ dx, float* __restrict__ dtable, long pad_id) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)rows * D; i += (size_t)gridDim.x * blockDim.x) {
@@ -206,6 +220,14 @@ int uia_fill_cls_launch(hipStream_t stream, int B, int N, int D, const float* cl
 int uia_embed_launch(hipStream_t stream, int rows, int L, int D, const int64_t* ids, const float* table, const float* pos, const float* type0, float* out) {
     UIA_CHECK_ARG(rows > 0 && L > 0 && D % 4 == 0 && ids && table && pos && out, "uia_embed: bad arguments");
     hipLaunchKernelGGL(embed_kernel, dim3(grid_for((size_t)rows * D / 4, 256)), dim3(256), 0, stream, rows, L, D, ids, table, pos, type0, out);
+    UIA_CHECK_LAUNCH();
+    return 0;
+}
+
+int uia_embed_packed_launch(hipStream_t stream, int rows, int D, const int64_t* ids, const int64_t* pos_idx, const float* table, const float* pos,
+                             const float* type0, float* out) {
+    UIA_CHECK_ARG(rows > 0 && D % 4 == 0 && ids && pos_idx && table && pos && out, "uia_embed_packed: bad arguments");
+    hipLaunchKernelGGL(embed_packed_kernel, dim3(grid_for((size_t)rows * D / 4, 256)), dim3(256), 0, stream, rows, D, ids, pos_idx, table, pos, type0, out);
     UIA_CHECK_LAUNCH();
     return 0;
 }

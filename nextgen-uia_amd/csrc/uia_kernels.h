@@ -55,3 +55,4 @@ size_t uia_dicece_ws_floats(int B);
 int uia_dicece_launch(hipStream_t stream, int B, int C, int HW, const float* logits, const float* label, float nr, float dr, float* ws, float* loss, float* dlogits);
 int uia_im2col_padded_launch(hipStream_t stream, int dtype, int B, int C, int H, int W, int P, const float* img, void* out, long ldo);
 int uia_embed_bwd_launch(hipStream_t stream, int rows, int D, const int64_t* ids, const float* dx, float* dtable, long pad_id);
+int uia_embed_packed_launch(hipStream_t stream, int rows, int D, const int64_t* ids, const int64_t* pos_idx, const float* table, const float* pos, const float* type0, float* out);

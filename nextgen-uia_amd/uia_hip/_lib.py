@@ -30,7 +30,7 @@ class GemmDesc(C.Structure):
 class AttnDesc(C.Structure):
     _fields_ = [("q", vp), ("k", vp), ("v", vp), ("ld_qkv", i64), ("out", vp), ("ldo", i64), ("lse", vp), ("keylen", vp),
                 ("B", i32), ("H", i32), ("L", i32), ("dh", i32), ("mask_kind", i32), ("scale", f32),
-                ("dout", vp), ("lddo", i64), ("dq", vp), ("dk", vp), ("dv", vp), ("ld_dqkv", i64)]
+                ("dout", vp), ("lddo", i64), ("dq", vp), ("dk", vp), ("dv", vp), ("ld_dqkv", i64), ("cu_seqlens", vp)]
 
 
 class MonaSpatialDesc(C.Structure):
@@ -92,6 +92,7 @@ PROTOTYPES = {
     "uia_fill_cls": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     "uia_embed": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
     "uia_embed_bwd": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, C.c_int64]),
+    "uia_embed_packed": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]),
     "uia_gather_rows": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp]),
 }
 

@@ -31,6 +31,13 @@ def compute_dtype():
     return _STATE["dtype"]
 
 
+def set_unpad_text(flag):
+    """Opt-in: the frozen text tower computes only the valid tokens of each caption (packed rows + per-caption attention) instead
+    of all `context_length` positions.  Features are identical (padded positions never reach the pooled CLS row); what changes
+    is the work executed, so the headline bench leaves it off."""
+    _STATE["unpad_text"] = bool(flag)
+
+
 def set_dropout_seed(seed):
     _STATE["seed"], _STATE["calls"] = int(seed), 0
 
@@ -292,9 +299,10 @@ def vit_block(x, spec):
 
 # ================================================================================================ forward-only pieces
 @torch.no_grad()
-def post_ln_layer(x32, x_t, L, B, heads, P, keylen, eps=1e-12):
+def post_ln_layer(x32, x_t, L, B, heads, P, keylen, eps=1e-12, cu_seqlens=None):
     """HF BertLayer (post-LN), frozen: returns the new (fp32, T) residual pair.  P: dict of Parameters with the HF
-    names relative to `encoder.layer.{i}.`; q/k/v weights are used as one fused [3D, D] matrix."""
+    names relative to `encoder.layer.{i}.`; q/k/v weights are used as one fused [3D, D] matrix.
+    cu_seqlens: rows are PACKED valid tokens (un-padded captions); L is then the longest caption and no mask is needed."""
     M, D = x32.shape
     dt = x_t.dtype
     # Post-LN: the residual entering each sub-layer IS the previous LayerNorm's output, so in bf16 mode its T copy (the GEMM
@@ -305,7 +313,10 @@ def post_ln_layer(x32, x_t, L, B, heads, P, keylen, eps=1e-12):
     qkv = _empty((M, 3 * D), dt, x32)
     ops.gemm(x_t, P["_qkv_w"](dt), bias=P["_qkv_b"], out_t=qkv)
     a = _empty((M, D), dt, x32)
-    ops.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], a, B, heads, L, mask="keypad", keylen=keylen)
+    if cu_seqlens is not None:
+        ops.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], a, B, heads, L, cu_seqlens=cu_seqlens)
+    else:
+        ops.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], a, B, heads, L, mask="keypad", keylen=keylen)
     s = torch.empty_like(x32)
     res = dict(resid_t=x_t) if t_resid else dict(resid=x32)
     y32 = None if t_resid else x32

@@ -156,9 +156,13 @@ def _attn_desc(q, k, v, out, lse, B, H, L, mask, keylen, scale, dh=64):
     return d
 
 
-def attn_fwd(q, k, v, out, B, H, L, lse=None, mask=None, keylen=None, scale=None, dh=64):
-    """q,k,v: views whose element (b,l,h,d) is at base[(b*L+l)*ld + h*dh + d] (e.g. slices of the fused qkv)."""
+def attn_fwd(q, k, v, out, B, H, L, lse=None, mask=None, keylen=None, scale=None, dh=64, cu_seqlens=None):
+    """q,k,v: views whose element (b,l,h,d) is at base[(b*L+l)*ld + h*dh + d] (e.g. slices of the fused qkv).
+    cu_seqlens (int32 [B+1], forward only): packed sequences — sequence b is rows cu[b]..cu[b+1]-1, L = the longest one."""
     d = _attn_desc(q, k, v, out, lse, B, H, L, mask, keylen, scale, dh)
+    if cu_seqlens is not None:
+        assert cu_seqlens.dtype == torch.int32 and cu_seqlens.is_contiguous() and cu_seqlens.numel() == B + 1
+        d.cu_seqlens = _p(cu_seqlens)
     check(lib().uia_attn_fwd(_stream(), _code(q.dtype), C.byref(d)), "uia_attn_fwd")
 
 
@@ -217,6 +221,12 @@ def embed(ids, table, pos, type0, out):
     rows, L = ids.numel(), ids.shape[-1]
     assert ids.dtype == torch.int64 and ids.is_contiguous()
     check(lib().uia_embed(_stream(), rows, L, table.shape[1], _p(ids), _p(table), _p(pos), _p(type0), _p(out)), "uia_embed")
+
+
+def embed_packed(ids, pos_idx, table, pos, type0, out):
+    """out[r] = table[ids[r]] + pos[pos_idx[r]] + type0 for the packed (valid) tokens r."""
+    assert ids.dtype == pos_idx.dtype == torch.int64 and ids.is_contiguous() and pos_idx.is_contiguous() and ids.numel() == pos_idx.numel() == out.shape[0]
+    check(lib().uia_embed_packed(_stream(), ids.numel(), out.shape[1], _p(ids), _p(pos_idx), _p(table), _p(pos), _p(type0), _p(out)), "uia_embed_packed")
 
 
 def embed_bwd(ids, dx, dtable, pad_id=-1):

@@ -40,7 +40,7 @@ def test_descriptor_struct_sizes_match_c_layout():
     """The ctypes mirrors of uia_gemm_desc / uia_attn_desc / uia_mona_spatial_desc must have the C layout (LP64)."""
     from uia_hip import _lib
     assert ctypes.sizeof(_lib.GemmDesc) == 176
-    assert ctypes.sizeof(_lib.AttnDesc) == 136
+    assert ctypes.sizeof(_lib.AttnDesc) == 144
     assert ctypes.sizeof(_lib.MonaSpatialDesc) % 8 == 0 and ctypes.sizeof(_lib.MonaSpatialDesc) == 296
 
 

@@ -849,3 +849,32 @@ def test_finetune_entry_point_full_with_text_encoder(tmp_path, monkeypatch):
     out = finetune.main(["--method", "full", "--tune_text_encoder", "--synthetic", "--synthetic_train", "32", "--synthetic_val", "16", "--img_size", "32",
                          "--batch_size", "16", "--accumulation_steps", "1", "--epochs", "1", "--dtype", "bf16", "--exp", "fullt", "--model_config", cfg])
     assert out["updates"] == 2 and math.isfinite(out["best_val"])
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_unpadded_text_tower_equals_dense(mode):
+    """Opt-in packed (variable-length) text tower: same features as the dense one and as the oracle — padded positions never reach
+    the pooled CLS row."""
+    from oracle import text_ref
+    from uia_hip import functional as UF
+    from src.third_party.biomedclip.model import create_biomedclip
+    UF.set_compute_dtype(DT[mode])
+    g = torch.Generator().manual_seed(43)
+    model = create_biomedclip(config=TOY, seed=21)
+    randomize(model.text, g, 0.05)
+    for p in model.parameters():
+        p.requires_grad_(False)
+    model.eval()
+    _, ids = toy_batch(g, B=7)
+    ids[3, 2:] = 0                                          # a two-token caption
+    P = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    ref = text_ref.bert_text_forward(ids, P, heads=2)
+    model = model.to(dev())
+    try:
+        dense = model.encode_text(ids.to(dev()))
+        UF.set_unpad_text(True)
+        packed = model.encode_text(ids.to(dev()))
+    finally:
+        UF.set_unpad_text(False)
+    assert rel(dense, ref) < TOL[mode] and rel(packed, ref) < TOL[mode]
+    assert rel(packed, dense.cpu()) < (1e-5 if mode == "fp32" else 1e-2)
