@@ -163,14 +163,16 @@ int uia_im2col(void* stream, int dtype, int B, int C, int H, int W, int P, const
 /* same for any patch size (P need not be a multiple of 4), rows padded with zeros to ldo >= C*P*P columns (ViT-L/14: 588 -> 640) */
 int uia_im2col_padded(void* stream, int dtype, int B, int C, int H, int W, int P, const float* img, void* cols, int64_t ldo);
 int uia_fill_cls(void* stream, int B, int N, int D, const float* cls, const float* pos0, float* x);   /* model.py:237-245 */
-int uia_embed(void* stream, int rows, int L, int D, const int64_t* ids, const float* table, const float* pos,
+/* table [vocab, D], pos [max_pos, D]: L > max_pos is rejected; an id outside [0, vocab) (nn.Embedding raises for it) yields a NaN row,
+ * which trips the training loops' non-finite-loss check instead of reading past the table */
+int uia_embed(void* stream, int rows, int L, int D, int vocab, int max_pos, const int64_t* ids, const float* table, const float* pos,
               const float* type0, float* out);                                                          /* model.py:362-364 */
 /* un-padded text tower (opt-in): rows are the valid tokens only; pos_idx[r] is the token's position inside its caption */
-int uia_embed_packed(void* stream, int rows, int D, const int64_t* ids, const int64_t* pos_idx, const float* table, const float* pos,
-                     const float* type0, float* out);
+int uia_embed_packed(void* stream, int rows, int D, int vocab, int max_pos, const int64_t* ids, const int64_t* pos_idx, const float* table,
+                     const float* pos, const float* type0, float* out);
 /* nn.Embedding backward for --method full --tune_text_encoder: dtable[ids[r]] += dx[r] (fp32 atomics into a caller-zeroed table);
  * rows whose id equals pad_id are skipped (padding_idx). */
-int uia_embed_bwd(void* stream, int rows, int D, const int64_t* ids, const float* dx, float* dtable, int64_t pad_id);
+int uia_embed_bwd(void* stream, int rows, int D, int vocab, const int64_t* ids, const float* dx, float* dtable, int64_t pad_id);
 int uia_gather_rows(void* stream, int n, int D, const float* src, const int64_t* idx, float* dst);  /* model.py:372 */
 /* dst = (accumulate ? dst : 0) + src*keep/(1-p), keep from the counter hash of (seed, index): LoRA input dropout
  * (src/adapters/lora.py:82-83) and its backward (same seed). */

@@ -393,13 +393,10 @@ int launch_bf16(hipStream_t stream, const UiaAttnParams& p) {
     const int LT = (p.L + 15) / 16, NP = (LT + 1) / 2, LPK = NP * 32;
     const int lds = bwd_lds_bytes(LPK);
     auto kern = attn_bwd_bf16_kernel<LT_MAX>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static UiaDevOnce attr_once;
         constexpr int LPKM = ((LT_MAX + 1) / 2) * 32;
         static_assert(bwd_lds_bytes(LPKM) <= 160 * 1024, "LDS budget");
-        UIA_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bwd_lds_bytes(LPKM)));
-        attr_set = true;
-    }
+    UIA_ENSURE_LDS_ATTR(attr_once, kern, bwd_lds_bytes(LPKM));
     hipLaunchKernelGGL(kern, dim3(p.B * p.H), dim3(64 * BWD_WAVES), lds, stream, p);
     UIA_CHECK_LAUNCH();
     return 0;
@@ -422,11 +419,8 @@ int uia_attn_bwd_launch(hipStream_t stream, int dtype, const UiaAttnParams& p) {
     if (dtype == UIA_F32) {
         UIA_CHECK_ARG(p.L <= 272, "uia_attn_bwd: L=%d exceeds 272", p.L);
         const int lds = (2 * p.L * 64 + 2 * p.L) * 4;
-        static bool attr_set = false;
-        if (!attr_set) {
-            UIA_CHECK_HIP(hipFuncSetAttribute((const void*)attn_bwd_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (2 * 272 * 64 + 2 * 272) * 4));
-            attr_set = true;
-        }
+        static UiaDevOnce attr_once;
+        UIA_ENSURE_LDS_ATTR(attr_once, attn_bwd_f32_kernel, (2 * 272 * 64 + 2 * 272) * 4);
         hipLaunchKernelGGL(attn_bwd_f32_kernel, dim3(p.B * p.H), dim3(256), lds, stream, p);
         UIA_CHECK_LAUNCH();
         return 0;

@@ -249,11 +249,8 @@ int launch_bf16(hipStream_t stream, const UiaAttnParams& p) {
     const int LT = (p.L + 15) / 16, NP = (LT + 1) / 2;
     const int lds = 2 * NP * 32 * 128;
     auto kern = attn_fwd_bf16_kernel<LT_MAX>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        UIA_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ((LT_MAX + 1) / 2) * 32 * 128));
-        attr_set = true;
-    }
+    static UiaDevOnce attr_once;
+    UIA_ENSURE_LDS_ATTR(attr_once, kern, 2 * ((LT_MAX + 1) / 2) * 32 * 128);
     hipLaunchKernelGGL(kern, dim3(p.B * p.H), dim3(256), lds, stream, p);
     UIA_CHECK_LAUNCH();
     return 0;
@@ -276,11 +273,8 @@ int uia_attn_fwd_launch(hipStream_t stream, int dtype, const UiaAttnParams& p) {
                   "uia_attn_fwd: packed sequences (cu_seqlens) take no key-padding mask and write no lse (forward-only path)");
     if (dtype == UIA_F32) {
         const int lds = 2 * p.L * 64 * 4;
-        static bool attr_set = false;
-        if (!attr_set) {
-            UIA_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 272 * 64 * 4));
-            attr_set = true;
-        }
+        static UiaDevOnce attr_once;
+        UIA_ENSURE_LDS_ATTR(attr_once, attn_fwd_f32_kernel, 2 * 272 * 64 * 4);
         hipLaunchKernelGGL(attn_fwd_f32_kernel, dim3(p.B * p.H), dim3(256), lds, stream, p);
         UIA_CHECK_LAUNCH();
         return 0;

@@ -34,8 +34,8 @@ int uia_cast(void* stream, int dtype, size_t n, const float* src, void* dst, flo
 int uia_transpose_cast(void* stream, int dtype, int rows, int cols, const float* src, void* dst) { return uia_transpose_cast_launch((hipStream_t)stream, dtype, rows, cols, src, dst); }
 int uia_im2col(void* stream, int dtype, int B, int C, int H, int W, int P, const float* img, void* out) { return uia_im2col_launch((hipStream_t)stream, dtype, B, C, H, W, P, img, out); }
 int uia_fill_cls(void* stream, int B, int N, int D, const float* cls, const float* pos0, float* x) { return uia_fill_cls_launch((hipStream_t)stream, B, N, D, cls, pos0, x); }
-int uia_embed(void* stream, int rows, int L, int D, const int64_t* ids, const float* table, const float* pos, const float* type0, float* out) {
-    return uia_embed_launch((hipStream_t)stream, rows, L, D, ids, table, pos, type0, out);
+int uia_embed(void* stream, int rows, int L, int D, int vocab, int max_pos, const int64_t* ids, const float* table, const float* pos, const float* type0, float* out) {
+    return uia_embed_launch((hipStream_t)stream, rows, L, D, vocab, max_pos, ids, table, pos, type0, out);
 }
 int uia_gather_rows(void* stream, int n, int D, const float* src, const int64_t* idx, float* dst) { return uia_gather_rows_launch((hipStream_t)stream, n, D, src, idx, dst); }
 
@@ -122,13 +122,13 @@ int uia_im2col_padded(void* stream, int dtype, int B, int C, int H, int W, int P
     return uia_im2col_padded_launch((hipStream_t)stream, dtype, B, C, H, W, P, img, cols, (long)ldo);
 }
 
-int uia_embed_bwd(void* stream, int rows, int D, const int64_t* ids, const float* dx, float* dtable, int64_t pad_id) {
-    return uia_embed_bwd_launch((hipStream_t)stream, rows, D, ids, dx, dtable, (long)pad_id);
+int uia_embed_bwd(void* stream, int rows, int D, int vocab, const int64_t* ids, const float* dx, float* dtable, int64_t pad_id) {
+    return uia_embed_bwd_launch((hipStream_t)stream, rows, D, vocab, ids, dx, dtable, (long)pad_id);
 }
 
-int uia_embed_packed(void* stream, int rows, int D, const int64_t* ids, const int64_t* pos_idx, const float* table, const float* pos,
-                     const float* type0, float* out) {
-    return uia_embed_packed_launch((hipStream_t)stream, rows, D, ids, pos_idx, table, pos, type0, out);
+int uia_embed_packed(void* stream, int rows, int D, int vocab, int max_pos, const int64_t* ids, const int64_t* pos_idx, const float* table,
+                     const float* pos, const float* type0, float* out) {
+    return uia_embed_packed_launch((hipStream_t)stream, rows, D, vocab, max_pos, ids, pos_idx, table, pos, type0, out);
 }
 
 }  // extern "C"

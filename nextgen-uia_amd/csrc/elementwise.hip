@@ -76,12 +76,20 @@ __global__ void fill_cls_kernel(int B, int N, int D, const float* __restrict__ c
     x[(size_t)b * N * D + d] = cls[d] + (pos0 ? pos0[d] : 0.f);
 }
 
-__global__ void embed_kernel(int rows, int L, int D, const int64_t* __restrict__ ids, const float* __restrict__ table,
+// An id outside [0, vocab) (nn.Embedding raises for it) never reads the table: its row is filled with NaN, which reaches the
+// loss and trips the loops' non-finite check instead of silently training on whatever lies beyond the table.
+__global__ void embed_kernel(int rows, int L, int D, int vocab, const int64_t* __restrict__ ids, const float* __restrict__ table,
                              const float* __restrict__ pos, const float* __restrict__ type0, float* __restrict__ out) {
     const int D4 = D >> 2;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)rows * D4; i += (size_t)gridDim.x * blockDim.x) {
         const int r = (int)(i / D4), c = (int)(i % D4) * 4, l = r % L;
-        f32x4 v = load4(table + (size_t)ids[r] * D + c);
+        const int64_t id = ids[r];
+        if (id < 0 || id >= vocab) {
+            const float q = __builtin_nanf("");
+            store4(out + (size_t)r * D + c, f32x4{q, q, q, q});
+            continue;
+        }
+        f32x4 v = load4(table + (size_t)id * D + c);
         const f32x4 pv = load4(pos + (size_t)l * D + c);
         v += pv;
         if (type0) v += load4(type0 + c);
@@ -90,25 +98,31 @@ __global__ void embed_kernel(int rows, int L, int D, const int64_t* __restrict__
 }
 
 // packed rows: out[r] = table[ids[r]] + pos[pos_idx[r]] (+ type0)   (un-padded text tower: r runs over the valid tokens only)
-__global__ void embed_packed_kernel(int rows, int D, const int64_t* __restrict__ ids, const int64_t* __restrict__ pos_idx,
+__global__ void embed_packed_kernel(int rows, int D, int vocab, int max_pos, const int64_t* __restrict__ ids, const int64_t* __restrict__ pos_idx,
                                     const float* __restrict__ table, const float* __restrict__ pos, const float* __restrict__ type0,
                                     float* __restrict__ out) {
     const int D4 = D >> 2;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)rows * D4; i += (size_t)gridDim.x * blockDim.x) {
         const int r = (int)(i / D4), c = (int)(i % D4) * 4;
-        f32x4 v = load4(table + (size_t)ids[r] * D + c);
-        v += load4(pos + (size_t)pos_idx[r] * D + c);
+        const int64_t id = ids[r], pi = pos_idx[r];
+        if (id < 0 || id >= vocab || pi < 0 || pi >= max_pos) {
+            const float q = __builtin_nanf("");
+            store4(out + (size_t)r * D + c, f32x4{q, q, q, q});
+            continue;
+        }
+        f32x4 v = load4(table + (size_t)id * D + c);
+        v += load4(pos + (size_t)pi * D + c);
         if (type0) v += load4(type0 + c);
         store4(out + (size_t)r * D + c, v);
     }
 }
 
 // d table[ids[r]] += dx[r]   (nn.Embedding backward; rows whose id is `pad_id` contribute nothing: padding_idx semantics)
-__global__ void embed_bwd_kernel(int rows, int D, const int64_t* __restrict__ ids, const float* __restrict__ dx, float* __restrict__ dtable, long pad_id) {
+__global__ void embed_bwd_kernel(int rows, int D, int vocab, const int64_t* __restrict__ ids, const float* __restrict__ dx, float* __restrict__ dtable, long pad_id) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)rows * D; i += (size_t)gridDim.x * blockDim.x) {
         const int r = (int)(i / D), c = (int)(i % D);
         const int64_t id = ids[r];
-        if (id != pad_id) atomicAdd(dtable + (size_t)id * D + c, dx[i]);
+        if (id != pad_id && id >= 0 && id < vocab) atomicAdd(dtable + (size_t)id * D + c, dx[i]);
     }
 }
 
@@ -217,24 +231,25 @@ int uia_fill_cls_launch(hipStream_t stream, int B, int N, int D, const float* cl
     return 0;
 }
 
-int uia_embed_launch(hipStream_t stream, int rows, int L, int D, const int64_t* ids, const float* table, const float* pos, const float* type0, float* out) {
-    UIA_CHECK_ARG(rows > 0 && L > 0 && D % 4 == 0 && ids && table && pos && out, "uia_embed: bad arguments");
-    hipLaunchKernelGGL(embed_kernel, dim3(grid_for((size_t)rows * D / 4, 256)), dim3(256), 0, stream, rows, L, D, ids, table, pos, type0, out);
+int uia_embed_launch(hipStream_t stream, int rows, int L, int D, int vocab, int max_pos, const int64_t* ids, const float* table, const float* pos, const float* type0, float* out) {
+    UIA_CHECK_ARG(rows > 0 && L > 0 && D % 4 == 0 && vocab > 0 && ids && table && pos && out, "uia_embed: bad arguments");
+    UIA_CHECK_ARG(L <= max_pos, "uia_embed: sequence length %d exceeds the position table (%d rows)", L, max_pos);
+    hipLaunchKernelGGL(embed_kernel, dim3(grid_for((size_t)rows * D / 4, 256)), dim3(256), 0, stream, rows, L, D, vocab, ids, table, pos, type0, out);
     UIA_CHECK_LAUNCH();
     return 0;
 }
 
-int uia_embed_packed_launch(hipStream_t stream, int rows, int D, const int64_t* ids, const int64_t* pos_idx, const float* table, const float* pos,
+int uia_embed_packed_launch(hipStream_t stream, int rows, int D, int vocab, int max_pos, const int64_t* ids, const int64_t* pos_idx, const float* table, const float* pos,
                              const float* type0, float* out) {
-    UIA_CHECK_ARG(rows > 0 && D % 4 == 0 && ids && pos_idx && table && pos && out, "uia_embed_packed: bad arguments");
-    hipLaunchKernelGGL(embed_packed_kernel, dim3(grid_for((size_t)rows * D / 4, 256)), dim3(256), 0, stream, rows, D, ids, pos_idx, table, pos, type0, out);
+    UIA_CHECK_ARG(rows > 0 && D % 4 == 0 && vocab > 0 && max_pos > 0 && ids && pos_idx && table && pos && out, "uia_embed_packed: bad arguments");
+    hipLaunchKernelGGL(embed_packed_kernel, dim3(grid_for((size_t)rows * D / 4, 256)), dim3(256), 0, stream, rows, D, vocab, max_pos, ids, pos_idx, table, pos, type0, out);
     UIA_CHECK_LAUNCH();
     return 0;
 }
 
-int uia_embed_bwd_launch(hipStream_t stream, int rows, int D, const int64_t* ids, const float* dx, float* dtable, long pad_id) {
-    UIA_CHECK_ARG(rows > 0 && D > 0 && ids && dx && dtable, "uia_embed_bwd: bad arguments");
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid_for((size_t)rows * D, 256)), dim3(256), 0, stream, rows, D, ids, dx, dtable, pad_id);
+int uia_embed_bwd_launch(hipStream_t stream, int rows, int D, int vocab, const int64_t* ids, const float* dx, float* dtable, long pad_id) {
+    UIA_CHECK_ARG(rows > 0 && D > 0 && vocab > 0 && ids && dx && dtable, "uia_embed_bwd: bad arguments");
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid_for((size_t)rows * D, 256)), dim3(256), 0, stream, rows, D, vocab, ids, dx, dtable, pad_id);
     UIA_CHECK_LAUNCH();
     return 0;
 }

@@ -434,11 +434,8 @@ template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
 int launch_cfg(hipStream_t stream, const UiaGemmParams& p) {
     constexpr int LDS = 2 * (BM + BN) * 128;
     auto kern = gemm_tn_kernel<T, BM, BN, WAVES_M, WAVES_N>;
-    static bool attr_set = false;   // one process per GPU, calls come from one host thread at a time
-    if (!attr_set) {
-        UIA_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr_set = true;
-    }
+    static UiaDevOnce attr_once;
+    UIA_ENSURE_LDS_ATTR(attr_once, kern, LDS);
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(64 * WAVES_M * WAVES_N), LDS, stream, p);
     UIA_CHECK_LAUNCH();
@@ -618,11 +615,8 @@ int launch_pp(hipStream_t stream, const UiaGemmParams& p) {
     constexpr int EPI = WAVES_M * WAVES_N * EpiPatch<BM / WAVES_M / 16, BN / WAVES_N>::BYTES_PER_WAVE;
     constexpr int LDS = 2 * (BM + BN) * 128 > EPI ? 2 * (BM + BN) * 128 : EPI;
     auto kern = gemm_tn_pp_kernel<T, BM, BN, WAVES_M, WAVES_N>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        UIA_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr_set = true;
-    }
+    static UiaDevOnce attr_once;
+    UIA_ENSURE_LDS_ATTR(attr_once, kern, LDS);
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(64 * WAVES_M * WAVES_N), LDS, stream, p);
     UIA_CHECK_LAUNCH();
@@ -647,7 +641,7 @@ int launch_pp(hipStream_t stream, const UiaGemmParams& p) {
 // 64-byte rows use the 4-entry swizzle table {0,3,2,1} indexed by (row>>2)&3 (A) / the 16-row block of the
 // permuted W rows: conflict-free ds_read_b128 for both fragment patterns.
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int NBUF, int EPI>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_tn_ring_kernel(const UiaGemmParams p) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_tn_ring_kernel(const UiaGemmParams p, const int xflags) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
@@ -675,8 +669,32 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_tn_ring_kernel(co
         const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    // Tile order inside an XCD's run (xflags & 255 = GM): GM == 0 walks all column panels of one row panel, then the next row
+    // panel; GM > 0 walks GROUPS of GM row panels column by column, rows fastest, so that the ~32 tiles an XCD has in flight
+    // form a GM x (32/GM) block: (GM + 32/GM) operand panels per K slice instead of (32/tiles_n + tiles_n), and consecutive
+    // waves of a group keep its A panels in the XCD's L2.
+    int tm, tn;
+    {
+        const int gmv = xflags & 255;
+        if (gmv > 0) {
+            const int tiles_m = (p.M + BM - 1) / BM;
+            const int per_group = gmv * tiles_n;
+            const int grp_id = bid / per_group, first = grp_id * gmv;
+            const int gsz = tiles_m - first < gmv ? tiles_m - first : gmv;
+            const int r = bid - grp_id * per_group;
+            tn = r / gsz;
+            tm = first + (r - tn * gsz);
+        } else {
+            tm = bid / tiles_n;
+            tn = bid - tm * tiles_n;
+        }
+    }
     const int m0 = tm * BM, n0 = tn * BN;
+#if defined(UIA_GEMM_STAMPS) || defined(UIA_GEMM_EXP)
+    const bool kbA = (xflags >> 8) & 1, kbW = (xflags >> 9) & 1;      // diagnostic: operands addressed as K-blocked [K/32][rows][32]
+#else
+    constexpr bool kbA = false, kbW = false;
+#endif
 
     // swizzle of the 16-byte chunk index: 128-byte rows: (row>>1)&7 / 2a|(b>>1) as in the 2-buffer kernels;
     // 64-byte rows: table {0,3,2,1}[(row>>2)&3] for A, [(row_local>>4)&3] for the permuted W rows.
@@ -691,7 +709,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_tn_ring_kernel(co
         const int c = (lane % CPR) ^ swzA(r);
         int gm = m0 + r;
         gm = gm < p.M ? gm : p.M - 1;
-        srcA[i] = (const char*)p.A + ((size_t)gm * (size_t)p.lda) * ESZ + c * 16;
+        srcA[i] = kbA ? (const char*)p.A + (size_t)gm * BKB + c * 16 : (const char*)p.A + ((size_t)gm * (size_t)p.lda) * ESZ + c * 16;
     }
 #pragma unroll
     for (int i = 0; i < W_PER_WAVE; ++i) {
@@ -699,8 +717,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_tn_ring_kernel(co
         const int c = (lane % CPR) ^ swzW(r & (WTN - 1));
         int gn = n0 + r;
         gn = gn < p.N ? gn : p.N - 1;
-        srcW[i] = (const char*)p.W + ((size_t)gn * (size_t)p.ldw) * ESZ + c * 16;
+        srcW[i] = kbW ? (const char*)p.W + (size_t)gn * BKB + c * 16 : (const char*)p.W + ((size_t)gn * (size_t)p.ldw) * ESZ + c * 16;
     }
+    const size_t kstepA = kbA ? (size_t)p.M * BKB : (size_t)BKB, kstepW = kbW ? (size_t)p.N * BKB : (size_t)BKB;
     const int li = lane & 15, g = lane >> 4;
     const int rowA = wm * WTM + li;                                         // + 16·mt  (keeps (row>>1)&7 and (row>>2)&3)
     const int rowW = wn * WTN + (li >> 2) * 16 + (li & 3);                  // + 4·j
@@ -717,12 +736,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_tn_ring_kernel(co
     // part = which 1/SPT of this wave's pieces of sub-tile t (the DMA issue is spread over the wave's LOAD slots)
     auto stage = [&](int t, int part) {
         char* base = smem + (t % NBUF) * BUF_BYTES;
-        const size_t koff = (size_t)t * BKB;
+        const size_t koffA = (size_t)t * kstepA, koffW = (size_t)t * kstepW;
 #pragma unroll
         for (int i = 0; i < GPT; ++i) {
             if (i * SPT / GPT != part && SPT > 1) continue;
-            if (i < A_PER_WAVE) glds16_asm(srcA[i] + koff, base + (wave + NW * i) * 1024);
-            else glds16_asm(srcW[i - A_PER_WAVE] + koff, base + A_BYTES + (wave + NW * (i - A_PER_WAVE)) * 1024);
+            if (i < A_PER_WAVE) glds16_asm(srcA[i] + koffA, base + (wave + NW * i) * 1024);
+            else glds16_asm(srcW[i - A_PER_WAVE] + koffW, base + A_BYTES + (wave + NW * (i - A_PER_WAVE)) * 1024);
         }
     };
     uint4 af[MT], wf[NT];
@@ -802,18 +821,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_tn_ring_kernel(co
 }
 
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int NBUF, int EPI>
-int launch_ring_epi(hipStream_t stream, const UiaGemmParams& p) {
+int launch_ring_epi(hipStream_t stream, const UiaGemmParams& p, int xflags) {
     constexpr int EPB = WAVES_M * WAVES_N * EpiPatch<BM / WAVES_M / 16, BN / WAVES_N>::BYTES_PER_WAVE;
     constexpr int LDS = NBUF * (BM + BN) * BKB > EPB ? NBUF * (BM + BN) * BKB : EPB;
     static_assert(LDS <= 160 * 1024, "LDS budget");
     auto kern = gemm_tn_ring_kernel<T, BM, BN, WAVES_M, WAVES_N, BKB, NBUF, EPI>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        UIA_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr_set = true;
-    }
+    static UiaDevOnce attr_once;
+    UIA_ENSURE_LDS_ATTR(attr_once, kern, LDS);
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(64 * WAVES_M * WAVES_N), LDS, stream, p);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(64 * WAVES_M * WAVES_N), LDS, stream, p, xflags);
     UIA_CHECK_LAUNCH();
     return 0;
 }
@@ -981,11 +997,8 @@ template <typename T, int EPI>
 int launch_persist_epi(hipStream_t stream, const UiaGemmParams& p) {
     constexpr int LDS = 4 * 512 * 64;
     auto kern = gemm_tn_persist_kernel<T, EPI>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        UIA_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr_set = true;
-    }
+    static UiaDevOnce attr_once;
+    UIA_ENSURE_LDS_ATTR(attr_once, kern, LDS);
     const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
     const int ncu = uia_num_cus();
     hipLaunchKernelGGL(kern, dim3(tiles < ncu ? tiles : ncu), dim3(512), LDS, stream, p);
@@ -1002,10 +1015,10 @@ inline int epi_mask_of(const UiaGemmParams& p) {
 }
 
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int NBUF>
-int launch_ring(hipStream_t stream, const UiaGemmParams& p, bool specialise) {
+int launch_ring(hipStream_t stream, const UiaGemmParams& p, bool specialise, int xflags) {
     if (specialise) {
         switch (epi_mask_of(p)) {    // the six masks of a training step, by time spent (tools/gemm_census.py)
-#define UIA_EPI_CASE(MASK) case (MASK): return launch_ring_epi<T, BM, BN, WAVES_M, WAVES_N, BKB, NBUF, (MASK)>(stream, p)
+#define UIA_EPI_CASE(MASK) case (MASK): return launch_ring_epi<T, BM, BN, WAVES_M, WAVES_N, BKB, NBUF, (MASK)>(stream, p, xflags)
             UIA_EPI_CASE(EPI_BIAS | EPI_RESID | EPI_OUT32);                    // proj / fc2 / Mona project2 forward
             UIA_EPI_CASE(EPI_BIAS | EPI_RESIDT | EPI_OUT32);                   // post-LN (BERT) sub-layer sums on the T residual
             UIA_EPI_CASE(EPI_OUTT);                                            // dgrads
@@ -1017,7 +1030,7 @@ int launch_ring(hipStream_t stream, const UiaGemmParams& p, bool specialise) {
             default: break;
         }
     }
-    return launch_ring_epi<T, BM, BN, WAVES_M, WAVES_N, BKB, NBUF, EPI_GENERIC>(stream, p);
+    return launch_ring_epi<T, BM, BN, WAVES_M, WAVES_N, BKB, NBUF, EPI_GENERIC>(stream, p, xflags);
 }
 
 template <typename T>
@@ -1038,7 +1051,10 @@ int launch_persist(hipStream_t stream, const UiaGemmParams& p) {
 }
 
 template <typename T>
-int launch_typed(hipStream_t stream, const UiaGemmParams& p, int cfg) {
+int launch_typed(hipStream_t stream, const UiaGemmParams& p, int cfg_in) {
+    // bits 8.. of the tile argument carry experiment knobs for the ring kernels (tile-order group size, diagnostic layouts);
+    // 0 there = the launcher's own choice.
+    int cfg = cfg_in & 255, xflags = cfg_in >> 8;
     // cfg: 0 = auto. Tile choice is a pure speed knob (results are identical for every config
     // up to fp32 summation order inside a K-step, which does not depend on the tile).
     if (cfg == 0) {
@@ -1056,9 +1072,9 @@ int launch_typed(hipStream_t stream, const UiaGemmParams& p, int cfg) {
         case 5: return launch_cfg<T, 128, 64, 2, 1>(stream, p);
         case 6: return launch_pp<T, 256, 256, 2, 4>(stream, p);
         case 7: return launch_pp<T, 256, 128, 4, 2>(stream, p);
-        case 8: return launch_ring<T, 256, 256, 2, 4, 64, 4>(stream, p, true);
-        case 9: return launch_ring<T, 256, 128, 4, 2, 128, 3>(stream, p, false);
-        case 10: return launch_ring<T, 256, 256, 2, 4, 64, 4>(stream, p, false);   // cfg 8 with the run-time (generic) epilogue: parity cross-check
+        case 8: return launch_ring<T, 256, 256, 2, 4, 64, 4>(stream, p, true, xflags);
+        case 9: return launch_ring<T, 256, 128, 4, 2, 128, 3>(stream, p, false, xflags);
+        case 10: return launch_ring<T, 256, 256, 2, 4, 64, 4>(stream, p, false, xflags);   // cfg 8 with the run-time (generic) epilogue: parity cross-check
         case 12: return launch_persist<T>(stream, p);
         default: uia_set_error("uia_gemm: unknown tile config %d", cfg); return -1;
     }
@@ -1087,6 +1103,13 @@ int uia_gemm_launch(hipStream_t stream, int dtype, const UiaGemmParams& p, int c
     UIA_CHECK_ARG(!p.aux_in || (p.ldaux_in % 8 == 0 && (uintptr_t)p.aux_in % 16 == 0), "uia_gemm: aux_in alignment");
     UIA_CHECK_ARG(!p.aux_out || (p.ldaux_out % 8 == 0 && (uintptr_t)p.aux_out % 16 == 0), "uia_gemm: aux_out alignment");
     UIA_CHECK_ARG(p.resid_mod == 0 || p.resid, "uia_gemm: resid_mod without resid");
+    // every row the epilogue touches must hold N elements: a leading dimension below N would make row m's tail overwrite row m+1
+    UIA_CHECK_ARG(!p.outT || p.ldo >= p.N, "uia_gemm: ldo=%lld < N=%d", (long long)p.ldo, p.N);
+    UIA_CHECK_ARG(!p.out32 || p.ldo32 >= p.N, "uia_gemm: ldo32=%lld < N=%d", (long long)p.ldo32, p.N);
+    UIA_CHECK_ARG(!p.aux_out || p.ldaux_out >= p.N, "uia_gemm: ldaux_out=%lld < N=%d", (long long)p.ldaux_out, p.N);
+    UIA_CHECK_ARG(!p.aux_in || p.ldaux_in >= p.N, "uia_gemm: ldaux_in=%lld < N=%d", (long long)p.ldaux_in, p.N);
+    UIA_CHECK_ARG(!p.resid || p.ldr >= p.N, "uia_gemm: ldr=%lld < N=%d", (long long)p.ldr, p.N);
+    UIA_CHECK_ARG(!p.residT || p.ldrT >= p.N, "uia_gemm: ldrT=%lld < N=%d", (long long)p.ldrT, p.N);
     if (dtype == UIA_BF16) return launch_typed<bf16_t>(stream, p, cfg);
     return launch_typed<float>(stream, p, cfg);
 }

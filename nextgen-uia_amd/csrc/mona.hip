@@ -903,11 +903,8 @@ size_t spatial_lds(int hw, bool bwd) {
 template <int W, bool BWD>
 int launch_spatial_fast(hipStream_t stream, const uia_mona_spatial_desc& p) {
     auto kern = mona_spatial_fast_kernel<W, BWD>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        UIA_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static UiaDevOnce attr_once;
+    UIA_ENSURE_LDS_ATTR(attr_once, kern, 160 * 1024);
     hipLaunchKernelGGL(kern, dim3(p.B), dim3(512), spatial_fast_lds(p.h * W, BWD), stream, p);
     return 0;
 }
@@ -926,11 +923,8 @@ int launch_spatial(hipStream_t stream, const uia_mona_spatial_desc& p) {
         else launch_spatial_fast<4, BWD>(stream, p);
     } else {
     auto kern = mona_spatial_kernel<T, BWD>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        UIA_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static UiaDevOnce attr_once;
+    UIA_ENSURE_LDS_ATTR(attr_once, kern, 160 * 1024);
     hipLaunchKernelGGL(kern, dim3(p.B), dim3(512), lds, stream, p);
     }
     if (BWD && p.ws) {

@@ -115,12 +115,12 @@ static void bench(int dtype, int M, int N, int K, int cfg, int mode) {
 }
 
 #ifdef UIA_GEMM_STAMPS
-extern __device__ unsigned long long* uia_stamp_buf;
-extern __device__ int uia_epi_diag;
+#include "../gemm.hip"      // one translation unit: the stamp buffer / diag switch are __device__ globals of gemm.hip
 static void stamps(int cfg, int M, int N, int K, int mode, int diag = 0) {
     HC(hipMemcpyToSymbol(HIP_SYMBOL(uia_epi_diag), &diag, sizeof(diag)));
     if (diag) printf("-- diag %d (1: no stores, 2: no stores/operand loads, +4 no ds_reads, +8 no DMA, +16 no MFMA)\n", diag);
-    const int BM = 256, BN = (cfg == 7 || cfg == 9) ? 128 : 256, NW = 8;
+    const int cfgb = cfg & 255;
+    const int BM = 256, BN = (cfgb == 7 || cfgb == 9) ? 128 : 256, NW = 8;
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     unsigned long long* d; HC(hipMalloc(&d, ((size_t)tiles * NW * 4 + (size_t)tiles * 4) * 8));
     HC(hipMemcpyToSymbol(HIP_SYMBOL(uia_stamp_buf), &d, sizeof(d)));
@@ -132,7 +132,7 @@ static void stamps(int cfg, int M, int N, int K, int mode, int diag = 0) {
     const double n = (double)tiles * NW;
     printf("STAMPS cfg=%d M=%d N=%d K=%d mode=%d: per-wave ticks (100MHz s_memtime? see ratio) prologue %.0f  k-loop %.0f (%.0f per K-step)  epilogue %.0f  total %.0f ; kernel span %llu ticks\n",
            cfg, M, N, K, mode, pro / n, loop / n, loop / n / (K / 64), epi / n, tot / n, t1 - t0);
-    if (cfg >= 8) {   // ring kernel: q[0] = HW_ID, q[1] = XCC_ID of wave 0.  Group blocks by CU and look at the gaps between consecutive blocks.
+    if (cfgb >= 8) {   // ring kernel: q[0] = HW_ID, q[1] = XCC_ID of wave 0.  Group blocks by CU and look at the gaps between consecutive blocks.
         const unsigned long long* q = h.data() + (size_t)tiles * NW * 4;
         std::map<unsigned, std::vector<std::pair<unsigned long long, unsigned long long>>> per_cu;
         for (int b = 0; b < tiles; ++b) {
@@ -160,9 +160,22 @@ static void stamps(int cfg, int M, int N, int K, int mode, int diag = 0) {
 
 int main(int argc, char** argv) {
 #ifdef UIA_GEMM_STAMPS
-    stamps(8, 50432, 2304, 768, 0, 0);
+    // ./test_gemm_stamps [cfg|flags<<8  M N K mode diag]
+    if (argc > 6) stamps(atoi(argv[1]), atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]));
+    else stamps(8, 50432, 2304, 768, 0, 0);
     return 0;
 #endif
+    if (argc > 1 && !strcmp(argv[1], "exp")) {      // ./test_gemm exp: tile-order group size (bits 8..15) x diagnostic K-blocked operand addressing (bits 16, 17)
+        const int shapes[][4] = {{50432, 768, 768, 2}, {50432, 2304, 768, 0}, {50432, 3072, 768, 1}, {50432, 768, 3072, 2}, {65536, 3072, 768, 0}, {50432, 768, 2304, 0}};
+        for (auto& sh : shapes)
+            for (int kb : {0, 1, 2, 3})
+                for (int gm : {0, 4, 8, 16}) {
+                    if (kb && gm != 0 && gm != 8) continue;
+                    printf("gm=%d kbA=%d kbW=%d  ", gm, kb & 1, kb >> 1);
+                    bench(UIA_BF16, sh[0], sh[1], sh[2], 8 | (gm << 8) | (kb << 16), sh[3]);
+                }
+        return 0;
+    }
     if (argc > 1 && !strcmp(argv[1], "cmp")) {      // ./test_gemm cmp: ring (8) vs persistent (12) on the training step's shapes
         const int shapes[][4] = {{50432, 2304, 768, 0}, {65536, 2304, 768, 0}, {50432, 3072, 768, 1}, {50432, 768, 3072, 2}, {65536, 768, 3072, 2},
                                  {50432, 768, 768, 2}, {65536, 768, 768, 2}, {50432, 768, 2304, 0}, {50432, 768, 64, 2}};

@@ -38,6 +38,25 @@ void uia_set_error(const char* fmt, ...);
     } while (0)
 #define UIA_CHECK_LAUNCH() UIA_CHECK_HIP(hipGetLastError())
 
+// ---------------------------------------------------------------- per-device launch attributes
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is recorded PER DEVICE, so the "already done" flag of a kernel
+// instantiation is a bit per device ordinal (a process that touches a second GPU must set it there too), atomically
+// updated (two host threads racing set the same idempotent attribute twice at worst).
+#include <atomic>
+struct UiaDevOnce {
+    std::atomic<unsigned long long> mask{0};
+};
+#define UIA_ENSURE_LDS_ATTR(once, kern, bytes)                                                                     \
+    do {                                                                                                           \
+        int _dev = 0;                                                                                              \
+        UIA_CHECK_HIP(hipGetDevice(&_dev));                                                                        \
+        const unsigned long long _bit = 1ull << (_dev & 63);                                                       \
+        if (!((once).mask.load(std::memory_order_acquire) & _bit)) {                                               \
+            UIA_CHECK_HIP(hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes))); \
+            (once).mask.fetch_or(_bit, std::memory_order_release);                                                 \
+        }                                                                                                          \
+    } while (0)
+
 // ---------------------------------------------------------------- element load/store
 __device__ __forceinline__ float to_f32(float x) { return x; }
 __device__ __forceinline__ float to_f32(bf16_t x) { return (float)x; }

@@ -21,7 +21,7 @@ int uia_cast_launch(hipStream_t stream, int dtype, size_t n, const float* src, v
 int uia_transpose_cast_launch(hipStream_t stream, int dtype, int rows, int cols, const float* src, void* dst);
 int uia_im2col_launch(hipStream_t stream, int dtype, int B, int C, int H, int W, int P, const float* img, void* out);
 int uia_fill_cls_launch(hipStream_t stream, int B, int N, int D, const float* cls, const float* pos0, float* x);
-int uia_embed_launch(hipStream_t stream, int rows, int L, int D, const int64_t* ids, const float* table, const float* pos, const float* type0, float* out);
+int uia_embed_launch(hipStream_t stream, int rows, int L, int D, int vocab, int max_pos, const int64_t* ids, const float* table, const float* pos, const float* type0, float* out);
 int uia_gather_rows_launch(hipStream_t stream, int n, int D, const float* src, const int64_t* idx, float* dst);
 int uia_wgrad_launch(hipStream_t stream, int dtype, int M, int I, int J, const void* A, long lda, const void* B, long ldb, float alpha, float* dW, float* dbias);
 int uia_mona_pre_fwd_launch(hipStream_t stream, int dtype, int M, int D, const float* x, const float* nw, const float* nb, const float* gamma,
@@ -54,5 +54,5 @@ int uia_segment_mean_launch(hipStream_t stream, bool bwd, int B, int n, int C, c
 size_t uia_dicece_ws_floats(int B);
 int uia_dicece_launch(hipStream_t stream, int B, int C, int HW, const float* logits, const float* label, float nr, float dr, float* ws, float* loss, float* dlogits);
 int uia_im2col_padded_launch(hipStream_t stream, int dtype, int B, int C, int H, int W, int P, const float* img, void* out, long ldo);
-int uia_embed_bwd_launch(hipStream_t stream, int rows, int D, const int64_t* ids, const float* dx, float* dtable, long pad_id);
-int uia_embed_packed_launch(hipStream_t stream, int rows, int D, const int64_t* ids, const int64_t* pos_idx, const float* table, const float* pos, const float* type0, float* out);
+int uia_embed_bwd_launch(hipStream_t stream, int rows, int D, int vocab, const int64_t* ids, const float* dx, float* dtable, long pad_id);
+int uia_embed_packed_launch(hipStream_t stream, int rows, int D, int vocab, int max_pos, const int64_t* ids, const int64_t* pos_idx, const float* table, const float* pos, const float* type0, float* out);

@@ -40,9 +40,47 @@ class TensorPairs(Dataset):
         return (img.float() / 255.0 if img.dtype == torch.uint8 else img.float()), self.texts[i]
 
 
+class RankShardSampler(torch.utils.data.Sampler):
+    """torch.utils.data.DistributedSampler semantics without needing an initialised process group: every rank draws the SAME
+    permutation of the dataset (seeded by seed + epoch), the index list is padded by wrap-around (or truncated with
+    drop_last) to a multiple of `world`, and rank r takes indices r, r + world, r + 2·world, ...  Every rank therefore sees
+    the same NUMBER of samples — the loops' collectives stay aligned — and the ranks' shards are disjoint: R ranks x 1
+    micro-batch is the reference's accumulation over R different micro-batches (finetune.py:287-302)."""
+
+    def __init__(self, n, rank=0, world=1, shuffle=True, seed=0, drop_last=False):
+        assert 0 <= rank < world
+        self.n, self.rank, self.world, self.shuffle, self.seed, self.drop_last = n, rank, world, shuffle, seed, drop_last
+        self.epoch = 0
+        self.per_rank = n // world if drop_last else (n + world - 1) // world
+
+    def set_epoch(self, epoch):
+        self.epoch = int(epoch)
+
+    def indices(self):
+        if self.shuffle:
+            order = torch.randperm(self.n, generator=torch.Generator().manual_seed(self.seed + self.epoch)).tolist()
+        else:
+            order = list(range(self.n))
+        total = self.per_rank * self.world
+        if total > len(order):
+            order = (order * (total // max(len(order), 1) + 1))[:total]
+        return order[:total][self.rank::self.world]
+
+    def __iter__(self):
+        return iter(self.indices())
+
+    def __len__(self):
+        return self.per_rank
+
+
 class DataModule:
-    def __init__(self, args):
+    def __init__(self, args, rank=None, world=None):
+        """rank / world default to the torch.distributed.run environment (RANK / WORLD_SIZE); world == 1 is the reference's
+        single-process loader (shuffle=True, drop_last=True, datasets/finetune.py:124-142)."""
+        import os
         self.args = args
+        self.rank = int(os.environ.get("RANK", 0)) if rank is None else rank
+        self.world = int(os.environ.get("WORLD_SIZE", 1)) if world is None else world
         if getattr(args, "data_pt", None):
             blob = torch.load(args.data_pt)
             n_val = max(args.batch_size, len(blob["texts"]) // 10)
@@ -54,9 +92,23 @@ class DataModule:
         else:
             raise RuntimeError("no dataset: pass --synthetic or --data_pt (the reference's CSV/PIL loaders need torchvision, "
                                "which is outside this build)")
+        self.train_sampler = self.val_sampler = None
+
+    def _loader(self, ds, shuffle):
+        if self.world > 1:
+            sampler = RankShardSampler(len(ds), self.rank, self.world, shuffle=shuffle, seed=getattr(self.args, "seed", 0))
+            return DataLoader(ds, batch_size=self.args.batch_size, sampler=sampler, num_workers=0, drop_last=True), sampler
+        return DataLoader(ds, batch_size=self.args.batch_size, shuffle=shuffle, num_workers=0, drop_last=True), None
 
     def train_dataloader(self):
-        return DataLoader(self.train, batch_size=self.args.batch_size, shuffle=True, num_workers=0, drop_last=True)
+        loader, self.train_sampler = self._loader(self.train, True)
+        return loader
 
     def val_dataloader(self):
-        return DataLoader(self.val, batch_size=self.args.batch_size, shuffle=False, num_workers=0, drop_last=True)
+        loader, self.val_sampler = self._loader(self.val, False)
+        return loader
+
+    def set_epoch(self, epoch):
+        """Reshuffle the rank shards for a new epoch (DistributedSampler.set_epoch); no-op in a single process."""
+        if self.train_sampler is not None:
+            self.train_sampler.set_epoch(epoch)

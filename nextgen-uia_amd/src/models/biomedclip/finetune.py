@@ -32,7 +32,7 @@ from src.losses import InfoNCELoss
 from src.third_party.biomedclip.model import SyntheticTokenizer, create_biomedclip
 from src.utils.tools import model_summary, parse_config, setup_logging
 from uia_hip import functional as UF
-from uia_hip.engine import FlatAdapterOptimizer, cosine_lr, init_data_parallel
+from uia_hip.engine import FlatAdapterOptimizer, all_ranks_agree, bind_device, cosine_lr, init_data_parallel, sum_over_ranks
 
 
 def get_args(argv=None):
@@ -138,44 +138,49 @@ def _save_checkpoint(model, args, save_path):
 
 
 def train(args):
+    rank, _, world = bind_device(args)                         # data parallel: cuda:LOCAL_RANK before anything is allocated
     UF.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
-    UF.set_dropout_seed(args.seed)
+    UF.set_dropout_seed(args.seed + 7919 * rank)                # ranks draw different dropout masks, like different micro-batches
     model, tokenizer = prepare_model(args)
     model.train()
     logging.info(model_summary({"model": model}))
-    dm = dataset_finetune.DataModule(args)
+    dm = dataset_finetune.DataModule(args, rank=rank, world=world)
     trainloader, valloader = dm.train_dataloader(), dm.val_dataloader()
     criterion = InfoNCELoss(temperature=args.temperature)
     opt = FlatAdapterOptimizer([(n, p) for n, p in model.named_parameters() if p.requires_grad], lr=args.lr,
                                betas=(args.beta1_adam, args.beta2_adam), weight_decay=args.weight_decay, max_norm=args.grad_clip)
-    rank, _, world = init_data_parallel(opt) if int(os.environ.get("WORLD_SIZE", 1)) > 1 else (0, 0, 1)
+    if world > 1:
+        init_data_parallel(opt)
     updates_per_epoch = math.ceil(len(trainloader) / args.accumulation_steps)
     total_updates = updates_per_epoch * args.epochs
     logging.info(f"Gradient accumulation steps: {args.accumulation_steps}; updates per epoch: {updates_per_epoch}; world: {world}")
 
     update_count, best_loss, best_epoch, patience = 0, float("inf"), 0, 0
+    avg_train = 0.0
     opt.zero_grad()
     for epoch in range(args.epochs):
         model.train()
-        ep_loss, ep_n, in_cycle = 0.0, 0, 0
+        dm.set_epoch(epoch)
+        ep_loss, ep_n = 0.0, 0
         for batch_idx, (images, texts) in enumerate(trainloader):
             images = images.to(args.device)
             tokens = tokenizer(list(texts)).to(args.device)
             loss = criterion(model.encode_image(images), model.encode_text(tokens))
-            if not torch.isfinite(loss):
+            # reference :281-285 skips a non-finite micro-batch (and with it the update check of that iteration).  Under data
+            # parallelism the decision is COLLECTIVE: a rank that skipped alone would miss opt.all_reduce() below while the
+            # others wait in it, so every rank skips when any rank's loss is non-finite (same control flow everywhere).
+            if not all_ranks_agree(bool(torch.isfinite(loss))):
                 logging.warning(f"Non-finite loss detected at batch {batch_idx} in epoch {epoch + 1}, skipping batch")
                 continue
             (loss / args.accumulation_steps).backward()
             ep_loss += loss.item()
             ep_n += 1
-            in_cycle += 1
             if ((batch_idx + 1) % args.accumulation_steps == 0) or (batch_idx + 1 == len(trainloader)):
                 opt.all_reduce()
                 update_count += 1
                 opt.step(lr=cosine_lr(args.lr, args.lr_min, update_count - 1, total_updates))
                 opt.zero_grad()
                 UF.clear_t_copies()
-                in_cycle = 0
         model.eval()
         val_loss, val_n = 0.0, 0
         with torch.no_grad():
@@ -184,6 +189,9 @@ def train(args):
                 if torch.isfinite(loss):
                     val_loss += loss.item()
                     val_n += 1
+        # every rank evaluated its own shard: the epoch's figures are the sums over ranks, so that the checkpoint / patience /
+        # early-stop decisions below are identical on every rank (a rank that stopped alone would strand the others)
+        val_loss, val_n, ep_loss, ep_n = sum_over_ranks(val_loss, val_n, ep_loss, ep_n)
         avg_val, avg_train = (val_loss / val_n if val_n else 0.0), (ep_loss / ep_n if ep_n else 0.0)
         if avg_val < best_loss:
             best_loss, patience, best_epoch = avg_val, 0, epoch
@@ -197,7 +205,12 @@ def train(args):
             logging.info(f"\nEarly stopping at epoch {epoch + 1} as validation loss did not improve for {args.patience} epochs.")
             break
     logging.info(f"\n✓ Training completed! Best validation loss: {best_loss:.4f} at epoch {best_epoch + 1}")
-    return {"best_val": best_loss, "updates": update_count, "last_train": avg_train}
+    if world > 1:
+        from uia_hip import ops
+        import torch.distributed as dist
+        dist.barrier()
+        ops.comm_destroy()
+    return {"best_val": best_loss, "updates": update_count, "last_train": avg_train, "rank": rank, "world": world}
 
 
 def main(argv=None):

@@ -29,7 +29,7 @@ from src.third_party.biomedclip.model import create_biomedclip
 from src.third_party.timm.clip_adapter import TimmCLIPAdapter
 from src.utils.tools import model_summary, parse_config, setup_logging
 from uia_hip import functional as UF
-from uia_hip.engine import FlatAdapterOptimizer, cosine_lr, init_data_parallel
+from uia_hip.engine import FlatAdapterOptimizer, bind_device, cosine_lr, init_data_parallel
 
 
 def get_args(argv=None):
@@ -105,7 +105,9 @@ def _batches(args, n, seed0, rank=0, world=1):
     if args.data_pt:
         blob = torch.load(args.data_pt)
         images, labels = blob["images"].float(), blob["labels"].float()
-        for i in range(0, len(images) - args.batch_size + 1, args.batch_size):
+        nb = len(images) // args.batch_size // world * world                  # every rank takes the same number of batches, its own ones
+        for b in range(rank, nb, world):
+            i = b * args.batch_size
             yield images[i:i + args.batch_size].to(args.device), labels[i:i + args.batch_size].to(args.device)
         return
     if not args.synthetic:
@@ -115,16 +117,18 @@ def _batches(args, n, seed0, rank=0, world=1):
 
 
 def train(args):
+    rank, _, world = bind_device(args)                         # data parallel: cuda:LOCAL_RANK before anything is allocated
     UF.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
-    UF.set_dropout_seed(args.seed)
+    UF.set_dropout_seed(args.seed + 7919 * rank)
     model = prepare_model(args)
     model.train()
     logging.info(model_summary({"model": model}))
     criterion = DiceCELoss()
     opt = FlatAdapterOptimizer([(n, p) for n, p in model.named_parameters() if p.requires_grad], lr=args.lr, betas=(args.beta1, args.beta2),
                                weight_decay=args.weight_decay, max_norm=0.0)
-    rank, _, world = init_data_parallel(opt) if int(os.environ.get("WORLD_SIZE", 1)) > 1 else (0, 0, 1)
-    iters_per_epoch = len(list(_batches(args, args.synthetic_train, 0))) if args.data_pt else max(1, args.synthetic_train // args.batch_size)
+    if world > 1:
+        init_data_parallel(opt)
+    iters_per_epoch = len(list(_batches(args, args.synthetic_train, 0, rank, world))) if args.data_pt else max(1, args.synthetic_train // args.batch_size)
     max_iters = iters_per_epoch * args.epochs
     iter_num, best_val_dice, patience, last = 0, 0.0, 0, None
     for epoch in range(args.epochs):

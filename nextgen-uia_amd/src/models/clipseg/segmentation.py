@@ -23,7 +23,7 @@ from src.third_party.openai_clip.clipseg_adapter import CLIPSegAdapter
 from src.third_party.openai_clip.model import CLIP, build_model
 from src.utils.tools import model_summary, setup_logging
 from uia_hip import functional as UF
-from uia_hip.engine import FlatAdapterOptimizer, cosine_lr, init_data_parallel
+from uia_hip.engine import FlatAdapterOptimizer, bind_device, cosine_lr, init_data_parallel
 
 
 def get_args(argv=None):
@@ -76,13 +76,15 @@ def prepare_model(args):
 
 
 def train(args):
+    rank, _, world = bind_device(args)                         # data parallel: cuda:LOCAL_RANK before anything is allocated
     UF.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
     model = prepare_model(args)
     logging.info(model_summary({"model": model}))
     criterion = DiceCELoss()
     opt = FlatAdapterOptimizer([(n, p) for n, p in model.named_parameters() if p.requires_grad], lr=args.lr, betas=(0.9, 0.999),
                                weight_decay=args.weight_decay, max_norm=0.0)
-    rank, _, world = init_data_parallel(opt) if int(os.environ.get("WORLD_SIZE", 1)) > 1 else (0, 0, 1)
+    if world > 1:
+        init_data_parallel(opt)
     prompt = (busi_prompt if args.dataset == "BUSI" else synthetic_prompt(seed=hash(args.dataset) % 1000)).to(args.device)
     if not args.synthetic:
         raise RuntimeError("no dataset: pass --synthetic (the reference's PIL/torchvision loaders are outside this build)")

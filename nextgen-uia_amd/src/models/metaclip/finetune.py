@@ -26,7 +26,7 @@ from src.losses import InfoNCELoss
 from src.third_party.open_clip.model import SyntheticClipTokenizer, create_metaclip
 from src.utils.tools import model_summary, parse_config, setup_logging
 from uia_hip import functional as UF
-from uia_hip.engine import FlatAdapterOptimizer, cosine_lr, init_data_parallel
+from uia_hip.engine import FlatAdapterOptimizer, all_ranks_agree, bind_device, cosine_lr, init_data_parallel, sum_over_ranks
 
 
 def get_args(argv=None):
@@ -88,27 +88,30 @@ def _features(model, tokenizer, images, texts, device):
 
 
 def train(args):
+    rank, _, world = bind_device(args)                         # data parallel: cuda:LOCAL_RANK before anything is allocated
     UF.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
-    UF.set_dropout_seed(args.seed)
+    UF.set_dropout_seed(args.seed + 7919 * rank)
     model, tokenizer = prepare_model(args)
     model.train()
     logging.info(model_summary({"model": model}))
-    dm = dataset_finetune.DataModule(args)
+    dm = dataset_finetune.DataModule(args, rank=rank, world=world)
     trainloader, valloader = dm.train_dataloader(), dm.val_dataloader()
     criterion = InfoNCELoss(temperature=args.temperature)
     opt = FlatAdapterOptimizer([(n, p) for n, p in model.named_parameters() if p.requires_grad], lr=args.lr,
                                betas=(args.beta1_adam, args.beta2_adam), weight_decay=args.weight_decay, max_norm=1.0)
-    rank, _, world = init_data_parallel(opt) if int(os.environ.get("WORLD_SIZE", 1)) > 1 else (0, 0, 1)
+    if world > 1:
+        init_data_parallel(opt)
     max_iters = len(trainloader) * args.epochs
     iter_num, best_loss, best_epoch, patience = 0, float("inf"), 0, 0
     train_loss = 0.0
     for epoch in range(args.epochs):
         model.train()
+        dm.set_epoch(epoch)
         train_loss = 0.0
         for images, texts in trainloader:
             fi, ft = _features(model, tokenizer, images, texts, args.device)
             loss = criterion(fi, ft)
-            if not torch.isfinite(loss):
+            if not all_ranks_agree(bool(torch.isfinite(loss))):      # collective decision: a lone skip would strand the other ranks in the all-reduce
                 logging.warning(f"Non-finite loss detected at iteration {iter_num}, skipping batch")
                 continue
             opt.zero_grad()
@@ -127,6 +130,7 @@ def train(args):
                 if torch.isfinite(loss):
                     val_loss += loss.item()
         val_loss /= max(1, len(valloader))
+        val_loss, train_loss = (v / world for v in sum_over_ranks(val_loss, train_loss))      # same figures, same decisions on every rank
         logging.info(f"Epoch {epoch + 1}/{args.epochs}: Train={train_loss:.4f}, Val={val_loss:.4f}, Best={best_loss:.4f}")
         if val_loss < best_loss:
             best_loss, best_epoch, patience = val_loss, epoch, 0
@@ -140,6 +144,11 @@ def train(args):
             logging.info(f"Early stopping triggered at epoch {epoch + 1}")
             break
     logging.info(f"\n✓ Training completed! Best loss: {best_loss:.4f} (epoch {best_epoch + 1})")
+    if world > 1:
+        from uia_hip import ops
+        import torch.distributed as dist
+        dist.barrier()
+        ops.comm_destroy()
     return {"best_val": best_loss, "iters": iter_num, "last_train": train_loss}
 
 

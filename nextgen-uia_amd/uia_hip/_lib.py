@@ -90,9 +90,9 @@ PROTOTYPES = {
     "uia_im2col": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "uia_im2col_padded": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int64]),
     "uia_fill_cls": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
-    "uia_embed": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
-    "uia_embed_bwd": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, C.c_int64]),
-    "uia_embed_packed": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]),
+    "uia_embed": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
+    "uia_embed_bwd": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int64]),
+    "uia_embed_packed": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]),
     "uia_gather_rows": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp]),
 }
 

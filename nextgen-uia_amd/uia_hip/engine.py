@@ -18,44 +18,99 @@ from . import functional as UF
 from . import ops
 
 
-class FlatAdapterOptimizer:
-    def __init__(self, named_params, lr=1e-4, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.01, max_norm=1.0):
+class FlatLayout:
+    """Where every trainable parameter lives inside the flat fp32 buffers: element offsets (each view 16-byte aligned) and the
+    four buffers themselves.  Device-agnostic on purpose — the world-size-2 gloo test (tests/test_dp_gloo.py) drives exactly
+    this code on CPU tensors; the optimiser below adds the fused HIP update on top of it."""
+
+    ALIGN = 4                                                   # fp32 elements per 16 bytes
+
+    def __init__(self, named_params):
         self.names = [k for k, _ in named_params]
         self.params = [p for _, p in named_params]
         assert self.params, "no trainable parameters"
         dev = self.params[0].device
-        assert dev.type == "cuda", "the fused optimiser runs on the GPU only"
+        assert all(p.device == dev for p in self.params), "trainable parameters must live on ONE device (one process per GPU)"
+        assert all(p.dtype == torch.float32 for p in self.params), "adapter parameters are fp32 masters"
+        self.device = dev
         self.offsets, n = [], 0
         for p in self.params:
             self.offsets.append(n)
-            n += (p.numel() + 3) // 4 * 4                     # keep every view 16-byte aligned
+            n += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
         self.numel = n
         self.p = torch.zeros(n, device=dev)
         self.g = torch.zeros(n, device=dev)
         self.m = torch.zeros(n, device=dev)
         self.v = torch.zeros(n, device=dev)
-        self.ws = torch.zeros(2, device=dev)
         with torch.no_grad():
             for p, off in zip(self.params, self.offsets):
                 view = self.p[off:off + p.numel()].view(p.shape)
                 view.copy_(p.data)
                 p.data = view
                 p.grad = self.g[off:off + p.numel()].view(p.shape)
+
+    def grad_views_intact(self):
+        """True while every parameter's .grad is still the view of the flat gradient buffer handed out at construction
+        (an `optimizer.zero_grad(set_to_none=True)` or a re-assigned .grad breaks it)."""
+        g0 = self.g.data_ptr()
+        return all(p.grad is not None and p.grad.data_ptr() == g0 + 4 * off for p, off in zip(self.params, self.offsets))
+
+    def rebind_grads(self):
+        for p, off in zip(self.params, self.offsets):
+            p.grad = self.g[off:off + p.numel()].view(p.shape)
+
+    def unflatten(self, flat):
+        return {k: flat[off:off + p.numel()].view(p.shape) for k, p, off in zip(self.names, self.params, self.offsets)}
+
+
+def dp_grad_scale(world, global_loss=False):
+    """Factor applied to the all-reduced (SUMMED) gradient buffer: 1/world for the reference-equivalent local loss (every
+    rank back-propagates its own mean loss ≡ finetune.py:287-288 with accumulation_steps = world); 1 for the opt-in
+    global-batch loss, whose per-rank contributions already add up to the gradient of the one global loss."""
+    return 1.0 if global_loss else 1.0 / world
+
+
+class FlatAdapterOptimizer(FlatLayout):
+    def __init__(self, named_params, lr=1e-4, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.01, max_norm=1.0):
+        super().__init__(named_params)
+        assert self.device.type == "cuda", "the fused optimiser runs on the GPU only"
+        self.ws = torch.zeros(2, device=self.device)
         self.lr, self.betas, self.eps, self.weight_decay, self.max_norm = lr, betas, eps, weight_decay, max_norm
         self.steps = 0
         self.world = 1
+        for p in self.params:                                   # MonaFn may accumulate straight into these views (functional.mona_apply)
+            p._uia_flat_grad = True
 
-    def zero_grad(self):
+    def zero_grad(self, set_to_none=False):
+        """Zeroes the flat gradient buffer; the .grad views stay bound (set_to_none is accepted for torch.optim call sites and
+        ignored: dropping the views would orphan the buffer the all-reduce and the fused update work on)."""
         self.g.zero_()
+        if not self.grad_views_intact():
+            self.rebind_grads()
+
+    def _adopt_grads(self):
+        """A caller that dropped or replaced the .grad views (zero_grad(set_to_none=True), manual assignment) makes autograd
+        write gradients into tensors of its own: fold those into the flat buffer and re-bind the views, so that the
+        all-reduce and the fused update never run on a buffer the backward did not fill."""
+        if self.grad_views_intact():
+            return
+        with torch.no_grad():
+            for p, off in zip(self.params, self.offsets):
+                view = self.g[off:off + p.numel()].view(p.shape)
+                if p.grad is not None and p.grad.data_ptr() != view.data_ptr():
+                    view.add_(p.grad.to(view.dtype))
+                p.grad = view
 
     def all_reduce(self):
+        self._adopt_grads()
         if self.world > 1:
             ops.allreduce_sum(self.g)
 
     def step(self, lr=None, grad_scale=None):
         """One update from the accumulated gradient buffer (already all-reduced when world > 1)."""
+        self._adopt_grads()
         self.steps += 1
-        gs = (1.0 / self.world) if grad_scale is None else grad_scale
+        gs = dp_grad_scale(self.world) if grad_scale is None else grad_scale
         ops.adamw_clip_step(self.p, self.g, self.m, self.v, self.lr if lr is None else lr, self.betas, self.eps, self.weight_decay,
                             self.max_norm, self.steps, gs, self.ws)
         UF.WEIGHTS.bump()                                      # T copies of the adapter weights are stale now
@@ -77,12 +132,28 @@ def dist_env():
     return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
 
 
+def bind_device(args=None):
+    """FIRST call of an entry point under torch.distributed.run: binds this process to cuda:LOCAL_RANK *before* the model, the
+    flat optimiser buffers or any stream exist, and points `args.device` there (the reference's single `--device` flag,
+    finetune.py:101, cannot name a per-rank GPU).  Single process: leaves everything alone."""
+    rank, local, world = dist_env()
+    if world > 1:
+        torch.cuda.set_device(local)
+        if args is not None:
+            args.device = f"cuda:{local}"
+    return rank, local, world
+
+
 def init_data_parallel(opt=None):
-    """One process per GPU.  torch.distributed (RCCL backend) is used for rendezvous, barriers and the unique-id
-    broadcast only; the gradient all-reduce itself is the library's own RCCL call on the compute stream."""
+    """One process per GPU.  torch.distributed (RCCL backend) is used for rendezvous, barriers, the unique-id broadcast and the
+    scalar control-flow agreements below; the gradient all-reduce itself is the library's own RCCL call on the compute stream.
+    The device must already be bound (bind_device) — buffers created before that would sit on cuda:0 on every rank."""
     import torch.distributed as dist
     rank, local, world = dist_env()
     torch.cuda.set_device(local)
+    if opt is not None and opt.device.type == "cuda" and opt.device.index not in (None, local):
+        raise RuntimeError(f"rank {rank}: optimiser buffers are on {opt.device} but this process owns cuda:{local}; call "
+                           "uia_hip.engine.bind_device(args) before building the model")
     if world > 1:
         if not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -90,13 +161,42 @@ def init_data_parallel(opt=None):
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         uid = [ops.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
-        ops.comm_init(rank, world, uid[0])
+        try:
+            ops.comm_init(rank, world, uid[0])
+        except Exception as e:                                 # surface WHICH rank failed: the others will be blocked in the init
+            raise RuntimeError(f"rank {rank}/{world} (cuda:{local}): RCCL communicator init failed: {e}") from e
     if opt is not None:
         opt.world = world
         if world > 1:                                          # identical adapter weights on every rank
-            import torch.distributed as dist
             dist.broadcast(opt.p, src=0)
     return rank, local, world
+
+
+# ---- scalar agreements between ranks (control plane; torch.distributed, any backend).  Every rank must take the same branch
+#      around a collective, otherwise the others block in it forever (a rank that `continue`s past opt.all_reduce()).
+def all_ranks_agree(flag, device=None):
+    """True iff `flag` is true on EVERY rank (single process: flag itself)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return bool(flag)
+    t = torch.tensor([1.0 if flag else 0.0], device=device if device is not None else _pg_device())
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(t.item() > 0.5)
+
+
+def sum_over_ranks(*values, device=None):
+    """Element-wise sum of python scalars over the ranks (single process: the values)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return tuple(float(v) for v in values)
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device if device is not None else _pg_device())
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return tuple(t.tolist())
+
+
+def _pg_device():
+    import torch.distributed as dist
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
 
 
 class GatherFeaturesFn(torch.autograd.Function):
@@ -165,5 +265,5 @@ def contrastive_step(model, criterion, opt, images, ids, micro_batches=1, lr=Non
         (loss / micro_batches).backward()
         total = loss.detach() if total is None else total + loss.detach()
     opt.all_reduce()
-    opt.step(lr=lr, grad_scale=1.0 if global_loss else None)
+    opt.step(lr=lr, grad_scale=dp_grad_scale(opt.world, global_loss))
     return total / micro_batches

@@ -146,7 +146,7 @@ class MonaFn(torch.autograd.Function):
     """y = x + project2(drop(gelu(spatial(project1(LN(x)·γ + x·γx)))))  on batch-first x [B, N, D] fp32."""
 
     @staticmethod
-    def forward(ctx, x, variant, hw, p_drop, keep_mask, names, grad_bufs, *params):
+    def forward(ctx, x, variant, hw, p_drop, keep_mask, names, direct, *params):
         P = dict(zip(names, params))
         B, N, D = x.shape
         h, w = hw
@@ -169,7 +169,7 @@ class MonaFn(torch.autograd.Function):
         ops.gemm(d, w2, bias=P["project2.bias"], resid=x.view(M, D), out32=y.view(M, D))
         ctx.save_for_backward(x, u, t, d, keep_mask if keep_mask is not None else x.new_empty(0), *params)
         ctx.meta = (variant, hw, p_drop, seed, names, keep_mask is not None)
-        ctx.grad_bufs = grad_bufs
+        ctx.direct_params = tuple(params) if direct else None      # the Parameter objects themselves: .grad is looked up at BACKWARD time
         return y
 
     @staticmethod
@@ -184,8 +184,13 @@ class MonaFn(torch.autograd.Function):
         bott = t.shape[1]
         dy = dy.contiguous()
         dy_t = t_copy_of(dy, dt).view(M, D)
-        direct = ctx.grad_bufs is not None          # accumulate straight into the (flat-buffer) .grad views: no fills, no adds
-        G = dict(zip(names, ctx.grad_bufs)) if direct else {k: torch.zeros_like(v, dtype=torch.float32) for k, v in P.items()}
+        # Direct mode: accumulate straight into the flat-buffer .grad views (no fills, no adds, nothing returned to autograd).
+        # It is an explicit opt-in of FlatAdapterOptimizer (engine.py marks its parameters), and the views are re-read HERE,
+        # at backward time: if the caller dropped or replaced them in between (optimizer.zero_grad(set_to_none=True),
+        # torch.autograd.grad, a GradScaler-style consumer) the gradients are returned to autograd like any other Function.
+        direct = ctx.direct_params is not None and all(_is_flat_grad(p) for p in ctx.direct_params)
+        G = ({k: p.grad for k, p in zip(names, ctx.direct_params)} if direct
+             else {k: torch.zeros_like(v, dtype=torch.float32) for k, v in P.items()})
         # project2: dd = dy·W2 ; dW2 = dyᵀ·d ; db2 = Σ dy
         w2t = WEIGHTS.get(P["project2.weight"], dt, transpose=True)          # [bott, D]
         dd = _empty((M, bott), dt, x)
@@ -212,15 +217,19 @@ class MonaFn(torch.autograd.Function):
         return (dx, None, None, None, None, None, None) + grads
 
 
+def _is_flat_grad(p):
+    g = p.grad
+    return (getattr(p, "_uia_flat_grad", False) and g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.shape == p.shape
+            and g.device == p.device)
+
+
 def mona_apply(x_bnd, module_params, variant, hw, p_drop, training, keep_mask=None):
     """module_params: ordered {relative name: Parameter}."""
     names = tuple(k for k in MONA_PARAM_ORDER if k in module_params)
     pd = p_drop if (training or keep_mask is not None) else 0.0
     params = [module_params[k] for k in names]
-    bufs = [p.grad for p in params]
-    direct = torch.is_grad_enabled() and all(p.requires_grad and g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.shape == p.shape
-                                             for p, g in zip(params, bufs))
-    return MonaFn.apply(x_bnd, variant, tuple(hw), pd, keep_mask, names, bufs if direct else None, *params)
+    direct = torch.is_grad_enabled() and all(p.requires_grad and _is_flat_grad(p) for p in params)
+    return MonaFn.apply(x_bnd, variant, tuple(hw), pd, keep_mask, names, direct, *params)
 
 
 # ================================================================================================ ViT block
@@ -479,7 +488,13 @@ class MlpHalfFn(torch.autograd.Function):
         return dx1.view(shape), None
 
 
-LORA_PAD = 64     # rank is zero-padded to the GEMM's K granule; padded rows/columns contribute exactly 0
+LORA_PAD = 64     # rank is zero-padded to a multiple of the GEMM's K granule; padded rows/columns contribute exactly 0
+
+
+def _rank_pad(r):
+    """Padded rank: the next multiple of 64 (r = 16 -> 64, r = 96 -> 128).  Every [., rank] buffer of the rank-form path is
+    allocated with this width, so no GEMM ever writes N = r columns into a narrower row (an out-of-bounds write for r > 64)."""
+    return max(LORA_PAD, (int(r) + LORA_PAD - 1) // LORA_PAD * LORA_PAD)
 
 
 class LoraLinearFn(torch.autograd.Function):
@@ -503,15 +518,14 @@ class LoraLinearFn(torch.autograd.Function):
             xd = torch.empty_like(x)
             ops.dropout(x, xd, p_drop, seed)
         if r > 0:
-            t = _empty((M, LORA_PAD), dt, x)
-            ops.gemm(xd, WEIGHTS.get(A, dt, pad_rows_to=LORA_PAD), out_t=t)
-            bpad = WEIGHTS.get(Bm, dt, transpose=True, pad_rows_to=None)            # [r, N] → need [N, LORA_PAD]
-            bmat = _pad_cols(Bm, dt)
+            rp = _rank_pad(r)
+            t = _empty((M, rp), dt, x)
+            ops.gemm(xd, WEIGHTS.get(A, dt, pad_rows_to=rp), out_t=t)
+            bmat = _pad_cols(Bm, dt)                                                # [N, rp]
             if y32 is not None:
                 ops.gemm(t, bmat, alpha=scaling, resid=y32, out32=y32)
             else:
                 ops.gemm(t, bmat, alpha=scaling, resid_t=y_t, out_t=y_t)
-            del bpad
         else:
             t = None
         ctx.save_for_backward(xd, t if t is not None else x.new_empty(0), weight, A, Bm)
@@ -531,18 +545,19 @@ class LoraLinearFn(torch.autograd.Function):
         ops.gemm(dy_t, WEIGHTS.get(weight, dt, transpose=True), out_t=dx)
         dA = dB = db = None
         if r > 0:
-            q = _empty((M, LORA_PAD), dt, xd)
-            ops.gemm(dy_t, _pad_cols(Bm, dt, transpose=True), out_t=q)              # q = dy·B   [M, 64]
-            at = _pad_cols(A, dt, transpose=True, rows=True)                        # Aᵀ padded: [K, 64]
+            rp = _rank_pad(r)
+            q = _empty((M, rp), dt, xd)
+            ops.gemm(dy_t, _pad_cols(Bm, dt, transpose=True), out_t=q)              # q = dy·B   [M, rp]
+            at = _pad_cols(A, dt, transpose=True, rows=True)                        # Aᵀ padded: [K, rp]
             if p_drop > 0:
                 dxd = _empty((M, K), dt, xd)
                 ops.gemm(q, at, alpha=scaling, out_t=dxd)
                 ops.dropout(dxd, dx, p_drop, seed, accumulate=True)
             else:
                 ops.gemm(q, at, alpha=scaling, resid_t=dx, out_t=dx)
-            gB = torch.zeros(N, LORA_PAD, device=xd.device, dtype=torch.float32)
+            gB = torch.zeros(N, rp, device=xd.device, dtype=torch.float32)
             ops.wgrad(dy_t, t, gB, alpha=scaling)
-            gA = torch.zeros(LORA_PAD, K, device=xd.device, dtype=torch.float32)
+            gA = torch.zeros(rp, K, device=xd.device, dtype=torch.float32)
             ops.wgrad(q, xd, gA, alpha=scaling)
             dB, dA = gB[:, :r].contiguous(), gA[:r].contiguous()
         if has_bias and ctx.needs_input_grad[2]:
@@ -552,21 +567,23 @@ class LoraLinearFn(torch.autograd.Function):
 
 
 def _pad_cols(p, dt, transpose=False, rows=False):
-    """T copy of a LoRA factor zero-padded to LORA_PAD along its rank dimension.
-    B [out, r]  -> [out, 64] (transpose=False)  or  Bᵀ -> [64, out] (transpose=True)
-    A [r, in]   -> Aᵀ padded [in, 64] (transpose=True, rows=True)"""
+    """T copy of a LoRA factor zero-padded to _rank_pad(r) along its rank dimension.
+    B [out, r]  -> [out, rp] (transpose=False)  or  Bᵀ -> [rp, out] (transpose=True)
+    A [r, in]   -> Aᵀ padded [in, rp] (transpose=True, rows=True)"""
     src = p.detach().float()
     if rows:                                   # A: rank is the row dim
-        if src.shape[0] < LORA_PAD:
-            src = torch.cat([src, src.new_zeros(LORA_PAD - src.shape[0], src.shape[1])], 0)
-        out = torch.empty(src.shape[1], LORA_PAD, device=src.device, dtype=dt)
+        rp = _rank_pad(src.shape[0])
+        if src.shape[0] < rp:
+            src = torch.cat([src, src.new_zeros(rp - src.shape[0], src.shape[1])], 0)
+        out = torch.empty(src.shape[1], rp, device=src.device, dtype=dt)
         ops.transpose_cast(src.contiguous(), out)
         return out
-    if src.shape[1] < LORA_PAD:                # B: rank is the column dim
-        src = torch.cat([src, src.new_zeros(src.shape[0], LORA_PAD - src.shape[1])], 1)
+    rp = _rank_pad(src.shape[1])
+    if src.shape[1] < rp:                      # B: rank is the column dim
+        src = torch.cat([src, src.new_zeros(src.shape[0], rp - src.shape[1])], 1)
     src = src.contiguous()
     if transpose:
-        out = torch.empty(LORA_PAD, src.shape[0], device=src.device, dtype=dt)
+        out = torch.empty(rp, src.shape[0], device=src.device, dtype=dt)
         ops.transpose_cast(src, out)
         return out
     if dt == torch.float32:

@@ -105,6 +105,11 @@ def gemm(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None, res
                           ("out_t", out_t, a.dtype), ("resid", resid, torch.float32), ("out32", out32, torch.float32)):
         if t is not None and t.dtype != want:
             raise UiaError(f"gemm {name} must be {want}, got {t.dtype}")
+    for name, t in (("aux_in", aux_in), ("aux_out", aux_out), ("resid_t", resid_t), ("out_t", out_t), ("out32", out32)):
+        if t is not None and (t.dim() != 2 or t.shape[1] < d.N or (t.shape[0] < d.M and out_group == 0)):
+            raise UiaError(f"gemm {name} is {tuple(t.shape)}: too small for the [{d.M}, {d.N}] result")
+    if resid is not None and resid_mod == 0 and out_group == 0 and (resid.dim() != 2 or resid.shape[1] < d.N or resid.shape[0] < d.M):
+        raise UiaError(f"gemm resid is {tuple(resid.shape)}: too small for the [{d.M}, {d.N}] result")
     if aux_in is not None:
         d.aux_in, d.ldaux_in = _p(aux_in), _rowmajor(aux_in, "aux_in")
     if aux_out is not None:
@@ -220,19 +225,20 @@ def fill_cls(x, cls, pos0):
 def embed(ids, table, pos, type0, out):
     rows, L = ids.numel(), ids.shape[-1]
     assert ids.dtype == torch.int64 and ids.is_contiguous()
-    check(lib().uia_embed(_stream(), rows, L, table.shape[1], _p(ids), _p(table), _p(pos), _p(type0), _p(out)), "uia_embed")
+    check(lib().uia_embed(_stream(), rows, L, table.shape[1], table.shape[0], pos.shape[0], _p(ids), _p(table), _p(pos), _p(type0), _p(out)), "uia_embed")
 
 
 def embed_packed(ids, pos_idx, table, pos, type0, out):
     """out[r] = table[ids[r]] + pos[pos_idx[r]] + type0 for the packed (valid) tokens r."""
     assert ids.dtype == pos_idx.dtype == torch.int64 and ids.is_contiguous() and pos_idx.is_contiguous() and ids.numel() == pos_idx.numel() == out.shape[0]
-    check(lib().uia_embed_packed(_stream(), ids.numel(), out.shape[1], _p(ids), _p(pos_idx), _p(table), _p(pos), _p(type0), _p(out)), "uia_embed_packed")
+    check(lib().uia_embed_packed(_stream(), ids.numel(), out.shape[1], table.shape[0], pos.shape[0], _p(ids), _p(pos_idx), _p(table), _p(pos), _p(type0), _p(out)),
+          "uia_embed_packed")
 
 
 def embed_bwd(ids, dx, dtable, pad_id=-1):
     """dtable[ids[r]] += dx[r] for every row r with ids[r] != pad_id (dtable fp32, caller-zeroed or accumulating)."""
     assert ids.dtype == torch.int64 and ids.is_contiguous() and dx.dtype == dtable.dtype == torch.float32 and dx.is_contiguous() and dtable.is_contiguous()
-    check(lib().uia_embed_bwd(_stream(), ids.numel(), dx.shape[-1], _p(ids), _p(dx), _p(dtable), pad_id), "uia_embed_bwd")
+    check(lib().uia_embed_bwd(_stream(), ids.numel(), dx.shape[-1], dtable.shape[0], _p(ids), _p(dx), _p(dtable), pad_id), "uia_embed_bwd")
 
 
 def gather_rows(src, idx, dst):
