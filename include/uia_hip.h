@@ -215,11 +215,13 @@ int uia_adamw_clip_step(void* stream, size_t n, float* p, const float* g, float*
 
 /* ---------------------------------------------------------------------------------------------
  * Data-parallel exchange (new: the reference is single-process, finetune.py:287-302 accumulates
- * instead).  RCCL all-reduce on the caller's stream; the unique id travels through the host. */
+ * instead).  RCCL all-reduce on the caller's stream; the unique id travels through the host.
+ * Every RCCL failure is reported as "rank r/world: <call> failed: <reason>" through uia_last_error(). */
 int uia_comm_unique_id_bytes(void);
 int uia_comm_get_unique_id(void* out, int bytes);
 int uia_comm_init(int rank, int world, const void* unique_id, int bytes);
 int uia_comm_world(void);
+int uia_comm_initialised(void);   /* 1 once uia_comm_init succeeded (a one-rank communicator is valid: its all-reduce is the identity) */
 int uia_allreduce_sum(void* stream, int dtype, void* buf, size_t n);
 /* opt-in global-batch contrastive loss: recv[r*n_per_rank ...] = rank r's send buffer (RCCL all-gather). */
 int uia_allgather(void* stream, int dtype, const void* send, void* recv, size_t n_per_rank);

@@ -13,13 +13,13 @@
 void uia_set_error(const char* fmt, ...);
 
 static ncclComm_t g_comm = nullptr;
-static int g_world = 1;
+static int g_world = 1, g_rank = 0;
 
 #define NCCL_TRY(expr)                                                                         \
     do {                                                                                       \
         ncclResult_t _r = (expr);                                                              \
         if (_r != ncclSuccess) {                                                               \
-            uia_set_error("%s failed: %s", #expr, ncclGetErrorString(_r));                     \
+            uia_set_error("rank %d/%d: %s failed: %s", g_rank, g_world, #expr, ncclGetErrorString(_r)); \
             return -3;                                                                         \
         }                                                                                      \
     } while (0)
@@ -41,12 +41,19 @@ int uia_comm_init(int rank, int world, const void* unique_id, int bytes) {
     if (!unique_id || bytes < (int)sizeof(ncclUniqueId) || rank < 0 || rank >= world) { uia_set_error("uia_comm_init: bad arguments"); return -1; }
     ncclUniqueId id;
     memcpy(&id, unique_id, sizeof(id));
-    NCCL_TRY(ncclCommInitRank(&g_comm, world, id, rank));
+    g_rank = rank;
     g_world = world;
+    ncclResult_t r = ncclCommInitRank(&g_comm, world, id, rank);
+    if (r != ncclSuccess) {
+        uia_set_error("rank %d/%d: ncclCommInitRank failed: %s", rank, world, ncclGetErrorString(r));
+        g_comm = nullptr; g_world = 1; g_rank = 0;
+        return -3;
+    }
     return 0;
 }
 
 int uia_comm_world(void) { return g_comm ? g_world : 1; }
+int uia_comm_initialised(void) { return g_comm ? 1 : 0; }
 
 int uia_allreduce_sum(void* stream, int dtype, void* buf, size_t n) {
     if (!g_comm) { uia_set_error("uia_allreduce_sum: communicator not initialised"); return -1; }
@@ -65,7 +72,7 @@ int uia_allgather(void* stream, int dtype, const void* send, void* recv, size_t 
 }
 
 int uia_comm_destroy(void) {
-    if (g_comm) { NCCL_TRY(ncclCommDestroy(g_comm)); g_comm = nullptr; g_world = 1; }
+    if (g_comm) { NCCL_TRY(ncclCommDestroy(g_comm)); g_comm = nullptr; g_world = 1; g_rank = 0; }
     return 0;
 }
 

@@ -102,9 +102,21 @@ class _MonaBase(nn.Module):
         """x: [N, B, D] sequence-first (reference :115-151); returns [N, B, D]."""
         xb = x.permute(1, 0, 2)
         n = xb.shape[1]
-        if hw_shapes is None:                              # reference :140-144 (no CLS token, square grid)
-            raise NotImplementedError("hw_shapes=None (token grid without a CLS token) is not on the fused path; "
-                                      "both injectors always pass hw_shapes")
+        if hw_shapes is None:
+            # reference :140-144: no CLS token — ALL n tokens form an int(sqrt(n))-square grid and go through the spatial operator.
+            # The fused kernels are laid out for [CLS ; h*w tokens], so a zero row stands in for the CLS slot and is dropped from
+            # the result: its output is never used, hence its upstream gradient is zero and it adds exactly nothing to any
+            # parameter gradient.  (Neither injector takes this path; it serves direct callers of the module.)
+            h = w = int(math.isqrt(n))
+            if h * w != n:
+                raise RuntimeError(f"shape '[{xb.shape[0]}, {h}, {w}, {self.project1.out_features}]' is invalid for {n} tokens: "
+                                   "hw_shapes=None needs a square token grid (reference mona.py:141-142)")
+            mask = self.keep_mask
+            if mask is not None:
+                mask = torch.cat([mask.new_ones(mask.shape[0], 1, mask.shape[2]), mask], dim=1).contiguous()
+            xp = torch.cat([xb.new_zeros(xb.shape[0], 1, xb.shape[2]), xb], dim=1)
+            y = UF.mona_apply(xp.contiguous(), self._params(), self.variant, (h, w), self.dropout.p, self.training, mask)
+            return y[:, 1:, :].permute(1, 0, 2)
         y = UF.mona_apply(xb.contiguous(), self._params(), self.variant, hw_shapes, self.dropout.p, self.training, self.keep_mask)
         return y.permute(1, 0, 2)
 

@@ -72,6 +72,7 @@ PROTOTYPES = {
     "uia_comm_get_unique_id": (C.c_int, [vp, C.c_int]),
     "uia_comm_init": (C.c_int, [C.c_int, C.c_int, vp, C.c_int]),
     "uia_comm_world": (C.c_int, []),
+    "uia_comm_initialised": (C.c_int, []),
     "uia_allreduce_sum": (C.c_int, [vp, C.c_int, vp, sz]),
     "uia_allgather": (C.c_int, [vp, C.c_int, vp, vp, sz]),
     "uia_comm_destroy": (C.c_int, []),

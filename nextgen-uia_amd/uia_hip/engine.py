@@ -78,6 +78,7 @@ class FlatAdapterOptimizer(FlatLayout):
         self.lr, self.betas, self.eps, self.weight_decay, self.max_norm = lr, betas, eps, weight_decay, max_norm
         self.steps = 0
         self.world = 1
+        self.collective = False                                 # True: run the RCCL all-reduce even at world 1 (tests of the comm path)
         for p in self.params:                                   # MonaFn may accumulate straight into these views (functional.mona_apply)
             p._uia_flat_grad = True
 
@@ -103,7 +104,7 @@ class FlatAdapterOptimizer(FlatLayout):
 
     def all_reduce(self):
         self._adopt_grads()
-        if self.world > 1:
+        if self.world > 1 or self.collective:
             ops.allreduce_sum(self.g)
 
     def step(self, lr=None, grad_scale=None):
@@ -144,10 +145,12 @@ def bind_device(args=None):
     return rank, local, world
 
 
-def init_data_parallel(opt=None):
+def init_data_parallel(opt=None, force_comm=False):
     """One process per GPU.  torch.distributed (RCCL backend) is used for rendezvous, barriers, the unique-id broadcast and the
     scalar control-flow agreements below; the gradient all-reduce itself is the library's own RCCL call on the compute stream.
-    The device must already be bound (bind_device) — buffers created before that would sit on cuda:0 on every rank."""
+    The device must already be bound (bind_device) — buffers created before that would sit on cuda:0 on every rank.
+    force_comm: build the RCCL communicator and route opt.all_reduce() through it even when world == 1 (a one-rank
+    all-reduce is the identity): the GPU tests use it to exercise the exact product path on a single-GPU box."""
     import torch.distributed as dist
     rank, local, world = dist_env()
     torch.cuda.set_device(local)
@@ -165,8 +168,11 @@ def init_data_parallel(opt=None):
             ops.comm_init(rank, world, uid[0])
         except Exception as e:                                 # surface WHICH rank failed: the others will be blocked in the init
             raise RuntimeError(f"rank {rank}/{world} (cuda:{local}): RCCL communicator init failed: {e}") from e
+    elif force_comm and ops.comm_world_initialised() is False:
+        ops.comm_init(0, 1, ops.comm_unique_id())
     if opt is not None:
         opt.world = world
+        opt.collective = bool(force_comm)
         if world > 1:                                          # identical adapter weights on every rank
             dist.broadcast(opt.p, src=0)
     return rank, local, world

@@ -333,8 +333,16 @@ def comm_world():
     return lib().uia_comm_world()
 
 
+def comm_world_initialised():
+    return bool(lib().uia_comm_initialised())
+
+
 def allreduce_sum(buf):
-    check(lib().uia_allreduce_sum(_stream(), _code(buf.dtype), _p(buf), buf.numel()), "uia_allreduce_sum")
+    import os
+    try:
+        check(lib().uia_allreduce_sum(_stream(), _code(buf.dtype), _p(buf), buf.numel()), "uia_allreduce_sum")
+    except UiaError as e:                                       # say WHICH rank: the others are most likely blocked inside the collective
+        raise UiaError(f"rank {os.environ.get('RANK', '0')}/{os.environ.get('WORLD_SIZE', '1')}: {e}") from e
 
 
 def allgather(send, recv):

@@ -81,6 +81,18 @@ def gen_mona(mona):
             arrays["g." + k] = p.grad
         save(f"mona_{variant}_drop", **arrays)
 
+        # hw_shapes=None (mona.py:140-144): no CLS token, all 16 tokens form a 4x4 grid
+        m2 = cls(32, 8).eval()
+        fill_module(m2)
+        x3 = fill((16, 2, 32), 0.13, 0.5).requires_grad_(True)
+        y3 = m2(x3)
+        (y3 * fill((16, 2, 32), 0.07, 1.0)).sum().backward()
+        arrays = {"x_nbd": x3, "y_nbd": y3, "dx_nbd": x3.grad, "dy_nbd": fill((16, 2, 32), 0.07, 1.0)}
+        for k, p in m2.named_parameters():
+            arrays["p." + k] = p
+            arrays["g." + k] = p.grad
+        save(f"mona_{variant}_nohw", **arrays)
+
 
 def gen_lora(lora):
     lin = torch.nn.Linear(8, 6)

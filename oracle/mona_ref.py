@@ -85,18 +85,24 @@ def forward(x, P, variant, hw, keep_mask=None, p_drop=0.1, training=False):
     """
     assert variant in VARIANTS
     D = x.shape[-1]
-    h, w = hw
     B, N, _ = x.shape
-    assert N == 1 + h * w
     n = F.layer_norm(x, (D,), P["norm.weight"], P["norm.bias"], 1e-5)
     u = n * P["gamma"] + x * P["gammax"]                                  # :125
     t = F.linear(u, P["project1.weight"], P["project1.bias"])             # :127
     bott = t.shape[-1]
-    cls_tok, spat = t[:, :1], t[:, 1:]
-    img = spat.reshape(B, h, w, bott).permute(0, 3, 1, 2)                 # :135
-    img = spatial_op(img, P, variant)
-    spat = img.permute(0, 2, 3, 1).reshape(B, h * w, bott)                # :137
-    z = torch.cat([cls_tok, spat], dim=1)                                 # :139
+    if hw is None:                                                        # :140-144: no CLS token, ALL n tokens form a square grid
+        h = w = int(math.sqrt(N))
+        img = t.reshape(B, h, w, bott).permute(0, 3, 1, 2)                # (raises, like the reference, unless n is a perfect square)
+        img = spatial_op(img, P, variant)
+        z = img.permute(0, 2, 3, 1).reshape(B, N, bott)
+    else:
+        h, w = hw
+        assert N == 1 + h * w
+        cls_tok, spat = t[:, :1], t[:, 1:]
+        img = spat.reshape(B, h, w, bott).permute(0, 3, 1, 2)             # :135
+        img = spatial_op(img, P, variant)
+        spat = img.permute(0, 2, 3, 1).reshape(B, h * w, bott)            # :137
+        z = torch.cat([cls_tok, spat], dim=1)                             # :139
     g = F.gelu(z)                                                         # exact erf GELU :146
     if keep_mask is not None:
         g = g * keep_mask / (1.0 - p_drop)

@@ -36,24 +36,36 @@ def _flatten(d, names):
 
 
 def _worker(rank, world, port, out):
+    """One rank of the exchange, on the ENGINE's flat-buffer code (uia_hip.engine.FlatLayout: offsets, 16-byte padding, .grad views,
+    dp_grad_scale) with gloo standing in for the RCCL all-reduce and the oracle's clip+AdamW for the fused HIP update."""
+    from uia_hip.engine import FlatLayout, dp_grad_scale, all_ranks_agree, sum_over_ranks
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     P, loss_fn, batches = _problem()
     names = list(P)
-    grads, _ = train_ref.grads_of(loss_fn, P, names, [batches[rank]])             # local micro-batch only
-    flat = _flatten(grads, names)                                                  # the flat adapter-gradient buffer
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)                                    # ONE collective per step
-    flat /= world
-    off, g = 0, {}
-    for k in names:
-        n = P[k].numel()
-        g[k] = flat[off:off + n].view(P[k].shape).clone()
-        off += n
-    params = {k: v.clone() for k, v in P.items()}
-    m = {k: torch.zeros_like(v) for k, v in P.items()}
-    v = {k: torch.zeros_like(v) for k, v in P.items()}
-    norm = train_ref.clip_and_adamw(params, g, m, v, 1, 1e-3, (0.9, 0.95), 1e-8, 0.01, 1.0)
-    torch.save({"params": params, "norm": norm}, os.path.join(out, f"rank{rank}.pt"))
+    params = [(k, torch.nn.Parameter(P[k].clone())) for k in names]
+    lay = FlatLayout(params)                                                       # parameters / gradients now live in the flat buffers
+    assert lay.grad_views_intact() and lay.numel % 4 == 0 and all(o % 4 == 0 for o in lay.offsets)
+    if rank == 1:                                                                  # replicas must start identical: rank 0's weights win
+        with torch.no_grad():
+            lay.p.add_(1.0)
+    dist.broadcast(lay.p, src=0)
+    Pq = {k: p for k, p in params}
+    loss = loss_fn(Pq, *batches[rank])                                             # local micro-batch only
+    ok = all_ranks_agree(bool(torch.isfinite(loss)))                               # the entry points' collective skip decision
+    loss.backward()                                                                # autograd accumulates INTO the flat views
+    assert lay.grad_views_intact()
+    dist.all_reduce(lay.g, op=dist.ReduceOp.SUM)                                   # ONE collective per step over the flat buffer
+    g = {k: v.clone() * dp_grad_scale(world) for k, v in lay.unflatten(lay.g).items()}
+    pd = {k: v.detach().clone() for k, v in lay.unflatten(lay.p).items()}
+    m = {k: torch.zeros_like(v) for k, v in pd.items()}
+    v = {k: torch.zeros_like(v) for k, v in pd.items()}
+    norm = train_ref.clip_and_adamw(pd, g, m, v, 1, 1e-3, (0.9, 0.95), 1e-8, 0.01, 1.0)
+    tot = sum_over_ranks(float(loss.detach()), 1.0)
+    # a rank-local "non-finite" must become a global skip, identically on both ranks
+    skip = not all_ranks_agree(rank != 1)
+    torch.save({"params": pd, "norm": norm, "ok": ok, "skip": skip, "tot": tot, "numel": lay.numel, "offsets": lay.offsets},
+               os.path.join(out, f"rank{rank}.pt"))
     dist.destroy_process_group()
 
 
@@ -63,16 +75,51 @@ def test_dp2_equals_accumulation(tmp_path):
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     P, loss_fn, batches = _problem()
     names = list(P)
-    grads, _ = train_ref.grads_of(loss_fn, P, names, batches)                      # single process, 2 accumulation steps
+    grads, mean_loss = train_ref.grads_of(loss_fn, P, names, batches)              # single process, 2 accumulation steps
     params = {k: v.clone() for k, v in P.items()}
     m = {k: torch.zeros_like(v) for k, v in P.items()}
     v = {k: torch.zeros_like(v) for k, v in P.items()}
     norm = train_ref.clip_and_adamw(params, grads, m, v, 1, 1e-3, (0.9, 0.95), 1e-8, 0.01, 1.0)
     r0, r1 = (torch.load(os.path.join(tmp_path, f"rank{r}.pt")) for r in range(2))
     assert abs(r0["norm"] - norm) < 1e-5 * norm
+    assert r0["ok"] and r1["ok"] and r0["skip"] and r1["skip"]                      # agreements are global
+    assert r0["tot"] == r1["tot"] and abs(r0["tot"][0] / r0["tot"][1] - mean_loss) < 1e-5
+    assert r0["numel"] >= sum(v.numel() for v in P.values()) and r0["offsets"] == r1["offsets"]
     for k in names:
         assert torch.equal(r0["params"][k], r1["params"][k])                        # replicas stay bit-identical
         assert torch.allclose(r0["params"][k], params[k], rtol=1e-5, atol=1e-7), k  # == accumulation (fp32 summation order aside)
+
+
+def test_rank_shard_sampler_partitions_the_epoch():
+    """DistributedSampler semantics of src/datasets/finetune.RankShardSampler: equal shard sizes (collectives stay aligned),
+    disjoint shards that together cover the epoch's permutation, a new permutation per epoch, identical across ranks."""
+    from src.datasets.finetune import RankShardSampler
+    for n, world in ((10, 2), (11, 2), (37, 8), (8, 8)):
+        shards = [RankShardSampler(n, r, world, shuffle=True, seed=5) for r in range(world)]
+        idx = [s.indices() for s in shards]
+        assert len({len(i) for i in idx}) == 1 and len(idx[0]) == len(shards[0]) == -(-n // world)
+        flat = sorted(j for i in idx for j in i)
+        assert set(flat) == set(range(n)) and len(flat) - n < world                 # everything seen; only the wrap-around padding repeats
+        for s in shards:
+            s.set_epoch(1)
+        idx1 = [s.indices() for s in shards]
+        assert idx1 != idx and sorted(set(j for i in idx1 for j in i)) == list(range(n))
+    a, b = RankShardSampler(16, 0, 2, shuffle=False), RankShardSampler(16, 1, 2, shuffle=False)
+    assert a.indices() == list(range(0, 16, 2)) and b.indices() == list(range(1, 16, 2))
+
+
+def test_flat_layout_survives_set_to_none(tmp_path):
+    """zero_grad(set_to_none=True)-style callers orphan the .grad views; the layout notices and re-binds."""
+    from uia_hip.engine import FlatLayout
+    ps = [("a", torch.nn.Parameter(torch.randn(5))), ("b", torch.nn.Parameter(torch.randn(3, 3)))]
+    lay = FlatLayout(ps)
+    assert lay.offsets == [0, 8] and lay.numel == 20 and lay.grad_views_intact()
+    ps[0][1].grad = None
+    assert not lay.grad_views_intact()
+    lay.rebind_grads()
+    assert lay.grad_views_intact()
+    (ps[0][1].sum() * 2 + ps[1][1].sum()).backward()
+    assert torch.equal(lay.g[:5], torch.full((5,), 2.0)) and torch.equal(lay.g[8:17], torch.ones(9)) and float(lay.g[5:8].abs().sum()) == 0
 
 
 # ---- opt-in global-batch loss (SURVEY §8f-4): all-gather the features, every rank evaluates the same global InfoNCE and

@@ -1,0 +1,345 @@
+"""-m gpu: parity at the geometry the benchmark actually runs — not toy dimensions.
+
+  * BASELINE configs[1] model: ViT-B/16 (D 768, 12 heads, 197 tokens, 12 blocks) + 12 Mona adapters + BERT-base (L = 256, 12 layers),
+    B = 4, against oracle/train_ref.py: image / text features, loss and EVERY Mona gradient;
+  * configs[3]: CLIPSeg on OpenAI ViT-B/16 with the real decoder geometry (reduce_dim 64, 4 heads, 2048, 224x224 logits);
+  * configs[4] geometry: ViT-L/14 blocks (width 1024, 16 heads, 257 tokens) + LoRA r = 16 through inject_lora_to_clip;
+  * the GEMM at M = 50 432 x N {768, 2304, 3072} x K {64, 768, 3072} through each compile-time epilogue mask, and the attention at
+    B = 8, H = 12, L = 197 / 256 / 257, against torch fp32 on the GPU.
+
+Bars: fp32 mode <= 1e-3 relative per tensor (forward AND every gradient); bf16 mode <= 1e-2 on features / logits, gradients as the
+whole-vector cosine / L2 (InfoNCE at tau = 0.07 multiplies feature error by ~14 in the logits), with the worst per-tensor bf16
+gradient error REPORTED (gpurun_out/parity_fullshape.json and the test's stdout) so that DESIGN.md can quote it."""
+import json
+import os
+
+import pytest
+import torch
+
+from oracle import losses_ref, text_ref, train_ref, vit_ref
+
+pytestmark = pytest.mark.gpu
+DT = {"fp32": torch.float32, "bf16": torch.bfloat16}
+TOL = {"fp32": 1e-3, "bf16": 1e-2}
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def report(key, payload):
+    """Append measured parity figures to gpurun_out/parity_fullshape.json (scratch on the GPU box; copied into profiles/ by hand)."""
+    path = os.path.join(ROOT, "gpurun_out", "parity_fullshape.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        data = json.load(open(path)) if os.path.exists(path) else {}
+        data[key] = payload
+        json.dump(data, open(path, "w"), indent=1, sort_keys=True)
+    except OSError:
+        pass
+    print(f"[parity] {key}: {json.dumps(payload)}")
+
+
+@pytest.fixture(autouse=True)
+def _mode():
+    from uia_hip import functional as UF
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))          # the oracle runs on the host cores
+    yield
+    UF.set_compute_dtype(torch.bfloat16)
+    UF.clear_t_copies()
+
+
+def _scale_adapters(model, gen, key, std=0.02):
+    """Adapters away from their (partly zero / 1e-6) initialisation so that every gradient path carries signal."""
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            if key not in k.lower():
+                continue
+            if k.endswith(("norm.weight", "gammax", "freq_filter")):
+                p.copy_(1.0 + 0.2 * torch.randn(p.shape, generator=gen))
+            elif k.endswith("gamma"):
+                p.copy_(0.1 * torch.randn(p.shape, generator=gen))
+            elif p.dim() >= 2:
+                p.copy_(std * torch.randn(p.shape, generator=gen))
+            else:
+                p.copy_(0.05 * torch.randn(p.shape, generator=gen))
+
+
+def _captions(g, B, L=256):
+    ids = torch.zeros(B, L, dtype=torch.long)
+    for b in range(B):
+        n = int(torch.randint(24, 129, (1,), generator=g))
+        ids[b, 1:n - 1] = torch.randint(1000, 30000, (n - 2,), generator=g)
+        ids[b, 0], ids[b, n - 1] = 2, 3
+    return ids
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("variant", ["freq_enhanced", "hybrid"])
+def test_fullshape_biomedclip_mona_train_step_vs_oracle(mode, variant):
+    """reference call path: biomedclip/finetune.py:272-302 (encode_image, encode_text, InfoNCE, backward) at full model size."""
+    from uia_hip import functional as UF
+    from src.adapters import inject_mona_variant_to_open_clip
+    from src.losses import InfoNCELoss
+    from src.third_party.biomedclip.model import create_biomedclip
+    UF.set_compute_dtype(DT[mode])
+    g = torch.Generator().manual_seed(41)
+    model = create_biomedclip(seed=3)                                   # full geometry, N(0, 0.02) weights, LayerNorm weights 1
+    for p in model.parameters():
+        p.requires_grad_(False)
+    inject_mona_variant_to_open_clip(model, variant=variant, bottleneck_dim=64)
+    _scale_adapters(model, g, "mona", std=0.03)
+    for k, p in model.named_parameters():
+        p.requires_grad_("mona" in k)
+    model.eval()
+    B = 4
+    images, ids = torch.rand(B, 3, 224, 224, generator=g), _captions(g, B)
+    P = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    trainable = [k for k in P if "mona" in k]
+    assert len(trainable) == 12 * (21 if variant == "hybrid" else 17) and sum(P[k].numel() for k in trainable) == (1356324 if variant == "hybrid" else 1343232)
+    mona = dict(variant=variant, hw=(14, 14))
+    gref, lref = train_ref.grads_of(lambda Pq, im, tk: train_ref.biomedclip_loss(Pq, im, tk, mona=mona), P, trainable, [(images, ids)])
+    with torch.no_grad():
+        fref = vit_ref.timm_vit_forward(images, P, heads=12, mona=mona)
+        tref = text_ref.bert_text_forward(ids, P, heads=12)
+
+    model = model.to(dev())
+    fi = model.encode_image(images.to(dev()))
+    ft = model.encode_text(ids.to(dev()))
+    loss = InfoNCELoss(0.07)(fi, ft)
+    loss.backward()
+    e_img, e_txt = rel(fi, fref), rel(ft, tref)
+    params = dict(model.named_parameters())
+    per_tensor = {k: rel(params[k].grad, gref[k]) for k in trainable}
+    worst_k = max(per_tensor, key=per_tensor.get)
+    got = torch.cat([params[k].grad.detach().float().cpu().flatten() for k in trainable])
+    want = torch.cat([gref[k].flatten() for k in trainable])
+    cos = float(torch.dot(got, want) / (got.norm() * want.norm()))
+    l2 = float((got - want).norm() / want.norm())
+    report(f"biomedclip_vitb16_mona_{variant}_{mode}",
+           {"B": B, "image_features_rel": e_img, "text_features_rel": e_txt, "loss": float(loss), "loss_ref": lref,
+            "grad_worst_per_tensor_rel": per_tensor[worst_k], "grad_worst_tensor": worst_k, "grad_cosine": cos, "grad_rel_l2": l2,
+            "grad_median_per_tensor_rel": sorted(per_tensor.values())[len(per_tensor) // 2]})
+    assert e_img < TOL[mode], f"image features {e_img}"
+    assert e_txt < TOL[mode], f"text features {e_txt}"
+    assert abs(float(loss) - lref) < (1e-3 if mode == "fp32" else 3e-2) * max(1.0, abs(lref))
+    if mode == "fp32":
+        assert per_tensor[worst_k] < 1e-3, f"worst per-tensor gradient error {per_tensor[worst_k]} at {worst_k}"
+    else:
+        assert cos > 0.99 and l2 < 0.15, f"bf16 gradient cosine {cos}, relative L2 {l2}; worst tensor {worst_k} {per_tensor[worst_k]}"
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_fullshape_clipseg_vs_oracle(mode):
+    """configs[3]: OpenAI ViT-B/16 (QuickGELU, eps 1e-5) taps 3/6/9 -> FiLM decoder (64, 4 heads, 2048) -> [B, 2, 224, 224];
+    reference clipseg_adapter.py:73-98.  Logits, argmax masks (Dice parity) and every decoder gradient."""
+    from oracle import clipseg_ref
+    from uia_hip import functional as UF
+    from src.third_party.openai_clip.model import CLIP
+    from src.third_party.openai_clip.clipseg_adapter import CLIPSegAdapter, CLIPSegDecoder
+    UF.set_compute_dtype(DT[mode])
+    g = torch.Generator().manual_seed(43)
+    torch.manual_seed(43)
+    clip = CLIP(512, 224, 12, 768, 16, 77, 49408, 512, 8, 12).eval()
+    dec = CLIPSegDecoder(vision_hidden=768, projection_dim=512, reduce_dim=64, extract_layers=(3, 6, 9), heads=4, intermediate=2048, patch_size=16)
+    model = CLIPSegAdapter(clip, decoder=dec)
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            if p.dim() >= 2:
+                p.copy_(torch.randn(p.shape, generator=g) * (0.02 if k.startswith("clip_model.") else 0.05))
+            elif "ln" in k.lower() or "norm" in k.lower():
+                p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g)) if k.endswith("weight") else p.copy_(0.02 * torch.randn(p.shape, generator=g))
+            else:
+                p.copy_(0.02 * torch.randn(p.shape, generator=g))
+    model.freeze_clip_backbone()
+    B = 2
+    images = torch.rand(B, 3, 224, 224, generator=g)
+    ids = torch.zeros(B, 77, dtype=torch.long)
+    n = 12
+    ids[:, :n] = torch.randint(1, 49000, (n,), generator=g)[None]
+    ids[:, n - 1] = 49407                                               # EOT = highest id; identical prompt rows (segmentation.py:142)
+    dl = torch.randn(B, 2, 224, 224, generator=g) * 0.01
+    P = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    names = [k for k in P if k.startswith("decoder.")]
+    assert sum(P[k].numel() for k in names) == 1127009                  # rd64-refined decoder
+    leaves = {k: P[k].clone().requires_grad_(True) for k in names}
+    Pq = dict(P)
+    Pq.update(leaves)
+    ref = clipseg_ref.adapter_forward(images, ids, Pq, vit_heads=12, text_heads=8, extract_layers=(3, 6, 9))
+    (ref * dl).sum().backward()
+    model = model.to(dev())
+    out = model(images.to(dev()), input_ids=ids.to(dev()))
+    (out * dl.to(dev())).sum().backward()
+    assert tuple(out.shape) == (B, 2, 224, 224)
+    e_out = rel(out, ref)
+    margin = (ref[:, 1] - ref[:, 0]).abs()
+    disagree = (out.argmax(1).cpu() != ref.argmax(1))
+    thr = (1e-3 if mode == "fp32" else 2e-2) * float(ref.abs().max())
+    gmax = max(float(v.grad.abs().max()) for v in leaves.values())
+    params = dict(model.named_parameters())
+    per_tensor = {k: rel(params[k].grad, leaves[k].grad) for k in names}
+    worst_k = max(per_tensor, key=per_tensor.get)
+    got = torch.cat([params[k].grad.detach().float().cpu().flatten() for k in names])
+    want = torch.cat([leaves[k].grad.flatten() for k in names])
+    cos, l2 = float(torch.dot(got, want) / (got.norm() * want.norm())), float((got - want).norm() / want.norm())
+    report(f"clipseg_vitb16_{mode}", {"B": B, "logits_rel": e_out, "mask_pixels_disagreeing": int(disagree.sum()),
+                                      "of_which_outside_margin": int((disagree & (margin >= thr)).sum()), "grad_worst_per_tensor_rel": per_tensor[worst_k],
+                                      "grad_worst_tensor": worst_k, "grad_cosine": cos, "grad_rel_l2": l2})
+    assert e_out < TOL[mode]
+    assert not bool((disagree & (margin >= thr)).any())                 # identical masks except where |logit margin| is negligible
+    if mode == "fp32":
+        for k in names:
+            err = float((params[k].grad.detach().float().cpu() - leaves[k].grad).abs().max())
+            assert err < 1e-3 * float(leaves[k].grad.abs().max()) or err < 1e-4 * gmax, (k, err)
+    else:
+        assert cos > 0.995 and l2 < 0.1, (cos, l2)
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_fullshape_vit_l14_lora_vs_oracle(mode):
+    """configs[4] geometry: in-tree CLIP ViT-L/14 blocks (width 1024, 16 heads, 257 tokens, patch 14 -> zero-padded im2col) with
+    inject_lora_to_clip(r=16, alpha=32) on q,k,v,o (reference lora.py:202-248); 3 of the 24 blocks keep the oracle cheap."""
+    from uia_hip import functional as UF
+    from src.adapters import inject_lora_to_clip
+    from src.third_party.openai_clip.model import CLIP
+    UF.set_compute_dtype(DT[mode])
+    g = torch.Generator().manual_seed(47)
+    torch.manual_seed(47)
+    model = CLIP(768, 224, 3, 1024, 14, 77, 49408, 768, 12, 2).eval()
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            if p.dim() >= 2:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.02)
+            elif k.endswith("weight") and "ln" in k:
+                p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g))
+            else:
+                p.copy_(0.02 * torch.randn(p.shape, generator=g))
+    for p in model.parameters():
+        p.requires_grad_(False)
+    model, n = inject_lora_to_clip(model, lora_r=16, lora_alpha=32, lora_dropout=0.0)
+    assert n == 3
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            if "lora" in k:
+                p.copy_(0.02 * torch.randn(p.shape, generator=g))
+    for k, p in model.named_parameters():
+        if "lora" in k:
+            p.requires_grad_(True)
+    model.eval()
+    B = 3
+    images = torch.rand(B, 3, 224, 224, generator=g)
+    P = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    trainable = [k for k, p in model.named_parameters() if p.requires_grad]
+    assert sum(P[k].numel() for k in trainable if "lora" in k) == 3 * 4 * 2 * 16 * 1024
+    leaves = {k: P[k].clone().requires_grad_(True) for k in trainable}
+    Pq = dict(P)
+    Pq.update(leaves)
+    fr = vit_ref.openai_vit_forward(images, Pq, heads=16, lora=dict(r=16, alpha=32))
+    fr.square().sum().backward()
+    model = model.to(dev())
+    fi = model.encode_image(images.to(dev()))
+    fi.square().sum().backward()
+    e_f = rel(fi, fr)
+    params = dict(model.named_parameters())
+    gmax = max(float(v.grad.abs().max()) for v in leaves.values())
+    per_tensor = {k: rel(params[k].grad, leaves[k].grad) for k in trainable if float(leaves[k].grad.abs().max()) > 1e-3 * gmax}
+    worst_k = max(per_tensor, key=per_tensor.get)
+    got = torch.cat([params[k].grad.detach().float().cpu().flatten() for k in trainable])
+    want = torch.cat([leaves[k].grad.flatten() for k in trainable])
+    cos, l2 = float(torch.dot(got, want) / (got.norm() * want.norm())), float((got - want).norm() / want.norm())
+    report(f"vit_l14_lora_r16_{mode}", {"B": B, "blocks": 3, "features_rel": e_f, "grad_worst_per_tensor_rel": per_tensor[worst_k],
+                                        "grad_worst_tensor": worst_k, "grad_cosine": cos, "grad_rel_l2": l2})
+    assert e_f < TOL[mode]
+    if mode == "fp32":
+        for k in trainable:
+            err = float((params[k].grad.detach().float().cpu() - leaves[k].grad).abs().max())
+            assert err < 1e-3 * float(leaves[k].grad.abs().max()) or err < 1e-4 * gmax, (k, err)
+    else:
+        assert cos > 0.99 and l2 < 0.15, (cos, l2)
+
+
+# ------------------------------------------------------------------------------------------------ kernels at production shapes
+M_PROD = 256 * 197                                                       # 50 432 token rows of one bs-256 step
+MASKS = ("proj_resid32", "postln_residT", "dgrad", "qkv_bias", "fc1_gelu", "fc2_dgelu", "fc1_gelu_stash")
+
+
+@pytest.mark.parametrize("N", [768, 2304, 3072])
+@pytest.mark.parametrize("K", [64, 768, 3072])
+def test_gemm_production_shapes_every_epilogue_mask(N, K):
+    """uia_gemm (ring kernel, the seven compile-time epilogue masks of a training step) at M = 50 432 against torch's fp32 matmul of the
+    same bf16 operands on the GPU: K up to 3072 = 96 ring sub-tiles, 197 x {3, 9, 12} tiles incl. the M tail, every tile-order group."""
+    from uia_hip import ops
+    torch.manual_seed(100 + N + K)
+    M, dt = M_PROD, torch.bfloat16
+    a = torch.randn(M, K, device=dev()).to(dt)
+    w = (torch.randn(N, K, device=dev()) * (K ** -0.5)).to(dt)
+    bias = torch.randn(N, device=dev())
+    pre = a.float() @ w.float().T                                       # torch fp32 reference (operands are exact in bf16)
+    gelu = torch.nn.functional.gelu
+    scale = float(pre.abs().max())
+
+    def close32(y, ref):
+        return float((y - ref).abs().max()) <= 3e-5 * max(scale, float(ref.abs().max()))
+
+    def closeT(y, ref):                                                 # one bf16 rounding of the result (2^-9 relative) + the GELU polynomial
+        return float((y.float() - ref).abs().max()) <= 6e-3 * float(ref.abs().max())
+
+    o_t = lambda: torch.full((M, N), float("nan"), device=dev(), dtype=dt)
+    o32 = lambda: torch.full((M, N), float("nan"), device=dev())
+    resid = torch.randn(M, N, device=dev())
+    y = o32(); ops.gemm(a, w, bias=bias, resid=resid, out32=y)                                     # mask 81
+    assert bool(torch.isfinite(y).all()) and close32(y, pre + bias + resid), "proj_resid32"
+    rt = torch.randn(M, N, device=dev()).to(dt)
+    y = o32(); ops.gemm(a, w, bias=bias, resid_t=rt, out32=y)                                      # mask 97
+    assert close32(y, pre + bias + rt.float()), "postln_residT"
+    del resid, rt
+    y = o_t(); ops.gemm(a, w, out_t=y)                                                             # mask 128
+    assert closeT(y, pre), "dgrad"
+    y = o_t(); ops.gemm(a, w, bias=bias, out_t=y)                                                  # mask 129
+    assert closeT(y, pre + bias), "qkv_bias"
+    y = o_t(); ops.gemm(a, w, bias=bias, act="gelu", out_t=y)                                      # mask 133
+    assert closeT(y, gelu(pre + bias)), "fc1_gelu"
+    aux = o_t(); y = o_t(); ops.gemm(a, w, bias=bias, act="gelu", aux_out=aux, out_t=y)            # mask 135
+    assert closeT(y, gelu(pre + bias)) and closeT(aux, pre + bias), "fc1_gelu_stash"
+    x = aux.float()
+    dg = 0.5 * (1 + torch.erf(x * 0.7071067811865476)) + x * torch.exp(-0.5 * x * x) * 0.3989422804014327
+    y = o_t(); ops.gemm(a, w, dact="gelu", aux_in=aux, out_t=y)                                    # mask 136
+    assert closeT(y, pre * dg), "fc2_dgelu"
+
+
+@pytest.mark.parametrize("L,mask", [(197, "none"), (256, "keypad"), (257, "none")])
+def test_attention_production_shapes(L, mask):
+    """B = 8, H = 12 (ViT-B / BERT-base head count; 257 = ViT-L/14 tokens) forward + backward against torch fp32 softmax attention."""
+    from uia_hip import ops
+    torch.manual_seed(7 + L)
+    B, H, dt = 8, 12, torch.bfloat16
+    D = H * 64
+    qkv = (torch.randn(B * L, 3 * D, device=dev()) * 1.2).to(dt)
+    q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+    keylen = torch.randint(24, 129, (B,), device=dev(), dtype=torch.int32) if mask == "keypad" else None
+    out = torch.empty(B * L, D, device=dev(), dtype=dt)
+    lse = torch.empty(B, H, L, device=dev())
+    ops.attn_fwd(q, k, v, out, B, H, L, lse=lse, mask=mask, keylen=keylen)
+    qf = qkv.float().view(B, L, 3, H, 64).permute(2, 0, 3, 1, 4).contiguous().requires_grad_(True)
+    s = qf[0] @ qf[1].transpose(-1, -2) / 8.0
+    if mask == "keypad":
+        ar = torch.arange(L, device=dev())
+        s = s.masked_fill(ar[None, None, None, :] >= keylen[:, None, None, None], float("-inf"))
+    ref = torch.softmax(s, -1) @ qf[2]
+    assert rel(out, ref.permute(0, 2, 1, 3).reshape(B * L, D)) < 1.2e-2
+    dout = torch.randn(B * L, D, device=dev()).to(dt)
+    ref.backward(dout.float().view(B, L, H, 64).permute(0, 2, 1, 3))
+    dqkv = torch.zeros(B * L, 3 * D, device=dev(), dtype=dt)
+    ops.attn_bwd(q, k, v, out, dout, lse, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], B, H, L, mask=mask, keylen=keylen)
+    gq = qf.grad.permute(1, 3, 0, 2, 4).reshape(B * L, 3 * D)
+    for i, name in enumerate("qkv"):
+        assert rel(dqkv[:, i * D:(i + 1) * D], gq[:, i * D:(i + 1) * D]) < 2.5e-2, name

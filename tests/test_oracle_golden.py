@@ -84,6 +84,20 @@ def test_mona_matches_reference(golden, variant, drop):
         close(P[k].grad, g["g." + k], 5e-5, 1e-5)
 
 
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_mona_without_hw_shapes_matches_reference(golden, variant):
+    """forward(x) with hw_shapes=None (mona.py:140-144): every token goes through the spatial operator on a sqrt(n) grid."""
+    g = golden(f"mona_{variant}_nohw")
+    P = {k: v.clone().requires_grad_(True) for k, v in params_of(g).items()}
+    x = g["x_nbd"].permute(1, 0, 2).contiguous().requires_grad_(True)
+    y = mona_ref.forward(x, P, variant, None)
+    y.backward(g["dy_nbd"].permute(1, 0, 2))
+    close(y, g["y_nbd"].permute(1, 0, 2))
+    close(x.grad, g["dx_nbd"].permute(1, 0, 2))
+    for k in P:
+        close(P[k].grad, g["g." + k], 5e-5, 1e-5)
+
+
 def test_mona_merged_stencil_identity(golden):
     """rfft2*f_c*irfft2 == f_c scale, and (DW3+DW5+DW7)/3 == one merged 7x7."""
     g = golden("mona_freq_enhanced")
@@ -247,3 +261,44 @@ def test_fpn_adapter_matches_reference(golden, task):
     assert gnames and all(n.startswith(("reduces.", "blocks.", "seg_head." if task == "seg" else "cls_head.")) for n in gnames)
     for n in gnames:
         close(A[n].grad, g[f"{task}.g.{n}"], 2e-3, 1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ MONAI DiceCE / Dice (f3)
+DICE_CASES = ("A_empty_gt", "B_empty_pred", "C_three_class", "D_all_foreground")
+
+
+@pytest.mark.parametrize("case", DICE_CASES)
+def test_dicece_restatement_vs_independent_float64_vectors(golden, case):
+    """oracle/losses_ref.dice_ce (torch, vectorised, autograd) against tests/golden/dicece_cases.npz — MONAI's published DiceCELoss
+    algorithm restated a SECOND time, independently, in float64 numpy with per-pixel loops and a finite-difference gradient
+    (oracle/gen_dice_golden.py).  MONAI itself is absent from the image: the pin is this cross-check plus the hand cases below."""
+    from oracle import losses_ref
+    z = golden("dicece_cases")
+    logits = z[case + "_logits"].clone().requires_grad_(True)
+    label = z[case + "_label"][:, None].float()
+    loss = losses_ref.dice_ce(logits, label)
+    loss.backward()
+    assert abs(float(loss) - float(z[case + "_loss"])) < 2e-6 * abs(float(z[case + "_loss"]))
+    g = z[case + "_grad"].float()
+    assert float((logits.grad - g).abs().max()) < 2e-5 * float(g.abs().max()) + 1e-7
+    if case + "_dice" in z:
+        d, want = losses_ref.dice_metric(logits.detach(), label), z[case + "_dice"]
+        assert torch.equal(torch.isnan(d), torch.isnan(want)) and torch.allclose(torch.nan_to_num(d), torch.nan_to_num(want), atol=1e-12)
+
+
+def test_dicece_hand_cases():
+    """Closed forms: a perfect, saturated prediction has loss -> 0; a uniform prediction on a 50/50 binary image has
+    dice = 1 - (2*(n/4))/(n/4 + n/4 + n/2)... evaluated by hand: p = 1/2 everywhere, t one-hot."""
+    from oracle import losses_ref
+    H = W = 4
+    label = torch.zeros(1, 1, H, W)
+    label[0, 0, :2] = 1                                                  # 8 foreground, 8 background pixels
+    sat = torch.stack([(1 - label[0, 0]) * 40 - 20, label[0, 0] * 40 - 20])[None]
+    assert float(losses_ref.dice_ce(sat, label)) < 1e-6
+    uni = torch.zeros(1, 2, H, W)
+    # per channel: I = 8*0.5 = 4, sum p^2 = 16*0.25 = 4, sum t^2 = 8  ->  dice_c = 1 - 8/12 = 1/3; CE = ln 2
+    want = 1.0 / 3.0 + math.log(2.0)
+    assert abs(float(losses_ref.dice_ce(uni, label)) - want) < 1e-6
+    # metric: prediction = all background on an image with foreground -> 0; empty ground truth -> NaN
+    d = losses_ref.dice_metric(torch.cat([sat * -1, sat]), torch.cat([label, torch.zeros_like(label)]))
+    assert float(d[0]) == 0.0 and math.isnan(float(d[1]))
