@@ -166,19 +166,25 @@ def test_fullshape_clipseg_vs_oracle(mode):
     n = 12
     ids[:, :n] = torch.randint(1, 49000, (n,), generator=g)[None]
     ids[:, n - 1] = 49407                                               # EOT = highest id; identical prompt rows (segmentation.py:142)
-    dl = torch.randn(B, 2, 224, 224, generator=g) * 0.01
+    # the training loss of config 4 (clipseg/segmentation.py:84,146): DiceCE against an elliptic ground-truth mask
+    yy, xx = torch.meshgrid(torch.arange(224.0), torch.arange(224.0), indexing="ij")
+    label = torch.stack([(((yy - 100) / 50) ** 2 + ((xx - 120) / 70) ** 2 <= 1), (((yy - 150) / 30) ** 2 + ((xx - 60) / 40) ** 2 <= 1)])[:, None].float()
     P = {k: v.detach().clone() for k, v in model.state_dict().items()}
     names = [k for k in P if k.startswith("decoder.")]
     assert sum(P[k].numel() for k in names) == 1127009                  # rd64-refined decoder
     leaves = {k: P[k].clone().requires_grad_(True) for k in names}
     Pq = dict(P)
     Pq.update(leaves)
+    from src.losses.dice import DiceCELoss
     ref = clipseg_ref.adapter_forward(images, ids, Pq, vit_heads=12, text_heads=8, extract_layers=(3, 6, 9))
-    (ref * dl).sum().backward()
+    lref = losses_ref.dice_ce(ref, label)
+    lref.backward()
     model = model.to(dev())
     out = model(images.to(dev()), input_ids=ids.to(dev()))
-    (out * dl.to(dev())).sum().backward()
+    loss = DiceCELoss()(out, label.to(dev()))
+    loss.backward()
     assert tuple(out.shape) == (B, 2, 224, 224)
+    assert abs(float(loss) - float(lref)) < (1e-4 if mode == "fp32" else 1e-2) * abs(float(lref))
     e_out = rel(out, ref)
     margin = (ref[:, 1] - ref[:, 0]).abs()
     disagree = (out.argmax(1).cpu() != ref.argmax(1))
@@ -190,7 +196,7 @@ def test_fullshape_clipseg_vs_oracle(mode):
     got = torch.cat([params[k].grad.detach().float().cpu().flatten() for k in names])
     want = torch.cat([leaves[k].grad.flatten() for k in names])
     cos, l2 = float(torch.dot(got, want) / (got.norm() * want.norm())), float((got - want).norm() / want.norm())
-    report(f"clipseg_vitb16_{mode}", {"B": B, "logits_rel": e_out, "mask_pixels_disagreeing": int(disagree.sum()),
+    report(f"clipseg_vitb16_{mode}", {"B": B, "logits_rel": e_out, "dicece": float(loss), "dicece_ref": float(lref), "mask_pixels_disagreeing": int(disagree.sum()),
                                       "of_which_outside_margin": int((disagree & (margin >= thr)).sum()), "grad_worst_per_tensor_rel": per_tensor[worst_k],
                                       "grad_worst_tensor": worst_k, "grad_cosine": cos, "grad_rel_l2": l2})
     assert e_out < TOL[mode]
