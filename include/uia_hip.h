@@ -61,6 +61,9 @@ typedef struct uia_gemm_desc {
     int32_t out_group;                  /* >0: output row = m + m/out_group + 1 (patch rows -> token rows, CLS slot skipped) */
     void* outT; int64_t ldo;
     float* out32; int64_t ldo32;
+    int32_t w_kblocked;                 /* 1: W is stored K-blocked, [K/g][N][g] with g = 64 bytes / sizeof(T) elements (ldw ignored): the layout
+                                           the ring tile configs (8, 10; the automatic choice for M > 2048, N > 64) stream fastest; other tile
+                                           configs reject it */
 } uia_gemm_desc;
 int uia_gemm(void* stream, int dtype, const uia_gemm_desc* d, int tile_cfg /* 0 = auto */);
 

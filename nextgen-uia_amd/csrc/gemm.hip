@@ -205,7 +205,8 @@ __device__ __forceinline__ void gemm_epilogue(const UiaGemmParams& p, f32x4 (&ac
 // instruction-fetch bound.  The K-loop's LDS buffers are dead by now, so the bigger patch costs nothing.
 template <int MT, int WTN> struct EpiPatch {
     static constexpr int LDW = WTN + 4;                 // floats per staged row (+4 keeps the b128 accesses conflict-free)
-    static constexpr int GPP = MT < 4 ? MT : 4;         // MFMA row groups per phase
+    static constexpr int GPP = MT < 4 ? MT : (MT == 4 ? 2 : 4);   // MFMA row groups per phase (half-height tiles: 32-row patches, so that the
+                                                                  // eight patches fit the 72 KB of a 3-deep ring and two workgroups share a CU)
     static constexpr int ROWS = GPP * 16;
     static constexpr int BYTES_PER_WAVE = ROWS * LDW * 4;
 };
@@ -662,6 +663,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_tn_ring_kernel(co
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int grp = wave >= NW / 2 ? 1 : 0;
 
+#if defined(UIA_GEMM_STAMPS) || defined(UIA_GEMM_EXP)
+    {   // experiment: de-phase the two workgroups that share a CU (first generation only; later ones inherit the phase)
+        const int stg = (xflags >> 10) & 63;                  // delay in units of 4096 cycles
+        const bool second = ((xflags >> 16) & 1) ? ((blockIdx.x >> 3) & 1) : ((blockIdx.x >> 8) & 1);
+        if (stg && blockIdx.x < 512 && second) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+            while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)stg * 4096ull) __builtin_amdgcn_s_sleep(32);
+        }
+    }
+#endif
     const int tiles_n = (p.N + BN - 1) / BN;
     const int nwg = gridDim.x;
     int bid = blockIdx.x;
@@ -690,10 +701,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_tn_ring_kernel(co
         }
     }
     const int m0 = tm * BM, n0 = tn * BN;
+    // W may arrive K-BLOCKED ([K·ESZ/64][N][64 bytes], packed once per weight by the host): a sub-tile of a column panel is then
+    // one contiguous 16 KiB run, each 1 KiB LDS-DMA piece reads 8 whole 128-byte lines instead of 16 half lines, and the DMA-only
+    // K step drops from 3150 to 2880 cycles (N = 2304) / 2350 to 1980 (N = 768): +2…9 % on the whole kernel (profiles/r02_a).
 #if defined(UIA_GEMM_STAMPS) || defined(UIA_GEMM_EXP)
-    const bool kbA = (xflags >> 8) & 1, kbW = (xflags >> 9) & 1;      // diagnostic: operands addressed as K-blocked [K/32][rows][32]
+    const bool kbA = (xflags >> 8) & 1;                               // diagnostic only: A addressed as if it were K-blocked too
+    const bool kbW = p.w_kblocked != 0 || ((xflags >> 9) & 1);
 #else
-    constexpr bool kbA = false, kbW = false;
+    constexpr bool kbA = false;
+    const bool kbW = p.w_kblocked != 0;
 #endif
 
     // swizzle of the 16-byte chunk index: 128-byte rows: (row>>1)&7 / 2a|(b>>1) as in the 2-buffer kernels;
@@ -1055,6 +1071,7 @@ int launch_typed(hipStream_t stream, const UiaGemmParams& p, int cfg_in) {
     // bits 8.. of the tile argument carry experiment knobs for the ring kernels (tile-order group size, diagnostic layouts);
     // 0 there = the launcher's own choice.
     int cfg = cfg_in & 255, xflags = cfg_in >> 8;
+    const int gm_req = xflags & 255;                           // tile-order group: 0 = the launcher's choice, 255 = none (row-panel-major)
     // cfg: 0 = auto. Tile choice is a pure speed knob (results are identical for every config
     // up to fp32 summation order inside a K-step, which does not depend on the tile).
     if (cfg == 0) {
@@ -1063,6 +1080,19 @@ int launch_typed(hipStream_t stream, const UiaGemmParams& p, int cfg_in) {
         else cfg = 8;            // 256x256 ping-pong, 4-deep 64-byte ring, LDS-staged epilogue: best measured on every large shape.
                                  // (cfg 12, the persistent variant, is +2-3.5 % on store-only epilogues in isolation, -15-25 % on the
                                  //  fp32-residual ones, and a net loss inside the two-stream training step: opt-in only.)
+    }
+    const bool ring = cfg == 8 || cfg == 9 || cfg == 10 || cfg == 13 || cfg == 14;
+    if (p.w_kblocked && !ring) {
+        uia_set_error("uia_gemm: a K-blocked W needs a ring tile config (8, 9, 10, 13), not %d", cfg);
+        return -1;
+    }
+    if (ring) {
+        // Tile order (measured at M = 50 432 / 65 536, profiles/r02_a_gemm_order_layout.txt): a weight that does not fit the XCD's 4 MiB L2
+        // beside the A panels (N = 2304: 3.5 MB, N = 3072: 4.7 MB at K = 768) wants the XCD's ~32 concurrent tiles arranged as a block,
+        // 8 row panels deep for N = 2304 (+8 %), 16 for N = 3072 (+3 %); for N = 768 the whole W stays resident and the plain order wins.
+        int gm = gm_req == 255 ? 0 : gm_req;
+        if (gm_req == 0) gm = p.N >= 3072 ? 16 : (p.N >= 1536 ? 8 : 0);
+        xflags = (xflags & ~255) | gm;
     }
     switch (cfg) {
         case 1: return launch_cfg<T, 256, 256, 2, 4>(stream, p);
@@ -1076,6 +1106,9 @@ int launch_typed(hipStream_t stream, const UiaGemmParams& p, int cfg_in) {
         case 9: return launch_ring<T, 256, 128, 4, 2, 128, 3>(stream, p, false, xflags);
         case 10: return launch_ring<T, 256, 256, 2, 4, 64, 4>(stream, p, false, xflags);   // cfg 8 with the run-time (generic) epilogue: parity cross-check
         case 12: return launch_persist<T>(stream, p);
+        case 14: return launch_ring<T, 128, 256, 2, 4, 64, 3>(stream, p, true, xflags);   // 3-deep ring: 72 KB of LDS, two workgroups per CU
+        case 13: return launch_ring<T, 128, 256, 2, 4, 64, 4>(stream, p, true, xflags);   // half-height tiles: the M tail of a launch whose last round
+                                                                                         // would leave most CUs idle (host splits the rows, ops.gemm)
         default: uia_set_error("uia_gemm: unknown tile config %d", cfg); return -1;
     }
 }

@@ -165,6 +165,16 @@ int main(int argc, char** argv) {
     else stamps(8, 50432, 2304, 768, 0, 0);
     return 0;
 #endif
+    if (argc > 1 && !strcmp(argv[1], "stagger")) {  // ./test_gemm_exp stagger: two workgroups per CU (cfg 14), the second one delayed by s x 4096 cycles
+        const int shapes[][4] = {{50432, 768, 768, 2}, {65536, 768, 768, 2}, {50432, 768, 3072, 2}, {50432, 768, 64, 2}, {50432, 2304, 768, 0}, {50432, 3072, 768, 1}};
+        for (auto& sh : shapes) {
+            bench(UIA_BF16, sh[0], sh[1], sh[2], 8, sh[3]);
+            for (int mode : {0, 1})
+                for (int s : {0, 4, 8, 12, 16, 24})
+                    { if (s == 0 && mode) continue; printf("stagger=%d mode=%d  ", s, mode); bench(UIA_BF16, sh[0], sh[1], sh[2], 14 | (s << 18) | (mode << 24), sh[3]); }
+        }
+        return 0;
+    }
     if (argc > 1 && !strcmp(argv[1], "exp")) {      // ./test_gemm exp: tile-order group size (bits 8..15) x diagnostic K-blocked operand addressing (bits 16, 17)
         const int shapes[][4] = {{50432, 768, 768, 2}, {50432, 2304, 768, 0}, {50432, 3072, 768, 1}, {50432, 768, 3072, 2}, {65536, 3072, 768, 0}, {50432, 768, 2304, 0}};
         for (auto& sh : shapes)

@@ -24,7 +24,7 @@ class GemmDesc(C.Structure):
     _fields_ = [("A", vp), ("lda", i64), ("W", vp), ("ldw", i64), ("M", i32), ("N", i32), ("K", i32), ("alpha", f32),
                 ("bias", vp), ("act", i32), ("dact", i32), ("aux_in", vp), ("ldaux_in", i64), ("aux_out", vp), ("ldaux_out", i64),
                 ("resid", vp), ("ldr", i64), ("resid_mod", i32), ("resid_row_off", i32), ("residT", vp), ("ldrT", i64),
-                ("out_group", i32), ("outT", vp), ("ldo", i64), ("out32", vp), ("ldo32", i64)]
+                ("out_group", i32), ("outT", vp), ("ldo", i64), ("out32", vp), ("ldo32", i64), ("w_kblocked", i32)]
 
 
 class AttnDesc(C.Structure):

@@ -100,7 +100,7 @@ class WeightCache:
     def get(self, p, dt, transpose=False, pad_rows_to=None, pad_cols_to=None):
         key = (id(p), dt, transpose, pad_rows_to, pad_cols_to)
         hit = self._c.get(key)
-        if hit is not None and hit[0] == p._version and hit[1]() is p and hit[2].device == p.device and (not p.requires_grad or hit[3] == self.epoch):
+        if hit is not None and hit[0] == p._version and hit[1]() is p and hit[2].row.device == p.device and (not p.requires_grad or hit[3] == self.epoch):
             return hit[2]
         src = p.detach()
         if src.dim() != 2:
@@ -118,6 +118,7 @@ class WeightCache:
         else:
             out = torch.empty(src.shape, device=src.device, dtype=dt)
             ops.cast(src, out)
+        out = ops.PackedW(out)                                 # the ring GEMMs take the K-blocked twin, built on first use
         self._c[key] = (p._version, weakref.ref(p), out, self.epoch)
         return out
 

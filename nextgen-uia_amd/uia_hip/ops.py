@@ -43,6 +43,61 @@ def auto_tile_cfg(M, N, K=None, esz=2, mask=EPI_GENERIC):
     return 8
 
 
+RING_CFGS = (8, 9, 10, 13)
+KBLOCK_W = True          # hand the ring kernels their weights K-blocked (PackedW.kblocked()); False = row-major everywhere
+TAIL_SPLIT = True        # split off the M tail of a launch whose last round of 256x256 tiles would leave most CUs idle
+_NCU = {}
+
+
+def num_cus(device=None):
+    dev = torch.cuda.current_device() if device is None else device
+    if dev not in _NCU:
+        _NCU[dev] = torch.cuda.get_device_properties(dev).multi_processor_count
+    return _NCU[dev]
+
+
+def tail_split_rows(M, N, ncu, bm=256, bn=256):
+    """Rows of the MAIN launch (a multiple of `bm`) when the 256x256 tiling should be split, else M.
+
+    tiles = ceil(M/bm)·ceil(N/bn) workgroups run in rounds of `ncu`; when the last round holds at most half of the CUs
+    (M = 50 432, N = 768: 591 = 2·256 + 79) its tiles are re-cut at half height (tile config 13, 128x256) so that they spread over
+    twice as many CUs and the round takes about half as long: 2.55 instead of 3 tile times for that shape.  Pure scheduling —
+    every output element is still one K-ordered fp32 accumulation, so results are identical to the unsplit launch."""
+    tm, tn = -(-M // bm), -(-N // bn)
+    tiles = tm * tn
+    rem = tiles % ncu
+    if tiles <= ncu or rem == 0 or 2 * rem > ncu:
+        return M
+    main_panels = (tiles - rem) // tn
+    if main_panels < 1 or main_panels >= tm:
+        return M
+    return main_panels * bm
+
+
+class PackedW:
+    """A GEMM weight [N, K] in the compute dtype, with its K-blocked twin [K/g][N][g] (g = 64 bytes of elements) built on first
+    use by a ring-kernel launch.  Layout plumbing only (a strided copy); which one a launch takes is decided in gemm()."""
+    __slots__ = ("row", "_kb")
+
+    def __init__(self, row):
+        self.row, self._kb = row, None
+
+    @property
+    def shape(self):
+        return self.row.shape
+
+    @property
+    def dtype(self):
+        return self.row.dtype
+
+    def kblocked(self):
+        if self._kb is None:
+            N, K = self.row.shape
+            g = 64 // self.row.element_size()
+            self._kb = self.row.view(N, K // g, g).permute(1, 0, 2).contiguous()
+        return self._kb
+
+
 def gemm_kernel_name(cfg, mask, dtype):
     """(readable name, mangled fragment) of the instantiation a launch runs on.  rocprofv3 prints these kernels mangled
     (its demangler does not know the bf16 type code), so the fragment is what to grep for in profiles/*.csv."""
@@ -51,8 +106,9 @@ def gemm_kernel_name(cfg, mask, dtype):
     mi = lambda v: f"Li{v}E" if v >= 0 else f"Lin{-v}E"
     if cfg == 12:
         return f"gemm_tn_persist_kernel<{tn},{m}>", f"gemm_tn_persist_kernelI{tc}{mi(m)}E"
-    if cfg == 8:
-        return f"gemm_tn_ring_kernel<{tn},256,256,2,4,64,4,{m}>", "gemm_tn_ring_kernelI" + tc + "".join(mi(v) for v in (256, 256, 2, 4, 64, 4, m)) + "E"
+    if cfg in (8, 13):
+        bm = 256 if cfg == 8 else 128
+        return f"gemm_tn_ring_kernel<{tn},{bm},256,2,4,64,4,{m}>", "gemm_tn_ring_kernelI" + tc + "".join(mi(v) for v in (bm, 256, 2, 4, 64, 4, m)) + "E"
     shape = {1: (256, 256, 2, 4), 2: (256, 128, 4, 2), 3: (128, 128, 2, 2), 4: (256, 64, 4, 1), 5: (128, 64, 2, 1)}.get(cfg)
     if shape:
         return f"gemm_tn_kernel<{tn},{','.join(map(str, shape))}>", "gemm_tn_kernelI" + tc + "".join(mi(v) for v in shape) + "E"
@@ -89,13 +145,40 @@ def _rowmajor(t, name):
 
 def gemm(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None, resid=None, resid_mod=0, resid_row_off=0,
          resid_t=None, out_group=0, out_t=None, out32=None, alpha=1.0, tile_cfg=0):
-    """C = epilogue(alpha * a @ w.T).  a [M,K], w [N,K] share a dtype (bf16 | fp32); see include/uia_hip.h."""
+    """C = epilogue(alpha * a @ w.T).  a [M,K], w [N,K] (tensor or PackedW) share a dtype (bf16 | fp32); see include/uia_hip.h.
+
+    Host-side scheduling on top of uia_gemm (results do not depend on it): with the automatic tile choice, a weight that came
+    as a PackedW is handed to the ring kernels K-blocked, and the M tail of a launch whose last round of tiles would leave most
+    CUs idle goes through a second launch with half-height tiles (tail_split_rows)."""
+    packed = w if isinstance(w, PackedW) else None
+    wrow = packed.row if packed is not None else w
+    M, N = a.shape[0], wrow.shape[0]
+    if (TAIL_SPLIT and tile_cfg == 0 and out_group == 0 and resid_mod == 0 and a.is_cuda and auto_tile_cfg(M, N) == 8):
+        m_main = tail_split_rows(M, N, num_cus(a.device.index))
+        if m_main < M:
+            cut = lambda t, lo, hi: None if t is None else t[lo:hi]
+            for lo, hi, cfg in ((0, m_main, 8), (m_main, M, 13)):
+                _gemm_one(a[lo:hi], w, bias=bias, act=act, dact=dact, aux_in=cut(aux_in, lo, hi), aux_out=cut(aux_out, lo, hi), resid=cut(resid, lo, hi),
+                          resid_t=cut(resid_t, lo, hi), out_t=cut(out_t, lo, hi), out32=cut(out32, lo, hi), alpha=alpha, tile_cfg=cfg)
+            return
+    _gemm_one(a, w, bias=bias, act=act, dact=dact, aux_in=aux_in, aux_out=aux_out, resid=resid, resid_mod=resid_mod, resid_row_off=resid_row_off,
+              resid_t=resid_t, out_group=out_group, out_t=out_t, out32=out32, alpha=alpha, tile_cfg=tile_cfg)
+
+
+def _gemm_one(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None, resid=None, resid_mod=0, resid_row_off=0,
+              resid_t=None, out_group=0, out_t=None, out32=None, alpha=1.0, tile_cfg=0):
     d = GemmDesc()
+    packed = w if isinstance(w, PackedW) else None
+    if packed is not None:
+        w = packed.row
     d.lda, d.ldw = _rowmajor(a, "a"), _rowmajor(w, "w")
     if a.dtype != w.dtype or a.shape[1] != w.shape[1]:
         raise UiaError(f"gemm operand mismatch: a {tuple(a.shape)} {a.dtype}, w {tuple(w.shape)} {w.dtype}")
     d.A, d.W = _p(a), _p(w)
     d.M, d.K, d.N = a.shape[0], a.shape[1], w.shape[0]
+    base_cfg = (tile_cfg & 255) or auto_tile_cfg(d.M, d.N)
+    if packed is not None and KBLOCK_W and base_cfg in RING_CFGS and a.is_cuda:
+        d.W, d.w_kblocked = _p(packed.kblocked()), 1
     d.alpha = alpha
     d.act, d.dact = _ACT[act], _ACT[dact]
     if bias is not None:
@@ -132,7 +215,7 @@ def gemm(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None, res
         nbytes = esz * (d.M * d.K + d.N * d.K) + d.M * d.N * (esz * sum(t is not None for t in (aux_in, aux_out, resid_t, out_t))
                                                              + 4 * sum(t is not None for t in (resid, out32)))
         mask = epi_mask_of(d)
-        GEMM_PROFILE.append((e0, e1, d.M, d.N, d.K, a.dtype, tile_cfg or auto_tile_cfg(d.M, d.N, d.K, esz, mask), nbytes, mask))
+        GEMM_PROFILE.append((e0, e1, d.M, d.N, d.K, a.dtype, base_cfg, nbytes, mask))
         return
     check(lib().uia_gemm(_stream(), _code(a.dtype), C.byref(d), tile_cfg), "uia_gemm")
 

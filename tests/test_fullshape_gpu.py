@@ -349,3 +349,36 @@ def test_attention_production_shapes(L, mask):
     gq = qf.grad.permute(1, 3, 0, 2, 4).reshape(B * L, 3 * D)
     for i, name in enumerate("qkv"):
         assert rel(dqkv[:, i * D:(i + 1) * D], gq[:, i * D:(i + 1) * D]) < 2.5e-2, name
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("N,K", [(768, 768), (3072, 768), (768, 3072), (768, 64)])
+def test_gemm_scheduling_knobs_do_not_change_results(dt, N, K):
+    """K-blocked weight (PackedW), tile-order group and the M-tail split (half-height tiles, config 13) are scheduling only: every
+    output element is the same K-ordered fp32 accumulation, so the result is BIT-identical to the plain row-major, unsplit launch."""
+    from uia_hip import ops
+    torch.manual_seed(3 + N + K)
+    M = M_PROD
+    if dt == torch.float32:
+        K = max(64, K // 4)                                             # keep the exact-fp32 MFMA case short
+    a = torch.randn(M, K, device=dev()).to(dt)
+    w = (torch.randn(N, K, device=dev()) * (K ** -0.5)).to(dt)
+    bias, resid = torch.randn(N, device=dev()), torch.randn(M, N, device=dev())
+    assert ops.tail_split_rows(M, N, ops.num_cus()) < M
+    outs = []
+    for split, kb, order in ((False, False, 255), (True, False, 0), (False, True, 0), (True, True, 0), (False, True, 4)):
+        ops.TAIL_SPLIT, ops.KBLOCK_W = split, kb
+        try:
+            y32 = torch.full((M, N), float("nan"), device=dev())
+            yt = torch.full((M, N), float("nan"), device=dev(), dtype=dt)
+            wk = ops.PackedW(w)
+            cfg = 0 if split else (8 | (order << 8))                    # the split applies to the automatic tile choice only
+            ops.gemm(a, wk, bias=bias, resid=resid, out32=y32, tile_cfg=cfg)
+            ops.gemm(a, wk, bias=bias, act="gelu", out_t=yt, tile_cfg=cfg)
+            outs.append((y32, yt))
+        finally:
+            ops.TAIL_SPLIT, ops.KBLOCK_W = True, True
+    ref = a.float() @ w.float().T + bias + resid
+    assert float((outs[0][0] - ref).abs().max()) <= 3e-5 * float(ref.abs().max())
+    for y32, yt in outs[1:]:
+        assert torch.equal(y32, outs[0][0]) and torch.equal(yt, outs[0][1])

@@ -171,3 +171,39 @@ def test_model_config_parser_accepts_dict_calls_and_nothing_executable():
     for bad in ("__import__('os').system('true')", "dict(a=open('x'))", "dict(**{'a': 1})", "[x for x in (1,)]"):
         with pytest.raises((ValueError, TypeError, SyntaxError)):
             parse_config(bad)
+
+
+def test_gemm_tail_split_policy():
+    """ops.tail_split_rows: which launches get their M tail re-cut into half-height tiles (pure host scheduling)."""
+    from uia_hip import ops
+    # ViT-B/16 at bs 256: 197 row panels x 3 column panels = 591 = 2*256 + 79 -> the main launch keeps 170 whole panels (510 tiles)
+    assert ops.tail_split_rows(50432, 768, 256) == 170 * 256
+    # N = 3072: 2364 = 9*256 + 60 -> 192 panels in the main launch, 5 panels (60 tiles -> 120 half tiles) in the tail
+    assert ops.tail_split_rows(50432, 3072, 256) == 192 * 256
+    # N = 2304: 1773 = 6*256 + 237: the last round is 93 % full, no split
+    assert ops.tail_split_rows(50432, 2304, 256) == 50432
+    # BERT rows (65 536): every N of the model is a whole number of rounds
+    for n in (768, 2304, 3072):
+        assert ops.tail_split_rows(65536, n, 256) == 65536
+    # fewer tiles than CUs, or a single row panel: nothing to split
+    assert ops.tail_split_rows(4096, 768, 256) == 4096 and ops.tail_split_rows(256, 768, 2) == 256
+    for M, N, ncu in ((50432, 768, 256), (50432, 3072, 256), (32896, 1024, 256), (12345, 4096, 304)):
+        m = ops.tail_split_rows(M, N, ncu)
+        assert m % 256 == 0 or m == M
+        if m < M:                                                       # main = whole rounds; the tail's half tiles fit one round
+            tn = -(-N // 256)
+            assert (m // 256 * tn) <= (-(-M // 256) * tn) // ncu * ncu
+            assert -(-(M - m) // 128) * tn <= ncu + tn * 2
+
+
+def test_packed_weight_kblocked_layout():
+    """PackedW.kblocked(): element (n, k) of the row-major weight sits at [k // g][n][k % g], g = 64 bytes of elements."""
+    import torch
+    from uia_hip import ops
+    for dt, g in ((torch.bfloat16, 32), (torch.float32, 16)):
+        w = torch.arange(6 * 2 * g, dtype=torch.float32).view(6, 2 * g).to(dt)
+        pw = ops.PackedW(w)
+        kb = pw.kblocked()
+        assert tuple(kb.shape) == (2, 6, g) and kb.is_contiguous() and pw.kblocked() is kb and pw.shape == w.shape and pw.dtype == dt
+        for n, k in ((0, 0), (5, g - 1), (3, g), (2, 2 * g - 1)):
+            assert float(kb[k // g, n, k % g]) == float(w[n, k])

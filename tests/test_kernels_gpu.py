@@ -49,7 +49,7 @@ def test_gemm_epilogues(ops, dt):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 13])
 def test_gemm_every_tile_config_and_epilogue_mask(ops, dt, cfg):
     """Every tile instantiation (lockstep 1-5, ping-pong 6-7, ring 8-10) against torch on a ragged shape, through
     the six compile-time epilogue masks of the ring kernel (cfg 8) and the run-time epilogue (everything else)."""
