@@ -66,6 +66,27 @@ def synthetic_batch(batch, rank, device):
     return images.to(device), ids.to(device)
 
 
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def text_attention_flops(ids, heads=12, dh=64, layers=12, pad_id=0):
+    """(algorithmic, executed) attention FLOPs of the frozen text tower for one batch: the reference computes all L x L scores
+    (HF BertSelfAttention with an additive mask); attn_fwd skips key tiles that are entirely padding, 64 keys (4 MFMA tiles) at a time."""
+    B, L = ids.shape
+    klen = (ids != pad_id).sum(dim=1).clamp(min=1)
+    keys_exec = ((klen + 15) // 16 + 3) // 4 * 64
+    keys_exec = keys_exec.clamp(max=(L + 15) // 16 * 16)
+    per_key = 4.0 * heads * L * dh * layers
+    return float(B * L * per_key), float(keys_exec.sum().item() * per_key)
+
+
 def cpu_baseline(state, variant, batch, steps):
     """The oracle (CPU restatement of the reference path) timed on this host's cores: the reported CPU baseline."""
     import torch
@@ -89,7 +110,8 @@ def cpu_baseline(state, variant, batch, steps):
             break
     timed = times[1:] if len(times) > 1 else times
     dt = sum(timed) / len(timed)
-    return {"value": round(batch / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+    return {"value": round(batch / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(), "host_logical_cpus": os.cpu_count(),
+            "host_cpu_model": _cpu_model(), "kind": "port",
             "sample": f"{len(timed)} fwd+bwd step(s){' after 1 warm-up' if len(times) > 1 else ' (no warm-up: first step exceeded the 30 s budget)'} "
                       f"of the same model at micro-batch {batch}, fp32, oracle/train_ref.py",
             "s_per_step": round(dt, 3)}
@@ -142,12 +164,15 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for s in range(args.steps):
-        if s == args.steps - 1:
-            ops.GEMM_PROFILE = []                                    # live per-launch events on the last timed step
         loss = contrastive_step(model, criterion, opt, images, ids, overlap_text=args.overlap_text, global_loss=args.global_loss)
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    # per-launch HIP events (on the launch stream) around every uia_gemm of ONE more step of the same loop, outside the timed region:
+    # the event records cost host time the throughput figure should not carry; the step itself is identical to the timed ones
+    ops.GEMM_PROFILE = []
+    contrastive_step(model, criterion, opt, images, ids, overlap_text=args.overlap_text, global_loss=args.global_loss)
+    torch.cuda.synchronize()
     prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
     prof_serial = prof
     if args.overlap_text:
@@ -177,6 +202,19 @@ def main():
                 d[2] += 1
                 d[3] += nbytes
             return acc
+        def shape_table(events, peak):
+            acc = {}
+            for e0, e1, M, N, K, dt, cfg, nbytes, mask in events:
+                d = acc.setdefault((cfg, mask if mask in ops._SPECIALISED else ops.EPI_GENERIC, M, N, K), [0.0, 0, nbytes])
+                d[0] += e0.elapsed_time(e1) * 1e-3
+                d[1] += 1
+            rows = []
+            for (cfg, mask, M, N, K), (tsec, n, nbytes) in sorted(acc.items(), key=lambda kv: -kv[1][0]):
+                tf = 2.0 * M * N * K * n / tsec * 1e-12
+                rows.append({"kernel": ops.gemm_kernel_name(cfg, mask, torch.bfloat16 if args.dtype == "bf16" else torch.float32)[0], "M": M, "N": N, "K": K,
+                             "launches": n, "avg_us": round(tsec / n * 1e6, 1), "tflops": round(tf, 1), "frac_of_mfma_peak": round(tf / peak, 4),
+                             "algorithmic_GBps": round(nbytes * n / tsec * 1e-9), "frac_of_hbm_spec": round(nbytes * n / tsec * 1e-12 / 8.0, 3)})
+            return rows
         per_kernel = lambda c, m: (c, m if m in ops._SPECIALISED else ops.EPI_GENERIC)
         by_k, by_k_serial = group(prof, per_kernel), group(prof_serial, per_kernel)
         fam, fam_serial = group(prof, lambda c, m: c in (8, 12, 13)), group(prof_serial, lambda c, m: c in (8, 12, 13))
@@ -189,7 +227,10 @@ def main():
             ts, fs, ns, _ = by_k_serial.get(dom, (tsec, flops, n, algo_bytes))
             kname, kmangled = ops.gemm_kernel_name(dom[0], dom[1], torch.bfloat16 if args.dtype == "bf16" else torch.float32)
             traffic, traffic_src = None, None
-            tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_g_traffic_pmc.json")
+            tdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+            tpath = os.path.join(tdir, "r02_traffic_pmc.json")
+            if not os.path.exists(tpath):
+                tpath = os.path.join(tdir, "r01_g_traffic_pmc.json")
             if args.dtype == "bf16" and args.batch == 256 and os.path.exists(tpath):
                 # HBM bytes per launch of this kernel from rocprofv3 PMC passes over the same workload (tools/pmc_traffic.sh):
                 # FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies the 128-B requests of wide coalesced
@@ -198,7 +239,7 @@ def main():
                 f, w = pm["FETCH_SIZE"].get(kmangled), pm["WRITE_SIZE"].get(kmangled)
                 if f and w:
                     traffic = round((2.0 * f["sum"] / f["launches"] + w["sum"] / w["launches"]) * 1024)
-                    traffic_src = ("profiles/r01_g_traffic_pmc.json (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, same "
+                    traffic_src = (f"profiles/{os.path.basename(tpath)} (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, same "
                                    "workload; FETCH_SIZE doubled per the gfx950 note of the microarchitecture guide)")
             ft, ff, fn, _ = fam.get(True, (tsec, flops, n, 0.0))
             fts, ffs, fns, _ = fam_serial.get(True, (ts, fs, ns, 0.0))
@@ -207,13 +248,21 @@ def main():
                     "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(algo_bytes / n), "launches_per_step": n,
                     "avg_launch_us": round(tsec / n * 1e6, 2), "flop_per_launch_avg": round(flops / n),
                     "share_of_step": round(tsec / (elapsed / args.steps), 3),
-                    "note": ("HIP events around every launch of this kernel during the last timed step, on the launch stream" +
+                    "note": ("HIP events around every launch of this kernel, on the launch stream, during one extra step of the same loop right after the timed region" +
                              ("; --overlap-text: the text tower runs on a second stream, so a launch's duration includes time shared with "
                               "that stream's kernels (see standalone)" if args.overlap_text else "")),
                     "gemm_family": {"kernels": "gemm_tn_ring_kernel<...,EPI> (+ gemm_tn_persist_kernel when selected), all epilogue masks",
                                     "launches_per_step": fn, "achieved": round(ff / ft * 1e-12, 1), "frac": round(ff / ft * 1e-12 / peak, 4)},
+                    "per_shape": shape_table(prof_serial, peak),
                     # with --unpad-text the executed text-tower work is below the dense count GFLOP_PER_PAIR is quoted on: no fraction then
                     "whole_step_frac_of_peak": None if args.unpad_text else round(value / world * GFLOP_PER_PAIR * 1e-3 / peak, 4)}
+            if not args.unpad_text:
+                algo, execd = text_attention_flops(ids.cpu())
+                gf_exec = GFLOP_PER_PAIR - (algo - execd) * 1e-9 / args.batch
+                roof["text_attention_flops"] = {"algorithmic_GF_per_step": round(algo * 1e-9, 1), "executed_GF_per_step": round(execd * 1e-9, 1),
+                                                "note": "fully padded 64-key chunks are skipped; every GEMM runs all 256 positions"}
+                roof["gflop_per_pair_executed"] = round(gf_exec, 2)
+                roof["whole_step_frac_of_peak_executed"] = round(value / world * gf_exec * 1e-3 / peak, 4)
             if args.overlap_text:
                 roof["standalone"] = {"achieved": round(fs / ts * 1e-12, 1), "frac": round(fs / ts * 1e-12 / peak, 4), "avg_launch_us": round(ts / ns * 1e6, 2),
                                       "family_achieved": round(ffs / fts * 1e-12, 1), "how": "one extra untimed step with both towers on one stream"}

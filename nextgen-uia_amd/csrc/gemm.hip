@@ -641,7 +641,7 @@ int launch_pp(hipStream_t stream, const UiaGemmParams& p) {
 //   sub-tile t-1, whose final ds_reads (group 1, wall slot 2·t·SPT-1) were retired before that slot's barrier.
 // 64-byte rows use the 4-entry swizzle table {0,3,2,1} indexed by (row>>2)&3 (A) / the 16-row block of the
 // permuted W rows: conflict-free ds_read_b128 for both fragment patterns.
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int NBUF, int EPI>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int NBUF, int EPI, int LOOP = 0>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_tn_ring_kernel(const UiaGemmParams p, const int xflags) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NW = WAVES_M * WAVES_N;
@@ -790,6 +790,89 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_tn_ring_kernel(co
 #ifdef UIA_GEMM_STAMPS
     unsigned long long t_start = __builtin_amdgcn_s_memtime(), t_pro = 0, t_loop = 0;
 #endif
+    if constexpr (LOOP >= 1) {
+        // ---- FREE-RUNNING loop (tile cfg 15): no LOAD / COMPUTE alternation between two wave groups.  Every wave keeps TWO fragment
+        // sets in registers: during step t it issues the LDS-DMA of sub-tile t+NBUF, reads the fragments of sub-tile t+1 into the idle
+        // set and runs its 32 MFMAs on the set it read one step earlier, so its own ds_reads fly under its own (and its SIMD partner's)
+        // MFMAs and the workgroup meets at ONE barrier per sub-tile instead of two (in-kernel stamps of the ping-pong loop: 650 cycles
+        // per slot with MFMAs and barriers alone against 512 of MFMA issue).  Reading a sub-tile into registers one step ahead also
+        // frees its ring buffer one step earlier: NBUF sub-tiles stay in flight instead of NBUF-1.
+        //   step t:  DMA(t+NBUF) -> buffer t%NBUF   | its last reader: the fragment reads of step t-1, retired (lgkmcnt(0)) before that
+        //                                             step's closing barrier                                                    (WAR)
+        //            read fragments(t+1)            | sub-tile t+1 was retired (counted vmcnt) before the closing barrier of step t-1  (RAW)
+        //            MFMAs(t)
+        //            wait: own pieces of sub-tile t+2 (all but the younger sub-tiles t+3, t+4), lgkmcnt(0);  barrier
+        static_assert(SPT == 1 && (NBUF == 3 || NBUF == 4), "free-running loop: 64-byte sub-tiles, three or four ring buffers");
+        constexpr int PDF = NBUF;                                   // sub-tiles issued ahead
+        for (int t = 0; t < PDF && t < ntl; ++t) stage(t, 0);
+        // sub-tiles 0 and 1 resident before the first reads: leave the younger ones in flight
+        {
+            const int younger = (ntl > 2 ? (ntl < PDF ? ntl : PDF) - 2 : 0);
+            if (younger >= 2 && PDF >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PDF - 2) * GPT) : "memory");
+            else if (younger == 1 || (younger >= 1 && PDF == 3)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GPT) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef UIA_GEMM_STAMPS
+        t_pro = __builtin_amdgcn_s_memtime();
+#endif
+        uint4 af2[MT], wf2[NT];
+        auto read_into = [&](uint4 (&a_)[MT], uint4 (&w_)[NT], const char* buf) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) w_[j] = *(const uint4*)(buf + offW0 + j * 4 * BKB);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) a_[i] = *(const uint4*)(buf + offA0 + i * 16 * BKB);
+        };
+        // LOOP == 2: the second wave group runs HALF A STEP behind the first one (same program on both waves of a SIMD runs in
+        // lockstep otherwise: both in their fragment reads, both in their MFMAs).  Its step is [second half of the previous
+        // step's MFMAs | DMA + fragment reads into the set that just became free | first half of this step's MFMAs]: while
+        // group 0 reads, group 1 multiplies, and the other way round in the middle of the step.
+        constexpr bool STAGGER = LOOP == 2;
+        auto mma_lo = [&](uint4 (&a_)[MT], uint4 (&w_)[NT]) {
+#pragma unroll
+            for (int i = 0; i < MT / 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = MfmaTile<T>::mma(w_[j], a_[i], acc[i][j]);
+        };
+        auto mma_hi = [&](uint4 (&a_)[MT], uint4 (&w_)[NT]) {
+#pragma unroll
+            for (int i = MT / 2; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = MfmaTile<T>::mma(w_[j], a_[i], acc[i][j]);
+        };
+        auto step = [&](int t, uint4 (&ac)[MT], uint4 (&wc)[NT], uint4 (&an)[MT], uint4 (&wn_)[NT]) {
+            if (STAGGER && grp == 1 && t > 0 && !UIA_DIAG_NO_MFMA) { mma_hi(an, wn_); __builtin_amdgcn_sched_barrier(0); }
+            if (t + PDF < ntl && !UIA_DIAG_NO_DMA) stage(t + PDF, 0);
+            if (t + 1 < ntl && !UIA_DIAG_NO_FRAGS) read_into(an, wn_, smem + ((t + 1) % NBUF) * BUF_BYTES);
+            if (!UIA_DIAG_NO_MFMA) {
+                if (STAGGER && grp == 1) mma_lo(ac, wc);
+                else { mma_lo(ac, wc); mma_hi(ac, wc); }
+            }
+            if (t + 2 < ntl) {                                      // own pieces of sub-tile t+2 landed; t+3 .. t+PDF may stay in flight
+                const int rest = ntl - (t + 3);                     // sub-tiles younger than t+2 that exist
+                const int fly = rest < 0 ? 0 : (rest > PDF - 2 ? PDF - 2 : rest);
+                if (fly >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * GPT) : "memory");
+                else if (fly == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GPT) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        read_into(af, wf, smem);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // step 0 refills buffer 0: every wave's reads of it must be back first
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        for (int t = 0; t < ntl; t += 2) {
+            step(t, af, wf, af2, wf2);
+            if (t + 1 < ntl) step(t + 1, af2, wf2, af, wf);
+        }
+        if (STAGGER && grp == 1 && !UIA_DIAG_NO_MFMA) {             // the deferred half of the last step
+            if (ntl & 1) mma_hi(af, wf);
+            else mma_hi(af2, wf2);
+        }
+    } else {
     for (int t = 0; t < PD && t < ntl; ++t)
 #pragma unroll
         for (int part = 0; part < SPT; ++part) stage(t, part);
@@ -820,6 +903,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_tn_ring_kernel(co
     if (grp == 0) {
         UIA_SLOT_END();
     }
+    }   // LOOP == 0
 #undef UIA_SLOT_END
 #ifdef UIA_GEMM_STAMPS
     t_loop = __builtin_amdgcn_s_memtime();
@@ -836,12 +920,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_tn_ring_kernel(co
 #endif
 }
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int NBUF, int EPI>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int NBUF, int EPI, int LOOP = 0>
 int launch_ring_epi(hipStream_t stream, const UiaGemmParams& p, int xflags) {
     constexpr int EPB = WAVES_M * WAVES_N * EpiPatch<BM / WAVES_M / 16, BN / WAVES_N>::BYTES_PER_WAVE;
     constexpr int LDS = NBUF * (BM + BN) * BKB > EPB ? NBUF * (BM + BN) * BKB : EPB;
     static_assert(LDS <= 160 * 1024, "LDS budget");
-    auto kern = gemm_tn_ring_kernel<T, BM, BN, WAVES_M, WAVES_N, BKB, NBUF, EPI>;
+    auto kern = gemm_tn_ring_kernel<T, BM, BN, WAVES_M, WAVES_N, BKB, NBUF, EPI, LOOP>;
     static UiaDevOnce attr_once;
     UIA_ENSURE_LDS_ATTR(attr_once, kern, LDS);
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
@@ -1030,11 +1114,11 @@ inline int epi_mask_of(const UiaGemmParams& p) {
            (p.residT ? EPI_RESIDT : 0) | (p.out32 ? EPI_OUT32 : 0) | (p.outT ? EPI_OUTT : 0);
 }
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int NBUF>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int NBUF, int LOOP = 0>
 int launch_ring(hipStream_t stream, const UiaGemmParams& p, bool specialise, int xflags) {
     if (specialise) {
         switch (epi_mask_of(p)) {    // the six masks of a training step, by time spent (tools/gemm_census.py)
-#define UIA_EPI_CASE(MASK) case (MASK): return launch_ring_epi<T, BM, BN, WAVES_M, WAVES_N, BKB, NBUF, (MASK)>(stream, p, xflags)
+#define UIA_EPI_CASE(MASK) case (MASK): return launch_ring_epi<T, BM, BN, WAVES_M, WAVES_N, BKB, NBUF, (MASK), LOOP>(stream, p, xflags)
             UIA_EPI_CASE(EPI_BIAS | EPI_RESID | EPI_OUT32);                    // proj / fc2 / Mona project2 forward
             UIA_EPI_CASE(EPI_BIAS | EPI_RESIDT | EPI_OUT32);                   // post-LN (BERT) sub-layer sums on the T residual
             UIA_EPI_CASE(EPI_OUTT);                                            // dgrads
@@ -1046,7 +1130,7 @@ int launch_ring(hipStream_t stream, const UiaGemmParams& p, bool specialise, int
             default: break;
         }
     }
-    return launch_ring_epi<T, BM, BN, WAVES_M, WAVES_N, BKB, NBUF, EPI_GENERIC>(stream, p, xflags);
+    return launch_ring_epi<T, BM, BN, WAVES_M, WAVES_N, BKB, NBUF, EPI_GENERIC, LOOP>(stream, p, xflags);
 }
 
 template <typename T>
@@ -1081,7 +1165,7 @@ int launch_typed(hipStream_t stream, const UiaGemmParams& p, int cfg_in) {
                                  // (cfg 12, the persistent variant, is +2-3.5 % on store-only epilogues in isolation, -15-25 % on the
                                  //  fp32-residual ones, and a net loss inside the two-stream training step: opt-in only.)
     }
-    const bool ring = cfg == 8 || cfg == 9 || cfg == 10 || cfg == 13 || cfg == 14;
+    const bool ring = cfg == 8 || cfg == 9 || cfg == 10 || cfg == 13 || cfg == 14 || cfg == 15;
     if (p.w_kblocked && !ring) {
         uia_set_error("uia_gemm: a K-blocked W needs a ring tile config (8, 9, 10, 13), not %d", cfg);
         return -1;
@@ -1106,6 +1190,10 @@ int launch_typed(hipStream_t stream, const UiaGemmParams& p, int cfg_in) {
         case 9: return launch_ring<T, 256, 128, 4, 2, 128, 3>(stream, p, false, xflags);
         case 10: return launch_ring<T, 256, 256, 2, 4, 64, 4>(stream, p, false, xflags);   // cfg 8 with the run-time (generic) epilogue: parity cross-check
         case 12: return launch_persist<T>(stream, p);
+#ifdef UIA_GEMM_EXP
+        case 15: return launch_ring<T, 256, 256, 2, 4, 64, 4, 1>(stream, p, true, xflags);  // free-running loop (two fragment sets, one barrier per sub-tile):
+                                                                                            // 5-10 % SLOWER than the ping-pong loop on every shape; experiment builds only
+#endif
         case 14: return launch_ring<T, 128, 256, 2, 4, 64, 3>(stream, p, true, xflags);   // 3-deep ring: 72 KB of LDS, two workgroups per CU
         case 13: return launch_ring<T, 128, 256, 2, 4, 64, 4>(stream, p, true, xflags);   // half-height tiles: the M tail of a launch whose last round
                                                                                          // would leave most CUs idle (host splits the rows, ops.gemm)

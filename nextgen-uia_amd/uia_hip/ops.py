@@ -108,7 +108,7 @@ def gemm_kernel_name(cfg, mask, dtype):
         return f"gemm_tn_persist_kernel<{tn},{m}>", f"gemm_tn_persist_kernelI{tc}{mi(m)}E"
     if cfg in (8, 13):
         bm = 256 if cfg == 8 else 128
-        return f"gemm_tn_ring_kernel<{tn},{bm},256,2,4,64,4,{m}>", "gemm_tn_ring_kernelI" + tc + "".join(mi(v) for v in (bm, 256, 2, 4, 64, 4, m)) + "E"
+        return f"gemm_tn_ring_kernel<{tn},{bm},256,2,4,64,4,{m}>", "gemm_tn_ring_kernelI" + tc + "".join(mi(v) for v in (bm, 256, 2, 4, 64, 4, m, 0)) + "E"
     shape = {1: (256, 256, 2, 4), 2: (256, 128, 4, 2), 3: (128, 128, 2, 2), 4: (256, 64, 4, 1), 5: (128, 64, 2, 1)}.get(cfg)
     if shape:
         return f"gemm_tn_kernel<{tn},{','.join(map(str, shape))}>", "gemm_tn_kernelI" + tc + "".join(mi(v) for v in shape) + "E"
