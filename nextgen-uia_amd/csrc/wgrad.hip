@@ -195,9 +195,9 @@ int uia_wgrad_launch(hipStream_t stream, int dtype, int M, int I, int J, const v
     UIA_CHECK_ARG(lda >= I && ldb >= J, "uia_wgrad: leading dimension too small");
     const dim3 grid((I / 64) * (J / 64), (M + SLAB * CHUNK_SLABS - 1) / (SLAB * CHUNK_SLABS));
     const int lds = 4 * 4096 * 4;   // reduction buffer (covers the 32 KiB of slabs)
-    static UiaDevOnce attr_once;
-        UIA_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    UIA_ENSURE_LDS_ATTR(attr_once, wgrad_f32_kernel, lds);
+    static UiaDevOnce once_bf16, once_f32;
+    UIA_ENSURE_LDS_ATTR(once_bf16, wgrad_bf16_kernel, lds);
+    UIA_ENSURE_LDS_ATTR(once_f32, wgrad_f32_kernel, lds);
     if (dtype == UIA_BF16)
         hipLaunchKernelGGL(wgrad_bf16_kernel, grid, dim3(256), lds, stream, M, I, J, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, alpha, dW, dbias);
     else

@@ -340,8 +340,10 @@ def mona_pre_fwd(x, norm_w, norm_b, gamma, gammax, u, eps=1e-5):
 
 def mona_pre_bwd(du, x, dy, norm_w, norm_b, gamma, gammax, dx32, dx_t, g_gamma, g_gammax, g_norm_w, g_norm_b, eps=1e-5):
     D = gamma.numel()
-    check(lib().uia_mona_pre_bwd(_stream(), _code(du.dtype), x.numel() // D, D, _p(du), _p(x), _p(dy), _p(norm_w), _p(norm_b), _p(gamma), _p(gammax),
-                                 eps, _p(dx32), _p(dx_t), _p(g_gamma), _p(g_gammax), _p(g_norm_w), _p(g_norm_b)), "uia_mona_pre_bwd")
+    M = x.numel() // D
+    ws = torch.empty(lib().uia_mona_pre_bwd_workspace_bytes(M, D) // 4, device=x.device, dtype=torch.float32)
+    check(lib().uia_mona_pre_bwd(_stream(), _code(du.dtype), M, D, _p(du), _p(x), _p(dy), _p(norm_w), _p(norm_b), _p(gamma), _p(gammax),
+                                 eps, _p(dx32), _p(dx_t), _p(g_gamma), _p(g_gammax), _p(g_norm_w), _p(g_norm_b), _p(ws)), "uia_mona_pre_bwd")
 
 
 def _spatial_desc(variant, B, h, w, t, params, p_drop, seed, keep_mask):

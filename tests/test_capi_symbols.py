@@ -2,6 +2,7 @@
 covers all of them (no compute calls: there is no GPU here)."""
 import ctypes
 import os
+import sys
 import re
 
 import pytest
@@ -68,3 +69,22 @@ def test_header_is_plain_c(tmp_path):
     src = tmp_path / "t.c"
     src.write_text('#include "uia_hip.h"\nint main(void){ return (int)sizeof(uia_gemm_desc) == 0; }\n')
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-fsyntax-only", str(src)], check=True)
+
+
+@pytest.mark.timeout(900)
+def test_c_abi_error_paths_under_host_asan_ubsan():
+    """SURVEY §5 "sanitizers": the whole library built with HOST AddressSanitizer + UBSan (`make asan`; device code is not instrumented
+    — GPU ASan needs XNACK) and every argument-validation / error path of the C ABI driven on this CPU-only box (tests/asan_driver.py):
+    null descriptors, empty / misaligned / undersized operands, unknown tile configs, communicator misuse, the no-device launch failure.
+    A sanitizer report aborts the child process."""
+    import glob
+    import subprocess
+    csrc = os.path.join(ROOT, "nextgen-uia_amd", "csrc")
+    subprocess.run(["make", "-C", csrc, "-j8", "asan"], check=True, capture_output=True)
+    lib = os.path.join(ROOT, "nextgen-uia_amd", "uia_hip", "libuia_hip_asan.so")
+    rts = sorted(glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so"))
+    assert os.path.exists(lib) and rts, "sanitizer build or runtime missing"
+    env = dict(os.environ, LD_PRELOAD=rts[-1], ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1",
+               HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")                      # error paths only: never touch a GPU even if one is present
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "asan_driver.py"), lib], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "no sanitizer report" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
