@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--unpad-text", action="store_true", help="opt-in: the frozen text tower computes only the valid tokens of each caption "
                     "(identical features, less executed work than the reference's dense 256 positions; not the headline configuration)")
     ap.add_argument("--no-kblock-w", action="store_true", help="A/B knob: keep the GEMM weights row-major (default: K-blocked for the ring kernels)")
+    ap.add_argument("--no-k64-cfg14", action="store_true", help="A/B knob: single-K-step GEMMs on the 256x256 tiles")
     ap.add_argument("--no-tail-split", action="store_true", help="A/B knob: no half-height tiles for the M tail of a launch")
     ap.add_argument("--global-loss", action="store_true", help="opt-in: InfoNCE over the global batch (all-gathered features) instead of "
                     "the reference-equivalent local loss; changes the objective, not the headline configuration")
@@ -135,7 +136,7 @@ def main():
     device = torch.device("cuda", local)
     UF.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
     UF.set_unpad_text(args.unpad_text)
-    ops.KBLOCK_W, ops.TAIL_SPLIT = not args.no_kblock_w, not args.no_tail_split
+    ops.KBLOCK_W, ops.TAIL_SPLIT, ops.K64_CFG14 = not args.no_kblock_w, not args.no_tail_split, not args.no_k64_cfg14
 
     model = create_biomedclip(seed=0)                                # same weights on every rank (random init: no network for checkpoints)
     for p in model.parameters():
@@ -217,7 +218,7 @@ def main():
             return rows
         per_kernel = lambda c, m: (c, m if m in ops._SPECIALISED else ops.EPI_GENERIC)
         by_k, by_k_serial = group(prof, per_kernel), group(prof_serial, per_kernel)
-        fam, fam_serial = group(prof, lambda c, m: c in (8, 12, 13)), group(prof_serial, lambda c, m: c in (8, 12, 13))
+        fam, fam_serial = group(prof, lambda c, m: c in (8, 12, 13, 14)), group(prof_serial, lambda c, m: c in (8, 12, 13, 14))
         dom = max(by_k, key=lambda k: by_k[k][0]) if by_k else None
         roof = None
         if dom is not None:

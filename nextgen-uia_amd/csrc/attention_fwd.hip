@@ -66,6 +66,19 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const UiaAttnParams 
     const int LTk = (klen + 15) >> 4;        // key tiles in use (wave-uniform: depends on the batch row only)
     const int NPk = (LTk + 1) >> 1;
 
+    // ---- this wave's query fragments (tiles wave, wave+4, ...), fetched straight from HBM BEFORE the K/V wait: their latency
+    //      (1-2 us per tile when loaded at the top of each tile's iteration, a third of the workgroup's life) hides under the staging.
+    constexpr int NQT = (LT_MAX + 3) / 4;
+    const int li_q = lane & 15, g_q = lane >> 4;
+    uint4 qa[NQT], qb2[NQT];
+#pragma unroll
+    for (int i = 0; i < NQT; ++i) {
+        const int qt = wave + 4 * i;
+        int qr = 16 * qt + li_q;
+        qr = qr < L ? qr : L - 1;
+        qa[i] = *(const uint4*)(qb + qr * rs + g_q * 16);
+        qb2[i] = *(const uint4*)(qb + qr * rs + (g_q + 4) * 16);
+    }
     // ---- stage K and V (rows past L are clamped to row L-1: finite, and masked / multiplied by 0)
     const int ninstr = (NPk * 32) >> 3;      // 1 KiB wave-instructions per tensor
     for (int q = wave; q < ninstr; q += 4) {
@@ -89,11 +102,12 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const UiaAttnParams 
     const int vrow0 = 4 * g + qq;                       // + 32u + 16hh  (multiples of 16 keep (row>>1)&3)
     const int vsw = (vrow0 >> 1) & 3;
 
-    for (int qt = wave; qt < LT; qt += 4) {
+#pragma unroll
+    for (int qi = 0; qi < NQT; ++qi) {
+        const int qt = wave + 4 * qi;
+        if (qt >= LT) break;
         const int qrow = 16 * qt + li;
-        const int qld = qrow < L ? qrow : L - 1;
-        const uint4 q0 = *(const uint4*)(qb + qld * rs + g * 16);
-        const uint4 q1 = *(const uint4*)(qb + qld * rs + (g + 4) * 16);
+        const uint4 q0 = qa[qi], q1 = qb2[qi];
 
         const int LTq = (p.mask_kind == UIA_MASK_CAUSAL && qt + 1 < LTk) ? qt + 1 : LTk;   // key tiles this query tile can see
         const int NPq = (LTq + 1) >> 1;

@@ -1161,6 +1161,8 @@ int launch_typed(hipStream_t stream, const UiaGemmParams& p, int cfg_in) {
     if (cfg == 0) {
         if (p.N <= 64) cfg = 4;
         else if (p.M <= 2048) cfg = 3;
+        else if (p.K * (int)sizeof(T) <= 128) cfg = 14;   // one K step (Mona project2 / project1-dgrad, K = 64): nothing but prologue + epilogue, HBM-bound:
+                                                          // half-height tiles, two workgroups per CU (70.9 vs 86.6 us and 20.0 vs 26.3 us at M = 50 432)
         else cfg = 8;            // 256x256 ping-pong, 4-deep 64-byte ring, LDS-staged epilogue: best measured on every large shape.
                                  // (cfg 12, the persistent variant, is +2-3.5 % on store-only epilogues in isolation, -15-25 % on the
                                  //  fp32-residual ones, and a net loss inside the two-stream training step: opt-in only.)

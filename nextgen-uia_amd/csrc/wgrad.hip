@@ -102,19 +102,34 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(int M, int I, int J, co
             }
         }
     }
-    // ---- reduce the four waves through LDS, then one atomic per element
+    // ---- reduce the four waves through LDS in two rounds (waves 0,1 store; waves 2,3 add in place), then one atomic per element.
+    //      The reduction buffer overlays the (dead) slabs and is no larger than they are: 32 KiB per workgroup, five workgroups per CU
+    //      (a 64 KiB buffer for all four waves at once capped the kernel at two per CU: 48 us for 84 MB, latency-bound).
     __syncthreads();
-    float* red = (float*)smem;                         // [4 waves][64*64] fp32 = 64 KiB
+    float* red = (float*)smem;                         // [2][64*64] fp32 = 32 KiB
+    float* mine = red + (wave & 1) * 4096;
+    if (wave < 2) {
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+            for (int b = 0; b < 4; ++b)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)                // D[row = i = 16a + 4g + r][col = j = 16b + li]
-                red[wave * 4096 + (16 * a + 4 * g + r) * 64 + 16 * b + li] = acc[a][b][r];
+                for (int r = 0; r < 4; ++r)            // D[row = i = 16a + 4g + r][col = j = 16b + li]
+                    mine[(16 * a + 4 * g + r) * 64 + 16 * b + li] = acc[a][b][r];
+    }
+    __syncthreads();
+    if (wave >= 2) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    mine[(16 * a + 4 * g + r) * 64 + 16 * b + li] += acc[a][b][r];
+    }
     __syncthreads();
     for (int e = tid; e < 4096; e += 256) {
-        const float v = red[e] + red[4096 + e] + red[8192 + e] + red[12288 + e];
+        const float v = red[e] + red[4096 + e];
         atomicAdd(dW + (size_t)(ti * 64 + (e >> 6)) * J + tj * 64 + (e & 63), v * alpha);
     }
     if (dbias && tj == 0) {
@@ -194,12 +209,13 @@ int uia_wgrad_launch(hipStream_t stream, int dtype, int M, int I, int J, const v
     UIA_CHECK_ARG((lda * esz) % 16 == 0 && (ldb * esz) % 16 == 0 && (uintptr_t)A % 16 == 0 && (uintptr_t)B % 16 == 0, "uia_wgrad: alignment");
     UIA_CHECK_ARG(lda >= I && ldb >= J, "uia_wgrad: leading dimension too small");
     const dim3 grid((I / 64) * (J / 64), (M + SLAB * CHUNK_SLABS - 1) / (SLAB * CHUNK_SLABS));
-    const int lds = 4 * 4096 * 4;   // reduction buffer (covers the 32 KiB of slabs)
+    const int lds = 4 * 4096 * 4;   // fp32 path: reduction buffer for four waves at once
+    const int lds_bf16 = 2 * SLAB * 128;   // bf16 path: two 16 KiB slabs, re-used as a two-wave reduction buffer
     static UiaDevOnce once_bf16, once_f32;
-    UIA_ENSURE_LDS_ATTR(once_bf16, wgrad_bf16_kernel, lds);
+    UIA_ENSURE_LDS_ATTR(once_bf16, wgrad_bf16_kernel, lds_bf16);
     UIA_ENSURE_LDS_ATTR(once_f32, wgrad_f32_kernel, lds);
     if (dtype == UIA_BF16)
-        hipLaunchKernelGGL(wgrad_bf16_kernel, grid, dim3(256), lds, stream, M, I, J, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, alpha, dW, dbias);
+        hipLaunchKernelGGL(wgrad_bf16_kernel, grid, dim3(256), lds_bf16, stream, M, I, J, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, alpha, dW, dbias);
     else
         hipLaunchKernelGGL(wgrad_f32_kernel, grid, dim3(256), lds, stream, M, I, J, (const float*)A, lda, (const float*)B, ldb, alpha, dW, dbias);
     UIA_CHECK_LAUNCH();

@@ -40,11 +40,14 @@ def auto_tile_cfg(M, N, K=None, esz=2, mask=EPI_GENERIC):
         return 4
     if M <= 2048:
         return 3
+    if K is not None and K * esz <= 128:
+        return 14
     return 8
 
 
-RING_CFGS = (8, 9, 10, 13)
+RING_CFGS = (8, 9, 10, 13, 14)
 KBLOCK_W = True          # hand the ring kernels their weights K-blocked (PackedW.kblocked()); False = row-major everywhere
+K64_CFG14 = True         # single-K-step GEMMs on the two-workgroups-per-CU half-height config (False: 256x256 like every other large shape)
 TAIL_SPLIT = True        # split off the M tail of a launch whose last round of 256x256 tiles would leave most CUs idle
 _NCU = {}
 
@@ -106,9 +109,9 @@ def gemm_kernel_name(cfg, mask, dtype):
     mi = lambda v: f"Li{v}E" if v >= 0 else f"Lin{-v}E"
     if cfg == 12:
         return f"gemm_tn_persist_kernel<{tn},{m}>", f"gemm_tn_persist_kernelI{tc}{mi(m)}E"
-    if cfg in (8, 13):
-        bm = 256 if cfg == 8 else 128
-        return f"gemm_tn_ring_kernel<{tn},{bm},256,2,4,64,4,{m}>", "gemm_tn_ring_kernelI" + tc + "".join(mi(v) for v in (bm, 256, 2, 4, 64, 4, m, 0)) + "E"
+    if cfg in (8, 13, 14):
+        bm, nbuf = (256, 4) if cfg == 8 else ((128, 4) if cfg == 13 else (128, 3))
+        return f"gemm_tn_ring_kernel<{tn},{bm},256,2,4,64,{nbuf},{m}>", "gemm_tn_ring_kernelI" + tc + "".join(mi(v) for v in (bm, 256, 2, 4, 64, nbuf, m, 0)) + "E"
     shape = {1: (256, 256, 2, 4), 2: (256, 128, 4, 2), 3: (128, 128, 2, 2), 4: (256, 64, 4, 1), 5: (128, 64, 2, 1)}.get(cfg)
     if shape:
         return f"gemm_tn_kernel<{tn},{','.join(map(str, shape))}>", "gemm_tn_kernelI" + tc + "".join(mi(v) for v in shape) + "E"
@@ -153,7 +156,9 @@ def gemm(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None, res
     packed = w if isinstance(w, PackedW) else None
     wrow = packed.row if packed is not None else w
     M, N = a.shape[0], wrow.shape[0]
-    if (TAIL_SPLIT and tile_cfg == 0 and out_group == 0 and resid_mod == 0 and a.is_cuda and auto_tile_cfg(M, N) == 8):
+    if not K64_CFG14 and tile_cfg == 0 and auto_tile_cfg(M, N, a.shape[1], a.element_size()) == 14:
+        tile_cfg = 8
+    if (TAIL_SPLIT and tile_cfg == 0 and out_group == 0 and resid_mod == 0 and a.is_cuda and auto_tile_cfg(M, N, a.shape[1], a.element_size()) == 8):
         m_main = tail_split_rows(M, N, num_cus(a.device.index))
         if m_main < M:
             cut = lambda t, lo, hi: None if t is None else t[lo:hi]
@@ -176,7 +181,7 @@ def _gemm_one(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None
         raise UiaError(f"gemm operand mismatch: a {tuple(a.shape)} {a.dtype}, w {tuple(w.shape)} {w.dtype}")
     d.A, d.W = _p(a), _p(w)
     d.M, d.K, d.N = a.shape[0], a.shape[1], w.shape[0]
-    base_cfg = (tile_cfg & 255) or auto_tile_cfg(d.M, d.N)
+    base_cfg = (tile_cfg & 255) or auto_tile_cfg(d.M, d.N, d.K, a.element_size())
     if packed is not None and KBLOCK_W and base_cfg in RING_CFGS and a.is_cuda:
         d.W, d.w_kblocked = _p(packed.kblocked()), 1
     d.alpha = alpha
