@@ -95,25 +95,21 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void attn_bwd_bf16_kernel(const Uia
         vf[a][0] = *(const uint4*)(vb + r * rs + g * 16);
         vf[a][1] = *(const uint4*)(vb + r * rs + (g + 4) * 16);
     }
-    // δ·scale and lse (plain loads, independent of the LDS image); dSᵀ rows of the key tiles nobody owns are zeroed once
+    // δ·scale and lse.  Two threads per query row: each fetches its 64-byte half of the O row NOW (four 16-byte loads that fly
+    // under the staging wait) and, once the dO image is resident, reads the matching half of the dO row from LDS: the first version
+    // had 224 of the 512 threads read both 128-byte rows from HBM after each other (33 us of the 328 us kernel, tools/abwd_variants.sh).
     const float sc = p.scale * 1.44269504088896341f;
-    for (int r = tid; r < LPK; r += 64 * BWD_WAVES) {
-        float d = 0.f, l2 = 0.f;
-        if (r < L) {
-            const bf16_t* go = (const bf16_t*)(gb + r * rso);
-            const bf16_t* oo = (const bf16_t*)(ob + (size_t)r * p.ldo * 2);
+    const int drow = tid >> 1, dhalf = tid & 1;           // rows drow and drow + 256 (L up to 288)
+    uint4 ov[2][4];
 #pragma unroll
-            for (int c = 0; c < 64; c += 8) {
-                float x[8], y[8];
-                load8(go + c, x);
-                load8(oo + c, y);
+    for (int rr = 0; rr < 2; ++rr) {
+        int r = drow + 256 * rr;
+        r = r < L ? r : L - 1;
+        const char* oo = ob + (size_t)r * p.ldo * 2 + dhalf * 64;
+        if (rr == 0 || LPK > 256) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) d = fmaf(x[e], y[e], d);
-            }
-            l2 = p.lse[((size_t)b * p.H + h) * L + r] * 1.44269504088896341f;
+            for (int c = 0; c < 4; ++c) ov[rr][c] = *(const uint4*)(oo + 16 * c);
         }
-        dls[r] = d * p.scale;
-        lse2[r] = l2;
     }
     for (int i = tid; i < (LPK - 16 * LT) * 4; i += 64 * BWD_WAVES) {
         *(uint4*)(dST0 + 16 * LT * 64 + i * 16) = uint4{0u, 0u, 0u, 0u};
@@ -121,7 +117,35 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void attn_bwd_bf16_kernel(const Uia
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int row = drow + 256 * rr;
+        if (row < LPK) {                                   // (wave-uniform for rr == 1: LPK - 256 is a multiple of 32 rows = one wave)
+            float d = 0.f;
+#ifndef ABWD_NO_DELTA
+            if (row < L) {
+                const int sw = (row >> 1) & 7;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const uint4 gv = *(const uint4*)(Gs + row * 128 + (((4 * dhalf + c) ^ sw) << 4));
+                    const bf16x8 gx = __builtin_bit_cast(bf16x8, gv), ox = __builtin_bit_cast(bf16x8, ov[rr][c]);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) d = fmaf((float)gx[e], (float)ox[e], d);
+                }
+            }
+#endif
+            d += __shfl_xor(d, 1, 64);
+            if (dhalf == 0) {
+                dls[row] = d * p.scale;
+                lse2[row] = row < L ? p.lse[((size_t)b * p.H + h) * L + row] * 1.44269504088896341f : 0.f;
+            }
+        }
+    }
+    __syncthreads();
 
+#ifdef ABWD_PROLOGUE_ONLY
+    if (p.L > 0) return;                                  // diagnostic: how long does staging alone take?
+#endif
     int klen = L;
     if (p.mask_kind == UIA_MASK_KEYPAD && p.keylen) { klen = p.keylen[b]; klen = klen < 1 ? 1 : (klen > L ? L : klen); }
 
@@ -256,16 +280,22 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void attn_bwd_bf16_kernel(const Uia
         if (false) {
 #endif
             const int hq = wave >> 2, dt = wave & 3;
-            f32x4 dq = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 dq = f32x4{0.f, 0.f, 0.f, 0.f}, dq1 = f32x4{0.f, 0.f, 0.f, 0.f};   // two chains: the 7-9 MFMAs no longer wait on each other
             const int ch = 2 * dt + (pp >> 1);
             const int c8 = 4 * hq + pp;
-            for (int kbk = 0; kbk < NP; ++kbk) {
+            auto dq_step = [&](int kbk, f32x4 accq) {
                 const char* klo = Ks + (32 * kbk + nrow) * 128 + ((ch ^ nsw_lo) << 4) + 8 * (pp & 1);
                 const char* khi = Ks + (32 * kbk + nrow + 4) * 128 + ((ch ^ nsw_hi) << 4) + 8 * (pp & 1);
                 const char* slo = dSTr + (32 * kbk + nrow) * 64 + ((c8 ^ nsw_lo) << 3);
                 const char* shi = dSTr + (32 * kbk + nrow + 4) * 64 + ((c8 ^ nsw_hi) << 3);
-                dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_pair(klo, khi), tr_pair(slo, shi), dq, 0, 0, 0);
+                return __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_pair(klo, khi), tr_pair(slo, shi), accq, 0, 0, 0);
+            };
+#pragma unroll 1
+            for (int kbk = 0; kbk < NP; kbk += 2) {
+                dq = dq_step(kbk, dq);
+                if (kbk + 1 < NP) dq1 = dq_step(kbk + 1, dq1);
             }
+            dq += dq1;
             const int qrow = 32 * (u - 1) + 16 * hq + li;
             if (qrow < L) {
                 bf16_t* drow = (bf16_t*)p.dq + (row0 + qrow) * p.ld_dqkv + (size_t)h * 64 + 4 * g;
