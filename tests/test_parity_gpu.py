@@ -691,8 +691,11 @@ def test_global_batch_loss_with_one_rank_equals_local_loss():
         images, ids = toy_batch(torch.Generator().manual_seed(4))
         loss = contrastive_step(model, InfoNCELoss(0.07), opt, images.to(dev()), ids.to(dev()), overlap_text=False, global_loss=flag)
         outs.append((float(loss), opt.p.clone()))
-    # float atomics in the loss / weight-gradient reductions make two runs differ in the last bits
-    assert abs(outs[0][0] - outs[1][0]) < 1e-6 * abs(outs[0][0]) and torch.allclose(outs[0][1], outs[1][1], rtol=1e-5, atol=1e-7)
+    # float atomics in the loss / weight-gradient reductions make two runs differ in the last bits of the GRADIENT; Adam's first step is
+    # lr * g / (|g| + 1e-8), so an element whose gradient is itself ~1e-8 can land anywhere within +-lr: compare the update in units of lr
+    assert abs(outs[0][0] - outs[1][0]) < 1e-6 * abs(outs[0][0])
+    diff = (outs[0][1] - outs[1][1]).abs()
+    assert float(diff.mean()) < 0.01 * 1e-3 and float((diff > 0.1 * 1e-3).float().mean()) < 0.01, (float(diff.max()), float(diff.mean()))
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])

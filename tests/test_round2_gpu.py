@@ -146,9 +146,11 @@ def test_mona_gradients_do_not_depend_on_the_flat_optimiser_idiom():
             opt.all_reduce()
             opt.step()                                                   # folds the foreign .grad tensors back into the flat buffer first
             assert opt.grad_views_intact() and not torch.equal(before, opt.p)
-            assert torch.allclose(torch.cat([v.flatten() for v in opt.unflatten(opt.g).values()]).cpu(), runs[how], rtol=1e-5, atol=1e-8)
+            assert torch.equal(torch.cat([v.flatten() for v in opt.unflatten(opt.g).values()]).cpu(), runs[how])
+    scale = float(runs["direct"].abs().max())
     for how in ("dropped_views", "plain_autograd", "autograd_grad"):
-        assert torch.allclose(runs[how], runs["direct"], rtol=2e-5, atol=1e-7), how     # float atomics: last bits differ between runs
+        # float atomics: two runs differ in the last bits (relative to the sums that cancel, not to each element)
+        assert float((runs[how] - runs["direct"]).abs().max()) < 1e-4 * scale, how
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
