@@ -113,11 +113,25 @@ def lib():
             raise UiaError(f"{LIB_PATH} not built: run `make -C nextgen-uia_amd/csrc` (hipcc --offload-arch=gfx950). "
                            "There is no CPU fallback for the uia hot path.")
         handle = C.CDLL(LIB_PATH)
+        _one_copy_of("librccl")                  # the library's RCCL must be the one PyTorch loaded (same SONAME: the loader re-uses it
+        _one_copy_of("libamdhip64")              # when torch is imported first); two runtimes in one process would not share state
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(handle, name)
             fn.restype, fn.argtypes = res, args
         _lib = handle
     return _lib
+
+
+def _one_copy_of(stem):
+    """Fail loudly if two different files of a runtime library are mapped into this process (e.g. /opt/rocm/lib/librccl.so beside
+    torch/lib/librccl.so): collectives or streams created through one copy are invisible to the other."""
+    try:
+        paths = {line.split()[-1] for line in open("/proc/self/maps") if stem in line and ".so" in line}
+    except OSError:
+        return
+    real = {os.path.realpath(p) for p in paths}
+    if len(real) > 1:
+        raise UiaError(f"two copies of {stem} are loaded ({sorted(real)}): import torch before uia_hip so that libuia_hip.so binds to PyTorch's runtime")
 
 
 def check(rc, what=""):
