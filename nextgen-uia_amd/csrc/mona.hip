@@ -564,8 +564,11 @@ __global__ __launch_bounds__(512) void mona_spatial_kernel(const uia_mona_spatia
 //     (v_mfma_f32_16x16x32_bf16, operands converted from the fp32 LDS tiles on the way into the registers).
 //     c and dz tiles use a row stride of 68 floats so that row-per-lane fragment reads are conflict-free.
 constexpr int FLD = 68;
+constexpr int FAST_RED = 4 * 64 * 51;                          // four [64 channels][49 taps + Σdc, stride 51] reduction images
+constexpr int KW_FLOATS = 64 * (9 + 25 + 49);                  // stencil-weight staging area (forward: its own; backward: inside the dz tile)
 __host__ __device__ constexpr size_t spatial_fast_lds(int hw, bool bwd) {
-    return ((size_t)(hw + 1) * BOTT + (size_t)((hw * FLD > RED_FLOATS) ? hw * FLD : RED_FLOATS) + (bwd ? (size_t)(hw + 1) * FLD : 0) + SCR_SIZE) * sizeof(float);
+    return ((size_t)(hw + 1) * BOTT + (size_t)((hw * FLD > FAST_RED) ? hw * FLD : FAST_RED) +
+            (bwd ? (size_t)(((hw + 1) * FLD > KW_FLOATS) ? (hw + 1) * FLD : KW_FLOATS) : (size_t)KW_FLOATS) + SCR_SIZE) * sizeof(float);
 }
 __device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
     bf16x8 r = {(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3], (bf16_t)b[0], (bf16_t)b[1], (bf16_t)b[2], (bf16_t)b[3]};
@@ -598,9 +601,9 @@ __global__ __launch_bounds__(512) void mona_spatial_fast_kernel(const uia_mona_s
     const int h = p.h, hw = h * W, ntok = hw + 1;
     float* tS = (float*)smem;                                   // [ntok][64]      t (token 0 = CLS)
     float* cS = tS + ntok * BOTT;                               // [hw][FLD]       c = conv + identity  (later: reduction scratch)
-    const int cs_floats = (hw * FLD > RED_FLOATS) ? hw * FLD : RED_FLOATS;
+    const int cs_floats = (hw * FLD > FAST_RED) ? hw * FLD : FAST_RED;
     float* gS = cS + cs_floats;                                 // [ntok][FLD]     dz, then dc (backward only)
-    float* scr = BWD ? gS + ntok * FLD : cS + cs_floats;
+    float* scr = BWD ? gS + ((ntok * FLD > KW_FLOATS) ? ntok * FLD : KW_FLOATS) : cS + cs_floats;
     const int tid = threadIdx.x, lane = tid & 63, c = lane, grp = tid >> 6;
     const int li = lane & 15, g = lane >> 4;
     const int b = blockIdx.x;
@@ -610,8 +613,18 @@ __global__ __launch_bounds__(512) void mona_spatial_fast_kernel(const uia_mona_s
     const size_t tok0 = (size_t)b * ntok;
     float* wsrow = (BWD && p.ws) ? p.ws + (size_t)b * WS_ROW : nullptr;
 
+    // stencil weights: coalesced 16-byte loads into LDS, then each lane picks its channel's 9 + 25 + 49 taps (odd strides: conflict-free).
+    // (Per-lane global loads at a 36 / 100 / 196-byte lane stride touched 64 cache lines per instruction, 83 times.)
+    float* wst = BWD ? gS : scr + SCR_SIZE;                     // backward: the dz tile is not written before the projector phase
+    for (int i = tid; i < KW_FLOATS / 4; i += 512) {
+        const float* src = i < 144 ? p.conv1_w + 4 * i : (i < 544 ? p.conv2_w + 4 * (i - 144) : p.conv3_w + 4 * (i - 544));
+        *(f32x4*)(wst + 4 * i) = load4(src);
+    }
     load_tokens((const T*)p.t + tok0 * BOTT, tS, ntok, tid);
     __syncthreads();
+#if defined(MSB_STOP) && MSB_STOP == 0
+    if (BWD && p.B > 0) return;             // diagnostic (tools/msb_variants.sh): time up to here
+#endif
     const float f = has_freq ? p.freq[c] : 1.0f;
     float w1 = 1.f / 3.f, w2 = 1.f / 3.f, w3 = 1.f / 3.f;
     if (has_noise) {
@@ -622,11 +635,11 @@ __global__ __launch_bounds__(512) void mona_spatial_fast_kernel(const uia_mona_s
     {
         float k1[9], k2[25], k3[49];
 #pragma unroll
-        for (int i = 0; i < 9; ++i) k1[i] = p.conv1_w[c * 9 + i];
+        for (int i = 0; i < 9; ++i) k1[i] = wst[c * 9 + i];
 #pragma unroll
-        for (int i = 0; i < 25; ++i) k2[i] = p.conv2_w[c * 25 + i];
+        for (int i = 0; i < 25; ++i) k2[i] = wst[576 + c * 25 + i];
 #pragma unroll
-        for (int i = 0; i < 49; ++i) k3[i] = p.conv3_w[c * 49 + i];
+        for (int i = 0; i < 49; ++i) k3[i] = wst[2176 + c * 49 + i];
 #pragma unroll
         for (int i = 0; i < 7; ++i)
 #pragma unroll
@@ -634,6 +647,9 @@ __global__ __launch_bounds__(512) void mona_spatial_fast_kernel(const uia_mona_s
     }
     const float b1 = p.conv1_b[c], b2 = p.conv2_b[c], b3 = p.conv3_b[c];
     const float bm = w1 * b1 + w2 * b2 + w3 * b3;
+#if defined(MSB_STOP) && MSB_STOP == 1
+    if (BWD && p.B > 0) return;             // diagnostic (tools/msb_variants.sh): time up to here
+#endif
     // ---- c[px][ch] = f·(K ⋆ t) + Σ w_k b_k + t
     for (int y = grp; y < h; y += NGRP) {
         float acc[W];
@@ -645,6 +661,9 @@ __global__ __launch_bounds__(512) void mona_spatial_fast_kernel(const uia_mona_s
     }
     __syncthreads();
 
+#if defined(MSB_STOP) && MSB_STOP == 2
+    if (BWD && p.B > 0) return;             // diagnostic (tools/msb_variants.sh): time up to here
+#endif
     // ---- projector on the matrix cores: z[px][co] = c[px][co] + Σ_ci c[px][ci]·P[co][ci] + pb[co]
     const float inv_keep = p.p_drop > 0.f ? 1.0f / (1.0f - p.p_drop) : 1.0f;
     const uint32_t thresh = p.p_drop > 0.f ? (uint32_t)fminf(p.p_drop * 4294967296.0f, 4294967295.0f) : 0u;
@@ -702,6 +721,9 @@ __global__ __launch_bounds__(512) void mona_spatial_fast_kernel(const uia_mona_s
     }
     if (!BWD) return;
 
+#if defined(MSB_STOP) && MSB_STOP == 3
+    if (BWD && p.B > 0) return;             // diagnostic (tools/msb_variants.sh): time up to here
+#endif
     // ======================================================================== backward
     __syncthreads();
     // ---- dP[co][ci] = Σ_px dz[px][co]·c[px][ci] on the matrix cores (k = pixels, zero beyond hw); db_p[co] = Σ_px dz[px][co]
@@ -727,13 +749,16 @@ __global__ __launch_bounds__(512) void mona_spatial_fast_kernel(const uia_mona_s
         for (int q = 0; q < 2; ++q)
 #pragma unroll
             for (int r = 0; r < 4; ++r) grad_out(wsrow, WS_PROJ_W, p.g_proj_w, (16 * mt + 4 * g + r) * 64 + 16 * (nt0 + q) + li, acc[q][r]);
-        if (tid < 64) {
+        {   // partial of db_p over this wave's share of the pixels (summed in the output phase below)
             float sb = 0.f;
-            for (int px = 0; px < hw; ++px) sb += gS[(1 + px) * FLD + tid];
-            grad_out(wsrow, WS_PROJ_B, p.g_proj_b, tid, sb);
+            for (int px = grp; px < hw; px += NGRP) sb += gS[(1 + px) * FLD + c];
+            scr[SCR_PART + grp * 64 + c] = sb;
         }
     }
     __syncthreads();
+#if defined(MSB_STOP) && MSB_STOP == 4
+    if (BWD && p.B > 0) return;             // diagnostic (tools/msb_variants.sh): time up to here
+#endif
     // ---- dc = dz + dz·P, in place (the rows of an m-tile belong to one wave)
     {
         bf16x8 pt[4][2];                                        // B fragments: k = co = 32kk + 8g + e, n = ci = 16nt + li  →  P[co][ci]
@@ -769,6 +794,9 @@ __global__ __launch_bounds__(512) void mona_spatial_fast_kernel(const uia_mona_s
         }
     }
     __syncthreads();
+#if defined(MSB_STOP) && MSB_STOP == 5
+    if (BWD && p.B > 0) return;             // diagnostic (tools/msb_variants.sh): time up to here
+#endif
     // ---- pass A: stencil weight gradients dK[i][j] = Σ_px dc[px]·t[px + off]  (and the mixing-weight gradients of the noise variants)
     float dkm[49];
 #pragma unroll
@@ -811,30 +839,56 @@ __global__ __launch_bounds__(512) void mona_spatial_fast_kernel(const uia_mona_s
         dwm2 = fmaf(f, s2, b2 * sdc);
         dwm3 = fmaf(f, s3, b3 * sdc);
     }
-    // reduce over the waves with LDS atomics into [64][50] (the c tile is free now)
+#if defined(MSB_STOP) && MSB_STOP == 6
+    if (BWD && p.B > 0) return;             // diagnostic (tools/msb_variants.sh): time up to here
+#endif
+    // reduce over the eight waves through the (now free) c tile: waves 4-7 park their partials, waves 0-3 add their own on top, and the
+    // output phase sums the four [64][51] images.  (LDS float atomics from 8 waves onto the same 3200 addresses took 37 us here.)
     float* red = cS;
-    for (int i = tid; i < RED_FLOATS; i += 512) red[i] = 0.f;
-    __syncthreads();
+    constexpr int RST = 51, RW = 64 * RST;
+    if (grp >= 4) {
+        float* dst = red + (grp - 4) * RW + c * RST;
 #pragma unroll
-    for (int i = 0; i < 49; ++i) atomicAdd(red + c * 50 + i, dkm[i]);
-    atomicAdd(red + c * 50 + 49, sdc);
-    __syncthreads();
-    if (grp == 0) {
-#pragma unroll
-        for (int i = 0; i < 49; ++i) dkm[i] = f * red[c * 50 + i];      // Σ dc·xf[nbr]
-        sdc = red[c * 50 + 49];
-#pragma unroll
-        for (int i = 0; i < 7; ++i)
-#pragma unroll
-            for (int j = 0; j < 7; ++j) {
-                grad_out(wsrow, WS_C3W, p.g_conv3_w, c * 49 + i * 7 + j, w3 * dkm[i * 7 + j]);
-                if (i >= 1 && i <= 5 && j >= 1 && j <= 5) grad_out(wsrow, WS_C2W, p.g_conv2_w, c * 25 + (i - 1) * 5 + (j - 1), w2 * dkm[i * 7 + j]);
-                if (i >= 2 && i <= 4 && j >= 2 && j <= 4) grad_out(wsrow, WS_C1W, p.g_conv1_w, c * 9 + (i - 2) * 3 + (j - 2), w1 * dkm[i * 7 + j]);
-            }
-        grad_out(wsrow, WS_C1B, p.g_conv1_b, c, w1 * sdc);
-        grad_out(wsrow, WS_C2B, p.g_conv2_b, c, w2 * sdc);
-        grad_out(wsrow, WS_C3B, p.g_conv3_b, c, w3 * sdc);
+        for (int i = 0; i < 49; ++i) dst[i] = dkm[i];
+        dst[49] = sdc;
     }
+    __syncthreads();
+    if (grp < 4) {
+        float* dst = red + grp * RW + c * RST;
+#pragma unroll
+        for (int i = 0; i < 49; ++i) dst[i] += dkm[i];
+        dst[49] += sdc;
+    }
+    __syncthreads();
+    auto red4 = [&](int ch, int k) { const float* r = red + ch * RST + k; return (r[0] + r[RW]) + (r[2 * RW] + r[3 * RW]); };
+    // All 512 threads write the per-image partials in the order of the parameter tensors (consecutive lanes → consecutive floats).
+    // The first version had wave 0 write 86 values per lane at a 196-byte lane stride: 42 of the kernel's 82 us (tools/msb_variants.sh).
+    for (int i = tid; i < 64 * 49; i += 512) {
+        const int ch = i / 49, k = i - 49 * ch;
+        grad_out(wsrow, WS_C3W, p.g_conv3_w, i, w3 * (has_freq ? p.freq[ch] : 1.0f) * red4(ch, k));      // f·Σ dc·t[nbr]
+    }
+    for (int i = tid; i < 64 * 25; i += 512) {
+        const int ch = i / 25, k = i - 25 * ch, ki = k / 5, kj = k - 5 * ki;
+        grad_out(wsrow, WS_C2W, p.g_conv2_w, i, w2 * (has_freq ? p.freq[ch] : 1.0f) * red4(ch, (ki + 1) * 7 + kj + 1));
+    }
+    for (int i = tid; i < 64 * 9; i += 512) {
+        const int ch = i / 9, k = i - 9 * ch, ki = k / 3, kj = k - 3 * ki;
+        grad_out(wsrow, WS_C1W, p.g_conv1_w, i, w1 * (has_freq ? p.freq[ch] : 1.0f) * red4(ch, (ki + 2) * 7 + kj + 2));
+    }
+    if (tid < 64) {
+        const float sd = red4(tid, 49);
+        grad_out(wsrow, WS_C1B, p.g_conv1_b, tid, w1 * sd);
+        grad_out(wsrow, WS_C2B, p.g_conv2_b, tid, w2 * sd);
+        grad_out(wsrow, WS_C3B, p.g_conv3_b, tid, w3 * sd);
+    } else if (tid < 128) {                                   // db_p[co] = Σ_px dz[px][co]: the eight per-wave partials of the dz phase
+        float sb = 0.f;
+#pragma unroll
+        for (int q = 0; q < NGRP; ++q) sb += scr[SCR_PART + q * 64 + tid - 64];
+        grad_out(wsrow, WS_PROJ_B, p.g_proj_b, tid - 64, sb);
+    }
+#if defined(MSB_STOP) && MSB_STOP == 7
+    if (BWD && p.B > 0) return;             // diagnostic (tools/msb_variants.sh): time up to here
+#endif
     float dpool_c = 0.f;
     if (has_noise) {
         __syncthreads();
@@ -870,6 +924,9 @@ __global__ __launch_bounds__(512) void mona_spatial_fast_kernel(const uia_mona_s
         __syncthreads();
         dpool_c = scr[SCR_DPOOL + c];
     }
+#if defined(MSB_STOP) && MSB_STOP == 8
+    if (BWD && p.B > 0) return;             // diagnostic (tools/msb_variants.sh): time up to here
+#endif
     // ---- pass B: dxf = Kᵀ ⋆ dc (+ pool path);  dt = dc + f·dxf;  df = Σ dxf·t
     float dfc = 0.f;
     T* dt = (T*)p.dt;
@@ -887,6 +944,9 @@ __global__ __launch_bounds__(512) void mona_spatial_fast_kernel(const uia_mona_s
         }
     }
     if (grp == NGRP - 1) dt[tok0 * BOTT + c] = (T)gS[c];
+#if defined(MSB_STOP) && MSB_STOP == 9
+    if (BWD && p.B > 0) return;             // diagnostic (tools/msb_variants.sh): time up to here
+#endif
     if (has_freq) {
         __syncthreads();
         scr[SCR_PART + grp * 64 + c] = dfc;
@@ -901,26 +961,30 @@ __global__ __launch_bounds__(512) void mona_spatial_fast_kernel(const uia_mona_s
 }
 
 // g[param][i] += Σ_b ws[b][off + i]   (fixed summation order: deterministic, no atomics)
-// 64 columns per block × 4 image phases: every phase walks its images with 8 independent loads in flight.
-__global__ __launch_bounds__(256) void mona_ws_reduce_kernel(int B, const float* __restrict__ ws, uia_mona_spatial_desc p, int has_freq, int has_noise) {
-    __shared__ float part[4][64];
+// 64 columns per block × 16 image phases: every phase walks its images with 4 independent loads in flight (16 loads per thread at
+// B = 256; the four-phase version had 64 dependent-issue loads per thread and took 17 us for 11 MB).
+constexpr int WSR_PH = 16;
+__global__ __launch_bounds__(64 * WSR_PH) void mona_ws_reduce_kernel(int B, const float* __restrict__ ws, uia_mona_spatial_desc p, int has_freq, int has_noise) {
+    __shared__ float part[WSR_PH][64];
     const int cx = threadIdx.x & 63, ph = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + cx;
     float s = 0.f;
     if (col < WS_ROW) {
-        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
         int b = ph;
-        for (; b + 28 < B; b += 32) {
+        for (; b + 3 * WSR_PH < B; b += 4 * WSR_PH) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) a[k] += ws[(size_t)(b + 4 * k) * WS_ROW + col];
+            for (int k = 0; k < 4; ++k) a[k] += ws[(size_t)(b + WSR_PH * k) * WS_ROW + col];
         }
-        for (; b < B; b += 4) a[0] += ws[(size_t)b * WS_ROW + col];
-        s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+        for (; b < B; b += WSR_PH) a[0] += ws[(size_t)b * WS_ROW + col];
+        s = (a[0] + a[1]) + (a[2] + a[3]);
     }
     part[ph][cx] = s;
     __syncthreads();
     if (ph != 0 || col >= WS_ROW) return;
-    s = (part[0][cx] + part[1][cx]) + (part[2][cx] + part[3][cx]);
+    s = 0.f;
+#pragma unroll
+    for (int q = 0; q < WSR_PH; q += 4) s += (part[q][cx] + part[q + 1][cx]) + (part[q + 2][cx] + part[q + 3][cx]);
     float* dst = nullptr;
     int idx = 0;
     if (col < WS_PROJ_B) { dst = p.g_proj_w; idx = col - WS_PROJ_W; }
@@ -976,7 +1040,8 @@ int launch_spatial(hipStream_t stream, const uia_mona_spatial_desc& p) {
     if (BWD && p.ws) {
         const bool has_freq = p.variant == UIA_MONA_FREQ_ENHANCED || p.variant == UIA_MONA_HYBRID;
         const bool has_noise = p.variant == UIA_MONA_NOISE_AWARE || p.variant == UIA_MONA_HYBRID;
-        hipLaunchKernelGGL(mona_ws_reduce_kernel, dim3((WS_ROW + 63) / 64), dim3(256), 0, stream, p.B, p.ws, p, (int)has_freq, (int)has_noise);
+        const int cols = has_noise ? WS_ROW : (has_freq ? WS_NE1W : WS_FREQ);     // the noise-estimator / frequency columns only where the variant has them
+        hipLaunchKernelGGL(mona_ws_reduce_kernel, dim3((cols + 63) / 64), dim3(64 * WSR_PH), 0, stream, p.B, p.ws, p, (int)has_freq, (int)has_noise);
     }
     UIA_CHECK_LAUNCH();
     return 0;
@@ -993,6 +1058,8 @@ int check_spatial(const uia_mona_spatial_desc& p, bool bwd) {
     UIA_CHECK_ARG(!has_freq || p.freq, "uia_mona_spatial: variant needs freq_filter");
     UIA_CHECK_ARG(!has_noise || (p.ne1_w && p.ne1_b && p.ne3_w && p.ne3_b), "uia_mona_spatial: variant needs noise_estimator parameters");
     UIA_CHECK_ARG(p.p_drop >= 0.f && p.p_drop < 1.f, "uia_mona_spatial: p_drop %f", p.p_drop);
+    UIA_CHECK_ARG((((uintptr_t)p.conv1_w | (uintptr_t)p.conv2_w | (uintptr_t)p.conv3_w | (uintptr_t)p.proj_w) & 15) == 0,
+                  "uia_mona_spatial: conv / projector weights must be 16-byte aligned");
     if (!bwd) { UIA_CHECK_ARG(p.d, "uia_mona_spatial_fwd: null output"); }
     else {
         UIA_CHECK_ARG(p.dd && p.dt && p.g_conv1_w && p.g_conv1_b && p.g_conv2_w && p.g_conv2_b && p.g_conv3_w && p.g_conv3_b && p.g_proj_w && p.g_proj_b,
