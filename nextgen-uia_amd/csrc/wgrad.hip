@@ -30,7 +30,10 @@ __device__ __forceinline__ s16x4 lds_tr16(const char* p) {
 }
 
 constexpr int SLAB = 128;            // rows per LDS slab (32 per wave)
-constexpr int CHUNK_SLABS = 4;       // slabs per workgroup → 512 rows per chunk
+#ifndef WG_CHUNK_SLABS
+#define WG_CHUNK_SLABS 4
+#endif
+constexpr int CHUNK_SLABS = WG_CHUNK_SLABS;       // slabs per workgroup → 512 rows per chunk
 
 // ---- bf16: slabs are [128][128 B] images, 32-B column groups swizzled by (row>>1)&3
 __global__ __launch_bounds__(256) void wgrad_bf16_kernel(int M, int I, int J, const bf16_t* __restrict__ A, long lda,
@@ -50,7 +53,9 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(int M, int I, int J, co
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float bsum = 0.f;
+    const bool want_bias = dbias != nullptr && tj == 0;
+    f32x4 bacc[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    const bf16x8 ones = {(bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f};
 
     const int trow = 32 * wave + 4 * g + qq;          // lo rows; hi rows = +16
     const int tsw = (trow >> 1) & 3;                  // (+16 keeps (row>>1)&3)
@@ -92,14 +97,10 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(int M, int I, int J, co
         for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
-        if (dbias && tj == 0) {   // column sums of A: thread = (column tid&63, row quarter tid>>6)
-            const int col = tid & 63, r0 = 32 * (tid >> 6);
-            for (int r = r0; r < r0 + 32; ++r) {
-                if (m0 + r < M) {
-                    const int ch = (col >> 3) ^ (((r >> 1) & 3) << 1);
-                    bsum += (float)*(const bf16_t*)(As + r * 128 + ch * 16 + (col & 7) * 2);
-                }
-            }
+        if (want_bias) {          // column sums of A = Aᵀ·1 on the matrix cores: four more MFMAs per slab (the first version read the slab
+                                  // back with 32 two-byte LDS loads per thread: 17 of the 51 us at I = 768, tools/wgrad_variants.sh)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) bacc[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], ones, bacc[a], 0, 0, 0);
         }
     }
     // ---- reduce the four waves through LDS in two rounds (waves 0,1 store; waves 2,3 add in place), then one atomic per element.
@@ -128,15 +129,22 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(int M, int I, int J, co
                     mine[(16 * a + 4 * g + r) * 64 + 16 * b + li] += acc[a][b][r];
     }
     __syncthreads();
+#ifndef WG_NO_ATOMIC
     for (int e = tid; e < 4096; e += 256) {
         const float v = red[e] + red[4096 + e];
         atomicAdd(dW + (size_t)(ti * 64 + (e >> 6)) * J + tj * 64 + (e & 63), v * alpha);
     }
-    if (dbias && tj == 0) {
+#endif
+    if (want_bias) {              // every column of bacc[a] holds Σ_m A[m][16a + 4g + r]: column 0 of each wave → LDS → one atomic per element
         __syncthreads();
-        red[tid] = bsum;
+        if (li == 0) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[wave * 64 + 16 * a + 4 * g + r] = bacc[a][r];
+        }
         __syncthreads();
-        if (tid < 64) atomicAdd(dbias + ti * 64 + tid, red[tid] + red[64 + tid] + red[128 + tid] + red[192 + tid]);
+        if (tid < 64) atomicAdd(dbias + ti * 64 + tid, (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]));
     }
 }
 
