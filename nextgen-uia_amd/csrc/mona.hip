@@ -72,148 +72,171 @@ __global__ __launch_bounds__(256) void mona_pre_fwd_kernel(int M, int D, const f
     }
 }
 
-// rows are dealt to waves in a grid-stride loop so that every wave keeps per-column partial sums of
-// the four parameter gradients in registers; one LDS reduction + one atomic per column per block.
-// NV = float4 per lane (D ≤ 256·NV): the common D = 768 runs with NV = 3 and ~3 waves/SIMD.
+// rows are dealt to waves in a grid-stride loop so that every wave keeps per-column partial sums in registers; one LDS reduction
+// and one partial row per block.  With u = n·γ + x·γx, n = x̂·w + b  (mona.py:118-124) the four parameter gradients are
+//     dγ = w·S1 + b·S0,   dw = γ·S1,   db = γ·S0,   dγx = S2      with  S0 = Σ_m du,  S1 = Σ_m du·x̂,  S2 = Σ_m du·x,
+// so the row loop carries THREE column sums and needs two parameter vectors (γ·w and γx); the reduce kernel applies w, b, γ.
+// (The first version carried dγ, dγx, dw, db and read w, b, γ, γx per row: 184 VGPRs, two waves per SIMD, 159 us for 619 MB.)
+// NV = float4 per lane (D ≤ 256·NV): the common D = 768 runs with NV = 3.
 template <typename T, int NV>
 __global__ __launch_bounds__(256) void mona_pre_bwd_kernel(int M, int D, const T* __restrict__ du, const float* __restrict__ x,
                                                             const float* __restrict__ dy, const float* __restrict__ nw,
-                                                            const float* __restrict__ nb, const float* __restrict__ gamma,
-                                                            const float* __restrict__ gammax, float eps, float* __restrict__ dx32,
-                                                            T* __restrict__ dxT, float* __restrict__ ws) {
+                                                            const float* __restrict__ gamma, const float* __restrict__ gammax, float eps,
+                                                            float* __restrict__ dx32, T* __restrict__ dxT, float* __restrict__ ws) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // wave-uniform row → scalar row pointers
     const int nv = D >> 2;
-    // The four parameter vectors live in LDS ([4][D] floats after the reduction area) and are re-read per row through an
-    // opaque offset: left to itself the compiler hoists all 4 x NV float4 of them out of the row loop (216 VGPRs, two waves
-    // per SIMD, 176 us for the 619 MB the LayerNorm backward moves in 94 us at seven waves per SIMD).
-    float* prm = (float*)smem + 16 * D;
+    // The parameter vectors live in LDS ([2][D] floats after the reduction area) and are re-read per row through an opaque offset:
+    // left to itself the compiler hoists them out of the row loop and the kernel drops to two waves per SIMD.
+    float* prm = (float*)smem + 6 * D;
     for (int i = threadIdx.x; i < D; i += 256) {
-        prm[i] = nw[i];
-        prm[D + i] = nb[i];
-        prm[2 * D + i] = gamma[i];
-        prm[3 * D + i] = gammax[i];
+        prm[i] = gamma[i] * nw[i];
+        prm[D + i] = gammax[i];
     }
     __syncthreads();
-    f32x4 a_g[NV], a_gx[NV], a_w[NV], a_b[NV];
+    const bool want_dx = dx32 != nullptr || dxT != nullptr;
+    f32x4 a0[NV], a1[NV], a2[NV];
 #pragma unroll
-    for (int k = 0; k < NV; ++k) a_g[k] = a_gx[k] = a_w[k] = a_b[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
-        int poff = 0;
-        asm volatile("" : "+v"(poff));                            // keeps the parameter reads inside the loop
-        const float* pr = prm + poff;
+    for (int k = 0; k < NV; ++k) a0[k] = a1[k] = a2[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // x, du and dy of a row are requested together, and the NEXT row of the wave is requested before the current one is processed
+    // (two register sets, the loop is unrolled by two): at four waves per SIMD one row in flight per wave left HBM at 4.6 TB/s.
+    auto issue = [&](int row, f32x4 (&v)[NV], f32x4 (&d)[NV], f32x4 (&o)[NV]) {
         const float* xr = x + (size_t)row * D;
         const T* dur = du + (size_t)row * D;
-        f32x4 v[NV], d[NV];
-        float s = 0.f;
+        const float* dyr = dy + (size_t)row * D;
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             const int c = lane + 64 * k;
             const bool ok = c < nv;
             v[k] = ok ? load4(xr + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
             d[k] = ok ? load4(dur + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
-            s += v[k][0] + v[k][1] + v[k][2] + v[k][3];
+            if (want_dx) o[k] = ok ? load4(dyr + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
+    };
+    auto process = [&](int row, f32x4 (&v)[NV], f32x4 (&d)[NV], f32x4 (&o)[NV]) {
+        int poff = 0;
+        asm volatile("" : "+v"(poff));                            // keeps the parameter reads inside the loop
+        const float* pr = prm + poff;
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
         const float mean = wave_sum(s) / D;
         float q = 0.f;
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             const int c = lane + 64 * k;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { const float t = c < nv ? v[k][e] - mean : 0.f; q = fmaf(t, t, q); }
+            for (int e = 0; e < 4; ++e) { const float t = c < nv ? v[k][e] - mean : 0.f; v[k][e] = t; q = fmaf(t, t, q); }   // v := x − mean
         }
         const float rstd = rsqrtf(wave_sum(q) / D + eps);
-        // g = dn·w_n with dn = du·γ ; parameter partial sums (x̂ and g are recomputed in the last loop instead of being kept)
         float sg = 0.f, sgx = 0.f;
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             const int c = lane + 64 * k;
-            const bool ok = c < nv;
-            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-            const f32x4 pw = ok ? *(const f32x4*)(pr + 4 * c) : z4, pb = ok ? *(const f32x4*)(pr + D + 4 * c) : z4;
-            const f32x4 pg = ok ? *(const f32x4*)(pr + 2 * D + 4 * c) : z4;
+            const f32x4 pgw = c < nv ? *(const f32x4*)(pr + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float xhat = ok ? (v[k][e] - mean) * rstd : 0.f;
-                const float dn = d[k][e] * pg[e];
-                const float n = fmaf(xhat, pw[e], pb[e]);
-                a_g[k][e] = fmaf(d[k][e], n, a_g[k][e]);            // dγ  = Σ du·n
-                a_gx[k][e] = fmaf(d[k][e], v[k][e], a_gx[k][e]);    // dγx = Σ du·x
-                a_w[k][e] = fmaf(dn, xhat, a_w[k][e]);              // dw_n = Σ dn·x̂
-                a_b[k][e] += dn;                                    // db_n = Σ dn
-                const float gv = dn * pw[e];
+                const float xhat = v[k][e] * rstd;
+                a0[k][e] += d[k][e];                                       // S0
+                a1[k][e] = fmaf(d[k][e], xhat, a1[k][e]);                  // S1
+                a2[k][e] = fmaf(d[k][e], v[k][e] + mean, a2[k][e]);        // S2 (x itself)
+                const float gv = d[k][e] * pgw[e];                         // dL/dx̂
                 sg += gv;
                 sgx = fmaf(gv, xhat, sgx);
+                v[k][e] = xhat;                                            // v := x̂
             }
         }
         const float mg = wave_sum(sg) / D, mgx = wave_sum(sgx) / D;
-        if (dx32 || dxT) {
-            const float* dyr = dy + (size_t)row * D;
+        if (want_dx) {
             float* dx32r = dx32 ? dx32 + (size_t)row * D : nullptr;
             T* dxTr = dxT ? dxT + (size_t)row * D : nullptr;
 #pragma unroll
             for (int k = 0; k < NV; ++k) {
                 const int c = lane + 64 * k;
                 if (c < nv) {
-                    f32x4 o = load4(dyr + 4 * c);
-                    const f32x4 pw = *(const f32x4*)(pr + 4 * c), pg = *(const f32x4*)(pr + 2 * D + 4 * c), pgx = *(const f32x4*)(pr + 3 * D + 4 * c);
+                    const f32x4 pgw = *(const f32x4*)(pr + 4 * c), pgx = *(const f32x4*)(pr + D + 4 * c);
+                    f32x4 r;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float xhat = (v[k][e] - mean) * rstd;
-                        const float gv = d[k][e] * pg[e] * pw[e];
-                        o[e] += fmaf(d[k][e], pgx[e], rstd * (gv - mg - xhat * mgx));
+                        const float gv = d[k][e] * pgw[e];
+                        r[e] = o[k][e] + fmaf(d[k][e], pgx[e], rstd * (gv - mg - v[k][e] * mgx));
                     }
-                    if (dx32r) store4(dx32r + 4 * c, o);
-                    if (dxTr) store4(dxTr + 4 * c, o);
+                    if (dx32r) store4(dx32r + 4 * c, r);
+                    if (dxTr) store4(dxTr + 4 * c, r);
                 }
             }
         }
+    };
+    const int rstep = gridDim.x * 4;
+    int row = blockIdx.x * 4 + wave;
+    f32x4 vA[NV], dA[NV], oA[NV], vB[NV], dB[NV], oB[NV];
+    if (row < M) issue(row, vA, dA, oA);
+    while (row < M) {
+        const int rowB = row + rstep;
+        if (rowB < M) issue(rowB, vB, dB, oB);
+        process(row, vA, dA, oA);
+        if (rowB >= M) break;
+        row = rowB + rstep;
+        if (row < M) issue(row, vA, dA, oA);
+        process(rowB, vB, dB, oB);
     }
-    // block reduction: [4 waves][4 quantities][D]
+    // block reduction in two rounds through [2][3 sums][D] (waves 2,3 park, waves 0,1 add on top): 8·D floats of LDS with the parameter
+    // vectors, so that four workgroups fit a CU beside the 120 VGPRs
     float* red = (float*)smem;
+    float* mine = red + (wave & 1) * 3 * D;
+    if (wave >= 2) {
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        const int c = lane + 64 * k;
-        if (c < nv) {
-            store4(red + ((wave * 4 + 0) * D) + 4 * c, a_g[k]);
-            store4(red + ((wave * 4 + 1) * D) + 4 * c, a_gx[k]);
-            store4(red + ((wave * 4 + 2) * D) + 4 * c, a_w[k]);
-            store4(red + ((wave * 4 + 3) * D) + 4 * c, a_b[k]);
+        for (int k = 0; k < NV; ++k) {
+            const int c = lane + 64 * k;
+            if (c < nv) { store4(mine + 4 * c, a0[k]); store4(mine + D + 4 * c, a1[k]); store4(mine + 2 * D + 4 * c, a2[k]); }
         }
     }
     __syncthreads();
-    // One partial row [4][D] per block, summed over the blocks by mona_pre_reduce_kernel.  (The first version added every block's
-    // row straight into the four gradient vectors: 1024 blocks x 3072 float atomics onto the SAME 3072 addresses, all issued as the
-    // blocks finish together — the one-row contention case of the microarchitecture guide, 14x below the atomic rate — and the
-    // kernel took 176 us for 619 MB while the LayerNorm backward moves the same bytes in 94.)
-    float* wrow = ws + (size_t)blockIdx.x * 4 * D;
-    for (int i = threadIdx.x; i < 4 * D; i += 256) {
-        const int qn = i / D, c = i - qn * D;
-        wrow[i] = red[(0 * 4 + qn) * D + c] + red[(1 * 4 + qn) * D + c] + red[(2 * 4 + qn) * D + c] + red[(3 * 4 + qn) * D + c];
+    if (wave < 2) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int c = lane + 64 * k;
+            if (c < nv) {
+                store4(mine + 4 * c, load4(mine + 4 * c) + a0[k]);
+                store4(mine + D + 4 * c, load4(mine + D + 4 * c) + a1[k]);
+                store4(mine + 2 * D + 4 * c, load4(mine + 2 * D + 4 * c) + a2[k]);
+            }
+        }
+    }
+    __syncthreads();
+    // One partial row [3][D] per block, summed over the blocks by mona_pre_reduce_kernel.  (The very first version added every block's
+    // row straight into the gradient vectors: 1024 blocks x 3072 float atomics onto the SAME 3072 addresses, all issued as the
+    // blocks finish together — the one-row contention case of the microarchitecture guide, 14x below the atomic rate.)
+    float* wrow = ws + (size_t)blockIdx.x * 3 * D;
+    for (int i = threadIdx.x; i < 3 * D; i += 256) {
+        wrow[i] = red[i] + red[3 * D + i];
     }
 }
 
-// g_{gamma, gammax, nw, nb}[c] += Σ_blocks ws[block][q][c]: grid (ceil(4D/256), NSPLIT); each block sums a slice of the partial rows
-// (coalesced: consecutive threads = consecutive columns) and adds its slice total with ONE atomic per column: NSPLIT adds per address.
+// Sums the per-block rows [S0 | S1 | S2] and applies the parameter factors: grid (ceil(3D/256), NSPLIT); each block sums a slice of the
+// rows (coalesced: consecutive threads = consecutive columns) and adds its slice's contribution with ONE atomic per output element.
 constexpr int PRE_RED_SPLIT = 16;
-__global__ __launch_bounds__(256) void mona_pre_reduce_kernel(int nblocks, int D, const float* __restrict__ ws, float* __restrict__ g_gamma,
-                                                               float* __restrict__ g_gammax, float* __restrict__ g_nw, float* __restrict__ g_nb) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= 4 * D) return;
+__global__ __launch_bounds__(256) void mona_pre_reduce_kernel(int nblocks, int D, const float* __restrict__ ws, const float* __restrict__ nw,
+                                                               const float* __restrict__ nb, const float* __restrict__ gamma,
+                                                               float* __restrict__ g_gamma, float* __restrict__ g_gammax,
+                                                               float* __restrict__ g_nw, float* __restrict__ g_nb) {
+    const int i = blockIdx.x * 256 + threadIdx.x;                  // (sum index qn, column c)
+    if (i >= 3 * D) return;
     const int per = (nblocks + PRE_RED_SPLIT - 1) / PRE_RED_SPLIT;
     const int b0 = blockIdx.y * per, b1 = b0 + per < nblocks ? b0 + per : nblocks;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (b1 <= b0) return;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int b = b0;
-    for (; b + 4 <= b1; b += 4) {
-        s0 += ws[(size_t)(b + 0) * 4 * D + i];
-        s1 += ws[(size_t)(b + 1) * 4 * D + i];
-        s2 += ws[(size_t)(b + 2) * 4 * D + i];
-        s3 += ws[(size_t)(b + 3) * 4 * D + i];
+    for (; b + 8 <= b1; b += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] += ws[(size_t)(b + k) * 3 * D + i];
     }
-    for (; b < b1; ++b) s0 += ws[(size_t)b * 4 * D + i];
+    for (; b < b1; ++b) a[0] += ws[(size_t)b * 3 * D + i];
+    const float S = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     const int qn = i / D, c = i - qn * D;
-    float* outs[4] = {g_gamma, g_gammax, g_nw, g_nb};
-    if (b1 > b0) atomicAdd(outs[qn] + c, (s0 + s1) + (s2 + s3));
+    if (qn == 0) { atomicAdd(g_gamma + c, nb[c] * S); atomicAdd(g_nb + c, gamma[c] * S); }          // S0 = Σ du
+    else if (qn == 1) { atomicAdd(g_gamma + c, nw[c] * S); atomicAdd(g_nw + c, gamma[c] * S); }     // S1 = Σ du·x̂
+    else atomicAdd(g_gammax + c, S);                                                                // S2 = Σ du·x
 }
 
 // ======================================================================================= spatial
@@ -1097,17 +1120,24 @@ int uia_mona_pre_bwd_launch(hipStream_t stream, int dtype, int M, int D, const v
     UIA_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 1024, "uia_mona_pre_bwd: unsupported shape M=%d D=%d", M, D);
     UIA_CHECK_ARG(du && x && nw && nb && gamma && gammax && g_gamma && g_gammax && g_nw && g_nb && ws, "uia_mona_pre_bwd: null tensor");
     UIA_CHECK_ARG(dy || !(dx32 || dxT), "uia_mona_pre_bwd: dx requested without dy");
-    const int blocks = mona_pre_bwd_blocks(M);
-    const size_t lds = (size_t)20 * D * sizeof(float);   // [4 waves][4][D] reduction area + [4][D] parameter vectors
+    int blocks = mona_pre_bwd_blocks(M);
+    const size_t lds = (size_t)8 * D * sizeof(float);   // [2][3][D] reduction area + [2][D] parameter vectors
     const int nvsel = D <= 256 ? 1 : (D <= 768 ? 3 : 4);
-#define UIA_PRE_BWD(TT, NVV) hipLaunchKernelGGL((mona_pre_bwd_kernel<TT, NVV>), dim3(blocks), dim3(256), lds, stream, M, D, (const TT*)du, x, dy, nw, nb, \
-                                                gamma, gammax, eps, dx32, (TT*)dxT, ws)
+    // persistent grid: exactly as many workgroups as are resident at once (a second, partial round would leave most CUs idle at the end)
+#define UIA_PRE_BWD(TT, NVV) do {                                                                                                              \
+        auto kern = mona_pre_bwd_kernel<TT, NVV>;                                                                                              \
+        int per_cu = 0, dev = 0, ncu = 0;                                                                                                      \
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds) == hipSuccess && per_cu > 0 &&                               \
+            hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&       \
+            ncu > 0 && per_cu * ncu < blocks) blocks = per_cu * ncu;                                                                           \
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, stream, M, D, (const TT*)du, x, dy, nw, gamma, gammax, eps, dx32, (TT*)dxT, ws); \
+    } while (0)
     if (dtype == UIA_BF16) { if (nvsel == 1) UIA_PRE_BWD(bf16_t, 1); else if (nvsel == 3) UIA_PRE_BWD(bf16_t, 3); else UIA_PRE_BWD(bf16_t, 4); }
     else if (dtype == UIA_F32) { if (nvsel == 1) UIA_PRE_BWD(float, 1); else if (nvsel == 3) UIA_PRE_BWD(float, 3); else UIA_PRE_BWD(float, 4); }
     else { uia_set_error("uia_mona_pre_bwd: bad dtype %d", dtype); return -1; }
 #undef UIA_PRE_BWD
     UIA_CHECK_LAUNCH();
-    hipLaunchKernelGGL(mona_pre_reduce_kernel, dim3((4 * D + 255) / 256, PRE_RED_SPLIT), dim3(256), 0, stream, blocks, D, ws, g_gamma, g_gammax, g_nw, g_nb);
+    hipLaunchKernelGGL(mona_pre_reduce_kernel, dim3((3 * D + 255) / 256, PRE_RED_SPLIT), dim3(256), 0, stream, blocks, D, ws, nw, nb, gamma, g_gamma, g_gammax, g_nw, g_nb);
     UIA_CHECK_LAUNCH();
     return 0;
 }
