@@ -7,8 +7,9 @@
 //     P = exp(S·scale − lse),  dP = dO·Vᵀ,  δ = rowsum(dO ⊙ O),  dS = P ⊙ (dP − δ)·scale,
 //     dV = Pᵀ·dO,  dK = dSᵀ·Q,  dQ = dS·K.
 //
-// bf16 path (MFMA), 8 waves: Q, K, dO of the head are staged once in LDS (row-major, XOR-swizzled); V goes straight
-// to the registers of the wave that owns the key tile.
+// bf16 path (MFMA), 8 waves: K of the head is staged once in LDS (row-major, XOR-swizzled); V passes through the dSᵀ buffers into
+// the registers of the wave that owns the key tile; Q, dO and O stream through a 4-slot ring of 32-query blocks (LDS-DMA issued
+// three blocks ahead, retired with counted vmcnt waits), δ = rowsum(dO ⊙ O) is computed one block ahead from the ring.
 //   * S and dP are computed with the KEY on the MFMA lane (A = Q / dO rows, B = K / V rows), so a
 //     lane holds P[q = 16·qt + 4g + r][key]; two query tiles give the 8-element B fragment of
 //     dVᵀ += dOᵀ·P and dKᵀ += Qᵀ·dS with no lane movement.  The transposed A operands (dOᵀ, Qᵀ)
@@ -29,9 +30,30 @@ namespace {
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 
+// LDS-DMA through inline asm: hipcc models the builtin as an LDS store and drains it (s_waitcnt vmcnt(0)) in front of the next LDS
+// access, which would serialise the ring below.  The asm form is invisible to that pass; the kernel retires its pieces with its own
+// counted s_waitcnt vmcnt(N) + barrier before any read.  M0 carries the wave-uniform LDS byte address of the piece (lane i lands at
+// +16·i, or +4·i for the dword form); it is saved and restored around the instruction.
 __device__ __forceinline__ void glds16(const char* gsrc, char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+    const unsigned dst_u = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds_wave_base);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(dst_u) : "memory");
+}
+__device__ __forceinline__ void glds4(const char* gsrc, char* lds_wave_base) {
+    const unsigned dst_u = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds_wave_base);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(dst_u) : "memory");
+}
+// sum over the 16 lanes of a DPP row, in every lane: four v_add_f32 with a DPP operand (quad swaps, half-row mirror, row mirror);
+// __shfl_xor goes through ds_bpermute, a 4-deep chain of LDS round trips at the top of every block (23 us of the kernel).
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));   // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));   // row_mirror
+    return v;
 }
 __device__ __forceinline__ s16x4 lds_tr16(const char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
@@ -45,10 +67,26 @@ __device__ __forceinline__ f32x4 mma(const uint4& a, const uint4& b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-// K, Q, dO tiles share one image: [rows][128 B], 16-B chunk c of row r stored at chunk c ^ ((r>>1)&7).
+// K image: [rows][128 B], 16-B chunk c of row r stored at chunk c ^ ((r>>1)&7).  Q, dO and O travel through a ring of 32-query
+// blocks (one 12 KiB slot = [Q | dO | O] pieces of [32][128 B], same swizzle): a block is only ever needed in "its" iteration
+// (S / dP / dV / dK) and, one iteration earlier, for δ = rowsum(dO ⊙ O); the K image and dSᵀ carry everything else.  The whole head
+// used to be staged before the first MFMA (75 of the kernel's 313 us with nothing beside it at one workgroup per CU,
+// tools/abwd_variants.sh); now K + block 0 are, and block u+3 lands while block u is processed.
 // dSᵀ tile: [keys][64 B] (32 queries of the current block), 8-B chunk c of row r stored at chunk c ^ ((r>>1)&7).
 constexpr int BWD_WAVES = 8;
-__host__ __device__ constexpr int bwd_lds_bytes(int LPK) { return 3 * LPK * 128 + 2 * LPK * 64 + 2 * LPK * 4; }
+constexpr int RING = 4, SLOT = 3 * 32 * 128;
+__host__ __device__ constexpr int bwd_lds_bytes(int LPK) { return LPK * 128 + RING * SLOT + 2 * LPK * 64 + 3 * LPK * 4; }
+
+// LDS-DMA and plain loads complete in issue order, so "everything but the last n issued" is a counted wait (stores in flight only
+// make it wait longer).
+__device__ __forceinline__ void wait_vm(int n) {
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    }
+}
 
 template <int LT_MAX>
 __global__ __launch_bounds__(64 * BWD_WAVES) void attn_bwd_bf16_kernel(const UiaAttnParams p) {
@@ -57,98 +95,95 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void attn_bwd_bf16_kernel(const Uia
     const int L = p.L;
     const int LT = (L + 15) >> 4, NP = (LT + 1) >> 1, LPK = NP * 32;
     char* Ks = smem;
-    char* Qs = Ks + LPK * 128;
-    char* Gs = Qs + LPK * 128;                     // dO
-    char* dST0 = Gs + LPK * 128;                   // 2 × [LPK keys][32 queries] bf16: block u writes buffer u&1 while dQ of block u-1 reads the other
-    float* lse2 = (float*)(dST0 + 2 * LPK * 64);   // [LPK] lse in base-2 units
+    char* ring = Ks + LPK * 128;
+    char* dST0 = ring + RING * SLOT;               // 2 × [LPK keys][32 queries] bf16: block u writes buffer u&1 while dQ of block u-1 reads the other
+    float* lraw = (float*)(dST0 + 2 * LPK * 64);   // [LPK] lse as stored by the forward
+    float* lse2 = lraw + LPK;                      // [LPK] lse in base-2 units
     float* dls = lse2 + LPK;                       // [LPK] δ·scale
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.x / p.H, h = blockIdx.x - b * p.H;
     const size_t row0 = (size_t)b * L;
-    const size_t rs = (size_t)p.ld_qkv * 2, rso = (size_t)p.lddo * 2;
+    const size_t rs = (size_t)p.ld_qkv * 2, rso = (size_t)p.lddo * 2, rsO = (size_t)p.ldo * 2;
     const char* qb = (const char*)p.q + (row0 * p.ld_qkv + (size_t)h * 64) * 2;
     const char* kb = (const char*)p.k + (row0 * p.ld_qkv + (size_t)h * 64) * 2;
     const char* vb = (const char*)p.v + (row0 * p.ld_qkv + (size_t)h * 64) * 2;
     const char* gb = (const char*)p.dout + (row0 * p.lddo + (size_t)h * 64) * 2;
     const char* ob = (const char*)p.out + (row0 * p.ldo + (size_t)h * 64) * 2;
     const int li = lane & 15, g = lane >> 4;
+    int klen = L;                                          // read before any piece is in flight: the compiler answers this load with vmcnt(0)
+    if (p.mask_kind == UIA_MASK_KEYPAD && p.keylen) { klen = p.keylen[b]; klen = klen < 1 ? 1 : (klen > L ? L : klen); }
+    asm volatile("" : "+v"(klen));
 
+    // ---- issue order = order of need: K, V (registers), lse, blocks 0..2
     const int ninstr = LPK >> 3;
     for (int q = wave; q < ninstr; q += BWD_WAVES) {
         const int r = 8 * q + (lane >> 3);
         const int gr = r < L ? r : L - 1;
         const int c = ((lane & 7) ^ ((r >> 1) & 7)) * 16;
         glds16(kb + gr * rs + c, Ks + q * 1024);
-        glds16(qb + gr * rs + c, Qs + q * 1024);
-        glds16(gb + gr * rso + c, Gs + q * 1024);
     }
-    // V is only ever a B operand of the wave that owns the key tile: its fragments go straight from HBM to registers
-    // (row 16kt+li, 16-B chunks g and g+4), for the whole sweep over queries.
-    uint4 vf[KTW][2];
-#pragma unroll
-    for (int a = 0; a < KTW; ++a) {
-        const int kt = wave + BWD_WAVES * a;
-        int r = 16 * kt + li;
+    // V is only ever a B operand of the wave that owns the key tile, for the whole sweep over queries: its image lands in the (still
+    // unused) dSᵀ buffers, the fragments are read into registers next to K's, and the first dSᵀ store comes two barriers later.
+    // (Plain loads into registers would not do: the compiler answers their first use with vmcnt(0), which drains the ring.)
+    for (int q = wave; q < ninstr; q += BWD_WAVES) {
+        const int r = 8 * q + (lane >> 3);
+        const int gr = r < L ? r : L - 1;
+        const int c = ((lane & 7) ^ ((r >> 1) & 7)) * 16;
+        glds16(vb + gr * rs + c, dST0 + q * 1024);
+    }
+    for (int i = wave; i * 64 < LPK; i += BWD_WAVES) {
+        int r = 64 * i + lane;
         r = r < L ? r : L - 1;
-        vf[a][0] = *(const uint4*)(vb + r * rs + g * 16);
-        vf[a][1] = *(const uint4*)(vb + r * rs + (g + 4) * 16);
+        glds4((const char*)(p.lse + ((size_t)b * p.H + h) * L + r), (char*)(lraw + 64 * i));
     }
-    // δ·scale and lse.  Two threads per query row: each fetches its 64-byte half of the O row NOW (four 16-byte loads that fly
-    // under the staging wait) and, once the dO image is resident, reads the matching half of the dO row from LDS: the first version
-    // had 224 of the 512 threads read both 128-byte rows from HBM after each other (33 us of the 328 us kernel, tools/abwd_variants.sh).
+    // one block = 12 pieces of 1 KiB: waves 0-3 bring a Q and an O piece each, waves 4-7 a dO piece
+    const int pb = wave < 4 ? 2 : 1;
+    auto issue_block = [&](int u) {
+        char* slot = ring + (u & (RING - 1)) * SLOT;
+        const int wq = wave & 3;
+        const int r = 8 * wq + (lane >> 3);                      // row within the block
+        int gr = 32 * u + r;
+        gr = gr < L ? gr : L - 1;
+        const int c = ((lane & 7) ^ ((r >> 1) & 7)) * 16;
+        if (wave < 4) {
+            glds16(qb + gr * rs + c, slot + wq * 1024);
+            glds16(ob + gr * rsO + c, slot + 8192 + wq * 1024);
+        } else {
+            glds16(gb + gr * rso + c, slot + 4096 + wq * 1024);
+        }
+    };
+    issue_block(0);
+    if (NP > 1) issue_block(1);
+    if (NP > 2) issue_block(2);
+    // δ·scale and lse of one block: 16 threads per query row, 8 bytes of dO and of O each
     const float sc = p.scale * 1.44269504088896341f;
-    const int drow = tid >> 1, dhalf = tid & 1;           // rows drow and drow + 256 (L up to 288)
-    uint4 ov[2][4];
-#pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
-        int r = drow + 256 * rr;
-        r = r < L ? r : L - 1;
-        const char* oo = ob + (size_t)r * p.ldo * 2 + dhalf * 64;
-        if (rr == 0 || LPK > 256) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) ov[rr][c] = *(const uint4*)(oo + 16 * c);
-        }
-    }
-    for (int i = tid; i < (LPK - 16 * LT) * 4; i += 64 * BWD_WAVES) {
-        *(uint4*)(dST0 + 16 * LT * 64 + i * 16) = uint4{0u, 0u, 0u, 0u};
-        *(uint4*)(dST0 + LPK * 64 + 16 * LT * 64 + i * 16) = uint4{0u, 0u, 0u, 0u};
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-#pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
-        const int row = drow + 256 * rr;
-        if (row < LPK) {                                   // (wave-uniform for rr == 1: LPK - 256 is a multiple of 32 rows = one wave)
-            float d = 0.f;
+    auto delta_block = [&](int ub) {
+        const char* slot = ring + (ub & (RING - 1)) * SLOT;
+        const int rl = tid >> 4, part = tid & 15;
+        const int row = 32 * ub + rl;
+        const int off = rl * 128 + ((((part >> 1) ^ (rl >> 1)) & 7) << 4) + 8 * (part & 1);
+        typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+        const bf16x4_t gv = *(const bf16x4_t*)(slot + 4096 + off), ov = *(const bf16x4_t*)(slot + 8192 + off);
+        float d = 0.f;
 #ifndef ABWD_NO_DELTA
-            if (row < L) {
-                const int sw = (row >> 1) & 7;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const uint4 gv = *(const uint4*)(Gs + row * 128 + (((4 * dhalf + c) ^ sw) << 4));
-                    const bf16x8 gx = __builtin_bit_cast(bf16x8, gv), ox = __builtin_bit_cast(bf16x8, ov[rr][c]);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) d = fmaf((float)gx[e], (float)ox[e], d);
-                }
-            }
+        for (int e = 0; e < 4; ++e) d = fmaf((float)gv[e], (float)ov[e], d);
 #endif
-            d += __shfl_xor(d, 1, 64);
-            if (dhalf == 0) {
-                dls[row] = d * p.scale;
-                lse2[row] = row < L ? p.lse[((size_t)b * p.H + h) * L + row] * 1.44269504088896341f : 0.f;
-            }
+        d = row16_sum(d);
+        if (part == 0) {
+            dls[row] = row < L ? d * p.scale : 0.f;
+            lse2[row] = row < L ? lraw[row] * 1.44269504088896341f : 0.f;
         }
-    }
+    };
+    wait_vm((NP > 2 ? 2 : NP - 1) * pb);                   // K, V, lse and block 0 have landed; blocks 1, 2 stay in flight
     __syncthreads();
+    delta_block(0);
 
 #ifdef ABWD_PROLOGUE_ONLY
     if (p.L > 0) return;                                  // diagnostic: how long does staging alone take?
 #endif
-    int klen = L;
-    if (p.mask_kind == UIA_MASK_KEYPAD && p.keylen) { klen = p.keylen[b]; klen = klen < 1 ? 1 : (klen > L ? L : klen); }
-
     // row-read fragment offset: row (16·tile + li), chunk g (+4 for the second k-half via ^64)
     const int offR = li * 128 + ((g ^ (li >> 1)) << 4);
     // transpose-read (A operand with k = rows of the image): group g, lane (qq,pp) → row 4g+qq (+16 for hi),
@@ -160,14 +195,16 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void attn_bwd_bf16_kernel(const Uia
     const int nrow = 8 * g + qq;
     const int nsw_lo = (nrow >> 1) & 7, nsw_hi = ((nrow + 4) >> 1) & 7;
 
-    // K fragments of the owned key tiles (B operand of S = Q·Kᵀ), kept for the whole sweep
-    uint4 kf[KTW][2];
+    // K and V fragments of the owned key tiles (B operands of S = Q·Kᵀ and dP = dO·Vᵀ), kept for the whole sweep
+    uint4 kf[KTW][2], vf[KTW][2];
 #pragma unroll
     for (int a = 0; a < KTW; ++a) {
         const int kt = wave + BWD_WAVES * a;
         const int ktc = kt < 2 * NP ? kt : 0;
         kf[a][0] = *(const uint4*)(Ks + ktc * 2048 + offR);
         kf[a][1] = *(const uint4*)(Ks + ktc * 2048 + (offR ^ 64));
+        vf[a][0] = *(const uint4*)(dST0 + ktc * 2048 + offR);
+        vf[a][1] = *(const uint4*)(dST0 + ktc * 2048 + (offR ^ 64));
     }
     f32x4 dVt[KTW][4], dKt[KTW][4];
 #pragma unroll
@@ -181,6 +218,20 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void attn_bwd_bf16_kernel(const Uia
     for (int u = 0; u <= NP; ++u) {
         char* dST = dST0 + (u & 1) * LPK * 64;
         const char* dSTr = dST0 + ((u + 1) & 1) * LPK * 64;
+        const char* Qb = ring + (u & (RING - 1)) * SLOT;
+        const char* Gb = Qb + 4096;
+        // block u+1 must have landed (its δ is computed now), block u+2 may stay in flight.  The barrier also publishes δ of block u
+        // and dSᵀ of block u-1, and frees the slot of block u-1 for block u+3.
+        if (u + 1 < NP) wait_vm(u + 2 < NP ? pb : 0);
+        __syncthreads();
+        if (u == 0) {                                     // the V image is in registers everywhere: the dSᵀ pad rows (keys past the last tile) become zeros
+            for (int i = tid; i < (LPK - 16 * LT) * 4; i += 64 * BWD_WAVES) {
+                *(uint4*)(dST0 + 16 * LT * 64 + i * 16) = uint4{0u, 0u, 0u, 0u};
+                *(uint4*)(dST0 + LPK * 64 + 16 * LT * 64 + i * 16) = uint4{0u, 0u, 0u, 0u};
+            }
+        }
+        if (u + 3 < NP) issue_block(u + 3);
+        if (u + 1 < NP) delta_block(u + 1);
         if (u < NP) {
         // per-lane query rows of this 32-query block: q(hq, r) = 32u + 16hq + 4g + r
         f32x4 ls[2], dl[2];
@@ -195,16 +246,16 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void attn_bwd_bf16_kernel(const Uia
         for (int hq = 0; hq < 2; ++hq)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                qf[hq][kk] = *(const uint4*)(Qs + (2 * u + hq) * 2048 + (offR ^ (kk << 6)));
-                gf[hq][kk] = *(const uint4*)(Gs + (2 * u + hq) * 2048 + (offR ^ (kk << 6)));
+                qf[hq][kk] = *(const uint4*)(Qb + hq * 2048 + (offR ^ (kk << 6)));
+                gf[hq][kk] = *(const uint4*)(Gb + hq * 2048 + (offR ^ (kk << 6)));
             }
         // transposed A operands for dV / dK: dOᵀ and Qᵀ of this block, per d-tile
         bf16x8 gT[4], qT[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-            const int off = (32 * u + trow) * 128 + (((2 * dt + (pp >> 1)) ^ tsw) << 4) + 8 * (pp & 1);
-            gT[dt] = tr_pair(Gs + off, Gs + off + 16 * 128);
-            qT[dt] = tr_pair(Qs + off, Qs + off + 16 * 128);
+            const int off = trow * 128 + (((2 * dt + (pp >> 1)) ^ tsw) << 4) + 8 * (pp & 1);
+            gT[dt] = tr_pair(Gb + off, Gb + off + 16 * 128);
+            qT[dt] = tr_pair(Qb + off, Qb + off + 16 * 128);
         }
         const bool full_q = p.mask_kind == UIA_MASK_NONE && 32 * u + 32 <= L;
 #pragma unroll
@@ -302,7 +353,6 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void attn_bwd_bf16_kernel(const Uia
                 store4(drow + 16 * dt, dq);
             }
         }
-        __syncthreads();
     }
     // ---- dK, dV: lane owns key 16kt+li, d = 16dt + 4g + r
 #pragma unroll
