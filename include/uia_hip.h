@@ -165,6 +165,24 @@ int uia_dicece_fwd_bwd(void* stream, int B, int C, int HW, const float* logits, 
  * Layout helpers around the GEMMs. */
 int uia_cast(void* stream, int dtype, size_t n, const float* src, void* dst, float scale);          /* dst = T(scale*src) */
 int uia_transpose_cast(void* stream, int dtype, int rows, int cols, const float* src, void* dst);   /* dst[c][r] = T(src[r][c]) */
+
+/* All GEMM-operand forms of a set of small trainable fp32 matrices in ONE launch (the adapter weights after an optimiser step):
+ * for matrix i (src [rows][cols] fp32), any non-null of
+ *     row    [rows][cols]            T copy                         (weight [N = rows][K = cols] of y = x·Wᵀ)
+ *     row_kb [cols/g][rows][g]       its K-blocked twin, g = 64 bytes of T elements (cols % g == 0)
+ *     tr     [cols][rows]            T transpose                    (the dgrad weight)
+ *     tr_kb  [rows/g][cols][g]       K-blocked twin of the transpose (rows % g == 0)
+ * The descriptor table lives in DEVICE memory (the caller uploads it once and re-uses it every step).  Replaces, per matrix and
+ * step, the reference's implicit autocast casts (torch.autocast around F.linear: /root/reference/src/models/biomedclip/finetune.py:277). */
+typedef struct uia_pack_desc {
+    const float* src;
+    void* row;
+    void* row_kb;
+    void* tr;
+    void* tr_kb;
+    int32_t rows, cols;
+} uia_pack_desc;
+int uia_pack_weights(void* stream, int dtype, int n, const uia_pack_desc* descs_device, int max_elems);
 int uia_im2col(void* stream, int dtype, int B, int C, int H, int W, int P, const float* img, void* out); /* model.py:221,234 */
 /* same for any patch size (P need not be a multiple of 4), rows padded with zeros to ldo >= C*P*P columns (ViT-L/14: 588 -> 640) */
 int uia_im2col_padded(void* stream, int dtype, int B, int C, int H, int W, int P, const float* img, void* cols, int64_t ldo);

@@ -32,6 +32,7 @@ int uia_layernorm_bwd(void* stream, int dtype, int M, int D, int64_t ldx, const 
 }
 int uia_cast(void* stream, int dtype, size_t n, const float* src, void* dst, float scale) { return uia_cast_launch((hipStream_t)stream, dtype, n, src, dst, scale); }
 int uia_transpose_cast(void* stream, int dtype, int rows, int cols, const float* src, void* dst) { return uia_transpose_cast_launch((hipStream_t)stream, dtype, rows, cols, src, dst); }
+int uia_pack_weights(void* stream, int dtype, int n, const uia_pack_desc* descs_device, int max_elems) { return uia_pack_weights_launch((hipStream_t)stream, dtype, n, descs_device, max_elems); }
 int uia_im2col(void* stream, int dtype, int B, int C, int H, int W, int P, const float* img, void* out) { return uia_im2col_launch((hipStream_t)stream, dtype, B, C, H, W, P, img, out); }
 int uia_fill_cls(void* stream, int B, int N, int D, const float* cls, const float* pos0, float* x) { return uia_fill_cls_launch((hipStream_t)stream, B, N, D, cls, pos0, x); }
 int uia_embed(void* stream, int rows, int L, int D, int vocab, int max_pos, const int64_t* ids, const float* table, const float* pos, const float* type0, float* out) {

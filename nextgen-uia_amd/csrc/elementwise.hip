@@ -36,6 +36,24 @@ __global__ __launch_bounds__(256) void transpose_cast_kernel(int rows, int cols,
     }
 }
 
+// every operand form of matrix blockIdx.y (uia_pack_desc) from one read of its fp32 source; the matrices are adapter-sized
+// (≤ a few hundred KB), so the scattered 2-byte stores of the transposed / K-blocked forms stay inside L2
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weights_kernel(const uia_pack_desc* __restrict__ descs) {
+    const uia_pack_desc d = descs[blockIdx.y];
+    constexpr int g = 64 / (int)sizeof(T);
+    const int R = d.rows, C = d.cols, total = R * C;
+    T* row = (T*)d.row; T* row_kb = (T*)d.row_kb; T* tr = (T*)d.tr; T* tr_kb = (T*)d.tr_kb;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        const int r = e / C, c = e - r * C;
+        const T v = from_f32<T>(d.src[e]);
+        if (row) row[e] = v;
+        if (row_kb) row_kb[((size_t)(c / g) * R + r) * g + (c % g)] = v;
+        if (tr) tr[(size_t)c * R + r] = v;
+        if (tr_kb) tr_kb[((size_t)(r / g) * C + c) * g + (r % g)] = v;
+    }
+}
+
 // out[(b*gh+py)*gw+px][(c*P+ky)*P+kx] = img[b][c][py*P+ky][px*P+kx]; one thread = 4 consecutive kx
 template <typename T>
 __global__ void im2col_kernel(int B, int C, int H, int W, int P, const float* __restrict__ img, T* __restrict__ out) {
@@ -197,6 +215,17 @@ int uia_transpose_cast_launch(hipStream_t stream, int dtype, int rows, int cols,
     if (dtype == UIA_BF16) hipLaunchKernelGGL(transpose_cast_kernel<bf16_t>, grid, dim3(256), 0, stream, rows, cols, src, (bf16_t*)dst);
     else if (dtype == UIA_F32) hipLaunchKernelGGL(transpose_cast_kernel<float>, grid, dim3(256), 0, stream, rows, cols, src, (float*)dst);
     else { uia_set_error("uia_transpose_cast: bad dtype %d", dtype); return -1; }
+    UIA_CHECK_LAUNCH();
+    return 0;
+}
+
+int uia_pack_weights_launch(hipStream_t stream, int dtype, int n, const uia_pack_desc* descs_device, int max_elems) {
+    UIA_CHECK_ARG(n > 0 && n <= 65535 && descs_device && max_elems > 0, "uia_pack_weights: bad arguments (n=%d, max_elems=%d)", n, max_elems);
+    int bx = (max_elems + 1023) / 1024;                     // ~4 elements per thread
+    bx = bx < 1 ? 1 : (bx > 256 ? 256 : bx);
+    if (dtype == UIA_BF16) hipLaunchKernelGGL(pack_weights_kernel<bf16_t>, dim3(bx, n), dim3(256), 0, stream, descs_device);
+    else if (dtype == UIA_F32) hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(bx, n), dim3(256), 0, stream, descs_device);
+    else { uia_set_error("uia_pack_weights: bad dtype %d", dtype); return -1; }
     UIA_CHECK_LAUNCH();
     return 0;
 }

@@ -82,12 +82,22 @@ __global__ __launch_bounds__(256) void dfeat_kernel(int B, int E, const float* _
     float acc[MAXE];
 #pragma unroll
     for (int k = 0; k < MAXE; ++k) acc[k] = 0.f;
-    for (int j = 0; j < B; ++j) {
-        const float w = txt ? dS[(size_t)j * B + i] : dS[(size_t)i * B + j];
+    // the row (image side) or column (text side) of dS goes to LDS in chunks of 256, so that the sweep over j is a run of independent,
+    // unrolled loads of `other` with a broadcast LDS operand (one dependent global load of w per j made this 135 us at B = 256)
+    __shared__ float wS[256];
+    for (int j0 = 0; j0 < B; j0 += 256) {
+        __syncthreads();
+        if (j0 + tid < B) wS[tid] = txt ? dS[(size_t)(j0 + tid) * B + i] : dS[(size_t)i * B + j0 + tid];
+        __syncthreads();
+        const int jn = B - j0 < 256 ? B - j0 : 256;
+#pragma unroll 8
+        for (int j = 0; j < jn; ++j) {
+            const float w = wS[j];
 #pragma unroll
-        for (int k = 0; k < MAXE; ++k) {
-            const int e = tid + 256 * k;
-            if (e < E) acc[k] = fmaf(w, other[(size_t)j * E + e], acc[k]);
+            for (int k = 0; k < MAXE; ++k) {
+                const int e = tid + 256 * k;
+                if (e < E) acc[k] = fmaf(w, other[(size_t)(j0 + j) * E + e], acc[k]);
+            }
         }
     }
 #pragma unroll

@@ -19,6 +19,7 @@ int uia_layernorm_bwd_launch(hipStream_t stream, int dtype, int M, int D, long l
                              const float* dres, float* dx32, void* dxT);
 int uia_cast_launch(hipStream_t stream, int dtype, size_t n, const float* src, void* dst, float scale);
 int uia_transpose_cast_launch(hipStream_t stream, int dtype, int rows, int cols, const float* src, void* dst);
+int uia_pack_weights_launch(hipStream_t stream, int dtype, int n, const uia_pack_desc* descs_device, int max_elems);
 int uia_im2col_launch(hipStream_t stream, int dtype, int B, int C, int H, int W, int P, const float* img, void* out);
 int uia_fill_cls_launch(hipStream_t stream, int B, int N, int D, const float* cls, const float* pos0, float* x);
 int uia_embed_launch(hipStream_t stream, int rows, int L, int D, int vocab, int max_pos, const int64_t* ids, const float* table, const float* pos, const float* type0, float* out);

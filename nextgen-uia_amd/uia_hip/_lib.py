@@ -20,6 +20,11 @@ MONA_VARIANTS = {"baseline": 0, "noise_aware": 1, "freq_enhanced": 2, "hybrid": 
 vp, i32, i64, f32, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
 
 
+class PackDesc(C.Structure):
+    """uia_pack_desc (include/uia_hip.h): one small trainable matrix and the operand forms to derive from it."""
+    _fields_ = [("src", vp), ("row", vp), ("row_kb", vp), ("tr", vp), ("tr_kb", vp), ("rows", i32), ("cols", i32)]
+
+
 class GemmDesc(C.Structure):
     _fields_ = [("A", vp), ("lda", i64), ("W", vp), ("ldw", i64), ("M", i32), ("N", i32), ("K", i32), ("alpha", f32),
                 ("bias", vp), ("act", i32), ("dact", i32), ("aux_in", vp), ("ldaux_in", i64), ("aux_out", vp), ("ldaux_out", i64),
@@ -89,6 +94,7 @@ PROTOTYPES = {
     "uia_act_bwd": (C.c_int, [vp, C.c_int, sz, vp, vp, C.c_int, vp]),
     "uia_cast": (C.c_int, [vp, C.c_int, sz, vp, vp, f32]),
     "uia_transpose_cast": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "uia_pack_weights": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int]),
     "uia_im2col": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "uia_im2col_padded": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int64]),
     "uia_fill_cls": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]),

@@ -83,21 +83,89 @@ def clear_t_copies():
 
 
 # ------------------------------------------------------------------------------------------------
+class _PackedParam:
+    """All GEMM-operand forms of one small trainable matrix, refreshed in place by uia_pack_weights."""
+    __slots__ = ("ref", "version", "epoch", "dt", "row", "row_kb", "tr", "tr_kb", "fwd", "bwd", "src_ptr")
+
+    def __init__(self, p, dt):
+        R, Cc = p.shape
+        g = 64 // torch.empty(0, dtype=dt).element_size()
+        mk = lambda *shape: torch.empty(shape, device=p.device, dtype=dt)
+        self.ref, self.version, self.epoch, self.dt, self.src_ptr = weakref.ref(p), -1, -1, dt, 0
+        self.row, self.tr = mk(R, Cc), mk(Cc, R)
+        self.row_kb = mk(Cc // g, R, g) if Cc % g == 0 else None
+        self.tr_kb = mk(R // g, Cc, g) if R % g == 0 else None
+        self.fwd, self.bwd = ops.PackedW(self.row, self.row_kb), ops.PackedW(self.tr, self.tr_kb)
+
+    def entry(self):
+        return (self.ref().detach(), self.row, self.row_kb, self.tr, self.tr_kb)
+
+
 class WeightCache:
     """T copies (and transposes, for dgrad-as-TN) of fp32 parameters, refreshed when the parameter's
-    version counter changes (frozen weights are converted exactly once)."""
+    version counter changes (frozen weights are converted exactly once).
+
+    Small trainable matrices (the adapters' projections) take a batched path: their row, transposed and K-blocked forms live in
+    persistent buffers that ONE uia_pack_weights launch rewrites after every optimiser step (bump()); before that every Mona
+    layer paid two casts, two transposes and two layout copies per step, 73 launches of ~5 us for 12 layers."""
+    PACK_MAX_ELEMS = 1 << 20
 
     def __init__(self):
         self._c = {}
         self.epoch = 0
+        self._packed = {}                  # id(p) -> _PackedParam
+        self._table = None                 # (device table, n, max_elems, dtype, [entries kept alive])
+
+    def _repack(self, items):
+        dt, dev = items[0].dt, items[0].row.device
+        entries = [it.entry() for it in items]
+        table, n, mx = ops.pack_table(entries, dev)
+        ops.pack_weights(table, n, mx, dt)
+        for it in items:
+            it.version, it.epoch, it.src_ptr = it.ref()._version, self.epoch, it.ref().data_ptr()
+        return table, n, mx, dt, entries
 
     def bump(self):
         """Trainable parameters were updated behind autograd's back (fused optimiser kernel)."""
         self.epoch += 1
         if len(self._c) > 8192:
             self._c = {k: v for k, v in self._c.items() if v[1]() is not None}
+        live = [it for it in self._packed.values() if it.ref() is not None]
+        if len(live) != len(self._packed):
+            self._packed = {id(it.ref()): it for it in live}
+            self._table = None
+        if not live:
+            return
+        groups = {}
+        for it in live:
+            groups.setdefault((it.dt, it.row.device), []).append(it)
+        if (len(groups) == 1 and self._table is not None and self._table[1] == len(live)
+                and all(it.src_ptr == it.ref().data_ptr() for it in live)):
+            table, n, mx, dt, _ = self._table                 # same set as last step: the resident table is still right
+            ops.pack_weights(table, n, mx, dt)
+            for it in live:
+                it.version, it.epoch = it.ref()._version, self.epoch
+        else:
+            self._table = None
+            for items in groups.values():
+                t = self._repack(items)
+                if len(groups) == 1:
+                    self._table = t
+
+    def _packed_get(self, p, dt, transpose):
+        it = self._packed.get(id(p))
+        if it is None or it.ref() is not p or it.dt != dt or it.row.device != p.device or tuple(it.row.shape) != tuple(p.shape):
+            it = _PackedParam(p, dt)
+            self._packed[id(p)] = it
+            self._table = None
+        if it.version != p._version or it.epoch != self.epoch:
+            self._repack([it])                                # first use, or the parameter changed outside the optimiser step
+        return it.bwd if transpose else it.fwd
 
     def get(self, p, dt, transpose=False, pad_rows_to=None, pad_cols_to=None):
+        if (p.requires_grad and dt != torch.float32 and pad_rows_to is None and pad_cols_to is None and p.dim() == 2 and p.is_cuda
+                and p.dtype == torch.float32 and p.is_contiguous() and p.numel() <= self.PACK_MAX_ELEMS):
+            return self._packed_get(p, dt, transpose)
         key = (id(p), dt, transpose, pad_rows_to, pad_cols_to)
         hit = self._c.get(key)
         if hit is not None and hit[0] == p._version and hit[1]() is p and hit[2].row.device == p.device and (not p.requires_grad or hit[3] == self.epoch):

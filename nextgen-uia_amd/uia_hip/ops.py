@@ -9,7 +9,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import AttnDesc, GemmDesc, MonaSpatialDesc, UiaError, check, lib
+from ._lib import AttnDesc, GemmDesc, MonaSpatialDesc, PackDesc, UiaError, check, lib
 
 _ACT = {None: 0, "none": 0, "gelu": 1, "quick_gelu": 2, "relu": 3}
 
@@ -82,8 +82,8 @@ class PackedW:
     use by a ring-kernel launch.  Layout plumbing only (a strided copy); which one a launch takes is decided in gemm()."""
     __slots__ = ("row", "_kb")
 
-    def __init__(self, row):
-        self.row, self._kb = row, None
+    def __init__(self, row, kb=None):
+        self.row, self._kb = row, kb
 
     @property
     def shape(self):
@@ -292,6 +292,28 @@ def transpose_cast(src, dst):
     assert src.dtype == torch.float32 and src.dim() == 2 and src.is_contiguous() and dst.is_contiguous()
     assert tuple(dst.shape) == (src.shape[1], src.shape[0])
     check(lib().uia_transpose_cast(_stream(), _code(dst.dtype), src.shape[0], src.shape[1], _p(src), _p(dst)), "uia_transpose_cast")
+
+
+def pack_table(entries, device):
+    """Device-resident uia_pack_desc table for `entries` = [(src fp32 [R, C], row, row_kb, tr, tr_kb)] (None = form not wanted).
+    Returns (table tensor, n, max_elems); keep the tensors of `entries` alive as long as the table is used."""
+    arr = (PackDesc * len(entries))()
+    max_elems = 0
+    for d, (src, row, row_kb, tr, tr_kb) in zip(arr, entries):
+        assert src.dtype == torch.float32 and src.dim() == 2 and src.is_contiguous()
+        R, Cc = src.shape
+        d.src, d.rows, d.cols = _p(src), R, Cc
+        for name, t in (("row", row), ("row_kb", row_kb), ("tr", tr), ("tr_kb", tr_kb)):
+            if t is not None:
+                assert t.is_contiguous() and t.numel() == src.numel() and t.device == src.device
+                setattr(d, name, _p(t))
+        max_elems = max(max_elems, R * Cc)
+    raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone()
+    return raw.to(device), len(entries), max_elems
+
+
+def pack_weights(table, n, max_elems, dtype):
+    check(lib().uia_pack_weights(_stream(), _code(dtype), n, _p(table), max_elems), "uia_pack_weights")
 
 
 def im2col(img, out, patch):

@@ -339,3 +339,45 @@ def test_dicece_kernel_vs_independent_float64_vectors(golden, case):
     if case + "_dice" in z:
         d, want = dice_per_image(logits.detach(), label).cpu(), z[case + "_dice"]
         assert torch.equal(torch.isnan(d), torch.isnan(want)) and torch.allclose(torch.nan_to_num(d), torch.nan_to_num(want), atol=1e-12)
+
+
+def test_pack_weights_all_forms_and_cache_refresh():
+    """uia_pack_weights (one launch for every operand form of the small trainable matrices) against torch, and the WeightCache
+    contract around it: forms are rewritten in place by bump() (the optimiser step), a parameter changed by other means is
+    repacked on its next use, frozen and padded weights keep the per-tensor path."""
+    from uia_hip import functional as UF, ops
+    torch.manual_seed(3)
+    dt = torch.bfloat16
+    g = 32
+    ps = [torch.nn.Parameter(torch.randn(64, 768, device=dev())), torch.nn.Parameter(torch.randn(768, 64, device=dev())),
+          torch.nn.Parameter(torch.randn(96, 40, device=dev()))]                       # the last one: no K-blocked forms (40 % 32, 96 % 32 == 0 only)
+    cache = UF.WeightCache()
+
+    def check(p):
+        f, b = cache.get(p, dt), cache.get(p, dt, transpose=True)
+        ref = p.detach().to(dt)
+        assert torch.equal(f.row, ref) and torch.equal(b.row, ref.t().contiguous())
+        R, Cc = p.shape
+        if Cc % g == 0:
+            assert torch.equal(f.kblocked(), ref.view(R, Cc // g, g).permute(1, 0, 2).contiguous())
+        if R % g == 0:
+            assert torch.equal(b.kblocked(), ref.t().contiguous().view(Cc, R // g, g).permute(1, 0, 2).contiguous())
+        return f, b
+
+    first = [check(p) for p in ps]
+    with torch.no_grad():                                       # "fused optimiser": data changes, version counters do not
+        for p in ps:
+            p.data.add_(0.25)
+    cache.bump()
+    for p, (f0, b0) in zip(ps, first):
+        f, b = check(p)
+        assert f.row.data_ptr() == f0.row.data_ptr() and b.row.data_ptr() == b0.row.data_ptr()      # refreshed in place
+    cache.bump()                                                # second step: the resident descriptor table is re-used
+    [check(p) for p in ps]
+    with torch.no_grad():
+        ps[0].mul_(2.0)                                         # in-place op: version counter moves, no bump
+    check(ps[0])
+    frozen = torch.randn(64, 768, device=dev())
+    assert cache.get(frozen, dt) is cache.get(frozen, dt) and id(frozen) not in cache._packed
+    padded = cache.get(ps[2], dt, pad_rows_to=128)
+    assert tuple(padded.shape) == (128, 40) and torch.equal(padded.row[:96], ps[2].detach().to(dt))
