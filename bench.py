@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--no-overlap-text", action="store_true", help=argparse.SUPPRESS)        # former spelling of the default
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--no-deferred-text-ln", action="store_true", help="scheduling A/B (same results): every text-tower LayerNorm also writes its fp32 output "
+                    "instead of leaving it to the consuming GEMM epilogue")
     ap.add_argument("--unpad-text", action="store_true", help="opt-in: the frozen text tower computes only the valid tokens of each caption "
                     "(identical features, less executed work than the reference's dense 256 positions; not the headline configuration)")
     ap.add_argument("--no-kblock-w", action="store_true", help="A/B knob: keep the GEMM weights row-major (default: K-blocked for the ring kernels)")
@@ -136,6 +138,7 @@ def main():
     device = torch.device("cuda", local)
     UF.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
     UF.set_unpad_text(args.unpad_text)
+    UF.set_deferred_text_ln(not args.no_deferred_text_ln)
     ops.KBLOCK_W, ops.TAIL_SPLIT, ops.K64_CFG14 = not args.no_kblock_w, not args.no_tail_split, not args.no_k64_cfg14
 
     model = create_biomedclip(seed=0)                                # same weights on every rank (random init: no network for checkpoints)

@@ -64,6 +64,13 @@ typedef struct uia_gemm_desc {
     int32_t w_kblocked;                 /* 1: W is stored K-blocked, [K/g][N][g] with g = 64 bytes / sizeof(T) elements (ldw ignored): the layout
                                            the ring tile configs (8, 10; the automatic choice for M > 2048, N > 64) stream fastest; other tile
                                            configs reject it */
+    const float* resid_ln_stats;        /* non-null: `resid` holds the INPUT of a LayerNorm and the residual added is that LayerNorm's output,
+                                           fmaf((resid[m][n] - mean_m)·rstd_m, resid_ln_w[n], resid_ln_b[n]) with (mean_m, rstd_m) =
+                                           resid_ln_stats[2m], [2m+1] as written by uia_layernorm_fwd_stats: a post-LN (BERT) sub-layer sum
+                                           then reads the previous sum once instead of the LayerNorm writing its fp32 output for it
+                                           (HF BertSelfOutput / BertOutput: LayerNorm(dense(h) + input_tensor) [third-party]) */
+    const float* resid_ln_w;
+    const float* resid_ln_b;
 } uia_gemm_desc;
 int uia_gemm(void* stream, int dtype, const uia_gemm_desc* d, int tile_cfg /* 0 = auto */);
 
@@ -100,6 +107,10 @@ int uia_attn_bwd(void* stream, int dtype, const uia_attn_desc* d);
  * gamma/beta (dx only): dx = dres + LN'(dy); statistics are recomputed from x. */
 int uia_layernorm_fwd(void* stream, int dtype, int M, int D, int64_t ldx, const float* x, const float* gamma, const float* beta,
                       float eps, void* yT, float* y32);
+/* Same, and additionally stats[2m] = mean_m, stats[2m+1] = rstd_m (fp32) when `stats` is non-null; yT and y32 may then both be null
+ * only if stats is given.  The deferred-residual form of uia_gemm (resid_ln_stats) consumes them. */
+int uia_layernorm_fwd_stats(void* stream, int dtype, int M, int D, int64_t ldx, const float* x, const float* gamma, const float* beta,
+                            float eps, void* yT, float* y32, float* stats);
 int uia_layernorm_bwd(void* stream, int dtype, int M, int D, int64_t ldx, const void* dy, const float* x, const float* gamma,
                       float eps, const float* dres, float* dx32, void* dxT);
 

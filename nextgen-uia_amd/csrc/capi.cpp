@@ -25,7 +25,11 @@ int uia_attn_bwd(void* stream, int dtype, const uia_attn_desc* d) {
     return uia_attn_bwd_launch((hipStream_t)stream, dtype, *d);
 }
 int uia_layernorm_fwd(void* stream, int dtype, int M, int D, int64_t ldx, const float* x, const float* gamma, const float* beta, float eps, void* yT, float* y32) {
-    return uia_layernorm_fwd_launch((hipStream_t)stream, dtype, M, D, ldx, x, gamma, beta, eps, yT, y32);
+    return uia_layernorm_fwd_launch((hipStream_t)stream, dtype, M, D, ldx, x, gamma, beta, eps, yT, y32, nullptr);
+}
+int uia_layernorm_fwd_stats(void* stream, int dtype, int M, int D, int64_t ldx, const float* x, const float* gamma, const float* beta, float eps, void* yT, float* y32,
+                            float* stats) {
+    return uia_layernorm_fwd_launch((hipStream_t)stream, dtype, M, D, ldx, x, gamma, beta, eps, yT, y32, stats);
 }
 int uia_layernorm_bwd(void* stream, int dtype, int M, int D, int64_t ldx, const void* dy, const float* x, const float* gamma, float eps, const float* dres, float* dx32, void* dxT) {
     return uia_layernorm_bwd_launch((hipStream_t)stream, dtype, M, D, ldx, dy, x, gamma, eps, dres, dx32, dxT);

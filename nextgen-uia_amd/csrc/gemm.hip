@@ -177,6 +177,14 @@ __device__ __forceinline__ void gemm_epilogue(const UiaGemmParams& p, f32x4 (&ac
             if (p.resid) {
                 float r[8];
                 load8(p.resid + rrow * p.ldr + n, r);
+                if (p.resid_ln_stats) {                       // the residual is LayerNorm(resid row): same expression as ln_fwd_kernel
+                    const float2 ms = *(const float2*)(p.resid_ln_stats + 2 * rrow);
+                    float lw[8], lb[8];
+                    load8(p.resid_ln_w + n, lw);
+                    load8(p.resid_ln_b + n, lb);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) r[e] = fmaf((r[e] - ms.x) * ms.y, lw[e], lb[e]);
+                }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += r[e];
             }
@@ -217,6 +225,7 @@ template <int MT, int WTN> struct EpiPatch {
 // compiler interleaves two read-back passes.  Specialised masks imply alpha == 1, no row remapping and GELU as the
 // activation; anything else takes the generic instantiation.
 enum : int { EPI_BIAS = 1, EPI_AUX_OUT = 2, EPI_GELU = 4, EPI_DGELU = 8, EPI_RESID = 16, EPI_RESIDT = 32, EPI_OUT32 = 64, EPI_OUTT = 128,
+             EPI_RESID_LN = 256,          // with EPI_RESID: the residual is the LayerNorm of the rows of `resid` (resid_ln_stats / _w / _b)
              EPI_GENERIC = -1 };
 
 template <typename T, int MT, int NT, int WTM, int WTN, int EPI = EPI_GENERIC, bool PATCH16 = false>
@@ -227,6 +236,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const UiaGemmParams& p, f32x4 
     const bool f_aux_out = GEN ? p.aux_out != nullptr : (EPI & EPI_AUX_OUT) != 0;
     const bool f_resid = GEN ? p.resid != nullptr : (EPI & EPI_RESID) != 0;
     const bool f_residT = GEN ? p.residT != nullptr : (EPI & EPI_RESIDT) != 0;
+    const bool f_rln = GEN ? (p.resid != nullptr && p.resid_ln_stats != nullptr) : (EPI & EPI_RESID_LN) != 0;
     const bool f_out32 = GEN ? p.out32 != nullptr : (EPI & EPI_OUT32) != 0;
     const bool f_outT = GEN ? p.outT != nullptr : (EPI & EPI_OUTT) != 0;
     const int act = GEN ? p.act : ((EPI & EPI_GELU) ? UIA_ACT_GELU : UIA_ACT_NONE);
@@ -248,6 +258,10 @@ __device__ __forceinline__ void gemm_epilogue_lds(const UiaGemmParams& p, f32x4 
     for (int e = 0; e < 8; ++e) bias[e] = 0.f;
     if (f_bias && n < p.N) load8(p.bias + n, bias);
     const bool col_ok = n < p.N;
+    float lnw[8], lnb[8];                           // deferred LayerNorm residual: the lane's eight columns of its weight and bias
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { lnw[e] = 1.f; lnb[e] = 0.f; }
+    if (f_rln && col_ok) { load8(p.resid_ln_w + n, lnw); load8(p.resid_ln_b + n, lnb); }
 
     // one row segment of 8 columns: bias / activation / residuals / stores
     auto apply = [&](const f32x4& lo, const f32x4& hi, int m) {
@@ -272,6 +286,11 @@ __device__ __forceinline__ void gemm_epilogue_lds(const UiaGemmParams& p, f32x4 
         if (f_resid && UIA_EPI_LOADS) {
             float r[8];
             load8(p.resid + rrow * p.ldr + n, r);
+            if (f_rln) {                                  // same expression, same operands as ln_fwd_kernel: bit-identical to reading its fp32 output
+                const float2 ms = *(const float2*)(p.resid_ln_stats + 2 * rrow);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) r[e] = fmaf((r[e] - ms.x) * ms.y, lnw[e], lnb[e]);
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += r[e];
         }
@@ -667,7 +686,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_tn_ring_kernel(co
     {   // experiment: de-phase the two workgroups that share a CU (first generation only; later ones inherit the phase)
         const int stg = (xflags >> 10) & 63;                  // delay in units of 4096 cycles
         const bool second = ((xflags >> 16) & 1) ? ((blockIdx.x >> 3) & 1) : ((blockIdx.x >> 8) & 1);
-        if (stg && blockIdx.x < 512 && second) {
+        if (stg && blockIdx.x < (((xflags >> 17) & 1) ? 256 : 512) && second) {   // bit 17: one workgroup per CU (cfg 8): de-phase CUs, not co-residents
             const unsigned long long t0 = __builtin_amdgcn_s_memtime();
             while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)stg * 4096ull) __builtin_amdgcn_s_sleep(32);
         }
@@ -1111,6 +1130,7 @@ inline int epi_mask_of(const UiaGemmParams& p) {
     if (p.alpha != 1.0f || p.out_group > 0 || p.resid_mod > 0) return EPI_GENERIC;
     if ((p.act && p.act != UIA_ACT_GELU) || (p.dact && p.dact != UIA_ACT_GELU)) return EPI_GENERIC;
     return (p.bias ? EPI_BIAS : 0) | (p.aux_out ? EPI_AUX_OUT : 0) | (p.act ? EPI_GELU : 0) | (p.dact ? EPI_DGELU : 0) | (p.resid ? EPI_RESID : 0) |
+           ((p.resid && p.resid_ln_stats) ? EPI_RESID_LN : 0) |
            (p.residT ? EPI_RESIDT : 0) | (p.out32 ? EPI_OUT32 : 0) | (p.outT ? EPI_OUTT : 0);
 }
 
@@ -1121,6 +1141,7 @@ int launch_ring(hipStream_t stream, const UiaGemmParams& p, bool specialise, int
 #define UIA_EPI_CASE(MASK) case (MASK): return launch_ring_epi<T, BM, BN, WAVES_M, WAVES_N, BKB, NBUF, (MASK), LOOP>(stream, p, xflags)
             UIA_EPI_CASE(EPI_BIAS | EPI_RESID | EPI_OUT32);                    // proj / fc2 / Mona project2 forward
             UIA_EPI_CASE(EPI_BIAS | EPI_RESIDT | EPI_OUT32);                   // post-LN (BERT) sub-layer sums on the T residual
+            UIA_EPI_CASE(EPI_BIAS | EPI_RESID | EPI_RESID_LN | EPI_OUT32);     // post-LN (BERT) sub-layer sums, LayerNorm of the previous sum applied here
             UIA_EPI_CASE(EPI_OUTT);                                            // dgrads
             UIA_EPI_CASE(EPI_BIAS | EPI_OUTT);                                 // QKV
             UIA_EPI_CASE(EPI_BIAS | EPI_GELU | EPI_OUTT);                      // fc1, frozen tower
@@ -1226,6 +1247,9 @@ int uia_gemm_launch(hipStream_t stream, int dtype, const UiaGemmParams& p, int c
     UIA_CHECK_ARG(!p.aux_in || (p.ldaux_in % 8 == 0 && (uintptr_t)p.aux_in % 16 == 0), "uia_gemm: aux_in alignment");
     UIA_CHECK_ARG(!p.aux_out || (p.ldaux_out % 8 == 0 && (uintptr_t)p.aux_out % 16 == 0), "uia_gemm: aux_out alignment");
     UIA_CHECK_ARG(p.resid_mod == 0 || p.resid, "uia_gemm: resid_mod without resid");
+    UIA_CHECK_ARG(!p.resid_ln_stats || (p.resid && p.resid_ln_w && p.resid_ln_b), "uia_gemm: resid_ln_stats needs resid, resid_ln_w and resid_ln_b");
+    UIA_CHECK_ARG(!p.resid_ln_stats || ((uintptr_t)p.resid_ln_stats % 8 == 0 && (uintptr_t)p.resid_ln_w % 16 == 0 && (uintptr_t)p.resid_ln_b % 16 == 0),
+                  "uia_gemm: resid_ln alignment");
     // every row the epilogue touches must hold N elements: a leading dimension below N would make row m's tail overwrite row m+1
     UIA_CHECK_ARG(!p.outT || p.ldo >= p.N, "uia_gemm: ldo=%lld < N=%d", (long long)p.ldo, p.N);
     UIA_CHECK_ARG(!p.out32 || p.ldo32 >= p.N, "uia_gemm: ldo32=%lld < N=%d", (long long)p.ldo32, p.N);

@@ -21,7 +21,8 @@ constexpr int LN_MAXV = 4;   // float4 per lane → D ≤ 64*4*4 = 1024
 
 template <typename T>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(int M, int D, long ldx, const float* __restrict__ x, const float* __restrict__ gamma,
-                                                      const float* __restrict__ beta, float eps, T* __restrict__ yT, float* __restrict__ y32) {
+                                                      const float* __restrict__ beta, float eps, T* __restrict__ yT, float* __restrict__ y32,
+                                                      float* __restrict__ stats) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= M) return;
     const int nv = D >> 2;
@@ -45,6 +46,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(int M, int D, long ldx, con
         }
     }
     const float rstd = rsqrtf(wave_sum(q) / D + eps);
+    if (stats && lane == 0) *(float2*)(stats + 2 * (size_t)row) = float2{mean, rstd};   // for uia_gemm's deferred LayerNorm residual
 #pragma unroll
     for (int k = 0; k < LN_MAXV; ++k) {
         const int c = lane + 64 * k;
@@ -121,14 +123,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int M, int D, long ldx, con
 }  // namespace
 
 int uia_layernorm_fwd_launch(hipStream_t stream, int dtype, int M, int D, long ldx, const float* x, const float* gamma, const float* beta,
-                             float eps, void* yT, float* y32) {
+                             float eps, void* yT, float* y32, float* stats) {
     UIA_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 1024, "uia_layernorm_fwd: unsupported shape M=%d D=%d", M, D);
-    UIA_CHECK_ARG(x && gamma && beta && (yT || y32), "uia_layernorm_fwd: null tensor");
+    UIA_CHECK_ARG(x && gamma && beta && (yT || y32 || stats), "uia_layernorm_fwd: null tensor");
     UIA_CHECK_ARG(ldx >= D && ldx % 4 == 0, "uia_layernorm_fwd: row stride %ld", ldx);
-    UIA_CHECK_ARG(((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)yT | (uintptr_t)y32) % 8 == 0, "uia_layernorm_fwd: alignment");
+    UIA_CHECK_ARG(((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)yT | (uintptr_t)y32 | (uintptr_t)stats) % 8 == 0, "uia_layernorm_fwd: alignment");
     const dim3 grid((M + 3) / 4), block(256);
-    if (dtype == UIA_BF16) hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, grid, block, 0, stream, M, D, ldx, x, gamma, beta, eps, (bf16_t*)yT, y32);
-    else if (dtype == UIA_F32) hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, block, 0, stream, M, D, ldx, x, gamma, beta, eps, (float*)yT, y32);
+    if (dtype == UIA_BF16) hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, grid, block, 0, stream, M, D, ldx, x, gamma, beta, eps, (bf16_t*)yT, y32, stats);
+    else if (dtype == UIA_F32) hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, block, 0, stream, M, D, ldx, x, gamma, beta, eps, (float*)yT, y32, stats);
     else { uia_set_error("uia_layernorm_fwd: bad dtype %d", dtype); return -1; }
     UIA_CHECK_LAUNCH();
     return 0;

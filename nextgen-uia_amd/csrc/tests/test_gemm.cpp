@@ -182,6 +182,13 @@ int main(int argc, char** argv) {
         }
         return 0;
     }
+    if (argc > 1 && !strcmp(argv[1], "dephase")) {  // ./test_gemm_exp dephase: cfg 8 (one workgroup per CU), every other first-round workgroup delayed by s x 4096 cycles
+        const int shapes[][4] = {{65536, 768, 768, 2}, {50432, 768, 768, 2}, {65536, 768, 3072, 2}, {65536, 2304, 768, 0}, {65536, 3072, 768, 1}, {50432, 3072, 768, 1}};
+        for (auto& sh : shapes) {
+            for (int s : {0, 2, 4, 6, 8, 12, 16}) { printf("dephase=%d  ", s); bench(UIA_BF16, sh[0], sh[1], sh[2], 8 | (s << 18) | (3 << 24), sh[3]); }
+        }
+        return 0;
+    }
     if (argc > 1 && !strcmp(argv[1], "exp")) {      // ./test_gemm exp: tile-order group size (bits 8..15) x diagnostic K-blocked operand addressing (bits 16, 17)
         const int shapes[][4] = {{50432, 768, 768, 2}, {50432, 2304, 768, 0}, {50432, 3072, 768, 1}, {50432, 768, 3072, 2}, {65536, 3072, 768, 0}, {50432, 768, 2304, 0}};
         for (auto& sh : shapes)

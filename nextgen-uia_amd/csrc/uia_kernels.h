@@ -14,7 +14,7 @@ int uia_gemm_launch(hipStream_t stream, int dtype, const UiaGemmParams& p, int c
 int uia_attn_fwd_launch(hipStream_t stream, int dtype, const UiaAttnParams& p);
 int uia_attn_bwd_launch(hipStream_t stream, int dtype, const UiaAttnParams& p);
 int uia_layernorm_fwd_launch(hipStream_t stream, int dtype, int M, int D, long ldx, const float* x, const float* gamma, const float* beta,
-                             float eps, void* yT, float* y32);
+                             float eps, void* yT, float* y32, float* stats);
 int uia_layernorm_bwd_launch(hipStream_t stream, int dtype, int M, int D, long ldx, const void* dy, const float* x, const float* gamma, float eps,
                              const float* dres, float* dx32, void* dxT);
 int uia_cast_launch(hipStream_t stream, int dtype, size_t n, const float* src, void* dst, float scale);

@@ -29,7 +29,8 @@ class GemmDesc(C.Structure):
     _fields_ = [("A", vp), ("lda", i64), ("W", vp), ("ldw", i64), ("M", i32), ("N", i32), ("K", i32), ("alpha", f32),
                 ("bias", vp), ("act", i32), ("dact", i32), ("aux_in", vp), ("ldaux_in", i64), ("aux_out", vp), ("ldaux_out", i64),
                 ("resid", vp), ("ldr", i64), ("resid_mod", i32), ("resid_row_off", i32), ("residT", vp), ("ldrT", i64),
-                ("out_group", i32), ("outT", vp), ("ldo", i64), ("out32", vp), ("ldo32", i64), ("w_kblocked", i32)]
+                ("out_group", i32), ("outT", vp), ("ldo", i64), ("out32", vp), ("ldo32", i64), ("w_kblocked", i32),
+                ("resid_ln_stats", vp), ("resid_ln_w", vp), ("resid_ln_b", vp)]
 
 
 class AttnDesc(C.Structure):
@@ -58,6 +59,7 @@ PROTOTYPES = {
     "uia_attn_fwd": (C.c_int, [vp, C.c_int, C.POINTER(AttnDesc)]),
     "uia_attn_bwd": (C.c_int, [vp, C.c_int, C.POINTER(AttnDesc)]),
     "uia_layernorm_fwd": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, i64, vp, vp, vp, f32, vp, vp]),
+    "uia_layernorm_fwd_stats": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, i64, vp, vp, vp, f32, vp, vp, vp]),
     "uia_layernorm_bwd": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, i64, vp, vp, vp, f32, vp, vp, vp]),
     "uia_mona_pre_fwd": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, f32, vp]),
     "uia_mona_pre_bwd": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp]),

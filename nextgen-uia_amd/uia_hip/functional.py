@@ -31,6 +31,13 @@ def compute_dtype():
     return _STATE["dtype"]
 
 
+def set_deferred_text_ln(flag):
+    """Scheduling knob of the frozen text tower (results are bit-identical either way): True (default) keeps the fp32 residual of
+    a post-LN sub-layer as the LayerNorm's INPUT + row statistics and lets the consuming GEMM epilogue normalise it; False makes
+    every LayerNorm write its fp32 output as well."""
+    _STATE["text_ln_deferred"] = bool(flag)
+
+
 def set_unpad_text(flag):
     """Opt-in: the frozen text tower computes only the valid tokens of each caption (packed rows + per-caption attention) instead
     of all `context_length` positions.  Features are identical (padded positions never reach the pooled CLS row); what changes
@@ -377,35 +384,66 @@ def vit_block(x, spec):
 
 # ================================================================================================ forward-only pieces
 @torch.no_grad()
-def post_ln_layer(x32, x_t, L, B, heads, P, keylen, eps=1e-12, cu_seqlens=None):
-    """HF BertLayer (post-LN), frozen: returns the new (fp32, T) residual pair.  P: dict of Parameters with the HF
-    names relative to `encoder.layer.{i}.`; q/k/v weights are used as one fused [3D, D] matrix.
+class LnResidual:
+    """The fp32 residual entering a post-LN sub-layer, kept as the INPUT of the LayerNorm that produces it: (raw sum, per-row
+    (mean, rstd), LayerNorm weight, bias).  uia_gemm's epilogue applies the LayerNorm to the rows it reads (resid_ln_*), so the
+    LayerNorm kernel writes only the T operand and 8 bytes of statistics per row instead of a second, fp32 copy of its output
+    (201 MB per LayerNorm at 65536 x 768: 24 of them per step in the BERT tower)."""
+    __slots__ = ("raw", "stats", "w", "b")
+
+    def __init__(self, raw, stats, w, b):
+        self.raw, self.stats, self.w, self.b = raw, stats, w, b
+
+    def gemm_kw(self):
+        return dict(resid=self.raw) if self.stats is None else dict(resid=self.raw, resid_ln=(self.stats, self.w, self.b))
+
+
+def _post_ln(raw, w, b, eps, x_t, stats_buf=None):
+    """LayerNorm of a sub-layer sum: writes the T operand into x_t and returns the fp32 residual for the next sum, deferred
+    (raw + statistics) or — set_deferred_text_ln(False) — materialised in place of the sum."""
+    if _STATE.get("text_ln_deferred", True):
+        stats = stats_buf if stats_buf is not None else torch.empty(raw.shape[0], 2, device=raw.device, dtype=torch.float32)
+        ops.layernorm_fwd(raw, w, b, eps, y_t=x_t, stats=stats)
+        return LnResidual(raw, stats, w, b)
+    ops.layernorm_fwd(raw, w, b, eps, y_t=x_t, y32=raw)
+    return LnResidual(raw, None, w, b)
+
+
+def post_ln_embed(e32, ln, x_t):
+    """LayerNorm of the embedding sum: the T operand of the first layer + the fp32 residual."""
+    return _post_ln(e32, ln.weight, ln.bias, ln.eps, x_t)
+
+
+def post_ln_layer(res, x_t, L, B, heads, P, keylen, eps=1e-12, cu_seqlens=None):
+    """HF BertLayer (post-LN), frozen: returns the new (deferred fp32 residual, T operand) pair.  P: dict of Parameters with the HF
+    names relative to `encoder.layer.{i}.`; q/k/v weights are used as one fused [3D, D] matrix.  res: LnResidual.
     cu_seqlens: rows are PACKED valid tokens (un-padded captions); L is then the longest caption and no mask is needed."""
-    M, D = x32.shape
+    M, D = x_t.shape
     dt = x_t.dtype
     # Post-LN: the residual entering each sub-layer IS the previous LayerNorm's output, so in bf16 mode its T copy (the GEMM
-    # operand) could serve as the residual too (saves the fp32 LN write and half of the epilogue's residual read: 51.7 vs
-    # 52.3 ms per step).  Measured at full depth (tools/text_residual_error.py, 12 layers, bf16 vs fp32 mode): the text
-    # features' error goes from 6.4e-3 to 1.05e-2, past the 1e-2 bound — so it is OFF unless _STATE["text_resid_t"] is set.
+    # operand) could serve as the residual too (saves the residual's fp32 read as well).  Measured at full depth
+    # (tools/text_residual_error.py, 12 layers, bf16 vs fp32 mode): the text features' error goes from 6.4e-3 to 1.05e-2, past the
+    # 1e-2 bound — so it is OFF unless _STATE["text_resid_t"] is set; the default keeps the fp32 residual exactly (LnResidual).
     t_resid = dt != torch.float32 and _STATE.get("text_resid_t", False)
-    qkv = _empty((M, 3 * D), dt, x32)
+    qkv = _empty((M, 3 * D), dt, x_t)
     ops.gemm(x_t, P["_qkv_w"](dt), bias=P["_qkv_b"], out_t=qkv)
-    a = _empty((M, D), dt, x32)
+    a = _empty((M, D), dt, x_t)
     if cu_seqlens is not None:
         ops.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], a, B, heads, L, cu_seqlens=cu_seqlens)
     else:
         ops.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], a, B, heads, L, mask="keypad", keylen=keylen)
-    s = torch.empty_like(x32)
-    res = dict(resid_t=x_t) if t_resid else dict(resid=x32)
-    y32 = None if t_resid else x32
-    ops.gemm(a, WEIGHTS.get(P["attention.output.dense.weight"], dt), bias=P["attention.output.dense.bias"], out32=s, **res)
-    ops.layernorm_fwd(s, P["attention.output.LayerNorm.weight"], P["attention.output.LayerNorm.bias"], eps, y_t=x_t, y32=y32)
+    del qkv
+    s_a = torch.empty(M, D, device=x_t.device, dtype=torch.float32)
+    ops.gemm(a, WEIGHTS.get(P["attention.output.dense.weight"], dt), bias=P["attention.output.dense.bias"], out32=s_a,
+             **(dict(resid_t=x_t) if t_resid else res.gemm_kw()))
+    res_a = _post_ln(s_a, P["attention.output.LayerNorm.weight"], P["attention.output.LayerNorm.bias"], eps, x_t)
     F = P["intermediate.dense.weight"].shape[0]
-    f = _empty((M, F), dt, x32)
+    f = _empty((M, F), dt, x_t)
     ops.gemm(x_t, WEIGHTS.get(P["intermediate.dense.weight"], dt), bias=P["intermediate.dense.bias"], act="gelu", out_t=f)
-    ops.gemm(f, WEIGHTS.get(P["output.dense.weight"], dt), bias=P["output.dense.bias"], out32=s, **res)
-    ops.layernorm_fwd(s, P["output.LayerNorm.weight"], P["output.LayerNorm.bias"], eps, y_t=x_t, y32=y32)
-    return x32, x_t
+    s_o = res.raw                                     # the previous sub-layer sum was last read by the first GEMM above: its storage takes the new sum
+    ops.gemm(f, WEIGHTS.get(P["output.dense.weight"], dt), bias=P["output.dense.bias"], out32=s_o,
+             **(dict(resid_t=x_t) if t_resid else res_a.gemm_kw()))
+    return _post_ln(s_o, P["output.LayerNorm.weight"], P["output.LayerNorm.bias"], eps, x_t, stats_buf=res.stats), x_t
 
 
 class PatchEmbedFn(torch.autograd.Function):

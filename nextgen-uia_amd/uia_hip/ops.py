@@ -18,8 +18,8 @@ _ACT = {None: 0, "none": 0, "gelu": 1, "quick_gelu": 2, "relu": 3}
 GEMM_PROFILE = None
 
 
-EPI_BIAS, EPI_AUX_OUT, EPI_GELU, EPI_DGELU, EPI_RESID, EPI_RESIDT, EPI_OUT32, EPI_OUTT, EPI_GENERIC = 1, 2, 4, 8, 16, 32, 64, 128, -1
-_SPECIALISED = {EPI_BIAS | EPI_RESID | EPI_OUT32, EPI_BIAS | EPI_RESIDT | EPI_OUT32, EPI_OUTT, EPI_BIAS | EPI_OUTT, EPI_BIAS | EPI_GELU | EPI_OUTT, EPI_DGELU | EPI_OUTT,
+EPI_BIAS, EPI_AUX_OUT, EPI_GELU, EPI_DGELU, EPI_RESID, EPI_RESIDT, EPI_OUT32, EPI_OUTT, EPI_RESID_LN, EPI_GENERIC = 1, 2, 4, 8, 16, 32, 64, 128, 256, -1
+_SPECIALISED = {EPI_BIAS | EPI_RESID | EPI_OUT32, EPI_BIAS | EPI_RESIDT | EPI_OUT32, EPI_BIAS | EPI_RESID | EPI_RESID_LN | EPI_OUT32, EPI_OUTT, EPI_BIAS | EPI_OUTT, EPI_BIAS | EPI_GELU | EPI_OUTT, EPI_DGELU | EPI_OUTT,
                 EPI_BIAS | EPI_GELU | EPI_AUX_OUT | EPI_OUTT}
 
 
@@ -30,7 +30,8 @@ def epi_mask_of(d):
     if (d.act and d.act != _ACT["gelu"]) or (d.dact and d.dact != _ACT["gelu"]):
         return EPI_GENERIC
     m = ((EPI_BIAS if d.bias else 0) | (EPI_AUX_OUT if d.aux_out else 0) | (EPI_GELU if d.act else 0) | (EPI_DGELU if d.dact else 0) |
-         (EPI_RESID if d.resid else 0) | (EPI_RESIDT if d.residT else 0) | (EPI_OUT32 if d.out32 else 0) | (EPI_OUTT if d.outT else 0))
+         (EPI_RESID if d.resid else 0) | (EPI_RESIDT if d.residT else 0) | (EPI_OUT32 if d.out32 else 0) | (EPI_OUTT if d.outT else 0) |
+         (EPI_RESID_LN if (d.resid and d.resid_ln_stats) else 0))
     return m
 
 
@@ -147,12 +148,13 @@ def _rowmajor(t, name):
 
 
 def gemm(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None, resid=None, resid_mod=0, resid_row_off=0,
-         resid_t=None, out_group=0, out_t=None, out32=None, alpha=1.0, tile_cfg=0):
+         resid_t=None, out_group=0, out_t=None, out32=None, alpha=1.0, tile_cfg=0, resid_ln=None):
     """C = epilogue(alpha * a @ w.T).  a [M,K], w [N,K] (tensor or PackedW) share a dtype (bf16 | fp32); see include/uia_hip.h.
 
     Host-side scheduling on top of uia_gemm (results do not depend on it): with the automatic tile choice, a weight that came
     as a PackedW is handed to the ring kernels K-blocked, and the M tail of a launch whose last round of tiles would leave most
-    CUs idle goes through a second launch with half-height tiles (tail_split_rows)."""
+    CUs idle goes through a second launch with half-height tiles (tail_split_rows).
+    resid_ln = (stats [M, 2], ln_weight, ln_bias): `resid` is the INPUT of a LayerNorm whose output is the residual to add."""
     packed = w if isinstance(w, PackedW) else None
     wrow = packed.row if packed is not None else w
     M, N = a.shape[0], wrow.shape[0]
@@ -164,14 +166,15 @@ def gemm(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None, res
             cut = lambda t, lo, hi: None if t is None else t[lo:hi]
             for lo, hi, cfg in ((0, m_main, 8), (m_main, M, 13)):
                 _gemm_one(a[lo:hi], w, bias=bias, act=act, dact=dact, aux_in=cut(aux_in, lo, hi), aux_out=cut(aux_out, lo, hi), resid=cut(resid, lo, hi),
-                          resid_t=cut(resid_t, lo, hi), out_t=cut(out_t, lo, hi), out32=cut(out32, lo, hi), alpha=alpha, tile_cfg=cfg)
+                          resid_t=cut(resid_t, lo, hi), out_t=cut(out_t, lo, hi), out32=cut(out32, lo, hi), alpha=alpha, tile_cfg=cfg,
+                          resid_ln=None if resid_ln is None else (resid_ln[0][lo:hi], resid_ln[1], resid_ln[2]))
             return
     _gemm_one(a, w, bias=bias, act=act, dact=dact, aux_in=aux_in, aux_out=aux_out, resid=resid, resid_mod=resid_mod, resid_row_off=resid_row_off,
-              resid_t=resid_t, out_group=out_group, out_t=out_t, out32=out32, alpha=alpha, tile_cfg=tile_cfg)
+              resid_t=resid_t, out_group=out_group, out_t=out_t, out32=out32, alpha=alpha, tile_cfg=tile_cfg, resid_ln=resid_ln)
 
 
 def _gemm_one(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None, resid=None, resid_mod=0, resid_row_off=0,
-              resid_t=None, out_group=0, out_t=None, out32=None, alpha=1.0, tile_cfg=0):
+              resid_t=None, out_group=0, out_t=None, out32=None, alpha=1.0, tile_cfg=0, resid_ln=None):
     d = GemmDesc()
     packed = w if isinstance(w, PackedW) else None
     if packed is not None:
@@ -205,6 +208,13 @@ def _gemm_one(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None
     if resid is not None:
         d.resid, d.ldr = _p(resid), _rowmajor(resid, "resid")
     d.resid_mod, d.resid_row_off, d.out_group = resid_mod, resid_row_off, out_group
+    if resid_ln is not None:
+        st, lw, lb = resid_ln
+        if resid is None or resid_mod or out_group:
+            raise UiaError("gemm resid_ln needs a plain fp32 resid (no row remapping)")
+        if not (st.dtype == lw.dtype == lb.dtype == torch.float32 and st.is_contiguous() and st.numel() >= 2 * d.M and lw.numel() >= d.N and lb.numel() >= d.N):
+            raise UiaError(f"gemm resid_ln: stats {tuple(st.shape)} / weight {tuple(lw.shape)} / bias {tuple(lb.shape)} do not cover [{d.M}, {d.N}]")
+        d.resid_ln_stats, d.resid_ln_w, d.resid_ln_b = _p(st), _p(lw), _p(lb)
     if resid_t is not None:
         d.residT, d.ldrT = _p(resid_t), _rowmajor(resid_t, "resid_t")
     if out_t is not None:
@@ -267,12 +277,16 @@ def attn_bwd(q, k, v, out, dout, lse, dq, dk, dv, B, H, L, mask=None, keylen=Non
     check(lib().uia_attn_bwd(_stream(), _code(q.dtype), C.byref(d)), "uia_attn_bwd")
 
 
-def layernorm_fwd(x, gamma, beta, eps, y_t=None, y32=None, rows=None, ldx=None):
-    """x fp32 [rows, D] (row stride ldx); y_t (bf16|fp32) and/or y32 compact [rows, D]."""
+def layernorm_fwd(x, gamma, beta, eps, y_t=None, y32=None, rows=None, ldx=None, stats=None):
+    """x fp32 [rows, D] (row stride ldx); y_t (bf16|fp32) and/or y32 compact [rows, D]; stats fp32 [rows, 2] receives (mean, rstd)."""
     D = gamma.numel()
     rows = x.numel() // D if rows is None else rows
     ldx = D if ldx is None else ldx
     dt = _code(y_t.dtype) if y_t is not None else _lib.F32
+    if stats is not None:
+        assert stats.dtype == torch.float32 and stats.is_contiguous() and stats.numel() >= 2 * rows
+        check(lib().uia_layernorm_fwd_stats(_stream(), dt, rows, D, ldx, _p(x), _p(gamma), _p(beta), eps, _p(y_t), _p(y32), _p(stats)), "uia_layernorm_fwd_stats")
+        return
     check(lib().uia_layernorm_fwd(_stream(), dt, rows, D, ldx, _p(x), _p(gamma), _p(beta), eps, _p(y_t), _p(y32)), "uia_layernorm_fwd")
 
 

@@ -381,3 +381,31 @@ def test_pack_weights_all_forms_and_cache_refresh():
     assert cache.get(frozen, dt) is cache.get(frozen, dt) and id(frozen) not in cache._packed
     padded = cache.get(ps[2], dt, pad_rows_to=128)
     assert tuple(padded.shape) == (128, 40) and torch.equal(padded.row[:96], ps[2].detach().to(dt))
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp32"])
+@pytest.mark.parametrize("M,N,K,cfg", [(700, 768, 768, 0), (4096, 768, 3072, 8), (300, 256, 128, 3)])
+def test_gemm_deferred_layernorm_residual_is_bit_identical(mode, M, N, K, cfg):
+    """uia_gemm with resid_ln_* (the residual is LayerNorm(resid rows), statistics from uia_layernorm_fwd_stats) must give exactly
+    what the two-step form gives: LayerNorm writes its fp32 output, the GEMM adds it (HF BertSelfOutput / BertOutput)."""
+    from uia_hip import ops
+    torch.manual_seed(11)
+    dt = torch.bfloat16 if mode == "bf16" else torch.float32
+    a = torch.randn(M, K, device=dev()).to(dt)
+    w = (torch.randn(N, K, device=dev()) * K ** -0.5).to(dt)
+    bias = torch.randn(N, device=dev())
+    raw = torch.randn(M, N, device=dev()) * 3 + 0.5
+    lw, lb = torch.randn(N, device=dev()), torch.randn(N, device=dev())
+    y32 = torch.empty_like(raw)
+    y_t = torch.empty(M, N, device=dev(), dtype=dt)
+    stats = torch.empty(M, 2, device=dev())
+    ops.layernorm_fwd(raw, lw, lb, 1e-12, y_t=y_t, y32=y32, stats=stats)
+    mu = raw.double().mean(1)
+    assert float((stats[:, 0].double() - mu).abs().max()) < 1e-5
+    assert float((stats[:, 1].double() * (raw.double().var(1, unbiased=False) + 1e-12).sqrt() - 1).abs().max()) < 1e-5
+    two_step, fused = torch.empty(M, N, device=dev()), torch.empty(M, N, device=dev())
+    ops.gemm(a, w, bias=bias, resid=y32, out32=two_step, tile_cfg=cfg)
+    ops.gemm(a, w, bias=bias, resid=raw, resid_ln=(stats, lw, lb), out32=fused, tile_cfg=cfg)
+    assert torch.equal(two_step, fused)
+    with pytest.raises(Exception):
+        ops.gemm(a, w, bias=bias, resid_ln=(stats, lw, lb), out32=fused)                    # statistics without a residual
