@@ -19,6 +19,7 @@
 //   fetched from the row-major V tile with ds_read_b64_tr_b16 (hardware transpose), so V is never
 //   transposed in memory.
 // fp32 path (parity mode): plain VALU two-pass softmax, one query per thread.
+#include <type_traits>
 #include "uia_common.h"
 #include "uia_kernels.h"
 
@@ -42,7 +43,7 @@ __device__ __forceinline__ s16x4 lds_tr16(const char* p) {
 // 93 -> 74 us).  Thirteen waves with one tile each leave one workgroup per CU and are slower (124 us); waiting for K and V
 // separately (scores under the V landing, LDS-DMA from inline asm with counted vmcnt) was slower too (120 us).
 template <int LT_MAX, int NW>
-__global__ __launch_bounds__(64 * NW) void attn_fwd_bf16_kernel(const UiaAttnParams p) {
+__global__ __launch_bounds__(64 * NW, NW >= 7 ? 4 : 1) void attn_fwd_bf16_kernel(const UiaAttnParams p) {   // two 7/8-wave workgroups per CU: ≤ 128 VGPRs
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NP_MAX = (LT_MAX + 1) / 2;
     const int bb = blockIdx.x / p.H;
@@ -122,27 +123,33 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_bf16_kernel(const UiaAttnPar
         constexpr int NCH = (LT_MAX + 3) / 4;
         const int kmax = p.mask_kind == UIA_MASK_CAUSAL ? (qrow < klen - 1 ? qrow : klen - 1) : klen - 1;  // last valid key
         f32x4 s[4 * NCH];
-        float m = -INFINITY;
+        float m = -INFINITY;                                     // row max of the RAW scores (scale > 0: the scaled max is m·sc)
+        // one key tile: scores of 16 keys for this lane's query.  TEST = false for chunks that lie entirely inside the valid keys of a
+        // non-causal head: no per-element compare / select (the 197-token image heads spend 12 of their 13 tiles there).
+        auto tile = [&](int t, auto test) {
+            const int tl = t < 2 * NP ? t : 2 * NP - 1;              // stay inside the LDS allocation
+            const uint4 k0 = *(const uint4*)(Ks + tl * 2048 + offK0);
+            const uint4 k1 = *(const uint4*)(Ks + tl * 2048 + (offK0 ^ 64));
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, k0), __builtin_bit_cast(bf16x8, q0), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, k1), __builtin_bit_cast(bf16x8, q1), acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {                             // lane owns query qrow, keys 16t + 4g + r
+                if (decltype(test)::value) acc[r] = (16 * t + 4 * g + r) <= kmax ? acc[r] : -INFINITY;
+                m = fmaxf(m, acc[r]);
+            }
+            s[t] = acc;
+        };
+        const int interior = p.mask_kind == UIA_MASK_CAUSAL ? 0 : klen >> 6;     // chunks of 4 tiles (64 keys) with no masked key
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             if (4 * c < LTq) {
+                if (c < interior) {
 #pragma unroll
-                for (int t = 4 * c; t < 4 * c + 4; ++t) {
-                    const int tl = t < 2 * NP ? t : 2 * NP - 1;              // stay inside the LDS allocation
-                    const uint4 k0 = *(const uint4*)(Ks + tl * 2048 + offK0);
-                    const uint4 k1 = *(const uint4*)(Ks + tl * 2048 + (offK0 ^ 64));
-                    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, k0), __builtin_bit_cast(bf16x8, q0), acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, k1), __builtin_bit_cast(bf16x8, q1), acc, 0, 0, 0);
-                    // ---- mask, row max (lane owns query qrow, keys 16t + 4g + r)
+                    for (int t = 4 * c; t < 4 * c + 4; ++t) tile(t, std::false_type{});
+                } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int key = 16 * t + 4 * g + r;
-                        const float v = key <= kmax ? acc[r] * sc : -INFINITY;
-                        acc[r] = v;
-                        m = fmaxf(m, v);
-                    }
-                    s[t] = acc;
+                    for (int t = 4 * c; t < 4 * c + 4; ++t) tile(t, std::true_type{});
                 }
             } else {
 #pragma unroll
@@ -151,6 +158,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_bf16_kernel(const UiaAttnPar
         }
         m = fmaxf(m, __shfl_xor(m, 16, 64));
         m = fmaxf(m, __shfl_xor(m, 32, 64));
+        const float msc = m * sc;                                // softmax in base 2: exp2(s·sc − m·sc), one fma per element
         float sum = 0.f;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
@@ -159,7 +167,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_bf16_kernel(const UiaAttnPar
                 for (int t = 4 * c; t < 4 * c + 4; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float e = __builtin_amdgcn_exp2f(s[t][r] - m);      // exp2(-inf) = 0 for masked keys
+                        const float e = __builtin_amdgcn_exp2f(fmaf(s[t][r], sc, -msc));      // exp2(-inf) = 0 for masked keys
                         s[t][r] = e;
                         sum += e;
                     }
@@ -201,7 +209,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_bf16_kernel(const UiaAttnPar
                 const f32x4 v = {o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv};
                 store4(orow + 16 * dt, v);
             }
-            if (p.lse && g == 0) p.lse[((size_t)b * p.H + h) * L + qrow] = (m + log2f(sum)) * 0.69314718055994531f;
+            if (p.lse && g == 0) p.lse[((size_t)b * p.H + h) * L + qrow] = (msc + log2f(sum)) * 0.69314718055994531f;
         }
     }
 }
