@@ -1171,6 +1171,87 @@ int launch_persist(hipStream_t stream, const UiaGemmParams& p) {
     return launch_persist_epi<T, EPI_GENERIC>(stream, p);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Tile cfg 16 — N = 64 (the adapters' down-projections and their data gradients: Mona project1 forward, project2 dgrad; 768 → 64):
+// 2·M·64·K FLOP against M·K·2 bytes of A is 64 FLOP per byte, i.e. the launch is a stream over A.  One workgroup per CU keeps ALL of W
+// (64 x K bf16, ≤ 160 KB) in LDS for its lifetime; every wave walks 16-row tiles of A with its fragments loaded straight from HBM
+// into registers (16 rows x 64 contiguous bytes per instruction, CH instructions in flight per wave) and W as the MFMA A operand,
+// so that a lane ends up with four consecutive outputs of one row.  The 256 x 64 tile config had 197 workgroups for 256 CUs, each
+// streaming its rows through a double-buffered LDS ring with a barrier per K step: 35 / 34 us inside the step; this one 31 / 26 (14 at HBM rate).
+template <int CH>      // K steps (32 columns each) whose A fragments a wave requests before it starts multiplying
+__global__ __launch_bounds__(512) void gemm_skinny64_kernel(const UiaGemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int K = p.K, KS = K >> 5;
+    const int ldw_b = 2 * K + 16;                          // row stride of the W image: +16 B staggers the rows over the banks
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    {
+        const int cpr = K >> 3;                            // 16-byte chunks per row of W
+        for (int c = tid; c < 64 * cpr; c += 512) {
+            const int r = c / cpr, cc = c - r * cpr;
+            *(uint4*)(smem + r * ldw_b + cc * 16) = *(const uint4*)((const char*)p.W + ((size_t)r * p.ldw) * 2 + cc * 16);
+        }
+    }
+    __syncthreads();
+    float bias[4][4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias[nt][r] = p.bias ? p.bias[16 * nt + 4 * g + r] : 0.f;
+    const char* wfrag = smem + li * ldw_b + g * 16;        // W row 16nt + li, bytes 64ks + 16g: + nt·16·ldw_b + ks·64
+    const int ntiles = (p.M + 15) >> 4;
+    for (int tile = blockIdx.x * 8 + wave; tile < ntiles; tile += gridDim.x * 8) {
+        const int m = 16 * tile + li;
+        const int mc = m < p.M ? m : p.M - 1;
+        const char* arow = (const char*)p.A + ((size_t)mc * p.lda) * 2 + g * 16;
+        f32x4 acc[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        for (int ks0 = 0; ks0 < KS; ks0 += CH) {
+            uint4 a[CH];
+#pragma unroll
+            for (int i = 0; i < CH; ++i) a[i] = ks0 + i < KS ? *(const uint4*)(arow + (ks0 + i) * 64) : uint4{0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                if (ks0 + i < KS) {
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        const uint4 wf = *(const uint4*)(wfrag + nt * 16 * ldw_b + (ks0 + i) * 64);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf), __builtin_bit_cast(bf16x8, a[i]), acc[nt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (m < p.M) {                                     // lane: row m, columns 16nt + 4g .. +3
+            bf16_t* orow = (bf16_t*)p.outT + (size_t)m * p.ldo + 4 * g;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const f32x4 v = {acc[nt][0] + bias[nt][0], acc[nt][1] + bias[nt][1], acc[nt][2] + bias[nt][2], acc[nt][3] + bias[nt][3]};
+                store4(orow + 16 * nt, v);
+            }
+        }
+    }
+}
+
+// cfg 16 takes: bf16, N == 64, K % 32 == 0 with the W image inside the LDS, and nothing in the epilogue but an optional bias and the T output
+inline bool skinny64_ok(const UiaGemmParams& p, int esz) {
+    return esz == 2 && p.N == 64 && p.K % 32 == 0 && 64 * (2 * p.K + 16) <= 160 * 1024 && p.alpha == 1.0f && p.outT && !p.out32 && !p.act && !p.dact &&
+           !p.aux_out && !p.resid && !p.residT && p.out_group == 0 && !p.w_kblocked;
+}
+
+int launch_skinny64(hipStream_t stream, const UiaGemmParams& p) {
+    const int lds = 64 * (2 * p.K + 16);
+    static UiaDevOnce once8;
+    UIA_ENSURE_LDS_ATTR(once8, gemm_skinny64_kernel<8>, 160 * 1024);
+    const int ncu = uia_num_cus();
+    const int ntiles = (p.M + 15) / 16;
+    int grid = (ntiles + 7) / 8;
+    grid = grid < ncu ? grid : ncu;
+    // eight K steps (8 KiB per wave) in flight: requesting a whole 768-wide row tile at once (24 steps, 160 VGPRs) measured slower
+    // inside the step (34 / 30 us against 31 / 26 for the two Mona launches)
+    hipLaunchKernelGGL(gemm_skinny64_kernel<8>, dim3(grid), dim3(512), lds, stream, p);
+    UIA_CHECK_LAUNCH();
+    return 0;
+}
+
 template <typename T>
 int launch_typed(hipStream_t stream, const UiaGemmParams& p, int cfg_in) {
     // bits 8.. of the tile argument carry experiment knobs for the ring kernels (tile-order group size, diagnostic layouts);
@@ -1180,7 +1261,7 @@ int launch_typed(hipStream_t stream, const UiaGemmParams& p, int cfg_in) {
     // cfg: 0 = auto. Tile choice is a pure speed knob (results are identical for every config
     // up to fp32 summation order inside a K-step, which does not depend on the tile).
     if (cfg == 0) {
-        if (p.N <= 64) cfg = 4;
+        if (p.N <= 64) cfg = (p.M > 2048 && skinny64_ok(p, (int)sizeof(T))) ? 16 : 4;
         else if (p.M <= 2048) cfg = 3;
         else if (p.K * (int)sizeof(T) <= 128) cfg = 14;   // one K step (Mona project2 / project1-dgrad, K = 64): nothing but prologue + epilogue, HBM-bound:
                                                           // half-height tiles, two workgroups per CU (70.9 vs 86.6 us and 20.0 vs 26.3 us at M = 50 432)
@@ -1213,6 +1294,9 @@ int launch_typed(hipStream_t stream, const UiaGemmParams& p, int cfg_in) {
         case 9: return launch_ring<T, 256, 128, 4, 2, 128, 3>(stream, p, false, xflags);
         case 10: return launch_ring<T, 256, 256, 2, 4, 64, 4>(stream, p, false, xflags);   // cfg 8 with the run-time (generic) epilogue: parity cross-check
         case 12: return launch_persist<T>(stream, p);
+        case 16:
+            if (!skinny64_ok(p, (int)sizeof(T))) { uia_set_error("uia_gemm: tile cfg 16 is the bf16 N = 64 stream kernel (bias + T output only)"); return -1; }
+            return launch_skinny64(stream, p);
 #ifdef UIA_GEMM_EXP
         case 15: return launch_ring<T, 256, 256, 2, 4, 64, 4, 1>(stream, p, true, xflags);  // free-running loop (two fragment sets, one barrier per sub-tile):
                                                                                             // 5-10 % SLOWER than the ping-pong loop on every shape; experiment builds only

@@ -38,7 +38,8 @@ def epi_mask_of(d):
 def auto_tile_cfg(M, N, K=None, esz=2, mask=EPI_GENERIC):
     """Mirror of launch_typed() in csrc/gemm.hip (which kernel instantiation a shape runs on)."""
     if N <= 64:
-        return 4
+        stream64 = N == 64 and M > 2048 and esz == 2 and K is not None and K % 32 == 0 and 64 * (2 * K + 16) <= 160 * 1024
+        return 16 if (stream64 and mask in (EPI_OUTT, EPI_BIAS | EPI_OUTT)) else 4
     if M <= 2048:
         return 3
     if K is not None and K * esz <= 128:
@@ -113,6 +114,8 @@ def gemm_kernel_name(cfg, mask, dtype):
     if cfg in (8, 13, 14):
         bm, nbuf = (256, 4) if cfg == 8 else ((128, 4) if cfg == 13 else (128, 3))
         return f"gemm_tn_ring_kernel<{tn},{bm},256,2,4,64,{nbuf},{m}>", "gemm_tn_ring_kernelI" + tc + "".join(mi(v) for v in (bm, 256, 2, 4, 64, nbuf, m, 0)) + "E"
+    if cfg == 16:
+        return "gemm_skinny64_kernel", "gemm_skinny64_kernel"
     shape = {1: (256, 256, 2, 4), 2: (256, 128, 4, 2), 3: (128, 128, 2, 2), 4: (256, 64, 4, 1), 5: (128, 64, 2, 1)}.get(cfg)
     if shape:
         return f"gemm_tn_kernel<{tn},{','.join(map(str, shape))}>", "gemm_tn_kernelI" + tc + "".join(mi(v) for v in shape) + "E"
@@ -230,6 +233,8 @@ def _gemm_one(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None
         nbytes = esz * (d.M * d.K + d.N * d.K) + d.M * d.N * (esz * sum(t is not None for t in (aux_in, aux_out, resid_t, out_t))
                                                              + 4 * sum(t is not None for t in (resid, out32)))
         mask = epi_mask_of(d)
+        if not (tile_cfg & 255):
+            base_cfg = auto_tile_cfg(d.M, d.N, d.K, esz, mask)
         GEMM_PROFILE.append((e0, e1, d.M, d.N, d.K, a.dtype, base_cfg, nbytes, mask))
         return
     check(lib().uia_gemm(_stream(), _code(a.dtype), C.byref(d), tile_cfg), "uia_gemm")

@@ -409,3 +409,26 @@ def test_gemm_deferred_layernorm_residual_is_bit_identical(mode, M, N, K, cfg):
     assert torch.equal(two_step, fused)
     with pytest.raises(Exception):
         ops.gemm(a, w, bias=bias, resid_ln=(stats, lw, lb), out32=fused)                    # statistics without a residual
+
+
+@pytest.mark.parametrize("M,K,with_bias", [(50432, 768, True), (3000, 768, False), (2049, 64, True), (4100, 1024, True)])
+def test_gemm_n64_stream_kernel(M, K, with_bias):
+    """Tile cfg 16 (N = 64: W resident in LDS, A streamed from HBM into MFMA fragments) against the 256x64 tile config and torch;
+    ragged M, the automatic choice, and the rejection of epilogues it does not carry."""
+    from uia_hip import ops
+    torch.manual_seed(21)
+    a = torch.randn(M, K, device=dev()).bfloat16()
+    w = (torch.randn(64, K, device=dev()) * K ** -0.5).bfloat16()
+    bias = torch.randn(64, device=dev()) if with_bias else None
+    y16, y4, yauto = (torch.empty(M, 64, device=dev(), dtype=torch.bfloat16) for _ in range(3))
+    ops.gemm(a, w, bias=bias, out_t=y16, tile_cfg=16)
+    ops.gemm(a, w, bias=bias, out_t=y4, tile_cfg=4)
+    ops.gemm(a, w, bias=bias, out_t=yauto)
+    ref = a.float() @ w.float().t() + (bias if with_bias else 0)
+    scale = float(ref.abs().max())
+    assert float((y16.float() - ref).abs().max()) < 1e-2 * scale
+    assert float((y16.float() - y4.float()).abs().max()) < 1e-2 * scale            # same products, different summation order inside fp32
+    assert torch.equal(yauto, y16)                                                  # M > 2048, bias + T output: the automatic choice
+    assert ops.auto_tile_cfg(M, 64, K, 2, ops.EPI_BIAS | ops.EPI_OUTT) == 16
+    with pytest.raises(Exception):
+        ops.gemm(a, w, bias=bias, act="gelu", out_t=y16, tile_cfg=16)
