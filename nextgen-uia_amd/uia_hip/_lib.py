@@ -6,6 +6,7 @@ wrapper raises if handed a non-CUDA tensor.
 """
 import ctypes as C
 import os
+import re
 
 import torch  # noqa: F401  -- must come first: libuia_hip.so has to bind to the SAME libamdhip64 that PyTorch loaded
 
@@ -134,7 +135,8 @@ def _one_copy_of(stem):
     """Fail loudly if two different files of a runtime library are mapped into this process (e.g. /opt/rocm/lib/librccl.so beside
     torch/lib/librccl.so): collectives or streams created through one copy are invisible to the other."""
     try:
-        paths = {line.split()[-1] for line in open("/proc/self/maps") if stem in line and ".so" in line}
+        pat = re.compile(r"^" + re.escape(stem) + r"\.so(\.\d+)*$")         # the runtime itself, not plugins that share its prefix
+        paths = {line.split()[-1] for line in open("/proc/self/maps") if pat.match(os.path.basename(line.split()[-1]) if line.split() else "")}
     except OSError:
         return
     real = {os.path.realpath(p) for p in paths}
