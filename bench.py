@@ -14,6 +14,7 @@ InfoNCE + backward through blocks 11..1 and all 12 adapters + gradient clipping 
 before the timed region.  Prints ONE JSON line on rank 0.
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -144,7 +145,8 @@ def main():
     model = create_biomedclip(seed=0)                                # same weights on every rank (random init: no network for checkpoints)
     for p in model.parameters():
         p.requires_grad_(False)
-    inject_mona_variant_to_open_clip(model, variant=args.variant, bottleneck_dim=64)
+    with contextlib.redirect_stdout(sys.stderr):          # the injector's banner (reference-compatible print) must not share stdout with the JSON line
+        inject_mona_variant_to_open_clip(model, variant=args.variant, bottleneck_dim=64)
     for k, p in model.named_parameters():
         p.requires_grad_("mona" in k.lower())                        # finetune.py:173-175
     cpu_state = {k: v.detach().clone() for k, v in model.state_dict().items()} if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
