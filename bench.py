@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--no-overlap-text", action="store_true", help=argparse.SUPPRESS)        # former spelling of the default
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--no-ln-fold", action="store_true", help="A/B: run the stand-alone LayerNorm kernels instead of folding each frozen LayerNorm into the "
+                    "GEMMs on either side of it (UF.set_ln_fold)")
     ap.add_argument("--no-deferred-text-ln", action="store_true", help="scheduling A/B (same results): every text-tower LayerNorm also writes its fp32 output "
                     "instead of leaving it to the consuming GEMM epilogue")
     ap.add_argument("--unpad-text", action="store_true", help="opt-in: the frozen text tower computes only the valid tokens of each caption "
@@ -140,6 +142,7 @@ def main():
     UF.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
     UF.set_unpad_text(args.unpad_text)
     UF.set_deferred_text_ln(not args.no_deferred_text_ln)
+    UF.set_ln_fold(not args.no_ln_fold)
     ops.KBLOCK_W, ops.TAIL_SPLIT, ops.K64_CFG14 = not args.no_kblock_w, not args.no_tail_split, not args.no_k64_cfg14
 
     model = create_biomedclip(seed=0)                                # same weights on every rank (random init: no network for checkpoints)
@@ -280,7 +283,7 @@ def main():
                                       "InfoNCE, clip+AdamW; random-init weights",
                           "mona_variant": args.variant, "batch_per_gpu": args.batch, "global_batch": args.batch * world, "image": "3x224x224",
                           "text_len": 256, "text_positions_computed": "valid tokens only (opt-in --unpad-text)" if args.unpad_text else "all 256",
-                          "parallelism": f"dp{world}", "text_tower_stream": "second stream" if args.overlap_text else "same stream", "contrastive_batch": "global (opt-in)" if args.global_loss else "per-rank (reference-equivalent)", "mona_dropout": 0.1, "bert_dropout_emulated": False,
+                          "parallelism": f"dp{world}", "text_tower_stream": "second stream" if args.overlap_text else "same stream", "contrastive_batch": "global (opt-in)" if args.global_loss else "per-rank (reference-equivalent)", "mona_dropout": 0.1, "bert_dropout_emulated": False, "layernorm": "stand-alone kernels" if args.no_ln_fold else "folded into the neighbouring GEMMs (row sums in the producer epilogue, normalised accumulators in the consumer)",
                           "gflop_per_pair_algorithmic": GFLOP_PER_PAIR},
                "loss": round(final_loss, 5), "roofline": roof}
         if cpu_state is not None:

@@ -71,6 +71,20 @@ typedef struct uia_gemm_desc {
                                            (HF BertSelfOutput / BertOutput: LayerNorm(dense(h) + input_tensor) [third-party]) */
     const float* resid_ln_w;
     const float* resid_ln_b;
+    /* LayerNorm folded into the GEMMs on either side of it (frozen affine; timm Block norm1 / norm2 and HF BertSelfOutput / BertOutput
+     * LayerNorm [third-party], model.py:163-169 + 181-202 for the OpenAI blocks): the PRODUCER of the normalised rows x adds their row
+     * sums to `rowsum_out` while it stores them (and can write their T copy through outT beside out32); the CONSUMER takes that T copy of
+     * the RAW rows as A and a weight whose columns are pre-scaled by the LayerNorm weight, W'[n][k] = W[n][k]·ln_w[k], and evaluates
+     *     LN(x)·Wᵀ + b  =  rstd_m·(x·W'ᵀ − mean_m·colsum[n]) + (b + W·ln_b)[n]
+     * in its epilogue (the caller passes colsum[n] = Σ_k W'[n][k] and the combined bias as `bias`), so the stand-alone LayerNorm pass
+     * over the rows (read 4 B, write 2 B per element) disappears. */
+    float* rowsum_out;                  /* non-null: rowsum_out[2m] += Σ_n v[m][n], rowsum_out[2m+1] += Σ_n v[m][n]² over the N columns of the fp32
+                                           result v this launch stores (fp32 atomics: caller zeroes; summation order is not fixed) */
+    const float* lnfold_sums;           /* non-null: A holds raw rows; (Σ, Σ²) of row m over lnfold_dim columns at lnfold_sums[2m], [2m+1] */
+    const float* lnfold_colsum;         /* [N] fp32 column sums of the pre-scaled weight */
+    int32_t lnfold_dim; float lnfold_eps;
+    int32_t resid_ln_dim; float resid_ln_eps;   /* resid_ln_dim > 0: resid_ln_stats holds (Σ, Σ²) over resid_ln_dim columns as rowsum_out leaves
+                                                   them, not (mean, rstd); mean = Σ/dim, rstd = rsqrt(max(Σ²/dim − mean², 0) + resid_ln_eps) */
 } uia_gemm_desc;
 int uia_gemm(void* stream, int dtype, const uia_gemm_desc* d, int tile_cfg /* 0 = auto */);
 

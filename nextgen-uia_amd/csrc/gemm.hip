@@ -138,6 +138,30 @@ __device__ __forceinline__ void glds16_asm(const char* gsrc, char* lds_wave_base
                  : "memory");
 }
 
+// (mean, rstd, -mean·rstd) of a row from its (Σ, Σ²) over `dim` columns, as the rowsum_out feature of a producing GEMM leaves them
+struct LnRow { float mean, rstd, nmr; };
+__device__ __forceinline__ LnRow ln_row_from_sums(float2 ss, int dim, float eps) {
+    const float inv = 1.0f / (float)dim;
+    const float mean = ss.x * inv;
+    const float var = fmaxf(fmaf(-mean, mean, ss.y * inv), 0.0f);
+    const float rstd = rsqrtf(var + eps);
+    return LnRow{mean, rstd, -mean * rstd};
+}
+
+// sum over the LPR consecutive lanes that share a row in the LDS-staged epilogue (LPR = 8: two quad permutes + a half-row mirror, all DPP)
+template <int LPR>
+__device__ __forceinline__ float row_lanes_sum(float v) {
+    if constexpr (LPR == 8) {
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    } else {
+#pragma unroll
+        for (int o = 1; o < LPR; o <<= 1) v += __shfl_xor(v, o);
+    }
+    return v;
+}
+
 template <typename T, int MT, int NT, int WTM, int WTN>
 __device__ __forceinline__ void gemm_epilogue(const UiaGemmParams& p, f32x4 (&acc)[MT][NT], int m0, int n0, int wm, int wn, int li, int g) {
     // ---- epilogue: lane owns row m, columns nb .. nb+4NT-1 (nb multiple of 16)
@@ -159,6 +183,14 @@ __device__ __forceinline__ void gemm_epilogue(const UiaGemmParams& p, f32x4 (&ac
             float v[8];
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] = acc[i][jj][e] * p.alpha; v[4 + e] = acc[i][jj + 1][e] * p.alpha; }
+            if (p.lnfold_sums) {                          // LayerNorm folded into this GEMM: A held the raw rows (include/uia_hip.h)
+                const float2 ss = *(const float2*)(p.lnfold_sums + 2 * (size_t)m);
+                const LnRow ln = ln_row_from_sums(ss, p.lnfold_dim, p.lnfold_eps);
+                float cs[8];
+                load8(p.lnfold_colsum + n, cs);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], ln.rstd, ln.nmr * cs[e]);
+            }
             if (p.bias) {
                 float b[8];
                 load8(p.bias + n, b);
@@ -178,7 +210,8 @@ __device__ __forceinline__ void gemm_epilogue(const UiaGemmParams& p, f32x4 (&ac
                 float r[8];
                 load8(p.resid + rrow * p.ldr + n, r);
                 if (p.resid_ln_stats) {                       // the residual is LayerNorm(resid row): same expression as ln_fwd_kernel
-                    const float2 ms = *(const float2*)(p.resid_ln_stats + 2 * rrow);
+                    float2 ms = *(const float2*)(p.resid_ln_stats + 2 * rrow);
+                    if (p.resid_ln_dim > 0) { const LnRow ln = ln_row_from_sums(ms, p.resid_ln_dim, p.resid_ln_eps); ms = float2{ln.mean, ln.rstd}; }
                     float lw[8], lb[8];
                     load8(p.resid_ln_w + n, lw);
                     load8(p.resid_ln_b + n, lb);
@@ -196,6 +229,13 @@ __device__ __forceinline__ void gemm_epilogue(const UiaGemmParams& p, f32x4 (&ac
             }
             if (p.out32) store8(p.out32 + orow * p.ldo32 + n, v);
             if (outT) store8(outT + orow * p.ldo + n, v);
+            if (p.rowsum_out) {                           // small-M configs: one pair of atomics per 8-column segment
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { s1 += v[e]; s2 = fmaf(v[e], v[e], s2); }
+                atomicAdd(p.rowsum_out + 2 * orow, s1);
+                atomicAdd(p.rowsum_out + 2 * orow + 1, s2);
+            }
         }
     }
 }
@@ -226,11 +266,13 @@ template <int MT, int WTN> struct EpiPatch {
 // activation; anything else takes the generic instantiation.
 enum : int { EPI_BIAS = 1, EPI_AUX_OUT = 2, EPI_GELU = 4, EPI_DGELU = 8, EPI_RESID = 16, EPI_RESIDT = 32, EPI_OUT32 = 64, EPI_OUTT = 128,
              EPI_RESID_LN = 256,          // with EPI_RESID: the residual is the LayerNorm of the rows of `resid` (resid_ln_stats / _w / _b)
+             EPI_ROWSUM = 512,            // rowsum_out: (Σ, Σ²) of the stored fp32 rows, for the LayerNorm folded into the consuming GEMM
+             EPI_LNFOLD = 1024,           // lnfold_*: A held raw rows, the LayerNorm is applied to the accumulators
              EPI_GENERIC = -1 };
 
 template <typename T, int MT, int NT, int WTM, int WTN, int EPI = EPI_GENERIC, bool PATCH16 = false>
 __device__ __forceinline__ void gemm_epilogue_lds(const UiaGemmParams& p, f32x4 (&acc)[MT][NT], char* smem, int wave, int lane, int m0, int n0,
-                                                  int wm, int wn) {
+                                                  int wm, int wn, float* lnrow_lds = nullptr, const float2* lnpre = nullptr) {
     constexpr bool GEN = EPI == EPI_GENERIC;
     const bool f_bias = GEN ? p.bias != nullptr : (EPI & EPI_BIAS) != 0;
     const bool f_aux_out = GEN ? p.aux_out != nullptr : (EPI & EPI_AUX_OUT) != 0;
@@ -239,6 +281,8 @@ __device__ __forceinline__ void gemm_epilogue_lds(const UiaGemmParams& p, f32x4 
     const bool f_rln = GEN ? (p.resid != nullptr && p.resid_ln_stats != nullptr) : (EPI & EPI_RESID_LN) != 0;
     const bool f_out32 = GEN ? p.out32 != nullptr : (EPI & EPI_OUT32) != 0;
     const bool f_outT = GEN ? p.outT != nullptr : (EPI & EPI_OUTT) != 0;
+    const bool f_rowsum = GEN ? p.rowsum_out != nullptr : (EPI & EPI_ROWSUM) != 0;
+    const bool f_lnfold = GEN ? p.lnfold_sums != nullptr : (EPI & EPI_LNFOLD) != 0;
     const int act = GEN ? p.act : ((EPI & EPI_GELU) ? UIA_ACT_GELU : UIA_ACT_NONE);
     const int dact = GEN ? p.dact : ((EPI & EPI_DGELU) ? UIA_ACT_GELU : UIA_ACT_NONE);
     using EP = EpiPatch<MT, WTN>;
@@ -262,14 +306,48 @@ __device__ __forceinline__ void gemm_epilogue_lds(const UiaGemmParams& p, f32x4 
 #pragma unroll
     for (int e = 0; e < 8; ++e) { lnw[e] = 1.f; lnb[e] = 0.f; }
     if (f_rln && col_ok) { load8(p.resid_ln_w + n, lnw); load8(p.resid_ln_b + n, lnb); }
+    float csum[8];                                  // folded LayerNorm: the lane's eight column sums of the pre-scaled weight
+#pragma unroll
+    for (int e = 0; e < 8; ++e) csum[e] = 0.f;
+    if (f_lnfold && col_ok) load8(p.lnfold_colsum + n, csum);
+    // Folded LayerNorm: (rstd, -mean·rstd) of the wave's WTM rows, staged ONCE in the wave's own LDS strip.  Reading the row sums from
+    // global memory inside the row loop put one L2 round trip on the critical path of every pass of an epilogue that has no other
+    // load (QKV: 224 -> 247 us per launch); staged, the pass reads them like its accumulators.
+    const int mrow0 = m0 + wm * WTM;
+    if (f_lnfold && lnrow_lds) {
+#pragma unroll
+        for (int i = 0; i < (WTM + 63) / 64; ++i) {
+            const int r = lane + 64 * i, m = mrow0 + r;
+            if (r < WTM) {
+                // lnpre: the caller requested the sums before its K loop (the ring kernel), so nothing waits on memory here
+                const float2 ss = lnpre ? lnpre[i] : (m < p.M ? *(const float2*)(p.lnfold_sums + 2 * (size_t)m) : float2{0.f, 1.f});
+                const LnRow ln = ln_row_from_sums(ss, p.lnfold_dim, p.lnfold_eps);
+                *(float2*)(lnrow_lds + 2 * r) = float2{ln.rstd, ln.nmr};
+            }
+        }
+    }
 
     // one row segment of 8 columns: bias / activation / residuals / stores
     auto apply = [&](const f32x4& lo, const f32x4& hi, int m) {
-        if (!(m < p.M && col_ok)) return;
+        const bool ok = m < p.M && col_ok;
+        if (!f_rowsum && !ok) return;
         float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         const size_t orow = GEN && p.out_group > 0 ? (size_t)(m + m / p.out_group + 1) : (size_t)m;
         const size_t rrow = GEN && p.resid_mod > 0 ? (size_t)(m % p.resid_mod + p.resid_row_off) : orow;
-        if (GEN) {
+        if (ok) {
+        if (f_lnfold) {                                   // rstd·(x·W'ᵀ − mean·colsum): the LayerNorm of the raw rows that A held
+            float2 st;                                    // (rstd, -mean·rstd)
+            if (lnrow_lds) st = *(const float2*)(lnrow_lds + 2 * (m - mrow0));
+            else { const LnRow ln = ln_row_from_sums(*(const float2*)(p.lnfold_sums + 2 * (size_t)m), p.lnfold_dim, p.lnfold_eps); st = float2{ln.rstd, ln.nmr}; }
+            const f32x2 rs = {st.x, st.x}, nm = {st.y, st.y};
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {              // bias folded in (alpha == 1 with lnfold): two packed fma per element pair
+                const f32x2 c2 = {csum[e], csum[e + 1]}, b2 = {bias[e], bias[e + 1]}, a2 = {v[e], v[e + 1]};
+                const f32x2 r2 = __builtin_elementwise_fma(a2, rs, __builtin_elementwise_fma(nm, c2, b2));
+                v[e] = r2[0];
+                v[e + 1] = r2[1];
+            }
+        } else if (GEN) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], p.alpha, bias[e]);
         } else if (f_bias) {
@@ -287,7 +365,8 @@ __device__ __forceinline__ void gemm_epilogue_lds(const UiaGemmParams& p, f32x4 
             float r[8];
             load8(p.resid + rrow * p.ldr + n, r);
             if (f_rln) {                                  // same expression, same operands as ln_fwd_kernel: bit-identical to reading its fp32 output
-                const float2 ms = *(const float2*)(p.resid_ln_stats + 2 * rrow);
+                float2 ms = *(const float2*)(p.resid_ln_stats + 2 * rrow);
+                if (p.resid_ln_dim > 0) { const LnRow ln = ln_row_from_sums(ms, p.resid_ln_dim, p.resid_ln_eps); ms = float2{ln.mean, ln.rstd}; }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) r[e] = fmaf((r[e] - ms.x) * ms.y, lnw[e], lnb[e]);
             }
@@ -302,6 +381,20 @@ __device__ __forceinline__ void gemm_epilogue_lds(const UiaGemmParams& p, f32x4 
         }
         if (f_out32 && UIA_EPI_STORES) store8(p.out32 + orow * p.ldo32 + n, v);
         if (f_outT && UIA_EPI_STORES) store8(outT + orow * p.ldo + n, v);
+        }
+        if (f_rowsum) {                                   // every lane takes part (DPP), rows / columns past the edge contribute zero
+            float s1 = 0.f, s2 = 0.f;
+            if (ok) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { s1 += v[e]; s2 = fmaf(v[e], v[e], s2); }
+            }
+            s1 = row_lanes_sum<LPR>(s1);
+            s2 = row_lanes_sum<LPR>(s2);
+            if ((lane % LPR) == 0 && m < p.M) {
+                atomicAdd(p.rowsum_out + 2 * orow, s1);
+                atomicAdd(p.rowsum_out + 2 * orow + 1, s2);
+            }
+        }
     };
 
     if constexpr (PATCH16) {
@@ -720,6 +813,20 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_tn_ring_kernel(co
         }
     }
     const int m0 = tm * BM, n0 = tn * BN;
+    // Folded LayerNorm (EPI_LNFOLD): the (Σ, Σ²) of the wave's rows are requested here, ahead of the K loop, and turned into
+    // (rstd, -mean·rstd) in the epilogue: the request is older than every LDS-DMA piece, so the counted waits of the ring are unchanged.
+    constexpr bool LNROW = EPI == EPI_GENERIC || (EPI & EPI_LNFOLD) != 0;      // launch_ring_epi adds the strips to the LDS size for these
+    constexpr int LNR = (BM / WAVES_M + 63) / 64;
+    float2 lnpre[LNR];
+#pragma unroll
+    for (int i = 0; i < LNR; ++i) lnpre[i] = float2{0.f, 1.f};
+    if (LNROW && p.lnfold_sums) {
+#pragma unroll
+        for (int i = 0; i < LNR; ++i) {
+            const int r = (tid & 63) + 64 * i, m = m0 + (__builtin_amdgcn_readfirstlane(tid >> 6) / WAVES_N) * (BM / WAVES_M) + r;
+            if (r < BM / WAVES_M && m < p.M) lnpre[i] = *(const float2*)(p.lnfold_sums + 2 * (size_t)m);
+        }
+    }
     // W may arrive K-BLOCKED ([K·ESZ/64][N][64 bytes], packed once per weight by the host): a sub-tile of a column panel is then
     // one contiguous 16 KiB run, each 1 KiB LDS-DMA piece reads 8 whole 128-byte lines instead of 16 half lines, and the DMA-only
     // K step drops from 3150 to 2880 cycles (N = 2304) / 2350 to 1980 (N = 768): +2…9 % on the whole kernel (profiles/r02_a).
@@ -927,7 +1034,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_tn_ring_kernel(co
 #ifdef UIA_GEMM_STAMPS
     t_loop = __builtin_amdgcn_s_memtime();
 #endif
-    gemm_epilogue_lds<T, MT, NT, WTM, WTN, EPI>(p, acc, smem, wave, lane, m0, n0, wm, wn);
+    gemm_epilogue_lds<T, MT, NT, WTM, WTN, EPI>(p, acc, smem, wave, lane, m0, n0, wm, wn,
+                                                LNROW ? (float*)(smem + NW * EpiPatch<MT, WTN>::BYTES_PER_WAVE + wave * (WTM * 8)) : nullptr,
+                                                LNROW ? lnpre : nullptr);
 #ifdef UIA_GEMM_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0 && uia_stamp_buf) {
@@ -941,7 +1050,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_tn_ring_kernel(co
 
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int NBUF, int EPI, int LOOP = 0>
 int launch_ring_epi(hipStream_t stream, const UiaGemmParams& p, int xflags) {
-    constexpr int EPB = WAVES_M * WAVES_N * EpiPatch<BM / WAVES_M / 16, BN / WAVES_N>::BYTES_PER_WAVE;
+    constexpr bool LNROW = EPI == EPI_GENERIC || (EPI & EPI_LNFOLD) != 0;      // + one (rstd, -mean·rstd) pair per tile row per column of waves
+    constexpr int EPB = WAVES_M * WAVES_N * EpiPatch<BM / WAVES_M / 16, BN / WAVES_N>::BYTES_PER_WAVE + (LNROW ? WAVES_N * BM * 8 : 0);
     constexpr int LDS = NBUF * (BM + BN) * BKB > EPB ? NBUF * (BM + BN) * BKB : EPB;
     static_assert(LDS <= 160 * 1024, "LDS budget");
     auto kern = gemm_tn_ring_kernel<T, BM, BN, WAVES_M, WAVES_N, BKB, NBUF, EPI, LOOP>;
@@ -1130,7 +1240,7 @@ inline int epi_mask_of(const UiaGemmParams& p) {
     if (p.alpha != 1.0f || p.out_group > 0 || p.resid_mod > 0) return EPI_GENERIC;
     if ((p.act && p.act != UIA_ACT_GELU) || (p.dact && p.dact != UIA_ACT_GELU)) return EPI_GENERIC;
     return (p.bias ? EPI_BIAS : 0) | (p.aux_out ? EPI_AUX_OUT : 0) | (p.act ? EPI_GELU : 0) | (p.dact ? EPI_DGELU : 0) | (p.resid ? EPI_RESID : 0) |
-           ((p.resid && p.resid_ln_stats) ? EPI_RESID_LN : 0) |
+           ((p.resid && p.resid_ln_stats) ? EPI_RESID_LN : 0) | (p.rowsum_out ? EPI_ROWSUM : 0) | (p.lnfold_sums ? EPI_LNFOLD : 0) |
            (p.residT ? EPI_RESIDT : 0) | (p.out32 ? EPI_OUT32 : 0) | (p.outT ? EPI_OUTT : 0);
 }
 
@@ -1147,6 +1257,12 @@ int launch_ring(hipStream_t stream, const UiaGemmParams& p, bool specialise, int
             UIA_EPI_CASE(EPI_BIAS | EPI_GELU | EPI_OUTT);                      // fc1, frozen tower
             UIA_EPI_CASE(EPI_DGELU | EPI_OUTT);                                // fc2 dgrad through GELU'
             UIA_EPI_CASE(EPI_BIAS | EPI_GELU | EPI_AUX_OUT | EPI_OUTT);        // fc1 with the pre-activation stashed
+            // LayerNorm folded into its neighbours (bf16 step): producers write fp32 + T rows and their row sums, consumers normalise the accumulators
+            UIA_EPI_CASE(EPI_BIAS | EPI_RESID | EPI_OUT32 | EPI_OUTT | EPI_ROWSUM);                  // proj / fc2 / Mona project2
+            UIA_EPI_CASE(EPI_BIAS | EPI_RESID | EPI_RESID_LN | EPI_OUT32 | EPI_OUTT | EPI_ROWSUM);   // BERT sub-layer sums
+            UIA_EPI_CASE(EPI_BIAS | EPI_OUTT | EPI_LNFOLD);                                          // QKV
+            UIA_EPI_CASE(EPI_BIAS | EPI_GELU | EPI_OUTT | EPI_LNFOLD);                               // fc1, frozen tower
+            UIA_EPI_CASE(EPI_BIAS | EPI_GELU | EPI_AUX_OUT | EPI_OUTT | EPI_LNFOLD);                 // fc1 with the pre-activation stashed
 #undef UIA_EPI_CASE
             default: break;
         }
@@ -1234,7 +1350,7 @@ __global__ __launch_bounds__(512) void gemm_skinny64_kernel(const UiaGemmParams 
 // cfg 16 takes: bf16, N == 64, K % 32 == 0 with the W image inside the LDS, and nothing in the epilogue but an optional bias and the T output
 inline bool skinny64_ok(const UiaGemmParams& p, int esz) {
     return esz == 2 && p.N == 64 && p.K % 32 == 0 && 64 * (2 * p.K + 16) <= 160 * 1024 && p.alpha == 1.0f && p.outT && !p.out32 && !p.act && !p.dact &&
-           !p.aux_out && !p.resid && !p.residT && p.out_group == 0 && !p.w_kblocked;
+           !p.aux_out && !p.resid && !p.residT && p.out_group == 0 && !p.w_kblocked && !p.rowsum_out && !p.lnfold_sums;
 }
 
 int launch_skinny64(hipStream_t stream, const UiaGemmParams& p) {
@@ -1334,6 +1450,10 @@ int uia_gemm_launch(hipStream_t stream, int dtype, const UiaGemmParams& p, int c
     UIA_CHECK_ARG(!p.resid_ln_stats || (p.resid && p.resid_ln_w && p.resid_ln_b), "uia_gemm: resid_ln_stats needs resid, resid_ln_w and resid_ln_b");
     UIA_CHECK_ARG(!p.resid_ln_stats || ((uintptr_t)p.resid_ln_stats % 8 == 0 && (uintptr_t)p.resid_ln_w % 16 == 0 && (uintptr_t)p.resid_ln_b % 16 == 0),
                   "uia_gemm: resid_ln alignment");
+    UIA_CHECK_ARG(!p.resid_ln_stats || p.resid_ln_dim >= 0, "uia_gemm: resid_ln_dim=%d", p.resid_ln_dim);
+    UIA_CHECK_ARG(!p.rowsum_out || ((uintptr_t)p.rowsum_out % 8 == 0 && p.out_group == 0), "uia_gemm: rowsum_out must be 8-byte aligned and takes no row remapping");
+    UIA_CHECK_ARG(!p.lnfold_sums || (p.lnfold_colsum && p.lnfold_dim > 0 && p.alpha == 1.0f && (uintptr_t)p.lnfold_sums % 8 == 0 && (uintptr_t)p.lnfold_colsum % 16 == 0),
+                  "uia_gemm: lnfold_sums needs lnfold_colsum (16-byte aligned), lnfold_dim > 0 and alpha == 1");
     // every row the epilogue touches must hold N elements: a leading dimension below N would make row m's tail overwrite row m+1
     UIA_CHECK_ARG(!p.outT || p.ldo >= p.N, "uia_gemm: ldo=%lld < N=%d", (long long)p.ldo, p.N);
     UIA_CHECK_ARG(!p.out32 || p.ldo32 >= p.N, "uia_gemm: ldo32=%lld < N=%d", (long long)p.ldo32, p.N);

@@ -31,7 +31,9 @@ class GemmDesc(C.Structure):
                 ("bias", vp), ("act", i32), ("dact", i32), ("aux_in", vp), ("ldaux_in", i64), ("aux_out", vp), ("ldaux_out", i64),
                 ("resid", vp), ("ldr", i64), ("resid_mod", i32), ("resid_row_off", i32), ("residT", vp), ("ldrT", i64),
                 ("out_group", i32), ("outT", vp), ("ldo", i64), ("out32", vp), ("ldo32", i64), ("w_kblocked", i32),
-                ("resid_ln_stats", vp), ("resid_ln_w", vp), ("resid_ln_b", vp)]
+                ("resid_ln_stats", vp), ("resid_ln_w", vp), ("resid_ln_b", vp),
+                ("rowsum_out", vp), ("lnfold_sums", vp), ("lnfold_colsum", vp), ("lnfold_dim", i32), ("lnfold_eps", f32),
+                ("resid_ln_dim", i32), ("resid_ln_eps", f32)]
 
 
 class AttnDesc(C.Structure):

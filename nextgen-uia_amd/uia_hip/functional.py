@@ -38,6 +38,18 @@ def set_deferred_text_ln(flag):
     _STATE["text_ln_deferred"] = bool(flag)
 
 
+def set_ln_fold(flag):
+    """bf16 mode only (default on): the frozen pre-/post-LN blocks fold each LayerNorm into the GEMMs on either side of it — the producing
+    epilogue writes the T copy of the raw rows and their (Σ, Σ²), the consuming GEMM runs on those raw rows with a weight pre-scaled by
+    the LayerNorm weight and normalises its accumulators (uia_gemm_desc.rowsum_out / lnfold_*) — instead of a stand-alone LayerNorm pass
+    over the rows.  fp32 mode always runs the LayerNorm kernels (exact parity path)."""
+    _STATE["ln_fold"] = bool(flag)
+
+
+def ln_fold_enabled(dt):
+    return dt != torch.float32 and _STATE.get("ln_fold", True)
+
+
 def set_unpad_text(flag):
     """Opt-in: the frozen text tower computes only the valid tokens of each caption (packed rows + per-caption attention) instead
     of all `context_length` positions.  Features are identical (padded positions never reach the pooled CLS row); what changes
@@ -87,6 +99,24 @@ def t_copy_of(g32, dt):
 
 def clear_t_copies():
     _T_COPIES.clear()
+    _ROWS[0] = None
+
+
+# The forward twin of the registry above, one slot deep: the GEMM that produces a residual-stream tensor (Mona project2, a block's fc2)
+# can leave the T copy of its rows and their (Σ, Σ²) for the LayerNorm folded into the next block's first GEMM.
+_ROWS = [None]
+
+
+def publish_rows(x32, x_t, sums):
+    _ROWS[0] = (x32, x32._version, x_t, sums)
+
+
+def take_rows(x32, dt):
+    hit, _ROWS[0] = _ROWS[0], None
+    if (hit is not None and hit[0].data_ptr() == x32.data_ptr() and hit[0].numel() == x32.numel() and hit[1] == x32._version
+            and hit[0].untyped_storage().data_ptr() == x32.untyped_storage().data_ptr() and x32.is_contiguous() and hit[2].dtype == dt):
+        return hit[2], hit[3]
+    return None
 
 
 # ------------------------------------------------------------------------------------------------
@@ -169,6 +199,26 @@ class WeightCache:
             self._repack([it])                                # first use, or the parameter changed outside the optimiser step
         return it.bwd if transpose else it.fwd
 
+    def get_lnfold(self, w, b, ln_w, ln_b, dt):
+        """Operands of a Linear with the LayerNorm in front of it folded in (frozen weights; set_ln_fold): (W' = w·ln_w[None, :] in `dt` as a
+        PackedW, colsum[n] = Σ_k W'[n][k] of the ROUNDED operand in fp32, bias' = b + w @ ln_b in fp32).  One-time weight preparation with
+        torch ops, cached per (weight, LayerNorm weight) and refreshed when any of the four tensors changes."""
+        key = (id(w), id(ln_w), dt, "lnfold")
+        vers = (w._version, ln_w._version, ln_b._version, -1 if b is None else b._version, w.device)
+        hit = self._c.get(key)
+        if hit is not None and hit[0] == vers and hit[1]() is w and hit[3]() is ln_w:
+            return hit[2]
+        with torch.no_grad():
+            w32 = w.detach().float()
+            wf = (w32 * ln_w.detach().float()[None, :]).to(dt).contiguous()
+            colsum = wf.float().sum(1).contiguous()
+            bias = (w32 @ ln_b.detach().float())
+            if b is not None:
+                bias = bias + b.detach().float()
+        out = (ops.PackedW(wf), colsum, bias.contiguous())
+        self._c[key] = (vers, weakref.ref(w), out, weakref.ref(ln_w))
+        return out
+
     def get(self, p, dt, transpose=False, pad_rows_to=None, pad_cols_to=None):
         if (p.requires_grad and dt != torch.float32 and pad_rows_to is None and pad_cols_to is None and p.dim() == 2 and p.is_cuda
                 and p.dtype == torch.float32 and p.is_contiguous() and p.numel() <= self.PACK_MAX_ELEMS):
@@ -242,7 +292,12 @@ class MonaFn(torch.autograd.Function):
         ops.mona_spatial_fwd(variant, B, h, w, t, sp, d, p_drop=p_drop, seed=seed, keep_mask=keep_mask)
         w2 = WEIGHTS.get(P["project2.weight"], dt)
         y = torch.empty_like(x)
-        ops.gemm(d, w2, bias=P["project2.bias"], resid=x.view(M, D), out32=y.view(M, D))
+        if ln_fold_enabled(dt):                # the next block's first LayerNorm is folded into its QKV GEMM: leave it the T rows and their sums
+            y_t, sums = _empty((M, D), dt, x), torch.zeros(M, 2, device=x.device, dtype=torch.float32)
+            ops.gemm(d, w2, bias=P["project2.bias"], resid=x.view(M, D), out32=y.view(M, D), out_t=y_t, rowsum=sums)
+            publish_rows(y, y_t, sums)
+        else:
+            ops.gemm(d, w2, bias=P["project2.bias"], resid=x.view(M, D), out32=y.view(M, D))
         ctx.save_for_backward(x, u, t, d, keep_mask if keep_mask is not None else x.new_empty(0), *params)
         ctx.meta = (variant, hw, p_drop, seed, names, keep_mask is not None)
         ctx.direct_params = tuple(params) if direct else None      # the Parameter objects themselves: .grad is looked up at BACKWARD time
@@ -312,8 +367,9 @@ def mona_apply(x_bnd, module_params, variant, hw, p_drop, training, keep_mask=No
 class BlockSpec:
     """Static description of a pre-LN block: which parameters play which role."""
 
-    def __init__(self, heads, eps, act, ln1, qkv, proj, ln2, fc1, fc2, mask=None):
+    def __init__(self, heads, eps, act, ln1, qkv, proj, ln2, fc1, fc2, mask=None, publish_out=False):
         self.heads, self.eps, self.act, self.mask = heads, eps, act, mask
+        self.publish_out = publish_out      # the next consumer of this block's output is another frozen block's LayerNorm (set_ln_fold): leave it T rows + sums
         self.ln1, self.qkv, self.proj, self.ln2, self.fc1, self.fc2 = ln1, qkv, proj, ln2, fc1, fc2   # each: (weight, bias)
 
 
@@ -327,22 +383,40 @@ class VitBlockFn(torch.autograd.Function):
         x = x.contiguous()
         x2d = x.view(M, D)
         train = ctx.needs_input_grad[0]
-        h1 = _empty((M, D), dt, x)
-        ops.layernorm_fwd(x2d, spec.ln1[0], spec.ln1[1], spec.eps, y_t=h1)
+        fold = ln_fold_enabled(dt)
+        rows = take_rows(x, dt) if fold else None        # (T copy of x, row sums) left by the GEMM that produced x
         qkv = _empty((M, 3 * D), dt, x)
-        ops.gemm(h1, WEIGHTS.get(spec.qkv[0], dt), bias=spec.qkv[1], out_t=qkv)
+        if rows is not None:                              # LN1 folded into the QKV GEMM
+            wq, cq, bq = WEIGHTS.get_lnfold(spec.qkv[0], spec.qkv[1], spec.ln1[0], spec.ln1[1], dt)
+            ops.gemm(rows[0].view(M, D), wq, bias=bq, out_t=qkv, lnfold=(rows[1], cq, D, spec.eps))
+            h1 = rows[0].view(M, D)                       # its storage is free after this GEMM
+        else:
+            h1 = _empty((M, D), dt, x)
+            ops.layernorm_fwd(x2d, spec.ln1[0], spec.ln1[1], spec.eps, y_t=h1)
+            ops.gemm(h1, WEIGHTS.get(spec.qkv[0], dt), bias=spec.qkv[1], out_t=qkv)
         a = _empty((M, D), dt, x)
         lse = torch.empty(B, spec.heads, N, device=x.device, dtype=torch.float32) if train else None
         ops.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], a, B, spec.heads, N, lse=lse, mask=spec.mask)
         x1 = torch.empty_like(x2d)
-        ops.gemm(a, WEIGHTS.get(spec.proj[0], dt), bias=spec.proj[1], resid=x2d, out32=x1)
-        ops.layernorm_fwd(x1, spec.ln2[0], spec.ln2[1], spec.eps, y_t=h1)          # h1 buffer reused as h2
         F = spec.fc1[0].shape[0]
         f = _empty((M, F), dt, x)
         pre = _empty((M, F), dt, x) if train else None
-        ops.gemm(h1, WEIGHTS.get(spec.fc1[0], dt), bias=spec.fc1[1], act=spec.act, aux_out=pre, out_t=f)
+        if fold:                                          # LN2 folded: proj leaves T rows + sums, fc1 normalises its accumulators
+            sums1 = torch.zeros(M, 2, device=x.device, dtype=torch.float32)
+            ops.gemm(a, WEIGHTS.get(spec.proj[0], dt), bias=spec.proj[1], resid=x2d, out32=x1, out_t=h1, rowsum=sums1)
+            w1, c1, b1 = WEIGHTS.get_lnfold(spec.fc1[0], spec.fc1[1], spec.ln2[0], spec.ln2[1], dt)
+            ops.gemm(h1, w1, bias=b1, act=spec.act, aux_out=pre, out_t=f, lnfold=(sums1, c1, D, spec.eps))
+        else:
+            ops.gemm(a, WEIGHTS.get(spec.proj[0], dt), bias=spec.proj[1], resid=x2d, out32=x1)
+            ops.layernorm_fwd(x1, spec.ln2[0], spec.ln2[1], spec.eps, y_t=h1)          # h1 buffer reused as h2
+            ops.gemm(h1, WEIGHTS.get(spec.fc1[0], dt), bias=spec.fc1[1], act=spec.act, aux_out=pre, out_t=f)
         x2 = torch.empty_like(x)
-        ops.gemm(f, WEIGHTS.get(spec.fc2[0], dt), bias=spec.fc2[1], resid=x1, out32=x2.view(M, D))
+        if fold and spec.publish_out:
+            sums2 = torch.zeros(M, 2, device=x.device, dtype=torch.float32)
+            ops.gemm(f, WEIGHTS.get(spec.fc2[0], dt), bias=spec.fc2[1], resid=x1, out32=x2.view(M, D), out_t=h1, rowsum=sums2)
+            publish_rows(x2, h1, sums2)
+        else:
+            ops.gemm(f, WEIGHTS.get(spec.fc2[0], dt), bias=spec.fc2[1], resid=x1, out32=x2.view(M, D))
         if train:
             ctx.save_for_backward(x, qkv, a, lse, x1, pre)
             ctx.spec = spec
@@ -383,19 +457,23 @@ def vit_block(x, spec):
 
 
 # ================================================================================================ forward-only pieces
-@torch.no_grad()
 class LnResidual:
     """The fp32 residual entering a post-LN sub-layer, kept as the INPUT of the LayerNorm that produces it: (raw sum, per-row
     (mean, rstd), LayerNorm weight, bias).  uia_gemm's epilogue applies the LayerNorm to the rows it reads (resid_ln_*), so the
     LayerNorm kernel writes only the T operand and 8 bytes of statistics per row instead of a second, fp32 copy of its output
     (201 MB per LayerNorm at 65536 x 768: 24 of them per step in the BERT tower)."""
-    __slots__ = ("raw", "stats", "w", "b")
+    __slots__ = ("raw", "stats", "w", "b", "dim", "eps")
 
-    def __init__(self, raw, stats, w, b):
+    def __init__(self, raw, stats, w, b, dim=None, eps=None):
         self.raw, self.stats, self.w, self.b = raw, stats, w, b
+        self.dim, self.eps = dim, eps          # dim set: `stats` holds the row sums (Σ, Σ²) a producing GEMM left (set_ln_fold), not (mean, rstd)
 
     def gemm_kw(self):
-        return dict(resid=self.raw) if self.stats is None else dict(resid=self.raw, resid_ln=(self.stats, self.w, self.b))
+        if self.stats is None:
+            return dict(resid=self.raw)
+        if self.dim is None:
+            return dict(resid=self.raw, resid_ln=(self.stats, self.w, self.b))
+        return dict(resid=self.raw, resid_ln=(self.stats, self.w, self.b, self.dim, self.eps))
 
 
 def _post_ln(raw, w, b, eps, x_t, stats_buf=None):
@@ -414,10 +492,13 @@ def post_ln_embed(e32, ln, x_t):
     return _post_ln(e32, ln.weight, ln.bias, ln.eps, x_t)
 
 
-def post_ln_layer(res, x_t, L, B, heads, P, keylen, eps=1e-12, cu_seqlens=None):
+def post_ln_layer(res, x_t, L, B, heads, P, keylen, eps=1e-12, cu_seqlens=None, fold_sums=None, fold_out=False):
     """HF BertLayer (post-LN), frozen: returns the new (deferred fp32 residual, T operand) pair.  P: dict of Parameters with the HF
     names relative to `encoder.layer.{i}.`; q/k/v weights are used as one fused [3D, D] matrix.  res: LnResidual.
-    cu_seqlens: rows are PACKED valid tokens (un-padded captions); L is then the longest caption and no mask is needed."""
+    cu_seqlens: rows are PACKED valid tokens (un-padded captions); L is then the longest caption and no mask is needed.
+    set_ln_fold (bf16): fold_sums = zeroed fp32 [2, M, 2] lets the two LayerNorms of this layer fold into their neighbouring GEMMs: the
+    attention-output LayerNorm always (both neighbours are inside the layer), the output LayerNorm when fold_out says that the next
+    layer will take (x_t = T copy of the RAW sum, res.dim set) instead of the normalised operand.  A `res` with .dim set is such an input."""
     M, D = x_t.shape
     dt = x_t.dtype
     # Post-LN: the residual entering each sub-layer IS the previous LayerNorm's output, so in bf16 mode its T copy (the GEMM
@@ -425,8 +506,13 @@ def post_ln_layer(res, x_t, L, B, heads, P, keylen, eps=1e-12, cu_seqlens=None):
     # (tools/text_residual_error.py, 12 layers, bf16 vs fp32 mode): the text features' error goes from 6.4e-3 to 1.05e-2, past the
     # 1e-2 bound — so it is OFF unless _STATE["text_resid_t"] is set; the default keeps the fp32 residual exactly (LnResidual).
     t_resid = dt != torch.float32 and _STATE.get("text_resid_t", False)
+    fold = fold_sums is not None and ln_fold_enabled(dt) and not t_resid
     qkv = _empty((M, 3 * D), dt, x_t)
-    ops.gemm(x_t, P["_qkv_w"](dt), bias=P["_qkv_b"], out_t=qkv)
+    if res.dim is not None:                           # x_t holds the raw rows of the previous layer's output sum: its LayerNorm folds in here
+        wq, cq, bq = WEIGHTS.get_lnfold(P["_qkv_raw"][0], P["_qkv_raw"][1], res.w, res.b, dt)
+        ops.gemm(x_t, wq, bias=bq, out_t=qkv, lnfold=(res.stats, cq, D, res.eps))
+    else:
+        ops.gemm(x_t, P["_qkv_w"](dt), bias=P["_qkv_b"], out_t=qkv)
     a = _empty((M, D), dt, x_t)
     if cu_seqlens is not None:
         ops.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], a, B, heads, L, cu_seqlens=cu_seqlens)
@@ -434,16 +520,31 @@ def post_ln_layer(res, x_t, L, B, heads, P, keylen, eps=1e-12, cu_seqlens=None):
         ops.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], a, B, heads, L, mask="keypad", keylen=keylen)
     del qkv
     s_a = torch.empty(M, D, device=x_t.device, dtype=torch.float32)
-    ops.gemm(a, WEIGHTS.get(P["attention.output.dense.weight"], dt), bias=P["attention.output.dense.bias"], out32=s_a,
-             **(dict(resid_t=x_t) if t_resid else res.gemm_kw()))
-    res_a = _post_ln(s_a, P["attention.output.LayerNorm.weight"], P["attention.output.LayerNorm.bias"], eps, x_t)
     F = P["intermediate.dense.weight"].shape[0]
     f = _empty((M, F), dt, x_t)
-    ops.gemm(x_t, WEIGHTS.get(P["intermediate.dense.weight"], dt), bias=P["intermediate.dense.bias"], act="gelu", out_t=f)
-    s_o = res.raw                                     # the previous sub-layer sum was last read by the first GEMM above: its storage takes the new sum
+    if fold:
+        lw_a, lb_a = P["attention.output.LayerNorm.weight"], P["attention.output.LayerNorm.bias"]
+        s_a_t = _empty((M, D), dt, x_t)
+        ops.gemm(a, WEIGHTS.get(P["attention.output.dense.weight"], dt), bias=P["attention.output.dense.bias"], out32=s_a, out_t=s_a_t,
+                 rowsum=fold_sums[0], **res.gemm_kw())
+        res_a = LnResidual(s_a, fold_sums[0], lw_a, lb_a, D, eps)
+        w1, c1, b1 = WEIGHTS.get_lnfold(P["intermediate.dense.weight"], P["intermediate.dense.bias"], lw_a, lb_a, dt)
+        ops.gemm(s_a_t, w1, bias=b1, act="gelu", out_t=f, lnfold=(fold_sums[0], c1, D, eps))
+        del s_a_t
+    else:
+        ops.gemm(a, WEIGHTS.get(P["attention.output.dense.weight"], dt), bias=P["attention.output.dense.bias"], out32=s_a,
+                 **(dict(resid_t=x_t) if t_resid else res.gemm_kw()))
+        res_a = _post_ln(s_a, P["attention.output.LayerNorm.weight"], P["attention.output.LayerNorm.bias"], eps, x_t)
+        ops.gemm(x_t, WEIGHTS.get(P["intermediate.dense.weight"], dt), bias=P["intermediate.dense.bias"], act="gelu", out_t=f)
+    s_o = res.raw                                     # the previous sub-layer sum was last read by the attention-output GEMM above: its storage takes the new sum
+    if fold and fold_out:                             # the next layer folds this LayerNorm into its QKV GEMM: x_t becomes the T copy of the raw sum
+        ops.gemm(f, WEIGHTS.get(P["output.dense.weight"], dt), bias=P["output.dense.bias"], out32=s_o, out_t=x_t, rowsum=fold_sums[1],
+                 **res_a.gemm_kw())
+        return LnResidual(s_o, fold_sums[1], P["output.LayerNorm.weight"], P["output.LayerNorm.bias"], D, eps), x_t
     ops.gemm(f, WEIGHTS.get(P["output.dense.weight"], dt), bias=P["output.dense.bias"], out32=s_o,
              **(dict(resid_t=x_t) if t_resid else res_a.gemm_kw()))
-    return _post_ln(s_o, P["output.LayerNorm.weight"], P["output.LayerNorm.bias"], eps, x_t, stats_buf=res.stats), x_t
+    stats_buf = res.stats if (res.dim is None and res.stats is not None) else None
+    return _post_ln(s_o, P["output.LayerNorm.weight"], P["output.LayerNorm.bias"], eps, x_t, stats_buf=stats_buf), x_t
 
 
 class PatchEmbedFn(torch.autograd.Function):

@@ -19,8 +19,11 @@ GEMM_PROFILE = None
 
 
 EPI_BIAS, EPI_AUX_OUT, EPI_GELU, EPI_DGELU, EPI_RESID, EPI_RESIDT, EPI_OUT32, EPI_OUTT, EPI_RESID_LN, EPI_GENERIC = 1, 2, 4, 8, 16, 32, 64, 128, 256, -1
+EPI_ROWSUM, EPI_LNFOLD = 512, 1024
 _SPECIALISED = {EPI_BIAS | EPI_RESID | EPI_OUT32, EPI_BIAS | EPI_RESIDT | EPI_OUT32, EPI_BIAS | EPI_RESID | EPI_RESID_LN | EPI_OUT32, EPI_OUTT, EPI_BIAS | EPI_OUTT, EPI_BIAS | EPI_GELU | EPI_OUTT, EPI_DGELU | EPI_OUTT,
-                EPI_BIAS | EPI_GELU | EPI_AUX_OUT | EPI_OUTT}
+                EPI_BIAS | EPI_GELU | EPI_AUX_OUT | EPI_OUTT,
+                EPI_BIAS | EPI_RESID | EPI_OUT32 | EPI_OUTT | EPI_ROWSUM, EPI_BIAS | EPI_RESID | EPI_RESID_LN | EPI_OUT32 | EPI_OUTT | EPI_ROWSUM,
+                EPI_BIAS | EPI_OUTT | EPI_LNFOLD, EPI_BIAS | EPI_GELU | EPI_OUTT | EPI_LNFOLD, EPI_BIAS | EPI_GELU | EPI_AUX_OUT | EPI_OUTT | EPI_LNFOLD}
 
 
 def epi_mask_of(d):
@@ -31,7 +34,7 @@ def epi_mask_of(d):
         return EPI_GENERIC
     m = ((EPI_BIAS if d.bias else 0) | (EPI_AUX_OUT if d.aux_out else 0) | (EPI_GELU if d.act else 0) | (EPI_DGELU if d.dact else 0) |
          (EPI_RESID if d.resid else 0) | (EPI_RESIDT if d.residT else 0) | (EPI_OUT32 if d.out32 else 0) | (EPI_OUTT if d.outT else 0) |
-         (EPI_RESID_LN if (d.resid and d.resid_ln_stats) else 0))
+         (EPI_RESID_LN if (d.resid and d.resid_ln_stats) else 0) | (EPI_ROWSUM if d.rowsum_out else 0) | (EPI_LNFOLD if d.lnfold_sums else 0))
     return m
 
 
@@ -151,13 +154,16 @@ def _rowmajor(t, name):
 
 
 def gemm(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None, resid=None, resid_mod=0, resid_row_off=0,
-         resid_t=None, out_group=0, out_t=None, out32=None, alpha=1.0, tile_cfg=0, resid_ln=None):
+         resid_t=None, out_group=0, out_t=None, out32=None, alpha=1.0, tile_cfg=0, resid_ln=None, rowsum=None, lnfold=None):
     """C = epilogue(alpha * a @ w.T).  a [M,K], w [N,K] (tensor or PackedW) share a dtype (bf16 | fp32); see include/uia_hip.h.
 
     Host-side scheduling on top of uia_gemm (results do not depend on it): with the automatic tile choice, a weight that came
     as a PackedW is handed to the ring kernels K-blocked, and the M tail of a launch whose last round of tiles would leave most
     CUs idle goes through a second launch with half-height tiles (tail_split_rows).
-    resid_ln = (stats [M, 2], ln_weight, ln_bias): `resid` is the INPUT of a LayerNorm whose output is the residual to add."""
+    resid_ln = (stats [M, 2], ln_weight, ln_bias): `resid` is the INPUT of a LayerNorm whose output is the residual to add; a fourth and
+    fifth element (dim, eps) say that `stats` holds the row sums (Σ, Σ²) a producing GEMM left through `rowsum`, not (mean, rstd).
+    rowsum = zeroed fp32 [M, 2]: receives (Σ, Σ²) of the stored fp32 rows.  lnfold = (sums [M, 2], colsum [N], dim, eps): `a` holds RAW
+    rows and `w` is pre-scaled by the LayerNorm weight; the epilogue applies the LayerNorm (include/uia_hip.h, uia_gemm_desc)."""
     packed = w if isinstance(w, PackedW) else None
     wrow = packed.row if packed is not None else w
     M, N = a.shape[0], wrow.shape[0]
@@ -170,14 +176,16 @@ def gemm(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None, res
             for lo, hi, cfg in ((0, m_main, 8), (m_main, M, 13)):
                 _gemm_one(a[lo:hi], w, bias=bias, act=act, dact=dact, aux_in=cut(aux_in, lo, hi), aux_out=cut(aux_out, lo, hi), resid=cut(resid, lo, hi),
                           resid_t=cut(resid_t, lo, hi), out_t=cut(out_t, lo, hi), out32=cut(out32, lo, hi), alpha=alpha, tile_cfg=cfg,
-                          resid_ln=None if resid_ln is None else (resid_ln[0][lo:hi], resid_ln[1], resid_ln[2]))
+                          resid_ln=None if resid_ln is None else (resid_ln[0][lo:hi],) + tuple(resid_ln[1:]), rowsum=cut(rowsum, lo, hi),
+                          lnfold=None if lnfold is None else (lnfold[0][lo:hi],) + tuple(lnfold[1:]))
             return
     _gemm_one(a, w, bias=bias, act=act, dact=dact, aux_in=aux_in, aux_out=aux_out, resid=resid, resid_mod=resid_mod, resid_row_off=resid_row_off,
-              resid_t=resid_t, out_group=out_group, out_t=out_t, out32=out32, alpha=alpha, tile_cfg=tile_cfg, resid_ln=resid_ln)
+              resid_t=resid_t, out_group=out_group, out_t=out_t, out32=out32, alpha=alpha, tile_cfg=tile_cfg, resid_ln=resid_ln,
+              rowsum=rowsum, lnfold=lnfold)
 
 
 def _gemm_one(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None, resid=None, resid_mod=0, resid_row_off=0,
-              resid_t=None, out_group=0, out_t=None, out32=None, alpha=1.0, tile_cfg=0, resid_ln=None):
+              resid_t=None, out_group=0, out_t=None, out32=None, alpha=1.0, tile_cfg=0, resid_ln=None, rowsum=None, lnfold=None):
     d = GemmDesc()
     packed = w if isinstance(w, PackedW) else None
     if packed is not None:
@@ -212,12 +220,23 @@ def _gemm_one(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None
         d.resid, d.ldr = _p(resid), _rowmajor(resid, "resid")
     d.resid_mod, d.resid_row_off, d.out_group = resid_mod, resid_row_off, out_group
     if resid_ln is not None:
-        st, lw, lb = resid_ln
+        st, lw, lb = resid_ln[:3]
+        if len(resid_ln) > 3:
+            d.resid_ln_dim, d.resid_ln_eps = int(resid_ln[3]), float(resid_ln[4])
         if resid is None or resid_mod or out_group:
             raise UiaError("gemm resid_ln needs a plain fp32 resid (no row remapping)")
         if not (st.dtype == lw.dtype == lb.dtype == torch.float32 and st.is_contiguous() and st.numel() >= 2 * d.M and lw.numel() >= d.N and lb.numel() >= d.N):
             raise UiaError(f"gemm resid_ln: stats {tuple(st.shape)} / weight {tuple(lw.shape)} / bias {tuple(lb.shape)} do not cover [{d.M}, {d.N}]")
         d.resid_ln_stats, d.resid_ln_w, d.resid_ln_b = _p(st), _p(lw), _p(lb)
+    if rowsum is not None:
+        if not (rowsum.dtype == torch.float32 and rowsum.is_contiguous() and rowsum.numel() >= 2 * d.M) or out_group:
+            raise UiaError(f"gemm rowsum must be a contiguous fp32 [{d.M}, 2] tensor (no row remapping), got {tuple(rowsum.shape)} {rowsum.dtype}")
+        d.rowsum_out = _p(rowsum)
+    if lnfold is not None:
+        sm, cs, dim, eps = lnfold
+        if not (sm.dtype == cs.dtype == torch.float32 and sm.is_contiguous() and cs.is_contiguous() and sm.numel() >= 2 * d.M and cs.numel() >= d.N) or alpha != 1.0:
+            raise UiaError(f"gemm lnfold: sums {tuple(sm.shape)} / colsum {tuple(cs.shape)} do not cover [{d.M}, {d.N}] (fp32, contiguous, alpha == 1)")
+        d.lnfold_sums, d.lnfold_colsum, d.lnfold_dim, d.lnfold_eps = _p(sm), _p(cs), int(dim), float(eps)
     if resid_t is not None:
         d.residT, d.ldrT = _p(resid_t), _rowmajor(resid_t, "resid_t")
     if out_t is not None:

@@ -1,0 +1,199 @@
+"""-m gpu: LayerNorm folded into the GEMMs on either side of it (uia_gemm_desc.rowsum_out / lnfold_* / resid_ln_dim; bf16 training step).
+
+Kernel level: the row sums a producing epilogue leaves, the normalised accumulators of a consuming GEMM and the deferred residual that
+reads sums instead of (mean, rstd), each against torch on the same operands, on the ring tile configs (compile-time masks and the run-time
+epilogue), the half-height tail config and the small-M config.  Model level: the folded ViT block / BERT layer against the same model
+with the stand-alone LayerNorm kernels (bf16) and against the oracle (tests/test_parity_gpu.py and test_fullshape_gpu.py run with the
+fold on, the default)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+@pytest.fixture(autouse=True)
+def _mode():
+    from uia_hip import functional as UF
+    yield
+    UF.set_compute_dtype(torch.bfloat16)
+    UF.set_ln_fold(True)
+    UF.clear_t_copies()
+
+
+def _ln(x, w, b, eps):
+    return torch.nn.functional.layer_norm(x, (x.shape[1],), w, b, eps)
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32], ids=["bf16", "fp32"])
+@pytest.mark.parametrize("M,cfg", [(4100, 0), (4100, 10), (2500, 13), (300, 0), (2500, 14)])
+def test_gemm_rowsum_of_stored_rows(dt, M, cfg):
+    """producer: out32 = a·wᵀ + bias + resid, T copy of the same rows, (Σ, Σ²) per row; M is no multiple of any tile height"""
+    from uia_hip import ops
+    g = torch.Generator().manual_seed(M + cfg)
+    N, K = 768, 256
+    a = torch.randn(M, K, generator=g).to(dev()).to(dt)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dev()).to(dt)
+    bias = torch.randn(N, generator=g).to(dev())
+    resid = (torch.randn(M, N, generator=g) * 2 + 0.5).to(dev())
+    out32 = torch.empty(M, N, device=dev())
+    out_t = torch.empty(M, N, device=dev(), dtype=dt)
+    sums = torch.zeros(M, 2, device=dev())
+    ops.gemm(a, w, bias=bias, resid=resid, out32=out32, out_t=out_t, rowsum=sums, tile_cfg=cfg)
+    ref = a.float() @ w.float().T + bias + resid
+    assert rel(out32, ref) < 2e-5
+    assert rel(out_t, ref.to(dt)) < (1e-2 if dt == torch.bfloat16 else 2e-5)
+    s1, s2 = out32.double().sum(1), (out32.double() ** 2).sum(1)            # sums of the rows the launch itself stored
+    assert float((sums[:, 0].double() - s1).abs().max() / s1.abs().max()) < 2e-6
+    assert float((sums[:, 1].double() - s2).abs().max() / s2.abs().max()) < 2e-6
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32], ids=["bf16", "fp32"])
+@pytest.mark.parametrize("M,cfg,act,aux", [(4100, 0, None, False), (4100, 0, "gelu", False), (4100, 0, "gelu", True), (4100, 10, "gelu", True),
+                                           (2500, 13, None, False), (300, 0, "gelu", True)])
+def test_gemm_layernorm_folded_into_consumer(dt, M, cfg, act, aux):
+    """consumer: A = raw rows, W' = W·ln_w, epilogue rstd·(acc − mean·colsum) + (b + W·ln_b): against LayerNorm → Linear in torch"""
+    from uia_hip import ops
+    g = torch.Generator().manual_seed(7 * M + cfg)
+    D, N, eps = 256, 768, 1e-6
+    x = (torch.randn(M, D, generator=g) * 1.7 + 0.3).to(dev())               # a non-zero row mean: the −mean·colsum term matters
+    lw = (1 + 0.3 * torch.randn(D, generator=g)).to(dev())
+    lb = (0.2 * torch.randn(D, generator=g)).to(dev())
+    W = (torch.randn(N, D, generator=g) * 0.05).to(dev())
+    b = torch.randn(N, generator=g).to(dev())
+    x_t = x.to(dt)
+    wf = (W * lw[None, :]).to(dt).contiguous()
+    colsum = wf.float().sum(1).contiguous()
+    bias = (b + W @ lb).contiguous()
+    sums = torch.stack([x.sum(1), (x * x).sum(1)], 1).contiguous()
+    out = torch.empty(M, N, device=dev(), dtype=dt)
+    pre = torch.empty(M, N, device=dev(), dtype=dt) if aux else None
+    ops.gemm(x_t, wf, bias=bias, act=act, aux_out=pre, out_t=out, lnfold=(sums, colsum, D, eps), tile_cfg=cfg)
+    # same operands, fp64 arithmetic
+    mean = x.double().mean(1, keepdim=True)
+    rstd = 1.0 / torch.sqrt(x.double().var(1, unbiased=False, keepdim=True) + eps)
+    z = rstd * (x_t.double() @ wf.double().T - mean * colsum.double()[None, :]) + bias.double()
+    y = torch.nn.functional.gelu(z) if act else z
+    tol = 1.2e-2 if dt == torch.bfloat16 else 3e-5                            # bf16: the output rounding (+ the polynomial GELU of the bf16 epilogue)
+    assert rel(out, y) < tol
+    if aux:
+        assert rel(pre, z) < tol
+    # and it IS the LayerNorm followed by the Linear, up to the rounding of the operands
+    true = _ln(x, lw, lb, eps) @ W.T + b
+    true = torch.nn.functional.gelu(true) if act else true
+    assert rel(out, true) < (3e-2 if dt == torch.bfloat16 else 1e-4)
+
+
+@pytest.mark.parametrize("M,cfg", [(4100, 0), (4100, 10), (300, 0)])
+def test_gemm_deferred_residual_from_row_sums(M, cfg):
+    """post-LN sub-layer sum whose residual is LayerNorm(resid) with the statistics given as (Σ, Σ²): against torch, and against the
+    (mean, rstd) form of the same descriptor"""
+    from uia_hip import ops
+    g = torch.Generator().manual_seed(M)
+    N, K, eps = 768, 256, 1e-12
+    a = torch.randn(M, K, generator=g).to(dev()).bfloat16()
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dev()).bfloat16()
+    bias = torch.randn(N, generator=g).to(dev())
+    raw = (torch.randn(M, N, generator=g) * 1.3 - 0.2).to(dev())
+    lw = (1 + 0.3 * torch.randn(N, generator=g)).to(dev())
+    lb = (0.2 * torch.randn(N, generator=g)).to(dev())
+    sums = torch.stack([raw.sum(1), (raw * raw).sum(1)], 1).contiguous()
+    out = torch.empty(M, N, device=dev())
+    out_t = torch.empty(M, N, device=dev(), dtype=torch.bfloat16)
+    s2 = torch.zeros(M, 2, device=dev())
+    ops.gemm(a, w, bias=bias, resid=raw, resid_ln=(sums, lw, lb, N, eps), out32=out, out_t=out_t, rowsum=s2, tile_cfg=cfg)
+    ref = a.float() @ w.float().T + bias + _ln(raw, lw, lb, eps)
+    assert rel(out, ref) < 2e-5
+    assert float((s2[:, 0] - out.sum(1)).abs().max() / out.sum(1).abs().max()) < 1e-5
+    stats = torch.stack([raw.mean(1), 1.0 / torch.sqrt(raw.var(1, unbiased=False) + eps)], 1).contiguous()
+    out2 = torch.empty_like(out)
+    ops.gemm(a, w, bias=bias, resid=raw, resid_ln=(stats, lw, lb), out32=out2, tile_cfg=cfg)
+    assert rel(out, out2) < 1e-5
+
+
+def test_gemm_lnfold_argument_checks():
+    from uia_hip import ops
+    from uia_hip._lib import UiaError
+    a = torch.zeros(256, 128, device=dev(), dtype=torch.bfloat16)
+    w = torch.zeros(64, 128, device=dev(), dtype=torch.bfloat16)
+    out = torch.empty(256, 64, device=dev(), dtype=torch.bfloat16)
+    with pytest.raises(UiaError):
+        ops.gemm(a, w, out_t=out, rowsum=torch.zeros(100, 2, device=dev()))                      # too few rows
+    with pytest.raises(UiaError):
+        ops.gemm(a, w, out_t=out, lnfold=(torch.zeros(256, 2, device=dev()), torch.zeros(32, device=dev()), 128, 1e-6))   # colsum too short
+    with pytest.raises(UiaError):
+        ops.gemm(a, w, out_t=out, alpha=2.0, lnfold=(torch.zeros(256, 2, device=dev()), torch.zeros(64, device=dev()), 128, 1e-6))
+
+
+TOY = dict(embed_dim=128, vision_cfg=dict(img_size=32, patch_size=8, embed_dim=128, depth=3, num_heads=2),
+           text_cfg=dict(vocab_size=120, hidden_size=128, num_hidden_layers=3, num_attention_heads=2, intermediate_size=256,
+                         max_position_embeddings=40))
+
+
+def _toy(variant="freq_enhanced"):
+    from src.adapters import inject_mona_variant_to_open_clip
+    from src.third_party.biomedclip.model import create_biomedclip
+    import contextlib, io
+    model = create_biomedclip(config=TOY, seed=11)
+    for p in model.parameters():
+        p.requires_grad_(False)
+    with contextlib.redirect_stdout(io.StringIO()):
+        inject_mona_variant_to_open_clip(model, variant=variant, bottleneck_dim=64)
+    g = torch.Generator().manual_seed(12)
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            if "mona" in k:
+                p.copy_((1.0 if k.endswith(("norm.weight", "gammax", "freq_filter")) else 0.0) + 0.08 * torch.randn(p.shape, generator=g))
+            elif "norm" in k.lower() and k.endswith("weight"):
+                p.copy_(1.0 + 0.3 * torch.randn(p.shape, generator=g))           # LayerNorm weights / biases away from (1, 0): the fold must carry them
+            elif "norm" in k.lower() and k.endswith("bias"):
+                p.copy_(0.2 * torch.randn(p.shape, generator=g))
+    for k, p in model.named_parameters():
+        p.requires_grad_("mona" in k)
+    return model.eval().to(dev())
+
+
+def test_folded_towers_match_the_layernorm_kernels():
+    """bf16 step with the fold (default) against the same step with the stand-alone LayerNorm kernels: features, loss and adapter
+    gradients agree to bf16 rounding; and the folded run stays within the bf16 bound of the fp32-mode features"""
+    from uia_hip import functional as UF
+    from src.losses import InfoNCELoss
+    model = _toy()
+    g = torch.Generator().manual_seed(3)
+    images = torch.rand(6, 3, 32, 32, generator=g).to(dev())
+    ids = torch.randint(4, 120, (6, 12), generator=g)
+    ids[:, 0] = 2
+    ids[1, 7:] = 0
+    ids[4, 3:] = 0
+    ids = ids.to(dev())
+
+    def run(fold, dt):
+        UF.set_compute_dtype(dt)
+        UF.set_ln_fold(fold)
+        UF.set_dropout_seed(5)
+        for p in model.parameters():
+            p.grad = None
+        fi, ft = model.encode_image(images), model.encode_text(ids)
+        loss = InfoNCELoss(0.07)(fi, ft)
+        loss.backward()
+        UF.clear_t_copies()
+        gr = torch.cat([p.grad.flatten() for p in model.parameters() if p.requires_grad])
+        return fi.detach().clone(), ft.detach().clone(), float(loss), gr.clone()
+
+    fi32, ft32, l32, g32 = run(False, torch.float32)
+    fi0, ft0, l0, g0 = run(False, torch.bfloat16)
+    fi1, ft1, l1, g1 = run(True, torch.bfloat16)
+    assert rel(fi1, fi32) < 1e-2 and rel(ft1, ft32) < 1e-2, (rel(fi1, fi32), rel(ft1, ft32))
+    # the fold is no less accurate than the LayerNorm kernels' bf16 path (same number of bf16 roundings on the way)
+    assert rel(fi1, fi32) < 2.0 * rel(fi0, fi32) + 2e-3 and rel(ft1, ft32) < 2.0 * rel(ft0, ft32) + 2e-3
+    cos = float(torch.nn.functional.cosine_similarity(g1, g32, dim=0))
+    assert cos > 0.99, cos
+    assert abs(l1 - l32) < 2e-2 * max(1.0, abs(l32))
