@@ -25,6 +25,17 @@
 #include "uia_common.h"
 #include "uia_kernels.h"
 
+#ifdef ABWD_STAMPS
+// diagnostic build (tools/abwd_stamps.sh): cycles per phase of the bf16 backward, summed over the query blocks of ONE workgroup, per wave:
+// [0] wait + barrier at the top of a block, [1] dQ store + LDS-DMA issue + delta, [2] S / dP / dS / dV / dK of the owned key tiles,
+// [3] dQ product, [4] prologue (to the first barrier + delta), [5] whole kernel
+__device__ unsigned long long uia_abwd_stamps[8 * 8];
+extern "C" int uia_abwd_read_stamps(unsigned long long* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(uia_abwd_stamps), sizeof(uia_abwd_stamps));
+}
+#define STAMP() __builtin_amdgcn_s_memtime()
+#endif
+
 namespace {
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -103,6 +114,10 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void attn_bwd_bf16_kernel(const Uia
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef ABWD_STAMPS
+    const unsigned long long st_begin = STAMP();
+    unsigned long long st_acc[4] = {0, 0, 0, 0}, st_pro = 0;
+#endif
     const int b = blockIdx.x / p.H, h = blockIdx.x - b * p.H;
     const size_t row0 = (size_t)b * L;
     const size_t rs = (size_t)p.ld_qkv * 2, rso = (size_t)p.lddo * 2, rsO = (size_t)p.ldo * 2;
@@ -180,6 +195,9 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void attn_bwd_bf16_kernel(const Uia
     wait_vm((NP > 2 ? 2 : NP - 1) * pb);                   // K, V, lse and block 0 have landed; blocks 1, 2 stay in flight
     __syncthreads();
     delta_block(0);
+#ifdef ABWD_STAMPS
+    st_pro = STAMP() - st_begin;
+#endif
 
 #ifdef ABWD_PROLOGUE_ONLY
     if (p.L > 0) return;                                  // diagnostic: how long does staging alone take?
@@ -214,6 +232,18 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void attn_bwd_bf16_kernel(const Uia
 
     // Software pipeline over the 32-query blocks: iteration u computes S/dP/dS (and dV, dK) of block u into dSᵀ buffer u&1 and, in the
     // same barrier interval, dQ of block u-1 from the other buffer: one barrier per block, and the two kinds of work interleave.
+    // dQ of a block is STORED one iteration after it was computed, right behind the barrier and in front of that iteration's LDS-DMA:
+    // vmcnt counts stores with the loads, so a store issued after block u+2's pieces made the counted wait at the top of the next
+    // iteration ("all but the youngest pb") wait for those pieces too — the ring ran one block shallower than it was built.
+    f32x4 dq_hold = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto store_dq = [&](int ub) {
+        const int hq = wave >> 2, dt = wave & 3;
+        const int qrow = 32 * ub + 16 * hq + li;
+        if (qrow < L) {
+            bf16_t* drow = (bf16_t*)p.dq + (row0 + qrow) * p.ld_dqkv + (size_t)h * 64 + 4 * g;
+            store4(drow + 16 * dt, dq_hold);
+        }
+    };
 #pragma unroll 1
     for (int u = 0; u <= NP; ++u) {
         char* dST = dST0 + (u & 1) * LPK * 64;
@@ -222,16 +252,28 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void attn_bwd_bf16_kernel(const Uia
         const char* Gb = Qb + 4096;
         // block u+1 must have landed (its δ is computed now), block u+2 may stay in flight.  The barrier also publishes δ of block u
         // and dSᵀ of block u-1, and frees the slot of block u-1 for block u+3.
+#ifdef ABWD_STAMPS
+        const unsigned long long st0 = STAMP();
+#endif
         if (u + 1 < NP) wait_vm(u + 2 < NP ? pb : 0);
         __syncthreads();
+#ifdef ABWD_STAMPS
+        const unsigned long long st1 = STAMP();
+#endif
         if (u == 0) {                                     // the V image is in registers everywhere: the dSᵀ pad rows (keys past the last tile) become zeros
             for (int i = tid; i < (LPK - 16 * LT) * 4; i += 64 * BWD_WAVES) {
                 *(uint4*)(dST0 + 16 * LT * 64 + i * 16) = uint4{0u, 0u, 0u, 0u};
                 *(uint4*)(dST0 + LPK * 64 + 16 * LT * 64 + i * 16) = uint4{0u, 0u, 0u, 0u};
             }
         }
+#ifndef ABWD_NO_DQ
+        if (u >= 2) store_dq(u - 2);
+#endif
         if (u + 3 < NP) issue_block(u + 3);
         if (u + 1 < NP) delta_block(u + 1);
+#ifdef ABWD_STAMPS
+        const unsigned long long st2 = STAMP();
+#endif
         if (u < NP) {
         // per-lane query rows of this 32-query block: q(hq, r) = 32u + 16hq + 4g + r
         f32x4 ls[2], dl[2];
@@ -250,12 +292,18 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void attn_bwd_bf16_kernel(const Uia
                 gf[hq][kk] = *(const uint4*)(Gb + hq * 2048 + (offR ^ (kk << 6)));
             }
         // transposed A operands for dV / dK: dOᵀ and Qᵀ of this block, per d-tile
+        // L > 256 (three key tiles per wave: ViT-L/14's 257 tokens): read these eight fragments one d-tile at a time next to the MFMAs
+        // that use them — held across the key loop they pushed that instantiation into scratch (38 spilled registers, 615 -> 502 us
+        // at B = 256, H = 12); with two tiles per wave holding them is the faster form (298 vs 302 us).
+        constexpr bool LAZY_T = LT_MAX > 16;
         bf16x8 gT[4], qT[4];
+        if constexpr (!LAZY_T) {
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            const int off = trow * 128 + (((2 * dt + (pp >> 1)) ^ tsw) << 4) + 8 * (pp & 1);
-            gT[dt] = tr_pair(Gb + off, Gb + off + 16 * 128);
-            qT[dt] = tr_pair(Qb + off, Qb + off + 16 * 128);
+            for (int dt = 0; dt < 4; ++dt) {
+                const int off = trow * 128 + (((2 * dt + (pp >> 1)) ^ tsw) << 4) + 8 * (pp & 1);
+                gT[dt] = tr_pair(Gb + off, Gb + off + 16 * 128);
+                qT[dt] = tr_pair(Qb + off, Qb + off + 16 * 128);
+            }
         }
         const bool full_q = p.mask_kind == UIA_MASK_NONE && 32 * u + 32 <= L;
 #pragma unroll
@@ -291,6 +339,22 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void attn_bwd_bf16_kernel(const Uia
                             pf[4 * hq + r] = (bf16_t)pv;
                             sf[4 * hq + r] = (bf16_t)dsv;
                         }
+                } else if (p.mask_kind != UIA_MASK_CAUSAL && 32 * u + 32 <= L) {
+                    // boundary key tile (or a key-padding mask) under full query rows: ONE select per element on the lane's key.
+                    // (The general path below costs ~10 VALU per element; the wave that owns the last, partial key tile of a
+                    // 197-token head took it in every block and was the one the other seven waited for: 20.5 K cycles against
+                    // 13 K for its two tiles, tools/abwd_stamps.sh.)
+                    const bool key_ok = key < klen;
+#pragma unroll
+                    for (int hq = 0; hq < 2; ++hq)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float pe = __builtin_amdgcn_exp2f(fmaf(s[hq][r], sc, -ls[hq][r]));
+                            const float pv = key_ok ? pe : 0.f;
+                            const float dsv = pv * fmaf(dp[hq][r], p.scale, -dl[hq][r]);
+                            pf[4 * hq + r] = (bf16_t)pv;
+                            sf[4 * hq + r] = (bf16_t)dsv;
+                        }
                 } else {
 #pragma unroll
                     for (int hq = 0; hq < 2; ++hq)
@@ -316,6 +380,11 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void attn_bwd_bf16_kernel(const Uia
 #ifndef ABWD_NO_DVDK
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
+                    if constexpr (LAZY_T) {
+                        const int off = trow * 128 + (((2 * dt + (pp >> 1)) ^ tsw) << 4) + 8 * (pp & 1);
+                        gT[dt] = tr_pair(Gb + off, Gb + off + 16 * 128);
+                        qT[dt] = tr_pair(Qb + off, Qb + off + 16 * 128);
+                    }
                     dVt[a][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gT[dt], pf, dVt[a][dt], 0, 0, 0);
                     dKt[a][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT[dt], sf, dKt[a][dt], 0, 0, 0);
                 }
@@ -323,6 +392,10 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void attn_bwd_bf16_kernel(const Uia
             }
         }
         }
+#ifdef ABWD_STAMPS
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const unsigned long long st3 = STAMP();
+#endif
         // ---- dQᵀ[d][q] = Σ_key Kᵀ[d][key] · dSᵀ[key][q] of the PREVIOUS block; wave w → query tile hq = w>>2, d-tile w&3.
         //      Both operands are transpose reads: Kᵀ from the K tile, dSᵀ columns from the [key][query] tile.
 #ifndef ABWD_NO_DQ
@@ -346,14 +419,17 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void attn_bwd_bf16_kernel(const Uia
                 dq = dq_step(kbk, dq);
                 if (kbk + 1 < NP) dq1 = dq_step(kbk + 1, dq1);
             }
-            dq += dq1;
-            const int qrow = 32 * (u - 1) + 16 * hq + li;
-            if (qrow < L) {
-                bf16_t* drow = (bf16_t*)p.dq + (row0 + qrow) * p.ld_dqkv + (size_t)h * 64 + 4 * g;
-                store4(drow + 16 * dt, dq);
-            }
+            dq_hold = dq + dq1;
         }
+#ifdef ABWD_STAMPS
+        asm volatile("" :: "v"(dq_hold));
+        const unsigned long long st4 = STAMP();
+        st_acc[0] += st1 - st0; st_acc[1] += st2 - st1; st_acc[2] += st3 - st2; st_acc[3] += st4 - st3;
+#endif
     }
+#ifndef ABWD_NO_DQ
+    store_dq(NP - 1);
+#endif
     // ---- dK, dV: lane owns key 16kt+li, d = 16dt + 4g + r
 #pragma unroll
     for (int a = 0; a < KTW; ++a) {
@@ -366,6 +442,12 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void attn_bwd_bf16_kernel(const Uia
             for (int dt = 0; dt < 4; ++dt) { store4(krow + 16 * dt, dKt[a][dt]); store4(vrow + 16 * dt, dVt[a][dt]); }
         }
     }
+#ifdef ABWD_STAMPS
+    if (blockIdx.x == 1500 && lane == 0) {
+        unsigned long long* o = uia_abwd_stamps + wave * 8;
+        o[0] = st_acc[0]; o[1] = st_acc[1]; o[2] = st_acc[2]; o[3] = st_acc[3]; o[4] = st_pro; o[5] = STAMP() - st_begin;
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------

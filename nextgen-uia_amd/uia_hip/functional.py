@@ -100,6 +100,22 @@ def t_copy_of(g32, dt):
 def clear_t_copies():
     _T_COPIES.clear()
     _ROWS[0] = None
+    _SUMS_ARENA[0] = None
+
+
+# Zeroed [M, 2] row-sum buffers for the producers of folded LayerNorms: slices of one arena that a single fill zeroes (a block needs two or
+# three of them per forward; 36 fills of 400 KB per step otherwise).  A slice is handed out once; the arena is dropped with the other
+# per-step registries (clear_t_copies) or when it runs out, and a new one is zeroed on the next request.
+_SUMS_ARENA = [None]
+
+
+def zero_sums(M, device):
+    a = _SUMS_ARENA[0]
+    if a is None or a[0].shape[1] != M or a[0].device != device or a[1] >= a[0].shape[0]:
+        a = [torch.zeros(48, M, 2, device=device, dtype=torch.float32), 0]
+        _SUMS_ARENA[0] = a
+    a[1] += 1
+    return a[0][a[1] - 1]
 
 
 # The forward twin of the registry above, one slot deep: the GEMM that produces a residual-stream tensor (Mona project2, a block's fc2)
@@ -293,7 +309,7 @@ class MonaFn(torch.autograd.Function):
         w2 = WEIGHTS.get(P["project2.weight"], dt)
         y = torch.empty_like(x)
         if ln_fold_enabled(dt):                # the next block's first LayerNorm is folded into its QKV GEMM: leave it the T rows and their sums
-            y_t, sums = _empty((M, D), dt, x), torch.zeros(M, 2, device=x.device, dtype=torch.float32)
+            y_t, sums = _empty((M, D), dt, x), zero_sums(M, x.device)
             ops.gemm(d, w2, bias=P["project2.bias"], resid=x.view(M, D), out32=y.view(M, D), out_t=y_t, rowsum=sums)
             publish_rows(y, y_t, sums)
         else:
@@ -402,7 +418,7 @@ class VitBlockFn(torch.autograd.Function):
         f = _empty((M, F), dt, x)
         pre = _empty((M, F), dt, x) if train else None
         if fold:                                          # LN2 folded: proj leaves T rows + sums, fc1 normalises its accumulators
-            sums1 = torch.zeros(M, 2, device=x.device, dtype=torch.float32)
+            sums1 = zero_sums(M, x.device)
             ops.gemm(a, WEIGHTS.get(spec.proj[0], dt), bias=spec.proj[1], resid=x2d, out32=x1, out_t=h1, rowsum=sums1)
             w1, c1, b1 = WEIGHTS.get_lnfold(spec.fc1[0], spec.fc1[1], spec.ln2[0], spec.ln2[1], dt)
             ops.gemm(h1, w1, bias=b1, act=spec.act, aux_out=pre, out_t=f, lnfold=(sums1, c1, D, spec.eps))
@@ -412,7 +428,7 @@ class VitBlockFn(torch.autograd.Function):
             ops.gemm(h1, WEIGHTS.get(spec.fc1[0], dt), bias=spec.fc1[1], act=spec.act, aux_out=pre, out_t=f)
         x2 = torch.empty_like(x)
         if fold and spec.publish_out:
-            sums2 = torch.zeros(M, 2, device=x.device, dtype=torch.float32)
+            sums2 = zero_sums(M, x.device)
             ops.gemm(f, WEIGHTS.get(spec.fc2[0], dt), bias=spec.fc2[1], resid=x1, out32=x2.view(M, D), out_t=h1, rowsum=sums2)
             publish_rows(x2, h1, sums2)
         else:

@@ -1,0 +1,30 @@
+#!/bin/bash
+# PMC counters of the attention kernels in isolation (tools/time_attention.py): instruction mix, LDS activity / bank conflicts, wait breakdown.
+# One rocprofv3 --pmc pass per counter group (no tracing domain beside them); CSVs -> gpurun_out/pmc_attn/<group>/
+cd /tmp && export TMPDIR=/tmp
+OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_attn
+mkdir -p $OUT
+cd $GRAFT_REPO_ROOT
+i=0
+for G in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU" \
+         "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC" \
+         "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_VMEM SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE"; do
+  i=$((i+1))
+  rocprofv3 --pmc $G --kernel-trace --output-format csv -d $OUT/g$i -o pmc -- python3 tools/time_attention.py > $OUT/g$i.log 2>&1 || { tail -5 $OUT/g$i.log; exit 1; }
+done
+python3 - <<'PY'
+import csv, glob, os, collections
+out = os.path.join(os.environ["GRAFT_REPO_ROOT"], "gpurun_out", "pmc_attn")
+acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+for f in glob.glob(out + "/g*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"][:48]
+        if "attn" not in k:
+            continue
+        a = acc[k][r["Counter_Name"]]
+        a[0] += float(r["Counter_Value"]); a[1] += 1
+for k, d in acc.items():
+    print(k)
+    for c, (v, n) in sorted(d.items()):
+        print(f"   {c:34s} {v / n:16.0f}  ({n} launches)")
+PY
