@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--unpad-text", action="store_true", help="opt-in: the frozen text tower computes only the valid tokens of each caption "
                     "(identical features, less executed work than the reference's dense 256 positions; not the headline configuration)")
     ap.add_argument("--no-kblock-w", action="store_true", help="A/B knob: keep the GEMM weights row-major (default: K-blocked for the ring kernels)")
+    ap.add_argument("--no-kblock-act", action="store_true", help="A/B knob: GEMM -> GEMM activations stay row-major (default: the producing epilogue writes them "
+                    "K-blocked for the ring kernel that reads them)")
     ap.add_argument("--no-k64-cfg14", action="store_true", help="A/B knob: single-K-step GEMMs on the 256x256 tiles")
     ap.add_argument("--no-tail-split", action="store_true", help="A/B knob: no half-height tiles for the M tail of a launch")
     ap.add_argument("--global-loss", action="store_true", help="opt-in: InfoNCE over the global batch (all-gathered features) instead of "
@@ -144,6 +146,7 @@ def main():
     UF.set_deferred_text_ln(not args.no_deferred_text_ln)
     UF.set_ln_fold(not args.no_ln_fold)
     ops.KBLOCK_W, ops.TAIL_SPLIT, ops.K64_CFG14 = not args.no_kblock_w, not args.no_tail_split, not args.no_k64_cfg14
+    ops.KBLOCK_ACT = not args.no_kblock_act
 
     model = create_biomedclip(seed=0)                                # same weights on every rank (random init: no network for checkpoints)
     for p in model.parameters():

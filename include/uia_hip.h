@@ -85,6 +85,15 @@ typedef struct uia_gemm_desc {
     int32_t lnfold_dim; float lnfold_eps;
     int32_t resid_ln_dim; float resid_ln_eps;   /* resid_ln_dim > 0: resid_ln_stats holds (Σ, Σ²) over resid_ln_dim columns as rowsum_out leaves
                                                    them, not (mean, rstd); mean = Σ/dim, rstd = rsqrt(max(Σ²/dim − mean², 0) + resid_ln_eps) */
+    /* K-BLOCKED ACTIVATIONS (ring tile configs with 64-byte sub-tiles: 8, 10, 13, 14; the other configs reject them).  The operand of a
+     * large GEMM streams fastest as [K·sizeof(T)/64][rows][64 bytes] (each 1 KiB LDS-DMA piece = 8 whole 128-byte lines; +1.5…3.4 % per
+     * launch on the step's shapes, profiles/r02_a_gemm_order_layout.txt).  A GEMM whose T result is the next GEMM's A operand can write it
+     * in that layout directly, and the consumer reads it with a_kb_rows set:
+     *   a_kb_rows    > 0: A is K-blocked; element (m, k) is at A[((k / g)·a_kb_rows + m)·g + k % g], g = 64 / sizeof(T) (lda ignored).
+     *                     a_kb_rows is the row count of the WHOLE K-blocked tensor (its plane stride), A may point at a row offset in it.
+     *   outT_kb_rows > 0: the T output is written K-blocked the same way, column n playing the part of k (N·sizeof(T) % 64 == 0; ldo ignored). */
+    int64_t a_kb_rows;
+    int64_t outT_kb_rows;
 } uia_gemm_desc;
 int uia_gemm(void* stream, int dtype, const uia_gemm_desc* d, int tile_cfg /* 0 = auto */);
 

@@ -380,7 +380,14 @@ __device__ __forceinline__ void gemm_epilogue_lds(const UiaGemmParams& p, f32x4 
             for (int e = 0; e < 8; ++e) v[e] += r[e];
         }
         if (f_out32 && UIA_EPI_STORES) store8(p.out32 + orow * p.ldo32 + n, v);
-        if (f_outT && UIA_EPI_STORES) store8(outT + orow * p.ldo + n, v);
+        if (f_outT && UIA_EPI_STORES) {
+            if (p.outT_kb_rows) {                         // K-blocked for the GEMM that reads it as A: 64-byte column blocks, rows contiguous inside a block
+                constexpr int G = 64 / (int)sizeof(T);
+                store8(outT + ((size_t)(n / G) * (size_t)p.outT_kb_rows + orow) * G + (n % G), v);
+            } else {
+                store8(outT + orow * p.ldo + n, v);
+            }
+        }
         }
         if (f_rowsum) {                                   // every lane takes part (DPP), rows / columns past the edge contribute zero
             float s1 = 0.f, s2 = 0.f;
@@ -831,10 +838,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_tn_ring_kernel(co
     // one contiguous 16 KiB run, each 1 KiB LDS-DMA piece reads 8 whole 128-byte lines instead of 16 half lines, and the DMA-only
     // K step drops from 3150 to 2880 cycles (N = 2304) / 2350 to 1980 (N = 768): +2…9 % on the whole kernel (profiles/r02_a).
 #if defined(UIA_GEMM_STAMPS) || defined(UIA_GEMM_EXP)
-    const bool kbA = (xflags >> 8) & 1;                               // diagnostic only: A addressed as if it were K-blocked too
+    const bool kbA = p.a_kb_rows != 0 || ((xflags >> 8) & 1);         // bit 8, diagnostic only: A addressed as if it were K-blocked
     const bool kbW = p.w_kblocked != 0 || ((xflags >> 9) & 1);
 #else
-    constexpr bool kbA = false;
+    const bool kbA = p.a_kb_rows != 0;
     const bool kbW = p.w_kblocked != 0;
 #endif
 
@@ -861,7 +868,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_tn_ring_kernel(co
         gn = gn < p.N ? gn : p.N - 1;
         srcW[i] = kbW ? (const char*)p.W + (size_t)gn * BKB + c * 16 : (const char*)p.W + ((size_t)gn * (size_t)p.ldw) * ESZ + c * 16;
     }
-    const size_t kstepA = kbA ? (size_t)p.M * BKB : (size_t)BKB, kstepW = kbW ? (size_t)p.N * BKB : (size_t)BKB;
+    const size_t kstepA = kbA ? (size_t)(p.a_kb_rows ? p.a_kb_rows : p.M) * BKB : (size_t)BKB, kstepW = kbW ? (size_t)p.N * BKB : (size_t)BKB;
     const int li = lane & 15, g = lane >> 4;
     const int rowA = wm * WTM + li;                                         // + 16·mt  (keeps (row>>1)&7 and (row>>2)&3)
     const int rowW = wn * WTN + (li >> 2) * 16 + (li & 3);                  // + 4·j
@@ -1386,6 +1393,10 @@ int launch_typed(hipStream_t stream, const UiaGemmParams& p, int cfg_in) {
                                  //  fp32-residual ones, and a net loss inside the two-stream training step: opt-in only.)
     }
     const bool ring = cfg == 8 || cfg == 9 || cfg == 10 || cfg == 13 || cfg == 14 || cfg == 15;
+    if ((p.a_kb_rows || p.outT_kb_rows) && !(cfg == 8 || cfg == 10 || cfg == 13 || cfg == 14 || cfg == 15)) {
+        uia_set_error("uia_gemm: K-blocked activations (a_kb_rows / outT_kb_rows) need a ring tile config with 64-byte sub-tiles (8, 10, 13, 14), not %d", cfg);
+        return -1;
+    }
     if (p.w_kblocked && !ring) {
         uia_set_error("uia_gemm: a K-blocked W needs a ring tile config (8, 9, 10, 13), not %d", cfg);
         return -1;
@@ -1434,11 +1445,11 @@ int uia_gemm_launch(hipStream_t stream, int dtype, const UiaGemmParams& p, int c
     UIA_CHECK_ARG(p.K % bk == 0, "uia_gemm: K=%d must be a multiple of %d for this dtype", p.K, bk);
     UIA_CHECK_ARG(p.N % 8 == 0, "uia_gemm: N=%d must be a multiple of 8", p.N);
     UIA_CHECK_ARG(p.A && p.W, "uia_gemm: null operand");
-    UIA_CHECK_ARG(p.lda >= p.K && p.ldw >= p.K, "uia_gemm: leading dimension smaller than K");
-    UIA_CHECK_ARG((p.lda * esz) % 16 == 0 && (p.ldw * esz) % 16 == 0, "uia_gemm: rows must be 16-byte aligned");
+    UIA_CHECK_ARG((p.a_kb_rows || p.lda >= p.K) && p.ldw >= p.K, "uia_gemm: leading dimension smaller than K");
+    UIA_CHECK_ARG((p.a_kb_rows || (p.lda * esz) % 16 == 0) && (p.ldw * esz) % 16 == 0, "uia_gemm: rows must be 16-byte aligned");
     UIA_CHECK_ARG(((uintptr_t)p.A % 16) == 0 && ((uintptr_t)p.W % 16) == 0, "uia_gemm: operands must be 16-byte aligned");
     UIA_CHECK_ARG(p.outT || p.out32, "uia_gemm: no output");
-    UIA_CHECK_ARG(!p.outT || (p.ldo % 8 == 0 && (uintptr_t)p.outT % 16 == 0), "uia_gemm: outT alignment");
+    UIA_CHECK_ARG(!p.outT || ((p.outT_kb_rows || p.ldo % 8 == 0) && (uintptr_t)p.outT % 16 == 0), "uia_gemm: outT alignment");
     UIA_CHECK_ARG(!p.out32 || (p.ldo32 % 4 == 0 && (uintptr_t)p.out32 % 16 == 0), "uia_gemm: out32 alignment");
     UIA_CHECK_ARG(!p.resid || (p.ldr % 4 == 0 && (uintptr_t)p.resid % 16 == 0), "uia_gemm: resid alignment");
     UIA_CHECK_ARG(!p.residT || (p.ldrT % 8 == 0 && (uintptr_t)p.residT % 16 == 0), "uia_gemm: residT alignment");
@@ -1450,12 +1461,15 @@ int uia_gemm_launch(hipStream_t stream, int dtype, const UiaGemmParams& p, int c
     UIA_CHECK_ARG(!p.resid_ln_stats || (p.resid && p.resid_ln_w && p.resid_ln_b), "uia_gemm: resid_ln_stats needs resid, resid_ln_w and resid_ln_b");
     UIA_CHECK_ARG(!p.resid_ln_stats || ((uintptr_t)p.resid_ln_stats % 8 == 0 && (uintptr_t)p.resid_ln_w % 16 == 0 && (uintptr_t)p.resid_ln_b % 16 == 0),
                   "uia_gemm: resid_ln alignment");
+    UIA_CHECK_ARG(p.a_kb_rows == 0 || p.a_kb_rows >= p.M, "uia_gemm: a_kb_rows=%lld < M=%d", (long long)p.a_kb_rows, p.M);
+    UIA_CHECK_ARG(p.outT_kb_rows == 0 || (p.outT && p.outT_kb_rows >= p.M && (p.N * esz) % 64 == 0 && p.out_group == 0),
+                  "uia_gemm: outT_kb_rows needs outT, at least M rows, N*sizeof(T) a multiple of 64 and no row remapping");
     UIA_CHECK_ARG(!p.resid_ln_stats || p.resid_ln_dim >= 0, "uia_gemm: resid_ln_dim=%d", p.resid_ln_dim);
     UIA_CHECK_ARG(!p.rowsum_out || ((uintptr_t)p.rowsum_out % 8 == 0 && p.out_group == 0), "uia_gemm: rowsum_out must be 8-byte aligned and takes no row remapping");
     UIA_CHECK_ARG(!p.lnfold_sums || (p.lnfold_colsum && p.lnfold_dim > 0 && p.alpha == 1.0f && (uintptr_t)p.lnfold_sums % 8 == 0 && (uintptr_t)p.lnfold_colsum % 16 == 0),
                   "uia_gemm: lnfold_sums needs lnfold_colsum (16-byte aligned), lnfold_dim > 0 and alpha == 1");
     // every row the epilogue touches must hold N elements: a leading dimension below N would make row m's tail overwrite row m+1
-    UIA_CHECK_ARG(!p.outT || p.ldo >= p.N, "uia_gemm: ldo=%lld < N=%d", (long long)p.ldo, p.N);
+    UIA_CHECK_ARG(!p.outT || p.outT_kb_rows || p.ldo >= p.N, "uia_gemm: ldo=%lld < N=%d", (long long)p.ldo, p.N);
     UIA_CHECK_ARG(!p.out32 || p.ldo32 >= p.N, "uia_gemm: ldo32=%lld < N=%d", (long long)p.ldo32, p.N);
     UIA_CHECK_ARG(!p.aux_out || p.ldaux_out >= p.N, "uia_gemm: ldaux_out=%lld < N=%d", (long long)p.ldaux_out, p.N);
     UIA_CHECK_ARG(!p.aux_in || p.ldaux_in >= p.N, "uia_gemm: ldaux_in=%lld < N=%d", (long long)p.ldaux_in, p.N);

@@ -271,6 +271,22 @@ def _empty(shape, dt, like):
     return torch.empty(shape, device=like.device, dtype=dt)
 
 
+def _act(M, K, dt, like, n_consumer):
+    """Storage of an [M, K] activation that one GEMM epilogue writes and one GEMM with n_consumer columns reads: K-blocked
+    ([K/g, M, g], ops.kb_empty) when both launches run on the ring kernels, plain row-major otherwise."""
+    if ops.kb_ok(M, n_consumer, K, dt):
+        return ops.kb_empty(M, K, dt, like.device)
+    return torch.empty((M, K), device=like.device, dtype=dt)
+
+
+def _as_act(buf, M, K, dt, n_consumer):
+    """The same, re-using the storage of a dead [M, K] buffer (either layout) of the same dtype."""
+    if ops.kb_ok(M, n_consumer, K, dt):
+        g = ops.kb_group(dt)
+        return buf if buf.dim() == 3 else buf.view(K // g, M, g)
+    return buf if buf.dim() == 2 else buf.reshape(-1).view(M, K)
+
+
 # ================================================================================================ Mona
 MONA_PARAM_ORDER = ("gamma", "gammax", "project1.weight", "project1.bias", "project2.weight", "project2.bias", "norm.weight", "norm.bias",
                     "adapter_conv.conv1.weight", "adapter_conv.conv1.bias", "adapter_conv.conv2.weight", "adapter_conv.conv2.bias",
@@ -309,7 +325,7 @@ class MonaFn(torch.autograd.Function):
         w2 = WEIGHTS.get(P["project2.weight"], dt)
         y = torch.empty_like(x)
         if ln_fold_enabled(dt):                # the next block's first LayerNorm is folded into its QKV GEMM: leave it the T rows and their sums
-            y_t, sums = _empty((M, D), dt, x), zero_sums(M, x.device)
+            y_t, sums = _act(M, D, dt, x, 3 * D), zero_sums(M, x.device)          # read by the next block's QKV GEMM only
             ops.gemm(d, w2, bias=P["project2.bias"], resid=x.view(M, D), out32=y.view(M, D), out_t=y_t, rowsum=sums)
             publish_rows(y, y_t, sums)
         else:
@@ -404,8 +420,9 @@ class VitBlockFn(torch.autograd.Function):
         qkv = _empty((M, 3 * D), dt, x)
         if rows is not None:                              # LN1 folded into the QKV GEMM
             wq, cq, bq = WEIGHTS.get_lnfold(spec.qkv[0], spec.qkv[1], spec.ln1[0], spec.ln1[1], dt)
-            ops.gemm(rows[0].view(M, D), wq, bias=bq, out_t=qkv, lnfold=(rows[1], cq, D, spec.eps))
-            h1 = rows[0].view(M, D)                       # its storage is free after this GEMM
+            xin_t = rows[0] if ops.is_kb(rows[0]) else rows[0].view(M, D)
+            ops.gemm(xin_t, wq, bias=bq, out_t=qkv, lnfold=(rows[1], cq, D, spec.eps))
+            h1 = xin_t                                    # its storage is free after this GEMM
         else:
             h1 = _empty((M, D), dt, x)
             ops.layernorm_fwd(x2d, spec.ln1[0], spec.ln1[1], spec.eps, y_t=h1)
@@ -415,20 +432,23 @@ class VitBlockFn(torch.autograd.Function):
         ops.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], a, B, spec.heads, N, lse=lse, mask=spec.mask)
         x1 = torch.empty_like(x2d)
         F = spec.fc1[0].shape[0]
-        f = _empty((M, F), dt, x)
+        f = _act(M, F, dt, x, D)                          # fc1's result is read by fc2 only
         pre = _empty((M, F), dt, x) if train else None
         if fold:                                          # LN2 folded: proj leaves T rows + sums, fc1 normalises its accumulators
             sums1 = zero_sums(M, x.device)
+            h1 = _as_act(h1, M, D, dt, F)
             ops.gemm(a, WEIGHTS.get(spec.proj[0], dt), bias=spec.proj[1], resid=x2d, out32=x1, out_t=h1, rowsum=sums1)
             w1, c1, b1 = WEIGHTS.get_lnfold(spec.fc1[0], spec.fc1[1], spec.ln2[0], spec.ln2[1], dt)
             ops.gemm(h1, w1, bias=b1, act=spec.act, aux_out=pre, out_t=f, lnfold=(sums1, c1, D, spec.eps))
         else:
             ops.gemm(a, WEIGHTS.get(spec.proj[0], dt), bias=spec.proj[1], resid=x2d, out32=x1)
+            h1 = _as_act(h1, M, D, dt, 0)                                              # row-major: the LayerNorm kernel writes it
             ops.layernorm_fwd(x1, spec.ln2[0], spec.ln2[1], spec.eps, y_t=h1)          # h1 buffer reused as h2
             ops.gemm(h1, WEIGHTS.get(spec.fc1[0], dt), bias=spec.fc1[1], act=spec.act, aux_out=pre, out_t=f)
         x2 = torch.empty_like(x)
         if fold and spec.publish_out:
             sums2 = zero_sums(M, x.device)
+            h1 = _as_act(h1, M, D, dt, 3 * D)
             ops.gemm(f, WEIGHTS.get(spec.fc2[0], dt), bias=spec.fc2[1], resid=x1, out32=x2.view(M, D), out_t=h1, rowsum=sums2)
             publish_rows(x2, h1, sums2)
         else:
@@ -448,7 +468,7 @@ class VitBlockFn(torch.autograd.Function):
         dx2 = dx2.contiguous()
         dx2_t = t_copy_of(dx2, dt).view(M, D)
         # fc2 dgrad fused with act'(pre)
-        dpre = _empty((M, F), dt, x)
+        dpre = _act(M, F, dt, x, D)                       # read by the fc1 dgrad GEMM only
         ops.gemm(dx2_t, WEIGHTS.get(spec.fc2[0], dt, transpose=True), dact=spec.act, aux_in=pre, out_t=dpre)
         dh = _empty((M, D), dt, x)
         ops.gemm(dpre, WEIGHTS.get(spec.fc1[0], dt, transpose=True), out_t=dh)
@@ -515,7 +535,8 @@ def post_ln_layer(res, x_t, L, B, heads, P, keylen, eps=1e-12, cu_seqlens=None, 
     set_ln_fold (bf16): fold_sums = zeroed fp32 [2, M, 2] lets the two LayerNorms of this layer fold into their neighbouring GEMMs: the
     attention-output LayerNorm always (both neighbours are inside the layer), the output LayerNorm when fold_out says that the next
     layer will take (x_t = T copy of the RAW sum, res.dim set) instead of the normalised operand.  A `res` with .dim set is such an input."""
-    M, D = x_t.shape
+    kb_in = ops.is_kb(x_t)                            # T copy of a raw sum written K-blocked by the previous layer's last GEMM
+    M, D = (x_t.shape[1], x_t.shape[0] * x_t.shape[2]) if kb_in else x_t.shape
     dt = x_t.dtype
     # Post-LN: the residual entering each sub-layer IS the previous LayerNorm's output, so in bf16 mode its T copy (the GEMM
     # operand) could serve as the residual too (saves the residual's fp32 read as well).  Measured at full depth
@@ -537,10 +558,10 @@ def post_ln_layer(res, x_t, L, B, heads, P, keylen, eps=1e-12, cu_seqlens=None, 
     del qkv
     s_a = torch.empty(M, D, device=x_t.device, dtype=torch.float32)
     F = P["intermediate.dense.weight"].shape[0]
-    f = _empty((M, F), dt, x_t)
+    f = _act(M, F, dt, x_t, D)
     if fold:
         lw_a, lb_a = P["attention.output.LayerNorm.weight"], P["attention.output.LayerNorm.bias"]
-        s_a_t = _empty((M, D), dt, x_t)
+        s_a_t = _act(M, D, dt, x_t, F)
         ops.gemm(a, WEIGHTS.get(P["attention.output.dense.weight"], dt), bias=P["attention.output.dense.bias"], out32=s_a, out_t=s_a_t,
                  rowsum=fold_sums[0], **res.gemm_kw())
         res_a = LnResidual(s_a, fold_sums[0], lw_a, lb_a, D, eps)
@@ -550,16 +571,19 @@ def post_ln_layer(res, x_t, L, B, heads, P, keylen, eps=1e-12, cu_seqlens=None, 
     else:
         ops.gemm(a, WEIGHTS.get(P["attention.output.dense.weight"], dt), bias=P["attention.output.dense.bias"], out32=s_a,
                  **(dict(resid_t=x_t) if t_resid else res.gemm_kw()))
+        x_t = _as_act(x_t, M, D, dt, 0)
         res_a = _post_ln(s_a, P["attention.output.LayerNorm.weight"], P["attention.output.LayerNorm.bias"], eps, x_t)
         ops.gemm(x_t, WEIGHTS.get(P["intermediate.dense.weight"], dt), bias=P["intermediate.dense.bias"], act="gelu", out_t=f)
     s_o = res.raw                                     # the previous sub-layer sum was last read by the attention-output GEMM above: its storage takes the new sum
     if fold and fold_out:                             # the next layer folds this LayerNorm into its QKV GEMM: x_t becomes the T copy of the raw sum
+        x_t = _as_act(x_t, M, D, dt, 3 * D)
         ops.gemm(f, WEIGHTS.get(P["output.dense.weight"], dt), bias=P["output.dense.bias"], out32=s_o, out_t=x_t, rowsum=fold_sums[1],
                  **res_a.gemm_kw())
         return LnResidual(s_o, fold_sums[1], P["output.LayerNorm.weight"], P["output.LayerNorm.bias"], D, eps), x_t
     ops.gemm(f, WEIGHTS.get(P["output.dense.weight"], dt), bias=P["output.dense.bias"], out32=s_o,
              **(dict(resid_t=x_t) if t_resid else res_a.gemm_kw()))
     stats_buf = res.stats if (res.dim is None and res.stats is not None) else None
+    x_t = _as_act(x_t, M, D, dt, 0)                   # the LayerNorm kernel writes row-major
     return _post_ln(s_o, P["output.LayerNorm.weight"], P["output.LayerNorm.bias"], eps, x_t, stats_buf=stats_buf), x_t
 
 

@@ -82,6 +82,38 @@ def tail_split_rows(M, N, ncu, bm=256, bn=256):
     return main_panels * bm
 
 
+KBLOCK_ACT = True        # GEMM -> GEMM activations travel K-blocked ([K/g][rows][g]) between ring-kernel launches (kb_empty / is_kb)
+
+
+def kb_group(dt):
+    return 64 // torch.empty(0, dtype=dt).element_size()
+
+
+def kb_ok(M, N_consumer, K, dt):
+    """May an [M, K] activation that ONE GEMM epilogue writes and ONE GEMM (N_consumer columns) reads travel K-blocked?  Both launches
+    must land on a ring tile config with 64-byte sub-tiles (M > 2048 and more than 64 columns on either side)."""
+    return (KBLOCK_ACT and K % kb_group(dt) == 0 and K > 64 and auto_tile_cfg(M, N_consumer, K, torch.empty(0, dtype=dt).element_size()) in (8, 14)
+            and auto_tile_cfg(M, K, 128, torch.empty(0, dtype=dt).element_size()) == 8)
+
+
+def kb_empty(M, K, dt, device):
+    """Storage of an [M, K] activation in the K-blocked layout: a [K/g, M, g] tensor (g = 64 bytes of elements).  ops.gemm recognises
+    3-D `a` / `out_t` arguments as K-blocked; nothing else may read such a tensor."""
+    g = kb_group(dt)
+    return torch.empty(K // g, M, g, device=device, dtype=dt)
+
+
+def is_kb(t):
+    return t is not None and t.dim() == 3
+
+
+def _kb_dims(t, name):
+    g = kb_group(t.dtype)
+    if t.shape[2] != g or t.stride(2) != 1 or t.stride(1) != g or t.stride(0) % g or t.stride(0) // g < t.shape[1]:
+        raise UiaError(f"{name}: not a K-blocked [K/{g}, rows, {g}] activation (shape {tuple(t.shape)}, stride {t.stride()})")
+    return t.shape[1], t.shape[0] * g, t.stride(0) // g          # rows, columns, rows of the whole tensor (plane stride)
+
+
 class PackedW:
     """A GEMM weight [N, K] in the compute dtype, with its K-blocked twin [K/g][N][g] (g = 64 bytes of elements) built on first
     use by a ring-kernel launch.  Layout plumbing only (a strided copy); which one a launch takes is decided in gemm()."""
@@ -166,15 +198,16 @@ def gemm(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None, res
     rows and `w` is pre-scaled by the LayerNorm weight; the epilogue applies the LayerNorm (include/uia_hip.h, uia_gemm_desc)."""
     packed = w if isinstance(w, PackedW) else None
     wrow = packed.row if packed is not None else w
-    M, N = a.shape[0], wrow.shape[0]
-    if not K64_CFG14 and tile_cfg == 0 and auto_tile_cfg(M, N, a.shape[1], a.element_size()) == 14:
+    M, N = (a.shape[1] if is_kb(a) else a.shape[0]), wrow.shape[0]
+    Ka = wrow.shape[1]
+    if not K64_CFG14 and tile_cfg == 0 and auto_tile_cfg(M, N, Ka, a.element_size()) == 14:
         tile_cfg = 8
-    if (TAIL_SPLIT and tile_cfg == 0 and out_group == 0 and resid_mod == 0 and a.is_cuda and auto_tile_cfg(M, N, a.shape[1], a.element_size()) == 8):
+    if (TAIL_SPLIT and tile_cfg == 0 and out_group == 0 and resid_mod == 0 and a.is_cuda and auto_tile_cfg(M, N, Ka, a.element_size()) == 8):
         m_main = tail_split_rows(M, N, num_cus(a.device.index))
         if m_main < M:
-            cut = lambda t, lo, hi: None if t is None else t[lo:hi]
+            cut = lambda t, lo, hi: None if t is None else (t[:, lo:hi] if is_kb(t) else t[lo:hi])     # K-blocked: rows are dim 1
             for lo, hi, cfg in ((0, m_main, 8), (m_main, M, 13)):
-                _gemm_one(a[lo:hi], w, bias=bias, act=act, dact=dact, aux_in=cut(aux_in, lo, hi), aux_out=cut(aux_out, lo, hi), resid=cut(resid, lo, hi),
+                _gemm_one(cut(a, lo, hi), w, bias=bias, act=act, dact=dact, aux_in=cut(aux_in, lo, hi), aux_out=cut(aux_out, lo, hi), resid=cut(resid, lo, hi),
                           resid_t=cut(resid_t, lo, hi), out_t=cut(out_t, lo, hi), out32=cut(out32, lo, hi), alpha=alpha, tile_cfg=cfg,
                           resid_ln=None if resid_ln is None else (resid_ln[0][lo:hi],) + tuple(resid_ln[1:]), rowsum=cut(rowsum, lo, hi),
                           lnfold=None if lnfold is None else (lnfold[0][lo:hi],) + tuple(lnfold[1:]))
@@ -190,11 +223,17 @@ def _gemm_one(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None
     packed = w if isinstance(w, PackedW) else None
     if packed is not None:
         w = packed.row
-    d.lda, d.ldw = _rowmajor(a, "a"), _rowmajor(w, "w")
-    if a.dtype != w.dtype or a.shape[1] != w.shape[1]:
+    d.ldw = _rowmajor(w, "w")
+    if is_kb(a):
+        d.M, d.K, d.a_kb_rows = _kb_dims(a, "gemm a")
+        d.lda = d.K
+    else:
+        d.lda = _rowmajor(a, "a")
+        d.M, d.K = a.shape[0], a.shape[1]
+    if a.dtype != w.dtype or d.K != w.shape[1]:
         raise UiaError(f"gemm operand mismatch: a {tuple(a.shape)} {a.dtype}, w {tuple(w.shape)} {w.dtype}")
     d.A, d.W = _p(a), _p(w)
-    d.M, d.K, d.N = a.shape[0], a.shape[1], w.shape[0]
+    d.N = w.shape[0]
     base_cfg = (tile_cfg & 255) or auto_tile_cfg(d.M, d.N, d.K, a.element_size())
     if packed is not None and KBLOCK_W and base_cfg in RING_CFGS and a.is_cuda:
         d.W, d.w_kblocked = _p(packed.kblocked()), 1
@@ -207,7 +246,11 @@ def _gemm_one(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None
                           ("out_t", out_t, a.dtype), ("resid", resid, torch.float32), ("out32", out32, torch.float32)):
         if t is not None and t.dtype != want:
             raise UiaError(f"gemm {name} must be {want}, got {t.dtype}")
-    for name, t in (("aux_in", aux_in), ("aux_out", aux_out), ("resid_t", resid_t), ("out_t", out_t), ("out32", out32)):
+    if is_kb(out_t):
+        rows, cols, plane = _kb_dims(out_t, "gemm out_t")
+        if rows < d.M or cols != d.N or out_group:
+            raise UiaError(f"gemm out_t (K-blocked {tuple(out_t.shape)}) does not hold the [{d.M}, {d.N}] result")
+    for name, t in (("aux_in", aux_in), ("aux_out", aux_out), ("resid_t", resid_t), ("out_t", None if is_kb(out_t) else out_t), ("out32", out32)):
         if t is not None and (t.dim() != 2 or t.shape[1] < d.N or (t.shape[0] < d.M and out_group == 0)):
             raise UiaError(f"gemm {name} is {tuple(t.shape)}: too small for the [{d.M}, {d.N}] result")
     if resid is not None and resid_mod == 0 and out_group == 0 and (resid.dim() != 2 or resid.shape[1] < d.N or resid.shape[0] < d.M):
@@ -239,7 +282,9 @@ def _gemm_one(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None
         d.lnfold_sums, d.lnfold_colsum, d.lnfold_dim, d.lnfold_eps = _p(sm), _p(cs), int(dim), float(eps)
     if resid_t is not None:
         d.residT, d.ldrT = _p(resid_t), _rowmajor(resid_t, "resid_t")
-    if out_t is not None:
+    if is_kb(out_t):
+        d.outT, d.ldo, d.outT_kb_rows = _p(out_t), d.N, _kb_dims(out_t, "gemm out_t")[2]
+    elif out_t is not None:
         d.outT, d.ldo = _p(out_t), _rowmajor(out_t, "out_t")
     if out32 is not None:
         d.out32, d.ldo32 = _p(out32), _rowmajor(out32, "out32")

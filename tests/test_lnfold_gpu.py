@@ -133,6 +133,64 @@ def test_gemm_lnfold_argument_checks():
         ops.gemm(a, w, out_t=out, alpha=2.0, lnfold=(torch.zeros(256, 2, device=dev()), torch.zeros(64, device=dev()), 128, 1e-6))
 
 
+def _to_kb(t):
+    """row-major [M, K] -> K-blocked [K/g, M, g] (g = 64 bytes of elements), with torch ops"""
+    g = 64 // t.element_size()
+    M, K = t.shape
+    return t.view(M, K // g, g).permute(1, 0, 2).contiguous()
+
+
+def _from_kb(t):
+    Kb, M, g = t.shape
+    return t.permute(1, 0, 2).reshape(M, Kb * g)
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32], ids=["bf16", "fp32"])
+@pytest.mark.parametrize("M,cfg", [(4100, 0), (4100, 10), (2500, 13), (50432, 0)])
+def test_gemm_kblocked_activations(dt, M, cfg):
+    """A read K-blocked and the T result written K-blocked (what a GEMM -> GEMM activation does between two ring launches), alone and
+    chained, against the row-major launches of the same operands: identical arithmetic, so the results must be bit-identical."""
+    from uia_hip import ops
+    if dt == torch.float32 and M > 5000:
+        pytest.skip("one large case is enough")
+    g = torch.Generator().manual_seed(M + cfg)
+    K, N = 256, 768
+    a = torch.randn(M, K, generator=g).to(dev()).to(dt)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dev()).to(dt)
+    w2 = (torch.randn(128, N, generator=g) * 0.05).to(dev()).to(dt)
+    bias = torch.randn(N, generator=g).to(dev())
+    ref = torch.empty(M, N, device=dev(), dtype=dt)
+    ops.gemm(a, w, bias=bias, act="gelu", out_t=ref, tile_cfg=cfg)
+    # (1) K-blocked A
+    o1 = torch.empty(M, N, device=dev(), dtype=dt)
+    ops.gemm(_to_kb(a), w, bias=bias, act="gelu", out_t=o1, tile_cfg=cfg)
+    assert torch.equal(o1, ref)
+    # (2) K-blocked T output (inside a larger K-blocked tensor: the plane stride is not M)
+    big = ops.kb_empty(M + 300, N, dt, dev())
+    big.zero_()
+    o2 = big[:, 100:100 + M]
+    ops.gemm(a, w, bias=bias, act="gelu", out_t=o2, tile_cfg=cfg)
+    assert torch.equal(_from_kb(o2), ref)
+    assert float(big[:, :100].float().abs().max()) == 0 and float(big[:, 100 + M:].float().abs().max()) == 0      # nothing outside its rows
+    # (3) chained: the K-blocked result is the next launch's A
+    r3, o3 = torch.empty(M, 128, device=dev(), dtype=dt), torch.empty(M, 128, device=dev(), dtype=dt)
+    ops.gemm(ref, w2, out_t=r3, tile_cfg=cfg)
+    ops.gemm(o2, w2, out_t=o3, tile_cfg=cfg)
+    assert torch.equal(o3, r3)
+
+
+def test_gemm_kblocked_needs_a_ring_config():
+    from uia_hip import ops
+    from uia_hip._lib import UiaError
+    a = torch.zeros(256, 128, device=dev(), dtype=torch.bfloat16)
+    w = torch.zeros(128, 128, device=dev(), dtype=torch.bfloat16)
+    out = torch.empty(256, 128, device=dev(), dtype=torch.bfloat16)
+    with pytest.raises(UiaError):
+        ops.gemm(_to_kb(a), w, out_t=out)                                   # M <= 2048: the small-M config cannot read it
+    with pytest.raises(UiaError):
+        ops.gemm(a, w, out_t=ops.kb_empty(256, 128, torch.bfloat16, dev()))
+
+
 TOY = dict(embed_dim=128, vision_cfg=dict(img_size=32, patch_size=8, embed_dim=128, depth=3, num_heads=2),
            text_cfg=dict(vocab_size=120, hidden_size=128, num_hidden_layers=3, num_attention_heads=2, intermediate_size=256,
                          max_position_embeddings=40))
@@ -197,3 +255,48 @@ def test_folded_towers_match_the_layernorm_kernels():
     cos = float(torch.nn.functional.cosine_similarity(g1, g32, dim=0))
     assert cos > 0.99, cos
     assert abs(l1 - l32) < 2e-2 * max(1.0, abs(l32))
+
+
+def test_large_batch_step_on_the_ring_kernels_fold_and_kblocked_vs_plain():
+    """M > 2048 rows in both towers: the step runs on the ring kernels with the LayerNorms folded and the GEMM -> GEMM activations
+    K-blocked (the configuration bench.py times) — against the same bf16 step with both switched off, and the fp32-mode features."""
+    from uia_hip import functional as UF, ops
+    from src.losses import InfoNCELoss
+    model = _toy()
+    g = torch.Generator().manual_seed(4)
+    B = 136                                                             # 136 x 17 tokens = 2312 rows; 136 x 24 positions = 3264 rows
+    images = torch.rand(B, 3, 32, 32, generator=g).to(dev())
+    ids = torch.randint(4, 120, (B, 24), generator=g)
+    ids[:, 0] = 2
+    for b in range(B):
+        ids[b, 5 + b % 19:] = 0
+    ids = ids.to(dev())
+    assert ops.kb_ok(B * 17, 384, 128, torch.bfloat16) and ops.kb_ok(B * 24, 256, 128, torch.bfloat16)
+
+    def run(fold, kb, dt):
+        UF.set_compute_dtype(dt)
+        UF.set_ln_fold(fold)
+        ops.KBLOCK_ACT = kb
+        UF.set_dropout_seed(5)
+        for p in model.parameters():
+            p.grad = None
+        fi, ft = model.encode_image(images), model.encode_text(ids)
+        loss = InfoNCELoss(0.07)(fi, ft)
+        loss.backward()
+        UF.clear_t_copies()
+        gr = torch.cat([p.grad.flatten() for p in model.parameters() if p.requires_grad])
+        return fi.detach().clone(), ft.detach().clone(), float(loss.detach()), gr.clone()
+
+    try:
+        fi32, ft32, l32, g32 = run(False, False, torch.float32)
+        fi0, ft0, l0, g0 = run(False, False, torch.bfloat16)
+        fi1, ft1, l1, g1 = run(True, False, torch.bfloat16)
+        fi2, ft2, l2, g2 = run(True, True, torch.bfloat16)
+    finally:
+        ops.KBLOCK_ACT = True
+    # the layout changes nothing: same kernels, same operands, same order of additions per output element (row sums: atomics, so only close)
+    assert rel(fi2, fi1) < 2e-3 and rel(ft2, ft1) < 2e-3
+    assert rel(fi2, fi32) < 1e-2 and rel(ft2, ft32) < 1e-2, (rel(fi2, fi32), rel(ft2, ft32))
+    assert rel(fi2, fi32) < 2.0 * rel(fi0, fi32) + 2e-3 and rel(ft2, ft32) < 2.0 * rel(ft0, ft32) + 2e-3
+    assert float(torch.nn.functional.cosine_similarity(g2, g32, dim=0)) > 0.99
+    assert abs(l2 - l32) < 2e-2 * max(1.0, abs(l32))
