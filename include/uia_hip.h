@@ -169,8 +169,11 @@ int uia_mona_pre_fwd(void* stream, int dtype, int M, int D, const float* x, cons
                      const float* gamma, const float* gammax, float eps, void* u);
 int uia_mona_pre_bwd(void* stream, int dtype, int M, int D, const void* du, const float* x, const float* dy,
                      const float* norm_w, const float* norm_b, const float* gamma, const float* gammax, float eps,
-                     float* dx32, void* dxT, float* g_gamma, float* g_gammax, float* g_norm_w, float* g_norm_b, float* ws);
-/* ws: caller-owned scratch of uia_mona_pre_bwd_workspace_bytes(M, D) bytes (per-workgroup partial rows of the four parameter
+                     float* dx32, void* dxT, float* g_gamma, float* g_gammax, float* g_norm_w, float* g_norm_b, float* ws,
+                     int64_t dxT_kb_rows);
+/* dxT_kb_rows > 0: the T copy of dx is written K-blocked, [D/g][dxT_kb_rows][g] with g = 64 / sizeof(T) elements (uia_gemm_desc.a_kb_rows):
+ * it is the A operand of the preceding block's fc2 data-gradient GEMM and of nothing else.
+ * ws: caller-owned scratch of uia_mona_pre_bwd_workspace_bytes(M, D) bytes (per-workgroup partial rows of the four parameter
  * gradients, summed by a second small launch: a direct atomic add from every workgroup serialises on the same 4*D addresses) */
 size_t uia_mona_pre_bwd_workspace_bytes(int M, int D);
 int uia_mona_spatial_fwd(void* stream, int dtype, const uia_mona_spatial_desc* d);

@@ -50,9 +50,9 @@ int uia_mona_pre_fwd(void* stream, int dtype, int M, int D, const float* x, cons
 }
 int uia_mona_pre_bwd(void* stream, int dtype, int M, int D, const void* du, const float* x, const float* dy, const float* norm_w,
                      const float* norm_b, const float* gamma, const float* gammax, float eps, float* dx32, void* dxT, float* g_gamma,
-                     float* g_gammax, float* g_norm_w, float* g_norm_b, float* ws) {
+                     float* g_gammax, float* g_norm_w, float* g_norm_b, float* ws, int64_t dxT_kb_rows) {
     return uia_mona_pre_bwd_launch((hipStream_t)stream, dtype, M, D, du, x, dy, norm_w, norm_b, gamma, gammax, eps, dx32, dxT, g_gamma, g_gammax,
-                                   g_norm_w, g_norm_b, ws);
+                                   g_norm_w, g_norm_b, ws, (long)dxT_kb_rows);
 }
 size_t uia_mona_pre_bwd_workspace_bytes(int M, int D) { return uia_mona_pre_bwd_ws_floats(M, D) * sizeof(float); }
 int uia_mona_spatial_fwd(void* stream, int dtype, const uia_mona_spatial_desc* d) {

@@ -82,9 +82,10 @@ template <typename T, int NV>
 __global__ __launch_bounds__(256) void mona_pre_bwd_kernel(int M, int D, const T* __restrict__ du, const float* __restrict__ x,
                                                             const float* __restrict__ dy, const float* __restrict__ nw,
                                                             const float* __restrict__ gamma, const float* __restrict__ gammax, float eps,
-                                                            float* __restrict__ dx32, T* __restrict__ dxT, float* __restrict__ ws) {
+                                                            float* __restrict__ dx32, T* __restrict__ dxT, float* __restrict__ ws, long dxT_kb) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // wave-uniform row → scalar row pointers
+    constexpr int KBG = 64 / (int)sizeof(T);          // K-blocked T copy (dxT_kb = its row count): 64-byte column blocks, rows contiguous inside a block
     const int nv = D >> 2;
     // The parameter vectors live in LDS ([2][D] floats after the reduction area) and are re-read per row through an opaque offset:
     // left to itself the compiler hoists them out of the row loop and the kernel drops to two waves per SIMD.
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(256) void mona_pre_bwd_kernel(int M, int D, const T
                         r[e] = o[k][e] + fmaf(d[k][e], pgx[e], rstd * (gv - mg - v[k][e] * mgx));
                     }
                     if (dx32r) store4(dx32r + 4 * c, r);
-                    if (dxTr) store4(dxTr + 4 * c, r);
+                    if (dxTr) store4(dxT_kb ? dxT + ((size_t)(4 * c / KBG) * (size_t)dxT_kb + row) * KBG + (4 * c) % KBG : dxTr + 4 * c, r);
                 }
             }
         }
@@ -1116,8 +1117,10 @@ size_t uia_mona_pre_bwd_ws_floats(int M, int D) { return (size_t)mona_pre_bwd_bl
 
 int uia_mona_pre_bwd_launch(hipStream_t stream, int dtype, int M, int D, const void* du, const float* x, const float* dy, const float* nw,
                             const float* nb, const float* gamma, const float* gammax, float eps, float* dx32, void* dxT, float* g_gamma,
-                            float* g_gammax, float* g_nw, float* g_nb, float* ws) {
+                            float* g_gammax, float* g_nw, float* g_nb, float* ws, long dxT_kb_rows) {
     UIA_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 1024, "uia_mona_pre_bwd: unsupported shape M=%d D=%d", M, D);
+    UIA_CHECK_ARG(dxT_kb_rows == 0 || (dxT && dxT_kb_rows >= M && (D * (dtype == UIA_BF16 ? 2 : 4)) % 64 == 0),
+                  "uia_mona_pre_bwd: dxT_kb_rows=%ld needs dxT, at least M=%d rows and whole 64-byte column blocks", dxT_kb_rows, M);
     UIA_CHECK_ARG(du && x && nw && nb && gamma && gammax && g_gamma && g_gammax && g_nw && g_nb && ws, "uia_mona_pre_bwd: null tensor");
     UIA_CHECK_ARG(dy || !(dx32 || dxT), "uia_mona_pre_bwd: dx requested without dy");
     int blocks = mona_pre_bwd_blocks(M);
@@ -1130,7 +1133,7 @@ int uia_mona_pre_bwd_launch(hipStream_t stream, int dtype, int M, int D, const v
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds) == hipSuccess && per_cu > 0 &&                               \
             hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&       \
             ncu > 0 && per_cu * ncu < blocks) blocks = per_cu * ncu;                                                                           \
-        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, stream, M, D, (const TT*)du, x, dy, nw, gamma, gammax, eps, dx32, (TT*)dxT, ws); \
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, stream, M, D, (const TT*)du, x, dy, nw, gamma, gammax, eps, dx32, (TT*)dxT, ws, dxT_kb_rows); \
     } while (0)
     if (dtype == UIA_BF16) { if (nvsel == 1) UIA_PRE_BWD(bf16_t, 1); else if (nvsel == 3) UIA_PRE_BWD(bf16_t, 3); else UIA_PRE_BWD(bf16_t, 4); }
     else if (dtype == UIA_F32) { if (nvsel == 1) UIA_PRE_BWD(float, 1); else if (nvsel == 3) UIA_PRE_BWD(float, 3); else UIA_PRE_BWD(float, 4); }

@@ -84,13 +84,16 @@ def publish_t_copy(g32, g_t):
         _T_COPIES[g32.data_ptr()] = (g32, g32._version, g_t)
 
 
-def t_copy_of(g32, dt):
-    """Return a T copy of the fp32 gradient `g32` (the one its producer published, if it is still that tensor's content)."""
+def t_copy_of(g32, dt, allow_kb=False):
+    """Return a T copy of the fp32 gradient `g32` (the one its producer published, if it is still that tensor's content).
+    allow_kb: the caller feeds the copy to a ring GEMM as its A operand and nothing else, so a K-blocked copy (3-D, ops.kb_empty) will do;
+    every other caller gets a row-major [.., D] tensor (a K-blocked publication is ignored and the copy is cast afresh)."""
     if dt == torch.float32:
         return g32
     hit = _T_COPIES.pop(g32.data_ptr(), None)
     if (hit is not None and hit[0].shape == g32.shape and hit[0].stride() == g32.stride() and hit[1] == g32._version
-            and hit[0].untyped_storage().data_ptr() == g32.untyped_storage().data_ptr() and hit[2].dtype == dt):
+            and hit[0].untyped_storage().data_ptr() == g32.untyped_storage().data_ptr() and hit[2].dtype == dt
+            and (allow_kb or not ops.is_kb(hit[2]))):
         return hit[2]
     out = torch.empty(g32.shape, device=g32.device, dtype=dt)
     ops.cast(g32.contiguous(), out)
@@ -282,9 +285,8 @@ def _act(M, K, dt, like, n_consumer):
 def _as_act(buf, M, K, dt, n_consumer):
     """The same, re-using the storage of a dead [M, K] buffer (either layout) of the same dtype."""
     if ops.kb_ok(M, n_consumer, K, dt):
-        g = ops.kb_group(dt)
-        return buf if buf.dim() == 3 else buf.view(K // g, M, g)
-    return buf if buf.dim() == 2 else buf.reshape(-1).view(M, K)
+        return buf if ops.is_kb(buf) else ops.KBlocked.over(buf.view(M, K))
+    return buf.as_rows() if ops.is_kb(buf) else buf
 
 
 # ================================================================================================ Mona
@@ -371,7 +373,9 @@ class MonaFn(torch.autograd.Function):
         ops.wgrad(dtt, u, G["project1.weight"], G["project1.bias"])
         need_dx = ctx.needs_input_grad[0]
         dx = torch.empty_like(x) if need_dx else None
-        dx_t = _empty((M, D), dt, x) if (need_dx and dt != torch.float32) else None
+        # the T copy of dx is the A operand of the preceding block's fc2 data-gradient GEMM (VitBlockFn.backward asks for it with
+        # allow_kb): K-blocked when that launch runs on the ring kernels
+        dx_t = _act(M, D, dt, x, 4 * D) if (need_dx and dt != torch.float32) else None
         ops.mona_pre_bwd(du, x, dy if need_dx else None, P["norm.weight"], P["norm.bias"], P["gamma"], P["gammax"], dx, dx_t,
                          G["gamma"], G["gammax"], G["norm.weight"], G["norm.bias"])
         if need_dx:
@@ -466,7 +470,9 @@ class VitBlockFn(torch.autograd.Function):
         M, dt = B * N, qkv.dtype
         F = pre.shape[1]
         dx2 = dx2.contiguous()
-        dx2_t = t_copy_of(dx2, dt).view(M, D)
+        dx2_t = t_copy_of(dx2, dt, allow_kb=True)
+        if not ops.is_kb(dx2_t):
+            dx2_t = dx2_t.view(M, D)
         # fc2 dgrad fused with act'(pre)
         dpre = _act(M, F, dt, x, D)                       # read by the fc1 dgrad GEMM only
         ops.gemm(dx2_t, WEIGHTS.get(spec.fc2[0], dt, transpose=True), dact=spec.act, aux_in=pre, out_t=dpre)
@@ -536,7 +542,7 @@ def post_ln_layer(res, x_t, L, B, heads, P, keylen, eps=1e-12, cu_seqlens=None, 
     attention-output LayerNorm always (both neighbours are inside the layer), the output LayerNorm when fold_out says that the next
     layer will take (x_t = T copy of the RAW sum, res.dim set) instead of the normalised operand.  A `res` with .dim set is such an input."""
     kb_in = ops.is_kb(x_t)                            # T copy of a raw sum written K-blocked by the previous layer's last GEMM
-    M, D = (x_t.shape[1], x_t.shape[0] * x_t.shape[2]) if kb_in else x_t.shape
+    M, D = (x_t.rows, x_t.cols) if kb_in else x_t.shape
     dt = x_t.dtype
     # Post-LN: the residual entering each sub-layer IS the previous LayerNorm's output, so in bf16 mode its T copy (the GEMM
     # operand) could serve as the residual too (saves the residual's fp32 read as well).  Measured at full depth

@@ -96,18 +96,53 @@ def kb_ok(M, N_consumer, K, dt):
             and auto_tile_cfg(M, K, 128, torch.empty(0, dtype=dt).element_size()) == 8)
 
 
+class KBlocked:
+    """An [M, K] activation stored K-blocked: `.t` is a [K/g, M, g] tensor (g = 64 bytes of elements; a row range `.t[:, lo:hi]` of a
+    larger one is fine).  An explicit type rather than "any 3-D tensor": only ops.gemm (a / out_t) and the few producer kernels that
+    were taught the layout accept it, everything else fails loudly on it."""
+    __slots__ = ("t",)
+
+    def __init__(self, t):
+        self.t = t
+
+    dtype = property(lambda self: self.t.dtype)
+    device = property(lambda self: self.t.device)
+    is_cuda = property(lambda self: self.t.is_cuda)
+    rows = property(lambda self: self.t.shape[1])
+    cols = property(lambda self: self.t.shape[0] * self.t.shape[2])
+
+    def element_size(self):
+        return self.t.element_size()
+
+    def data_ptr(self):
+        return self.t.data_ptr()
+
+    def row_range(self, lo, hi):
+        return KBlocked(self.t[:, lo:hi])
+
+    def as_rows(self):
+        """the same STORAGE as a row-major [M, K] buffer (contents are not converted: for re-use of a dead buffer)"""
+        return self.t.reshape(-1).view(self.rows, self.cols)
+
+    @staticmethod
+    def over(buf):
+        """the storage of a dead row-major [M, K] buffer as a K-blocked one (contents are not converted)"""
+        g = kb_group(buf.dtype)
+        M, K = buf.shape
+        return KBlocked(buf.view(K // g, M, g))
+
+
 def kb_empty(M, K, dt, device):
-    """Storage of an [M, K] activation in the K-blocked layout: a [K/g, M, g] tensor (g = 64 bytes of elements).  ops.gemm recognises
-    3-D `a` / `out_t` arguments as K-blocked; nothing else may read such a tensor."""
     g = kb_group(dt)
-    return torch.empty(K // g, M, g, device=device, dtype=dt)
+    return KBlocked(torch.empty(K // g, M, g, device=device, dtype=dt))
 
 
 def is_kb(t):
-    return t is not None and t.dim() == 3
+    return isinstance(t, KBlocked)
 
 
-def _kb_dims(t, name):
+def _kb_dims(kb, name):
+    t = kb.t
     g = kb_group(t.dtype)
     if t.shape[2] != g or t.stride(2) != 1 or t.stride(1) != g or t.stride(0) % g or t.stride(0) // g < t.shape[1]:
         raise UiaError(f"{name}: not a K-blocked [K/{g}, rows, {g}] activation (shape {tuple(t.shape)}, stride {t.stride()})")
@@ -198,14 +233,14 @@ def gemm(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None, res
     rows and `w` is pre-scaled by the LayerNorm weight; the epilogue applies the LayerNorm (include/uia_hip.h, uia_gemm_desc)."""
     packed = w if isinstance(w, PackedW) else None
     wrow = packed.row if packed is not None else w
-    M, N = (a.shape[1] if is_kb(a) else a.shape[0]), wrow.shape[0]
+    M, N = (a.rows if is_kb(a) else a.shape[0]), wrow.shape[0]
     Ka = wrow.shape[1]
     if not K64_CFG14 and tile_cfg == 0 and auto_tile_cfg(M, N, Ka, a.element_size()) == 14:
         tile_cfg = 8
     if (TAIL_SPLIT and tile_cfg == 0 and out_group == 0 and resid_mod == 0 and a.is_cuda and auto_tile_cfg(M, N, Ka, a.element_size()) == 8):
         m_main = tail_split_rows(M, N, num_cus(a.device.index))
         if m_main < M:
-            cut = lambda t, lo, hi: None if t is None else (t[:, lo:hi] if is_kb(t) else t[lo:hi])     # K-blocked: rows are dim 1
+            cut = lambda t, lo, hi: None if t is None else (t.row_range(lo, hi) if is_kb(t) else t[lo:hi])
             for lo, hi, cfg in ((0, m_main, 8), (m_main, M, 13)):
                 _gemm_one(cut(a, lo, hi), w, bias=bias, act=act, dact=dact, aux_in=cut(aux_in, lo, hi), aux_out=cut(aux_out, lo, hi), resid=cut(resid, lo, hi),
                           resid_t=cut(resid_t, lo, hi), out_t=cut(out_t, lo, hi), out32=cut(out32, lo, hi), alpha=alpha, tile_cfg=cfg,
@@ -231,8 +266,8 @@ def _gemm_one(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None
         d.lda = _rowmajor(a, "a")
         d.M, d.K = a.shape[0], a.shape[1]
     if a.dtype != w.dtype or d.K != w.shape[1]:
-        raise UiaError(f"gemm operand mismatch: a {tuple(a.shape)} {a.dtype}, w {tuple(w.shape)} {w.dtype}")
-    d.A, d.W = _p(a), _p(w)
+        raise UiaError(f"gemm operand mismatch: a {(d.M, d.K)} {a.dtype}, w {tuple(w.shape)} {w.dtype}")
+    d.A, d.W = _p(a.t if is_kb(a) else a), _p(w)
     d.N = w.shape[0]
     base_cfg = (tile_cfg & 255) or auto_tile_cfg(d.M, d.N, d.K, a.element_size())
     if packed is not None and KBLOCK_W and base_cfg in RING_CFGS and a.is_cuda:
@@ -249,7 +284,7 @@ def _gemm_one(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None
     if is_kb(out_t):
         rows, cols, plane = _kb_dims(out_t, "gemm out_t")
         if rows < d.M or cols != d.N or out_group:
-            raise UiaError(f"gemm out_t (K-blocked {tuple(out_t.shape)}) does not hold the [{d.M}, {d.N}] result")
+            raise UiaError(f"gemm out_t (K-blocked {tuple(out_t.t.shape)}) does not hold the [{d.M}, {d.N}] result")
     for name, t in (("aux_in", aux_in), ("aux_out", aux_out), ("resid_t", resid_t), ("out_t", None if is_kb(out_t) else out_t), ("out32", out32)):
         if t is not None and (t.dim() != 2 or t.shape[1] < d.N or (t.shape[0] < d.M and out_group == 0)):
             raise UiaError(f"gemm {name} is {tuple(t.shape)}: too small for the [{d.M}, {d.N}] result")
@@ -283,7 +318,7 @@ def _gemm_one(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None
     if resid_t is not None:
         d.residT, d.ldrT = _p(resid_t), _rowmajor(resid_t, "resid_t")
     if is_kb(out_t):
-        d.outT, d.ldo, d.outT_kb_rows = _p(out_t), d.N, _kb_dims(out_t, "gemm out_t")[2]
+        d.outT, d.ldo, d.outT_kb_rows = _p(out_t.t), d.N, _kb_dims(out_t, "gemm out_t")[2]
     elif out_t is not None:
         d.outT, d.ldo = _p(out_t), _rowmajor(out_t, "out_t")
     if out32 is not None:
@@ -452,8 +487,14 @@ def mona_pre_bwd(du, x, dy, norm_w, norm_b, gamma, gammax, dx32, dx_t, g_gamma, 
     D = gamma.numel()
     M = x.numel() // D
     ws = torch.empty(lib().uia_mona_pre_bwd_workspace_bytes(M, D) // 4, device=x.device, dtype=torch.float32)
+    kb_rows = 0
+    if is_kb(dx_t):                                    # K-blocked T copy of dx (read by a ring GEMM only)
+        rows, cols, kb_rows = _kb_dims(dx_t, "mona_pre_bwd dx_t")
+        if rows != M or cols != D:
+            raise UiaError(f"mona_pre_bwd dx_t (K-blocked {tuple(dx_t.t.shape)}) does not hold [{M}, {D}]")
+        dx_t = dx_t.t
     check(lib().uia_mona_pre_bwd(_stream(), _code(du.dtype), M, D, _p(du), _p(x), _p(dy), _p(norm_w), _p(norm_b), _p(gamma), _p(gammax),
-                                 eps, _p(dx32), _p(dx_t), _p(g_gamma), _p(g_gammax), _p(g_norm_w), _p(g_norm_b), _p(ws)), "uia_mona_pre_bwd")
+                                 eps, _p(dx32), _p(dx_t), _p(g_gamma), _p(g_gammax), _p(g_norm_w), _p(g_norm_b), _p(ws), kb_rows), "uia_mona_pre_bwd")
 
 
 def _spatial_desc(variant, B, h, w, t, params, p_drop, seed, keep_mask):

@@ -75,7 +75,7 @@ expect_fail(lib.uia_attn_bwd(None, 1, C.byref(a)), "null tensor")
 expect_fail(lib.uia_layernorm_fwd(None, 1, 4, 2048, 2048, FAKE, FAKE, FAKE, 1e-5, FAKE, None), "unsupported shape")
 expect_fail(lib.uia_layernorm_bwd(None, 1, 4, 64, 32, FAKE, FAKE, FAKE, 1e-5, None, FAKE, None), "row stride")
 expect_fail(lib.uia_embed(None, 8, 40, 64, 100, 16, FAKE, FAKE, FAKE, None, FAKE), "position table")
-expect_fail(lib.uia_mona_pre_bwd(None, 1, 8, 64, FAKE, FAKE, None, FAKE, FAKE, FAKE, FAKE, 1e-5, None, None, FAKE, FAKE, FAKE, FAKE, None), "null tensor")
+expect_fail(lib.uia_mona_pre_bwd(None, 1, 8, 64, FAKE, FAKE, None, FAKE, FAKE, FAKE, FAKE, 1e-5, None, None, FAKE, FAKE, FAKE, FAKE, None, 0), "null tensor")
 assert lib.uia_mona_pre_bwd_workspace_bytes(50432, 768) == 1024 * 4 * 768 * 4
 s = mod.MonaSpatialDesc()
 expect_fail(lib.uia_mona_spatial_fwd(None, 1, None), "null descriptor")

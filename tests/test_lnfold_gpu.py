@@ -134,15 +134,16 @@ def test_gemm_lnfold_argument_checks():
 
 
 def _to_kb(t):
-    """row-major [M, K] -> K-blocked [K/g, M, g] (g = 64 bytes of elements), with torch ops"""
+    """row-major [M, K] -> ops.KBlocked ([K/g, M, g], g = 64 bytes of elements), converted with torch ops"""
+    from uia_hip import ops
     g = 64 // t.element_size()
     M, K = t.shape
-    return t.view(M, K // g, g).permute(1, 0, 2).contiguous()
+    return ops.KBlocked(t.view(M, K // g, g).permute(1, 0, 2).contiguous())
 
 
-def _from_kb(t):
-    Kb, M, g = t.shape
-    return t.permute(1, 0, 2).reshape(M, Kb * g)
+def _from_kb(kb):
+    Kb, M, g = kb.t.shape
+    return kb.t.permute(1, 0, 2).reshape(M, Kb * g)
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32], ids=["bf16", "fp32"])
@@ -167,16 +168,35 @@ def test_gemm_kblocked_activations(dt, M, cfg):
     assert torch.equal(o1, ref)
     # (2) K-blocked T output (inside a larger K-blocked tensor: the plane stride is not M)
     big = ops.kb_empty(M + 300, N, dt, dev())
-    big.zero_()
-    o2 = big[:, 100:100 + M]
+    big.t.zero_()
+    o2 = big.row_range(100, 100 + M)
     ops.gemm(a, w, bias=bias, act="gelu", out_t=o2, tile_cfg=cfg)
     assert torch.equal(_from_kb(o2), ref)
-    assert float(big[:, :100].float().abs().max()) == 0 and float(big[:, 100 + M:].float().abs().max()) == 0      # nothing outside its rows
+    assert float(big.t[:, :100].float().abs().max()) == 0 and float(big.t[:, 100 + M:].float().abs().max()) == 0    # nothing outside its rows
     # (3) chained: the K-blocked result is the next launch's A
     r3, o3 = torch.empty(M, 128, device=dev(), dtype=dt), torch.empty(M, 128, device=dev(), dtype=dt)
     ops.gemm(ref, w2, out_t=r3, tile_cfg=cfg)
     ops.gemm(o2, w2, out_t=o3, tile_cfg=cfg)
     assert torch.equal(o3, r3)
+
+
+@pytest.mark.parametrize("M,D", [(2500, 768), (197, 128)])
+def test_mona_pre_bwd_kblocked_t_copy(M, D):
+    """the T copy of dx written K-blocked holds exactly the values of the row-major copy of the same launch"""
+    from uia_hip import ops
+    g = torch.Generator().manual_seed(M)
+    mk = lambda *sh: torch.randn(*sh, generator=g).to(dev())
+    du, x, dy = mk(M, D).bfloat16(), mk(M, D), mk(M, D)
+    nw, nb, ga, gx = 1 + 0.2 * mk(D), 0.1 * mk(D), 0.3 * mk(D), 1 + 0.2 * mk(D)
+    outs = []
+    for kb in (False, True):
+        dx32 = torch.empty(M, D, device=dev())
+        dx_t = ops.kb_empty(M, D, torch.bfloat16, dev()) if kb else torch.empty(M, D, device=dev(), dtype=torch.bfloat16)
+        grads = [torch.zeros(D, device=dev()) for _ in range(4)]
+        ops.mona_pre_bwd(du, x, dy, nw, nb, ga, gx, dx32, dx_t, *grads)
+        outs.append((dx32, _from_kb(dx_t) if kb else dx_t, grads))
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][0], outs[1][0])
+    assert rel(outs[1][1], outs[1][0]) < 1e-2
 
 
 def test_gemm_kblocked_needs_a_ring_config():
