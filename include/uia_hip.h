@@ -120,6 +120,13 @@ typedef struct uia_attn_desc {
     void *dq, *dk, *dv; int64_t ld_dqkv;         /* backward only */
     const int32_t* cu_seqlens; /* forward only, optional: [B+1] row offsets of PACKED (un-padded) sequences; sequence b then has
                                   cu[b+1]-cu[b] <= L tokens at rows cu[b].. and every key is valid (L is the maximum length) */
+    /* bf16, dh = 64: K-blocked tensors on the GEMM side of the attention (uia_gemm_desc.a_kb_rows; g = 32 elements).
+     *   out_kb_rows  > 0: `out` is K-blocked with that many rows — written so by the forward (it is the A operand of the output
+     *                     projection), read so by the backward; element (row, h, d) is at out[((2h + d/32)·out_kb_rows + row)·32 + d%32].
+     *   dqkv_kb_rows > 0: backward: dq, dk, dv are written K-blocked the same way (dq / dk / dv each point at the first column block
+     *                     of their part of the fused [rows, 3·H·64] gradient, the A operand of the QKV data-gradient GEMM). */
+    int64_t out_kb_rows;
+    int64_t dqkv_kb_rows;
 } uia_attn_desc;
 int uia_attn_fwd(void* stream, int dtype, const uia_attn_desc* d);
 int uia_attn_bwd(void* stream, int dtype, const uia_attn_desc* d);

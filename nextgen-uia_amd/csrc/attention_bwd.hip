@@ -164,7 +164,10 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void attn_bwd_bf16_kernel(const Uia
         const int c = ((lane & 7) ^ ((r >> 1) & 7)) * 16;
         if (wave < 4) {
             glds16(qb + gr * rs + c, slot + wq * 1024);
-            glds16(ob + gr * rsO + c, slot + 8192 + wq * 1024);
+            // K-blocked O (the forward wrote it for the output projection): 16-byte chunk j of the head's 128-byte row sits in column
+            // block 2h + (j >> 2), at (j & 3)·16 bytes of the row's 64-byte piece
+            glds16(p.out_kb_rows ? (const char*)p.out + (((size_t)(2 * h + (c >> 6)) * (size_t)p.out_kb_rows + row0 + gr) << 6) + (c & 63) : ob + gr * rsO + c,
+                   slot + 8192 + wq * 1024);
         } else {
             glds16(gb + gr * rso + c, slot + 4096 + wq * 1024);
         }
@@ -241,6 +244,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void attn_bwd_bf16_kernel(const Uia
         const int qrow = 32 * ub + 16 * hq + li;
         if (qrow < L) {
             bf16_t* drow = (bf16_t*)p.dq + (row0 + qrow) * p.ld_dqkv + (size_t)h * 64 + 4 * g;
+            if (p.dqkv_kb_rows) drow = (bf16_t*)p.dq + ((size_t)(2 * h + (dt >> 1)) * (size_t)p.dqkv_kb_rows + row0 + qrow) * 32 + 4 * g - 16 * (dt & ~1);
             store4(drow + 16 * dt, dq_hold);
         }
     };
@@ -438,8 +442,13 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void attn_bwd_bf16_kernel(const Uia
         if (kt < LT && key < L) {
             bf16_t* krow = (bf16_t*)p.dk + (row0 + key) * p.ld_dqkv + (size_t)h * 64 + 4 * g;
             bf16_t* vrow = (bf16_t*)p.dv + (row0 + key) * p.ld_dqkv + (size_t)h * 64 + 4 * g;
+            const size_t kbo = ((size_t)(2 * h) * (size_t)p.dqkv_kb_rows + row0 + key) * 32 + 4 * g, kbp = (size_t)p.dqkv_kb_rows * 32;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) { store4(krow + 16 * dt, dKt[a][dt]); store4(vrow + 16 * dt, dVt[a][dt]); }
+            for (int dt = 0; dt < 4; ++dt) {
+                // K-blocked: column block 2h + (dt >> 1), 16·(dt & 1) + 4g inside it
+                store4(p.dqkv_kb_rows ? (bf16_t*)p.dk + kbo + (dt >> 1) * kbp + 16 * (dt & 1) : krow + 16 * dt, dKt[a][dt]);
+                store4(p.dqkv_kb_rows ? (bf16_t*)p.dv + kbo + (dt >> 1) * kbp + 16 * (dt & 1) : vrow + 16 * dt, dVt[a][dt]);
+            }
         }
     }
 #ifdef ABWD_STAMPS
@@ -570,6 +579,9 @@ int uia_attn_bwd_launch(hipStream_t stream, int dtype, const UiaAttnParams& p) {
     UIA_CHECK_ARG(dtype == UIA_BF16 || dtype == UIA_F32, "uia_attn_bwd: bad dtype %d", dtype);
     UIA_CHECK_ARG(p.B > 0 && p.H > 0 && p.L > 0, "uia_attn_bwd: empty problem");
     UIA_CHECK_ARG(!p.cu_seqlens, "uia_attn_bwd: packed sequences (cu_seqlens) are a forward-only layout");
+    UIA_CHECK_ARG((p.out_kb_rows == 0 && p.dqkv_kb_rows == 0) ||
+                  (p.dh == 64 && dtype == UIA_BF16 && (p.out_kb_rows == 0 || p.out_kb_rows >= (int64_t)p.B * p.L) && (p.dqkv_kb_rows == 0 || p.dqkv_kb_rows >= (int64_t)p.B * p.L)),
+                  "uia_attn_bwd: K-blocked out / dq, dk, dv need the bf16 head-dim-64 path and at least B*L rows");
     if (p.dh != 64) return uia_attn_small_launch(stream, dtype, p, true);   // CLIPSeg decoder heads (d_h = 16)
     UIA_CHECK_ARG(p.q && p.k && p.v && p.out && p.dout && p.lse && p.dq && p.dk && p.dv, "uia_attn_bwd: null tensor");
     const int esz = dtype == UIA_BF16 ? 2 : 4;

@@ -204,10 +204,12 @@ __global__ __launch_bounds__(64 * NW, NW >= 7 ? 4 : 1) void attn_fwd_bf16_kernel
         // ---- store: lane owns query qrow, d = 16dt + 4g + r
         if (qrow < L) {
             bf16_t* orow = (bf16_t*)p.out + (row0 + qrow) * p.ldo + (size_t)h * 64 + 4 * g;
+            // K-blocked output (A operand of the output projection): column block 2h + (dt >> 1), 16·(dt & 1) + 4g inside it
+            bf16_t* okb = (bf16_t*)p.out + ((size_t)(2 * h) * (size_t)p.out_kb_rows + row0 + qrow) * 32 + 4 * g;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 const f32x4 v = {o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv};
-                store4(orow + 16 * dt, v);
+                store4(p.out_kb_rows ? okb + (size_t)(dt >> 1) * (size_t)p.out_kb_rows * 32 + 16 * (dt & 1) : orow + 16 * dt, v);
             }
             if (p.lse && g == 0) p.lse[((size_t)b * p.H + h) * L + qrow] = (msc + log2f(sum)) * 0.69314718055994531f;
         }
@@ -288,6 +290,8 @@ int launch_bf16(hipStream_t stream, const UiaAttnParams& p) {
 int uia_attn_fwd_launch(hipStream_t stream, int dtype, const UiaAttnParams& p) {
     UIA_CHECK_ARG(dtype == UIA_BF16 || dtype == UIA_F32, "uia_attn_fwd: bad dtype %d", dtype);
     UIA_CHECK_ARG(p.B > 0 && p.H > 0 && p.L > 0, "uia_attn_fwd: empty problem");
+    UIA_CHECK_ARG((p.out_kb_rows == 0 && p.dqkv_kb_rows == 0) || (p.dh == 64 && dtype == UIA_BF16 && p.dqkv_kb_rows == 0 && p.out_kb_rows >= (int64_t)p.B * p.L),
+                  "uia_attn_fwd: a K-blocked output needs the bf16 head-dim-64 path and out_kb_rows >= B*L");
     if (p.dh != 64) return uia_attn_small_launch(stream, dtype, p, false);   // CLIPSeg decoder heads (d_h = 16)
     UIA_CHECK_ARG(p.L <= 272, "uia_attn_fwd: L=%d exceeds the single-pass limit 272", p.L);
     UIA_CHECK_ARG(p.q && p.k && p.v && p.out, "uia_attn_fwd: null tensor");

@@ -39,7 +39,8 @@ class GemmDesc(C.Structure):
 class AttnDesc(C.Structure):
     _fields_ = [("q", vp), ("k", vp), ("v", vp), ("ld_qkv", i64), ("out", vp), ("ldo", i64), ("lse", vp), ("keylen", vp),
                 ("B", i32), ("H", i32), ("L", i32), ("dh", i32), ("mask_kind", i32), ("scale", f32),
-                ("dout", vp), ("lddo", i64), ("dq", vp), ("dk", vp), ("dv", vp), ("ld_dqkv", i64), ("cu_seqlens", vp)]
+                ("dout", vp), ("lddo", i64), ("dq", vp), ("dk", vp), ("dv", vp), ("ld_dqkv", i64), ("cu_seqlens", vp),
+                ("out_kb_rows", i64), ("dqkv_kb_rows", i64)]
 
 
 class MonaSpatialDesc(C.Structure):

@@ -282,6 +282,12 @@ def _act(M, K, dt, like, n_consumer):
     return torch.empty((M, K), device=like.device, dtype=dt)
 
 
+def _attn_act(M, K, dt, like, n_consumer):
+    """An activation the attention kernels write and a GEMM reads (forward output, fused dq/dk/dv): their K-blocked stores exist on the
+    bf16 path only."""
+    return _act(M, K, dt, like, n_consumer) if dt == torch.bfloat16 else torch.empty((M, K), device=like.device, dtype=dt)
+
+
 def _as_act(buf, M, K, dt, n_consumer):
     """The same, re-using the storage of a dead [M, K] buffer (either layout) of the same dtype."""
     if ops.kb_ok(M, n_consumer, K, dt):
@@ -431,7 +437,7 @@ class VitBlockFn(torch.autograd.Function):
             h1 = _empty((M, D), dt, x)
             ops.layernorm_fwd(x2d, spec.ln1[0], spec.ln1[1], spec.eps, y_t=h1)
             ops.gemm(h1, WEIGHTS.get(spec.qkv[0], dt), bias=spec.qkv[1], out_t=qkv)
-        a = _empty((M, D), dt, x)
+        a = _attn_act(M, D, dt, x, D) if D == 64 * spec.heads else _empty((M, D), dt, x)     # read by the output projection (and the backward kernel)
         lse = torch.empty(B, spec.heads, N, device=x.device, dtype=torch.float32) if train else None
         ops.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], a, B, spec.heads, N, lse=lse, mask=spec.mask)
         x1 = torch.empty_like(x2d)
@@ -458,13 +464,16 @@ class VitBlockFn(torch.autograd.Function):
         else:
             ops.gemm(f, WEIGHTS.get(spec.fc2[0], dt), bias=spec.fc2[1], resid=x1, out32=x2.view(M, D))
         if train:
-            ctx.save_for_backward(x, qkv, a, lse, x1, pre)
+            ctx.a_kb = ops.is_kb(a)                       # save_for_backward takes tensors: the K-blocked wrapper is rebuilt in backward
+            ctx.save_for_backward(x, qkv, a.t if ctx.a_kb else a, lse, x1, pre)
             ctx.spec = spec
         return x2
 
     @staticmethod
     def backward(ctx, dx2):
         x, qkv, a, lse, x1, pre = ctx.saved_tensors
+        if ctx.a_kb:
+            a = ops.KBlocked(a)
         spec = ctx.spec
         B, N, D = x.shape
         M, dt = B * N, qkv.dtype
@@ -484,8 +493,11 @@ class VitBlockFn(torch.autograd.Function):
         ops.layernorm_bwd(dh, x1, spec.ln2[0], spec.eps, dres=dx2.view(M, D), dx32=dx1, dx_t=dx1_t if dt != torch.float32 else None)
         da = dh                                                                     # reuse
         ops.gemm(dx1_t, WEIGHTS.get(spec.proj[0], dt, transpose=True), out_t=da)
-        dqkv = _empty((M, 3 * D), dt, x)
-        ops.attn_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], a, da, lse, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], B, spec.heads, N, mask=spec.mask)
+        dqkv = _attn_act(M, 3 * D, dt, x, D) if D == 64 * spec.heads else _empty((M, 3 * D), dt, x)   # read by the QKV dgrad GEMM only
+        if ops.is_kb(dqkv):
+            ops.attn_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], a, da, lse, dqkv, None, None, B, spec.heads, N, mask=spec.mask)
+        else:
+            ops.attn_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], a, da, lse, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], B, spec.heads, N, mask=spec.mask)
         ops.gemm(dqkv, WEIGHTS.get(spec.qkv[0], dt, transpose=True), out_t=da)       # dh1 into the same buffer
         dx = torch.empty_like(x)
         dx_t = _empty((M, D), dt, x) if dt != torch.float32 else None
@@ -556,7 +568,7 @@ def post_ln_layer(res, x_t, L, B, heads, P, keylen, eps=1e-12, cu_seqlens=None, 
         ops.gemm(x_t, wq, bias=bq, out_t=qkv, lnfold=(res.stats, cq, D, res.eps))
     else:
         ops.gemm(x_t, P["_qkv_w"](dt), bias=P["_qkv_b"], out_t=qkv)
-    a = _empty((M, D), dt, x_t)
+    a = _attn_act(M, D, dt, x_t, D) if (D == 64 * heads and cu_seqlens is None) else _empty((M, D), dt, x_t)
     if cu_seqlens is not None:
         ops.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], a, B, heads, L, cu_seqlens=cu_seqlens)
     else:

@@ -354,7 +354,13 @@ def _attn_desc(q, k, v, out, lse, B, H, L, mask, keylen, scale, dh=64):
             raise UiaError("attention operands must be unit-stride in the last dim and share a dtype")
     d.q, d.k, d.v, d.ld_qkv = _p(q), _p(k), _p(v), q.stride(-2)
     assert k.stride(-2) == q.stride(-2) == v.stride(-2)
-    d.out, d.ldo = _p(out), out.stride(-2)
+    if is_kb(out):                                     # K-blocked [B*L, H*dh] output (bf16, dh = 64): A operand of the output projection
+        rows, cols, d.out_kb_rows = _kb_dims(out, "attention out")
+        if rows < B * L or cols != H * dh or dh != 64 or q.dtype != torch.bfloat16:
+            raise UiaError(f"attention out (K-blocked {tuple(out.t.shape)}) must hold [{B * L}, {H * dh}] bf16 with head dim 64")
+        d.out, d.ldo = _p(out.t), cols
+    else:
+        d.out, d.ldo = _p(out), out.stride(-2)
     d.lse = _p(lse)
     d.keylen = _p(keylen)
     d.B, d.H, d.L, d.dh = B, H, L, dh
@@ -376,8 +382,15 @@ def attn_fwd(q, k, v, out, B, H, L, lse=None, mask=None, keylen=None, scale=None
 def attn_bwd(q, k, v, out, dout, lse, dq, dk, dv, B, H, L, mask=None, keylen=None, scale=None, dh=64):
     d = _attn_desc(q, k, v, out, lse, B, H, L, mask, keylen, scale, dh)
     d.dout, d.lddo = _p(dout), dout.stride(-2)
-    d.dq, d.dk, d.dv, d.ld_dqkv = _p(dq), _p(dk), _p(dv), dq.stride(-2)
-    assert dk.stride(-2) == dq.stride(-2) == dv.stride(-2)
+    if is_kb(dq):                                      # the fused [B*L, 3*H*dh] gradient, K-blocked (dk, dv are then None): A operand of the QKV dgrad
+        rows, cols, d.dqkv_kb_rows = _kb_dims(dq, "attention dqkv")
+        if rows < B * L or cols != 3 * H * dh or dh != 64 or q.dtype != torch.bfloat16 or dk is not None or dv is not None:
+            raise UiaError(f"attention dqkv (K-blocked {tuple(dq.t.shape)}) must hold [{B * L}, {3 * H * dh}] bf16 with head dim 64, dk = dv = None")
+        part = (H * dh // kb_group(q.dtype)) * d.dqkv_kb_rows * kb_group(q.dtype) * dq.t.element_size()      # bytes from one part's first column block to the next
+        d.dq, d.dk, d.dv, d.ld_dqkv = dq.t.data_ptr(), dq.t.data_ptr() + part, dq.t.data_ptr() + 2 * part, cols
+    else:
+        d.dq, d.dk, d.dv, d.ld_dqkv = _p(dq), _p(dk), _p(dv), dq.stride(-2)
+        assert dk.stride(-2) == dq.stride(-2) == dv.stride(-2)
     check(lib().uia_attn_bwd(_stream(), _code(q.dtype), C.byref(d)), "uia_attn_bwd")
 
 

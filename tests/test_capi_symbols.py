@@ -43,7 +43,7 @@ def test_descriptor_struct_sizes_match_c_layout():
     import tempfile
     from uia_hip import _lib
     assert ctypes.sizeof(_lib.GemmDesc) == 264
-    assert ctypes.sizeof(_lib.AttnDesc) == 144
+    assert ctypes.sizeof(_lib.AttnDesc) == 160
     assert ctypes.sizeof(_lib.MonaSpatialDesc) % 8 == 0 and ctypes.sizeof(_lib.MonaSpatialDesc) == 296
     # ... and the same numbers from the C compiler itself (sizes and the offset of the last field of the GEMM descriptor)
     with tempfile.TemporaryDirectory() as td:

@@ -199,6 +199,32 @@ def test_mona_pre_bwd_kblocked_t_copy(M, D):
     assert rel(outs[1][1], outs[1][0]) < 1e-2
 
 
+@pytest.mark.parametrize("L,mask", [(197, None), (256, "keypad"), (50, "causal")])
+def test_attention_kblocked_tensors(L, mask):
+    """forward output written K-blocked, backward reading it K-blocked and writing the fused dq/dk/dv K-blocked: the same values as the
+    row-major launches, bit for bit (only addresses change)"""
+    from uia_hip import ops
+    B, H, D = 3, 4, 256
+    g = torch.Generator().manual_seed(L)
+    qkv = (torch.randn(B * L, 3 * D, generator=g) * 0.5).to(dev()).bfloat16()
+    q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+    keylen = torch.tensor([L, max(1, L // 3), max(1, L - 7)], dtype=torch.int32, device=dev()) if mask == "keypad" else None
+    out = torch.empty(B * L, D, device=dev(), dtype=torch.bfloat16)
+    lse = torch.empty(B, H, L, device=dev())
+    ops.attn_fwd(q, k, v, out, B, H, L, lse=lse, mask=mask, keylen=keylen)
+    big = ops.kb_empty(B * L + 40, D, torch.bfloat16, dev())
+    okb = big.row_range(8, 8 + B * L)
+    lse2 = torch.empty_like(lse)
+    ops.attn_fwd(q, k, v, okb, B, H, L, lse=lse2, mask=mask, keylen=keylen)
+    assert torch.equal(_from_kb(okb), out) and torch.equal(lse, lse2)
+    do = torch.randn(B * L, D, generator=g).to(dev()).bfloat16()
+    dqkv = torch.empty_like(qkv)
+    ops.attn_bwd(q, k, v, out, do, lse, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], B, H, L, mask=mask, keylen=keylen)
+    dkb = ops.kb_empty(B * L, 3 * D, torch.bfloat16, dev())
+    ops.attn_bwd(q, k, v, okb, do, lse, dkb, None, None, B, H, L, mask=mask, keylen=keylen)
+    assert torch.equal(_from_kb(dkb), dqkv)
+
+
 def test_gemm_kblocked_needs_a_ring_config():
     from uia_hip import ops
     from uia_hip._lib import UiaError
