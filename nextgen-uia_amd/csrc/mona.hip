@@ -78,14 +78,19 @@ __global__ __launch_bounds__(256) void mona_pre_fwd_kernel(int M, int D, const f
 // so the row loop carries THREE column sums and needs two parameter vectors (γ·w and γx); the reduce kernel applies w, b, γ.
 // (The first version carried dγ, dγx, dw, db and read w, b, γ, γx per row: 184 VGPRs, two waves per SIMD, 159 us for 619 MB.)
 // NV = float4 per lane (D ≤ 256·NV): the common D = 768 runs with NV = 3.
-template <typename T, int NV>
+template <typename T, int NV, bool KB = false>
 __global__ __launch_bounds__(256) void mona_pre_bwd_kernel(int M, int D, const T* __restrict__ du, const float* __restrict__ x,
                                                             const float* __restrict__ dy, const float* __restrict__ nw,
                                                             const float* __restrict__ gamma, const float* __restrict__ gammax, float eps,
                                                             float* __restrict__ dx32, T* __restrict__ dxT, float* __restrict__ ws, long dxT_kb) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // wave-uniform row → scalar row pointers
-    constexpr int KBG = 64 / (int)sizeof(T);          // K-blocked T copy (dxT_kb = its row count): 64-byte column blocks, rows contiguous inside a block
+    // KB: the T copy of dx is written K-blocked ([D/g][dxT_kb rows][g], g = 64 bytes of elements).  A compile-time variant: the address
+    // arithmetic behind a run-time flag cost the row-major kernel 14 registers and with them its third wave per SIMD (105 -> 126 us).
+    // Lane l's four columns 4(l + 64k) lie in column block l/8 + 8k (bf16: l/4 + 16k for fp32) at (4l) % g: a per-lane element offset
+    // that fits 32 bits, plus a wave-uniform (row, k) part.
+    constexpr int KBG = 64 / (int)sizeof(T), LPB = KBG / 4;   // lanes per column block
+    const int kb_lane = KB ? (lane / LPB) * (int)dxT_kb * KBG + (lane % LPB) * 4 : 0;
     const int nv = D >> 2;
     // The parameter vectors live in LDS ([2][D] floats after the reduction area) and are re-read per row through an opaque offset:
     // left to itself the compiler hoists them out of the row loop and the kernel drops to two waves per SIMD.
@@ -163,7 +168,8 @@ __global__ __launch_bounds__(256) void mona_pre_bwd_kernel(int M, int D, const T
                         r[e] = o[k][e] + fmaf(d[k][e], pgx[e], rstd * (gv - mg - v[k][e] * mgx));
                     }
                     if (dx32r) store4(dx32r + 4 * c, r);
-                    if (dxTr) store4(dxT_kb ? dxT + ((size_t)(4 * c / KBG) * (size_t)dxT_kb + row) * KBG + (4 * c) % KBG : dxTr + 4 * c, r);
+                    if (KB) store4(dxT + ((size_t)(k * (64 / LPB)) * (size_t)dxT_kb + row) * KBG + kb_lane, r);
+                    else if (dxTr) store4(dxTr + 4 * c, r);
                 }
             }
         }
@@ -1119,7 +1125,7 @@ int uia_mona_pre_bwd_launch(hipStream_t stream, int dtype, int M, int D, const v
                             const float* nb, const float* gamma, const float* gammax, float eps, float* dx32, void* dxT, float* g_gamma,
                             float* g_gammax, float* g_nw, float* g_nb, float* ws, long dxT_kb_rows) {
     UIA_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 1024, "uia_mona_pre_bwd: unsupported shape M=%d D=%d", M, D);
-    UIA_CHECK_ARG(dxT_kb_rows == 0 || (dxT && dxT_kb_rows >= M && (D * (dtype == UIA_BF16 ? 2 : 4)) % 64 == 0),
+    UIA_CHECK_ARG(dxT_kb_rows == 0 || (dxT && dxT_kb_rows >= M && (D * (dtype == UIA_BF16 ? 2 : 4)) % 64 == 0 && dxT_kb_rows * (long)D < (1L << 31)),
                   "uia_mona_pre_bwd: dxT_kb_rows=%ld needs dxT, at least M=%d rows and whole 64-byte column blocks", dxT_kb_rows, M);
     UIA_CHECK_ARG(du && x && nw && nb && gamma && gammax && g_gamma && g_gammax && g_nw && g_nb && ws, "uia_mona_pre_bwd: null tensor");
     UIA_CHECK_ARG(dy || !(dx32 || dxT), "uia_mona_pre_bwd: dx requested without dy");
@@ -1128,7 +1134,7 @@ int uia_mona_pre_bwd_launch(hipStream_t stream, int dtype, int M, int D, const v
     const int nvsel = D <= 256 ? 1 : (D <= 768 ? 3 : 4);
     // persistent grid: exactly as many workgroups as are resident at once (a second, partial round would leave most CUs idle at the end)
 #define UIA_PRE_BWD(TT, NVV) do {                                                                                                              \
-        auto kern = mona_pre_bwd_kernel<TT, NVV>;                                                                                              \
+        auto kern = dxT_kb_rows ? mona_pre_bwd_kernel<TT, NVV, true> : mona_pre_bwd_kernel<TT, NVV, false>;                                   \
         int per_cu = 0, dev = 0, ncu = 0;                                                                                                      \
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds) == hipSuccess && per_cu > 0 &&                               \
             hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&       \
