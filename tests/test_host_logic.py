@@ -207,3 +207,33 @@ def test_packed_weight_kblocked_layout():
         assert tuple(kb.shape) == (2, 6, g) and kb.is_contiguous() and pw.kblocked() is kb and pw.shape == w.shape and pw.dtype == dt
         for n, k in ((0, 0), (5, g - 1), (3, g), (2, 2 * g - 1)):
             assert float(kb[k // g, n, k % g]) == float(w[n, k])
+
+
+def test_kblocked_activation_policy_and_views():
+    """ops.kb_ok: an activation travels K-blocked only when BOTH the GEMM that writes it and the GEMM that reads it run on the ring
+    kernels (M > 2048, more than 64 columns on either side, more than one 64-byte column block); ops.KBlocked: the wrapper's views share
+    storage with the row-major buffer they were laid over, and element (m, k) sits at [k // g, m, k % g]."""
+    from uia_hip import ops
+    bf, f32 = torch.bfloat16, torch.float32
+    assert ops.kb_ok(50432, 3072, 768, bf) and ops.kb_ok(65536, 768, 3072, bf) and ops.kb_ok(4096, 128, 128, f32)
+    assert not ops.kb_ok(788, 3072, 768, bf)          # B = 4 full-geometry parity tests: small-M tile config
+    assert not ops.kb_ok(50432, 64, 768, bf)          # the adapters' down-projection reads its rows straight from HBM (tile cfg 16)
+    assert not ops.kb_ok(50432, 768, 64, bf)          # single K step: nothing to stream
+    assert not ops.kb_ok(50432, 0, 768, bf)           # no GEMM consumer (a LayerNorm kernel writes / reads it row-major)
+    saved, ops.KBLOCK_ACT = ops.KBLOCK_ACT, False
+    try:
+        assert not ops.kb_ok(50432, 3072, 768, bf)
+    finally:
+        ops.KBLOCK_ACT = saved
+    M, K = 6, 96
+    buf = torch.arange(M * K, dtype=torch.float32).view(M, K).to(bf)
+    kb = ops.KBlocked.over(buf)
+    assert ops.is_kb(kb) and not ops.is_kb(buf) and not ops.is_kb(buf.view(3, 2, 96))
+    assert (kb.rows, kb.cols, kb.dtype, kb.t.shape) == (M, K, bf, (3, M, 32)) and kb.data_ptr() == buf.data_ptr()
+    assert kb.as_rows().data_ptr() == buf.data_ptr() and kb.as_rows().shape == (M, K)
+    logical = torch.randn(M, K).to(bf)
+    kb.t.copy_(logical.view(M, K // 32, 32).permute(1, 0, 2))
+    for m, k in ((0, 0), (5, 95), (2, 33), (3, 64)):
+        assert kb.t[k // 32, m, k % 32] == logical[m, k]
+    sl = kb.row_range(2, 5)
+    assert sl.rows == 3 and sl.t.stride(0) == M * 32 and sl.t.data_ptr() == buf.data_ptr() + 2 * 32 * 2
