@@ -23,6 +23,15 @@
 #include "uia_common.h"
 #include "uia_kernels.h"
 
+#ifdef AFWD_STAMPS
+// diagnostic build (tools/afwd_stamps.sh): cycles per phase of the bf16 forward for the waves of ONE workgroup:
+// [0] issue of the Q / K / V requests, [1] wait + barrier, [2] S = K·Qᵀ + row max, [3] exp / row sum, [4] Oᵀ = Vᵀ·Pᵀ, [5] stores, [6] kernel
+__device__ unsigned long long uia_afwd_stamps[8 * 8];
+extern "C" int uia_afwd_read_stamps(unsigned long long* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(uia_afwd_stamps), sizeof(uia_afwd_stamps));
+}
+#endif
+
 namespace {
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -57,6 +66,10 @@ __global__ __launch_bounds__(64 * NW, NW >= 7 ? 4 : 1) void attn_fwd_bf16_kernel
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef AFWD_STAMPS
+    const unsigned long long st_begin = __builtin_amdgcn_s_memtime();
+    unsigned long long st_acc[4] = {0, 0, 0, 0};
+#endif
     const int b = bb, h = blockIdx.x - b * p.H;
     const size_t row0 = p.cu_seqlens ? (size_t)p.cu_seqlens[b] : (size_t)b * L;
     const char* qb = (const char*)p.q + (row0 * p.ld_qkv + (size_t)h * 64) * 2;
@@ -95,8 +108,14 @@ __global__ __launch_bounds__(64 * NW, NW >= 7 ? 4 : 1) void attn_fwd_bf16_kernel
         glds16(kb + gr * rs + ck * 16, Ks + q * 1024);
         glds16(vb + gr * rs + cv * 16, Vs + q * 1024);
     }
+#ifdef AFWD_STAMPS
+    const unsigned long long st_issued = __builtin_amdgcn_s_memtime();
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+#ifdef AFWD_STAMPS
+    const unsigned long long st_staged = __builtin_amdgcn_s_memtime();
+#endif
 
     const int li = lane & 15, g = lane >> 4;
     const float sc = p.scale * 1.44269504088896341f;   // softmax in base 2
@@ -114,6 +133,9 @@ __global__ __launch_bounds__(64 * NW, NW >= 7 ? 4 : 1) void attn_fwd_bf16_kernel
         if (qt >= LT) break;
         const int qrow = 16 * qt + li;
         const uint4 q0 = qa[qi], q1 = qb2[qi];
+#ifdef AFWD_STAMPS
+        const unsigned long long st0 = __builtin_amdgcn_s_memtime();
+#endif
 
         const int LTq = (p.mask_kind == UIA_MASK_CAUSAL && qt + 1 < LTk) ? qt + 1 : LTk;   // key tiles this query tile can see
         const int NPq = (LTq + 1) >> 1;
@@ -158,6 +180,10 @@ __global__ __launch_bounds__(64 * NW, NW >= 7 ? 4 : 1) void attn_fwd_bf16_kernel
         }
         m = fmaxf(m, __shfl_xor(m, 16, 64));
         m = fmaxf(m, __shfl_xor(m, 32, 64));
+#ifdef AFWD_STAMPS
+        asm volatile("" :: "v"(m));
+        const unsigned long long st1 = __builtin_amdgcn_s_memtime();
+#endif
         const float msc = m * sc;                                // softmax in base 2: exp2(s·sc − m·sc), one fma per element
         float sum = 0.f;
 #pragma unroll
@@ -176,6 +202,10 @@ __global__ __launch_bounds__(64 * NW, NW >= 7 ? 4 : 1) void attn_fwd_bf16_kernel
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
         const float inv = 1.0f / sum;
+#ifdef AFWD_STAMPS
+        asm volatile("" :: "v"(inv));
+        const unsigned long long st2 = __builtin_amdgcn_s_memtime();
+#endif
 
         // ---- Oᵀ = Vᵀ · Pᵀ
         f32x4 o[4];
@@ -201,6 +231,10 @@ __global__ __launch_bounds__(64 * NW, NW >= 7 ? 4 : 1) void attn_fwd_bf16_kernel
                 }
             }
         }
+#ifdef AFWD_STAMPS
+        asm volatile("" :: "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]));
+        const unsigned long long st3 = __builtin_amdgcn_s_memtime();
+#endif
         // ---- store: lane owns query qrow, d = 16dt + 4g + r
         if (qrow < L) {
             bf16_t* orow = (bf16_t*)p.out + (row0 + qrow) * p.ldo + (size_t)h * 64 + 4 * g;
@@ -213,7 +247,18 @@ __global__ __launch_bounds__(64 * NW, NW >= 7 ? 4 : 1) void attn_fwd_bf16_kernel
             }
             if (p.lse && g == 0) p.lse[((size_t)b * p.H + h) * L + qrow] = (msc + log2f(sum)) * 0.69314718055994531f;
         }
+#ifdef AFWD_STAMPS
+        const unsigned long long st4 = __builtin_amdgcn_s_memtime();
+        st_acc[0] += st1 - st0; st_acc[1] += st2 - st1; st_acc[2] += st3 - st2; st_acc[3] += st4 - st3;
+#endif
     }
+#ifdef AFWD_STAMPS
+    if (blockIdx.x == 1500 && lane == 0 && wave < 8) {
+        unsigned long long* o = uia_afwd_stamps + wave * 8;
+        o[0] = st_issued - st_begin; o[1] = st_staged - st_issued; o[2] = st_acc[0]; o[3] = st_acc[1]; o[4] = st_acc[2]; o[5] = st_acc[3];
+        o[6] = __builtin_amdgcn_s_memtime() - st_begin;
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -266,6 +311,10 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const UiaAttnParams p
             for (int c = 0; c < 64; ++c) o[c] = fmaf(e, Vs[k * 64 + c], o[c]);
         }
         const float inv = 1.0f / sum;
+#ifdef AFWD_STAMPS
+        asm volatile("" :: "v"(inv));
+        const unsigned long long st2 = __builtin_amdgcn_s_memtime();
+#endif
         float* orow = (float*)p.out + (row0 + qi) * p.ldo + (size_t)h * 64;
 #pragma unroll
         for (int c = 0; c < 64; c += 4) *(f32x4*)(orow + c) = f32x4{o[c] * inv, o[c + 1] * inv, o[c + 2] * inv, o[c + 3] * inv};
