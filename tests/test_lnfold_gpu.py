@@ -92,6 +92,32 @@ def test_gemm_layernorm_folded_into_consumer(dt, M, cfg, act, aux):
     assert rel(out, true) < (3e-2 if dt == torch.bfloat16 else 1e-4)
 
 
+@pytest.mark.parametrize("shift", [0.0, 1.0, 4.0, 16.0])
+def test_fold_error_grows_with_row_mean_over_std(shift):
+    """What the fold costs when rows are NOT centred: the operand is bf16(x) instead of bf16(LN(x)), so its rounding error is relative to
+    |x| ≈ |mean| rather than to the spread, and the LayerNorm output inherits it amplified by |mean| / std.  The test pins that law
+    (error ≤ 2^-8·sqrt(1 + (mean/std)²) of the output scale, a few times the plain bf16 path at ratio 0-1) — transformer residual
+    rows sit at |mean| / std well below 1; a model whose rows do not should run with set_ln_fold(False)."""
+    from uia_hip import ops
+    g = torch.Generator().manual_seed(int(shift * 10) + 1)
+    M, D, N, eps = 2304, 256, 768, 1e-6
+    x = (torch.randn(M, D, generator=g) + shift).to(dev())                  # std 1, mean = shift
+    lw = (1 + 0.3 * torch.randn(D, generator=g)).to(dev())
+    lb = (0.2 * torch.randn(D, generator=g)).to(dev())
+    W = (torch.randn(N, D, generator=g) * 0.05).to(dev())
+    b = torch.randn(N, generator=g).to(dev())
+    wf = (W * lw[None, :]).bfloat16().contiguous()
+    sums = torch.stack([x.sum(1), (x * x).sum(1)], 1).contiguous()
+    out = torch.empty(M, N, device=dev(), dtype=torch.bfloat16)
+    ops.gemm(x.bfloat16(), wf, bias=(b + W @ lb).contiguous(), out_t=out, lnfold=(sums, wf.float().sum(1).contiguous(), D, eps))
+    true = _ln(x.double(), lw.double(), lb.double(), eps) @ W.double().T + b.double()
+    plain = (_ln(x, lw, lb, eps).bfloat16().float() @ W.bfloat16().float().T + b).bfloat16()
+    e_fold, e_plain = rel(out, true), rel(plain, true)
+    assert e_fold < 2.0 ** -8 * (1 + shift * shift) ** 0.5 + 4e-3, (shift, e_fold, e_plain)
+    if shift <= 1.0:
+        assert e_fold < 2.5 * e_plain + 2e-3, (shift, e_fold, e_plain)
+
+
 @pytest.mark.parametrize("M,cfg", [(4100, 0), (4100, 10), (300, 0)])
 def test_gemm_deferred_residual_from_row_sums(M, cfg):
     """post-LN sub-layer sum whose residual is LayerNorm(resid) with the statistics given as (Σ, Σ²): against torch, and against the
