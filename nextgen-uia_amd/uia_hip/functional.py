@@ -50,6 +50,27 @@ def ln_fold_enabled(dt):
     return dt != torch.float32 and _STATE.get("ln_fold", True)
 
 
+_FOLD_GUARD = {"left": 8, "limit": 8.0}
+
+
+def _fold_guard(sums, dim):
+    """The fold's one assumption is roughly centred rows (bf16(x) rounds relative to |x|: DESIGN.md §4).  The first few row-sum
+    buffers of a process are checked on the host (one sync each, warm-up steps only): if some row has |mean| > 8 std the fold is switched
+    off for the rest of the run with a warning, and the stand-alone LayerNorm kernels take over from the next forward."""
+    if _FOLD_GUARD["left"] <= 0:
+        return
+    _FOLD_GUARD["left"] -= 1
+    mean = sums[:, 0] / dim
+    var = (sums[:, 1] / dim - mean * mean).clamp_min(0)
+    ratio = float((mean.abs() / (var.sqrt() + 1e-12)).max())
+    if ratio > _FOLD_GUARD["limit"]:
+        import warnings
+        warnings.warn(f"uia_hip: LayerNorm fold switched off: a row with |mean| / std = {ratio:.1f} (> {_FOLD_GUARD['limit']}) would lose "
+                      "bf16 precision as a raw GEMM operand; the LayerNorm kernels are used from the next forward on")
+        set_ln_fold(False)
+        _FOLD_GUARD["left"] = 0
+
+
 def set_unpad_text(flag):
     """Opt-in: the frozen text tower computes only the valid tokens of each caption (packed rows + per-caption attention) instead
     of all `context_length` positions.  Features are identical (padded positions never reach the pooled CLS row); what changes
@@ -336,6 +357,7 @@ class MonaFn(torch.autograd.Function):
             y_t, sums = _act(M, D, dt, x, 3 * D), zero_sums(M, x.device)          # read by the next block's QKV GEMM only
             ops.gemm(d, w2, bias=P["project2.bias"], resid=x.view(M, D), out32=y.view(M, D), out_t=y_t, rowsum=sums)
             publish_rows(y, y_t, sums)
+            _fold_guard(sums, D)
         else:
             ops.gemm(d, w2, bias=P["project2.bias"], resid=x.view(M, D), out32=y.view(M, D))
         ctx.save_for_backward(x, u, t, d, keep_mask if keep_mask is not None else x.new_empty(0), *params)
@@ -450,6 +472,7 @@ class VitBlockFn(torch.autograd.Function):
             ops.gemm(a, WEIGHTS.get(spec.proj[0], dt), bias=spec.proj[1], resid=x2d, out32=x1, out_t=h1, rowsum=sums1)
             w1, c1, b1 = WEIGHTS.get_lnfold(spec.fc1[0], spec.fc1[1], spec.ln2[0], spec.ln2[1], dt)
             ops.gemm(h1, w1, bias=b1, act=spec.act, aux_out=pre, out_t=f, lnfold=(sums1, c1, D, spec.eps))
+            _fold_guard(sums1, D)
         else:
             ops.gemm(a, WEIGHTS.get(spec.proj[0], dt), bias=spec.proj[1], resid=x2d, out32=x1)
             h1 = _as_act(h1, M, D, dt, 0)                                              # row-major: the LayerNorm kernel writes it
@@ -586,6 +609,7 @@ def post_ln_layer(res, x_t, L, B, heads, P, keylen, eps=1e-12, cu_seqlens=None, 
         w1, c1, b1 = WEIGHTS.get_lnfold(P["intermediate.dense.weight"], P["intermediate.dense.bias"], lw_a, lb_a, dt)
         ops.gemm(s_a_t, w1, bias=b1, act="gelu", out_t=f, lnfold=(fold_sums[0], c1, D, eps))
         del s_a_t
+        _fold_guard(fold_sums[0], D)
     else:
         ops.gemm(a, WEIGHTS.get(P["attention.output.dense.weight"], dt), bias=P["attention.output.dense.bias"], out32=s_a,
                  **(dict(resid_t=x_t) if t_resid else res.gemm_kw()))

@@ -372,3 +372,28 @@ def test_large_batch_step_on_the_ring_kernels_fold_and_kblocked_vs_plain():
     assert rel(fi2, fi32) < 2.0 * rel(fi0, fi32) + 2e-3 and rel(ft2, ft32) < 2.0 * rel(ft0, ft32) + 2e-3
     assert float(torch.nn.functional.cosine_similarity(g2, g32, dim=0)) > 0.99
     assert abs(l2 - l32) < 2e-2 * max(1.0, abs(l32))
+
+
+def test_fold_guard_switches_the_fold_off_for_uncentred_rows():
+    """host-side guard of the warm-up steps: a row-sum buffer holding a row with |mean| > 8 std turns the fold off (with a warning)"""
+    from uia_hip import functional as UF
+    D = 128
+    x = torch.randn(64, D, device=dev())
+    ok = torch.stack([x.sum(1), (x * x).sum(1)], 1)
+    x[7] += 40.0
+    bad = torch.stack([x.sum(1), (x * x).sum(1)], 1)
+    saved = dict(UF._FOLD_GUARD)
+    try:
+        UF._FOLD_GUARD["left"] = 2
+        UF.set_ln_fold(True)
+        UF._fold_guard(ok, D)
+        assert UF.ln_fold_enabled(torch.bfloat16)
+        with pytest.warns(UserWarning, match="LayerNorm fold switched off"):
+            UF._fold_guard(bad, D)
+        assert not UF.ln_fold_enabled(torch.bfloat16) and UF._FOLD_GUARD["left"] == 0
+        UF.set_ln_fold(True)
+        UF._fold_guard(bad, D)                     # budget spent: no more host syncs, no more checks
+        assert UF.ln_fold_enabled(torch.bfloat16)
+    finally:
+        UF._FOLD_GUARD.update(saved)
+        UF.set_ln_fold(True)
