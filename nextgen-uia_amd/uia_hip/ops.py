@@ -53,6 +53,7 @@ def auto_tile_cfg(M, N, K=None, esz=2, mask=EPI_GENERIC):
 RING_CFGS = (8, 9, 10, 13, 14)
 KBLOCK_W = True          # hand the ring kernels their weights K-blocked (PackedW.kblocked()); False = row-major everywhere
 K64_CFG14 = True         # single-K-step GEMMs on the two-workgroups-per-CU half-height config (False: 256x256 like every other large shape)
+TILE_GROUP = {}          # experiment knob: {N: row panels per tile-order group} overriding the launcher's choice for ring launches with that N
 TAIL_SPLIT = True        # split off the M tail of a launch whose last round of 256x256 tiles would leave most CUs idle
 _NCU = {}
 
@@ -323,6 +324,8 @@ def _gemm_one(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None
         d.outT, d.ldo = _p(out_t), _rowmajor(out_t, "out_t")
     if out32 is not None:
         d.out32, d.ldo32 = _p(out32), _rowmajor(out32, "out32")
+    if TILE_GROUP and d.N in TILE_GROUP and (tile_cfg >> 8) == 0 and base_cfg in RING_CFGS:
+        tile_cfg |= int(TILE_GROUP[d.N]) << 8
     if GEMM_PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
