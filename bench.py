@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--no-kblock-w", action="store_true", help="A/B knob: keep the GEMM weights row-major (default: K-blocked for the ring kernels)")
     ap.add_argument("--no-kblock-act", action="store_true", help="A/B knob: GEMM -> GEMM activations stay row-major (default: the producing epilogue writes them "
                     "K-blocked for the ring kernel that reads them)")
+    ap.add_argument("--persist-store-only", action="store_true", help="experiment knob: store-only 256x256 GEMM launches on the persistent ring variant (tile cfg 12)")
     ap.add_argument("--tile-group", default="", help="experiment knob: N=group[,N=group] overrides the ring kernels' tile-order group (row panels per group; "
                     "255 = row-panel-major) for launches with that many columns, e.g. 3072=8,2304=4")
     ap.add_argument("--no-k64-cfg14", action="store_true", help="A/B knob: single-K-step GEMMs on the 256x256 tiles")
@@ -149,6 +150,7 @@ def main():
     UF.set_ln_fold(not args.no_ln_fold)
     ops.KBLOCK_W, ops.TAIL_SPLIT, ops.K64_CFG14 = not args.no_kblock_w, not args.no_tail_split, not args.no_k64_cfg14
     ops.KBLOCK_ACT = not args.no_kblock_act
+    ops.PERSIST_STORE_ONLY = args.persist_store_only
     ops.TILE_GROUP = {int(k): int(v) for k, v in (kv.split("=") for kv in args.tile_group.split(",") if kv)}
 
     model = create_biomedclip(seed=0)                                # same weights on every rank (random init: no network for checkpoints)

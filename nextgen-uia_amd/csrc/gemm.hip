@@ -1112,6 +1112,7 @@ __global__ __launch_bounds__(512) void gemm_tn_persist_kernel(const UiaGemmParam
 
     auto swzA = [](int r) -> int { return (0x1230 >> (4 * ((r >> 2) & 3))) & 3; };
     auto swzW = [](int rl) -> int { return (0x1230 >> (4 * ((rl >> 4) & 3))) & 3; };
+    const bool kbA = p.a_kb_rows != 0, kbW = p.w_kblocked != 0;
     const char* srcA[A_PER_WAVE];
     const char* srcW[W_PER_WAVE];
     int m0 = 0, n0 = 0;
@@ -1125,7 +1126,7 @@ __global__ __launch_bounds__(512) void gemm_tn_persist_kernel(const UiaGemmParam
             const int c = (lane % CPR) ^ swzA(r);
             int gm = m0 + r;
             gm = gm < p.M ? gm : p.M - 1;
-            srcA[i] = (const char*)p.A + ((size_t)gm * (size_t)p.lda) * ESZ + c * 16;
+            srcA[i] = kbA ? (const char*)p.A + (size_t)gm * BKB + c * 16 : (const char*)p.A + ((size_t)gm * (size_t)p.lda) * ESZ + c * 16;
         }
 #pragma unroll
         for (int i = 0; i < W_PER_WAVE; ++i) {
@@ -1133,9 +1134,11 @@ __global__ __launch_bounds__(512) void gemm_tn_persist_kernel(const UiaGemmParam
             const int c = (lane % CPR) ^ swzW(r & (WTN - 1));
             int gn = n0 + r;
             gn = gn < p.N ? gn : p.N - 1;
-            srcW[i] = (const char*)p.W + ((size_t)gn * (size_t)p.ldw) * ESZ + c * 16;
+            srcW[i] = kbW ? (const char*)p.W + (size_t)gn * BKB + c * 16 : (const char*)p.W + ((size_t)gn * (size_t)p.ldw) * ESZ + c * 16;
         }
     };
+    // K-blocked operands ([K·ESZ/64][rows][64 B]: uia_gemm_desc.w_kblocked / a_kb_rows): one K step = one plane further
+    const size_t kstepA = kbA ? (size_t)p.a_kb_rows * BKB : (size_t)BKB, kstepW = kbW ? (size_t)p.N * BKB : (size_t)BKB;
     const int li = lane & 15, g = lane >> 4;
     const int rowA = wm * WTM + li;
     const int rowW = wn * WTN + (li >> 2) * 16 + (li & 3);
@@ -1145,11 +1148,10 @@ __global__ __launch_bounds__(512) void gemm_tn_persist_kernel(const UiaGemmParam
 
     auto stage = [&](int t) {
         char* base = smem + (t % NBUF) * BUF_BYTES;
-        const size_t koff = (size_t)t * BKB;
 #pragma unroll
-        for (int i = 0; i < A_PER_WAVE; ++i) glds16_asm(srcA[i] + koff, base + (wave + NW * i) * 1024);
+        for (int i = 0; i < A_PER_WAVE; ++i) glds16_asm(srcA[i] + (size_t)t * kstepA, base + (wave + NW * i) * 1024);
 #pragma unroll
-        for (int i = 0; i < W_PER_WAVE; ++i) glds16_asm(srcW[i] + koff, base + A_BYTES + (wave + NW * i) * 1024);
+        for (int i = 0; i < W_PER_WAVE; ++i) glds16_asm(srcW[i] + (size_t)t * kstepW, base + A_BYTES + (wave + NW * i) * 1024);
     };
     uint4 af[MT], wf[NT];
     auto load_frags = [&](const char* buf) {
@@ -1211,7 +1213,9 @@ __global__ __launch_bounds__(512) void gemm_tn_persist_kernel(const UiaGemmParam
             point_at(next);
             for (int t = 0; t < PD && t < ntl; ++t) stage(t);
         }
-        gemm_epilogue_lds<T, MT, NT, WTM, WTN, EPI, true>(p, acc, smem + (NBUF - 1) * BUF_BYTES, wave, lane, cm0, cn0, wm, wn);
+        constexpr bool LNROW = EPI == EPI_GENERIC || (EPI & EPI_LNFOLD) != 0;      // the per-wave (rstd, -mean·rstd) strips sit behind the ring
+        gemm_epilogue_lds<T, MT, NT, WTM, WTN, EPI, true>(p, acc, smem + (NBUF - 1) * BUF_BYTES, wave, lane, cm0, cn0, wm, wn,
+                                                          LNROW ? (float*)(smem + NBUF * BUF_BYTES + wave * (WTM * 8)) : nullptr);
         if (!more) break;
         tile = next;
     }
@@ -1231,7 +1235,7 @@ inline int uia_num_cus() {
 
 template <typename T, int EPI>
 int launch_persist_epi(hipStream_t stream, const UiaGemmParams& p) {
-    constexpr int LDS = 4 * 512 * 64;
+    constexpr int LDS = 4 * 512 * 64 + ((EPI == EPI_GENERIC || (EPI & EPI_LNFOLD) != 0) ? 4 * 256 * 8 : 0);
     auto kern = gemm_tn_persist_kernel<T, EPI>;
     static UiaDevOnce attr_once;
     UIA_ENSURE_LDS_ATTR(attr_once, kern, LDS);
@@ -1288,6 +1292,9 @@ int launch_persist(hipStream_t stream, const UiaGemmParams& p) {
         UIA_EPI_CASE(EPI_BIAS | EPI_GELU | EPI_OUTT);
         UIA_EPI_CASE(EPI_DGELU | EPI_OUTT);
         UIA_EPI_CASE(EPI_BIAS | EPI_GELU | EPI_AUX_OUT | EPI_OUTT);
+        UIA_EPI_CASE(EPI_BIAS | EPI_OUTT | EPI_LNFOLD);
+        UIA_EPI_CASE(EPI_BIAS | EPI_GELU | EPI_OUTT | EPI_LNFOLD);
+        UIA_EPI_CASE(EPI_BIAS | EPI_GELU | EPI_AUX_OUT | EPI_OUTT | EPI_LNFOLD);
 #undef UIA_EPI_CASE
         default: break;
     }
@@ -1392,8 +1399,8 @@ int launch_typed(hipStream_t stream, const UiaGemmParams& p, int cfg_in) {
                                  // (cfg 12, the persistent variant, is +2-3.5 % on store-only epilogues in isolation, -15-25 % on the
                                  //  fp32-residual ones, and a net loss inside the two-stream training step: opt-in only.)
     }
-    const bool ring = cfg == 8 || cfg == 9 || cfg == 10 || cfg == 13 || cfg == 14 || cfg == 15;
-    if ((p.a_kb_rows || p.outT_kb_rows) && !(cfg == 8 || cfg == 10 || cfg == 13 || cfg == 14 || cfg == 15)) {
+    const bool ring = cfg == 8 || cfg == 9 || cfg == 10 || cfg == 12 || cfg == 13 || cfg == 14 || cfg == 15;
+    if ((p.a_kb_rows || p.outT_kb_rows) && !(cfg == 8 || cfg == 10 || cfg == 12 || cfg == 13 || cfg == 14 || cfg == 15)) {
         uia_set_error("uia_gemm: K-blocked activations (a_kb_rows / outT_kb_rows) need a ring tile config with 64-byte sub-tiles (8, 10, 13, 14), not %d", cfg);
         return -1;
     }

@@ -50,7 +50,8 @@ def auto_tile_cfg(M, N, K=None, esz=2, mask=EPI_GENERIC):
     return 8
 
 
-RING_CFGS = (8, 9, 10, 13, 14)
+RING_CFGS = (8, 9, 10, 12, 13, 14)
+PERSIST_STORE_ONLY = False   # experiment knob: 256x256 ring launches whose epilogue only stores T results run on the persistent variant (cfg 12)
 KBLOCK_W = True          # hand the ring kernels their weights K-blocked (PackedW.kblocked()); False = row-major everywhere
 K64_CFG14 = True         # single-K-step GEMMs on the two-workgroups-per-CU half-height config (False: 256x256 like every other large shape)
 TILE_GROUP = {}          # experiment knob: {N: row panels per tile-order group} overriding the launcher's choice for ring launches with that N
@@ -271,6 +272,9 @@ def _gemm_one(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None
     d.A, d.W = _p(a.t if is_kb(a) else a), _p(w)
     d.N = w.shape[0]
     base_cfg = (tile_cfg & 255) or auto_tile_cfg(d.M, d.N, d.K, a.element_size())
+    if (PERSIST_STORE_ONLY and base_cfg == 8 and resid is None and resid_t is None and out32 is None and rowsum is None and out_group == 0
+            and alpha == 1.0 and d.K * a.element_size() >= 1024):
+        base_cfg, tile_cfg = 12, (tile_cfg & ~255) | 12
     if packed is not None and KBLOCK_W and base_cfg in RING_CFGS and a.is_cuda:
         d.W, d.w_kblocked = _p(packed.kblocked()), 1
     d.alpha = alpha

@@ -58,7 +58,7 @@ def test_gemm_rowsum_of_stored_rows(dt, M, cfg):
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32], ids=["bf16", "fp32"])
 @pytest.mark.parametrize("M,cfg,act,aux", [(4100, 0, None, False), (4100, 0, "gelu", False), (4100, 0, "gelu", True), (4100, 10, "gelu", True),
-                                           (2500, 13, None, False), (300, 0, "gelu", True)])
+                                           (4100, 12, "gelu", True), (70000, 12, None, False), (2500, 13, None, False), (300, 0, "gelu", True)])
 def test_gemm_layernorm_folded_into_consumer(dt, M, cfg, act, aux):
     """consumer: A = raw rows, W' = W·ln_w, epilogue rstd·(acc − mean·colsum) + (b + W·ln_b): against LayerNorm → Linear in torch"""
     from uia_hip import ops
@@ -173,7 +173,7 @@ def _from_kb(kb):
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32], ids=["bf16", "fp32"])
-@pytest.mark.parametrize("M,cfg", [(4100, 0), (4100, 10), (2500, 13), (50432, 0)])
+@pytest.mark.parametrize("M,cfg", [(4100, 0), (4100, 10), (4100, 12), (2500, 13), (50432, 0)])
 def test_gemm_kblocked_activations(dt, M, cfg):
     """A read K-blocked and the T result written K-blocked (what a GEMM -> GEMM activation does between two ring launches), alone and
     chained, against the row-major launches of the same operands: identical arithmetic, so the results must be bit-identical."""
