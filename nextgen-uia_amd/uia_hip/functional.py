@@ -46,8 +46,12 @@ def set_ln_fold(flag):
     _STATE["ln_fold"] = bool(flag)
 
 
-def ln_fold_enabled(dt):
-    return dt != torch.float32 and _STATE.get("ln_fold", True)
+def ln_fold_enabled(dt, rows=None):
+    """rows: the fold is a large-batch optimisation and is only applied where its GEMMs run on the ring kernels (more than 2048 rows).
+    Below that nothing is gained, and the row sums' float atomics would make the small parity cases non-reproducible from run to run
+    (bf16 results are chaotic at the level of their rounding: a 1e-7 change of a LayerNorm statistic re-rolls the last bits of everything
+    downstream — the CLIPSeg full-geometry case moved between 7.9e-3 and 1.07e-2 of its 1e-2 bound)."""
+    return dt != torch.float32 and _STATE.get("ln_fold", True) and (rows is None or rows > _STATE.get("ln_fold_min_rows", 2048))
 
 
 _FOLD_GUARD = {"left": 8, "limit": 8.0}
@@ -353,7 +357,7 @@ class MonaFn(torch.autograd.Function):
         ops.mona_spatial_fwd(variant, B, h, w, t, sp, d, p_drop=p_drop, seed=seed, keep_mask=keep_mask)
         w2 = WEIGHTS.get(P["project2.weight"], dt)
         y = torch.empty_like(x)
-        if ln_fold_enabled(dt):                # the next block's first LayerNorm is folded into its QKV GEMM: leave it the T rows and their sums
+        if ln_fold_enabled(dt, M):             # the next block's first LayerNorm is folded into its QKV GEMM: leave it the T rows and their sums
             y_t, sums = _act(M, D, dt, x, 3 * D), zero_sums(M, x.device)          # read by the next block's QKV GEMM only
             ops.gemm(d, w2, bias=P["project2.bias"], resid=x.view(M, D), out32=y.view(M, D), out_t=y_t, rowsum=sums)
             publish_rows(y, y_t, sums)
@@ -447,7 +451,7 @@ class VitBlockFn(torch.autograd.Function):
         x = x.contiguous()
         x2d = x.view(M, D)
         train = ctx.needs_input_grad[0]
-        fold = ln_fold_enabled(dt)
+        fold = ln_fold_enabled(dt, M)
         rows = take_rows(x, dt) if fold else None        # (T copy of x, row sums) left by the GEMM that produced x
         qkv = _empty((M, 3 * D), dt, x)
         if rows is not None:                              # LN1 folded into the QKV GEMM
@@ -584,7 +588,7 @@ def post_ln_layer(res, x_t, L, B, heads, P, keylen, eps=1e-12, cu_seqlens=None, 
     # (tools/text_residual_error.py, 12 layers, bf16 vs fp32 mode): the text features' error goes from 6.4e-3 to 1.05e-2, past the
     # 1e-2 bound — so it is OFF unless _STATE["text_resid_t"] is set; the default keeps the fp32 residual exactly (LnResidual).
     t_resid = dt != torch.float32 and _STATE.get("text_resid_t", False)
-    fold = fold_sums is not None and ln_fold_enabled(dt) and not t_resid
+    fold = fold_sums is not None and ln_fold_enabled(dt, M) and not t_resid
     qkv = _empty((M, 3 * D), dt, x_t)
     if res.dim is not None:                           # x_t holds the raw rows of the previous layer's output sum: its LayerNorm folds in here
         wq, cq, bq = WEIGHTS.get_lnfold(P["_qkv_raw"][0], P["_qkv_raw"][1], res.w, res.b, dt)
