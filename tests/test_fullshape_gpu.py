@@ -85,6 +85,18 @@ def _captions(g, B, L=256):
 @pytest.mark.parametrize("variant", ["freq_enhanced", "hybrid"])
 def test_fullshape_biomedclip_mona_train_step_vs_oracle(mode, variant):
     """reference call path: biomedclip/finetune.py:272-302 (encode_image, encode_text, InfoNCE, backward) at full model size."""
+    _biomedclip_fullshape(mode, variant, 4, f"biomedclip_vitb16_mona_{variant}_{mode}")
+
+
+@pytest.mark.timeout(1500)
+def test_fullshape_biomedclip_ring_batch_bf16_vs_oracle():
+    """The same at B = 12: 2364 image-token rows and 3072 text positions, i.e. past the 2048-row line above which the bf16 step runs the
+    configuration bench.py times — ring-kernel GEMMs, LayerNorms folded into them (row sums by float atomics), K-blocked activations,
+    the N = 64 stream GEMM — still against the CPU oracle."""
+    _biomedclip_fullshape("bf16", "freq_enhanced", 12, "biomedclip_vitb16_mona_freq_enhanced_bf16_B12")
+
+
+def _biomedclip_fullshape(mode, variant, B, key):
     from uia_hip import functional as UF
     from src.adapters import inject_mona_variant_to_open_clip
     from src.losses import InfoNCELoss
@@ -99,7 +111,6 @@ def test_fullshape_biomedclip_mona_train_step_vs_oracle(mode, variant):
     for k, p in model.named_parameters():
         p.requires_grad_("mona" in k)
     model.eval()
-    B = 4
     images, ids = torch.rand(B, 3, 224, 224, generator=g), _captions(g, B)
     P = {k: v.detach().clone() for k, v in model.state_dict().items()}
     trainable = [k for k in P if "mona" in k]
@@ -123,7 +134,7 @@ def test_fullshape_biomedclip_mona_train_step_vs_oracle(mode, variant):
     want = torch.cat([gref[k].flatten() for k in trainable])
     cos = float(torch.dot(got, want) / (got.norm() * want.norm()))
     l2 = float((got - want).norm() / want.norm())
-    report(f"biomedclip_vitb16_mona_{variant}_{mode}",
+    report(key,
            {"B": B, "image_features_rel": e_img, "text_features_rel": e_txt, "loss": float(loss), "loss_ref": lref,
             "grad_worst_per_tensor_rel": per_tensor[worst_k], "grad_worst_tensor": worst_k, "grad_cosine": cos, "grad_rel_l2": l2,
             "grad_median_per_tensor_rel": sorted(per_tensor.values())[len(per_tensor) // 2]})
