@@ -64,7 +64,7 @@ typedef struct uia_gemm_desc {
     int32_t w_kblocked;                 /* 1: W is stored K-blocked, [K/g][N][g] with g = 64 bytes / sizeof(T) elements (ldw ignored): the layout
                                            the ring tile configs (8, 10; the automatic choice for M > 2048, N > 64) stream fastest; other tile
                                            configs reject it */
-    const float* resid_ln_stats;        /* non-null: `resid` holds the INPUT of a LayerNorm and the residual added is that LayerNorm's output,
+    const void* resid_ln_stats;         /* non-null: `resid` holds the INPUT of a LayerNorm and the residual added is that LayerNorm's output,
                                            fmaf((resid[m][n] - mean_m)·rstd_m, resid_ln_w[n], resid_ln_b[n]) with (mean_m, rstd_m) =
                                            resid_ln_stats[2m], [2m+1] as written by uia_layernorm_fwd_stats: a post-LN (BERT) sub-layer sum
                                            then reads the previous sum once instead of the LayerNorm writing its fp32 output for it
@@ -78,13 +78,15 @@ typedef struct uia_gemm_desc {
      *     LN(x)·Wᵀ + b  =  rstd_m·(x·W'ᵀ − mean_m·colsum[n]) + (b + W·ln_b)[n]
      * in its epilogue (the caller passes colsum[n] = Σ_k W'[n][k] and the combined bias as `bias`), so the stand-alone LayerNorm pass
      * over the rows (read 4 B, write 2 B per element) disappears. */
-    float* rowsum_out;                  /* non-null: rowsum_out[2m] += Σ_n v[m][n], rowsum_out[2m+1] += Σ_n v[m][n]² over the N columns of the fp32
-                                           result v this launch stores (fp32 atomics: caller zeroes; summation order is not fixed) */
-    const float* lnfold_sums;           /* non-null: A holds raw rows; (Σ, Σ²) of row m over lnfold_dim columns at lnfold_sums[2m], [2m+1] */
+    int64_t* rowsum_out;                /* non-null: rowsum_out[2m] += Σ_n v[m][n], rowsum_out[2m+1] += Σ_n v[m][n]² over the N columns of the fp32
+                                           result v this launch stores, as 64-bit FIXED-POINT numbers in units of 2^-30 (integer atomics: the
+                                           sums do not depend on the order in which a row's column tiles arrive; caller zeroes; 16-byte aligned) */
+    const int64_t* lnfold_sums;         /* non-null: A holds raw rows; (Σ, Σ²) of row m over lnfold_dim columns at lnfold_sums[2m], [2m+1],
+                                           in the fixed-point form rowsum_out leaves them */
     const float* lnfold_colsum;         /* [N] fp32 column sums of the pre-scaled weight */
     int32_t lnfold_dim; float lnfold_eps;
-    int32_t resid_ln_dim; float resid_ln_eps;   /* resid_ln_dim > 0: resid_ln_stats holds (Σ, Σ²) over resid_ln_dim columns as rowsum_out leaves
-                                                   them, not (mean, rstd); mean = Σ/dim, rstd = rsqrt(max(Σ²/dim − mean², 0) + resid_ln_eps) */
+    int32_t resid_ln_dim; float resid_ln_eps;   /* resid_ln_dim > 0: resid_ln_stats points at (Σ, Σ²) over resid_ln_dim columns as rowsum_out leaves
+                                                   them (int64 fixed point), not at float (mean, rstd); mean = Σ/dim, rstd = rsqrt(max(Σ²/dim − mean², 0) + resid_ln_eps) */
     /* K-BLOCKED ACTIVATIONS (ring tile configs with 64-byte sub-tiles: 8, 10, 13, 14; the other configs reject them).  The operand of a
      * large GEMM streams fastest as [K·sizeof(T)/64][rows][64 bytes] (each 1 KiB LDS-DMA piece = 8 whole 128-byte lines; +1.5…3.4 % per
      * launch on the step's shapes, profiles/r02_a_gemm_order_layout.txt).  A GEMM whose T result is the next GEMM's A operand can write it

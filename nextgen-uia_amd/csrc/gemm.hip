@@ -138,6 +138,20 @@ __device__ __forceinline__ void glds16_asm(const char* gsrc, char* lds_wave_base
                  : "memory");
 }
 
+// Row sums travel as 64-bit FIXED-POINT numbers (units of 2^-30): integer atomics add exactly, so (Σ, Σ²) do not depend on the order in
+// which the column tiles of a row arrive — with float atomics they did, a 1e-7 wobble of a LayerNorm statistic re-rolled the bf16 roundings
+// of everything downstream, and the step was not reproducible from run to run.  Range: Σ² up to 8.6e9 (row RMS 3300 at 768 columns).
+typedef long long2 __attribute__((ext_vector_type(2)));
+constexpr float ROWSUM_SCALE = 1073741824.0f, ROWSUM_INV = 1.0f / 1073741824.0f;
+__device__ __forceinline__ void rowsum_add(void* dst, size_t row, float s1, float s2) {
+    unsigned long long* q = (unsigned long long*)dst + 2 * row;
+    atomicAdd(q, (unsigned long long)llrintf(s1 * ROWSUM_SCALE));        // two's complement: negative sums wrap correctly
+    atomicAdd(q + 1, (unsigned long long)llrintf(s2 * ROWSUM_SCALE));
+}
+__device__ __forceinline__ float2 rowsum_load(const void* src, size_t row) {
+    const long2 v = *(const long2*)((const long long*)src + 2 * row);
+    return float2{(float)v[0] * ROWSUM_INV, (float)v[1] * ROWSUM_INV};
+}
 // (mean, rstd, -mean·rstd) of a row from its (Σ, Σ²) over `dim` columns, as the rowsum_out feature of a producing GEMM leaves them
 struct LnRow { float mean, rstd, nmr; };
 __device__ __forceinline__ LnRow ln_row_from_sums(float2 ss, int dim, float eps) {
@@ -184,7 +198,7 @@ __device__ __forceinline__ void gemm_epilogue(const UiaGemmParams& p, f32x4 (&ac
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] = acc[i][jj][e] * p.alpha; v[4 + e] = acc[i][jj + 1][e] * p.alpha; }
             if (p.lnfold_sums) {                          // LayerNorm folded into this GEMM: A held the raw rows (include/uia_hip.h)
-                const float2 ss = *(const float2*)(p.lnfold_sums + 2 * (size_t)m);
+                const float2 ss = rowsum_load(p.lnfold_sums, (size_t)m);
                 const LnRow ln = ln_row_from_sums(ss, p.lnfold_dim, p.lnfold_eps);
                 float cs[8];
                 load8(p.lnfold_colsum + n, cs);
@@ -210,8 +224,9 @@ __device__ __forceinline__ void gemm_epilogue(const UiaGemmParams& p, f32x4 (&ac
                 float r[8];
                 load8(p.resid + rrow * p.ldr + n, r);
                 if (p.resid_ln_stats) {                       // the residual is LayerNorm(resid row): same expression as ln_fwd_kernel
-                    float2 ms = *(const float2*)(p.resid_ln_stats + 2 * rrow);
-                    if (p.resid_ln_dim > 0) { const LnRow ln = ln_row_from_sums(ms, p.resid_ln_dim, p.resid_ln_eps); ms = float2{ln.mean, ln.rstd}; }
+                    float2 ms;
+                    if (p.resid_ln_dim > 0) { const LnRow ln = ln_row_from_sums(rowsum_load(p.resid_ln_stats, rrow), p.resid_ln_dim, p.resid_ln_eps); ms = float2{ln.mean, ln.rstd}; }
+                    else ms = *(const float2*)((const float*)p.resid_ln_stats + 2 * rrow);
                     float lw[8], lb[8];
                     load8(p.resid_ln_w + n, lw);
                     load8(p.resid_ln_b + n, lb);
@@ -233,8 +248,7 @@ __device__ __forceinline__ void gemm_epilogue(const UiaGemmParams& p, f32x4 (&ac
                 float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { s1 += v[e]; s2 = fmaf(v[e], v[e], s2); }
-                atomicAdd(p.rowsum_out + 2 * orow, s1);
-                atomicAdd(p.rowsum_out + 2 * orow + 1, s2);
+                rowsum_add(p.rowsum_out, orow, s1, s2);
             }
         }
     }
@@ -320,7 +334,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const UiaGemmParams& p, f32x4 
             const int r = lane + 64 * i, m = mrow0 + r;
             if (r < WTM) {
                 // lnpre: the caller requested the sums before its K loop (the ring kernel), so nothing waits on memory here
-                const float2 ss = lnpre ? lnpre[i] : (m < p.M ? *(const float2*)(p.lnfold_sums + 2 * (size_t)m) : float2{0.f, 1.f});
+                const float2 ss = lnpre ? lnpre[i] : (m < p.M ? rowsum_load(p.lnfold_sums, (size_t)m) : float2{0.f, 1.f});
                 const LnRow ln = ln_row_from_sums(ss, p.lnfold_dim, p.lnfold_eps);
                 *(float2*)(lnrow_lds + 2 * r) = float2{ln.rstd, ln.nmr};
             }
@@ -338,7 +352,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const UiaGemmParams& p, f32x4 
         if (f_lnfold) {                                   // rstd·(x·W'ᵀ − mean·colsum): the LayerNorm of the raw rows that A held
             float2 st;                                    // (rstd, -mean·rstd)
             if (lnrow_lds) st = *(const float2*)(lnrow_lds + 2 * (m - mrow0));
-            else { const LnRow ln = ln_row_from_sums(*(const float2*)(p.lnfold_sums + 2 * (size_t)m), p.lnfold_dim, p.lnfold_eps); st = float2{ln.rstd, ln.nmr}; }
+            else { const LnRow ln = ln_row_from_sums(rowsum_load(p.lnfold_sums, (size_t)m), p.lnfold_dim, p.lnfold_eps); st = float2{ln.rstd, ln.nmr}; }
             const f32x2 rs = {st.x, st.x}, nm = {st.y, st.y};
 #pragma unroll
             for (int e = 0; e < 8; e += 2) {              // bias folded in (alpha == 1 with lnfold): two packed fma per element pair
@@ -365,8 +379,9 @@ __device__ __forceinline__ void gemm_epilogue_lds(const UiaGemmParams& p, f32x4 
             float r[8];
             load8(p.resid + rrow * p.ldr + n, r);
             if (f_rln) {                                  // same expression, same operands as ln_fwd_kernel: bit-identical to reading its fp32 output
-                float2 ms = *(const float2*)(p.resid_ln_stats + 2 * rrow);
-                if (p.resid_ln_dim > 0) { const LnRow ln = ln_row_from_sums(ms, p.resid_ln_dim, p.resid_ln_eps); ms = float2{ln.mean, ln.rstd}; }
+                float2 ms;
+                if (p.resid_ln_dim > 0) { const LnRow ln = ln_row_from_sums(rowsum_load(p.resid_ln_stats, rrow), p.resid_ln_dim, p.resid_ln_eps); ms = float2{ln.mean, ln.rstd}; }
+                else ms = *(const float2*)((const float*)p.resid_ln_stats + 2 * rrow);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) r[e] = fmaf((r[e] - ms.x) * ms.y, lnw[e], lnb[e]);
             }
@@ -397,10 +412,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const UiaGemmParams& p, f32x4 
             }
             s1 = row_lanes_sum<LPR>(s1);
             s2 = row_lanes_sum<LPR>(s2);
-            if ((lane % LPR) == 0 && m < p.M) {
-                atomicAdd(p.rowsum_out + 2 * orow, s1);
-                atomicAdd(p.rowsum_out + 2 * orow + 1, s2);
-            }
+            if ((lane % LPR) == 0 && m < p.M) rowsum_add(p.rowsum_out, orow, s1, s2);
         }
     };
 
@@ -831,7 +843,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_tn_ring_kernel(co
 #pragma unroll
         for (int i = 0; i < LNR; ++i) {
             const int r = (tid & 63) + 64 * i, m = m0 + (__builtin_amdgcn_readfirstlane(tid >> 6) / WAVES_N) * (BM / WAVES_M) + r;
-            if (r < BM / WAVES_M && m < p.M) lnpre[i] = *(const float2*)(p.lnfold_sums + 2 * (size_t)m);
+            if (r < BM / WAVES_M && m < p.M) lnpre[i] = rowsum_load(p.lnfold_sums, (size_t)m);
         }
     }
     // W may arrive K-BLOCKED ([K·ESZ/64][N][64 bytes], packed once per weight by the host): a sub-tile of a column panel is then
@@ -1472,8 +1484,9 @@ int uia_gemm_launch(hipStream_t stream, int dtype, const UiaGemmParams& p, int c
     UIA_CHECK_ARG(p.outT_kb_rows == 0 || (p.outT && p.outT_kb_rows >= p.M && (p.N * esz) % 64 == 0 && p.out_group == 0),
                   "uia_gemm: outT_kb_rows needs outT, at least M rows, N*sizeof(T) a multiple of 64 and no row remapping");
     UIA_CHECK_ARG(!p.resid_ln_stats || p.resid_ln_dim >= 0, "uia_gemm: resid_ln_dim=%d", p.resid_ln_dim);
-    UIA_CHECK_ARG(!p.rowsum_out || ((uintptr_t)p.rowsum_out % 8 == 0 && p.out_group == 0), "uia_gemm: rowsum_out must be 8-byte aligned and takes no row remapping");
-    UIA_CHECK_ARG(!p.lnfold_sums || (p.lnfold_colsum && p.lnfold_dim > 0 && p.alpha == 1.0f && (uintptr_t)p.lnfold_sums % 8 == 0 && (uintptr_t)p.lnfold_colsum % 16 == 0),
+    UIA_CHECK_ARG(!p.rowsum_out || ((uintptr_t)p.rowsum_out % 16 == 0 && p.out_group == 0), "uia_gemm: rowsum_out must be 16-byte aligned and takes no row remapping");
+    UIA_CHECK_ARG(!(p.resid_ln_stats && p.resid_ln_dim > 0) || (uintptr_t)p.resid_ln_stats % 16 == 0, "uia_gemm: row sums behind resid_ln_stats must be 16-byte aligned");
+    UIA_CHECK_ARG(!p.lnfold_sums || (p.lnfold_colsum && p.lnfold_dim > 0 && p.alpha == 1.0f && (uintptr_t)p.lnfold_sums % 16 == 0 && (uintptr_t)p.lnfold_colsum % 16 == 0),
                   "uia_gemm: lnfold_sums needs lnfold_colsum (16-byte aligned), lnfold_dim > 0 and alpha == 1");
     // every row the epilogue touches must hold N elements: a leading dimension below N would make row m's tail overwrite row m+1
     UIA_CHECK_ARG(!p.outT || p.outT_kb_rows || p.ldo >= p.N, "uia_gemm: ldo=%lld < N=%d", (long long)p.ldo, p.N);

@@ -64,6 +64,7 @@ def _fold_guard(sums, dim):
     if _FOLD_GUARD["left"] <= 0:
         return
     _FOLD_GUARD["left"] -= 1
+    sums = ops.rowsum_to_float(sums)
     mean = sums[:, 0] / dim
     var = (sums[:, 1] / dim - mean * mean).clamp_min(0)
     ratio = float((mean.abs() / (var.sqrt() + 1e-12)).max())
@@ -140,7 +141,7 @@ _SUMS_ARENA = [None]
 def zero_sums(M, device):
     a = _SUMS_ARENA[0]
     if a is None or a[0].shape[1] != M or a[0].device != device or a[1] >= a[0].shape[0]:
-        a = [torch.zeros(48, M, 2, device=device, dtype=torch.float32), 0]
+        a = [torch.zeros(48, M, 2, device=device, dtype=torch.int64), 0]
         _SUMS_ARENA[0] = a
     a[1] += 1
     return a[0][a[1] - 1]

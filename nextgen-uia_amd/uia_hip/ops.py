@@ -84,6 +84,18 @@ def tail_split_rows(M, N, ncu, bm=256, bn=256):
     return main_panels * bm
 
 
+ROWSUM_SCALE = float(1 << 30)    # row sums (uia_gemm rowsum / lnfold / resid_ln with dim) are int64 fixed point in units of 2^-30: exact, order-free atomics
+
+
+def rowsum_from_float(s):
+    """fp32 [M, 2] (Σ, Σ²) -> the fixed-point form the kernels exchange (tests and host-side producers)"""
+    return (s.double() * ROWSUM_SCALE).round().to(torch.int64).contiguous()
+
+
+def rowsum_to_float(q):
+    return (q.double() / ROWSUM_SCALE).float()
+
+
 KBLOCK_ACT = True        # GEMM -> GEMM activations travel K-blocked ([K/g][rows][g]) between ring-kernel launches (kb_empty / is_kb)
 
 
@@ -231,7 +243,7 @@ def gemm(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None, res
     CUs idle goes through a second launch with half-height tiles (tail_split_rows).
     resid_ln = (stats [M, 2], ln_weight, ln_bias): `resid` is the INPUT of a LayerNorm whose output is the residual to add; a fourth and
     fifth element (dim, eps) say that `stats` holds the row sums (Σ, Σ²) a producing GEMM left through `rowsum`, not (mean, rstd).
-    rowsum = zeroed fp32 [M, 2]: receives (Σ, Σ²) of the stored fp32 rows.  lnfold = (sums [M, 2], colsum [N], dim, eps): `a` holds RAW
+    rowsum = zeroed int64 [M, 2] (ROWSUM_SCALE fixed point; rowsum_to_float converts): receives (Σ, Σ²) of the stored fp32 rows.  lnfold = (sums [M, 2], colsum [N], dim, eps): `a` holds RAW
     rows and `w` is pre-scaled by the LayerNorm weight; the epilogue applies the LayerNorm (include/uia_hip.h, uia_gemm_desc)."""
     packed = w if isinstance(w, PackedW) else None
     wrow = packed.row if packed is not None else w
@@ -308,17 +320,18 @@ def _gemm_one(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None
             d.resid_ln_dim, d.resid_ln_eps = int(resid_ln[3]), float(resid_ln[4])
         if resid is None or resid_mod or out_group:
             raise UiaError("gemm resid_ln needs a plain fp32 resid (no row remapping)")
-        if not (st.dtype == lw.dtype == lb.dtype == torch.float32 and st.is_contiguous() and st.numel() >= 2 * d.M and lw.numel() >= d.N and lb.numel() >= d.N):
+        want_st = torch.int64 if len(resid_ln) > 3 else torch.float32       # row sums (fixed point) or (mean, rstd)
+        if not (st.dtype == want_st and lw.dtype == lb.dtype == torch.float32 and st.is_contiguous() and st.numel() >= 2 * d.M and lw.numel() >= d.N and lb.numel() >= d.N):
             raise UiaError(f"gemm resid_ln: stats {tuple(st.shape)} / weight {tuple(lw.shape)} / bias {tuple(lb.shape)} do not cover [{d.M}, {d.N}]")
         d.resid_ln_stats, d.resid_ln_w, d.resid_ln_b = _p(st), _p(lw), _p(lb)
     if rowsum is not None:
-        if not (rowsum.dtype == torch.float32 and rowsum.is_contiguous() and rowsum.numel() >= 2 * d.M) or out_group:
-            raise UiaError(f"gemm rowsum must be a contiguous fp32 [{d.M}, 2] tensor (no row remapping), got {tuple(rowsum.shape)} {rowsum.dtype}")
+        if not (rowsum.dtype == torch.int64 and rowsum.is_contiguous() and rowsum.numel() >= 2 * d.M) or out_group:
+            raise UiaError(f"gemm rowsum must be a contiguous int64 [{d.M}, 2] tensor (no row remapping), got {tuple(rowsum.shape)} {rowsum.dtype}")
         d.rowsum_out = _p(rowsum)
     if lnfold is not None:
         sm, cs, dim, eps = lnfold
-        if not (sm.dtype == cs.dtype == torch.float32 and sm.is_contiguous() and cs.is_contiguous() and sm.numel() >= 2 * d.M and cs.numel() >= d.N) or alpha != 1.0:
-            raise UiaError(f"gemm lnfold: sums {tuple(sm.shape)} / colsum {tuple(cs.shape)} do not cover [{d.M}, {d.N}] (fp32, contiguous, alpha == 1)")
+        if not (sm.dtype == torch.int64 and cs.dtype == torch.float32 and sm.is_contiguous() and cs.is_contiguous() and sm.numel() >= 2 * d.M and cs.numel() >= d.N) or alpha != 1.0:
+            raise UiaError(f"gemm lnfold: sums {tuple(sm.shape)} {sm.dtype} / colsum {tuple(cs.shape)} do not cover [{d.M}, {d.N}] (int64 row sums, fp32 colsum, contiguous, alpha == 1)")
         d.lnfold_sums, d.lnfold_colsum, d.lnfold_dim, d.lnfold_eps = _p(sm), _p(cs), int(dim), float(eps)
     if resid_t is not None:
         d.residT, d.ldrT = _p(resid_t), _rowmajor(resid_t, "resid_t")

@@ -47,8 +47,12 @@ def test_gemm_rowsum_of_stored_rows(dt, M, cfg):
     resid = (torch.randn(M, N, generator=g) * 2 + 0.5).to(dev())
     out32 = torch.empty(M, N, device=dev())
     out_t = torch.empty(M, N, device=dev(), dtype=dt)
-    sums = torch.zeros(M, 2, device=dev())
-    ops.gemm(a, w, bias=bias, resid=resid, out32=out32, out_t=out_t, rowsum=sums, tile_cfg=cfg)
+    sums_q = torch.zeros(M, 2, device=dev(), dtype=torch.int64)
+    ops.gemm(a, w, bias=bias, resid=resid, out32=out32, out_t=out_t, rowsum=sums_q, tile_cfg=cfg)
+    sums = ops.rowsum_to_float(sums_q)
+    again = torch.zeros_like(sums_q)                                        # integer atomics: the same bits on every launch
+    ops.gemm(a, w, bias=bias, resid=resid, out32=torch.empty_like(out32), out_t=torch.empty_like(out_t), rowsum=again, tile_cfg=cfg)
+    assert torch.equal(again, sums_q)
     ref = a.float() @ w.float().T + bias + resid
     assert rel(out32, ref) < 2e-5
     assert rel(out_t, ref.to(dt)) < (1e-2 if dt == torch.bfloat16 else 2e-5)
@@ -74,7 +78,7 @@ def test_gemm_layernorm_folded_into_consumer(dt, M, cfg, act, aux):
     wf = (W * lw[None, :]).to(dt).contiguous()
     colsum = wf.float().sum(1).contiguous()
     bias = (b + W @ lb).contiguous()
-    sums = torch.stack([x.sum(1), (x * x).sum(1)], 1).contiguous()
+    sums = ops.rowsum_from_float(torch.stack([x.sum(1), (x * x).sum(1)], 1))
     out = torch.empty(M, N, device=dev(), dtype=dt)
     pre = torch.empty(M, N, device=dev(), dtype=dt) if aux else None
     ops.gemm(x_t, wf, bias=bias, act=act, aux_out=pre, out_t=out, lnfold=(sums, colsum, D, eps), tile_cfg=cfg)
@@ -108,7 +112,7 @@ def test_fold_error_grows_with_row_mean_over_std(shift):
     W = (torch.randn(N, D, generator=g) * 0.05).to(dev())
     b = torch.randn(N, generator=g).to(dev())
     wf = (W * lw[None, :]).bfloat16().contiguous()
-    sums = torch.stack([x.sum(1), (x * x).sum(1)], 1).contiguous()
+    sums = ops.rowsum_from_float(torch.stack([x.sum(1), (x * x).sum(1)], 1))
     out = torch.empty(M, N, device=dev(), dtype=torch.bfloat16)
     ops.gemm(x.bfloat16(), wf, bias=(b + W @ lb).contiguous(), out_t=out, lnfold=(sums, wf.float().sum(1).contiguous(), D, eps))
     true = _ln(x.double(), lw.double(), lb.double(), eps) @ W.double().T + b.double()
@@ -132,11 +136,12 @@ def test_gemm_deferred_residual_from_row_sums(M, cfg):
     raw = (torch.randn(M, N, generator=g) * 1.3 - 0.2).to(dev())
     lw = (1 + 0.3 * torch.randn(N, generator=g)).to(dev())
     lb = (0.2 * torch.randn(N, generator=g)).to(dev())
-    sums = torch.stack([raw.sum(1), (raw * raw).sum(1)], 1).contiguous()
+    sums = ops.rowsum_from_float(torch.stack([raw.sum(1), (raw * raw).sum(1)], 1))
     out = torch.empty(M, N, device=dev())
     out_t = torch.empty(M, N, device=dev(), dtype=torch.bfloat16)
-    s2 = torch.zeros(M, 2, device=dev())
-    ops.gemm(a, w, bias=bias, resid=raw, resid_ln=(sums, lw, lb, N, eps), out32=out, out_t=out_t, rowsum=s2, tile_cfg=cfg)
+    s2q = torch.zeros(M, 2, device=dev(), dtype=torch.int64)
+    ops.gemm(a, w, bias=bias, resid=raw, resid_ln=(sums, lw, lb, N, eps), out32=out, out_t=out_t, rowsum=s2q, tile_cfg=cfg)
+    s2 = ops.rowsum_to_float(s2q)
     ref = a.float() @ w.float().T + bias + _ln(raw, lw, lb, eps)
     assert rel(out, ref) < 2e-5
     assert float((s2[:, 0] - out.sum(1)).abs().max() / out.sum(1).abs().max()) < 1e-5
@@ -153,11 +158,14 @@ def test_gemm_lnfold_argument_checks():
     w = torch.zeros(64, 128, device=dev(), dtype=torch.bfloat16)
     out = torch.empty(256, 64, device=dev(), dtype=torch.bfloat16)
     with pytest.raises(UiaError):
-        ops.gemm(a, w, out_t=out, rowsum=torch.zeros(100, 2, device=dev()))                      # too few rows
+        ops.gemm(a, w, out_t=out, rowsum=torch.zeros(100, 2, device=dev(), dtype=torch.int64))   # too few rows
     with pytest.raises(UiaError):
-        ops.gemm(a, w, out_t=out, lnfold=(torch.zeros(256, 2, device=dev()), torch.zeros(32, device=dev()), 128, 1e-6))   # colsum too short
+        ops.gemm(a, w, out_t=out, rowsum=torch.zeros(256, 2, device=dev()))                      # float sums: the kernels exchange int64 fixed point
+    q = torch.zeros(256, 2, device=dev(), dtype=torch.int64)
     with pytest.raises(UiaError):
-        ops.gemm(a, w, out_t=out, alpha=2.0, lnfold=(torch.zeros(256, 2, device=dev()), torch.zeros(64, device=dev()), 128, 1e-6))
+        ops.gemm(a, w, out_t=out, lnfold=(q, torch.zeros(32, device=dev()), 128, 1e-6))          # colsum too short
+    with pytest.raises(UiaError):
+        ops.gemm(a, w, out_t=out, alpha=2.0, lnfold=(q, torch.zeros(64, device=dev()), 128, 1e-6))
 
 
 def _to_kb(t):
@@ -386,9 +394,10 @@ def test_fold_guard_switches_the_fold_off_for_uncentred_rows():
     from uia_hip import functional as UF
     D = 128
     x = torch.randn(64, D, device=dev())
-    ok = torch.stack([x.sum(1), (x * x).sum(1)], 1)
+    from uia_hip import ops
+    ok = ops.rowsum_from_float(torch.stack([x.sum(1), (x * x).sum(1)], 1))
     x[7] += 40.0
-    bad = torch.stack([x.sum(1), (x * x).sum(1)], 1)
+    bad = ops.rowsum_from_float(torch.stack([x.sum(1), (x * x).sum(1)], 1))
     saved = dict(UF._FOLD_GUARD)
     try:
         UF._FOLD_GUARD["left"] = 2
