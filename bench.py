@@ -35,7 +35,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="pairs per GPU")
+    ap.add_argument("--config", default="mona", choices=["mona", "clipseg", "vitl_lora"],
+                    help="mona (default) = the headline: BASELINE configs[1] / [2]; clipseg = configs[3] (OpenAI ViT-B/16 + FiLM decoder, bs 128, DiceCE); "
+                         "vitl_lora = the per-GPU shape of configs[4] (ViT-L/14 + LoRA r=16, 128 pairs per GPU).  The secondary lines carry the same keys")
+    ap.add_argument("--batch", type=int, default=0, help="samples per GPU (default: 256 for mona, 128 for the secondary configs)")
     ap.add_argument("--variant", default="freq_enhanced", help="Mona variant (reference default: biomedclip/finetune.py:76)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -45,6 +48,7 @@ def parse():
     ap.add_argument("--no-overlap-text", action="store_true", help=argparse.SUPPRESS)        # former spelling of the default
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--no-cpu-wide", action="store_true", help="skip the second CPU sample (all logical CPUs, micro-batch 32)")
     ap.add_argument("--no-ln-fold", action="store_true", help="A/B: run the stand-alone LayerNorm kernels instead of folding each frozen LayerNorm into the "
                     "GEMMs on either side of it (UF.set_ln_fold)")
     ap.add_argument("--no-deferred-text-ln", action="store_true", help="scheduling A/B (same results): every text-tower LayerNorm also writes its fp32 output "
@@ -98,24 +102,14 @@ def text_attention_flops(ids, heads=12, dh=64, layers=12, pad_id=0):
     return float(B * L * per_key), float(keys_exec.sum().item() * per_key)
 
 
-def cpu_baseline(state, variant, batch, steps):
-    """The oracle (CPU restatement of the reference path) timed on this host's cores: the reported CPU baseline."""
+def _cpu_sample(fn, batch, steps, threads, what, budget=30.0):
+    """`fn()` = one fwd+bwd of the oracle at micro-batch `batch`; bounded: stops once ~budget seconds of CPU work are spent."""
     import torch
-    from oracle import train_ref
-    torch.set_num_threads(min(16, os.cpu_count()))                  # more threads than this only adds contention at micro-batch 8
-    g = torch.Generator().manual_seed(1)
-    images = torch.rand(batch, 3, 224, 224, generator=g)
-    ids = torch.zeros(batch, 256, dtype=torch.long)
-    for b in range(batch):
-        n = 24 + (b * 13) % 105
-        ids[b, 1:n - 1] = torch.randint(1000, 30000, (n - 2,), generator=g)
-        ids[b, 0], ids[b, n - 1] = 2, 3
-    names = [k for k in state if "mona" in k]
-    mona = dict(variant=variant, hw=(14, 14))
-    times, budget = [], 30.0                                        # bounded sample: stop once ~30 s of CPU work are spent
+    torch.set_num_threads(threads)
+    times = []
     for i in range(steps + 1):
         t0 = time.perf_counter()
-        train_ref.grads_of(lambda Pq, im, tk: train_ref.biomedclip_loss(Pq, im, tk, mona=mona), state, names, [(images, ids)])
+        fn()
         times.append(time.perf_counter() - t0)
         if sum(times) > budget:
             break
@@ -123,9 +117,159 @@ def cpu_baseline(state, variant, batch, steps):
     dt = sum(timed) / len(timed)
     return {"value": round(batch / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(), "host_logical_cpus": os.cpu_count(),
             "host_cpu_model": _cpu_model(), "kind": "port",
-            "sample": f"{len(timed)} fwd+bwd step(s){' after 1 warm-up' if len(times) > 1 else ' (no warm-up: first step exceeded the 30 s budget)'} "
-                      f"of the same model at micro-batch {batch}, fp32, oracle/train_ref.py",
+            "sample": f"{len(timed)} fwd+bwd step(s){' after 1 warm-up' if len(times) > 1 else ' (no warm-up: first step exceeded the budget)'} "
+                      f"of the same model at micro-batch {batch}, fp32, {what}",
             "s_per_step": round(dt, 3)}
+
+
+def cpu_baseline(state, variant, batch, steps, wide=True):
+    """The oracle (CPU restatement of the reference path) timed on this host's cores: the reported CPU baseline.  Two bounded samples:
+    micro-batch 8 on at most 16 threads (more threads only add contention at that size), and — BASELINE.md §3 asks for os.cpu_count() —
+    micro-batch 32 on every logical CPU, reported under "all_cores"."""
+    import torch
+    from oracle import train_ref
+    names = [k for k in state if "mona" in k]
+    mona = dict(variant=variant, hw=(14, 14))
+
+    def make(bs):
+        g = torch.Generator().manual_seed(1)
+        images = torch.rand(bs, 3, 224, 224, generator=g)
+        ids = torch.zeros(bs, 256, dtype=torch.long)
+        for b in range(bs):
+            n = 24 + (b * 13) % 105
+            ids[b, 1:n - 1] = torch.randint(1000, 30000, (n - 2,), generator=g)
+            ids[b, 0], ids[b, n - 1] = 2, 3
+        return lambda: train_ref.grads_of(lambda Pq, im, tk: train_ref.biomedclip_loss(Pq, im, tk, mona=mona), state, names, [(images, ids)])
+
+    out = _cpu_sample(make(batch), batch, steps, min(16, os.cpu_count()), "oracle/train_ref.py")
+    if wide and (os.cpu_count() or 1) > 16:
+        out["all_cores"] = _cpu_sample(make(32), 32, 2, os.cpu_count(), "oracle/train_ref.py", budget=25.0)
+    return out
+
+
+def gemm_roofline(prof, prof_serial, args, ms_per_step, ops, torch):
+    """Roofline of the dominant GEMM instantiation from per-launch HIP events.  Launches are grouped by the kernel instantiation they run
+    on (tile config, compile-time epilogue mask) — the same granularity as a row of rocprofv3's kernel_stats.csv — and the instantiation
+    with the largest share of the step is reported; the whole GEMM family and a per-(kernel, M, N, K) table are given beside it."""
+    dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
+
+    def group(events, key):
+        acc = {}
+        for e0, e1, M, N, K, _dt, cfg, nbytes, mask in events:
+            d = acc.setdefault(key(cfg, mask), [0.0, 0.0, 0, 0.0])
+            d[0] += e0.elapsed_time(e1) * 1e-3
+            d[1] += 2.0 * M * N * K
+            d[2] += 1
+            d[3] += nbytes
+        return acc
+
+    def shape_table(events):
+        acc = {}
+        for e0, e1, M, N, K, _dt, cfg, nbytes, mask in events:
+            d = acc.setdefault((cfg, mask if mask in ops._SPECIALISED else ops.EPI_GENERIC, M, N, K), [0.0, 0, nbytes])
+            d[0] += e0.elapsed_time(e1) * 1e-3
+            d[1] += 1
+        rows = []
+        for (cfg, mask, M, N, K), (tsec, n, nbytes) in sorted(acc.items(), key=lambda kv: -kv[1][0]):
+            tf = 2.0 * M * N * K * n / tsec * 1e-12
+            rows.append({"kernel": ops.gemm_kernel_name(cfg, mask, dt)[0], "M": M, "N": N, "K": K,
+                         "launches": n, "avg_us": round(tsec / n * 1e6, 1), "tflops": round(tf, 1), "frac_of_mfma_peak": round(tf / peak, 4),
+                         "algorithmic_GBps": round(nbytes * n / tsec * 1e-9), "frac_of_hbm_spec": round(nbytes * n / tsec * 1e-12 / 8.0, 3)})
+        return rows
+
+    per_kernel = lambda c, m: (c, m if m in ops._SPECIALISED else ops.EPI_GENERIC)
+    by_k, by_k_serial = group(prof, per_kernel), group(prof_serial, per_kernel)
+    fam, fam_serial = group(prof, lambda c, m: c in (8, 12, 13, 14)), group(prof_serial, lambda c, m: c in (8, 12, 13, 14))
+    if not by_k:
+        return None
+    dom = max(by_k, key=lambda k: by_k[k][0])
+    tsec, flops, n, algo_bytes = by_k[dom]
+    achieved = flops / tsec * 1e-12
+    ts, fs, ns, _ = by_k_serial.get(dom, (tsec, flops, n, algo_bytes))
+    kname, kmangled = ops.gemm_kernel_name(dom[0], dom[1], dt)
+    traffic, traffic_src = None, None
+    tdir = os.path.join(ROOT, "profiles")
+    for cand in ("r03_traffic_pmc.json", "r02_traffic_pmc.json", "r01_g_traffic_pmc.json"):
+        tpath = os.path.join(tdir, cand)
+        if os.path.exists(tpath):
+            break
+    if args.config == "mona" and args.dtype == "bf16" and args.batch == 256 and os.path.exists(tpath):
+        # HBM bytes per launch of this kernel from rocprofv3 PMC passes over the same workload (tools/pmc_traffic.sh):
+        # FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies the 128-B requests of wide coalesced
+        # reads at 64 B, so it is doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact for 16-B stores.
+        pm = json.load(open(tpath))
+        f, w = pm["FETCH_SIZE"].get(kmangled), pm["WRITE_SIZE"].get(kmangled)
+        if f and w:
+            traffic = round((2.0 * f["sum"] / f["launches"] + w["sum"] / w["launches"]) * 1024)
+            traffic_src = (f"profiles/{os.path.basename(tpath)} (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, same "
+                           "workload, measured in the round the file name carries; FETCH_SIZE doubled per the gfx950 note of the microarchitecture guide)")
+    ft, ff, fn, _ = fam.get(True, (tsec, flops, n, 0.0))
+    fts, ffs, fns, _ = fam_serial.get(True, (ts, fs, ns, 0.0))
+    roof = {"bound": "mfma", "kernel": kname, "kernel_in_rocprof_csv": kmangled, "achieved": round(achieved, 1), "peak": peak,
+            "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "bytes per launch (HBM, PMC)",
+            "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(algo_bytes / n), "launches_per_step": n,
+            "avg_launch_us": round(tsec / n * 1e6, 2), "flop_per_launch_avg": round(flops / n),
+            "share_of_step": round(tsec / (ms_per_step * 1e-3), 3),
+            "note": ("HIP events around every launch of this kernel, on the launch stream, during one extra step of the same loop right after the timed region" +
+                     ("; --overlap-text: the text tower runs on a second stream, so a launch's duration includes time shared with "
+                      "that stream's kernels (see standalone)" if args.overlap_text else "")),
+            "gemm_family": {"kernels": "gemm_tn_ring_kernel<...,EPI> (+ gemm_tn_persist_kernel when selected), all epilogue masks",
+                            "launches_per_step": fn, "achieved": round(ff / ft * 1e-12, 1), "frac": round(ff / ft * 1e-12 / peak, 4),
+                            "ms_per_step": round(ft * 1e3, 3)},
+            "per_shape": shape_table(prof_serial)}
+    if args.overlap_text:
+        roof["standalone"] = {"achieved": round(fs / ts * 1e-12, 1), "frac": round(fs / ts * 1e-12 / peak, 4), "avg_launch_us": round(ts / ns * 1e6, 2),
+                              "family_achieved": round(ffs / fts * 1e-12, 1), "how": "one extra untimed step with both towers on one stream"}
+    return roof
+
+
+def timed_loop(step, args, world, device, ops, torch):
+    """W untimed warm-up steps, then EXACTLY K steps bracketed by barrier + synchronize; returns (seconds MAX over ranks, per-rank list,
+    last loss, events of one extra profiled step [, of a serialised one])."""
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    loss = None
+    for _ in range(args.warmup):
+        loss = step(args.overlap_text)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step(args.overlap_text)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    # per-launch HIP events (on the launch stream) around every uia_gemm of ONE more step of the same loop, outside the timed region:
+    # the event records cost host time the throughput figure should not carry; the step itself is identical to the timed ones
+    ops.GEMM_PROFILE = []
+    step(args.overlap_text)
+    torch.cuda.synchronize()
+    prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
+    prof_serial = prof
+    if args.overlap_text:
+        # one extra, untimed step with the two towers serialised on one stream: the kernels' rates without the other stream beside them
+        ops.GEMM_PROFILE = []
+        step(False)
+        torch.cuda.synchronize()
+        prof_serial, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
+    per_rank = [elapsed]
+    if world > 1:
+        t = torch.zeros(world, device=device, dtype=torch.float64)
+        t[int(os.environ.get("RANK", 0))] = elapsed
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM)
+        per_rank = [float(v) for v in t.tolist()]
+        elapsed = max(per_rank)
+    return elapsed, per_rank, float(loss), prof, prof_serial
+
+
+def dist_fields(world, per_rank, steps, ops):
+    """What the communicator itself saw (not the environment): a multi-GPU line must prove RCCL had N ranks."""
+    ms = [e / steps * 1e3 for e in per_rank]
+    return {"rccl_world": int(ops.comm_world()), "rccl_initialised": bool(ops.comm_world_initialised()), "env_world_size": world,
+            "ms_per_step_per_rank": {"min": round(min(ms), 3), "max": round(max(ms), 3), "ranks": len(ms)}}
 
 
 def main():
@@ -134,9 +278,6 @@ def main():
     from uia_hip import functional as UF
     from uia_hip import ops
     from uia_hip.engine import FlatAdapterOptimizer, contrastive_step, init_data_parallel
-    from src.adapters import inject_mona_variant_to_open_clip
-    from src.losses import InfoNCELoss
-    from src.third_party.biomedclip.model import create_biomedclip
 
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
@@ -144,6 +285,8 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    if not args.batch:
+        args.batch = 256 if args.config == "mona" else 128
     UF.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
     UF.set_unpad_text(args.unpad_text)
     UF.set_deferred_text_ln(not args.no_deferred_text_ln)
@@ -152,6 +295,30 @@ def main():
     ops.KBLOCK_ACT = not args.no_kblock_act
     ops.PERSIST_STORE_ONLY = args.persist_store_only
     ops.TILE_GROUP = {int(k): int(v) for k, v in (kv.split("=") for kv in args.tile_group.split(",") if kv)}
+    try:
+        out = {"mona": bench_mona, "clipseg": bench_clipseg, "vitl_lora": bench_vitl_lora}[args.config](args, rank, world, device)
+    except Exception:
+        # a rank that dies here (a failed RCCL init above all) must take the job down with a non-zero code on EVERY rank: its peers
+        # are most likely blocked inside a collective, and torch.distributed.run only tears the group down when a worker exits non-zero
+        import traceback
+        traceback.print_exc()
+        sys.stderr.flush()
+        os._exit(13)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        ops.comm_destroy()
+        torch.distributed.destroy_process_group()
+
+
+def bench_mona(args, rank, world, device):
+    import torch
+    from uia_hip import functional as UF
+    from uia_hip import ops
+    from uia_hip.engine import FlatAdapterOptimizer, contrastive_step, init_data_parallel
+    from src.adapters import inject_mona_variant_to_open_clip
+    from src.losses import InfoNCELoss
+    from src.third_party.biomedclip.model import create_biomedclip
 
     model = create_biomedclip(seed=0)                                # same weights on every rank (random init: no network for checkpoints)
     for p in model.parameters():
@@ -170,138 +337,181 @@ def main():
     images, ids = synthetic_batch(args.batch, rank, device)
     UF.set_dropout_seed(1234 + rank)
 
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
+    step = lambda overlap: contrastive_step(model, criterion, opt, images, ids, overlap_text=overlap, global_loss=args.global_loss)
+    elapsed, per_rank, final_loss, prof, prof_serial = timed_loop(step, args, world, device, ops, torch)
+    if rank != 0:
+        return None
+    ms = elapsed / args.steps * 1e3
+    value = world * args.batch * args.steps / elapsed
+    peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
+    roof = gemm_roofline(prof, prof_serial, args, ms, ops, torch)
+    if roof is not None:
+        # with --unpad-text the executed text-tower work is below the dense count GFLOP_PER_PAIR is quoted on: no fraction then
+        roof["whole_step_frac_of_peak"] = None if args.unpad_text else round(value / world * GFLOP_PER_PAIR * 1e-3 / peak, 4)
+        if not args.unpad_text:
+            algo, execd = text_attention_flops(ids.cpu())
+            gf_exec = GFLOP_PER_PAIR - (algo - execd) * 1e-9 / args.batch
+            roof["text_attention_flops"] = {"algorithmic_GF_per_step": round(algo * 1e-9, 1), "executed_GF_per_step": round(execd * 1e-9, 1),
+                                            "note": "fully padded 64-key chunks are skipped; every GEMM runs all 256 positions"}
+            roof["gflop_per_pair_executed"] = round(gf_exec, 2)
+            roof["whole_step_frac_of_peak_executed"] = round(value / world * gf_exec * 1e-3 / peak, 4)
+    out = {"metric": "images/sec fwd+bwd BiomedCLIP+Mona bs=256", "value": round(value, 2), "unit": "images/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+           "config": {"workload": "BiomedCLIP ViT-B/16 + Mona fine-tune step (BASELINE configs[1]): image tower fwd+bwd with 12 Mona adapters, "
+                                  "frozen BERT-base text tower fwd (all 256 positions through every GEMM; attention skips key tiles that are entirely padding), "
+                                  "InfoNCE, clip+AdamW; random-init weights",
+                      "mona_variant": args.variant, "batch_per_gpu": args.batch, "global_batch": args.batch * world, "image": "3x224x224",
+                      "text_len": 256, "text_positions_computed": "valid tokens only (opt-in --unpad-text)" if args.unpad_text else "all 256",
+                      "parallelism": f"dp{world}", "text_tower_stream": "second stream" if args.overlap_text else "same stream",
+                      "contrastive_batch": "global (opt-in)" if args.global_loss else "per-rank (reference-equivalent)", "mona_dropout": 0.1,
+                      "bert_dropout_emulated": False,
+                      "layernorm": "stand-alone kernels" if args.no_ln_fold else "folded into the neighbouring GEMMs (row sums in the producer epilogue, normalised accumulators in the consumer)",
+                      "gflop_per_pair_algorithmic": GFLOP_PER_PAIR},
+           "loss": round(final_loss, 5), "roofline": roof}
+    out.update(dist_fields(world, per_rank, args.steps, ops))
+    out["cpu_baseline"] = cpu_baseline(cpu_state, args.variant, args.cpu_batch, args.cpu_steps, wide=not args.no_cpu_wide) if cpu_state is not None else None
+    return out
 
-    loss = None
-    for _ in range(args.warmup):
-        loss = contrastive_step(model, criterion, opt, images, ids, overlap_text=args.overlap_text, global_loss=args.global_loss)
-    barrier()
-    t0 = time.perf_counter()
-    for s in range(args.steps):
-        loss = contrastive_step(model, criterion, opt, images, ids, overlap_text=args.overlap_text, global_loss=args.global_loss)
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    # per-launch HIP events (on the launch stream) around every uia_gemm of ONE more step of the same loop, outside the timed region:
-    # the event records cost host time the throughput figure should not carry; the step itself is identical to the timed ones
-    ops.GEMM_PROFILE = []
-    contrastive_step(model, criterion, opt, images, ids, overlap_text=args.overlap_text, global_loss=args.global_loss)
-    torch.cuda.synchronize()
-    prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
-    prof_serial = prof
-    if args.overlap_text:
-        # one extra, untimed step with the two towers serialised on one stream: the kernels' rates without the other stream beside them
-        ops.GEMM_PROFILE = []
-        contrastive_step(model, criterion, opt, images, ids, overlap_text=False, global_loss=args.global_loss)
-        torch.cuda.synchronize()
-        prof_serial, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
-    if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t[0])
-    final_loss = float(loss)
 
-    if rank == 0:
-        ms = elapsed / args.steps * 1e3
-        value = world * args.batch * args.steps / elapsed
-        # ---- roofline of the dominant kernel.  Launches are grouped by the kernel instantiation they run on (tile config,
-        #      compile-time epilogue mask) — the same granularity as a row of rocprofv3's kernel_stats.csv — and the
-        #      instantiation with the largest share of the step is reported; the whole GEMM family is given beside it.
-        def group(events, key):
-            acc = {}
-            for e0, e1, M, N, K, dt, cfg, nbytes, mask in events:
-                d = acc.setdefault(key(cfg, mask), [0.0, 0.0, 0, 0.0])
-                d[0] += e0.elapsed_time(e1) * 1e-3
-                d[1] += 2.0 * M * N * K
-                d[2] += 1
-                d[3] += nbytes
-            return acc
-        def shape_table(events, peak):
-            acc = {}
-            for e0, e1, M, N, K, dt, cfg, nbytes, mask in events:
-                d = acc.setdefault((cfg, mask if mask in ops._SPECIALISED else ops.EPI_GENERIC, M, N, K), [0.0, 0, nbytes])
-                d[0] += e0.elapsed_time(e1) * 1e-3
-                d[1] += 1
-            rows = []
-            for (cfg, mask, M, N, K), (tsec, n, nbytes) in sorted(acc.items(), key=lambda kv: -kv[1][0]):
-                tf = 2.0 * M * N * K * n / tsec * 1e-12
-                rows.append({"kernel": ops.gemm_kernel_name(cfg, mask, torch.bfloat16 if args.dtype == "bf16" else torch.float32)[0], "M": M, "N": N, "K": K,
-                             "launches": n, "avg_us": round(tsec / n * 1e6, 1), "tflops": round(tf, 1), "frac_of_mfma_peak": round(tf / peak, 4),
-                             "algorithmic_GBps": round(nbytes * n / tsec * 1e-9), "frac_of_hbm_spec": round(nbytes * n / tsec * 1e-12 / 8.0, 3)})
-            return rows
-        per_kernel = lambda c, m: (c, m if m in ops._SPECIALISED else ops.EPI_GENERIC)
-        by_k, by_k_serial = group(prof, per_kernel), group(prof_serial, per_kernel)
-        fam, fam_serial = group(prof, lambda c, m: c in (8, 12, 13, 14)), group(prof_serial, lambda c, m: c in (8, 12, 13, 14))
-        dom = max(by_k, key=lambda k: by_k[k][0]) if by_k else None
-        roof = None
-        if dom is not None:
-            tsec, flops, n, algo_bytes = by_k[dom]
-            achieved = flops / tsec * 1e-12
-            peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
-            ts, fs, ns, _ = by_k_serial.get(dom, (tsec, flops, n, algo_bytes))
-            kname, kmangled = ops.gemm_kernel_name(dom[0], dom[1], torch.bfloat16 if args.dtype == "bf16" else torch.float32)
-            traffic, traffic_src = None, None
-            tdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-            tpath = os.path.join(tdir, "r02_traffic_pmc.json")
-            if not os.path.exists(tpath):
-                tpath = os.path.join(tdir, "r01_g_traffic_pmc.json")
-            if args.dtype == "bf16" and args.batch == 256 and os.path.exists(tpath):
-                # HBM bytes per launch of this kernel from rocprofv3 PMC passes over the same workload (tools/pmc_traffic.sh):
-                # FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies the 128-B requests of wide coalesced
-                # reads at 64 B, so it is doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact for 16-B stores.
-                pm = json.load(open(tpath))
-                f, w = pm["FETCH_SIZE"].get(kmangled), pm["WRITE_SIZE"].get(kmangled)
-                if f and w:
-                    traffic = round((2.0 * f["sum"] / f["launches"] + w["sum"] / w["launches"]) * 1024)
-                    traffic_src = (f"profiles/{os.path.basename(tpath)} (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, same "
-                                   "workload; FETCH_SIZE doubled per the gfx950 note of the microarchitecture guide)")
-            ft, ff, fn, _ = fam.get(True, (tsec, flops, n, 0.0))
-            fts, ffs, fns, _ = fam_serial.get(True, (ts, fs, ns, 0.0))
-            roof = {"bound": "mfma", "kernel": kname, "kernel_in_rocprof_csv": kmangled, "achieved": round(achieved, 1), "peak": peak,
-                    "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "bytes per launch (HBM, PMC)",
-                    "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(algo_bytes / n), "launches_per_step": n,
-                    "avg_launch_us": round(tsec / n * 1e6, 2), "flop_per_launch_avg": round(flops / n),
-                    "share_of_step": round(tsec / (elapsed / args.steps), 3),
-                    "note": ("HIP events around every launch of this kernel, on the launch stream, during one extra step of the same loop right after the timed region" +
-                             ("; --overlap-text: the text tower runs on a second stream, so a launch's duration includes time shared with "
-                              "that stream's kernels (see standalone)" if args.overlap_text else "")),
-                    "gemm_family": {"kernels": "gemm_tn_ring_kernel<...,EPI> (+ gemm_tn_persist_kernel when selected), all epilogue masks",
-                                    "launches_per_step": fn, "achieved": round(ff / ft * 1e-12, 1), "frac": round(ff / ft * 1e-12 / peak, 4)},
-                    "per_shape": shape_table(prof_serial, peak),
-                    # with --unpad-text the executed text-tower work is below the dense count GFLOP_PER_PAIR is quoted on: no fraction then
-                    "whole_step_frac_of_peak": None if args.unpad_text else round(value / world * GFLOP_PER_PAIR * 1e-3 / peak, 4)}
-            if not args.unpad_text:
-                algo, execd = text_attention_flops(ids.cpu())
-                gf_exec = GFLOP_PER_PAIR - (algo - execd) * 1e-9 / args.batch
-                roof["text_attention_flops"] = {"algorithmic_GF_per_step": round(algo * 1e-9, 1), "executed_GF_per_step": round(execd * 1e-9, 1),
-                                                "note": "fully padded 64-key chunks are skipped; every GEMM runs all 256 positions"}
-                roof["gflop_per_pair_executed"] = round(gf_exec, 2)
-                roof["whole_step_frac_of_peak_executed"] = round(value / world * gf_exec * 1e-3 / peak, 4)
-            if args.overlap_text:
-                roof["standalone"] = {"achieved": round(fs / ts * 1e-12, 1), "frac": round(fs / ts * 1e-12 / peak, 4), "avg_launch_us": round(ts / ns * 1e6, 2),
-                                      "family_achieved": round(ffs / fts * 1e-12, 1), "how": "one extra untimed step with both towers on one stream"}
-        out = {"metric": "images/sec fwd+bwd BiomedCLIP+Mona bs=256", "value": round(value, 2), "unit": "images/s", "n_gpus": world,
-               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-               "config": {"workload": "BiomedCLIP ViT-B/16 + Mona fine-tune step (BASELINE configs[1]): image tower fwd+bwd with 12 Mona adapters, "
-                                      "frozen BERT-base text tower fwd (all 256 positions through every GEMM; attention skips key tiles that are entirely padding), "
-                                      "InfoNCE, clip+AdamW; random-init weights",
-                          "mona_variant": args.variant, "batch_per_gpu": args.batch, "global_batch": args.batch * world, "image": "3x224x224",
-                          "text_len": 256, "text_positions_computed": "valid tokens only (opt-in --unpad-text)" if args.unpad_text else "all 256",
-                          "parallelism": f"dp{world}", "text_tower_stream": "second stream" if args.overlap_text else "same stream", "contrastive_batch": "global (opt-in)" if args.global_loss else "per-rank (reference-equivalent)", "mona_dropout": 0.1, "bert_dropout_emulated": False, "layernorm": "stand-alone kernels" if args.no_ln_fold else "folded into the neighbouring GEMMs (row sums in the producer epilogue, normalised accumulators in the consumer)",
-                          "gflop_per_pair_algorithmic": GFLOP_PER_PAIR},
-               "loss": round(final_loss, 5), "roofline": roof}
-        if cpu_state is not None:
-            out["cpu_baseline"] = cpu_baseline(cpu_state, args.variant, args.cpu_batch, args.cpu_steps)
-        else:
-            out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        ops.comm_destroy()
-        torch.distributed.destroy_process_group()
+def bench_clipseg(args, rank, world, device):
+    """BASELINE configs[3]: CLIPSeg — frozen OpenAI ViT-B/16 (QuickGELU) taps 3/6/9 + text prompt -> FiLM decoder (1 127 009 trainable), DiceCE,
+    bs 128 per GPU (reference: src/models/clipseg/segmentation.py:78-160, clipseg_adapter.py:73-98).  36.5 GF per image."""
+    import torch
+    from uia_hip import functional as UF
+    from uia_hip import ops
+    from uia_hip.engine import FlatAdapterOptimizer, init_data_parallel
+    from src.models.clipseg import segmentation as S
+    from src.losses.dice import DiceCELoss
+    GF = 36.5
+    sargs = S.get_args(["--synthetic", "--batch_size", str(args.batch)])
+    sargs.device = str(device)
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(sys.stderr):
+        model = S.prepare_model(sargs)
+    cpu_state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()} if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
+    opt = FlatAdapterOptimizer([(n, p) for n, p in model.named_parameters() if p.requires_grad], lr=1e-4, betas=(0.9, 0.999), max_norm=0.0)
+    init_data_parallel(opt)
+    crit = DiceCELoss()
+    images, labels = S.synthetic_batch(args.batch, 224, 1 + rank, str(device))
+    prompt = S.busi_prompt.to(device).repeat(args.batch, 1)
+
+    def step(_overlap):
+        opt.zero_grad()
+        loss = crit(model(images, input_ids=prompt), labels)
+        loss.backward()
+        opt.all_reduce()
+        opt.step()
+        UF.clear_t_copies()
+        return loss
+
+    elapsed, per_rank, final_loss, prof, prof_serial = timed_loop(step, args, world, device, ops, torch)
+    if rank != 0:
+        return None
+    ms = elapsed / args.steps * 1e3
+    value = world * args.batch * args.steps / elapsed
+    peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
+    roof = gemm_roofline(prof, prof_serial, args, ms, ops, torch)
+    if roof is not None:
+        roof["whole_step_frac_of_peak"] = round(value / world * GF * 1e-3 / peak, 4)
+    out = {"metric": "images/sec fwd+bwd CLIPSeg ViT-B/16 + FiLM decoder bs=128 (BASELINE configs[3]; secondary line)", "value": round(value, 2),
+           "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+           "config": {"workload": "CLIPSeg segmentation step (BASELINE configs[3]): frozen OpenAI ViT-B/16 forward with taps 3/6/9 + prompt text tower, "
+                                  "FiLM decoder fwd+bwd (1 127 009 trainable), DiceCE, AdamW; random-init weights, synthetic ellipse masks",
+                      "batch_per_gpu": args.batch, "global_batch": args.batch * world, "image": "3x224x224", "parallelism": f"dp{world}",
+                      "gflop_per_image_algorithmic": GF},
+           "loss": round(final_loss, 5), "roofline": roof}
+    out.update(dist_fields(world, per_rank, args.steps, ops))
+    out["cpu_baseline"] = None
+    if cpu_state is not None:
+        from oracle import clipseg_ref, losses_ref
+        bs = 4
+        im, lab = images[:bs].cpu(), labels[:bs].cpu().float()
+        pr = prompt[:bs].cpu()
+        names = [k for k in cpu_state if k.startswith("decoder.")]
+
+        def fn():
+            leaves = {k: cpu_state[k].clone().requires_grad_(True) for k in names}
+            Pq = dict(cpu_state)
+            Pq.update(leaves)
+            losses_ref.dice_ce(clipseg_ref.adapter_forward(im, pr, Pq, vit_heads=12, text_heads=8, extract_layers=(3, 6, 9)), lab).backward()
+        out["cpu_baseline"] = _cpu_sample(fn, bs, 3, min(16, os.cpu_count()), "oracle/clipseg_ref.py", budget=20.0)
+    return out
+
+
+def bench_vitl_lora(args, rank, world, device):
+    """Per-GPU shape of BASELINE configs[4]: in-tree CLIP with a ViT-L/14 image tower (24 blocks, width 1024, 16 heads, 257 tokens) and the
+    12-layer causal text tower, LoRA r = 16 (alpha 32, dropout 0.1) on q, k, v, o of the image tower through inject_lora_to_clip
+    (reference src/adapters/lora.py:202-248), contrastive step at 128 pairs per GPU.  335 + 13.3 GF per pair."""
+    import torch
+    from uia_hip import functional as UF
+    from uia_hip import ops
+    from uia_hip.engine import FlatAdapterOptimizer, contrastive_step, init_data_parallel
+    from src.adapters import inject_lora_to_clip
+    from src.losses import InfoNCELoss
+    from src.third_party.openai_clip.model import CLIP
+    GF = 335.0 + 13.3
+    torch.manual_seed(0)
+    model = CLIP(768, 224, 24, 1024, 14, 77, 49408, 768, 12, 12)
+    for p in model.parameters():
+        p.requires_grad_(False)
+    with contextlib.redirect_stdout(sys.stderr):
+        model, n = inject_lora_to_clip(model, lora_r=16, lora_alpha=32, lora_dropout=0.1)
+    for k, p in model.named_parameters():
+        p.requires_grad_("lora" in k.lower())
+    cpu_state = {k: v.detach().clone() for k, v in model.state_dict().items()} if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
+    trainable_names = [k for k, p in model.named_parameters() if p.requires_grad]
+    model = model.to(device).train()
+    opt = FlatAdapterOptimizer([(k, p) for k, p in model.named_parameters() if p.requires_grad], lr=1e-4, betas=(0.9, 0.95), weight_decay=0.01, max_norm=1.0)
+    init_data_parallel(opt)
+    g = torch.Generator().manual_seed(1 + rank)
+    B = args.batch
+    images = torch.rand(B, 3, 224, 224, generator=g)
+    ids = torch.zeros(B, 77, dtype=torch.long)
+    for b in range(B):
+        L = int(torch.randint(8, 60, (1,), generator=g))
+        ids[b, 0] = 49406
+        ids[b, 1:L] = torch.randint(1000, 40000, (L - 1,), generator=g)
+        ids[b, L] = 49407
+    images_d, ids_d = images.to(device), ids.to(device)
+    crit = InfoNCELoss(0.07)
+    UF.set_dropout_seed(3 + rank)
+    step = lambda overlap: contrastive_step(model, crit, opt, images_d, ids_d, overlap_text=overlap)
+    elapsed, per_rank, final_loss, prof, prof_serial = timed_loop(step, args, world, device, ops, torch)
+    if rank != 0:
+        return None
+    ms = elapsed / args.steps * 1e3
+    value = world * B * args.steps / elapsed
+    peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
+    roof = gemm_roofline(prof, prof_serial, args, ms, ops, torch)
+    if roof is not None:
+        roof["whole_step_frac_of_peak"] = round(value / world * GF * 1e-3 / peak, 4)
+    out = {"metric": "images/sec fwd+bwd ViT-L/14 + LoRA r=16, 128 pairs/GPU (per-GPU shape of BASELINE configs[4]; secondary line)", "value": round(value, 2),
+           "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+           "config": {"workload": "contrastive fine-tune step on the in-tree CLIP with a ViT-L/14 image tower (24 blocks, width 1024, 257 tokens) + LoRA r=16 on "
+                                  "q,k,v,o (3 145 728 trainable factor elements), frozen 12-layer causal text tower (77 tokens), InfoNCE, clip+AdamW; random-init weights",
+                      "lora_layers": n, "batch_per_gpu": B, "global_batch": B * world, "image": "3x224x224", "parallelism": f"dp{world}",
+                      "gflop_per_pair_algorithmic": GF, "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)},
+           "loss": round(final_loss, 5), "roofline": roof}
+    out.update(dist_fields(world, per_rank, args.steps, ops))
+    out["cpu_baseline"] = None
+    if cpu_state is not None:
+        from oracle import losses_ref, text_ref, vit_ref
+        bs = 2
+        im, tk = images[:bs], ids[:bs]
+
+        def fn():
+            leaves = {k: cpu_state[k].clone().requires_grad_(True) for k in trainable_names}
+            Pq = dict(cpu_state)
+            Pq.update(leaves)
+            fi = vit_ref.openai_vit_forward(im, Pq, heads=16, lora=dict(r=16, alpha=32))
+            with torch.no_grad():
+                ft = text_ref.openai_text_forward(tk, Pq, heads=12)
+            losses_ref.info_nce(fi, ft, 0.07).backward()
+        out["cpu_baseline"] = _cpu_sample(fn, bs, 2, min(16, os.cpu_count()), "oracle/vit_ref.py + text_ref.py (ViT-L/14 + LoRA r=16)", budget=25.0)
+    return out
 
 
 if __name__ == "__main__":

@@ -96,6 +96,15 @@ typedef struct uia_gemm_desc {
      *   outT_kb_rows > 0: the T output is written K-blocked the same way, column n playing the part of k (N·sizeof(T) % 64 == 0; ldo ignored). */
     int64_t a_kb_rows;
     int64_t outT_kb_rows;
+    /* Guard of the folded LayerNorms (optional; a caller-owned, caller-zeroed device word that many launches may share).  The fold hands
+     * the GEMM bf16(x) instead of bf16(LN(x)): fine for roughly centred rows, lossy for |mean| >> std.  Every launch that carries
+     * rowsum_out / lnfold_sums / resid_ln_dim checks the rows it touches and ORs into *ln_flag
+     *   bit 0: a consumer saw a row with |mean|·rstd > ln_flag_limit   (the caller should go back to the stand-alone LayerNorm kernels)
+     *   bit 1: a producer's partial row sum was non-finite or outside the fixed-point range (|Σ| or Σ² >= 5e8 per wave column; the partial
+     *          is clamped so that the integer atomics cannot wrap, and the statistics of that row are garbage: the caller must fail loudly)
+     * The atomics are issued only for offending rows, so a healthy step pays one compare per row. */
+    int32_t* ln_flag;
+    float ln_flag_limit;                /* <= 0: 8.0 */
 } uia_gemm_desc;
 int uia_gemm(void* stream, int dtype, const uia_gemm_desc* d, int tile_cfg /* 0 = auto */);
 

@@ -578,6 +578,7 @@ int launch_bf16(hipStream_t stream, const UiaAttnParams& p) {
 int uia_attn_bwd_launch(hipStream_t stream, int dtype, const UiaAttnParams& p) {
     UIA_CHECK_ARG(dtype == UIA_BF16 || dtype == UIA_F32, "uia_attn_bwd: bad dtype %d", dtype);
     UIA_CHECK_ARG(p.B > 0 && p.H > 0 && p.L > 0, "uia_attn_bwd: empty problem");
+    UIA_CHECK_ARG(p.scale > 0.f && p.scale < 3.0e38f, "uia_attn_bwd: scale must be positive and finite (matches the forward's lse), got %g", (double)p.scale);
     UIA_CHECK_ARG(!p.cu_seqlens, "uia_attn_bwd: packed sequences (cu_seqlens) are a forward-only layout");
     UIA_CHECK_ARG((p.out_kb_rows == 0 && p.dqkv_kb_rows == 0) ||
                   (p.dh == 64 && dtype == UIA_BF16 && (p.out_kb_rows == 0 || p.out_kb_rows >= (int64_t)p.B * p.L) && (p.dqkv_kb_rows == 0 || p.dqkv_kb_rows >= (int64_t)p.B * p.L)),

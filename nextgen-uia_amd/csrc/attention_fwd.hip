@@ -339,6 +339,7 @@ int launch_bf16(hipStream_t stream, const UiaAttnParams& p) {
 int uia_attn_fwd_launch(hipStream_t stream, int dtype, const UiaAttnParams& p) {
     UIA_CHECK_ARG(dtype == UIA_BF16 || dtype == UIA_F32, "uia_attn_fwd: bad dtype %d", dtype);
     UIA_CHECK_ARG(p.B > 0 && p.H > 0 && p.L > 0, "uia_attn_fwd: empty problem");
+    UIA_CHECK_ARG(p.scale > 0.f && p.scale < 3.0e38f, "uia_attn_fwd: scale must be positive and finite (the row max is taken on the raw scores), got %g", (double)p.scale);
     UIA_CHECK_ARG((p.out_kb_rows == 0 && p.dqkv_kb_rows == 0) || (p.dh == 64 && dtype == UIA_BF16 && p.dqkv_kb_rows == 0 && p.out_kb_rows >= (int64_t)p.B * p.L),
                   "uia_attn_fwd: a K-blocked output needs the bf16 head-dim-64 path and out_kb_rows >= B*L");
     if (p.dh != 64) return uia_attn_small_launch(stream, dtype, p, false);   // CLIPSeg decoder heads (d_h = 16)

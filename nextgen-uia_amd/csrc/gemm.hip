@@ -143,7 +143,16 @@ __device__ __forceinline__ void glds16_asm(const char* gsrc, char* lds_wave_base
 // of everything downstream, and the step was not reproducible from run to run.  Range: Σ² up to 8.6e9 (row RMS 3300 at 768 columns).
 typedef long long2 __attribute__((ext_vector_type(2)));
 constexpr float ROWSUM_SCALE = 1073741824.0f, ROWSUM_INV = 1.0f / 1073741824.0f;
-__device__ __forceinline__ void rowsum_add(void* dst, size_t row, float s1, float s2) {
+// A partial sum (one wave column of one launch) is kept below ROWSUM_PART_MAX: up to 16 of them per row cannot wrap the 64-bit sum, and
+// llrintf never sees an infinity or a NaN (undefined).  A clamped partial means the row's statistics are garbage: bit 1 of the caller's
+// guard word (uia_gemm_desc.ln_flag) says so, and the host fails loudly instead of training on a finite but wrong LayerNorm.
+constexpr float ROWSUM_PART_MAX = 5.0e8f;
+__device__ __forceinline__ void rowsum_add(void* dst, size_t row, float s1, float s2, int* flag) {
+    if (!(fabsf(s1) < ROWSUM_PART_MAX) || !(s2 < ROWSUM_PART_MAX)) {
+        if (flag) atomicOr(flag, 2);
+        s1 = fminf(fmaxf(s1, -ROWSUM_PART_MAX), ROWSUM_PART_MAX);        // fmaxf(NaN, a) = a
+        s2 = fminf(fmaxf(s2, 0.0f), ROWSUM_PART_MAX);
+    }
     unsigned long long* q = (unsigned long long*)dst + 2 * row;
     atomicAdd(q, (unsigned long long)llrintf(s1 * ROWSUM_SCALE));        // two's complement: negative sums wrap correctly
     atomicAdd(q + 1, (unsigned long long)llrintf(s2 * ROWSUM_SCALE));
@@ -160,6 +169,11 @@ __device__ __forceinline__ LnRow ln_row_from_sums(float2 ss, int dim, float eps)
     const float var = fmaxf(fmaf(-mean, mean, ss.y * inv), 0.0f);
     const float rstd = rsqrtf(var + eps);
     return LnRow{mean, rstd, -mean * rstd};
+}
+// Guard of a folded LayerNorm (uia_gemm_desc.ln_flag): the consumer's A operand was bf16(x), whose rounding error relative to the row's
+// spread grows with |mean| / std.  Only an offending row issues the atomic.
+__device__ __forceinline__ void ln_fold_guard(const UiaGemmParams& p, const LnRow& ln) {
+    if (p.ln_flag && fabsf(ln.nmr) > (p.ln_flag_limit > 0.f ? p.ln_flag_limit : 8.0f)) atomicOr(p.ln_flag, 1);
 }
 
 // sum over the LPR consecutive lanes that share a row in the LDS-staged epilogue (LPR = 8: two quad permutes + a half-row mirror, all DPP)
@@ -200,6 +214,7 @@ __device__ __forceinline__ void gemm_epilogue(const UiaGemmParams& p, f32x4 (&ac
             if (p.lnfold_sums) {                          // LayerNorm folded into this GEMM: A held the raw rows (include/uia_hip.h)
                 const float2 ss = rowsum_load(p.lnfold_sums, (size_t)m);
                 const LnRow ln = ln_row_from_sums(ss, p.lnfold_dim, p.lnfold_eps);
+                if (jj == 0 && nb == 0) ln_fold_guard(p, ln);
                 float cs[8];
                 load8(p.lnfold_colsum + n, cs);
 #pragma unroll
@@ -248,7 +263,7 @@ __device__ __forceinline__ void gemm_epilogue(const UiaGemmParams& p, f32x4 (&ac
                 float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { s1 += v[e]; s2 = fmaf(v[e], v[e], s2); }
-                rowsum_add(p.rowsum_out, orow, s1, s2);
+                rowsum_add(p.rowsum_out, orow, s1, s2, p.ln_flag);
             }
         }
     }
@@ -336,6 +351,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const UiaGemmParams& p, f32x4 
                 // lnpre: the caller requested the sums before its K loop (the ring kernel), so nothing waits on memory here
                 const float2 ss = lnpre ? lnpre[i] : (m < p.M ? rowsum_load(p.lnfold_sums, (size_t)m) : float2{0.f, 1.f});
                 const LnRow ln = ln_row_from_sums(ss, p.lnfold_dim, p.lnfold_eps);
+                if (wn == 0 && n0 == 0 && m < p.M) ln_fold_guard(p, ln);        // once per row: the first column tile's first wave column
                 *(float2*)(lnrow_lds + 2 * r) = float2{ln.rstd, ln.nmr};
             }
         }
@@ -352,7 +368,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const UiaGemmParams& p, f32x4 
         if (f_lnfold) {                                   // rstd·(x·W'ᵀ − mean·colsum): the LayerNorm of the raw rows that A held
             float2 st;                                    // (rstd, -mean·rstd)
             if (lnrow_lds) st = *(const float2*)(lnrow_lds + 2 * (m - mrow0));
-            else { const LnRow ln = ln_row_from_sums(rowsum_load(p.lnfold_sums, (size_t)m), p.lnfold_dim, p.lnfold_eps); st = float2{ln.rstd, ln.nmr}; }
+            else { const LnRow ln = ln_row_from_sums(rowsum_load(p.lnfold_sums, (size_t)m), p.lnfold_dim, p.lnfold_eps); st = float2{ln.rstd, ln.nmr}; if (n == 0) ln_fold_guard(p, ln); }
             const f32x2 rs = {st.x, st.x}, nm = {st.y, st.y};
 #pragma unroll
             for (int e = 0; e < 8; e += 2) {              // bias folded in (alpha == 1 with lnfold): two packed fma per element pair
@@ -412,7 +428,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const UiaGemmParams& p, f32x4 
             }
             s1 = row_lanes_sum<LPR>(s1);
             s2 = row_lanes_sum<LPR>(s2);
-            if ((lane % LPR) == 0 && m < p.M) rowsum_add(p.rowsum_out, orow, s1, s2);
+            if ((lane % LPR) == 0 && m < p.M) rowsum_add(p.rowsum_out, orow, s1, s2, p.ln_flag);
         }
     };
 
@@ -934,6 +950,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_tn_ring_kernel(co
 
 #ifdef UIA_GEMM_STAMPS
     unsigned long long t_start = __builtin_amdgcn_s_memtime(), t_pro = 0, t_loop = 0;
+    const unsigned long long r_start = __builtin_amdgcn_s_memrealtime();      // 100 MHz: in-kernel clock = Δs_memtime / Δs_memrealtime x 100 MHz
 #endif
     if constexpr (LOOP >= 1) {
         // ---- FREE-RUNNING loop (tile cfg 15): no LOAD / COMPUTE alternation between two wave groups.  Every wave keeps TWO fragment
@@ -1062,7 +1079,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_tn_ring_kernel(co
         unsigned long long t_end = __builtin_amdgcn_s_memtime();
         unsigned long long* o = uia_stamp_buf + ((size_t)blockIdx.x * NW + wave) * 4;
         o[0] = t_start; o[1] = t_pro; o[2] = t_loop; o[3] = t_end;
-        if (wave == 0) { unsigned long long* q = uia_stamp_buf + (size_t)gridDim.x * NW * 4 + (size_t)blockIdx.x * 4; q[0] = __builtin_amdgcn_s_getreg(63492); q[1] = __builtin_amdgcn_s_getreg(63508); q[2] = q[3] = 0; }
+        if (wave == 0) { unsigned long long* q = uia_stamp_buf + (size_t)gridDim.x * NW * 4 + (size_t)blockIdx.x * 4; q[0] = __builtin_amdgcn_s_getreg(63492); q[1] = __builtin_amdgcn_s_getreg(63508); q[2] = t_end - t_start; q[3] = __builtin_amdgcn_s_memrealtime() - r_start; }
     }
 #endif
 }
@@ -1486,6 +1503,7 @@ int uia_gemm_launch(hipStream_t stream, int dtype, const UiaGemmParams& p, int c
     UIA_CHECK_ARG(!p.resid_ln_stats || p.resid_ln_dim >= 0, "uia_gemm: resid_ln_dim=%d", p.resid_ln_dim);
     UIA_CHECK_ARG(!p.rowsum_out || ((uintptr_t)p.rowsum_out % 16 == 0 && p.out_group == 0), "uia_gemm: rowsum_out must be 16-byte aligned and takes no row remapping");
     UIA_CHECK_ARG(!(p.resid_ln_stats && p.resid_ln_dim > 0) || (uintptr_t)p.resid_ln_stats % 16 == 0, "uia_gemm: row sums behind resid_ln_stats must be 16-byte aligned");
+    UIA_CHECK_ARG(!p.ln_flag || (uintptr_t)p.ln_flag % 4 == 0, "uia_gemm: ln_flag must be a 4-byte aligned device word");
     UIA_CHECK_ARG(!p.lnfold_sums || (p.lnfold_colsum && p.lnfold_dim > 0 && p.alpha == 1.0f && (uintptr_t)p.lnfold_sums % 16 == 0 && (uintptr_t)p.lnfold_colsum % 16 == 0),
                   "uia_gemm: lnfold_sums needs lnfold_colsum (16-byte aligned), lnfold_dim > 0 and alpha == 1");
     // every row the epilogue touches must hold N elements: a leading dimension below N would make row m's tail overwrite row m+1

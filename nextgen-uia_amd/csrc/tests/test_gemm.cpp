@@ -116,6 +116,7 @@ static void bench(int dtype, int M, int N, int K, int cfg, int mode) {
 
 #ifdef UIA_GEMM_STAMPS
 #include "../gemm.hip"      // one translation unit: the stamp buffer / diag switch are __device__ globals of gemm.hip
+static int g_warm_launches = 0;      // stamps(): back-to-back launches before the stamped ones (DVFS settles over ~2 s of load)
 static void stamps(int cfg, int M, int N, int K, int mode, int diag = 0) {
     HC(hipMemcpyToSymbol(HIP_SYMBOL(uia_epi_diag), &diag, sizeof(diag)));
     if (diag) printf("-- diag %d (1: no stores, 2: no stores/operand loads, +4 no ds_reads, +8 no DMA, +16 no MFMA)\n", diag);
@@ -124,6 +125,7 @@ static void stamps(int cfg, int M, int N, int K, int mode, int diag = 0) {
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     unsigned long long* d; HC(hipMalloc(&d, ((size_t)tiles * NW * 4 + (size_t)tiles * 4) * 8));
     HC(hipMemcpyToSymbol(HIP_SYMBOL(uia_stamp_buf), &d, sizeof(d)));
+    for (int w = 0; w < g_warm_launches; w += 23) bench(UIA_BF16, M, N, K, cfg, mode);
     bench(UIA_BF16, M, N, K, cfg, mode);
     std::vector<unsigned long long> h((size_t)tiles * NW * 4 + (size_t)tiles * 4);
     HC(hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost));
@@ -151,6 +153,14 @@ static void stamps(int cfg, int M, int N, int K, int mode, int diag = 0) {
         printf("   %zu CUs seen, blocks/CU %.2f, block busy %.0f cycles avg, gap between consecutive blocks on a CU %.0f cycles avg, longest CU span %llu cycles\n",
                per_cu.size(), (double)tiles / per_cu.size(), busy / tiles, ngap ? gap / ngap : 0.0, span);
     }
+    if (cfgb >= 8) {   // in-kernel clock of the LAST launch: per workgroup, shader cycles (s_memtime) over 100 MHz ticks (s_memrealtime)
+        const unsigned long long* q = h.data() + (size_t)tiles * NW * 4;
+        std::vector<double> ghz;
+        for (int b = 0; b < tiles; ++b) if (q[4*b+3] > 0) ghz.push_back((double)q[4*b+2] / (double)q[4*b+3] * 0.1);
+        if (!ghz.empty()) { std::sort(ghz.begin(), ghz.end());
+            printf("   CLOCK in-kernel (s_memtime / s_memrealtime x 100 MHz, per workgroup, after %d warm launches): median %.3f GHz  p10 %.3f  p90 %.3f  (%zu workgroups)\n",
+                   g_warm_launches, ghz[ghz.size()/2], ghz[ghz.size()/10], ghz[ghz.size()*9/10], ghz.size()); }
+    }
     { double sl[4] = {0,0,0,0}; const unsigned long long* q = h.data() + (size_t)tiles * NW * 4;
       for (int i = 0; i < tiles; ++i) for (int k = 0; k < 4; ++k) sl[k] += q[4*i+k];
       printf("   group-0 wave-0 slot cycles per K-step: LOAD0(+8 glds) %.0f | COMPUTE0 %.0f | LOAD1 %.0f | COMPUTE1(+vmcnt) %.0f\n", sl[0]/tiles/(K/64), sl[1]/tiles/(K/64), sl[2]/tiles/(K/64), sl[3]/tiles/(K/64)); }
@@ -161,6 +171,7 @@ static void stamps(int cfg, int M, int N, int K, int mode, int diag = 0) {
 int main(int argc, char** argv) {
 #ifdef UIA_GEMM_STAMPS
     // ./test_gemm_stamps [cfg|flags<<8  M N K mode diag]
+    if (argc > 7) g_warm_launches = atoi(argv[7]);
     if (argc > 6) stamps(atoi(argv[1]), atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]));
     else stamps(8, 50432, 2304, 768, 0, 0);
     return 0;

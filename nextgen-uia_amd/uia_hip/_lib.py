@@ -33,7 +33,7 @@ class GemmDesc(C.Structure):
                 ("out_group", i32), ("outT", vp), ("ldo", i64), ("out32", vp), ("ldo32", i64), ("w_kblocked", i32),
                 ("resid_ln_stats", vp), ("resid_ln_w", vp), ("resid_ln_b", vp),
                 ("rowsum_out", vp), ("lnfold_sums", vp), ("lnfold_colsum", vp), ("lnfold_dim", i32), ("lnfold_eps", f32),
-                ("resid_ln_dim", i32), ("resid_ln_eps", f32), ("a_kb_rows", i64), ("outT_kb_rows", i64)]
+                ("resid_ln_dim", i32), ("resid_ln_eps", f32), ("a_kb_rows", i64), ("outT_kb_rows", i64), ("ln_flag", vp), ("ln_flag_limit", f32)]
 
 
 class AttnDesc(C.Structure):

@@ -115,6 +115,8 @@ class FlatAdapterOptimizer(FlatLayout):
         ops.adamw_clip_step(self.p, self.g, self.m, self.v, self.lr if lr is None else lr, self.betas, self.eps, self.weight_decay,
                             self.max_norm, self.steps, gs, self.ws)
         UF.WEIGHTS.bump()                                      # T copies of the adapter weights are stale now
+        if UF.ln_fold_enabled(UF.compute_dtype()):             # guard of the folded LayerNorms: every folded layer of every step was checked on
+            UF.poll_ln_flag(self.device)                       # the device; this reads the verdict without a host sync (one step late)
 
     def grad_norm(self):
         return math.sqrt(float(self.ws[0]))
@@ -214,9 +216,9 @@ class GatherFeaturesFn(torch.autograd.Function):
     def forward(ctx, x, rank, world):
         x = x.contiguous()
         out = torch.empty(world * x.shape[0], x.shape[1], device=x.device, dtype=x.dtype)
-        if world > 1:
-            ops.allgather(x, out)
-        else:
+        if world > 1 or (x.is_cuda and ops.comm_world_initialised() and ops.comm_world() == world):
+            ops.allgather(x, out)          # also at world 1 once a communicator exists (init_data_parallel(force_comm=True)): the GPU tests
+        else:                              # drive the very collective the multi-GPU job uses on a one-GPU box
             out.copy_(x)
         ctx.meta = (rank, x.shape[0])
         return out

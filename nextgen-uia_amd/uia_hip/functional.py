@@ -47,33 +47,69 @@ def set_ln_fold(flag):
 
 
 def ln_fold_enabled(dt, rows=None):
-    """rows: the fold is a large-batch optimisation and is only applied where its GEMMs run on the ring kernels (more than 2048 rows).
-    Below that nothing is gained, and the row sums' float atomics would make the small parity cases non-reproducible from run to run
-    (bf16 results are chaotic at the level of their rounding: a 1e-7 change of a LayerNorm statistic re-rolls the last bits of everything
-    downstream — the CLIPSeg full-geometry case moved between 7.9e-3 and 1.07e-2 of its 1e-2 bound)."""
+    """rows: the fold is a large-batch optimisation and is only applied where its GEMMs run on the ring kernels (more than 2048 rows);
+    below that nothing is gained.  (The row sums are 64-bit fixed-point integer atomics — exact and order-free, so the folded forward is
+    bit-reproducible; the first version used float atomics and was not: DESIGN.md §4.)"""
     return dt != torch.float32 and _STATE.get("ln_fold", True) and (rows is None or rows > _STATE.get("ln_fold_min_rows", 2048))
 
 
-_FOLD_GUARD = {"left": 8, "limit": 8.0}
+class LnFoldRangeError(FloatingPointError):
+    """A GEMM that left row sums for a folded LayerNorm saw a non-finite or out-of-range partial sum: the LayerNorm statistics of that
+    row — and everything downstream of it — are wrong."""
 
 
-def _fold_guard(sums, dim):
-    """The fold's one assumption is roughly centred rows (bf16(x) rounds relative to |x|: DESIGN.md §4).  The first few row-sum
-    buffers of a process are checked on the host (one sync each, warm-up steps only): if some row has |mean| > 8 std the fold is switched
-    off for the rest of the run with a warning, and the stand-alone LayerNorm kernels take over from the next forward."""
-    if _FOLD_GUARD["left"] <= 0:
-        return
-    _FOLD_GUARD["left"] -= 1
-    sums = ops.rowsum_to_float(sums)
-    mean = sums[:, 0] / dim
-    var = (sums[:, 1] / dim - mean * mean).clamp_min(0)
-    ratio = float((mean.abs() / (var.sqrt() + 1e-12)).max())
-    if ratio > _FOLD_GUARD["limit"]:
+_FOLD_POLL = {}          # device index -> (pinned host word, event) of a read-back in flight
+_FOLD_REPORTED = {}      # device index -> bits already reported
+
+
+def reset_ln_flag(device=None):
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    _FOLD_POLL.pop(key, None)
+    _FOLD_REPORTED.pop(key, None)
+    if key in ops._LN_FLAG:
+        ops._LN_FLAG[key].zero_()
+
+
+def poll_ln_flag(device=None, sync=False):
+    """Reads the guard word of the folded LayerNorms (ops.ln_flag; include/uia_hip.h, uia_gemm_desc.ln_flag).  The fold's one assumption
+    is roughly centred rows — bf16(x) rounds relative to |x|, so a row with |mean| >> std loses precision as a raw GEMM operand
+    (DESIGN.md §4).  EVERY launch that writes or reads row sums checks the rows it touches on the device; this is the host side:
+      bit 0 (a row with |mean| / std > ops.LN_FLAG_LIMIT): a warning, and the fold is switched off — the stand-alone LayerNorm kernels
+            take over from the next forward;
+      bit 1 (a non-finite or out-of-range partial sum): LnFoldRangeError — the step that produced it must not be trusted.
+    sync=False (the training loops, once per step): no host synchronisation — the word is copied to pinned memory behind the step's
+    kernels and the copy of the PREVIOUS call is examined, so a bad step is reported one step late; sync=True waits for this one."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    flag = ops._LN_FLAG.get(key)
+    if flag is None:
+        return 0
+    seen = 0
+    prev = _FOLD_POLL.pop(key, None)
+    if prev is not None:
+        prev[1].synchronize()                                   # long done: it was recorded a whole step ago
+        seen |= int(prev[0][0])
+    host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+    host.copy_(flag, non_blocking=True)                         # the bits are sticky (no per-step fill launch): reset_ln_flag() clears them
+    ev = torch.cuda.Event()
+    ev.record()
+    if sync:
+        ev.synchronize()
+        seen |= int(host[0])
+    else:
+        _FOLD_POLL[key] = (host, ev)
+    seen &= ~_FOLD_REPORTED.get(key, 0) | 2                       # a centring warning is given once; a range error every time it is seen
+    _FOLD_REPORTED[key] = _FOLD_REPORTED.get(key, 0) | (seen & 1)
+    if seen & 2:
+        raise LnFoldRangeError("uia_hip: a LayerNorm row sum was non-finite or out of the fixed-point range (|Σ| or Σ² >= 5e8 in one column "
+                               "block): the activations have diverged; the statistics of that row are not valid")
+    if seen & 1 and _STATE.get("ln_fold", True):
         import warnings
-        warnings.warn(f"uia_hip: LayerNorm fold switched off: a row with |mean| / std = {ratio:.1f} (> {_FOLD_GUARD['limit']}) would lose "
-                      "bf16 precision as a raw GEMM operand; the LayerNorm kernels are used from the next forward on")
+        warnings.warn(f"uia_hip: LayerNorm fold switched off: a row with |mean| / std > {ops.LN_FLAG_LIMIT} would lose bf16 precision as a raw "
+                      "GEMM operand; the LayerNorm kernels are used from the next forward on")
         set_ln_fold(False)
-        _FOLD_GUARD["left"] = 0
+    return seen
 
 
 def set_unpad_text(flag):
@@ -128,36 +164,43 @@ def t_copy_of(g32, dt, allow_kb=False):
 
 def clear_t_copies():
     _T_COPIES.clear()
-    _ROWS[0] = None
-    _SUMS_ARENA[0] = None
+    _ROWS.clear()
+    _SUMS_ARENA.clear()
 
 
 # Zeroed [M, 2] row-sum buffers for the producers of folded LayerNorms: slices of one arena that a single fill zeroes (a block needs two or
 # three of them per forward; 36 fills of 400 KB per step otherwise).  A slice is handed out once; the arena is dropped with the other
-# per-step registries (clear_t_copies) or when it runs out, and a new one is zeroed on the next request.
-_SUMS_ARENA = [None]
+# per-step registries (clear_t_copies) or when it runs out, and a new one is zeroed on the next request.  One arena per STREAM: the fill
+# that zeroes it and the atomics that land in its slices are ordered by that stream only (contrastive_step(overlap_text=True) runs the
+# text tower on a second stream; a shared arena would hand it slices with no event between the fill and their first use).
+_SUMS_ARENA = {}
+
+
+def _stream_key():
+    return torch.cuda.current_stream().cuda_stream
 
 
 def zero_sums(M, device):
-    a = _SUMS_ARENA[0]
+    key = _stream_key()
+    a = _SUMS_ARENA.get(key)
     if a is None or a[0].shape[1] != M or a[0].device != device or a[1] >= a[0].shape[0]:
         a = [torch.zeros(48, M, 2, device=device, dtype=torch.int64), 0]
-        _SUMS_ARENA[0] = a
+        _SUMS_ARENA[key] = a
     a[1] += 1
     return a[0][a[1] - 1]
 
 
 # The forward twin of the registry above, one slot deep: the GEMM that produces a residual-stream tensor (Mona project2, a block's fc2)
 # can leave the T copy of its rows and their (Σ, Σ²) for the LayerNorm folded into the next block's first GEMM.
-_ROWS = [None]
+_ROWS = {}          # one slot per stream (the producer and the consumer of a hand-off run on the same stream)
 
 
 def publish_rows(x32, x_t, sums):
-    _ROWS[0] = (x32, x32._version, x_t, sums)
+    _ROWS[_stream_key()] = (x32, x32._version, x_t, sums)
 
 
 def take_rows(x32, dt):
-    hit, _ROWS[0] = _ROWS[0], None
+    hit = _ROWS.pop(_stream_key(), None)
     if (hit is not None and hit[0].data_ptr() == x32.data_ptr() and hit[0].numel() == x32.numel() and hit[1] == x32._version
             and hit[0].untyped_storage().data_ptr() == x32.untyped_storage().data_ptr() and x32.is_contiguous() and hit[2].dtype == dt):
         return hit[2], hit[3]
@@ -362,7 +405,6 @@ class MonaFn(torch.autograd.Function):
             y_t, sums = _act(M, D, dt, x, 3 * D), zero_sums(M, x.device)          # read by the next block's QKV GEMM only
             ops.gemm(d, w2, bias=P["project2.bias"], resid=x.view(M, D), out32=y.view(M, D), out_t=y_t, rowsum=sums)
             publish_rows(y, y_t, sums)
-            _fold_guard(sums, D)
         else:
             ops.gemm(d, w2, bias=P["project2.bias"], resid=x.view(M, D), out32=y.view(M, D))
         ctx.save_for_backward(x, u, t, d, keep_mask if keep_mask is not None else x.new_empty(0), *params)
@@ -477,7 +519,6 @@ class VitBlockFn(torch.autograd.Function):
             ops.gemm(a, WEIGHTS.get(spec.proj[0], dt), bias=spec.proj[1], resid=x2d, out32=x1, out_t=h1, rowsum=sums1)
             w1, c1, b1 = WEIGHTS.get_lnfold(spec.fc1[0], spec.fc1[1], spec.ln2[0], spec.ln2[1], dt)
             ops.gemm(h1, w1, bias=b1, act=spec.act, aux_out=pre, out_t=f, lnfold=(sums1, c1, D, spec.eps))
-            _fold_guard(sums1, D)
         else:
             ops.gemm(a, WEIGHTS.get(spec.proj[0], dt), bias=spec.proj[1], resid=x2d, out32=x1)
             h1 = _as_act(h1, M, D, dt, 0)                                              # row-major: the LayerNorm kernel writes it
@@ -614,7 +655,6 @@ def post_ln_layer(res, x_t, L, B, heads, P, keylen, eps=1e-12, cu_seqlens=None, 
         w1, c1, b1 = WEIGHTS.get_lnfold(P["intermediate.dense.weight"], P["intermediate.dense.bias"], lw_a, lb_a, dt)
         ops.gemm(s_a_t, w1, bias=b1, act="gelu", out_t=f, lnfold=(fold_sums[0], c1, D, eps))
         del s_a_t
-        _fold_guard(fold_sums[0], D)
     else:
         ops.gemm(a, WEIGHTS.get(P["attention.output.dense.weight"], dt), bias=P["attention.output.dense.bias"], out32=s_a,
                  **(dict(resid_t=x_t) if t_resid else res.gemm_kw()))

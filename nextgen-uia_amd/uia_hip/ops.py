@@ -96,6 +96,21 @@ def rowsum_to_float(q):
     return (q.double() / ROWSUM_SCALE).float()
 
 
+# Guard word of the folded LayerNorms (uia_gemm_desc.ln_flag): one zeroed int32 per device, handed to EVERY launch that writes or reads
+# row sums, so every folded layer of every step is checked (on the device, at the cost of a compare per row) — not just the first few
+# buffers of a warm-up step.  uia_hip.functional.poll_ln_flag() reads it back.
+LN_FLAG_LIMIT = 8.0
+_LN_FLAG = {}
+
+
+def ln_flag(device):
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    t = _LN_FLAG.get(key)
+    if t is None:
+        t = _LN_FLAG[key] = torch.zeros(1, device=device, dtype=torch.int32)
+    return t
+
+
 KBLOCK_ACT = True        # GEMM -> GEMM activations travel K-blocked ([K/g][rows][g]) between ring-kernel launches (kb_empty / is_kb)
 
 
@@ -333,6 +348,8 @@ def _gemm_one(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None
         if not (sm.dtype == torch.int64 and cs.dtype == torch.float32 and sm.is_contiguous() and cs.is_contiguous() and sm.numel() >= 2 * d.M and cs.numel() >= d.N) or alpha != 1.0:
             raise UiaError(f"gemm lnfold: sums {tuple(sm.shape)} {sm.dtype} / colsum {tuple(cs.shape)} do not cover [{d.M}, {d.N}] (int64 row sums, fp32 colsum, contiguous, alpha == 1)")
         d.lnfold_sums, d.lnfold_colsum, d.lnfold_dim, d.lnfold_eps = _p(sm), _p(cs), int(dim), float(eps)
+    if (rowsum is not None or lnfold is not None) and a.is_cuda:
+        d.ln_flag, d.ln_flag_limit = _p(ln_flag(a.device)), LN_FLAG_LIMIT
     if resid_t is not None:
         d.residT, d.ldrT = _p(resid_t), _rowmajor(resid_t, "resid_t")
     if is_kb(out_t):

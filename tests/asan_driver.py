@@ -68,6 +68,10 @@ a = mod.AttnDesc()
 expect_fail(lib.uia_attn_fwd(None, 1, None), "null descriptor")
 expect_fail(lib.uia_attn_fwd(None, 1, C.byref(a)), "empty problem")
 a.B, a.H, a.L, a.dh = 2, 2, 400, 64
+expect_fail(lib.uia_attn_fwd(None, 1, C.byref(a)), "scale must be positive")          # scale = 0 in a zeroed descriptor
+a.scale = -0.125
+expect_fail(lib.uia_attn_bwd(None, 1, C.byref(a)), "scale must be positive")
+a.scale = 0.125
 expect_fail(lib.uia_attn_fwd(None, 1, C.byref(a)), "L=400")
 a.L = 64
 expect_fail(lib.uia_attn_fwd(None, 1, C.byref(a)), "null tensor")

@@ -42,17 +42,17 @@ def test_descriptor_struct_sizes_match_c_layout():
     import subprocess
     import tempfile
     from uia_hip import _lib
-    assert ctypes.sizeof(_lib.GemmDesc) == 264
+    assert ctypes.sizeof(_lib.GemmDesc) == 280
     assert ctypes.sizeof(_lib.AttnDesc) == 160
     assert ctypes.sizeof(_lib.MonaSpatialDesc) % 8 == 0 and ctypes.sizeof(_lib.MonaSpatialDesc) == 296
     # ... and the same numbers from the C compiler itself (sizes and the offset of the last field of the GEMM descriptor)
     with tempfile.TemporaryDirectory() as td:
         src, exe = os.path.join(td, "s.c"), os.path.join(td, "s")
         open(src, "w").write('#include <stdio.h>\n#include <stddef.h>\n#include "uia_hip.h"\nint main(void){ printf("%zu %zu %zu %zu\\n", sizeof(uia_gemm_desc), '
-                             'sizeof(uia_attn_desc), sizeof(uia_mona_spatial_desc), offsetof(uia_gemm_desc, outT_kb_rows)); return 0; }\n')
+                             'sizeof(uia_attn_desc), sizeof(uia_mona_spatial_desc), offsetof(uia_gemm_desc, ln_flag_limit)); return 0; }\n')
         subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), "-o", exe, src], check=True)
         got = [int(v) for v in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()]
-    assert got == [ctypes.sizeof(_lib.GemmDesc), ctypes.sizeof(_lib.AttnDesc), ctypes.sizeof(_lib.MonaSpatialDesc), _lib.GemmDesc.outT_kb_rows.offset]
+    assert got == [ctypes.sizeof(_lib.GemmDesc), ctypes.sizeof(_lib.AttnDesc), ctypes.sizeof(_lib.MonaSpatialDesc), _lib.GemmDesc.ln_flag_limit.offset]
 
 
 def test_error_path_without_gpu():

@@ -390,26 +390,59 @@ def test_large_batch_step_on_the_ring_kernels_fold_and_kblocked_vs_plain():
 
 
 def test_fold_guard_switches_the_fold_off_for_uncentred_rows():
-    """host-side guard of the warm-up steps: a row-sum buffer holding a row with |mean| > 8 std turns the fold off (with a warning)"""
+    """device-side guard (uia_gemm_desc.ln_flag): EVERY consumer launch of a folded LayerNorm checks its rows; a row with |mean| > 8 std sets
+    bit 0, and the host poll turns the fold off with a warning.  Centred rows leave the word clear."""
     from uia_hip import functional as UF
-    D = 128
-    x = torch.randn(64, D, device=dev())
     from uia_hip import ops
-    ok = ops.rowsum_from_float(torch.stack([x.sum(1), (x * x).sum(1)], 1))
-    x[7] += 40.0
-    bad = ops.rowsum_from_float(torch.stack([x.sum(1), (x * x).sum(1)], 1))
-    saved = dict(UF._FOLD_GUARD)
+    M, D, N = 4096, 768, 768
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = torch.randn(M, D, generator=g).to(dev())
+    w = ops.PackedW((torch.randn(N, D, generator=g) * 0.03).to(dev()).to(torch.bfloat16))
+    cs = w.row.float().sum(1).contiguous()
+    out = torch.empty(M, N, device=dev(), dtype=torch.bfloat16)
+
+    def consume(rows):
+        sums = ops.rowsum_from_float(torch.stack([rows.sum(1), (rows * rows).sum(1)], 1))
+        ops.gemm(rows.to(torch.bfloat16), w, out_t=out, lnfold=(sums, cs, D, 1e-5), bias=torch.zeros(N, device=dev()))
+
     try:
-        UF._FOLD_GUARD["left"] = 2
         UF.set_ln_fold(True)
-        UF._fold_guard(ok, D)
-        assert UF.ln_fold_enabled(torch.bfloat16)
+        UF.reset_ln_flag()
+        consume(x)
+        assert UF.poll_ln_flag(sync=True) == 0 and UF.ln_fold_enabled(torch.bfloat16)
+        x[3001] += 40.0                                        # one row deep inside the launch, far from the first tiles
+        consume(x)
         with pytest.warns(UserWarning, match="LayerNorm fold switched off"):
-            UF._fold_guard(bad, D)
-        assert not UF.ln_fold_enabled(torch.bfloat16) and UF._FOLD_GUARD["left"] == 0
-        UF.set_ln_fold(True)
-        UF._fold_guard(bad, D)                     # budget spent: no more host syncs, no more checks
-        assert UF.ln_fold_enabled(torch.bfloat16)
+            assert UF.poll_ln_flag(sync=True) & 1
+        assert not UF.ln_fold_enabled(torch.bfloat16)
     finally:
-        UF._FOLD_GUARD.update(saved)
+        UF.reset_ln_flag()
         UF.set_ln_fold(True)
+
+
+def test_rowsum_out_of_range_is_flagged_not_wrapped():
+    """A producer whose rows leave the fixed-point range (or are not finite) clamps its partial sums — no integer wrap, no undefined
+    llrintf — and sets bit 1 of the guard word: the host raises instead of training on a finite but wrong LayerNorm statistic."""
+    from uia_hip import functional as UF
+    from uia_hip import ops
+    M, K, N = 4096, 64, 768
+    a = torch.randn(M, K, device=dev()).to(torch.bfloat16)
+    w = ops.PackedW((torch.randn(N, K, device=dev()) * 0.1).to(torch.bfloat16))
+    resid = torch.randn(M, N, device=dev())
+    resid[2500, 17] = 3.0e5                                    # Σ² of that wave column = 9e10 > 5e8
+    resid[100, 5] = float("inf")
+    out32, out_t = torch.empty(M, N, device=dev()), torch.empty(M, N, device=dev(), dtype=torch.bfloat16)
+    sums = torch.zeros(M, 2, device=dev(), dtype=torch.int64)
+    try:
+        UF.reset_ln_flag()
+        ops.gemm(a, w, bias=torch.zeros(N, device=dev()), resid=resid, out32=out32, out_t=out_t, rowsum=sums)
+        with pytest.raises(UF.LnFoldRangeError):
+            UF.poll_ln_flag(sync=True)
+        s = ops.rowsum_to_float(sums)
+        assert torch.isfinite(s).all() and float(s[2500, 1]) <= 12 * 5.0e8 * 1.001 and float(s[2500, 1]) >= 5.0e8 * 0.999
+        ok = torch.ones(M, dtype=torch.bool, device=dev())
+        ok[2500] = ok[100] = False
+        want = torch.stack([out32.sum(1), (out32 * out32).sum(1)], 1)
+        assert torch.allclose(s[ok], want[ok], rtol=2e-4, atol=1e-2)
+    finally:
+        UF.reset_ln_flag()

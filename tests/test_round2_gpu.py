@@ -115,6 +115,42 @@ def test_engine_step_through_rccl_vs_oracle():
         ops.comm_destroy()
 
 
+def test_global_batch_gather_through_rccl_allgather_world1():
+    """§8 f4: GatherFeaturesFn routed through uia_allgather on a one-rank RCCL communicator (init_data_parallel(force_comm=True)) — the
+    collective the multi-GPU job uses, not the world-1 copy: the gathered rows equal the input bit for bit, the backward returns the
+    local slice, and a global-loss step through it equals the local-loss step (one rank: same batch)."""
+    from uia_hip import functional as UF
+    from uia_hip import ops
+    from uia_hip.engine import FlatAdapterOptimizer, GatherFeaturesFn, contrastive_step, init_data_parallel
+    from src.losses import InfoNCELoss
+    UF.set_compute_dtype(torch.float32)
+    calls = []
+    real = ops.allgather
+    try:
+        init_data_parallel(None, force_comm=True)
+        assert ops.comm_world_initialised() and ops.comm_world() == 1
+        ops.allgather = lambda a, b: (calls.append(a.numel()), real(a, b))[1]
+        x = torch.randn(6, 32, device=dev(), requires_grad=True)
+        y = GatherFeaturesFn.apply(x, 0, 1)
+        assert calls == [6 * 32] and torch.equal(y.detach(), x.detach())
+        (y * torch.arange(6, device=dev())[:, None]).sum().backward()
+        assert torch.equal(x.grad, torch.arange(6, device=dev(), dtype=torch.float32)[:, None].expand(6, 32))
+        outs = []
+        for flag in (False, True):
+            model = _toy_model("baseline", seed=11).to(dev())
+            opt = FlatAdapterOptimizer([(k, p) for k, p in model.named_parameters() if p.requires_grad], lr=1e-3)
+            init_data_parallel(opt, force_comm=True)
+            images, ids = _toy_batch(4)
+            n0 = len(calls)
+            loss = contrastive_step(model, InfoNCELoss(0.07), opt, images.to(dev()), ids.to(dev()), overlap_text=False, global_loss=flag)
+            assert len(calls) - n0 == (2 if flag else 0)               # image and text features each went through the collective
+            outs.append(float(loss))
+        assert abs(outs[0] - outs[1]) < 1e-6 * abs(outs[0])
+    finally:
+        ops.allgather = real
+        ops.comm_destroy()
+
+
 def test_mona_gradients_do_not_depend_on_the_flat_optimiser_idiom():
     """ADVICE r01 (functional.py:220): `out = model(x); optimizer.zero_grad(set_to_none=True); loss.backward()` used to orphan the
     gradient buffers captured at forward time.  The .grad views are now looked up at BACKWARD time and the direct path is an

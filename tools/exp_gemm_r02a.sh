@@ -1,5 +1,7 @@
 #!/bin/bash
 # round-2 experiment A: tile-order group size and K-blocked (diagnostic) operand addressing on the ring GEMM
+# the diagnostic binaries are not tracked: build them here (hipcc is on the GPU box too)
+make -C $GRAFT_REPO_ROOT/nextgen-uia_amd/csrc tests/test_gemm_exp tests/test_gemm_dma tests/test_gemm_stamps > /dev/null || exit 1
 cd $GRAFT_REPO_ROOT/nextgen-uia_amd/csrc/tests
 OUT=$GRAFT_REPO_ROOT/gpurun_out/exp_r02a
 mkdir -p $OUT

@@ -10,7 +10,7 @@ for G in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_I
          "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC" \
          "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_VMEM SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  rocprofv3 --pmc $G --kernel-trace --output-format csv -d $OUT/g$i -o pmc -- python3 tools/time_attention.py > $OUT/g$i.log 2>&1 || { tail -5 $OUT/g$i.log; exit 1; }
+  rocprofv3 --pmc $G --output-format csv -d $OUT/g$i -o pmc -- python3 tools/time_attention.py > $OUT/g$i.log 2>&1 || { tail -5 $OUT/g$i.log; exit 1; }
 done
 python3 - <<'PY'
 import csv, glob, os, collections
