@@ -46,9 +46,11 @@ def parse():
                     "off by default so that the per-launch HIP-event durations behind `roofline` are not inflated by the other stream's kernels "
                     "and agree with the rocprofv3 summary of the same command")
     ap.add_argument("--no-overlap-text", action="store_true", help=argparse.SUPPRESS)        # former spelling of the default
+    ap.add_argument("--streams", type=int, default=1, help="cut each rank's batch into this many slices whose towers run on as many HIP streams (same batch, "
+                    "same single InfoNCE over all pairs, same gradients: engine.contrastive_step(streams=...))")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-steps", type=int, default=3)
-    ap.add_argument("--no-cpu-wide", action="store_true", help="skip the second CPU sample (all logical CPUs, micro-batch 32)")
+    ap.add_argument("--no-cpu-wide", action="store_true", help="skip the second CPU sample (micro-batch 32)")
     ap.add_argument("--no-ln-fold", action="store_true", help="A/B: run the stand-alone LayerNorm kernels instead of folding each frozen LayerNorm into the "
                     "GEMMs on either side of it (UF.set_ln_fold)")
     ap.add_argument("--no-deferred-text-ln", action="store_true", help="scheduling A/B (same results): every text-tower LayerNorm also writes its fp32 output "
@@ -122,14 +124,40 @@ def _cpu_sample(fn, batch, steps, threads, what, budget=30.0):
             "s_per_step": round(dt, 3)}
 
 
+def _cpu_share():
+    """CPUs this process may actually use: the scheduler affinity mask, cut by the cgroup quota (a GPU box hands a 1-GPU job a 16-CPU
+    share of its 256 logical CPUs: 256 threads on that share ran one micro-batch-32 step in 298 s — profiles/r03_a_bench_default.json)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    n = min(n, max(1, int(q / int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read()) + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_baseline(state, variant, batch, steps, wide=True):
-    """The oracle (CPU restatement of the reference path) timed on this host's cores: the reported CPU baseline.  Two bounded samples:
-    micro-batch 8 on at most 16 threads (more threads only add contention at that size), and — BASELINE.md §3 asks for os.cpu_count() —
-    micro-batch 32 on every logical CPU, reported under "all_cores"."""
+    """The oracle (CPU restatement of the reference path) timed on this host's cores: the reported CPU baseline.  Threads = the CPUs this
+    process is ALLOWED to use (affinity mask and cgroup quota, capped at 32: beyond that micro-batch 8 only adds contention) — BASELINE.md §3
+    says os.cpu_count(), which on the GPU boxes counts 256 logical CPUs of which a 1-GPU job may use 16.  wide: a second bounded sample at
+    micro-batch 32 on the same threads, reported under "micro_batch_32"."""
     import torch
     from oracle import train_ref
     names = [k for k in state if "mona" in k]
     mona = dict(variant=variant, hw=(14, 14))
+    threads = max(1, min(32, _cpu_share()))
 
     def make(bs):
         g = torch.Generator().manual_seed(1)
@@ -141,9 +169,10 @@ def cpu_baseline(state, variant, batch, steps, wide=True):
             ids[b, 0], ids[b, n - 1] = 2, 3
         return lambda: train_ref.grads_of(lambda Pq, im, tk: train_ref.biomedclip_loss(Pq, im, tk, mona=mona), state, names, [(images, ids)])
 
-    out = _cpu_sample(make(batch), batch, steps, min(16, os.cpu_count()), "oracle/train_ref.py")
-    if wide and (os.cpu_count() or 1) > 16:
-        out["all_cores"] = _cpu_sample(make(32), 32, 2, os.cpu_count(), "oracle/train_ref.py", budget=25.0)
+    out = _cpu_sample(make(batch), batch, steps, threads, "oracle/train_ref.py", budget=20.0)
+    out["cpu_share"] = _cpu_share()
+    if wide:
+        out["micro_batch_32"] = _cpu_sample(make(32), 32, 1, threads, "oracle/train_ref.py", budget=10.0)
     return out
 
 
@@ -212,13 +241,13 @@ def gemm_roofline(prof, prof_serial, args, ms_per_step, ops, torch):
             "avg_launch_us": round(tsec / n * 1e6, 2), "flop_per_launch_avg": round(flops / n),
             "share_of_step": round(tsec / (ms_per_step * 1e-3), 3),
             "note": ("HIP events around every launch of this kernel, on the launch stream, during one extra step of the same loop right after the timed region" +
-                     ("; --overlap-text: the text tower runs on a second stream, so a launch's duration includes time shared with "
-                      "that stream's kernels (see standalone)" if args.overlap_text else "")),
+                     ("; more than one HIP stream: a launch's duration includes time shared with the other stream's kernels "
+                      "(see standalone)" if (args.overlap_text or getattr(args, "streams", 1) > 1) else "")),
             "gemm_family": {"kernels": "gemm_tn_ring_kernel<...,EPI> (+ gemm_tn_persist_kernel when selected), all epilogue masks",
                             "launches_per_step": fn, "achieved": round(ff / ft * 1e-12, 1), "frac": round(ff / ft * 1e-12 / peak, 4),
                             "ms_per_step": round(ft * 1e3, 3)},
             "per_shape": shape_table(prof_serial)}
-    if args.overlap_text:
+    if args.overlap_text or getattr(args, "streams", 1) > 1:
         roof["standalone"] = {"achieved": round(fs / ts * 1e-12, 1), "frac": round(fs / ts * 1e-12 / peak, 4), "avg_launch_us": round(ts / ns * 1e6, 2),
                               "family_achieved": round(ffs / fts * 1e-12, 1), "how": "one extra untimed step with both towers on one stream"}
     return roof
@@ -232,24 +261,26 @@ def timed_loop(step, args, world, device, ops, torch):
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    multi = args.overlap_text or getattr(args, "streams", 1) > 1            # more than one stream: per-launch events also see the other stream's kernels
+    mode = True if args.overlap_text else None                               # step(False) = everything on one stream
     loss = None
     for _ in range(args.warmup):
-        loss = step(args.overlap_text)
+        loss = step(mode)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = step(args.overlap_text)
+        loss = step(mode)
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
     # per-launch HIP events (on the launch stream) around every uia_gemm of ONE more step of the same loop, outside the timed region:
     # the event records cost host time the throughput figure should not carry; the step itself is identical to the timed ones
     ops.GEMM_PROFILE = []
-    step(args.overlap_text)
+    step(mode)
     torch.cuda.synchronize()
     prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
     prof_serial = prof
-    if args.overlap_text:
+    if multi:
         # one extra, untimed step with the two towers serialised on one stream: the kernels' rates without the other stream beside them
         ops.GEMM_PROFILE = []
         step(False)
@@ -337,7 +368,8 @@ def bench_mona(args, rank, world, device):
     images, ids = synthetic_batch(args.batch, rank, device)
     UF.set_dropout_seed(1234 + rank)
 
-    step = lambda overlap: contrastive_step(model, criterion, opt, images, ids, overlap_text=overlap, global_loss=args.global_loss)
+    step = lambda overlap: contrastive_step(model, criterion, opt, images, ids, overlap_text=bool(overlap) and args.streams == 1, global_loss=args.global_loss,
+                                            streams=args.streams if overlap is not False else 1)
     elapsed, per_rank, final_loss, prof, prof_serial = timed_loop(step, args, world, device, ops, torch)
     if rank != 0:
         return None
@@ -364,6 +396,7 @@ def bench_mona(args, rank, world, device):
                       "mona_variant": args.variant, "batch_per_gpu": args.batch, "global_batch": args.batch * world, "image": "3x224x224",
                       "text_len": 256, "text_positions_computed": "valid tokens only (opt-in --unpad-text)" if args.unpad_text else "all 256",
                       "parallelism": f"dp{world}", "text_tower_stream": "second stream" if args.overlap_text else "same stream",
+                      "hip_streams": (f"{args.streams}: the batch's towers run as {args.streams} slices on {args.streams} HIP streams, one InfoNCE over all pairs" if args.streams > 1 else 1),
                       "contrastive_batch": "global (opt-in)" if args.global_loss else "per-rank (reference-equivalent)", "mona_dropout": 0.1,
                       "bert_dropout_emulated": False,
                       "layernorm": "stand-alone kernels" if args.no_ln_fold else "folded into the neighbouring GEMMs (row sums in the producer epilogue, normalised accumulators in the consumer)",
@@ -436,7 +469,7 @@ def bench_clipseg(args, rank, world, device):
             Pq = dict(cpu_state)
             Pq.update(leaves)
             losses_ref.dice_ce(clipseg_ref.adapter_forward(im, pr, Pq, vit_heads=12, text_heads=8, extract_layers=(3, 6, 9)), lab).backward()
-        out["cpu_baseline"] = _cpu_sample(fn, bs, 3, min(16, os.cpu_count()), "oracle/clipseg_ref.py", budget=20.0)
+        out["cpu_baseline"] = _cpu_sample(fn, bs, 3, max(1, min(32, _cpu_share())), "oracle/clipseg_ref.py", budget=20.0)
     return out
 
 
@@ -510,7 +543,7 @@ def bench_vitl_lora(args, rank, world, device):
             with torch.no_grad():
                 ft = text_ref.openai_text_forward(tk, Pq, heads=12)
             losses_ref.info_nce(fi, ft, 0.07).backward()
-        out["cpu_baseline"] = _cpu_sample(fn, bs, 2, min(16, os.cpu_count()), "oracle/vit_ref.py + text_ref.py (ViT-L/14 + LoRA r=16)", budget=25.0)
+        out["cpu_baseline"] = _cpu_sample(fn, bs, 2, max(1, min(32, _cpu_share())), "oracle/vit_ref.py + text_ref.py (ViT-L/14 + LoRA r=16)", budget=25.0)
     return out
 
 

@@ -343,6 +343,20 @@ __device__ __forceinline__ void gemm_epilogue_lds(const UiaGemmParams& p, f32x4 
     // global memory inside the row loop put one L2 round trip on the critical path of every pass of an epilogue that has no other
     // load (QKV: 224 -> 247 us per launch); staged, the pass reads them like its accumulators.
     const int mrow0 = m0 + wm * WTM;
+    // Deferred LayerNorm of the residual (EPI_RESID_LN): (mean, rstd) of the wave's rows staged the same way when the caller requested the
+    // statistics ahead of its K loop (lnpre): the row passes then read them from LDS instead of waiting on one more load each.
+    const bool rln_staged = f_rln && !f_lnfold && lnrow_lds != nullptr && lnpre != nullptr && !(GEN && (p.resid_mod > 0 || p.out_group > 0));
+    if (rln_staged) {
+#pragma unroll
+        for (int i = 0; i < (WTM + 63) / 64; ++i) {
+            const int r = lane + 64 * i;
+            if (r < WTM) {
+                float2 ms = lnpre[i];
+                if (p.resid_ln_dim > 0) { const LnRow ln = ln_row_from_sums(ms, p.resid_ln_dim, p.resid_ln_eps); ms = float2{ln.mean, ln.rstd}; }
+                *(float2*)(lnrow_lds + 2 * r) = ms;
+            }
+        }
+    }
     if (f_lnfold && lnrow_lds) {
 #pragma unroll
         for (int i = 0; i < (WTM + 63) / 64; ++i) {
@@ -357,8 +371,13 @@ __device__ __forceinline__ void gemm_epilogue_lds(const UiaGemmParams& p, f32x4 
         }
     }
 
-    // one row segment of 8 columns: bias / activation / residuals / stores
-    auto apply = [&](const f32x4& lo, const f32x4& hi, int m) {
+    // one row segment of 8 columns: bias / activation / residuals / stores.  pre_aux: the lane's eight aux_in values of this row, requested ahead
+    // by the caller (bf16 dact epilogues: the load is otherwise one HBM round trip per pass on an epilogue that has nothing else to wait for)
+    // pre_res / pre_rt: likewise the fp32 residual (two 16-byte halves) and the T residual.  os1 / os2: where the row sums of this pass go
+    // instead of straight into their atomics (the caller issues those after the tile's last store: an atomic stays in the in-order
+    // vmcnt queue for thousands of cycles under load, and every later load of the wave would wait behind it).
+    auto apply = [&](const f32x4& lo, const f32x4& hi, int m, const bf16x8* pre_aux = nullptr, const f32x4* pre_res = nullptr,
+                     const bf16x8* pre_rt = nullptr, float* os1 = nullptr, float* os2 = nullptr) {
         const bool ok = m < p.M && col_ok;
         if (!f_rowsum && !ok) return;
         float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -388,15 +407,26 @@ __device__ __forceinline__ void gemm_epilogue_lds(const UiaGemmParams& p, f32x4 
         if (act) apply_act8<sizeof(T) == 2>(v, act);
         if (dact && UIA_EPI_LOADS) {
             float a[8];
-            load8(aux_in + orow * p.ldaux_in + n, a);
+            if (pre_aux) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a[e] = (float)(*pre_aux)[e];
+            } else {
+                load8(aux_in + orow * p.ldaux_in + n, a);
+            }
             apply_dact8<sizeof(T) == 2>(v, a, dact);
         }
         if (f_resid && UIA_EPI_LOADS) {
             float r[8];
-            load8(p.resid + rrow * p.ldr + n, r);
+            if (pre_res) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { r[e] = pre_res[0][e]; r[4 + e] = pre_res[1][e]; }
+            } else {
+                load8(p.resid + rrow * p.ldr + n, r);
+            }
             if (f_rln) {                                  // same expression, same operands as ln_fwd_kernel: bit-identical to reading its fp32 output
                 float2 ms;
-                if (p.resid_ln_dim > 0) { const LnRow ln = ln_row_from_sums(rowsum_load(p.resid_ln_stats, rrow), p.resid_ln_dim, p.resid_ln_eps); ms = float2{ln.mean, ln.rstd}; }
+                if (rln_staged) ms = *(const float2*)(lnrow_lds + 2 * (m - mrow0));
+                else if (p.resid_ln_dim > 0) { const LnRow ln = ln_row_from_sums(rowsum_load(p.resid_ln_stats, rrow), p.resid_ln_dim, p.resid_ln_eps); ms = float2{ln.mean, ln.rstd}; }
                 else ms = *(const float2*)((const float*)p.resid_ln_stats + 2 * rrow);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) r[e] = fmaf((r[e] - ms.x) * ms.y, lnw[e], lnb[e]);
@@ -406,7 +436,12 @@ __device__ __forceinline__ void gemm_epilogue_lds(const UiaGemmParams& p, f32x4 
         }
         if (f_residT && UIA_EPI_LOADS) {
             float r[8];
-            load8(residT + orow * p.ldrT + n, r);
+            if (pre_rt) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) r[e] = (float)(*pre_rt)[e];
+            } else {
+                load8(residT + orow * p.ldrT + n, r);
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += r[e];
         }
@@ -428,7 +463,8 @@ __device__ __forceinline__ void gemm_epilogue_lds(const UiaGemmParams& p, f32x4 
             }
             s1 = row_lanes_sum<LPR>(s1);
             s2 = row_lanes_sum<LPR>(s2);
-            if ((lane % LPR) == 0 && m < p.M) rowsum_add(p.rowsum_out, orow, s1, s2, p.ln_flag);
+            if (os1) { *os1 = s1; *os2 = s2; }
+            else if ((lane % LPR) == 0 && m < p.M) rowsum_add(p.rowsum_out, orow, s1, s2, p.ln_flag);
         }
     };
 
@@ -457,6 +493,71 @@ __device__ __forceinline__ void gemm_epilogue_lds(const UiaGemmParams& p, f32x4 
         }
     } else {
         float* stg = (float*)(smem + wave * EP::BYTES_PER_WAVE);
+        // PIPELINED row passes (bf16, compile-time masks with an operand to read or row sums to leave).  The epilogue's loads, stores and
+        // atomics share the wave's in-order vmcnt queue: a pass that loads its aux_in / residual rows in line waits for the PREVIOUS pass's
+        // stores (and atomics) to be acknowledged first — one HBM round trip per pass, 16 per tile (in-kernel stamps, round 3: the GELU'
+        // epilogue of the fc2 data gradient took 36 K cycles, 5.8 K of them arithmetic; the fold producer's 71 K).  Here the operand rows are
+        // requested a CHUNK (half a 64-row phase) at a time into two register sets, two chunks ahead of their use, and the row-sum atomics are
+        // issued after the tile's last store.  Same arithmetic in the same order: results are bit-identical to the in-line form.
+#ifdef UIA_NO_PREAUX
+        constexpr bool PIPE = false;                       // A/B build (tests/test_gemm_stamps_nopre)
+#else
+        constexpr bool PIPE = !GEN && sizeof(T) == 2 && (EPI & (EPI_DGELU | EPI_RESID | EPI_RESIDT | EPI_ROWSUM)) != 0;
+#endif
+        constexpr int NPASS = ROWS / RPP, NPH = MT / GPP;
+        if constexpr (PIPE && NPASS % 2 == 0) {
+            constexpr bool H_AUX = (EPI & EPI_DGELU) != 0, H_RES = (EPI & EPI_RESID) != 0, H_RT = (EPI & EPI_RESIDT) != 0, H_SUM = (EPI & EPI_ROWSUM) != 0;
+            constexpr int CH = NPASS / 2, NCH = 2 * NPH;                 // passes per chunk, chunks per tile
+            bf16x8 pa[2][H_AUX ? CH : 1];
+            f32x4 pr[2][H_RES ? 2 * CH : 1];
+            bf16x8 prt[2][H_RT ? CH : 1];
+            float rs1[H_SUM ? NCH * CH : 1], rs2[H_SUM ? NCH * CH : 1];
+            const int mrow = m0 + wm * WTM + rr;
+            const int nc = col_ok ? n : 0;
+            auto issue = [&](int c, int set) {                          // chunk c = passes [c·CH, (c+1)·CH) of the wave's WTM / RPP row passes
+                if (!UIA_EPI_LOADS) return;
+#pragma unroll
+                for (int q = 0; q < CH; ++q) {
+                    const int m = mrow + (c * CH + q) * RPP;
+                    const size_t mc = (size_t)(m < p.M ? m : p.M - 1);
+                    if constexpr (H_AUX) pa[set][q] = *(const bf16x8*)((const bf16_t*)p.aux_in + mc * p.ldaux_in + nc);
+                    if constexpr (H_RES) { const float* src = p.resid + mc * p.ldr + nc; pr[set][2 * q] = *(const f32x4*)src; pr[set][2 * q + 1] = *(const f32x4*)(src + 4); }
+                    if constexpr (H_RT) prt[set][q] = *(const bf16x8*)((const bf16_t*)p.residT + mc * p.ldrT + nc);
+                }
+            };
+            issue(0, 0);
+            issue(1, 1);
+#pragma clang loop unroll(full)
+            for (int c = 0; c < NCH; ++c) {
+                const int ph = c / 2, set = c & 1;
+                if ((c & 1) == 0) {
+#pragma clang loop unroll(full)
+                    for (int gi = 0; gi < GPP; ++gi)
+#pragma clang loop unroll(full)
+                        for (int j = 0; j < NT; ++j) *(f32x4*)(stg + (gi * 16 + li) * LDW + g * (4 * NT) + 4 * j) = acc[ph * GPP + gi][j];
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_wave_barrier();
+                }
+#pragma unroll
+                for (int q = 0; q < CH; ++q) {
+                    const int row = ((c & 1) * CH + q) * RPP + rr;
+                    const f32x4 lo = *(const f32x4*)(stg + row * LDW + rc), hi = *(const f32x4*)(stg + row * LDW + rc + 4);
+                    apply(lo, hi, mrow + (c * CH + q) * RPP, H_AUX ? &pa[set][q] : nullptr, H_RES ? &pr[set][2 * q] : nullptr, H_RT ? &prt[set][q] : nullptr,
+                          H_SUM ? &rs1[c * CH + q] : nullptr, H_SUM ? &rs2[c * CH + q] : nullptr);
+                }
+                if (c + 2 < NCH) issue(c + 2, set);
+                if ((c & 1) == 1) __builtin_amdgcn_wave_barrier();
+            }
+            if constexpr (H_SUM) {
+                if ((lane % LPR) == 0) {
+#pragma unroll
+                    for (int k = 0; k < NCH * CH; ++k) {
+                        const int m = mrow + k * RPP;
+                        if (m < p.M) rowsum_add(p.rowsum_out, (size_t)m, rs1[k], rs2[k], p.ln_flag);
+                    }
+                }
+            }
+        } else {
 #pragma clang loop unroll(full)
         for (int ph = 0; ph < MT / GPP; ++ph) {
 #pragma clang loop unroll(full)
@@ -473,6 +574,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const UiaGemmParams& p, f32x4 
                 apply(lo, hi, mbase + q * RPP);
             }
             __builtin_amdgcn_wave_barrier();
+        }
         }
     }
 }
@@ -789,7 +891,8 @@ int launch_pp(hipStream_t stream, const UiaGemmParams& p) {
 // 64-byte rows use the 4-entry swizzle table {0,3,2,1} indexed by (row>>2)&3 (A) / the 16-row block of the
 // permuted W rows: conflict-free ds_read_b128 for both fragment patterns.
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int NBUF, int EPI, int LOOP = 0>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_tn_ring_kernel(const UiaGemmParams p, const int xflags) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_tn_ring_kernel(const UiaGemmParams p, const int xflags) {   // 2 waves per SIMD: one 8-wave
+                                                                                                                            // workgroup, or two 4-wave ones, per CU
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
@@ -850,7 +953,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_tn_ring_kernel(co
     const int m0 = tm * BM, n0 = tn * BN;
     // Folded LayerNorm (EPI_LNFOLD): the (Σ, Σ²) of the wave's rows are requested here, ahead of the K loop, and turned into
     // (rstd, -mean·rstd) in the epilogue: the request is older than every LDS-DMA piece, so the counted waits of the ring are unchanged.
-    constexpr bool LNROW = EPI == EPI_GENERIC || (EPI & EPI_LNFOLD) != 0;      // launch_ring_epi adds the strips to the LDS size for these
+    constexpr bool LNROW = EPI == EPI_GENERIC || (EPI & (EPI_LNFOLD | EPI_RESID_LN)) != 0;      // launch_ring_epi adds the strips to the LDS size for these
     constexpr int LNR = (BM / WAVES_M + 63) / 64;
     float2 lnpre[LNR];
 #pragma unroll
@@ -861,7 +964,20 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_tn_ring_kernel(co
             const int r = (tid & 63) + 64 * i, m = m0 + (__builtin_amdgcn_readfirstlane(tid >> 6) / WAVES_N) * (BM / WAVES_M) + r;
             if (r < BM / WAVES_M && m < p.M) lnpre[i] = rowsum_load(p.lnfold_sums, (size_t)m);
         }
+    } else if (LNROW && p.resid_ln_stats && p.resid_mod == 0 && p.out_group == 0) {
+        // deferred LayerNorm of the residual (EPI_RESID_LN): the rows' statistics — (Σ, Σ²) a producing GEMM left, or (mean, rstd) —
+        // requested here like the fold's, so that the row passes of the epilogue do not wait on one more load each
+#pragma unroll
+        for (int i = 0; i < LNR; ++i) {
+            const int r = (tid & 63) + 64 * i, m = m0 + (__builtin_amdgcn_readfirstlane(tid >> 6) / WAVES_N) * (BM / WAVES_M) + r;
+            if (r < BM / WAVES_M && m < p.M)
+                lnpre[i] = p.resid_ln_dim > 0 ? rowsum_load(p.resid_ln_stats, (size_t)m) : *(const float2*)((const float*)p.resid_ln_stats + 2 * (size_t)m);
+        }
     }
+    // (Round 3, negative: "touching" the epilogue's residual / aux_in tile ahead of the K loop — one dword per 128-byte line, so that the
+    // lines travel HBM -> Infinity Cache while the chip is in its K loops — made every fp32-residual launch 6-14 % SLOWER: vmcnt retires in
+    // order, so the ring's first counted wait absorbed the 64 MB burst of 256 CUs touching at once (prologue 3 K -> 10-20 K cycles), and the
+    // lockstep epilogue it was meant to relieve got only 4-15 % shorter: that phase is bound by its stores.)
     // W may arrive K-BLOCKED ([K·ESZ/64][N][64 bytes], packed once per weight by the host): a sub-tile of a column panel is then
     // one contiguous 16 KiB run, each 1 KiB LDS-DMA piece reads 8 whole 128-byte lines instead of 16 half lines, and the DMA-only
     // K step drops from 3150 to 2880 cycles (N = 2304) / 2350 to 1980 (N = 768): +2…9 % on the whole kernel (profiles/r02_a).
@@ -1086,7 +1202,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_tn_ring_kernel(co
 
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int NBUF, int EPI, int LOOP = 0>
 int launch_ring_epi(hipStream_t stream, const UiaGemmParams& p, int xflags) {
-    constexpr bool LNROW = EPI == EPI_GENERIC || (EPI & EPI_LNFOLD) != 0;      // + one (rstd, -mean·rstd) pair per tile row per column of waves
+    constexpr bool LNROW = EPI == EPI_GENERIC || (EPI & (EPI_LNFOLD | EPI_RESID_LN)) != 0;      // + one (rstd, -mean·rstd) / (mean, rstd) pair per tile row per column of waves
     constexpr int EPB = WAVES_M * WAVES_N * EpiPatch<BM / WAVES_M / 16, BN / WAVES_N>::BYTES_PER_WAVE + (LNROW ? WAVES_N * BM * 8 : 0);
     constexpr int LDS = NBUF * (BM + BN) * BKB > EPB ? NBUF * (BM + BN) * BKB : EPB;
     static_assert(LDS <= 160 * 1024, "LDS budget");
@@ -1428,8 +1544,8 @@ int launch_typed(hipStream_t stream, const UiaGemmParams& p, int cfg_in) {
                                  // (cfg 12, the persistent variant, is +2-3.5 % on store-only epilogues in isolation, -15-25 % on the
                                  //  fp32-residual ones, and a net loss inside the two-stream training step: opt-in only.)
     }
-    const bool ring = cfg == 8 || cfg == 9 || cfg == 10 || cfg == 12 || cfg == 13 || cfg == 14 || cfg == 15;
-    if ((p.a_kb_rows || p.outT_kb_rows) && !(cfg == 8 || cfg == 10 || cfg == 12 || cfg == 13 || cfg == 14 || cfg == 15)) {
+    const bool ring = cfg == 8 || cfg == 9 || cfg == 10 || cfg == 12 || cfg == 13 || cfg == 14 || cfg == 15 || cfg == 17 || cfg == 18;
+    if ((p.a_kb_rows || p.outT_kb_rows) && !(cfg == 8 || cfg == 10 || cfg == 12 || cfg == 13 || cfg == 14 || cfg == 15 || cfg == 17 || cfg == 18)) {
         uia_set_error("uia_gemm: K-blocked activations (a_kb_rows / outT_kb_rows) need a ring tile config with 64-byte sub-tiles (8, 10, 13, 14), not %d", cfg);
         return -1;
     }
@@ -1463,6 +1579,11 @@ int launch_typed(hipStream_t stream, const UiaGemmParams& p, int cfg_in) {
 #ifdef UIA_GEMM_EXP
         case 15: return launch_ring<T, 256, 256, 2, 4, 64, 4, 1>(stream, p, true, xflags);  // free-running loop (two fragment sets, one barrier per sub-tile):
                                                                                             // 5-10 % SLOWER than the ping-pong loop on every shape; experiment builds only
+#endif
+#ifdef UIA_GEMM_EXP
+        // experiment (round 3): FOUR-wave workgroups, two per CU, so that one workgroup's epilogue runs beside the other's K loop
+        case 17: return launch_ring<T, 256, 128, 2, 2, 64, 3>(stream, p, true, xflags);   // 256 x 128 tiles (A panel re-read by the column neighbour)
+        case 18: return launch_ring<T, 128, 256, 1, 4, 64, 3>(stream, p, true, xflags);   // 128 x 256 tiles
 #endif
         case 14: return launch_ring<T, 128, 256, 2, 4, 64, 3>(stream, p, true, xflags);   // 3-deep ring: 72 KB of LDS, two workgroups per CU
         case 13: return launch_ring<T, 128, 256, 2, 4, 64, 4>(stream, p, true, xflags);   // half-height tiles: the M tail of a launch whose last round

@@ -990,7 +990,7 @@ __global__ __launch_bounds__(512) void mona_spatial_fast_kernel(const uia_mona_s
     }
 }
 
-// g[param][i] += Σ_b ws[b][off + i]   (fixed summation order: deterministic, no atomics)
+// g[param][i] += Σ_b ws[b][off + i]   (fixed summation order inside a launch; the final add into the gradient buffer is atomic)
 // 64 columns per block × 16 image phases: every phase walks its images with 4 independent loads in flight (16 loads per thread at
 // B = 256; the four-phase version had 64 dependent-issue loads per thread and took 17 us for 11 MB).
 constexpr int WSR_PH = 16;
@@ -1031,7 +1031,7 @@ __global__ __launch_bounds__(64 * WSR_PH) void mona_ws_reduce_kernel(int B, cons
     else if (col < WS_NE3W) { dst = p.g_ne1_b; idx = col - WS_NE1B; }
     else if (col < WS_NE3B) { dst = p.g_ne3_w; idx = col - WS_NE3W; if (idx >= 48) return; }
     else { dst = p.g_ne3_b; idx = col - WS_NE3B; if (idx >= 3) return; }
-    dst[idx] += s;
+    atomicAdd(dst + idx, s);          // one add per element and launch; atomic because two micro-batch streams may reduce into the same gradient buffer
 }
 
 size_t spatial_lds(int hw, bool bwd) {

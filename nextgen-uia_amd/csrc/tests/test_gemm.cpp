@@ -102,6 +102,10 @@ static void bench(int dtype, int M, int N, int K, int cfg, int mode) {
     if (mode == 0) { p.outT = dO; p.ldo = N; p.bias = dBias; }
     if (mode == 1) { p.outT = dO; p.ldo = N; p.bias = dBias; p.act = UIA_ACT_GELU; p.aux_out = dAux; p.ldaux_out = N; }
     if (mode == 2) { p.out32 = dRes; p.ldo32 = N; p.bias = dBias; p.resid = dRes; p.ldr = N; }
+    if (mode == 3) { p.outT = dO; p.ldo = N; p.dact = UIA_ACT_GELU; p.aux_in = dAux; p.ldaux_in = N; }                       // fc2 dgrad through GELU' (mask 136)
+    void* dSums = nullptr;
+    if (mode == 5) { HC(hipMalloc(&dSums, (size_t)M * 16)); HC(hipMemset(dSums, 0, (size_t)M * 16));                          // fold producer (mask 977)
+                     p.out32 = dRes; p.ldo32 = N; p.bias = dBias; p.resid = dRes; p.ldr = N; p.outT = dO; p.ldo = N; p.rowsum_out = (int64_t*)dSums; }
     hipEvent_t e0, e1; HC(hipEventCreate(&e0)); HC(hipEventCreate(&e1));
     for (int i = 0; i < 3; ++i) uia_gemm_launch(0, dtype, p, cfg);
     HC(hipDeviceSynchronize());
@@ -111,7 +115,7 @@ static void bench(int dtype, int M, int N, int K, int cfg, int mode) {
     HC(hipEventRecord(e1, 0)); HC(hipEventSynchronize(e1));
     float ms; HC(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
     printf("BENCH dtype=%s M=%d N=%d K=%d cfg=%d mode=%d  %.3f ms  %.1f TFLOP/s\n", dtype == UIA_BF16 ? "bf16" : "f32", M, N, K, cfg, mode, ms, 2.0 * M * N * K / ms * 1e-9);
-    hipFree(dA); hipFree(dW); hipFree(dO); hipFree(dAux); hipFree(dRes); hipFree(dBias);
+    hipFree(dA); hipFree(dW); hipFree(dO); hipFree(dAux); hipFree(dRes); hipFree(dBias); if (dSums) hipFree(dSums);
 }
 
 #ifdef UIA_GEMM_STAMPS
@@ -193,6 +197,18 @@ int main(int argc, char** argv) {
         }
         return 0;
     }
+    if (argc > 1 && !strcmp(argv[1], "twowg")) {    // ./test_gemm_exp twowg: one 8-wave 256x256 workgroup per CU (cfg 8) vs two co-resident workgroups (14: 8 waves 128x256; 17 / 18: 4 waves)
+        const int shapes[][4] = {{65536, 3072, 768, 1}, {65536, 3072, 768, 0}, {50432, 3072, 768, 1}, {65536, 2304, 768, 0}, {50432, 2304, 768, 0}, {65536, 768, 768, 2},
+                                 {65536, 768, 3072, 2}, {50432, 768, 3072, 0}, {50432, 768, 768, 0}};
+        for (auto& sh : shapes)
+            for (int kb : {0, 3})
+                for (int cfg : {8, 14, 17, 18})
+                    for (int gm : {0, 8, 255}) {
+                        if (cfg == 8 && gm != 0) continue;
+                        printf("kb=%d gm=%3d  ", kb, gm); bench(UIA_BF16, sh[0], sh[1], sh[2], cfg | (gm << 8) | (kb << 16), sh[3]);
+                    }
+        return 0;
+    }
     if (argc > 1 && !strcmp(argv[1], "dephase")) {  // ./test_gemm_exp dephase: cfg 8 (one workgroup per CU), every other first-round workgroup delayed by s x 4096 cycles
         const int shapes[][4] = {{65536, 768, 768, 2}, {50432, 768, 768, 2}, {65536, 768, 3072, 2}, {65536, 2304, 768, 0}, {65536, 3072, 768, 1}, {50432, 3072, 768, 1}};
         for (auto& sh : shapes) {
@@ -227,8 +243,13 @@ int main(int argc, char** argv) {
     const int dts[2] = {UIA_BF16, UIA_F32};
     for (int d = 0; d < 2; ++d) {
         const int dt = dts[d];
-        for (int cfg = 1; cfg <= 14; ++cfg) {
-            if (cfg == 11) continue;
+#ifdef UIA_GEMM_EXP
+        const int cfg_hi = 18;
+#else
+        const int cfg_hi = 14;
+#endif
+        for (int cfg = 1; cfg <= cfg_hi; ++cfg) {
+            if (cfg == 11 || cfg == 15 || cfg == 16) continue;
             const int N = (cfg == 4 || cfg == 5) ? 64 : 384;
             fails += check(dt, 300, N, 128, cfg, 0);          // ragged M, single N tile edge
             fails += check(dt, 197 * 3, N, 256, cfg, 1);

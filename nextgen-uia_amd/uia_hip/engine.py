@@ -238,7 +238,17 @@ def _side_stream(device):
     return _SIDE_STREAM[device]
 
 
-def contrastive_step(model, criterion, opt, images, ids, micro_batches=1, lr=None, overlap_text=True, global_loss=False):
+_MB_STREAMS = {}
+
+
+def _mb_streams(device, n):
+    key = (device.index if device.index is not None else torch.cuda.current_device(), n)
+    if key not in _MB_STREAMS:
+        _MB_STREAMS[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
+    return _MB_STREAMS[key]
+
+
+def contrastive_step(model, criterion, opt, images, ids, micro_batches=1, lr=None, overlap_text=True, global_loss=False, streams=1):
     """One optimiser update: encode → InfoNCE → backward (→ all-reduce) → clip+AdamW.  Returns the loss tensor (device).
 
     global_loss (opt-in, not the reference's semantics): the InfoNCE batch is the GLOBAL batch — features are all-gathered,
@@ -247,7 +257,14 @@ def contrastive_step(model, criterion, opt, images, ids, micro_batches=1, lr=Non
     reference's gradient accumulation).
 
     overlap_text: the frozen text tower does not depend on the image tower, so it runs on a second HIP stream beside
-    encode_image (same kernels, same results); the streams join before the loss."""
+    encode_image (same kernels, same results); the streams join before the loss.
+
+    streams = S > 1: the batch is cut into S slices whose towers (forward AND backward: autograd runs a node on the stream of its
+    forward) are enqueued on S HIP streams; the loss is still ONE InfoNCE over all B pairs, so features, loss and gradients are those
+    of the one-stream step (the weight gradients add up through the same float atomics).  Every kernel of the towers is per row, per
+    image or per (image, head): nothing but the loss couples the slices.  Why: a chain of dependent launches leaves the chip in
+    lockstep — every CU in its K loop, then every CU in its HBM-bound epilogue; two chains side by side fill each other's phases and
+    tails."""
     UF.clear_t_copies()
     opt.zero_grad()
     total = None
@@ -255,7 +272,21 @@ def contrastive_step(model, criterion, opt, images, ids, micro_batches=1, lr=Non
     cur = torch.cuda.current_stream()
     for i in range(micro_batches):
         im, tk = images[i * mb:(i + 1) * mb], ids[i * mb:(i + 1) * mb]
-        if overlap_text:
+        if streams > 1 and mb >= 2 * streams:
+            sts = _mb_streams(images.device, streams)
+            bounds = [mb * s // streams for s in range(streams + 1)]
+            fis, fts = [], []
+            for s, st in enumerate(sts):
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    fis.append(model.encode_image(im[bounds[s]:bounds[s + 1]]))
+                    fts.append(model.encode_text(tk[bounds[s]:bounds[s + 1]]))
+            for st, a, b in zip(sts, fis, fts):
+                cur.wait_stream(st)
+                a.record_stream(cur)
+                b.record_stream(cur)
+            fi, ft = torch.cat(fis, 0), torch.cat(fts, 0)
+        elif overlap_text:
             side = _side_stream(images.device)
             side.wait_stream(cur)
             with torch.cuda.stream(side):
@@ -271,6 +302,9 @@ def contrastive_step(model, criterion, opt, images, ids, micro_batches=1, lr=Non
             fi, ft = GatherFeaturesFn.apply(fi, rank, opt.world), GatherFeaturesFn.apply(ft, rank, opt.world)
         loss = criterion(fi, ft)
         (loss / micro_batches).backward()
+        if streams > 1 and mb >= 2 * streams:
+            for st in _mb_streams(images.device, streams):     # the adapters' weight gradients are side effects of the backward kernels (flat
+                cur.wait_stream(st)                            # buffer, direct mode): autograd's own end-of-backward sync does not know them
         total = loss.detach() if total is None else total + loss.detach()
     opt.all_reduce()
     opt.step(lr=lr, grad_scale=dp_grad_scale(opt.world, global_loss))

@@ -151,6 +151,30 @@ def test_global_batch_gather_through_rccl_allgather_world1():
         ops.comm_destroy()
 
 
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_contrastive_step_on_two_streams_equals_one_stream(mode):
+    """engine.contrastive_step(streams=2): the batch's towers run as two slices on two HIP streams (forward and backward), the loss is
+    still one InfoNCE over all pairs — same loss, same gradients (float atomics reorder the weight-gradient sums), same update."""
+    from uia_hip import functional as UF
+    from uia_hip.engine import FlatAdapterOptimizer, contrastive_step
+    from src.losses import InfoNCELoss
+    UF.set_compute_dtype(torch.float32 if mode == "fp32" else torch.bfloat16)
+    images, ids = _toy_batch(21, B=8)
+    outs = []
+    for streams in (1, 2):
+        model = _toy_model("hybrid", seed=13).to(dev())
+        opt = FlatAdapterOptimizer([(k, p) for k, p in model.named_parameters() if p.requires_grad], lr=1e-3)
+        UF.set_dropout_seed(7)
+        loss = contrastive_step(model, InfoNCELoss(0.07), opt, images.to(dev()), ids.to(dev()), overlap_text=False, streams=streams)
+        torch.cuda.synchronize()
+        outs.append((float(loss), opt.g.clone(), opt.grad_norm()))
+    tol = 1e-5 if mode == "fp32" else 2e-2
+    assert abs(outs[0][0] - outs[1][0]) < tol * max(1.0, abs(outs[0][0]))
+    g1, g2 = outs[0][1], outs[1][1]
+    assert float((g1 - g2).norm() / g1.norm()) < (1e-4 if mode == "fp32" else 5e-2), float((g1 - g2).norm() / g1.norm())
+    assert abs(outs[0][2] - outs[1][2]) < (1e-4 if mode == "fp32" else 5e-2) * outs[0][2]
+
+
 def test_mona_gradients_do_not_depend_on_the_flat_optimiser_idiom():
     """ADVICE r01 (functional.py:220): `out = model(x); optimizer.zero_grad(set_to_none=True); loss.backward()` used to orphan the
     gradient buffers captured at forward time.  The .grad views are now looked up at BACKWARD time and the direct path is an
