@@ -64,6 +64,7 @@ def parse():
     ap.add_argument("--tile-group", default="", help="experiment knob: N=group[,N=group] overrides the ring kernels' tile-order group (row panels per group; "
                     "255 = row-panel-major) for launches with that many columns, e.g. 3072=8,2304=4")
     ap.add_argument("--no-k64-cfg14", action="store_true", help="A/B knob: single-K-step GEMMs on the 256x256 tiles")
+    ap.add_argument("--mona-fused", action="store_true", help="A/B knob: the adapter forward as ONE launch (uia_mona_fused_fwd) instead of pre, project1, spatial, project2")
     ap.add_argument("--no-tail-split", action="store_true", help="A/B knob: no half-height tiles for the M tail of a launch")
     ap.add_argument("--global-loss", action="store_true", help="opt-in: InfoNCE over the global batch (all-gathered features) instead of "
                     "the reference-equivalent local loss; changes the objective, not the headline configuration")
@@ -324,6 +325,7 @@ def main():
     UF.set_ln_fold(not args.no_ln_fold)
     ops.KBLOCK_W, ops.TAIL_SPLIT, ops.K64_CFG14 = not args.no_kblock_w, not args.no_tail_split, not args.no_k64_cfg14
     ops.KBLOCK_ACT = not args.no_kblock_act
+    ops.MONA_FUSED = args.mona_fused
     ops.PERSIST_STORE_ONLY = args.persist_store_only
     ops.TILE_GROUP = {int(k): int(v) for k, v in (kv.split("=") for kv in args.tile_group.split(",") if kv)}
     try:

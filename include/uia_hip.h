@@ -197,6 +197,36 @@ size_t uia_mona_pre_bwd_workspace_bytes(int M, int D);
 int uia_mona_spatial_fwd(void* stream, int dtype, const uia_mona_spatial_desc* d);
 int uia_mona_spatial_bwd(void* stream, int dtype, const uia_mona_spatial_desc* d);
 
+/* The WHOLE adapter forward of mona.py:319-362 (and :96-151, :198-253, :427-487) in one launch, one workgroup per image:
+ *     y = x + project2(drop(gelu(spatial(project1(LN(x)·gamma + x·gammax)))))
+ * pre -> project1 (768 -> 64 on MFMA, W1 resident in LDS) -> the spatial op on the fp32 [tokens][64] LDS tile -> GELU / dropout ->
+ * project2 (64 -> 768 on MFMA, W2 fragments in registers) + residual, with u, t and d never travelling through HBM between stages.
+ * bf16 only, bottleneck 64, grid width 14 or 4, D % 128 == 0, D <= 768 (uia_mona_fused_supported says whether a shape qualifies; everything
+ * else runs as uia_mona_pre_fwd -> uia_gemm -> uia_mona_spatial_fwd -> uia_gemm with identical semantics).
+ *   sp      variant, B, h, w, bott, the adapter_conv parameters, p_drop / seed / keep_mask;  sp.d (optional): T [B,1+hw,64] copy of d for the
+ *           backward's weight gradient;  sp.t, sp.dd, sp.dt, sp.g_*, sp.ws are ignored
+ *   x       fp32 [B,1+hw,D];  norm_w/norm_b/gamma/gammax fp32 [D];  w1 T [64,D] (project1.weight), b1 fp32 [64];  w2 T [D,64] (project2.weight), b2 fp32 [D]
+ *   y32     fp32 [B,1+hw,D];  yT (optional) its T copy: row-major, or K-blocked with yT_kb_rows > 0 (uia_gemm_desc.a_kb_rows);
+ *   rowsum_out (optional) receives (Σ, Σ²) of every row of y in the fixed-point form of uia_gemm_desc.rowsum_out — STORED, not added
+ *           (an image's rows belong to one workgroup); ln_flag as in uia_gemm_desc
+ *   u_out, t_out (optional) T [B·(1+hw), D] / [B,1+hw,64]: u and t for the backward (uia_wgrad of project1 / uia_mona_spatial_bwd) */
+typedef struct uia_mona_fused_desc {
+    uia_mona_spatial_desc sp;
+    int32_t D; float eps;
+    const float* x;
+    const float *norm_w, *norm_b, *gamma, *gammax;
+    const void* w1; const float* b1;
+    const void* w2; const float* b2;
+    float* y32;
+    void* yT; int64_t yT_kb_rows;
+    int64_t* rowsum_out;
+    int32_t* ln_flag;
+    void* u_out;
+    void* t_out;
+} uia_mona_fused_desc;
+int uia_mona_fused_supported(int dtype, int D, int h, int w, int bott);
+int uia_mona_fused_fwd(void* stream, int dtype, const uia_mona_fused_desc* d);
+
 /* ---------------------------------------------------------------------------------------------
  * Task heads of the feature-pyramid adapter (reference src/third_party/timm/clip_adapter.py:47-57, 118-160).
  * uia_upsample_bilinear_fwd: nn.Upsample((H,W), mode="bilinear", align_corners=False) of a token-major map

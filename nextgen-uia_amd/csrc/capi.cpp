@@ -63,6 +63,10 @@ int uia_mona_spatial_bwd(void* stream, int dtype, const uia_mona_spatial_desc* d
     NEED(d, "uia_mona_spatial_bwd");
     return uia_mona_spatial_bwd_launch((hipStream_t)stream, dtype, *d);
 }
+int uia_mona_fused_fwd(void* stream, int dtype, const uia_mona_fused_desc* d) {
+    NEED(d, "uia_mona_fused_fwd");
+    return uia_mona_fused_fwd_launch((hipStream_t)stream, dtype, *d);
+}
 
 size_t uia_infonce_workspace_bytes(int B, int E) { return uia_infonce_workspace_floats(B, E) * sizeof(float); }
 int uia_infonce_fwd_bwd(void* stream, int B, int E, const float* img, const float* txt, float inv_temp, float grad_scale, float* loss,

@@ -209,6 +209,14 @@ int main(int argc, char** argv) {
                     }
         return 0;
     }
+    if (argc > 1 && !strcmp(argv[1], "resid")) {    // ./test_gemm_exp resid: the HBM-heavy epilogues (fp32 residual in / fp32 + T out + row sums) on one 256x256 workgroup
+                                                    // per CU (cfg 8) vs two half-height workgroups per CU (14: 3-deep ring; 13: 4-deep ring, one per CU)
+        const int shapes[][4] = {{65536, 768, 768, 5}, {43520, 768, 768, 5}, {65536, 768, 3072, 5}, {43520, 768, 3072, 2}, {50432, 768, 64, 5}, {49152, 3072, 768, 3}};
+        for (int rep = 0; rep < 2; ++rep)
+            for (auto& sh : shapes)
+                for (int cfg : {8, 14, 13}) { printf("kb=3 "); bench(UIA_BF16, sh[0], sh[1], sh[2], cfg | (3 << 16), sh[3]); }
+        return 0;
+    }
     if (argc > 1 && !strcmp(argv[1], "dephase")) {  // ./test_gemm_exp dephase: cfg 8 (one workgroup per CU), every other first-round workgroup delayed by s x 4096 cycles
         const int shapes[][4] = {{65536, 768, 768, 2}, {50432, 768, 768, 2}, {65536, 768, 3072, 2}, {65536, 2304, 768, 0}, {65536, 3072, 768, 1}, {50432, 3072, 768, 1}};
         for (auto& sh : shapes) {

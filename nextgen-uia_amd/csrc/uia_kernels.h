@@ -33,6 +33,7 @@ int uia_mona_pre_bwd_launch(hipStream_t stream, int dtype, int M, int D, const v
 size_t uia_mona_pre_bwd_ws_floats(int M, int D);
 int uia_mona_spatial_fwd_launch(hipStream_t stream, int dtype, const uia_mona_spatial_desc& p);
 int uia_mona_spatial_bwd_launch(hipStream_t stream, int dtype, const uia_mona_spatial_desc& p);
+int uia_mona_fused_fwd_launch(hipStream_t stream, int dtype, const uia_mona_fused_desc& q);
 size_t uia_infonce_workspace_floats(int B, int E);
 int uia_infonce_launch(hipStream_t stream, int B, int E, const float* img, const float* txt, float inv_temp, float grad_scale, float* loss,
                        float* dimg, float* dtxt, float* ws, size_t ws_floats);

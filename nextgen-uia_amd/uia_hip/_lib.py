@@ -54,6 +54,13 @@ class MonaSpatialDesc(C.Structure):
                 ("g_proj_w", vp), ("g_proj_b", vp), ("g_freq", vp), ("g_ne1_w", vp), ("g_ne1_b", vp), ("g_ne3_w", vp), ("g_ne3_b", vp), ("ws", vp)]
 
 
+class MonaFusedDesc(C.Structure):
+    """uia_mona_fused_desc (include/uia_hip.h): the whole adapter forward of one image in one workgroup."""
+    _fields_ = [("sp", MonaSpatialDesc), ("D", i32), ("eps", f32), ("x", vp), ("norm_w", vp), ("norm_b", vp), ("gamma", vp), ("gammax", vp),
+                ("w1", vp), ("b1", vp), ("w2", vp), ("b2", vp), ("y32", vp), ("yT", vp), ("yT_kb_rows", i64), ("rowsum_out", vp), ("ln_flag", vp),
+                ("u_out", vp), ("t_out", vp)]
+
+
 # name -> (restype, argtypes).  tests/test_capi_symbols.py checks this table against include/uia_hip.h.
 PROTOTYPES = {
     "uia_last_error": (C.c_char_p, []),
@@ -71,6 +78,8 @@ PROTOTYPES = {
     "uia_mona_spatial_fwd": (C.c_int, [vp, C.c_int, C.POINTER(MonaSpatialDesc)]),
     "uia_mona_spatial_bwd": (C.c_int, [vp, C.c_int, C.POINTER(MonaSpatialDesc)]),
     "uia_mona_spatial_workspace_bytes": (sz, [C.c_int]),
+    "uia_mona_fused_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "uia_mona_fused_fwd": (C.c_int, [vp, C.c_int, C.POINTER(MonaFusedDesc)]),
     "uia_upsample_bilinear_fwd": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int64, vp]),
     "uia_upsample_bilinear_bwd": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int64]),
     "uia_segment_mean_fwd": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int64, vp]),

@@ -390,6 +390,28 @@ class MonaFn(torch.autograd.Function):
         x = x.contiguous()
         M = B * N
         bott = P["project1.weight"].shape[0]
+        if ops.mona_fused_ok(dt, D, h, w, bott):
+            # the whole adapter in one launch (csrc/mona_fused.hip): u, t and d never travel through HBM between the stages
+            sp = {_SPATIAL_MAP[k]: v.detach().contiguous() for k, v in P.items() if k in _SPATIAL_MAP}
+            seed = _next_seed() if (p_drop > 0 and keep_mask is None) else 0
+            train = any(ctx.needs_input_grad)
+            u = _empty((M, D), dt, x) if train else None
+            t = _empty((M, bott), dt, x) if train else None
+            d = _empty((M, bott), dt, x) if train else None
+            w1, w2 = WEIGHTS.get(P["project1.weight"], dt), WEIGHTS.get(P["project2.weight"], dt)
+            y = torch.empty_like(x)
+            fold = ln_fold_enabled(dt, M)
+            y_t = _act(M, D, dt, x, 3 * D) if fold else None
+            sums = zero_sums(M, x.device) if fold else None
+            ops.mona_fused_fwd(variant, B, h, w, x, P["norm.weight"], P["norm.bias"], P["gamma"], P["gammax"], w1.row, P["project1.bias"], w2.row,
+                               P["project2.bias"], sp, y, y_t=y_t, rowsum=sums, u_out=u, t_out=t, d_out=d, p_drop=p_drop, seed=seed, keep_mask=keep_mask)
+            if fold:
+                publish_rows(y, y_t, sums)
+            if train:
+                ctx.save_for_backward(x, u, t, d, keep_mask if keep_mask is not None else x.new_empty(0), *params)
+            ctx.meta = (variant, hw, p_drop, seed, names, keep_mask is not None)
+            ctx.direct_params = tuple(params) if direct else None
+            return y
         u = _empty((M, D), dt, x)
         ops.mona_pre_fwd(x, P["norm.weight"], P["norm.bias"], P["gamma"], P["gammax"], u)
         w1 = WEIGHTS.get(P["project1.weight"], dt)

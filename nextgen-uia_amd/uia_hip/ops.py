@@ -9,7 +9,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import AttnDesc, GemmDesc, MonaSpatialDesc, PackDesc, UiaError, check, lib
+from ._lib import AttnDesc, GemmDesc, MonaFusedDesc, MonaSpatialDesc, PackDesc, UiaError, check, lib
 
 _ACT = {None: 0, "none": 0, "gelu": 1, "quick_gelu": 2, "relu": 3}
 
@@ -562,6 +562,53 @@ def _spatial_desc(variant, B, h, w, t, params, p_drop, seed, keep_mask):
         assert keep_mask.dtype == torch.uint8 and keep_mask.is_contiguous()
         d.keep_mask = _p(keep_mask)
     return d
+
+
+# The whole adapter forward in one launch (csrc/mona_fused.hip) where uia_mona_fused_supported says so.  Built, parity-tested and measured in
+# round 3 (tools/mff_variants.sh, profiles/r03_c_mona_fused_phases.txt): 199 us per ViT-B/16 layer with the u stash the backward's weight
+# gradient needs (181 without) against 179 us for the four unfused launches — its third phase IS the K = 64 projection with the fp32 residual
+# (387 MB, ~100 us either way) and the first two save 16 us of the 98 they replace.  Opt-in until the backward recomputes u.
+MONA_FUSED = False
+
+
+def mona_fused_ok(dt, D, h, w, bott):
+    return MONA_FUSED and dt == torch.bfloat16 and bool(lib().uia_mona_fused_supported(_code(dt), D, h, w, bott))
+
+
+def mona_fused_fwd(variant, B, h, w, x, norm_w, norm_b, gamma, gammax, w1, b1, w2, b2, params, y32, y_t=None, rowsum=None, u_out=None, t_out=None, d_out=None,
+                   p_drop=0.0, seed=0, keep_mask=None, eps=1e-5):
+    """y32 = x + project2(drop(gelu(spatial(project1(LN(x)·gamma + x·gammax)))))  for B images of 1 + h·w tokens, one launch
+    (include/uia_hip.h, uia_mona_fused_desc).  x fp32 [B, 1+h·w, D]; w1 [64, D] / w2 [D, 64] in the compute dtype; params as mona_spatial_fwd.
+    y_t: optional T copy of y (tensor or KBlocked); rowsum: int64 [M, 2] receiving the rows' (Σ, Σ²); u_out / t_out / d_out: optional stashes."""
+    D = x.shape[-1]
+    q = MonaFusedDesc()
+    sp = _spatial_desc(variant, B, h, w, w1.new_empty(0, w1.shape[0]) if t_out is None else t_out, params, p_drop, seed, keep_mask)
+    sp.t = None
+    if d_out is not None:
+        sp.d = _p(d_out)
+    q.sp = sp
+    q.D, q.eps = D, eps
+    assert x.dtype == torch.float32 and x.is_contiguous() and y32.dtype == torch.float32 and y32.is_contiguous() and y32.numel() == x.numel()
+    assert tuple(w1.shape) == (sp.bott, D) and tuple(w2.shape) == (D, sp.bott) and w1.is_contiguous() and w2.is_contiguous() and w1.dtype == w2.dtype
+    q.x, q.norm_w, q.norm_b, q.gamma, q.gammax = _p(x), _p(norm_w), _p(norm_b), _p(gamma), _p(gammax)
+    q.w1, q.b1, q.w2, q.b2, q.y32 = _p(w1), _p(b1), _p(w2), _p(b2), _p(y32)
+    M = B * (1 + h * w)
+    if is_kb(y_t):
+        rows, cols, plane = _kb_dims(y_t, "mona_fused y_t")
+        if rows < M or cols != D:
+            raise UiaError(f"mona_fused y_t (K-blocked {tuple(y_t.t.shape)}) does not hold [{M}, {D}]")
+        q.yT, q.yT_kb_rows = _p(y_t.t), plane
+    elif y_t is not None:
+        assert y_t.dtype == w1.dtype and y_t.is_contiguous() and y_t.numel() == M * D
+        q.yT = _p(y_t)
+    if rowsum is not None:
+        assert rowsum.dtype == torch.int64 and rowsum.is_contiguous() and rowsum.numel() >= 2 * M
+        q.rowsum_out, q.ln_flag = _p(rowsum), _p(ln_flag(x.device))
+    for name, t, width in (("u_out", u_out, D), ("t_out", t_out, sp.bott)):
+        if t is not None:
+            assert t.dtype == w1.dtype and t.is_contiguous() and t.numel() == M * width
+            setattr(q, name, _p(t))
+    check(lib().uia_mona_fused_fwd(_stream(), _code(w1.dtype), C.byref(q)), "uia_mona_fused_fwd")
 
 
 def mona_spatial_fwd(variant, B, h, w, t, params, d_out, p_drop=0.0, seed=0, keep_mask=None):
