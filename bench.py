@@ -46,6 +46,8 @@ def parse():
                     "off by default so that the per-launch HIP-event durations behind `roofline` are not inflated by the other stream's kernels "
                     "and agree with the rocprofv3 summary of the same command")
     ap.add_argument("--no-overlap-text", action="store_true", help=argparse.SUPPRESS)        # former spelling of the default
+    ap.add_argument("--also-streams", type=int, default=3, help="after the timed region, time 5 more steps with the batch's towers cut into this many slices on as many "
+                    "HIP streams and report them beside the headline as `multi_stream` (0 = skip); the headline itself stays on --streams")
     ap.add_argument("--streams", type=int, default=1, help="cut each rank's batch into this many slices whose towers run on as many HIP streams (same batch, "
                     "same single InfoNCE over all pairs, same gradients: engine.contrastive_step(streams=...))")
     ap.add_argument("--cpu-batch", type=int, default=8)
@@ -64,6 +66,7 @@ def parse():
     ap.add_argument("--tile-group", default="", help="experiment knob: N=group[,N=group] overrides the ring kernels' tile-order group (row panels per group; "
                     "255 = row-panel-major) for launches with that many columns, e.g. 3072=8,2304=4")
     ap.add_argument("--no-k64-cfg14", action="store_true", help="A/B knob: single-K-step GEMMs on the 256x256 tiles")
+    ap.add_argument("--wgrad-side-stream", action="store_true", help="A/B knob: the adapters' weight-gradient launches on a second HIP stream beside the data-gradient chain")
     ap.add_argument("--mona-fused", action="store_true", help="A/B knob: the adapter forward as ONE launch (uia_mona_fused_fwd) instead of pre, project1, spatial, project2")
     ap.add_argument("--no-tail-split", action="store_true", help="A/B knob: no half-height tiles for the M tail of a launch")
     ap.add_argument("--global-loss", action="store_true", help="opt-in: InfoNCE over the global batch (all-gathered features) instead of "
@@ -236,11 +239,16 @@ def gemm_roofline(prof, prof_serial, args, ms_per_step, ops, torch):
                            "workload, measured in the round the file name carries; FETCH_SIZE doubled per the gfx950 note of the microarchitecture guide)")
     ft, ff, fn, _ = fam.get(True, (tsec, flops, n, 0.0))
     fts, ffs, fns, _ = fam_serial.get(True, (ts, fs, ns, 0.0))
+    # in-kernel clock under sustained GEMM load (s_memtime / s_memrealtime, profiles/r03_a_inkernel_clock.txt): 1.51-1.65 GHz on this pool's
+    # devices against the 2.4 GHz the 2.5 PF datasheet peak is quoted at; `frac` stays against the datasheet peak
+    load_clock = {"measured_GHz": [1.51, 1.65], "source": "profiles/r03_a_inkernel_clock.txt (test_gemm_stamps: s_memtime / s_memrealtime x 100 MHz per workgroup, after 6-12 k warm launches)",
+                  "mfma_peak_at_that_clock_TFLOPs": [round(peak * 1.51 / 2.4), round(peak * 1.65 / 2.4)],
+                  "frac_of_that_peak": [round(achieved / (peak * 1.65 / 2.4), 4), round(achieved / (peak * 1.51 / 2.4), 4)]} if args.dtype == "bf16" else None
     roof = {"bound": "mfma", "kernel": kname, "kernel_in_rocprof_csv": kmangled, "achieved": round(achieved, 1), "peak": peak,
             "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "bytes per launch (HBM, PMC)",
             "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(algo_bytes / n), "launches_per_step": n,
             "avg_launch_us": round(tsec / n * 1e6, 2), "flop_per_launch_avg": round(flops / n),
-            "share_of_step": round(tsec / (ms_per_step * 1e-3), 3),
+            "share_of_step": round(tsec / (ms_per_step * 1e-3), 3), "load_clock": load_clock,
             "note": ("HIP events around every launch of this kernel, on the launch stream, during one extra step of the same loop right after the timed region" +
                      ("; more than one HIP stream: a launch's duration includes time shared with the other stream's kernels "
                       "(see standalone)" if (args.overlap_text or getattr(args, "streams", 1) > 1) else "")),
@@ -326,6 +334,7 @@ def main():
     ops.KBLOCK_W, ops.TAIL_SPLIT, ops.K64_CFG14 = not args.no_kblock_w, not args.no_tail_split, not args.no_k64_cfg14
     ops.KBLOCK_ACT = not args.no_kblock_act
     ops.MONA_FUSED = args.mona_fused
+    UF.set_wgrad_side_stream(args.wgrad_side_stream)
     ops.PERSIST_STORE_ONLY = args.persist_store_only
     ops.TILE_GROUP = {int(k): int(v) for k, v in (kv.split("=") for kv in args.tile_group.split(",") if kv)}
     try:
@@ -373,6 +382,28 @@ def bench_mona(args, rank, world, device):
     step = lambda overlap: contrastive_step(model, criterion, opt, images, ids, overlap_text=bool(overlap) and args.streams == 1, global_loss=args.global_loss,
                                             streams=args.streams if overlap is not False else 1)
     elapsed, per_rank, final_loss, prof, prof_serial = timed_loop(step, args, world, device, ops, torch)
+    multi = None
+    if args.also_streams > 1 and args.also_streams != args.streams:
+        # the same step with its towers as S batch slices on S HIP streams (same single InfoNCE, same gradients): what the chip gives when
+        # two or three dependent chains fill each other's lockstep phases and tails.  Reported beside the headline, not as it: with several
+        # streams a launch's HIP-event duration includes time shared with the other streams' kernels, and `roofline` would under-report.
+        stepm = lambda: contrastive_step(model, criterion, opt, images, ids, overlap_text=False, global_loss=args.global_loss, streams=args.also_streams)
+        for _ in range(2):
+            stepm()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            lm = stepm()
+        torch.cuda.synchronize()
+        dtm = time.perf_counter() - t0
+        if world > 1:
+            tm = torch.tensor([dtm], device=device, dtype=torch.float64)
+            torch.distributed.all_reduce(tm, op=torch.distributed.ReduceOp.MAX)
+            dtm = float(tm[0])
+        multi = {"hip_streams": args.also_streams, "steps": 5, "ms_per_step": round(dtm / 5 * 1e3, 3), "value": round(world * args.batch * 5 / dtm, 2),
+                 "loss": round(float(lm), 5), "how": "engine.contrastive_step(streams=S): S batch slices on S streams, one InfoNCE over all pairs; untimed in `value`"}
     if rank != 0:
         return None
     ms = elapsed / args.steps * 1e3
@@ -405,6 +436,7 @@ def bench_mona(args, rank, world, device):
                       "gflop_per_pair_algorithmic": GFLOP_PER_PAIR},
            "loss": round(final_loss, 5), "roofline": roof}
     out.update(dist_fields(world, per_rank, args.steps, ops))
+    out["multi_stream"] = multi
     out["cpu_baseline"] = cpu_baseline(cpu_state, args.variant, args.cpu_batch, args.cpu_steps, wide=not args.no_cpu_wide) if cpu_state is not None else None
     return out
 

@@ -103,12 +103,14 @@ class FlatAdapterOptimizer(FlatLayout):
                 p.grad = view
 
     def all_reduce(self):
+        UF.join_side_streams()                                 # weight-gradient launches on the side stream (UF.set_wgrad_side_stream) write into self.g
         self._adopt_grads()
         if self.world > 1 or self.collective:
             ops.allreduce_sum(self.g)
 
     def step(self, lr=None, grad_scale=None):
         """One update from the accumulated gradient buffer (already all-reduced when world > 1)."""
+        UF.join_side_streams()
         self._adopt_grads()
         self.steps += 1
         gs = dp_grad_scale(self.world) if grad_scale is None else grad_scale

@@ -456,8 +456,19 @@ class MonaFn(torch.autograd.Function):
         # project2: dd = dy·W2 ; dW2 = dyᵀ·d ; db2 = Σ dy
         w2t = WEIGHTS.get(P["project2.weight"], dt, transpose=True)          # [bott, D]
         dd = _empty((M, bott), dt, x)
+        side = _wgrad_side_stream(x.device) if _STATE.get("wgrad_side_stream", False) else None
+        if side is not None:
+            # the two weight gradients of the adapter depend on nothing the data-gradient chain produces later: on a second stream they
+            # run beside its launches (whose lockstep phases and one-round kernels leave CUs and HBM idle)
+            cur = torch.cuda.current_stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                ops.wgrad(dy_t, d, G["project2.weight"], G["project2.bias"])
+            dy_t.record_stream(side)
+            d.record_stream(side)
         ops.gemm(dy_t, w2t, out_t=dd)
-        ops.wgrad(dy_t, d, G["project2.weight"], G["project2.bias"])
+        if side is None:
+            ops.wgrad(dy_t, d, G["project2.weight"], G["project2.bias"])
         # spatial
         sp = {_SPATIAL_MAP[k]: v.detach().contiguous() for k, v in P.items() if k in _SPATIAL_MAP}
         sg = {_SPATIAL_MAP[k]: G[k] for k in P if k in _SPATIAL_MAP}
@@ -466,8 +477,15 @@ class MonaFn(torch.autograd.Function):
         # project1: du = dt·W1 ; dW1 = dtᵀ·u ; db1 = Σ dt
         w1t = WEIGHTS.get(P["project1.weight"], dt, transpose=True)          # [D, bott]
         du = _empty((M, D), dt, x)
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                ops.wgrad(dtt, u, G["project1.weight"], G["project1.bias"])
+            dtt.record_stream(side)
+            u.record_stream(side)
         ops.gemm(dtt, w1t, out_t=du)
-        ops.wgrad(dtt, u, G["project1.weight"], G["project1.bias"])
+        if side is None:
+            ops.wgrad(dtt, u, G["project1.weight"], G["project1.bias"])
         need_dx = ctx.needs_input_grad[0]
         dx = torch.empty_like(x) if need_dx else None
         # the T copy of dx is the A operand of the preceding block's fc2 data-gradient GEMM (VitBlockFn.backward asks for it with
@@ -479,6 +497,27 @@ class MonaFn(torch.autograd.Function):
             publish_t_copy(dx, dx_t)
         grads = tuple(None if direct else (G[k] if ctx.needs_input_grad[7 + i] else None) for i, k in enumerate(names))
         return (dx, None, None, None, None, None, None) + grads
+
+
+_WGRAD_SIDE = {}
+
+
+def _wgrad_side_stream(device):
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if key not in _WGRAD_SIDE:
+        _WGRAD_SIDE[key] = torch.cuda.Stream(device=device)
+    return _WGRAD_SIDE[key]
+
+
+def set_wgrad_side_stream(flag):
+    """Opt-in: MonaFn.backward launches its two uia_wgrad calls on a second HIP stream (join with join_side_streams() before the gradients are read)."""
+    _STATE["wgrad_side_stream"] = bool(flag)
+
+
+def join_side_streams():
+    cur = torch.cuda.current_stream()
+    for st in _WGRAD_SIDE.values():
+        cur.wait_stream(st)
 
 
 def _is_flat_grad(p):

@@ -284,6 +284,61 @@ def test_fullshape_vit_l14_lora_vs_oracle(mode):
         assert cos > 0.99 and l2 < 0.15, (cos, l2)
 
 
+@pytest.mark.timeout(1500)
+def test_fullshape_vit_l14_lora_all_24_blocks_bf16_vs_oracle():
+    """configs[4] at FULL depth (the test above covers 3 of 24 blocks): ViT-L/14 image tower, 24 blocks, width 1024, 16 heads,
+    257 tokens, LoRA r = 16 on q, k, v, o of every block (3 145 728 factor elements), bf16 mode, B = 2, against oracle/vit_ref.py: features
+    and the whole LoRA gradient.  Reference: src/adapters/lora.py:202-248 over src/third_party/openai_clip/model.py:233-257."""
+    from uia_hip import functional as UF
+    from src.adapters import inject_lora_to_clip
+    from src.third_party.openai_clip.model import CLIP
+    UF.set_compute_dtype(torch.bfloat16)
+    g = torch.Generator().manual_seed(53)
+    torch.manual_seed(53)
+    model = CLIP(768, 224, 24, 1024, 14, 77, 49408, 768, 12, 1).eval()
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            if p.dim() >= 2:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.02)
+            elif k.endswith("weight") and "ln" in k:
+                p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g))
+            else:
+                p.copy_(0.02 * torch.randn(p.shape, generator=g))
+    for p in model.parameters():
+        p.requires_grad_(False)
+    model, n = inject_lora_to_clip(model, lora_r=16, lora_alpha=32, lora_dropout=0.0)
+    assert n == 24
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            if "lora" in k:
+                p.copy_(0.02 * torch.randn(p.shape, generator=g))
+    for k, p in model.named_parameters():
+        if "lora" in k:
+            p.requires_grad_(True)
+    model.eval()
+    B = 2
+    images = torch.rand(B, 3, 224, 224, generator=g)
+    P = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    trainable = [k for k, p in model.named_parameters() if p.requires_grad]
+    assert sum(P[k].numel() for k in trainable if "lora" in k) == 3145728
+    leaves = {k: P[k].clone().requires_grad_(True) for k in trainable}
+    Pq = dict(P)
+    Pq.update(leaves)
+    fr = vit_ref.openai_vit_forward(images, Pq, heads=16, lora=dict(r=16, alpha=32))
+    fr.square().sum().backward()
+    model = model.to(dev())
+    fi = model.encode_image(images.to(dev()))
+    fi.square().sum().backward()
+    e_f = rel(fi, fr)
+    params = dict(model.named_parameters())
+    got = torch.cat([params[k].grad.detach().float().cpu().flatten() for k in trainable])
+    want = torch.cat([leaves[k].grad.flatten() for k in trainable])
+    cos, l2 = float(torch.dot(got, want) / (got.norm() * want.norm())), float((got - want).norm() / want.norm())
+    report("vit_l14_lora_r16_bf16_24blocks", {"B": B, "blocks": 24, "features_rel": e_f, "grad_cosine": cos, "grad_rel_l2": l2})
+    assert e_f < TOL["bf16"], e_f
+    assert cos > 0.99 and l2 < 0.15, (cos, l2)
+
+
 # ------------------------------------------------------------------------------------------------ kernels at production shapes
 M_PROD = 256 * 197                                                       # 50 432 token rows of one bs-256 step
 MASKS = ("proj_resid32", "postln_residT", "dgrad", "qkv_bias", "fc1_gelu", "fc2_dgelu", "fc1_gelu_stash")
