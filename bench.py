@@ -66,6 +66,7 @@ def parse():
     ap.add_argument("--tile-group", default="", help="experiment knob: N=group[,N=group] overrides the ring kernels' tile-order group (row panels per group; "
                     "255 = row-panel-major) for launches with that many columns, e.g. 3072=8,2304=4")
     ap.add_argument("--no-k64-cfg14", action="store_true", help="A/B knob: single-K-step GEMMs on the 256x256 tiles")
+    ap.add_argument("--bf16-heads", action="store_true", help="A/B knob: the two feature heads on bf16 operands (default: fp32 operands, UF.set_fp32_heads)")
     ap.add_argument("--wgrad-side-stream", action="store_true", help="A/B knob: the adapters' weight-gradient launches on a second HIP stream beside the data-gradient chain")
     ap.add_argument("--mona-fused", action="store_true", help="A/B knob: the adapter forward as ONE launch (uia_mona_fused_fwd) instead of pre, project1, spatial, project2")
     ap.add_argument("--no-tail-split", action="store_true", help="A/B knob: no half-height tiles for the M tail of a launch")
@@ -335,6 +336,7 @@ def main():
     ops.KBLOCK_ACT = not args.no_kblock_act
     ops.MONA_FUSED = args.mona_fused
     UF.set_wgrad_side_stream(args.wgrad_side_stream)
+    UF.set_fp32_heads(not args.bf16_heads)
     ops.PERSIST_STORE_ONLY = args.persist_store_only
     ops.TILE_GROUP = {int(k): int(v) for k, v in (kv.split("=") for kv in args.tile_group.split(",") if kv)}
     try:

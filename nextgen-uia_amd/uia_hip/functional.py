@@ -112,6 +112,18 @@ def poll_ln_flag(device=None, sync=False):
     return seen
 
 
+def set_fp32_heads(flag):
+    """bf16 mode (default on): the two feature heads — final LayerNorm of the CLS row + projection(s) — run on fp32 operands.  They are B x 768
+    rows of work (nothing next to the towers), and they are the one place where a bf16 rounding lands on the features undamped: a feature is a
+    768-term dot product whose terms largely cancel, so rounding its operands to 8 bits costs ≈ 2.8e-3 of the typical |feature| — about a
+    quarter of the towers' whole error variance at B = 256 (tools/parity_at_bench_batch.py)."""
+    _STATE["fp32_heads"] = bool(flag)
+
+
+def head_dtype():
+    return torch.float32 if _STATE.get("fp32_heads", True) else compute_dtype()
+
+
 def set_unpad_text(flag):
     """Opt-in: the frozen text tower computes only the valid tokens of each caption (packed rows + per-caption attention) instead
     of all `context_length` positions.  Features are identical (padded positions never reach the pooled CLS row); what changes
@@ -767,7 +779,7 @@ class ClsHeadFn(torch.autograd.Function):
     def forward(ctx, x, ln_w, ln_b, eps, w, w_is_in_out=False):
         """w: [out, in] (nn.Linear weight, timm head.proj) or, with w_is_in_out, [in, out] (OpenAI `x @ proj`)."""
         B, N, D = x.shape
-        dt = compute_dtype()
+        dt = head_dtype()                                   # fp32 operands by default (set_fp32_heads): B rows of work, undamped rounding
         x = x.contiguous()
         h = _empty((B, D), dt, x)
         ops.layernorm_fwd(x, ln_w, ln_b, eps, y_t=h, rows=B, ldx=N * D)
@@ -775,18 +787,22 @@ class ClsHeadFn(torch.autograd.Function):
         feat = torch.empty(B, E, device=x.device, dtype=torch.float32)
         ops.gemm(h, WEIGHTS.get(w, dt, transpose=w_is_in_out), out32=feat)
         ctx.save_for_backward(x, ln_w)
-        ctx.meta = (eps, w, w_is_in_out)
+        ctx.meta = (eps, w, w_is_in_out, dt)
         return feat
 
     @staticmethod
     def backward(ctx, dfeat):
         x, ln_w = ctx.saved_tensors
-        eps, w, w_is_in_out = ctx.meta
+        eps, w, w_is_in_out, hdt = ctx.meta
         B, N, D = x.shape
         dt = compute_dtype()
-        df = t_copy_of(dfeat.contiguous(), dt)
-        dh = _empty((B, D), dt, x)
-        ops.gemm(df, WEIGHTS.get(w, dt, transpose=not w_is_in_out), out_t=dh)
+        df = t_copy_of(dfeat.contiguous(), hdt)
+        dh = _empty((B, D), hdt, x)
+        ops.gemm(df, WEIGHTS.get(w, hdt, transpose=not w_is_in_out), out_t=dh)
+        if hdt != dt:                                       # the LayerNorm backward writes dx's T copy in the dtype of its dy: hand it a T copy of dh
+            dh_t = _empty((B, D), dt, x)
+            ops.cast(dh, dh_t)
+            dh = dh_t
         dx = torch.zeros_like(x)
         dx_t = torch.zeros(B * N, D, device=x.device, dtype=dt) if dt != torch.float32 else None
         ops.layernorm_bwd(dh, x, ln_w, eps, dx32=dx, dx_t=dx_t, rows=B, ldx=N * D)

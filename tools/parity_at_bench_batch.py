@@ -90,7 +90,20 @@ def oracle_step(P, trainable, images, ids, variant, chunk, threads):
     return fi, ft, float(loss), {k: v.grad for k, v in leaves.items()}, time.perf_counter() - t0
 
 
-def run_case(B, variant, stress, chunk, threads):
+def logits_of(fi, ft, tau=0.07):
+    """contrastive logits (reference losses.py:23-47): cosine similarities / temperature"""
+    fi, ft = fi.detach().float().cpu(), ft.detach().float().cpu()
+    fi = fi / fi.norm(dim=1, keepdim=True)
+    ft = ft / ft.norm(dim=1, keepdim=True)
+    return fi @ ft.t() / tau
+
+
+def rms_rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).pow(2).mean().sqrt() / (b.abs().max() + 1e-12))
+
+
+def run_case(B, variant, stress, chunk, threads, adapters="scaled"):
     from uia_hip import functional as UF
     from src.adapters import inject_mona_variant_to_open_clip
     from src.losses import InfoNCELoss
@@ -103,7 +116,8 @@ def run_case(B, variant, stress, chunk, threads):
     for p in model.parameters():
         p.requires_grad_(False)
     inject_mona_variant_to_open_clip(model, variant=variant, bottleneck_dim=64)
-    scale_adapters(model, g)
+    if adapters == "scaled":
+        scale_adapters(model, g)
     if stress:
         stress_weights(model)
     for k, p in model.named_parameters():
@@ -129,7 +143,11 @@ def run_case(B, variant, stress, chunk, threads):
     worst = max(per, key=per.get)
     got = torch.cat([params[k].grad.detach().float().cpu().flatten() for k in trainable])
     want = torch.cat([gref[k].flatten() for k in trainable])
-    out = {"B": B, "variant": variant, "stress": stress, "image_features_rel": rel(fi, fref), "text_features_rel": rel(ft, tref), "loss": float(loss), "loss_ref": lref,
+    lg, lgr = logits_of(fi, ft), logits_of(fref, tref)
+    out = {"B": B, "variant": variant, "stress": stress, "adapters": adapters, "image_features_rel": rel(fi, fref), "text_features_rel": rel(ft, tref),
+           "image_features_rms_rel": rms_rel(fi, fref), "text_features_rms_rel": rms_rel(ft, tref),
+           "logits_rel": float((lg - lgr).abs().max() / lgr.abs().max()), "logits_abs_max_err": float((lg - lgr).abs().max()), "logits_abs_max": float(lgr.abs().max()),
+           "logits_spread_ref": float(lgr.max() - lgr.min()), "loss": float(loss), "loss_ref": lref,
            "grad_cosine": float(torch.dot(got, want) / (got.norm() * want.norm())), "grad_rel_l2": float((got - want).norm() / want.norm()),
            "grad_median_per_tensor_rel": sorted(per.values())[len(per) // 2], "grad_worst_per_tensor_rel": per[worst], "grad_worst_tensor": worst,
            "ln_fold_guard_tripped": fold_tripped, "warnings": [str(w.message)[:120] for w in wlist if "uia_hip" in str(w.message)],
@@ -155,6 +173,8 @@ def main():
     ap.add_argument("--batches", default="64,256")
     ap.add_argument("--variant", default="freq_enhanced")
     ap.add_argument("--stress", action="store_true")
+    ap.add_argument("--adapters", default="scaled", choices=["scaled", "init"], help="scaled: adapters away from their init so that every gradient path carries "
+                    "signal (the parity tests' setting); init: as injected (what a fine-tune run starts from and what bench.py times)")
     ap.add_argument("--chunk", type=int, default=16)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "parity_bench_batch.json"))
     args = ap.parse_args()
@@ -162,8 +182,8 @@ def main():
     res = {}
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     for B in [int(b) for b in args.batches.split(",") if b]:
-        r = run_case(B, args.variant, False, args.chunk, threads)
-        res[f"biomedclip_vitb16_mona_{args.variant}_bf16_B{B}"] = r
+        r = run_case(B, args.variant, False, args.chunk, threads, args.adapters)
+        res[f"biomedclip_vitb16_mona_{args.variant}_bf16_B{B}" + ("" if args.adapters == "scaled" else "_adapters_at_init")] = r
         print(json.dumps(r), flush=True)
         json.dump(res, open(args.out, "w"), indent=1, sort_keys=True)
     if args.stress:
