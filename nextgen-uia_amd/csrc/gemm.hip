@@ -1163,21 +1163,44 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_tn_ring_kernel
     if (grp == 1) {                               // fall one slot behind group 0
         UIA_SLOT_END();
     }
+    // LOOP == 3 / 4 (round 3): the LAST TAILI row groups of a COMPUTE slot's MFMA cluster (8 / 16 of its 32 MFMAs) are issued BEHIND the
+    // slot's closing barrier, at the head of the wave's next LOAD slot.  With MFMAs and barriers alone the loop takes 650 cycles per slot for
+    // 512 cycles of MFMA issue: when a group's cluster ends, the matrix pipe idles for the barrier's turnaround before the other group's
+    // cluster starts.  The barrier orders LDS traffic (fragment reads against LDS-DMA), not arithmetic on registers, so the tail of one
+    // cluster may run beside the head of the other group's: the pipe sees them back to back.
+    constexpr int TAILI = LOOP == 3 ? 2 : (LOOP == 4 ? 4 : 0);
+    auto compute_head = [&]() {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < MT - TAILI; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = MfmaTile<T>::mma(wf[j], af[i], acc[i][j]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto compute_tail = [&]() {
+#pragma unroll
+        for (int i = MT - TAILI; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = MfmaTile<T>::mma(wf[j], af[i], acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+    };
     const int nu = ntl * SPT;
     for (int u = 0; u < nu; ++u) {
         const int t = u / SPT, kk = u % SPT;
         const char* buf = smem + (t % NBUF) * BUF_BYTES;
         const bool last_of_tile = kk == SPT - 1;
+        if (TAILI > 0 && u > 0 && !UIA_DIAG_NO_MFMA) compute_tail();      // the rest of COMPUTE(u-1): registers only, beside the other group's cluster
         // ---- LOAD(u): this group's DMA pieces of sub-tile t+PD ride beside the other group's MFMA cluster
         if (t + PD < ntl && !UIA_DIAG_NO_DMA) stage(t + PD, kk);
         if (!UIA_DIAG_NO_FRAGS) load_frags(buf, kk);
         if (grp == 1 && last_of_tile && t + 1 < ntl) retire(t + 1);
         UIA_SLOT_END();
         // ---- COMPUTE(u)
-        if (!UIA_DIAG_NO_MFMA) compute();
+        if (!UIA_DIAG_NO_MFMA) { if constexpr (TAILI > 0) compute_head(); else compute(); }
         if (grp == 0 && last_of_tile && t + 1 < ntl) retire(t + 1);
         UIA_SLOT_END();
     }
+    if (TAILI > 0 && nu > 0 && !UIA_DIAG_NO_MFMA) compute_tail();
     if (grp == 0) {
         UIA_SLOT_END();
     }
@@ -1544,8 +1567,8 @@ int launch_typed(hipStream_t stream, const UiaGemmParams& p, int cfg_in) {
                                  // (cfg 12, the persistent variant, is +2-3.5 % on store-only epilogues in isolation, -15-25 % on the
                                  //  fp32-residual ones, and a net loss inside the two-stream training step: opt-in only.)
     }
-    const bool ring = cfg == 8 || cfg == 9 || cfg == 10 || cfg == 12 || cfg == 13 || cfg == 14 || cfg == 15 || cfg == 17 || cfg == 18;
-    if ((p.a_kb_rows || p.outT_kb_rows) && !(cfg == 8 || cfg == 10 || cfg == 12 || cfg == 13 || cfg == 14 || cfg == 15 || cfg == 17 || cfg == 18)) {
+    const bool ring = cfg == 8 || cfg == 9 || cfg == 10 || cfg == 12 || cfg == 13 || cfg == 14 || cfg == 15 || (cfg >= 17 && cfg <= 20);
+    if ((p.a_kb_rows || p.outT_kb_rows) && !(cfg == 8 || cfg == 10 || cfg == 12 || cfg == 13 || cfg == 14 || cfg == 15 || (cfg >= 17 && cfg <= 20))) {
         uia_set_error("uia_gemm: K-blocked activations (a_kb_rows / outT_kb_rows) need a ring tile config with 64-byte sub-tiles (8, 10, 13, 14), not %d", cfg);
         return -1;
     }
@@ -1558,7 +1581,11 @@ int launch_typed(hipStream_t stream, const UiaGemmParams& p, int cfg_in) {
         // beside the A panels (N = 2304: 3.5 MB, N = 3072: 4.7 MB at K = 768) wants the XCD's ~32 concurrent tiles arranged as a block,
         // 8 row panels deep for N = 2304 (+8 %), 16 for N = 3072 (+3 %); for N = 768 the whole W stays resident and the plain order wins.
         int gm = gm_req == 255 ? 0 : gm_req;
-        if (gm_req == 0) gm = p.N >= 3072 ? 16 : (p.N >= 1536 ? 8 : 0);
+        // Round 3 (rocprofv3 --pmc FETCH_SIZE per group size, M = 65 536, K = 768, profiles/r03_f_tile_group_fetch.txt): fabric reads per launch at
+        // N = 3072 are 596 / 578 / 481 / 432 / 648 / 1188 MB for no group / 2 / 4 / 8 / 16 / 32 — and the launch takes 330-334 us with every one
+        // of them (as the in-step sweep of round 2 found: 43.7-44.3 ms).  The reads are served on-die and do not pace the K loop; 8 is kept for both
+        // widths because it moves the fewest bytes.
+        if (gm_req == 0) gm = p.N >= 1536 ? 8 : 0;
         xflags = (xflags & ~255) | gm;
     }
     switch (cfg) {
@@ -1581,6 +1608,8 @@ int launch_typed(hipStream_t stream, const UiaGemmParams& p, int cfg_in) {
                                                                                             // 5-10 % SLOWER than the ping-pong loop on every shape; experiment builds only
 #endif
 #ifdef UIA_GEMM_EXP
+        case 19: return launch_ring<T, 256, 256, 2, 4, 64, 4, 3>(stream, p, true, xflags);   // cfg 8 with the last 8 MFMAs of a cluster behind the slot barrier
+        case 20: return launch_ring<T, 256, 256, 2, 4, 64, 4, 4>(stream, p, true, xflags);   // ... the last 16
         // experiment (round 3): FOUR-wave workgroups, two per CU, so that one workgroup's epilogue runs beside the other's K loop
         case 17: return launch_ring<T, 256, 128, 2, 2, 64, 3>(stream, p, true, xflags);   // 256 x 128 tiles (A panel re-read by the column neighbour)
         case 18: return launch_ring<T, 128, 256, 1, 4, 64, 3>(stream, p, true, xflags);   // 128 x 256 tiles

@@ -209,6 +209,14 @@ int main(int argc, char** argv) {
                     }
         return 0;
     }
+    if (argc > 1 && !strcmp(argv[1], "tail")) {     // ./test_gemm_exp tail: cfg 8 vs the same loop with the last 8 (19) / 16 (20) MFMAs of every cluster behind the slot barrier
+        const int shapes[][4] = {{65536, 3072, 768, 0}, {65536, 2304, 768, 0}, {65536, 768, 3072, 0}, {50432, 3072, 768, 1}, {49152, 3072, 768, 3}, {65536, 768, 768, 5},
+                                 {43520, 768, 3072, 2}, {8192, 8192, 8192, 0}};
+        for (int rep = 0; rep < 2; ++rep)
+            for (auto& sh : shapes)
+                for (int cfg : {8, 19, 20}) { printf("kb=3 "); bench(UIA_BF16, sh[0], sh[1], sh[2], cfg | (3 << 16), sh[3]); }
+        return 0;
+    }
     if (argc > 1 && !strcmp(argv[1], "resid")) {    // ./test_gemm_exp resid: the HBM-heavy epilogues (fp32 residual in / fp32 + T out + row sums) on one 256x256 workgroup
                                                     // per CU (cfg 8) vs two half-height workgroups per CU (14: 3-deep ring; 13: 4-deep ring, one per CU)
         const int shapes[][4] = {{65536, 768, 768, 5}, {43520, 768, 768, 5}, {65536, 768, 3072, 5}, {43520, 768, 3072, 2}, {50432, 768, 64, 5}, {49152, 3072, 768, 3}};
@@ -252,7 +260,7 @@ int main(int argc, char** argv) {
     for (int d = 0; d < 2; ++d) {
         const int dt = dts[d];
 #ifdef UIA_GEMM_EXP
-        const int cfg_hi = 18;
+        const int cfg_hi = 20;
 #else
         const int cfg_hi = 14;
 #endif

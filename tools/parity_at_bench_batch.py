@@ -103,13 +103,16 @@ def rms_rel(a, b):
     return float((a - b).pow(2).mean().sqrt() / (b.abs().max() + 1e-12))
 
 
+FOLD = [True]
+
+
 def run_case(B, variant, stress, chunk, threads, adapters="scaled"):
     from uia_hip import functional as UF
     from src.adapters import inject_mona_variant_to_open_clip
     from src.losses import InfoNCELoss
     from src.third_party.biomedclip.model import create_biomedclip
     UF.set_compute_dtype(torch.bfloat16)
-    UF.set_ln_fold(True)
+    UF.set_ln_fold(FOLD[0])
     UF.reset_ln_flag()
     g = torch.Generator().manual_seed(41 + B)
     model = create_biomedclip(seed=3)
@@ -173,11 +176,13 @@ def main():
     ap.add_argument("--batches", default="64,256")
     ap.add_argument("--variant", default="freq_enhanced")
     ap.add_argument("--stress", action="store_true")
+    ap.add_argument("--no-ln-fold", action="store_true", help="the stand-alone LayerNorm kernels instead of the fold (A/B of the fold's share of the error)")
     ap.add_argument("--adapters", default="scaled", choices=["scaled", "init"], help="scaled: adapters away from their init so that every gradient path carries "
                     "signal (the parity tests' setting); init: as injected (what a fine-tune run starts from and what bench.py times)")
     ap.add_argument("--chunk", type=int, default=16)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "parity_bench_batch.json"))
     args = ap.parse_args()
+    FOLD[0] = not args.no_ln_fold
     threads = max(1, min(32, os.cpu_count() or 1))
     res = {}
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
