@@ -406,6 +406,23 @@ def bench_mona(args, rank, world, device):
             dtm = float(tm[0])
         multi = {"hip_streams": args.also_streams, "steps": 5, "ms_per_step": round(dtm / 5 * 1e3, 3), "value": round(world * args.batch * 5 / dtm, 2),
                  "loss": round(float(lm), 5), "how": "engine.contrastive_step(streams=S): S batch slices on S streams, one InfoNCE over all pairs; untimed in `value`"}
+        # and the entry points' default: the frozen text tower on a second stream beside the image tower (contrastive_step(overlap_text=True))
+        stepo = lambda: contrastive_step(model, criterion, opt, images, ids, overlap_text=True, global_loss=args.global_loss)
+        for _ in range(2):
+            stepo()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            lo = stepo()
+        torch.cuda.synchronize()
+        dto = time.perf_counter() - t0
+        if world > 1:
+            to = torch.tensor([dto], device=device, dtype=torch.float64)
+            torch.distributed.all_reduce(to, op=torch.distributed.ReduceOp.MAX)
+            dto = float(to[0])
+        multi["text_tower_on_second_stream"] = {"steps": 5, "ms_per_step": round(dto / 5 * 1e3, 3), "value": round(world * args.batch * 5 / dto, 2), "loss": round(float(lo), 5)}
     if rank != 0:
         return None
     ms = elapsed / args.steps * 1e3

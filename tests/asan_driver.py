@@ -84,6 +84,15 @@ assert lib.uia_mona_pre_bwd_workspace_bytes(50432, 768) == 1024 * 4 * 768 * 4
 s = mod.MonaSpatialDesc()
 expect_fail(lib.uia_mona_spatial_fwd(None, 1, None), "null descriptor")
 expect_fail(lib.uia_mona_spatial_fwd(None, 1, C.byref(s)))
+f = mod.MonaFusedDesc()
+expect_fail(lib.uia_mona_fused_fwd(None, 1, None), "null descriptor")
+expect_fail(lib.uia_mona_fused_fwd(None, 1, C.byref(f)), "use the unfused launches")          # zeroed descriptor: unsupported shape
+f.sp.B, f.sp.h, f.sp.w, f.sp.bott, f.D = 2, 14, 14, 64, 1024
+expect_fail(lib.uia_mona_fused_fwd(None, 1, C.byref(f)), "use the unfused launches")          # ViT-L width
+f.D = 768
+expect_fail(lib.uia_mona_fused_fwd(None, 0, C.byref(f)), "use the unfused launches")          # fp32
+expect_fail(lib.uia_mona_fused_fwd(None, 1, C.byref(f)), "null tensor")
+assert lib.uia_mona_fused_supported(1, 768, 14, 14, 64) == 1 and lib.uia_mona_fused_supported(1, 768, 16, 16, 64) == 0
 expect_fail(lib.uia_infonce_fwd_bwd(None, 0, 0, None, None, 1.0, 1.0, None, None, None, None, 0))
 expect_fail(lib.uia_adamw_clip_step(None, 0, None, None, None, None, 1e-3, 0.9, 0.95, 1e-8, 0.01, 1.0, 1, 1.0, None))
 # communicator: argument errors and use-before-init

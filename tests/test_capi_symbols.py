@@ -45,14 +45,17 @@ def test_descriptor_struct_sizes_match_c_layout():
     assert ctypes.sizeof(_lib.GemmDesc) == 280
     assert ctypes.sizeof(_lib.AttnDesc) == 160
     assert ctypes.sizeof(_lib.MonaSpatialDesc) % 8 == 0 and ctypes.sizeof(_lib.MonaSpatialDesc) == 296
+    assert ctypes.sizeof(_lib.MonaFusedDesc) == 432 and _lib.MonaFusedDesc.D.offset == 296
     # ... and the same numbers from the C compiler itself (sizes and the offset of the last field of the GEMM descriptor)
     with tempfile.TemporaryDirectory() as td:
         src, exe = os.path.join(td, "s.c"), os.path.join(td, "s")
-        open(src, "w").write('#include <stdio.h>\n#include <stddef.h>\n#include "uia_hip.h"\nint main(void){ printf("%zu %zu %zu %zu\\n", sizeof(uia_gemm_desc), '
-                             'sizeof(uia_attn_desc), sizeof(uia_mona_spatial_desc), offsetof(uia_gemm_desc, ln_flag_limit)); return 0; }\n')
+        open(src, "w").write('#include <stdio.h>\n#include <stddef.h>\n#include "uia_hip.h"\nint main(void){ printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(uia_gemm_desc), '
+                             'sizeof(uia_attn_desc), sizeof(uia_mona_spatial_desc), offsetof(uia_gemm_desc, ln_flag_limit), sizeof(uia_mona_fused_desc), '
+                             'offsetof(uia_mona_fused_desc, t_out)); return 0; }\n')
         subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), "-o", exe, src], check=True)
         got = [int(v) for v in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()]
-    assert got == [ctypes.sizeof(_lib.GemmDesc), ctypes.sizeof(_lib.AttnDesc), ctypes.sizeof(_lib.MonaSpatialDesc), _lib.GemmDesc.ln_flag_limit.offset]
+    assert got == [ctypes.sizeof(_lib.GemmDesc), ctypes.sizeof(_lib.AttnDesc), ctypes.sizeof(_lib.MonaSpatialDesc), _lib.GemmDesc.ln_flag_limit.offset,
+                   ctypes.sizeof(_lib.MonaFusedDesc), _lib.MonaFusedDesc.t_out.offset]
 
 
 def test_error_path_without_gpu():
