@@ -55,6 +55,7 @@ PERSIST_STORE_ONLY = False   # experiment knob: 256x256 ring launches whose epil
 KBLOCK_W = True          # hand the ring kernels their weights K-blocked (PackedW.kblocked()); False = row-major everywhere
 K64_CFG14 = True         # single-K-step GEMMs on the two-workgroups-per-CU half-height config (False: 256x256 like every other large shape)
 TILE_GROUP = {}          # experiment knob: {N: row panels per tile-order group} overriding the launcher's choice for ring launches with that N
+HALF_HEIGHT_SHORT_K = True   # N <= 768, K <= 768 (bf16) launches whose 256-row tiling leaves a ragged last round run on half-height tiles (cfg 14) in one launch
 TAIL_SPLIT = True        # split off the M tail of a launch whose last round of 256x256 tiles would leave most CUs idle
 _NCU = {}
 
@@ -268,6 +269,12 @@ def gemm(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None, res
         tile_cfg = 8
     if (TAIL_SPLIT and tile_cfg == 0 and out_group == 0 and resid_mod == 0 and a.is_cuda and auto_tile_cfg(M, N, Ka, a.element_size()) == 8):
         m_main = tail_split_rows(M, N, num_cus(a.device.index))
+        if m_main < M and HALF_HEIGHT_SHORT_K and N <= 768 and Ka * a.element_size() <= 1536:
+            # short K loops with a ragged last round (the image tower's output projection and its data gradient: 591 tiles on 256 CUs): the whole
+            # launch on half-height tiles, two workgroups per CU (tile cfg 14), instead of a main launch + a half-height tail launch — 1182 half
+            # tiles pack 2.31 rounds of 512, and one workgroup's epilogue runs beside its neighbour's K loop (round 3, isolated: 64 vs 62 + 21 us
+            # for the plain data gradient, 92 vs 102 us per 43 520 rows for the fp32-residual producer).  Longer K loops lose on it.
+            tile_cfg, m_main = 14, M
         if m_main < M:
             cut = lambda t, lo, hi: None if t is None else (t.row_range(lo, hi) if is_kb(t) else t[lo:hi])
             for lo, hi, cfg in ((0, m_main, 8), (m_main, M, 13)):
