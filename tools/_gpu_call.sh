@@ -1,11 +1,13 @@
-mkdir -p gpurun_out/r3s
-python -m pytest tests -m gpu -x -q > gpurun_out/r3s/gputest.log 2>&1; echo "pytest rc=$?"; tail -2 gpurun_out/r3s/gputest.log
-for f in "" "--no-half-height-short-k" "" "--no-half-height-short-k"; do
-  python bench.py --steps 10 --warmup 3 --no-cpu-baseline --also-streams 0 $f > gpurun_out/r3s/bench.json 2> gpurun_out/r3s/bench.err; echo "bench [$f] rc=$?"
-  python -c "
+set -o pipefail
+mkdir -p gpurun_out/r3t
+python -m pytest tests -m gpu -x -q > gpurun_out/r3t/gputest.log 2>&1; echo "pytest rc=$?"; tail -2 gpurun_out/r3t/gputest.log
+python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r3t/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 gpurun_out/r3t/smoke.log
+python bench.py > gpurun_out/r3t/bench_default.json 2> gpurun_out/r3t/bench_default.err; echo "bench rc=$?"
+python -c "
 import json
-d=json.loads(open('gpurun_out/r3s/bench.json').read().strip().splitlines()[-1])
-print({k:d[k] for k in ('value','ms_per_step','loss')}, d['roofline']['gemm_family']['ms_per_step'])
-for s in d['roofline']['per_shape']:
-    if s['N']==768 and s['K']==768: print('   ', s['kernel'][20:], s['M'], s['launches'], s['avg_us'])"
-done
+d=json.loads(open('gpurun_out/r3t/bench_default.json').read().strip().splitlines()[-1])
+print({k:d[k] for k in ('value','ms_per_step','loss','rccl_world')}, d['roofline']['kernel'], d['roofline']['frac'], d['roofline']['avg_launch_us'], d['roofline']['traffic'], d['roofline']['gemm_family'], d['multi_stream'], d['cpu_baseline']['value'])"
+bash tools/prof_step.sh > gpurun_out/r3t/prof_step.log 2>&1; echo "prof rc=$?"
+cp gpurun_out/prof/step_kernel_stats.csv gpurun_out/r3t/kernel_stats.csv; cp gpurun_out/prof/bench.log gpurun_out/r3t/prof_bench.log
+bash tools/pmc_step.sh > gpurun_out/r3t/pmc_step.log 2>&1; echo "pmc rc=$?"; tail -16 gpurun_out/r3t/pmc_step.log
+cp gpurun_out/pmc_step/summary.json gpurun_out/r3t/pmc_summary.json
