@@ -127,3 +127,59 @@ def test_fused_mona_rejects_unsupported_shapes_loudly():
               conv3_w=torch.zeros(64, 49, device=dev()), conv3_b=z, proj_w=torch.zeros(64, 64, device=dev()), proj_b=z)
     with pytest.raises(ops.UiaError, match="use the unfused launches"):
         ops.mona_fused_fwd("baseline", 2, 4, 4, x, v, v, v, v, w1, z, w2, v, sp, torch.empty_like(x))
+
+
+# ------------------------------------------------------------------------------------------------ the pipelined GEMM epilogue
+@pytest.mark.parametrize("M,N,K", [(2500, 768, 128), (4353, 776, 64), (2177, 2304, 192)])
+def test_pipelined_epilogue_equals_inline_epilogue_bit_for_bit(M, N, K):
+    """Round 3: the compile-time epilogue masks that read an operand or leave row sums (aux_in with GELU', fp32 / T residual, deferred-LayerNorm
+    residual, row sums) request their rows a chunk ahead and issue the row-sum atomics after the last store.  Same arithmetic in the same order:
+    on RAGGED shapes (last row panel and last column tile partial) every output must equal, bit for bit, what tile cfg 10 — the same ring kernel
+    with the run-time epilogue and its in-line loads — produces, on the 256-row tiles (8) and on both half-height configs (13, 14)."""
+    from uia_hip import ops
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    dt = torch.bfloat16
+    a = torch.randn(M, K, generator=g).to(dev()).to(dt)
+    w = ops.PackedW((torch.randn(N, K, generator=g) * K ** -0.5).to(dev()).to(dt))
+    bias = torch.randn(N, generator=g).to(dev())
+    resid = torch.randn(M, N, generator=g).to(dev())
+    resid_t = torch.randn(M, N, generator=g).to(dev()).to(dt)
+    aux = (torch.randn(M, N, generator=g) * 1.5).to(dev()).to(dt)
+    lnw, lnb = (1.0 + 0.2 * torch.randn(N, generator=g)).to(dev()), (0.1 * torch.randn(N, generator=g)).to(dev())
+    mean = resid.mean(1)
+    stats = torch.stack([mean, (resid.var(1, unbiased=False) + 1e-5).rsqrt()], 1).contiguous()
+    sums_in = ops.rowsum_from_float(torch.stack([resid.sum(1), (resid * resid).sum(1)], 1))
+
+    def run(cfg, kind):
+        o32 = torch.full((M, N), float("nan"), device=dev())
+        ot = torch.full((M, N), float("nan"), device=dev(), dtype=dt)
+        rs = torch.zeros(M, 2, device=dev(), dtype=torch.int64)
+        if kind == "dgelu":                                            # mask 136
+            ops.gemm(a, w, dact="gelu", aux_in=aux, out_t=ot, tile_cfg=cfg)
+        elif kind == "resid32":                                        # mask 81
+            ops.gemm(a, w, bias=bias, resid=resid, out32=o32, tile_cfg=cfg)
+        elif kind == "residT":                                         # mask 97
+            ops.gemm(a, w, bias=bias, resid_t=resid_t, out32=o32, tile_cfg=cfg)
+        elif kind == "fold_producer":                                  # mask 721
+            ops.gemm(a, w, bias=bias, resid=resid, out32=o32, out_t=ot, rowsum=rs, tile_cfg=cfg)
+        elif kind == "resid_ln":                                       # mask 337: (mean, rstd) statistics
+            ops.gemm(a, w, bias=bias, resid=resid, out32=o32, resid_ln=(stats, lnw, lnb), tile_cfg=cfg)
+        elif kind == "resid_ln_sums_fold_producer":                    # mask 977: statistics from row sums, and row sums out
+            ops.gemm(a, w, bias=bias, resid=resid, out32=o32, out_t=ot, rowsum=rs, resid_ln=(sums_in, lnw, lnb, N, 1e-5), tile_cfg=cfg)
+        torch.cuda.synchronize()
+        return o32, ot, rs
+
+    for kind in ("dgelu", "resid32", "residT", "fold_producer", "resid_ln", "resid_ln_sums_fold_producer"):
+        ref = run(10, kind)
+        for cfg in (8, 13, 14):
+            got = run(cfg, kind)
+            for name, x, y in zip(("out32", "outT", "rowsum"), got, ref):
+                same = torch.equal(x, y) if x.dtype == torch.int64 else torch.equal(torch.nan_to_num(x.float(), nan=-7.0), torch.nan_to_num(y.float(), nan=-7.0))
+                assert same, (kind, cfg, name)
+        # and against torch, so that "equal" is not "equally wrong"
+        pre = a.float() @ w.row.float().T
+        if kind == "fold_producer":
+            want = pre + bias + resid
+            assert float((ref[0] - want).abs().max()) <= 3e-5 * float(want.abs().max())
+            s = ops.rowsum_to_float(ref[2])
+            assert torch.allclose(s[:, 0], ref[0].sum(1), rtol=1e-4, atol=1e-2)
