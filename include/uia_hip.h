@@ -105,6 +105,16 @@ typedef struct uia_gemm_desc {
      * The atomics are issued only for offending rows, so a healthy step pays one compare per row. */
     int32_t* ln_flag;
     float ln_flag_limit;                /* <= 0: 8.0 */
+    /* LoRA input dropout (/root/reference/src/adapters/lora.py:82-83) without a pass of its own.  keep(seed, element index) is the generator
+     * of uia_dropout (eight consecutive elements per draw), so a fused launch and uia_dropout + a plain launch see the same mask.
+     *   drop_where = 1: the A operand is dropped while it streams through the N = 64 kernel (tile cfg 16; element (m, k) has index m·K + k);
+     *                   a_drop_out, if set, receives the dropped rows ([M, K], leading dimension lda) for the weight gradient.
+     *   drop_where = 2: alpha·acc (+ bias, activation) of output element (m, n), index m·N + n, is dropped before the residual adds:
+     *                   dx += drop(s·q·A), the backward of the same dropout (run-time epilogue; N % 8 == 0). */
+    int32_t drop_where;
+    float drop_p;
+    uint64_t drop_seed;
+    void* a_drop_out;
 } uia_gemm_desc;
 int uia_gemm(void* stream, int dtype, const uia_gemm_desc* d, int tile_cfg /* 0 = auto */);
 
@@ -113,6 +123,11 @@ int uia_gemm(void* stream, int dtype, const uia_gemm_desc* d, int tile_cfg /* 0 
  * Replaces autograd's wgrad of mona.py:127,148 and lora.py:87. */
 int uia_wgrad(void* stream, int dtype, int M, int I, int J, const void* A, int64_t lda, const void* B, int64_t ldb,
               float alpha, float* dW, float* dbias_A);
+/* The same with the operands zero-padded to the kernel's 64-wide tiles and the gradient not: only rows < i_valid and columns < j_valid are
+ * accumulated, into dW with leading dimension ldw — a LoRA factor's [out, r] / [r, in] gradient (r = 16 padded to 64) lands in the
+ * parameter's own .grad without a padded staging buffer, its zero fill and its slice copy (lora.py:87). */
+int uia_wgrad_ex(void* stream, int dtype, int M, int I, int J, const void* A, int64_t lda, const void* B, int64_t ldb,
+                 float alpha, float* dW, int64_t ldw, int i_valid, int j_valid, float* dbias_A);
 
 /* ---------------------------------------------------------------------------------------------
  * softmax(q kᵀ·scale + mask) v, head dim 64, L <= 272, one workgroup per (batch, head).
@@ -266,6 +281,12 @@ typedef struct uia_pack_desc {
     void* tr;
     void* tr_kb;
     int32_t rows, cols;
+    /* The destinations may be LARGER than the source: rows_pad x cols_pad (0 = rows / cols).  Only the source's elements are written, so
+     * destinations zeroed once stay zero-padded — a LoRA factor [r, in] / [out, r] (r = 16) becomes the 64-wide GEMM operand in the same
+     * launch that casts it.  scale (0 = 1) multiplies every element before the cast (lora.py:87's scaling folded into B). */
+    int32_t rows_pad, cols_pad;
+    float scale;
+    int32_t reserved_;
 } uia_pack_desc;
 int uia_pack_weights(void* stream, int dtype, int n, const uia_pack_desc* descs_device, int max_elems);
 int uia_im2col(void* stream, int dtype, int B, int C, int H, int W, int P, const float* img, void* out); /* model.py:221,234 */

@@ -16,6 +16,11 @@ int uia_gemm(void* stream, int dtype, const uia_gemm_desc* d, int tile_cfg) {
 int uia_wgrad(void* stream, int dtype, int M, int I, int J, const void* A, int64_t lda, const void* B, int64_t ldb, float alpha, float* dW, float* dbias_A) {
     return uia_wgrad_launch((hipStream_t)stream, dtype, M, I, J, A, lda, B, ldb, alpha, dW, dbias_A);
 }
+int uia_wgrad_ex(void* stream, int dtype, int M, int I, int J, const void* A, int64_t lda, const void* B, int64_t ldb, float alpha, float* dW, int64_t ldw,
+                 int i_valid, int j_valid, float* dbias_A) {
+    if (ldw <= 0) { uia_set_error("uia_wgrad_ex: ldw=%lld must be positive", (long long)ldw); return -1; }
+    return uia_wgrad_launch((hipStream_t)stream, dtype, M, I, J, A, lda, B, ldb, alpha, dW, dbias_A, ldw, i_valid, j_valid);
+}
 int uia_attn_fwd(void* stream, int dtype, const uia_attn_desc* d) {
     NEED(d, "uia_attn_fwd");
     return uia_attn_fwd_launch((hipStream_t)stream, dtype, *d);

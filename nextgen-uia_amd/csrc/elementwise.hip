@@ -43,14 +43,16 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const uia_pack_desc* 
     const uia_pack_desc d = descs[blockIdx.y];
     constexpr int g = 64 / (int)sizeof(T);
     const int R = d.rows, C = d.cols, total = R * C;
+    const int RP = d.rows_pad > 0 ? d.rows_pad : R, CP = d.cols_pad > 0 ? d.cols_pad : C;      // destination extents (zero padding is the caller's)
+    const float sc = d.scale != 0.f ? d.scale : 1.f;
     T* row = (T*)d.row; T* row_kb = (T*)d.row_kb; T* tr = (T*)d.tr; T* tr_kb = (T*)d.tr_kb;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
         const int r = e / C, c = e - r * C;
-        const T v = from_f32<T>(d.src[e]);
-        if (row) row[e] = v;
-        if (row_kb) row_kb[((size_t)(c / g) * R + r) * g + (c % g)] = v;
-        if (tr) tr[(size_t)c * R + r] = v;
-        if (tr_kb) tr_kb[((size_t)(r / g) * C + c) * g + (r % g)] = v;
+        const T v = from_f32<T>(d.src[e] * sc);
+        if (row) row[(size_t)r * CP + c] = v;
+        if (row_kb) row_kb[((size_t)(c / g) * RP + r) * g + (c % g)] = v;
+        if (tr) tr[(size_t)c * RP + r] = v;
+        if (tr_kb) tr_kb[((size_t)(r / g) * CP + c) * g + (r % g)] = v;
     }
 }
 
@@ -162,15 +164,17 @@ __global__ void scale_cast_kernel(size_t n4, float a, const float* __restrict__ 
 }
 
 // dst = (accumulate ? dst : 0) + src * keep(seed, idx) / (1 - p)      (LoRA input dropout, lora.py:82-83, and its backward)
+// One draw (dropout_keep8) per eight elements: the same generator the fused forms use (N = 64 stream kernel, run-time GEMM epilogue).
 template <typename T>
-__global__ void dropout_kernel(size_t n8, const T* __restrict__ src, T* __restrict__ dst, float inv_keep, uint32_t thresh, uint64_t seed, int accumulate) {
+__global__ void dropout_kernel(size_t n8, const T* __restrict__ src, T* __restrict__ dst, float inv_keep, uint32_t thresh16, uint64_t seed, int accumulate) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
         float v[8], o[8];
         load8(src + 8 * i, v);
         if (accumulate) load8(dst + 8 * i, o);
+        const uint32_t keep = dropout_keep8(seed, (uint32_t)i, thresh16);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float k = dropout_keep(seed, (uint32_t)(8 * i + e), thresh) ? inv_keep : 0.f;
+            const float k = (keep >> e) & 1u ? inv_keep : 0.f;
             o[e] = (accumulate ? o[e] : 0.f) + v[e] * k;
         }
         store8(dst + 8 * i, o);
@@ -293,7 +297,8 @@ int uia_gather_rows_launch(hipStream_t stream, int n, int D, const float* src, c
 int uia_dropout_launch(hipStream_t stream, int dtype, size_t n, const void* src, void* dst, float p, uint64_t seed, int accumulate) {
     UIA_CHECK_ARG(n % 8 == 0 && src && dst && p >= 0.f && p < 1.f, "uia_dropout: bad arguments (n=%zu, p=%f)", n, p);
     const float inv_keep = 1.0f / (1.0f - p);
-    const uint32_t thresh = (uint32_t)fminf(p * 4294967296.0f, 4294967295.0f);
+    UIA_CHECK_ARG(n / 8 <= 0xFFFFFFFFull, "uia_dropout: n=%zu exceeds the generator's 2^35 elements", n);
+    const uint32_t thresh = dropout_thresh16(p);
     const int g = grid_for(n / 8, 256);
     if (dtype == UIA_BF16) hipLaunchKernelGGL(dropout_kernel<bf16_t>, dim3(g), dim3(256), 0, stream, n / 8, (const bf16_t*)src, (bf16_t*)dst, inv_keep, thresh, seed, accumulate);
     else if (dtype == UIA_F32) hipLaunchKernelGGL(dropout_kernel<float>, dim3(g), dim3(256), 0, stream, n / 8, (const float*)src, (float*)dst, inv_keep, thresh, seed, accumulate);

@@ -235,6 +235,12 @@ __device__ __forceinline__ void gemm_epilogue(const UiaGemmParams& p, f32x4 (&ac
                 load8(aux_in + orow * p.ldaux_in + n, a);
                 apply_dact8<sizeof(T) == 2>(v, a, p.dact);
             }
+            if (p.drop_where == 2) {
+                const uint32_t keep = dropout_keep8(p.drop_seed, (uint32_t)(((size_t)m * (size_t)p.N + (size_t)n) >> 3), dropout_thresh16(p.drop_p));
+                const float inv_keep = 1.0f / (1.0f - p.drop_p);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (keep >> e) & 1u ? v[e] * inv_keep : 0.f;
+            }
             if (p.resid) {
                 float r[8];
                 load8(p.resid + rrow * p.ldr + n, r);
@@ -297,6 +303,7 @@ enum : int { EPI_BIAS = 1, EPI_AUX_OUT = 2, EPI_GELU = 4, EPI_DGELU = 8, EPI_RES
              EPI_RESID_LN = 256,          // with EPI_RESID: the residual is the LayerNorm of the rows of `resid` (resid_ln_stats / _w / _b)
              EPI_ROWSUM = 512,            // rowsum_out: (Σ, Σ²) of the stored fp32 rows, for the LayerNorm folded into the consuming GEMM
              EPI_LNFOLD = 1024,           // lnfold_*: A held raw rows, the LayerNorm is applied to the accumulators
+             EPI_QUICK = 2048,            // with EPI_GELU / EPI_DGELU: the activation is QuickGELU (OpenAI CLIP towers: ViT-L/14 + LoRA, CLIPSeg), not GELU
              EPI_GENERIC = -1 };
 
 template <typename T, int MT, int NT, int WTM, int WTN, int EPI = EPI_GENERIC, bool PATCH16 = false>
@@ -312,8 +319,8 @@ __device__ __forceinline__ void gemm_epilogue_lds(const UiaGemmParams& p, f32x4 
     const bool f_outT = GEN ? p.outT != nullptr : (EPI & EPI_OUTT) != 0;
     const bool f_rowsum = GEN ? p.rowsum_out != nullptr : (EPI & EPI_ROWSUM) != 0;
     const bool f_lnfold = GEN ? p.lnfold_sums != nullptr : (EPI & EPI_LNFOLD) != 0;
-    const int act = GEN ? p.act : ((EPI & EPI_GELU) ? UIA_ACT_GELU : UIA_ACT_NONE);
-    const int dact = GEN ? p.dact : ((EPI & EPI_DGELU) ? UIA_ACT_GELU : UIA_ACT_NONE);
+    const int act = GEN ? p.act : ((EPI & EPI_GELU) ? ((EPI & EPI_QUICK) ? UIA_ACT_QUICKGELU : UIA_ACT_GELU) : UIA_ACT_NONE);
+    const int dact = GEN ? p.dact : ((EPI & EPI_DGELU) ? ((EPI & EPI_QUICK) ? UIA_ACT_QUICKGELU : UIA_ACT_GELU) : UIA_ACT_NONE);
     using EP = EpiPatch<MT, WTN>;
     constexpr int LDW = EP::LDW, GPP = EP::GPP, ROWS = EP::ROWS;
     constexpr int LPR = WTN / 8;                    // lanes per row when reading back
@@ -415,6 +422,12 @@ __device__ __forceinline__ void gemm_epilogue_lds(const UiaGemmParams& p, f32x4 
             }
             apply_dact8<sizeof(T) == 2>(v, a, dact);
         }
+        if (GEN && p.drop_where == 2) {                   // dx += drop(s·q·A): the backward of the LoRA input dropout, same draw as the forward
+            const uint32_t keep = dropout_keep8(p.drop_seed, (uint32_t)(((size_t)m * (size_t)p.N + (size_t)n) >> 3), dropout_thresh16(p.drop_p));
+            const float inv_keep = 1.0f / (1.0f - p.drop_p);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (keep >> e) & 1u ? v[e] * inv_keep : 0.f;
+        }
         if (f_resid && UIA_EPI_LOADS) {
             float r[8];
             if (pre_res) {
@@ -505,6 +518,104 @@ __device__ __forceinline__ void gemm_epilogue_lds(const UiaGemmParams& p, f32x4 
         constexpr bool PIPE = !GEN && sizeof(T) == 2 && (EPI & (EPI_DGELU | EPI_RESID | EPI_RESIDT | EPI_ROWSUM)) != 0;
 #endif
         constexpr int NPASS = ROWS / RPP, NPH = MT / GPP;
+        // PACKED bounce (bf16, compile-time masks whose only outputs are T tensors and that read nothing: data gradients, QKV, fc1): the lane
+        // applies the epilogue's arithmetic to its 16 consecutive columns of a row IN THE MFMA LAYOUT — the per-column vectors are fixed per
+        // lane for the whole tile — and bounces the ROUNDED values through LDS (128 B per row instead of 256): half the LDS bytes of the fp32
+        // bounce (ds_write_b128 moves ≈ 79 B/clk per CU: 3.3 K of a store-only epilogue's ≈ 8 K cycles), and the read-back passes have nothing
+        // left to do but store.  Same arithmetic on the same values in the same order as the row passes: bit-identical results.
+#if defined(UIA_NO_PREAUX) || defined(UIA_NO_PACK)
+        constexpr bool PACK = false;                       // A/B builds
+#else
+        constexpr bool PACK = !GEN && sizeof(T) == 2 && NT == 4 && WTN == 64 && (EPI & EPI_OUTT) != 0 &&
+                              (EPI & (EPI_RESID | EPI_RESIDT | EPI_OUT32 | EPI_DGELU | EPI_ROWSUM | EPI_RESID_LN | EPI_AUX_OUT)) == 0;
+        // (masks with an aux_out stash stay on the fp32 bounce: two packed bounces per phase measured 275 vs 266 us on fc1's launch, same box)
+#endif
+        if constexpr (PACK) {
+            constexpr int LDB = 128 + 16;                              // bytes per staged row of 64 bf16 (+16: the b128 writes of 8 consecutive rows hit 32 distinct banks)
+            static_assert(ROWS * LDB <= EP::BYTES_PER_WAVE, "bf16 patch must fit the wave's fp32 patch");
+            char* stb = (char*)stg;
+            const int nl = n0 + wn * WTN + g * 16;                     // the lane's 16 columns in the MFMA layout
+            const bool lcol_ok = nl < p.N;                             // N is a multiple of 8: the second half is tested on its own
+            const bool lcol_ok2 = nl + 8 < p.N;
+            float b16[16], c16[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { b16[e] = 0.f; c16[e] = 0.f; }
+            if (f_bias) {
+                if (lcol_ok) { float t8[8]; load8(p.bias + nl, t8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) b16[e] = t8[e]; }
+                if (lcol_ok2) { float t8[8]; load8(p.bias + nl + 8, t8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) b16[8 + e] = t8[e]; }
+            }
+            if (f_lnfold) {
+                if (lcol_ok) { float t8[8]; load8(p.lnfold_colsum + nl, t8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) c16[e] = t8[e]; }
+                if (lcol_ok2) { float t8[8]; load8(p.lnfold_colsum + nl + 8, t8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) c16[8 + e] = t8[e]; }
+            }
+            // one bounce: `which` = 0 the T output (after the activation), 1 the aux_out stash (before it)
+            auto bounce = [&](int ph, int which) {
+#pragma clang loop unroll(full)
+                for (int gi = 0; gi < GPP; ++gi) {
+                    const int i = ph * GPP + gi;
+                    const int mloc = 16 * i + li;                      // row within the wave's WTM rows
+                    float2 st = float2{1.f, 0.f};
+                    if (f_lnfold) st = *(const float2*)(lnrow_lds + 2 * mloc);
+                    const f32x2 rs2 = {st.x, st.x}, nm2 = {st.y, st.y};
+                    bf16x8 outv[2];
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) {
+                        float v[8] = {acc[i][2 * hf][0], acc[i][2 * hf][1], acc[i][2 * hf][2], acc[i][2 * hf][3],
+                                      acc[i][2 * hf + 1][0], acc[i][2 * hf + 1][1], acc[i][2 * hf + 1][2], acc[i][2 * hf + 1][3]};
+                        if (f_lnfold) {
+#pragma unroll
+                            for (int e = 0; e < 8; e += 2) {
+                                const f32x2 c2 = {c16[8 * hf + e], c16[8 * hf + e + 1]}, bb2 = {b16[8 * hf + e], b16[8 * hf + e + 1]}, a2 = {v[e], v[e + 1]};
+                                const f32x2 r2 = __builtin_elementwise_fma(a2, rs2, __builtin_elementwise_fma(nm2, c2, bb2));
+                                v[e] = r2[0];
+                                v[e + 1] = r2[1];
+                            }
+                        } else if (f_bias) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] += b16[8 * hf + e];
+                        }
+                        if (which == 0 && act) apply_act8<true>(v, act);
+                        const f32x4 lo = {v[0], v[1], v[2], v[3]}, hi = {v[4], v[5], v[6], v[7]};
+                        bf16x8 r = {(bf16_t)lo[0], (bf16_t)lo[1], (bf16_t)lo[2], (bf16_t)lo[3], (bf16_t)hi[0], (bf16_t)hi[1], (bf16_t)hi[2], (bf16_t)hi[3]};
+                        outv[hf] = r;
+                    }
+                    *(bf16x8*)(stb + (gi * 16 + li) * LDB + g * 32) = outv[0];
+                    *(bf16x8*)(stb + (gi * 16 + li) * LDB + g * 32 + 16) = outv[1];
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                T* dstbase = which == 0 ? outT : aux_out;
+                const int mbase = m0 + wm * WTM + ph * ROWS + rr;
+#pragma unroll
+                for (int q = 0; q < NPASS; ++q) {
+                    const int row = q * RPP + rr;
+                    const int m = mbase + q * RPP;
+                    const bf16x8 val = *(const bf16x8*)(stb + row * LDB + rc * 2);
+                    if (m < p.M && col_ok && UIA_EPI_STORES) {
+                        if (which == 0 && p.outT_kb_rows) {
+                            constexpr int G = 32;
+                            *(bf16x8*)(dstbase + ((size_t)(n / G) * (size_t)p.outT_kb_rows + (size_t)m) * G + (n % G)) = val;
+                        } else {
+                            *(bf16x8*)(dstbase + (size_t)m * (which == 0 ? p.ldo : p.ldaux_out) + n) = val;
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            };
+#pragma clang loop unroll(full)
+            for (int ph = 0; ph < NPH; ++ph) {
+                if (f_aux_out) bounce(ph, 1);
+                bounce(ph, 0);
+            }
+        } else
         if constexpr (PIPE && NPASS % 2 == 0) {
             constexpr bool H_AUX = (EPI & EPI_DGELU) != 0, H_RES = (EPI & EPI_RESID) != 0, H_RT = (EPI & EPI_RESIDT) != 0, H_SUM = (EPI & EPI_ROWSUM) != 0;
             constexpr int CH = NPASS / 2, NCH = 2 * NPH;                 // passes per chunk, chunks per tile
@@ -1416,9 +1527,11 @@ int launch_persist_epi(hipStream_t stream, const UiaGemmParams& p) {
 
 // feature mask of a descriptor, or EPI_GENERIC when it uses something the specialised epilogues leave out
 inline int epi_mask_of(const UiaGemmParams& p) {
-    if (p.alpha != 1.0f || p.out_group > 0 || p.resid_mod > 0) return EPI_GENERIC;
-    if ((p.act && p.act != UIA_ACT_GELU) || (p.dact && p.dact != UIA_ACT_GELU)) return EPI_GENERIC;
-    return (p.bias ? EPI_BIAS : 0) | (p.aux_out ? EPI_AUX_OUT : 0) | (p.act ? EPI_GELU : 0) | (p.dact ? EPI_DGELU : 0) | (p.resid ? EPI_RESID : 0) |
+    if (p.alpha != 1.0f || p.out_group > 0 || p.resid_mod > 0 || p.drop_where == 2) return EPI_GENERIC;
+    const bool quick = p.act == UIA_ACT_QUICKGELU || p.dact == UIA_ACT_QUICKGELU;
+    if ((p.act && p.act != UIA_ACT_GELU && p.act != UIA_ACT_QUICKGELU) || (p.dact && p.dact != UIA_ACT_GELU && p.dact != UIA_ACT_QUICKGELU) ||
+        (p.act && p.dact && p.act != p.dact)) return EPI_GENERIC;
+    return (quick ? EPI_QUICK : 0) | (p.bias ? EPI_BIAS : 0) | (p.aux_out ? EPI_AUX_OUT : 0) | (p.act ? EPI_GELU : 0) | (p.dact ? EPI_DGELU : 0) | (p.resid ? EPI_RESID : 0) |
            ((p.resid && p.resid_ln_stats) ? EPI_RESID_LN : 0) | (p.rowsum_out ? EPI_ROWSUM : 0) | (p.lnfold_sums ? EPI_LNFOLD : 0) |
            (p.residT ? EPI_RESIDT : 0) | (p.out32 ? EPI_OUT32 : 0) | (p.outT ? EPI_OUTT : 0);
 }
@@ -1436,6 +1549,10 @@ int launch_ring(hipStream_t stream, const UiaGemmParams& p, bool specialise, int
             UIA_EPI_CASE(EPI_BIAS | EPI_GELU | EPI_OUTT);                      // fc1, frozen tower
             UIA_EPI_CASE(EPI_DGELU | EPI_OUTT);                                // fc2 dgrad through GELU'
             UIA_EPI_CASE(EPI_BIAS | EPI_GELU | EPI_AUX_OUT | EPI_OUTT);        // fc1 with the pre-activation stashed
+            // the same three with QuickGELU (OpenAI CLIP towers; on the run-time epilogue fc1 of ViT-L/14 took 410 us against 275 for fc2's 4x longer K)
+            UIA_EPI_CASE(EPI_QUICK | EPI_BIAS | EPI_GELU | EPI_OUTT);
+            UIA_EPI_CASE(EPI_QUICK | EPI_DGELU | EPI_OUTT);
+            UIA_EPI_CASE(EPI_QUICK | EPI_BIAS | EPI_GELU | EPI_AUX_OUT | EPI_OUTT);
             // LayerNorm folded into its neighbours (bf16 step): producers write fp32 + T rows and their row sums, consumers normalise the accumulators
             UIA_EPI_CASE(EPI_BIAS | EPI_RESID | EPI_OUT32 | EPI_OUTT | EPI_ROWSUM);                  // proj / fc2 / Mona project2
             UIA_EPI_CASE(EPI_BIAS | EPI_RESID | EPI_RESID_LN | EPI_OUT32 | EPI_OUTT | EPI_ROWSUM);   // BERT sub-layer sums
@@ -1497,6 +1614,9 @@ __global__ __launch_bounds__(512) void gemm_skinny64_kernel(const UiaGemmParams 
 #pragma unroll
         for (int r = 0; r < 4; ++r) bias[nt][r] = p.bias ? p.bias[16 * nt + 4 * g + r] : 0.f;
     const char* wfrag = smem + li * ldw_b + g * 16;        // W row 16nt + li, bytes 64ks + 16g: + nt·16·ldw_b + ks·64
+    const bool drop_a = p.drop_where == 1;
+    const uint32_t drop_th = dropout_thresh16(p.drop_p);
+    const float drop_inv = 1.0f / (1.0f - p.drop_p);
     const int ntiles = (p.M + 15) >> 4;
     for (int tile = blockIdx.x * 8 + wave; tile < ntiles; tile += gridDim.x * 8) {
         const int m = 16 * tile + li;
@@ -1507,6 +1627,19 @@ __global__ __launch_bounds__(512) void gemm_skinny64_kernel(const UiaGemmParams 
             uint4 a[CH];
 #pragma unroll
             for (int i = 0; i < CH; ++i) a[i] = ks0 + i < KS ? *(const uint4*)(arow + (ks0 + i) * 64) : uint4{0u, 0u, 0u, 0u};
+            if (drop_a) {                                  // LoRA input dropout on the operand in flight: what uia_dropout would have written, bit for bit
+#pragma unroll
+                for (int i = 0; i < CH; ++i) {
+                    if (ks0 + i < KS) {
+                        const uint32_t keep = dropout_keep8(p.drop_seed, (uint32_t)(((size_t)mc * (size_t)K + (size_t)((ks0 + i) * 32 + g * 8)) >> 3), drop_th);
+                        bf16x8 v = __builtin_bit_cast(bf16x8, a[i]);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((keep >> e) & 1u ? (float)v[e] * drop_inv : 0.f);
+                        a[i] = __builtin_bit_cast(uint4, v);
+                        if (p.a_drop_out && m < p.M) *(uint4*)((char*)p.a_drop_out + ((size_t)m * p.lda) * 2 + g * 16 + (ks0 + i) * 64) = a[i];
+                    }
+                }
+            }
 #pragma unroll
             for (int i = 0; i < CH; ++i) {
                 if (ks0 + i < KS) {
@@ -1531,7 +1664,7 @@ __global__ __launch_bounds__(512) void gemm_skinny64_kernel(const UiaGemmParams 
 
 // cfg 16 takes: bf16, N == 64, K % 32 == 0 with the W image inside the LDS, and nothing in the epilogue but an optional bias and the T output
 inline bool skinny64_ok(const UiaGemmParams& p, int esz) {
-    return esz == 2 && p.N == 64 && p.K % 32 == 0 && 64 * (2 * p.K + 16) <= 160 * 1024 && p.alpha == 1.0f && p.outT && !p.out32 && !p.act && !p.dact &&
+    return esz == 2 && p.N == 64 && p.K % 32 == 0 && 64 * (2 * p.K + 16) <= 160 * 1024 && p.alpha == 1.0f && p.outT && !p.out32 && !p.act && !p.dact && p.drop_where != 2 &&
            !p.aux_out && !p.resid && !p.residT && p.out_group == 0 && !p.w_kblocked && !p.rowsum_out && !p.lnfold_sums;
 }
 
@@ -1559,13 +1692,19 @@ int launch_typed(hipStream_t stream, const UiaGemmParams& p, int cfg_in) {
     // cfg: 0 = auto. Tile choice is a pure speed knob (results are identical for every config
     // up to fp32 summation order inside a K-step, which does not depend on the tile).
     if (cfg == 0) {
-        if (p.N <= 64) cfg = (p.M > 2048 && skinny64_ok(p, (int)sizeof(T))) ? 16 : 4;
-        else if (p.M <= 2048) cfg = 3;
+        if (p.N <= 64) cfg = ((p.M > 2048 || p.drop_where == 1) && skinny64_ok(p, (int)sizeof(T))) ? 16 : 4;
+        else if (p.M <= 2048) cfg = (sizeof(T) == 4 && ((p.M + 127) / 128) * ((p.N + 127) / 128) < 64) ? 21 : 3;
+            // fp32 MFMA issues 256 FLOP per clock per CU: the 8-12 workgroups of a [256, 512-768] head projection on 128 x 128 tiles were bound
+            // by their own CUs' matrix pipes (69 us at K = 768); 32 x 64 tiles spread the same MFMA sequence per element over 64-96 CUs
         else if (p.K * (int)sizeof(T) <= 128) cfg = 14;   // one K step (Mona project2 / project1-dgrad, K = 64): nothing but prologue + epilogue, HBM-bound:
                                                           // half-height tiles, two workgroups per CU (70.9 vs 86.6 us and 20.0 vs 26.3 us at M = 50 432)
         else cfg = 8;            // 256x256 ping-pong, 4-deep 64-byte ring, LDS-staged epilogue: best measured on every large shape.
                                  // (cfg 12, the persistent variant, is +2-3.5 % on store-only epilogues in isolation, -15-25 % on the
                                  //  fp32-residual ones, and a net loss inside the two-stream training step: opt-in only.)
+    }
+    if (p.drop_where == 1 && cfg != 16) {
+        uia_set_error("uia_gemm: dropout on the A operand (drop_where = 1) is the N = 64 stream kernel's (tile cfg 16: bf16, N == 64, M > 2048, bias + T output only), not tile cfg %d", cfg);
+        return -1;
     }
     const bool ring = cfg == 8 || cfg == 9 || cfg == 10 || cfg == 12 || cfg == 13 || cfg == 14 || cfg == 15 || (cfg >= 17 && cfg <= 20);
     if ((p.a_kb_rows || p.outT_kb_rows) && !(cfg == 8 || cfg == 10 || cfg == 12 || cfg == 13 || cfg == 14 || cfg == 15 || (cfg >= 17 && cfg <= 20))) {
@@ -1594,6 +1733,7 @@ int launch_typed(hipStream_t stream, const UiaGemmParams& p, int cfg_in) {
         case 3: return launch_cfg<T, 128, 128, 2, 2>(stream, p);
         case 4: return launch_cfg<T, 256, 64, 4, 1>(stream, p);
         case 5: return launch_cfg<T, 128, 64, 2, 1>(stream, p);
+        case 21: return launch_cfg<T, 32, 64, 2, 2>(stream, p);
         case 6: return launch_pp<T, 256, 256, 2, 4>(stream, p);
         case 7: return launch_pp<T, 256, 128, 4, 2>(stream, p);
         case 8: return launch_ring<T, 256, 256, 2, 4, 64, 4>(stream, p, true, xflags);
@@ -1654,6 +1794,12 @@ int uia_gemm_launch(hipStream_t stream, int dtype, const UiaGemmParams& p, int c
     UIA_CHECK_ARG(!p.rowsum_out || ((uintptr_t)p.rowsum_out % 16 == 0 && p.out_group == 0), "uia_gemm: rowsum_out must be 16-byte aligned and takes no row remapping");
     UIA_CHECK_ARG(!(p.resid_ln_stats && p.resid_ln_dim > 0) || (uintptr_t)p.resid_ln_stats % 16 == 0, "uia_gemm: row sums behind resid_ln_stats must be 16-byte aligned");
     UIA_CHECK_ARG(!p.ln_flag || (uintptr_t)p.ln_flag % 4 == 0, "uia_gemm: ln_flag must be a 4-byte aligned device word");
+    UIA_CHECK_ARG(p.drop_where >= 0 && p.drop_where <= 2, "uia_gemm: drop_where=%d (0 none, 1 A operand, 2 accumulator)", p.drop_where);
+    UIA_CHECK_ARG(p.drop_where == 0 || (p.drop_p >= 0.f && p.drop_p < 1.f), "uia_gemm: drop_p=%f outside [0, 1)", (double)p.drop_p);
+    UIA_CHECK_ARG(p.drop_where != 1 || (dtype == UIA_BF16 && (size_t)p.M * (size_t)p.K / 8 <= 0xFFFFFFFFull && (uintptr_t)p.a_drop_out % 16 == 0 && !p.a_kb_rows),
+                  "uia_gemm: dropout on the A operand needs bf16, row-major A, M*K <= 2^35 and a 16-byte aligned a_drop_out");
+    UIA_CHECK_ARG(p.drop_where != 2 || (size_t)p.M * (size_t)p.N / 8 <= 0xFFFFFFFFull, "uia_gemm: dropout on the accumulator needs M*N <= 2^35");
+    UIA_CHECK_ARG(p.drop_where == 1 || !p.a_drop_out, "uia_gemm: a_drop_out without drop_where = 1");
     UIA_CHECK_ARG(!p.lnfold_sums || (p.lnfold_colsum && p.lnfold_dim > 0 && p.alpha == 1.0f && (uintptr_t)p.lnfold_sums % 16 == 0 && (uintptr_t)p.lnfold_colsum % 16 == 0),
                   "uia_gemm: lnfold_sums needs lnfold_colsum (16-byte aligned), lnfold_dim > 0 and alpha == 1");
     // every row the epilogue touches must hold N elements: a leading dimension below N would make row m's tail overwrite row m+1

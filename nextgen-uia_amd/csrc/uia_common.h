@@ -194,6 +194,25 @@ __device__ __forceinline__ uint32_t uia_hash32(uint32_t x) {
     x ^= x >> 16;
     return x;
 }
+// Eight consecutive elements per draw (the LoRA input dropout: uia_dropout, the N = 64 stream kernel's A operand, the run-time GEMM
+// epilogue): bit e of the result = keep element 8·grp + e.  Five hashes per group instead of three per element — the stand-alone pass
+// was bound by its integer arithmetic (34 us for 134 MB), and a fused mask must not cost more than the pass it replaces.
+// thresh16 = round(p · 65536): the drop probability is quantised to 1/65536.
+__device__ __forceinline__ uint32_t dropout_keep8(uint64_t seed, uint32_t grp, uint32_t thresh16) {
+    const uint32_t base = uia_hash32(grp ^ (uint32_t)seed) + (uint32_t)(seed >> 32);
+    uint32_t m = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t h = uia_hash32(base + (uint32_t)q * 0x9E3779B9U);
+        m |= ((h & 0xFFFFu) >= thresh16 ? 1u : 0u) << (2 * q);
+        m |= ((h >> 16) >= thresh16 ? 1u : 0u) << (2 * q + 1);
+    }
+    return m;
+}
+__host__ __device__ inline uint32_t dropout_thresh16(float p) {
+    const float t = p * 65536.0f + 0.5f;
+    return t <= 0.f ? 0u : (t >= 65535.f ? 65535u : (uint32_t)t);
+}
 __device__ __forceinline__ bool dropout_keep(uint64_t seed, uint32_t idx, uint32_t thresh) {
     // thresh = floor(p * 2^32); keep iff hash >= thresh
     uint32_t h = uia_hash32(idx ^ (uint32_t)seed) ^ uia_hash32((idx * 0x9E3779B9U) + (uint32_t)(seed >> 32));

@@ -38,7 +38,7 @@ constexpr int CHUNK_SLABS = WG_CHUNK_SLABS;       // slabs per workgroup → 512
 // ---- bf16: slabs are [128][128 B] images, 32-B column groups swizzled by (row>>1)&3
 __global__ __launch_bounds__(256) void wgrad_bf16_kernel(int M, int I, int J, const bf16_t* __restrict__ A, long lda,
                                                           const bf16_t* __restrict__ B, long ldb, float alpha,
-                                                          float* __restrict__ dW, float* __restrict__ dbias) {
+                                                          float* __restrict__ dW, float* __restrict__ dbias, long ldw, int i_valid, int j_valid) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* As = smem;                  // 16 KiB
     char* Bs = smem + SLAB * 128;     // 16 KiB
@@ -139,7 +139,8 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(int M, int I, int J, co
 #ifndef WG_NO_ATOMIC
     for (int e = tid; e < 4096; e += 256) {
         const float v = red[e] + red[4096 + e];
-        atomicAdd(dW + (size_t)(ti * 64 + (e >> 6)) * J + tj * 64 + (e & 63), v * alpha);
+        const int i = ti * 64 + (e >> 6), j = tj * 64 + (e & 63);      // rows / columns past the valid extent are the caller's zero padding (LoRA rank)
+        if (i < i_valid && j < j_valid) atomicAdd(dW + (size_t)i * ldw + j, v * alpha);
     }
 #endif
     if (want_bias) {              // every column of bacc[a] holds Σ_m A[m][16a + 4g + r]: column 0 of each wave → LDS → one atomic per element
@@ -151,14 +152,14 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(int M, int I, int J, co
                 for (int r = 0; r < 4; ++r) red[wave * 64 + 16 * a + 4 * g + r] = bacc[a][r];
         }
         __syncthreads();
-        if (tid < 64) atomicAdd(dbias + ti * 64 + tid, (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]));
+        if (tid < 64 && ti * 64 + tid < i_valid) atomicAdd(dbias + ti * 64 + tid, (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]));
     }
 }
 
 // ---- fp32: 16x16x4 MFMA straight from global (parity path; not tuned)
 __global__ __launch_bounds__(256) void wgrad_f32_kernel(int M, int I, int J, const float* __restrict__ A, long lda,
                                                          const float* __restrict__ B, long ldb, float alpha,
-                                                         float* __restrict__ dW, float* __restrict__ dbias) {
+                                                         float* __restrict__ dW, float* __restrict__ dbias, long ldw, int i_valid, int j_valid) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -200,7 +201,8 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(int M, int I, int J, con
     __syncthreads();
     for (int e = tid; e < 4096; e += 256) {
         const float v = red[e] + red[4096 + e] + red[8192 + e] + red[12288 + e];
-        atomicAdd(dW + (size_t)(ti * 64 + (e >> 6)) * J + tj * 64 + (e & 63), v * alpha);
+        const int i = ti * 64 + (e >> 6), j = tj * 64 + (e & 63);
+        if (i < i_valid && j < j_valid) atomicAdd(dW + (size_t)i * ldw + j, v * alpha);
     }
     if (dbias && tj == 0) {   // separate simple pass: thread = column, quarter of the chunk's rows
         const int col = tid & 63, part = tid >> 6;
@@ -209,20 +211,22 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(int M, int I, int J, con
         __syncthreads();
         red[tid] = s;
         __syncthreads();
-        if (tid < 64) atomicAdd(dbias + ti * 64 + tid, red[tid] + red[64 + tid] + red[128 + tid] + red[192 + tid]);
+        if (tid < 64 && ti * 64 + tid < i_valid) atomicAdd(dbias + ti * 64 + tid, red[tid] + red[64 + tid] + red[128 + tid] + red[192 + tid]);
     }
 }
 
 }  // namespace
 
 int uia_wgrad_launch(hipStream_t stream, int dtype, int M, int I, int J, const void* A, long lda, const void* B, long ldb, float alpha,
-                     float* dW, float* dbias) {
+                     float* dW, float* dbias, long ldw, int i_valid, int j_valid) {
+    if (ldw == 0) { ldw = J; i_valid = I; j_valid = J; }              // the plain form: a dense [I, J] gradient
     UIA_CHECK_ARG(dtype == UIA_BF16 || dtype == UIA_F32, "uia_wgrad: bad dtype %d", dtype);
     UIA_CHECK_ARG(M > 0 && I > 0 && J > 0 && I % 64 == 0 && J % 64 == 0, "uia_wgrad: I=%d and J=%d must be multiples of 64 (M=%d)", I, J, M);
     UIA_CHECK_ARG(A && B && dW, "uia_wgrad: null tensor");
     const int esz = dtype == UIA_BF16 ? 2 : 4;
     UIA_CHECK_ARG((lda * esz) % 16 == 0 && (ldb * esz) % 16 == 0 && (uintptr_t)A % 16 == 0 && (uintptr_t)B % 16 == 0, "uia_wgrad: alignment");
     UIA_CHECK_ARG(lda >= I && ldb >= J, "uia_wgrad: leading dimension too small");
+    UIA_CHECK_ARG(i_valid > 0 && i_valid <= I && j_valid > 0 && j_valid <= J && ldw >= j_valid, "uia_wgrad: valid extent %d x %d (ldw %ld) outside the padded %d x %d", i_valid, j_valid, ldw, I, J);
     const int chunks = (M + SLAB * CHUNK_SLABS - 1) / (SLAB * CHUNK_SLABS);
     const dim3 grid_f32((I / 64) * (J / 64), chunks);
     const dim3 grid(8 * ((chunks + 7) / 8) * (I / 64) * (J / 64));          // bf16 kernel: 1-D, chunks dealt to XCDs (see the kernel)
@@ -232,9 +236,9 @@ int uia_wgrad_launch(hipStream_t stream, int dtype, int M, int I, int J, const v
     UIA_ENSURE_LDS_ATTR(once_bf16, wgrad_bf16_kernel, lds_bf16);
     UIA_ENSURE_LDS_ATTR(once_f32, wgrad_f32_kernel, lds);
     if (dtype == UIA_BF16)
-        hipLaunchKernelGGL(wgrad_bf16_kernel, grid, dim3(256), lds_bf16, stream, M, I, J, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, alpha, dW, dbias);
+        hipLaunchKernelGGL(wgrad_bf16_kernel, grid, dim3(256), lds_bf16, stream, M, I, J, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, alpha, dW, dbias, ldw, i_valid, j_valid);
     else
-        hipLaunchKernelGGL(wgrad_f32_kernel, grid_f32, dim3(256), lds, stream, M, I, J, (const float*)A, lda, (const float*)B, ldb, alpha, dW, dbias);
+        hipLaunchKernelGGL(wgrad_f32_kernel, grid_f32, dim3(256), lds, stream, M, I, J, (const float*)A, lda, (const float*)B, ldb, alpha, dW, dbias, ldw, i_valid, j_valid);
     UIA_CHECK_LAUNCH();
     return 0;
 }

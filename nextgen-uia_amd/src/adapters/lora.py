@@ -66,7 +66,9 @@ class LinearLoRA(nn.Linear, LoRALayer):
     def apply_rows(self, x2d, resid32=None):
         """x2d: [M, in] in the compute dtype → [M, out] (T, or fp32 when the fp32 residual is fused)."""
         if self.r > 0:
-            return UF.LoraLinearFn.apply(x2d, self.weight, self.bias, self.w_lora_A, self.w_lora_B, self.scaling, self._drop_p(), resid32)
+            trainable = [p for p in (self.w_lora_A, self.w_lora_B, self.bias) if p is not None]
+            direct = torch.is_grad_enabled() and all(p.requires_grad and UF._is_flat_grad(p) for p in trainable)
+            return UF.LoraLinearFn.apply(x2d, self.weight, self.bias, self.w_lora_A, self.w_lora_B, self.scaling, self._drop_p(), resid32, direct)
         empty = x2d.new_zeros(0, x2d.shape[1], dtype=torch.float32)
         return UF.LoraLinearFn.apply(x2d, self.weight, self.bias, empty, empty.new_zeros(self.out_features, 0), 0.0, 0.0, resid32)
 

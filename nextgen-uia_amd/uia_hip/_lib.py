@@ -23,7 +23,8 @@ vp, i32, i64, f32, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
 
 class PackDesc(C.Structure):
     """uia_pack_desc (include/uia_hip.h): one small trainable matrix and the operand forms to derive from it."""
-    _fields_ = [("src", vp), ("row", vp), ("row_kb", vp), ("tr", vp), ("tr_kb", vp), ("rows", i32), ("cols", i32)]
+    _fields_ = [("src", vp), ("row", vp), ("row_kb", vp), ("tr", vp), ("tr_kb", vp), ("rows", i32), ("cols", i32),
+                ("rows_pad", i32), ("cols_pad", i32), ("scale", f32), ("reserved_", i32)]
 
 
 class GemmDesc(C.Structure):
@@ -33,7 +34,8 @@ class GemmDesc(C.Structure):
                 ("out_group", i32), ("outT", vp), ("ldo", i64), ("out32", vp), ("ldo32", i64), ("w_kblocked", i32),
                 ("resid_ln_stats", vp), ("resid_ln_w", vp), ("resid_ln_b", vp),
                 ("rowsum_out", vp), ("lnfold_sums", vp), ("lnfold_colsum", vp), ("lnfold_dim", i32), ("lnfold_eps", f32),
-                ("resid_ln_dim", i32), ("resid_ln_eps", f32), ("a_kb_rows", i64), ("outT_kb_rows", i64), ("ln_flag", vp), ("ln_flag_limit", f32)]
+                ("resid_ln_dim", i32), ("resid_ln_eps", f32), ("a_kb_rows", i64), ("outT_kb_rows", i64), ("ln_flag", vp), ("ln_flag_limit", f32),
+                ("drop_where", i32), ("drop_p", f32), ("drop_seed", C.c_uint64), ("a_drop_out", vp)]
 
 
 class AttnDesc(C.Structure):
@@ -67,6 +69,7 @@ PROTOTYPES = {
     "uia_version": (C.c_int, []),
     "uia_gemm": (C.c_int, [vp, C.c_int, C.POINTER(GemmDesc), C.c_int]),
     "uia_wgrad": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, vp, i64, f32, vp, vp]),
+    "uia_wgrad_ex": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, vp, i64, f32, vp, i64, C.c_int, C.c_int, vp]),
     "uia_attn_fwd": (C.c_int, [vp, C.c_int, C.POINTER(AttnDesc)]),
     "uia_attn_bwd": (C.c_int, [vp, C.c_int, C.POINTER(AttnDesc)]),
     "uia_layernorm_fwd": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, i64, vp, vp, vp, f32, vp, vp]),

@@ -221,21 +221,25 @@ def take_rows(x32, dt):
 
 # ------------------------------------------------------------------------------------------------
 class _PackedParam:
-    """All GEMM-operand forms of one small trainable matrix, refreshed in place by uia_pack_weights."""
-    __slots__ = ("ref", "version", "epoch", "dt", "row", "row_kb", "tr", "tr_kb", "fwd", "bwd", "src_ptr")
+    """All GEMM-operand forms of one small trainable matrix, refreshed in place by uia_pack_weights.  With `pads` = (rows_pad, cols_pad) the
+    forms hold the matrix zero-padded to that extent (a LoRA factor's rank 16 -> 64): the buffers are zeroed once and every refresh writes the
+    parameter's own elements only."""
+    __slots__ = ("ref", "version", "epoch", "dt", "row", "row_kb", "tr", "tr_kb", "fwd", "bwd", "src_ptr", "pads")
 
-    def __init__(self, p, dt):
+    def __init__(self, p, dt, pads=None):
         R, Cc = p.shape
+        RP, CP = pads if pads is not None else (R, Cc)
         g = 64 // torch.empty(0, dtype=dt).element_size()
-        mk = lambda *shape: torch.empty(shape, device=p.device, dtype=dt)
-        self.ref, self.version, self.epoch, self.dt, self.src_ptr = weakref.ref(p), -1, -1, dt, 0
-        self.row, self.tr = mk(R, Cc), mk(Cc, R)
-        self.row_kb = mk(Cc // g, R, g) if Cc % g == 0 else None
-        self.tr_kb = mk(R // g, Cc, g) if R % g == 0 else None
+        mk = (lambda *shape: torch.zeros(shape, device=p.device, dtype=dt)) if pads is not None else (lambda *shape: torch.empty(shape, device=p.device, dtype=dt))
+        self.ref, self.version, self.epoch, self.dt, self.src_ptr, self.pads = weakref.ref(p), -1, -1, dt, 0, pads
+        self.row, self.tr = mk(RP, CP), mk(CP, RP)
+        self.row_kb = mk(CP // g, RP, g) if CP % g == 0 else None
+        self.tr_kb = mk(RP // g, CP, g) if RP % g == 0 else None
         self.fwd, self.bwd = ops.PackedW(self.row, self.row_kb), ops.PackedW(self.tr, self.tr_kb)
 
     def entry(self):
-        return (self.ref().detach(), self.row, self.row_kb, self.tr, self.tr_kb)
+        ent = (self.ref().detach(), self.row, self.row_kb, self.tr, self.tr_kb)
+        return ent if self.pads is None else ent + ((self.pads[0], self.pads[1], 1.0),)
 
 
 class WeightCache:
@@ -289,10 +293,11 @@ class WeightCache:
                 if len(groups) == 1:
                     self._table = t
 
-    def _packed_get(self, p, dt, transpose):
+    def _packed_get(self, p, dt, transpose, pads=None):
         it = self._packed.get(id(p))
-        if it is None or it.ref() is not p or it.dt != dt or it.row.device != p.device or tuple(it.row.shape) != tuple(p.shape):
-            it = _PackedParam(p, dt)
+        want = tuple(pads) if pads is not None else tuple(p.shape)
+        if it is None or it.ref() is not p or it.dt != dt or it.row.device != p.device or tuple(it.row.shape) != want or it.pads != pads:
+            it = _PackedParam(p, dt, pads)
             self._packed[id(p)] = it
             self._table = None
         if it.version != p._version or it.epoch != self.epoch:
@@ -320,9 +325,11 @@ class WeightCache:
         return out
 
     def get(self, p, dt, transpose=False, pad_rows_to=None, pad_cols_to=None):
-        if (p.requires_grad and dt != torch.float32 and pad_rows_to is None and pad_cols_to is None and p.dim() == 2 and p.is_cuda
-                and p.dtype == torch.float32 and p.is_contiguous() and p.numel() <= self.PACK_MAX_ELEMS):
-            return self._packed_get(p, dt, transpose)
+        padded = pad_rows_to is not None or pad_cols_to is not None
+        if (p.requires_grad and (dt != torch.float32 or padded) and p.dim() == 2 and p.is_cuda
+                and p.dtype == torch.float32 and p.is_contiguous() and 0 < p.numel() <= self.PACK_MAX_ELEMS):
+            pads = (max(p.shape[0], pad_rows_to or 0), max(p.shape[1], pad_cols_to or 0)) if padded else None
+            return self._packed_get(p, dt, transpose, pads)
         key = (id(p), dt, transpose, pad_rows_to, pad_cols_to)
         hit = self._c.get(key)
         if hit is not None and hit[0] == p._version and hit[1]() is p and hit[2].row.device == p.device and (not p.requires_grad or hit[3] == self.epoch):
@@ -912,10 +919,15 @@ def _rank_pad(r):
 class LoraLinearFn(torch.autograd.Function):
     """y = x·Wᵀ + b + s·drop(x)·Aᵀ·Bᵀ (+ resid32)  in RANK form (never materialises B·A; reference lora.py:78-90 does).
     x: [M, in] T.  Output: T, or fp32 when an fp32 residual is fused in.  W frozen; A, B (and the bias, reference quirk
-    SURVEY Appendix C-4) trainable."""
+    SURVEY Appendix C-4) trainable.
+
+    Launches per call (bf16): forward — frozen GEMM, the N = 64 stream kernel with the input dropout applied to its operand in flight
+    (the dropped rows leave as a by-product for dA), the rank GEMM onto the result; backward — frozen dgrad, q = dy·B, s·q·A with the
+    dropout's backward in its epilogue, two weight gradients accumulated straight into the factors' .grad when those are views of the
+    engine's flat buffer (`direct`).  The factors' padded operand forms come from WEIGHTS (one batched uia_pack_weights per step)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, A, Bm, scaling, p_drop, resid32):
+    def forward(ctx, x, weight, bias, A, Bm, scaling, p_drop, resid32, direct=False):
         dt = x.dtype
         M, K = x.shape
         N = weight.shape[0]
@@ -925,23 +937,29 @@ class LoraLinearFn(torch.autograd.Function):
         ops.gemm(x, WEIGHTS.get(weight, dt), bias=bias, resid=resid32, out32=y32, out_t=y_t)
         seed = 0
         xd = x
-        if p_drop > 0:
-            seed = _next_seed()
-            xd = torch.empty_like(x)
-            ops.dropout(x, xd, p_drop, seed)
+        t = None
         if r > 0:
             rp = _rank_pad(r)
             t = _empty((M, rp), dt, x)
-            ops.gemm(xd, WEIGHTS.get(A, dt, pad_rows_to=rp), out_t=t)
-            bmat = _pad_cols(Bm, dt)                                                # [N, rp]
+            a_op = WEIGHTS.get(A, dt, pad_rows_to=rp)
+            fuse = p_drop > 0 and dt == torch.bfloat16 and rp == 64 and x.is_cuda and x.is_contiguous() and 64 * (2 * K + 16) <= 160 * 1024 and K % 32 == 0
+            if p_drop > 0:
+                seed = _next_seed()
+                xd = torch.empty_like(x)
+                if not fuse:
+                    ops.dropout(x, xd, p_drop, seed)
+            if fuse:
+                ops.gemm(x, a_op.row, out_t=t, drop=("a", p_drop, seed, xd))
+            else:
+                ops.gemm(xd, a_op, out_t=t)
+            bmat = WEIGHTS.get(Bm, dt, pad_cols_to=rp)                              # [N, rp]
             if y32 is not None:
                 ops.gemm(t, bmat, alpha=scaling, resid=y32, out32=y32)
             else:
                 ops.gemm(t, bmat, alpha=scaling, resid_t=y_t, out_t=y_t)
-        else:
-            t = None
         ctx.save_for_backward(xd, t if t is not None else x.new_empty(0), weight, A, Bm)
         ctx.meta = (scaling, p_drop, seed, r, bias is not None, resid32 is not None)
+        ctx.direct_params = (A, Bm, bias) if direct else None                       # the Parameter objects: .grad is looked up at BACKWARD time
         return y32 if y32 is not None else y_t
 
     @staticmethod
@@ -956,26 +974,32 @@ class LoraLinearFn(torch.autograd.Function):
         dx = _empty((M, K), dt, xd)
         ops.gemm(dy_t, WEIGHTS.get(weight, dt, transpose=True), out_t=dx)
         dA = dB = db = None
+        pA, pB, pb = ctx.direct_params if ctx.direct_params is not None else (None, None, None)
+        direct = pA is not None and _is_flat_grad(pA) and _is_flat_grad(pB) and (pb is None or not has_bias or _is_flat_grad(pb))
         if r > 0:
             rp = _rank_pad(r)
             q = _empty((M, rp), dt, xd)
-            ops.gemm(dy_t, _pad_cols(Bm, dt, transpose=True), out_t=q)              # q = dy·B   [M, rp]
-            at = _pad_cols(A, dt, transpose=True, rows=True)                        # Aᵀ padded: [K, rp]
+            ops.gemm(dy_t, WEIGHTS.get(Bm, dt, transpose=True, pad_cols_to=rp), out_t=q)     # q = dy·B   [M, rp]
+            at = WEIGHTS.get(A, dt, transpose=True, pad_rows_to=rp)                          # Aᵀ padded: [K, rp]
             if p_drop > 0:
-                dxd = _empty((M, K), dt, xd)
-                ops.gemm(q, at, alpha=scaling, out_t=dxd)
-                ops.dropout(dxd, dx, p_drop, seed, accumulate=True)
+                ops.gemm(q, at, alpha=scaling, resid_t=dx, out_t=dx, drop=("acc", p_drop, seed))
             else:
                 ops.gemm(q, at, alpha=scaling, resid_t=dx, out_t=dx)
-            gB = torch.zeros(N, rp, device=xd.device, dtype=torch.float32)
-            ops.wgrad(dy_t, t, gB, alpha=scaling)
-            gA = torch.zeros(rp, K, device=xd.device, dtype=torch.float32)
-            ops.wgrad(q, xd, gA, alpha=scaling)
-            dB, dA = gB[:, :r].contiguous(), gA[:r].contiguous()
+            if direct:
+                ops.wgrad(dy_t, t, pB.grad, alpha=scaling)
+                ops.wgrad(q, xd, pA.grad, alpha=scaling)
+            else:
+                dB = torch.zeros(N, r, device=xd.device, dtype=torch.float32)
+                ops.wgrad(dy_t, t, dB, alpha=scaling)
+                dA = torch.zeros(r, K, device=xd.device, dtype=torch.float32)
+                ops.wgrad(q, xd, dA, alpha=scaling)
         if has_bias and ctx.needs_input_grad[2]:
-            db = torch.zeros(N, device=xd.device, dtype=torch.float32)
-            ops.colsum(dy_t, db)
-        return dx, None, db, dA, dB, None, None, (dy if has_resid else None)
+            if direct and pb is not None:
+                ops.colsum(dy_t, pb.grad)
+            else:
+                db = torch.zeros(N, device=xd.device, dtype=torch.float32)
+                ops.colsum(dy_t, db)
+        return dx, None, db, dA, dB, None, None, (dy if has_resid else None), None
 
 
 def _pad_cols(p, dt, transpose=False, rows=False):

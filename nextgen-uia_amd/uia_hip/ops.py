@@ -19,9 +19,11 @@ GEMM_PROFILE = None
 
 
 EPI_BIAS, EPI_AUX_OUT, EPI_GELU, EPI_DGELU, EPI_RESID, EPI_RESIDT, EPI_OUT32, EPI_OUTT, EPI_RESID_LN, EPI_GENERIC = 1, 2, 4, 8, 16, 32, 64, 128, 256, -1
+EPI_QUICK = 2048
 EPI_ROWSUM, EPI_LNFOLD = 512, 1024
 _SPECIALISED = {EPI_BIAS | EPI_RESID | EPI_OUT32, EPI_BIAS | EPI_RESIDT | EPI_OUT32, EPI_BIAS | EPI_RESID | EPI_RESID_LN | EPI_OUT32, EPI_OUTT, EPI_BIAS | EPI_OUTT, EPI_BIAS | EPI_GELU | EPI_OUTT, EPI_DGELU | EPI_OUTT,
                 EPI_BIAS | EPI_GELU | EPI_AUX_OUT | EPI_OUTT,
+                EPI_QUICK | EPI_BIAS | EPI_GELU | EPI_OUTT, EPI_QUICK | EPI_DGELU | EPI_OUTT, EPI_QUICK | EPI_BIAS | EPI_GELU | EPI_AUX_OUT | EPI_OUTT,
                 EPI_BIAS | EPI_RESID | EPI_OUT32 | EPI_OUTT | EPI_ROWSUM, EPI_BIAS | EPI_RESID | EPI_RESID_LN | EPI_OUT32 | EPI_OUTT | EPI_ROWSUM,
                 EPI_BIAS | EPI_OUTT | EPI_LNFOLD, EPI_BIAS | EPI_GELU | EPI_OUTT | EPI_LNFOLD, EPI_BIAS | EPI_GELU | EPI_AUX_OUT | EPI_OUTT | EPI_LNFOLD}
 
@@ -30,9 +32,11 @@ def epi_mask_of(d):
     """Mirror of epi_mask_of() in csrc/gemm.hip: the compile-time epilogue instantiation a descriptor lands on."""
     if d.alpha != 1.0 or d.out_group > 0 or d.resid_mod > 0:
         return EPI_GENERIC
-    if (d.act and d.act != _ACT["gelu"]) or (d.dact and d.dact != _ACT["gelu"]):
+    gl = (_ACT["gelu"], _ACT["quick_gelu"])
+    if (d.act and d.act not in gl) or (d.dact and d.dact not in gl) or (d.act and d.dact and d.act != d.dact):
         return EPI_GENERIC
-    m = ((EPI_BIAS if d.bias else 0) | (EPI_AUX_OUT if d.aux_out else 0) | (EPI_GELU if d.act else 0) | (EPI_DGELU if d.dact else 0) |
+    quick = _ACT["quick_gelu"] in (d.act, d.dact)
+    m = ((EPI_QUICK if quick else 0) | (EPI_BIAS if d.bias else 0) | (EPI_AUX_OUT if d.aux_out else 0) | (EPI_GELU if d.act else 0) | (EPI_DGELU if d.dact else 0) |
          (EPI_RESID if d.resid else 0) | (EPI_RESIDT if d.residT else 0) | (EPI_OUT32 if d.out32 else 0) | (EPI_OUTT if d.outT else 0) |
          (EPI_RESID_LN if (d.resid and d.resid_ln_stats) else 0) | (EPI_ROWSUM if d.rowsum_out else 0) | (EPI_LNFOLD if d.lnfold_sums else 0))
     return m
@@ -44,7 +48,7 @@ def auto_tile_cfg(M, N, K=None, esz=2, mask=EPI_GENERIC):
         stream64 = N == 64 and M > 2048 and esz == 2 and K is not None and K % 32 == 0 and 64 * (2 * K + 16) <= 160 * 1024
         return 16 if (stream64 and mask in (EPI_OUTT, EPI_BIAS | EPI_OUTT)) else 4
     if M <= 2048:
-        return 3
+        return 21 if (esz == 4 and ((M + 127) // 128) * ((N + 127) // 128) < 64) else 3
     if K is not None and K * esz <= 128:
         return 14
     return 8
@@ -216,7 +220,7 @@ def gemm_kernel_name(cfg, mask, dtype):
         return f"gemm_tn_ring_kernel<{tn},{bm},256,2,4,64,{nbuf},{m}>", "gemm_tn_ring_kernelI" + tc + "".join(mi(v) for v in (bm, 256, 2, 4, 64, nbuf, m, 0)) + "E"
     if cfg == 16:
         return "gemm_skinny64_kernel", "gemm_skinny64_kernel"
-    shape = {1: (256, 256, 2, 4), 2: (256, 128, 4, 2), 3: (128, 128, 2, 2), 4: (256, 64, 4, 1), 5: (128, 64, 2, 1)}.get(cfg)
+    shape = {1: (256, 256, 2, 4), 2: (256, 128, 4, 2), 3: (128, 128, 2, 2), 4: (256, 64, 4, 1), 5: (128, 64, 2, 1), 21: (32, 64, 2, 2)}.get(cfg)
     if shape:
         return f"gemm_tn_kernel<{tn},{','.join(map(str, shape))}>", "gemm_tn_kernelI" + tc + "".join(mi(v) for v in shape) + "E"
     return f"tile cfg {cfg}", f"cfg{cfg}"
@@ -251,7 +255,7 @@ def _rowmajor(t, name):
 
 
 def gemm(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None, resid=None, resid_mod=0, resid_row_off=0,
-         resid_t=None, out_group=0, out_t=None, out32=None, alpha=1.0, tile_cfg=0, resid_ln=None, rowsum=None, lnfold=None):
+         resid_t=None, out_group=0, out_t=None, out32=None, alpha=1.0, tile_cfg=0, resid_ln=None, rowsum=None, lnfold=None, drop=None):
     """C = epilogue(alpha * a @ w.T).  a [M,K], w [N,K] (tensor or PackedW) share a dtype (bf16 | fp32); see include/uia_hip.h.
 
     Host-side scheduling on top of uia_gemm (results do not depend on it): with the automatic tile choice, a weight that came
@@ -259,6 +263,8 @@ def gemm(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None, res
     CUs idle goes through a second launch with half-height tiles (tail_split_rows).
     resid_ln = (stats [M, 2], ln_weight, ln_bias): `resid` is the INPUT of a LayerNorm whose output is the residual to add; a fourth and
     fifth element (dim, eps) say that `stats` holds the row sums (Σ, Σ²) a producing GEMM left through `rowsum`, not (mean, rstd).
+    drop = ("a", p, seed[, a_drop_out]): LoRA input dropout applied to `a` in flight (N = 64 stream kernel only; a_drop_out receives the dropped
+    rows), or ("acc", p, seed): applied to alpha·acc of element (m, n) before the residual adds — the generator of ops.dropout in both cases.
     rowsum = zeroed int64 [M, 2] (ROWSUM_SCALE fixed point; rowsum_to_float converts): receives (Σ, Σ²) of the stored fp32 rows.  lnfold = (sums [M, 2], colsum [N], dim, eps): `a` holds RAW
     rows and `w` is pre-scaled by the LayerNorm weight; the epilogue applies the LayerNorm (include/uia_hip.h, uia_gemm_desc)."""
     packed = w if isinstance(w, PackedW) else None
@@ -267,7 +273,7 @@ def gemm(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None, res
     Ka = wrow.shape[1]
     if not K64_CFG14 and tile_cfg == 0 and auto_tile_cfg(M, N, Ka, a.element_size()) == 14:
         tile_cfg = 8
-    if (TAIL_SPLIT and tile_cfg == 0 and out_group == 0 and resid_mod == 0 and a.is_cuda and auto_tile_cfg(M, N, Ka, a.element_size()) == 8):
+    if (TAIL_SPLIT and tile_cfg == 0 and out_group == 0 and resid_mod == 0 and a.is_cuda and drop is None and auto_tile_cfg(M, N, Ka, a.element_size()) == 8):
         m_main = tail_split_rows(M, N, num_cus(a.device.index))
         if m_main < M and HALF_HEIGHT_SHORT_K and N <= 768 and Ka * a.element_size() <= 1536:
             # short K loops with a ragged last round (the image tower's output projection and its data gradient: 591 tiles on 256 CUs): the whole
@@ -285,12 +291,19 @@ def gemm(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None, res
             return
     _gemm_one(a, w, bias=bias, act=act, dact=dact, aux_in=aux_in, aux_out=aux_out, resid=resid, resid_mod=resid_mod, resid_row_off=resid_row_off,
               resid_t=resid_t, out_group=out_group, out_t=out_t, out32=out32, alpha=alpha, tile_cfg=tile_cfg, resid_ln=resid_ln,
-              rowsum=rowsum, lnfold=lnfold)
+              rowsum=rowsum, lnfold=lnfold, drop=drop)
 
 
 def _gemm_one(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None, resid=None, resid_mod=0, resid_row_off=0,
-              resid_t=None, out_group=0, out_t=None, out32=None, alpha=1.0, tile_cfg=0, resid_ln=None, rowsum=None, lnfold=None):
+              resid_t=None, out_group=0, out_t=None, out32=None, alpha=1.0, tile_cfg=0, resid_ln=None, rowsum=None, lnfold=None, drop=None):
     d = GemmDesc()
+    if drop is not None:
+        d.drop_where, d.drop_p, d.drop_seed = {"a": 1, "acc": 2}[drop[0]], float(drop[1]), int(drop[2]) & 0xFFFFFFFFFFFFFFFF
+        if len(drop) > 3 and drop[3] is not None:
+            xo = drop[3]
+            if drop[0] != "a" or xo.dtype != a.dtype or xo.shape != a.shape or xo.stride() != a.stride():
+                raise UiaError("gemm drop: a_drop_out must have a's dtype, shape and strides")
+            d.a_drop_out = _p(xo)
     packed = w if isinstance(w, PackedW) else None
     if packed is not None:
         w = packed.row
@@ -384,11 +397,17 @@ def _gemm_one(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None
 
 
 def wgrad(a, b, dw, dbias=None, alpha=1.0):
-    """dw[I,J] += alpha * a.T @ b   (a [M,I], b [M,J]); dbias[I] += a.sum(0).  dw/dbias fp32, pre-zeroed or accumulating."""
+    """dw[I,J] += alpha * a.T @ b   (a [M,I], b [M,J]); dbias[I] += a.sum(0).  dw/dbias fp32, pre-zeroed or accumulating.
+    dw may be SMALLER than [I, J] (a LoRA factor's own [out, r] / [r, in] gradient under 64-padded operands): only its extent is accumulated."""
     lda, ldb = _rowmajor(a, "a"), _rowmajor(b, "b")
-    assert a.dtype == b.dtype and a.shape[0] == b.shape[0] and dw.dtype == torch.float32 and dw.is_contiguous()
-    assert tuple(dw.shape) == (a.shape[1], b.shape[1])
-    check(lib().uia_wgrad(_stream(), _code(a.dtype), a.shape[0], a.shape[1], b.shape[1], _p(a), lda, _p(b), ldb, alpha, _p(dw), _p(dbias)), "uia_wgrad")
+    assert a.dtype == b.dtype and a.shape[0] == b.shape[0] and dw.dtype == torch.float32 and dw.is_contiguous() and dw.dim() == 2
+    I, J = a.shape[1], b.shape[1]
+    if tuple(dw.shape) == (I, J):
+        check(lib().uia_wgrad(_stream(), _code(a.dtype), a.shape[0], I, J, _p(a), lda, _p(b), ldb, alpha, _p(dw), _p(dbias)), "uia_wgrad")
+        return
+    assert dw.shape[0] <= I and dw.shape[1] <= J and (dbias is None or dbias.numel() >= dw.shape[0])
+    check(lib().uia_wgrad_ex(_stream(), _code(a.dtype), a.shape[0], I, J, _p(a), lda, _p(b), ldb, alpha, _p(dw), dw.shape[1], dw.shape[0], dw.shape[1],
+                             _p(dbias)), "uia_wgrad_ex")
 
 
 def _attn_desc(q, k, v, out, lse, B, H, L, mask, keylen, scale, dh=64):
@@ -470,17 +489,21 @@ def transpose_cast(src, dst):
 
 
 def pack_table(entries, device):
-    """Device-resident uia_pack_desc table for `entries` = [(src fp32 [R, C], row, row_kb, tr, tr_kb)] (None = form not wanted).
-    Returns (table tensor, n, max_elems); keep the tensors of `entries` alive as long as the table is used."""
+    """Device-resident uia_pack_desc table for `entries` = [(src fp32 [R, C], row, row_kb, tr, tr_kb[, (rows_pad, cols_pad, scale)])] (None = form
+    not wanted).  With the optional sixth element the destinations hold rows_pad x cols_pad elements (zero padding kept by the caller: the
+    launch writes only the source's elements).  Returns (table tensor, n, max_elems); keep the tensors of `entries` alive as long as the table is used."""
     arr = (PackDesc * len(entries))()
     max_elems = 0
-    for d, (src, row, row_kb, tr, tr_kb) in zip(arr, entries):
+    for d, ent in zip(arr, entries):
+        src, row, row_kb, tr, tr_kb = ent[:5]
         assert src.dtype == torch.float32 and src.dim() == 2 and src.is_contiguous()
         R, Cc = src.shape
-        d.src, d.rows, d.cols = _p(src), R, Cc
+        RP, CP, scale = ent[5] if len(ent) > 5 and ent[5] is not None else (R, Cc, 1.0)
+        assert RP >= R and CP >= Cc
+        d.src, d.rows, d.cols, d.rows_pad, d.cols_pad, d.scale = _p(src), R, Cc, RP, CP, float(scale)
         for name, t in (("row", row), ("row_kb", row_kb), ("tr", tr), ("tr_kb", tr_kb)):
             if t is not None:
-                assert t.is_contiguous() and t.numel() == src.numel() and t.device == src.device
+                assert t.is_contiguous() and t.numel() == RP * CP and t.device == src.device
                 setattr(d, name, _p(t))
         max_elems = max(max_elems, R * Cc)
     raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone()

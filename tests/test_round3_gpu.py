@@ -150,12 +150,31 @@ def test_pipelined_epilogue_equals_inline_epilogue_bit_for_bit(M, N, K):
     stats = torch.stack([mean, (resid.var(1, unbiased=False) + 1e-5).rsqrt()], 1).contiguous()
     sums_in = ops.rowsum_from_float(torch.stack([resid.sum(1), (resid * resid).sum(1)], 1))
 
+    csum = w.row.float().sum(1).contiguous()
+    aux_o = lambda: torch.full((M, N), float("nan"), device=dev(), dtype=dt)
+
     def run(cfg, kind):
+        if kind in ("plain", "bias", "gelu", "gelu_stash", "lnfold_bias", "lnfold_gelu", "lnfold_gelu_stash", "qgelu", "qgelu_stash"):     # T outputs only
+            ot, ax = aux_o(), aux_o()
+            kw = {}
+            if kind != "plain":
+                kw["bias"] = bias
+            if "gelu" in kind:
+                kw["act"] = "quick_gelu" if kind.startswith("q") else "gelu"
+            if "stash" in kind:
+                kw["aux_out"] = ax
+            if kind.startswith("lnfold"):
+                kw["lnfold"] = (sums_in, csum, N, 1e-5)                # row sums of SOME rows: any finite statistics exercise the arithmetic
+            ops.gemm(a, w, out_t=ot, tile_cfg=cfg, **kw)
+            torch.cuda.synchronize()
+            return ot, ax, torch.zeros(1, dtype=torch.int64)
         o32 = torch.full((M, N), float("nan"), device=dev())
         ot = torch.full((M, N), float("nan"), device=dev(), dtype=dt)
         rs = torch.zeros(M, 2, device=dev(), dtype=torch.int64)
         if kind == "dgelu":                                            # mask 136
             ops.gemm(a, w, dact="gelu", aux_in=aux, out_t=ot, tile_cfg=cfg)
+        elif kind == "dqgelu":                                         # mask 136 | EPI_QUICK: fc2 data gradient of an OpenAI-CLIP tower
+            ops.gemm(a, w, dact="quick_gelu", aux_in=aux, out_t=ot, tile_cfg=cfg)
         elif kind == "resid32":                                        # mask 81
             ops.gemm(a, w, bias=bias, resid=resid, out32=o32, tile_cfg=cfg)
         elif kind == "residT":                                         # mask 97
@@ -169,7 +188,8 @@ def test_pipelined_epilogue_equals_inline_epilogue_bit_for_bit(M, N, K):
         torch.cuda.synchronize()
         return o32, ot, rs
 
-    for kind in ("dgelu", "resid32", "residT", "fold_producer", "resid_ln", "resid_ln_sums_fold_producer"):
+    for kind in ("plain", "bias", "gelu", "gelu_stash", "lnfold_bias", "lnfold_gelu", "lnfold_gelu_stash", "qgelu", "qgelu_stash", "dqgelu",
+                 "dgelu", "resid32", "residT", "fold_producer", "resid_ln", "resid_ln_sums_fold_producer"):
         ref = run(10, kind)
         for cfg in (8, 13, 14):
             got = run(cfg, kind)
@@ -183,3 +203,139 @@ def test_pipelined_epilogue_equals_inline_epilogue_bit_for_bit(M, N, K):
             assert float((ref[0] - want).abs().max()) <= 3e-5 * float(want.abs().max())
             s = ops.rowsum_to_float(ref[2])
             assert torch.allclose(s[:, 0], ref[0].sum(1), rtol=1e-4, atol=1e-2)
+
+
+# ------------------------------------------------------------------------------------------------ small fp32 GEMMs on 32 x 64 tiles
+@pytest.mark.parametrize("M,N,K", [(256, 640, 768), (256, 512, 640), (100, 776, 96), (1, 72, 32)])
+def test_small_fp32_gemm_tile_cfg_21_equals_the_128_tile_bit_for_bit(M, N, K):
+    """The fp32 head projections ([B, 512-768] x K = 512-768) moved from 128 x 128 tiles (8-12 workgroups, bound by their CUs' fp32 MFMA rate)
+    to 32 x 64 tiles (tile cfg 21, the launcher's choice for fp32 shapes with fewer than 64 of the big tiles).  Every output element sees the
+    same MFMA sequence over K, so the results must be bit-identical to tile cfg 3 — ragged M / N, bias, GELU, residual included."""
+    from uia_hip import ops
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + N + K)
+    a = torch.randn(M, K, generator=g).to(dev())
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(dev())
+    bias = torch.randn(N, generator=g).to(dev())
+    resid = torch.randn(M, N, generator=g).to(dev())
+    assert ops.auto_tile_cfg(M, N, K, 4) == 21 and ops.auto_tile_cfg(M, N, K, 2) == 3
+    for kw in ({}, {"bias": bias}, {"bias": bias, "act": "gelu"}, {"bias": bias, "resid": resid}):
+        outs = []
+        for cfg in (3, 21, 0):
+            o = torch.full((M, N), float("nan"), device=dev())
+            ops.gemm(a, w, out32=o, tile_cfg=cfg, **kw)
+            torch.cuda.synchronize()
+            outs.append(o)
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), sorted(kw)
+        want = a.double() @ w.double().T
+        if "bias" in kw:
+            want = want + bias.double()
+        if "act" in kw:
+            want = torch.nn.functional.gelu(want)
+        if "resid" in kw:
+            want = want + resid.double()
+        assert rel(outs[1], want.float()) < 2e-5, sorted(kw)
+
+
+# ------------------------------------------------------------------------------------------------ LoRA: dropout without a pass of its own
+@pytest.mark.parametrize("M,K", [(2500, 1024), (300, 128), (16, 64)])
+def test_dropout_on_the_stream_kernels_operand_equals_the_dropout_pass_bit_for_bit(M, K):
+    """LoRA input dropout (lora.py:82-83) applied to the A operand of the N = 64 stream kernel in flight: t = drop(x)·Aᵀ and the by-product
+    drop(x) must equal, bit for bit, uia_dropout followed by the plain launch (same seed, same eight-wide generator)."""
+    from uia_hip import ops
+    g = torch.Generator(device="cpu").manual_seed(M + K)
+    x = torch.randn(M, K, generator=g).to(dev()).to(torch.bfloat16)
+    a = (torch.randn(64, K, generator=g) * K ** -0.5).to(dev()).to(torch.bfloat16)
+    for p_drop, seed in ((0.1, 12345), (0.5, (1 << 40) + 77)):
+        xd_ref = torch.empty_like(x)
+        ops.dropout(x, xd_ref, p_drop, seed)
+        t_ref = torch.empty(M, 64, device=dev(), dtype=torch.bfloat16)
+        ops.gemm(xd_ref, a, out_t=t_ref, tile_cfg=16)
+        xd = torch.full_like(x, float("nan"))
+        t = torch.empty_like(t_ref)
+        ops.gemm(x, a, out_t=t, drop=("a", p_drop, seed, xd))
+        t2 = torch.empty_like(t_ref)
+        ops.gemm(x, a, out_t=t2, drop=("a", p_drop, seed))                # without the by-product
+        torch.cuda.synchronize()
+        assert torch.equal(xd, xd_ref) and torch.equal(t, t_ref) and torch.equal(t2, t_ref)
+        kept = (xd_ref.float() != 0).float().mean().item()
+        assert abs(kept - (1.0 - p_drop)) < 0.02 + 2.0 / (M * K) ** 0.5
+    with pytest.raises(ops.UiaError, match="drop_where"):
+        ops.gemm(x, torch.randn(128, K, device=dev()).to(torch.bfloat16), out_t=torch.empty(M, 128, device=dev(), dtype=torch.bfloat16), drop=("a", 0.1, 1))
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp32"])
+@pytest.mark.parametrize("M,N", [(2500, 1024), (321, 136)])
+def test_dropout_in_the_gemm_epilogue_is_the_backward_of_the_same_mask(mode, M, N):
+    """dx += drop(s·q·A) in ONE launch (run-time epilogue, drop = ("acc", p, seed)) against s·q·A followed by uia_dropout(accumulate): the zero
+    pattern must be the mask uia_dropout draws for (seed, m·N + n), the kept values agree to rounding (the fused form does not round s·q·A to T
+    before scaling it)."""
+    from uia_hip import ops
+    dt = torch.bfloat16 if mode == "bf16" else torch.float32
+    g = torch.Generator(device="cpu").manual_seed(M + N)
+    q = torch.randn(M, 64, generator=g).to(dev()).to(dt)
+    at = (torch.randn(N, 64, generator=g) * 0.2).to(dev()).to(dt)
+    dx0 = torch.randn(M, N, generator=g).to(dev()).to(dt)
+    p_drop, seed, s = 0.25, 987654321, 1.75
+    ones = torch.ones(M, N, device=dev(), dtype=dt)
+    kept = torch.empty_like(ones)
+    ops.dropout(ones, kept, p_drop, seed)
+    keep = kept.float() > 0
+    # the mask alone: zero residual
+    zero = torch.zeros(M, N, device=dev(), dtype=dt)
+    only = torch.empty_like(zero)
+    ops.gemm(q, at, alpha=s, resid_t=zero, out_t=only, drop=("acc", p_drop, seed))
+    prod = (q.float() @ at.float().T) * s
+    want = torch.where(keep, prod / (1.0 - p_drop), torch.zeros_like(prod))
+    assert torch.equal(only.float() != 0, keep & (want.to(dt).float() != 0))
+    assert rel(only, want) < (1e-2 if mode == "bf16" else 1e-5)
+    # accumulate onto dx, in place, against the two-launch form
+    ref = dx0.clone()
+    dxd = torch.empty_like(ref)
+    ops.gemm(q, at, alpha=s, out_t=dxd)
+    ops.dropout(dxd, ref, p_drop, seed, accumulate=True)
+    got = dx0.clone()
+    ops.gemm(q, at, alpha=s, resid_t=got, out_t=got, drop=("acc", p_drop, seed))
+    torch.cuda.synchronize()
+    assert rel(got, ref) < (2e-2 if mode == "bf16" else 1e-5)
+    assert torch.equal(got[~keep], dx0[~keep])                           # dropped positions keep dx untouched
+
+
+def test_wgrad_into_the_unpadded_gradient_and_padded_factor_packs():
+    """uia_wgrad_ex: 64-padded operands, gradient of the factor's own shape ([out, r] / [r, in], r = 16), accumulating; and the batched
+    uia_pack_weights forms of a LoRA factor zero-padded to rank 64 (WEIGHTS.get(..., pad_rows_to / pad_cols_to) on a trainable parameter)."""
+    from uia_hip import functional as UF
+    from uia_hip import ops
+    g = torch.Generator(device="cpu").manual_seed(5)
+    M, N, K, r = 1500, 320, 256, 16
+    dy = torch.randn(M, N, generator=g).to(dev()).to(torch.bfloat16)
+    t = torch.zeros(M, 64, device=dev(), dtype=torch.bfloat16)
+    t[:, :r] = torch.randn(M, r, generator=g).to(dev()).to(torch.bfloat16)
+    full = torch.zeros(N, 64, device=dev())
+    ops.wgrad(dy, t, full, alpha=0.5)
+    small = torch.full((N, r), 3.0, device=dev())
+    ops.wgrad(dy, t, small, alpha=0.5)
+    torch.cuda.synchronize()
+    assert rel(small - 3.0, full[:, :r]) < 1e-5 and float(full[:, r:].abs().max()) == 0.0
+    qv = torch.zeros(M, 64, device=dev(), dtype=torch.bfloat16)
+    qv[:, :r] = torch.randn(M, r, generator=g).to(dev()).to(torch.bfloat16)
+    xd = torch.randn(M, K, generator=g).to(dev()).to(torch.bfloat16)
+    fullA = torch.zeros(64, K, device=dev())
+    ops.wgrad(qv, xd, fullA)
+    smallA = torch.zeros(r, K, device=dev())
+    ops.wgrad(qv, xd, smallA)
+    assert rel(smallA, fullA[:r]) < 1e-5
+    assert rel(smallA, qv[:, :r].float().T @ xd.float()) < 2e-3
+    for dt in (torch.bfloat16, torch.float32):
+        A = torch.nn.Parameter(torch.randn(r, K, generator=g).to(dev()))
+        Bm = torch.nn.Parameter(torch.randn(N, r, generator=g).to(dev()))
+        a_f, a_b = UF.WEIGHTS.get(A, dt, pad_rows_to=64), UF.WEIGHTS.get(A, dt, transpose=True, pad_rows_to=64)
+        b_f, b_b = UF.WEIGHTS.get(Bm, dt, pad_cols_to=64), UF.WEIGHTS.get(Bm, dt, transpose=True, pad_cols_to=64)
+        Ap = torch.zeros(64, K, device=dev()); Ap[:r] = A.detach()
+        Bp = torch.zeros(N, 64, device=dev()); Bp[:, :r] = Bm.detach()
+        assert torch.equal(a_f.row, Ap.to(dt)) and torch.equal(a_b.row, Ap.T.contiguous().to(dt))
+        assert torch.equal(b_f.row, Bp.to(dt)) and torch.equal(b_b.row, Bp.T.contiguous().to(dt))
+        gk = 64 // torch.empty(0, dtype=dt).element_size()
+        assert torch.equal(b_f.kblocked(), Bp.to(dt).view(N, 64 // gk, gk).permute(1, 0, 2).contiguous())
+        with torch.no_grad():
+            A.mul_(2.0)                                                   # the version counter moves: the next get() refreshes in place
+        assert torch.equal(UF.WEIGHTS.get(A, dt, pad_rows_to=64).row, (2.0 * Ap).to(dt))
