@@ -1683,6 +1683,152 @@ int launch_skinny64(hipStream_t stream, const UiaGemmParams& p) {
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Tile cfg 23 — K = 64 (the LoRA rank update y += s·t·Bᵀ and its data gradient dx += drop(s·q·A), r padded to 64; lora.py:87): 2·M·N·64 FLOP
+// against 4·M·N bytes of result read and written back is 32 FLOP per byte, i.e. the launch is a read-modify-write stream over the result.
+// The mirror image of cfg 16: one workgroup per CU keeps ALL of W (N x 64 bf16, N <= 1088) in LDS; a wave's unit of work is 16 rows x 64
+// columns — fine enough that M = 128·257 rows (ViT-L/14) deal out evenly, where the 128 x 256 tiles of cfg 14 left 1028 tiles for 512
+// slots (61 us per launch for 134 MB).  The A fragment of a unit (16 rows x 64 k) comes straight from global memory (the whole operand is
+// 4 MB: L2), W rows are read from LDS in the order that leaves a lane 16 CONSECUTIVE columns of one row (column 64c + 16g + 4nt + r from MFMA
+// row 4g + r of tile nt), so residual loads and stores are 32 contiguous bytes per lane and a full 128-byte line per row.  The residual of the
+// NEXT unit is requested before the current one is multiplied.  Dropout on the accumulator (drop_where = 2) is drawn per eight columns.
+template <bool OUT32>
+__global__ __launch_bounds__(512) void gemm_wide64_kernel(const UiaGemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int LDWB = 128 + 16;                         // row stride of the W image
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int c = tid; c < p.N * 8; c += 512) {
+        const int r = c >> 3, cc = c & 7;
+        *(uint4*)(smem + r * LDWB + cc * 16) = *(const uint4*)((const char*)p.W + ((size_t)r * p.ldw) * 2 + cc * 16);
+    }
+    __syncthreads();
+    const int nch = p.N >> 6, ntiles = (p.M + 15) >> 4;
+    const int nunits = ntiles * nch, ustep = gridDim.x * 8;
+    const bool drop = p.drop_where == 2;
+    const uint32_t drop_th = dropout_thresh16(p.drop_p);
+    const float drop_inv = 1.0f / (1.0f - p.drop_p);
+    const bf16_t* residT = (const bf16_t*)p.residT;
+    bf16_t* outT = (bf16_t*)p.outT;
+    // W fragment of (chunk c, tile nt, k-step ks): row 64c + 16(li>>2) + 4nt + (li&3), bytes 64ks + 16g
+    const char* wfrag = smem + (16 * (li >> 2) + (li & 3)) * LDWB + g * 16;
+
+    struct Unit { uint4 a0, a1; uint4 rt0, rt1; f32x4 r0, r1, r2, r3; };
+    auto request = [&](int u, Unit& q) {
+        const int rt = u / nch, c = u - rt * nch;
+        const int m = 16 * rt + li, mc = m < p.M ? m : p.M - 1;
+        const char* arow = (const char*)p.A + ((size_t)mc * p.lda) * 2 + g * 16;
+        q.a0 = *(const uint4*)arow;
+        q.a1 = *(const uint4*)(arow + 64);
+        const int n = 64 * c + 16 * g;
+        if (OUT32) {
+            if (p.resid) {
+                const float* rr = p.resid + (size_t)mc * p.ldr + n;
+                q.r0 = *(const f32x4*)rr; q.r1 = *(const f32x4*)(rr + 4); q.r2 = *(const f32x4*)(rr + 8); q.r3 = *(const f32x4*)(rr + 12);
+            }
+        } else if (residT) {
+            const bf16_t* rr = residT + (size_t)mc * p.ldrT + n;
+            q.rt0 = *(const uint4*)rr; q.rt1 = *(const uint4*)(rr + 8);
+        }
+    };
+    auto process = [&](int u, const Unit& q) {
+        const int rt = u / nch, c = u - rt * nch;
+        const int m = 16 * rt + li;
+        const int n = 64 * c + 16 * g;
+        const char* wc = wfrag + (size_t)(64 * c) * LDWB;
+        f32x4 acc[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const uint4 w0 = *(const uint4*)(wc + (4 * nt) * LDWB), w1 = *(const uint4*)(wc + (4 * nt) * LDWB + 64);
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w0), __builtin_bit_cast(bf16x8, q.a0), f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w1), __builtin_bit_cast(bf16x8, q.a1), acc[nt], 0, 0, 0);
+        }
+        if (m >= p.M) return;
+        float v[16];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {                   // alpha and bias in one fma, as the run-time epilogue of the tiled kernels has them
+            const f32x4 b = p.bias ? *(const f32x4*)(p.bias + n + 4 * nt) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[4 * nt + r] = fmaf(acc[nt][r], p.alpha, b[r]);
+        }
+        if (drop) {
+            const uint32_t grp = (uint32_t)(((size_t)m * (size_t)p.N + (size_t)n) >> 3);
+            const uint32_t k0 = dropout_keep8(p.drop_seed, grp, drop_th), k1 = dropout_keep8(p.drop_seed, grp + 1, drop_th);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { v[e] = (k0 >> e) & 1u ? v[e] * drop_inv : 0.f; v[8 + e] = (k1 >> e) & 1u ? v[8 + e] * drop_inv : 0.f; }
+        }
+        if (OUT32) {
+            if (p.resid) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { v[r] += q.r0[r]; v[4 + r] += q.r1[r]; v[8 + r] += q.r2[r]; v[12 + r] += q.r3[r]; }
+            }
+            float* o = p.out32 + (size_t)m * p.ldo32 + n;
+#pragma unroll
+            for (int h = 0; h < 4; ++h) *(f32x4*)(o + 4 * h) = f32x4{v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]};
+        } else {
+            if (residT) {
+                const bf16x8 x0 = __builtin_bit_cast(bf16x8, q.rt0), x1 = __builtin_bit_cast(bf16x8, q.rt1);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { v[e] += (float)x0[e]; v[8 + e] += (float)x1[e]; }
+            }
+            bf16x8 o0, o1;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { o0[e] = (bf16_t)v[e]; o1[e] = (bf16_t)v[8 + e]; }
+            bf16_t* o = outT + (size_t)m * p.ldo + n;
+            *(bf16x8*)o = o0;
+            *(bf16x8*)(o + 8) = o1;
+        }
+    };
+    // THREE units requested ahead of the one being multiplied (four register sets, the loop unrolled by four): with one unit ahead a wave had
+    // 4 KB in flight and the launch was bound by the round trip of a unit (49 us for 134 MB at M = 32 896, N = 1024)
+    int u = blockIdx.x * 8 + wave;
+    Unit q0, q1, q2, q3;
+    if (u < nunits) request(u, q0);
+    if (u + ustep < nunits) request(u + ustep, q1);
+    if (u + 2 * ustep < nunits) request(u + 2 * ustep, q2);
+    while (u < nunits) {
+        if (u + 3 * ustep < nunits) request(u + 3 * ustep, q3);
+        process(u, q0);
+        u += ustep;
+        if (u >= nunits) break;
+        if (u + 3 * ustep < nunits) request(u + 3 * ustep, q0);
+        process(u, q1);
+        u += ustep;
+        if (u >= nunits) break;
+        if (u + 3 * ustep < nunits) request(u + 3 * ustep, q1);
+        process(u, q2);
+        u += ustep;
+        if (u >= nunits) break;
+        if (u + 3 * ustep < nunits) request(u + 3 * ustep, q2);
+        process(u, q3);
+        u += ustep;
+    }
+}
+
+// cfg 23 takes: bf16, K == 64, N a multiple of 64 whose W image fits the LDS, row-major operands, and an epilogue of alpha, bias, dropout on the
+// accumulator and ONE residual of the output's type (T residual -> T output, or fp32 residual -> fp32 output)
+inline bool wide64_ok(const UiaGemmParams& p, int esz) {
+    const bool t_form = p.outT && !p.out32 && !p.resid, f_form = p.out32 && !p.outT && !p.residT;
+    return esz == 2 && p.K == 64 && p.N % 64 == 0 && p.N * (128 + 16) <= 160 * 1024 && (t_form || f_form) && !p.act && !p.dact && !p.aux_out && p.out_group == 0 &&
+           p.resid_mod == 0 && !p.w_kblocked && !p.a_kb_rows && !p.outT_kb_rows && !p.rowsum_out && !p.lnfold_sums && !p.resid_ln_stats && p.drop_where != 1 &&
+           (!p.outT || p.ldo % 8 == 0) && (!p.residT || p.ldrT % 8 == 0);
+}
+
+int launch_wide64(hipStream_t stream, const UiaGemmParams& p) {
+    const int lds = p.N * (128 + 16);
+    static UiaDevOnce once_t, once_f;
+    UIA_ENSURE_LDS_ATTR(once_t, gemm_wide64_kernel<false>, 160 * 1024);
+    UIA_ENSURE_LDS_ATTR(once_f, gemm_wide64_kernel<true>, 160 * 1024);
+    const int ncu = uia_num_cus();
+    const long units = (long)((p.M + 15) / 16) * (p.N / 64);
+    int grid = (int)((units + 7) / 8);
+    grid = grid < ncu ? grid : ncu;
+    if (p.out32) hipLaunchKernelGGL(gemm_wide64_kernel<true>, dim3(grid), dim3(512), lds, stream, p);
+    else hipLaunchKernelGGL(gemm_wide64_kernel<false>, dim3(grid), dim3(512), lds, stream, p);
+    UIA_CHECK_LAUNCH();
+    return 0;
+}
+
 template <typename T>
 int launch_typed(hipStream_t stream, const UiaGemmParams& p, int cfg_in) {
     // bits 8.. of the tile argument carry experiment knobs for the ring kernels (tile-order group size, diagnostic layouts);
@@ -1696,6 +1842,7 @@ int launch_typed(hipStream_t stream, const UiaGemmParams& p, int cfg_in) {
         else if (p.M <= 2048) cfg = (sizeof(T) == 4 && ((p.M + 127) / 128) * ((p.N + 127) / 128) < 64) ? 21 : 3;
             // fp32 MFMA issues 256 FLOP per clock per CU: the 8-12 workgroups of a [256, 512-768] head projection on 128 x 128 tiles were bound
             // by their own CUs' matrix pipes (69 us at K = 768); 32 x 64 tiles spread the same MFMA sequence per element over 64-96 CUs
+        else if (wide64_ok(p, (int)sizeof(T)) && (p.residT || p.resid || p.drop_where == 2)) cfg = 23;   // K = 64 read-modify-write stream (LoRA rank update)
         else if (p.K * (int)sizeof(T) <= 128) cfg = 14;   // one K step (Mona project2 / project1-dgrad, K = 64): nothing but prologue + epilogue, HBM-bound:
                                                           // half-height tiles, two workgroups per CU (70.9 vs 86.6 us and 20.0 vs 26.3 us at M = 50 432)
         else cfg = 8;            // 256x256 ping-pong, 4-deep 64-byte ring, LDS-staged epilogue: best measured on every large shape.
@@ -1734,6 +1881,9 @@ int launch_typed(hipStream_t stream, const UiaGemmParams& p, int cfg_in) {
         case 4: return launch_cfg<T, 256, 64, 4, 1>(stream, p);
         case 5: return launch_cfg<T, 128, 64, 2, 1>(stream, p);
         case 21: return launch_cfg<T, 32, 64, 2, 2>(stream, p);
+        case 23:
+            if (!wide64_ok(p, (int)sizeof(T))) { uia_set_error("uia_gemm: tile cfg 23 is the bf16 K = 64 stream kernel (alpha, bias, accumulator dropout, one residual of the output's type)"); return -1; }
+            return launch_wide64(stream, p);
         case 6: return launch_pp<T, 256, 256, 2, 4>(stream, p);
         case 7: return launch_pp<T, 256, 128, 4, 2>(stream, p);
         case 8: return launch_ring<T, 256, 256, 2, 4, 64, 4>(stream, p, true, xflags);

@@ -66,8 +66,8 @@ class LinearLoRA(nn.Linear, LoRALayer):
     def apply_rows(self, x2d, resid32=None):
         """x2d: [M, in] in the compute dtype → [M, out] (T, or fp32 when the fp32 residual is fused)."""
         if self.r > 0:
-            trainable = [p for p in (self.w_lora_A, self.w_lora_B, self.bias) if p is not None]
-            direct = torch.is_grad_enabled() and all(p.requires_grad and UF._is_flat_grad(p) for p in trainable)
+            trainable = [p for p in (self.w_lora_A, self.w_lora_B, self.bias) if p is not None and p.requires_grad]
+            direct = torch.is_grad_enabled() and len(trainable) >= 2 and all(UF._is_flat_grad(p) for p in trainable)
             return UF.LoraLinearFn.apply(x2d, self.weight, self.bias, self.w_lora_A, self.w_lora_B, self.scaling, self._drop_p(), resid32, direct)
         empty = x2d.new_zeros(0, x2d.shape[1], dtype=torch.float32)
         return UF.LoraLinearFn.apply(x2d, self.weight, self.bias, empty, empty.new_zeros(self.out_features, 0), 0.0, 0.0, resid32)
@@ -140,6 +140,23 @@ class PlainMultiheadAttentionLoRA(nn.Module):
         q, k, v = self.q_proj.apply_rows(h2d), self.k_proj.apply_rows(h2d), self.v_proj.apply_rows(h2d)
         a = UF.AttentionFn.apply(q, k, v, B, self.num_heads, L, mask)
         return self.proj.apply_rows(a, resid32)
+
+    def block_half(self, xb, ln, B, L, mask):
+        """x + proj(attention(LN x)) for the fp32 residual stream xb [B, L, D] of an OpenAI-CLIP block whose attention this module replaced
+        (model.py:195-201): one autograd node when q, k, v and the output projection all carry LoRA factors of one rank, scaling and dropout
+        (how inject_lora_to_clip builds them); the composition of rows_forward otherwise."""
+        ps = (self.q_proj, self.k_proj, self.v_proj, self.proj)
+        uniform = (all(m.r > 0 for m in ps) and len({(m.r, m.scaling, m._drop_p()) for m in ps}) == 1
+                   and len({m.bias is None for m in ps}) == 1 and self.head_dim == 64)
+        if not uniform:
+            D = xb.shape[-1]
+            h = UF.LayerNormFn.apply(xb, ln.weight, ln.bias, ln.eps).view(B * L, D)
+            return self.rows_forward(h, B, L, mask, resid32=xb.view(B * L, D)).view(B, L, D)
+        trainable = [p for m in ps for p in (m.w_lora_A, m.w_lora_B, m.bias) if p is not None and p.requires_grad]
+        direct = (torch.is_grad_enabled() and all(m.w_lora_A.requires_grad and m.w_lora_B.requires_grad for m in ps)
+                  and all(UF._is_flat_grad(p) for p in trainable))
+        flat = [t for m in ps for t in (m.weight, m.bias, m.w_lora_A, m.w_lora_B)]
+        return UF.LoraAttnHalfFn.apply(xb, ln.weight, ln.bias, ln.eps, self.num_heads, mask, ps[0].scaling, ps[0]._drop_p(), direct, *flat)
 
     def forward(self, query, key, value, key_padding_mask=None, need_weights=False, attn_mask=None, **kwargs):
         if not (query is key and key is value):

@@ -270,7 +270,8 @@ class WeightCache:
         """Trainable parameters were updated behind autograd's back (fused optimiser kernel)."""
         self.epoch += 1
         if len(self._c) > 8192:
-            self._c = {k: v for k, v in self._c.items() if v[1]() is not None}
+            alive = lambda r: all(x() is not None for x in r) if isinstance(r, tuple) else r() is not None
+            self._c = {k: v for k, v in self._c.items() if alive(v[1])}
         live = [it for it in self._packed.values() if it.ref() is not None]
         if len(live) != len(self._packed):
             self._packed = {id(it.ref()): it for it in live}
@@ -322,6 +323,21 @@ class WeightCache:
                 bias = bias + b.detach().float()
         out = (ops.PackedW(wf), colsum, bias.contiguous())
         self._c[key] = (vers, weakref.ref(w), out, weakref.ref(ln_w))
+        return out
+
+    def get_cat(self, ws, dt, transpose=False):
+        """The frozen weights `ws` ([N_i, K] each) stacked along N as ONE GEMM operand ([ΣN_i, K]; transpose: [K, ΣN_i] for the data gradient):
+        the q, k, v projections of a block run as one launch.  Converted once (frozen weights), refreshed if any of them changes."""
+        key = (tuple(id(w) for w in ws), dt, transpose, "cat")
+        vers = tuple(w._version for w in ws)
+        hit = self._c.get(key)
+        if hit is not None and hit[0] == vers and all(r() is w for r, w in zip(hit[1], ws)) and hit[2].row.device == ws[0].device:
+            return hit[2]
+        with torch.no_grad():
+            cat = torch.cat([w.detach().float() for w in ws], 0)
+            src = cat.t().contiguous() if transpose else cat
+            out = ops.PackedW(src.to(dt).contiguous())
+        self._c[key] = (vers, tuple(weakref.ref(w) for w in ws), out)
         return out
 
     def get(self, p, dt, transpose=False, pad_rows_to=None, pad_cols_to=None):
@@ -903,7 +919,9 @@ class MlpHalfFn(torch.autograd.Function):
         dh = _empty((M, D), dt, x1)
         ops.gemm(dpre, WEIGHTS.get(spec.fc1[0], dt, transpose=True), out_t=dh)
         dx1 = torch.empty_like(x1)
-        ops.layernorm_bwd(dh, x1, spec.ln2[0], spec.eps, dres=dx2, dx32=dx1)
+        dx1_t = _empty((M, D), dt, x1) if dt != torch.float32 else None
+        ops.layernorm_bwd(dh, x1, spec.ln2[0], spec.eps, dres=dx2, dx32=dx1, dx_t=dx1_t)
+        publish_t_copy(dx1, dx1_t)                                 # the attention half below starts with a data-gradient GEMM on it
         return dx1.view(shape), None
 
 
@@ -975,7 +993,11 @@ class LoraLinearFn(torch.autograd.Function):
         ops.gemm(dy_t, WEIGHTS.get(weight, dt, transpose=True), out_t=dx)
         dA = dB = db = None
         pA, pB, pb = ctx.direct_params if ctx.direct_params is not None else (None, None, None)
-        direct = pA is not None and _is_flat_grad(pA) and _is_flat_grad(pB) and (pb is None or not has_bias or _is_flat_grad(pb))
+        want_b = has_bias and ctx.needs_input_grad[2]
+        direct = pA is not None and _is_flat_grad(pA) and _is_flat_grad(pB) and (not want_b or (pb is not None and _is_flat_grad(pb)))
+        if want_b and not direct:
+            db = torch.zeros(N, device=xd.device, dtype=torch.float32)
+        gb = (pb.grad if direct else db) if want_b else None                      # Σ dy rides on the matrix cores of the dB launch
         if r > 0:
             rp = _rank_pad(r)
             q = _empty((M, rp), dt, xd)
@@ -986,20 +1008,139 @@ class LoraLinearFn(torch.autograd.Function):
             else:
                 ops.gemm(q, at, alpha=scaling, resid_t=dx, out_t=dx)
             if direct:
-                ops.wgrad(dy_t, t, pB.grad, alpha=scaling)
+                ops.wgrad(dy_t, t, pB.grad, dbias=gb, alpha=scaling)
                 ops.wgrad(q, xd, pA.grad, alpha=scaling)
             else:
                 dB = torch.zeros(N, r, device=xd.device, dtype=torch.float32)
-                ops.wgrad(dy_t, t, dB, alpha=scaling)
+                ops.wgrad(dy_t, t, dB, dbias=gb, alpha=scaling)
                 dA = torch.zeros(r, K, device=xd.device, dtype=torch.float32)
                 ops.wgrad(q, xd, dA, alpha=scaling)
-        if has_bias and ctx.needs_input_grad[2]:
-            if direct and pb is not None:
-                ops.colsum(dy_t, pb.grad)
-            else:
-                db = torch.zeros(N, device=xd.device, dtype=torch.float32)
-                ops.colsum(dy_t, db)
+        elif want_b:
+            ops.colsum(dy_t, gb)
         return dx, None, db, dA, dB, None, None, (dy if has_resid else None), None
+
+
+def _lora_down(x, A, p_drop, rp):
+    """t = drop(x)·Aᵀ ([M, rp]) and the dropped rows (for dA): the dropout rides in the N = 64 stream kernel's operand when that kernel takes
+    the shape (bf16, rank padded to 64), otherwise as a pass of its own.  Returns (t, xd, seed)."""
+    dt = x.dtype
+    M, K = x.shape
+    t = _empty((M, rp), dt, x)
+    a_op = WEIGHTS.get(A, dt, pad_rows_to=rp)
+    if p_drop <= 0:
+        ops.gemm(x, a_op, out_t=t)
+        return t, x, 0
+    seed = _next_seed()
+    xd = torch.empty_like(x)
+    if dt == torch.bfloat16 and rp == 64 and x.is_cuda and x.is_contiguous() and 64 * (2 * K + 16) <= 160 * 1024 and K % 32 == 0:
+        ops.gemm(x, a_op.row, out_t=t, drop=("a", p_drop, seed, xd))
+    else:
+        ops.dropout(x, xd, p_drop, seed)
+        ops.gemm(xd, a_op, out_t=t)
+    return t, xd, seed
+
+
+def _lora_grads(dy_t, t, xd, q, A, Bm, bias, scaling, direct):
+    """dB = s·dyᵀ·t, dA = s·qᵀ·x̃ and, for a bias that trains (reference quirk C-4), db = Σ dy on the matrix cores of the dB launch: into the
+    parameters' .grad (flat-buffer views) when `direct`, else returned."""
+    r = A.shape[0]
+    want_b = bias is not None and bias.requires_grad
+    if direct:
+        ops.wgrad(dy_t, t, Bm.grad, dbias=bias.grad if want_b else None, alpha=scaling)
+        ops.wgrad(q, xd, A.grad, alpha=scaling)
+        return None, None, None
+    db = torch.zeros(bias.numel(), device=xd.device, dtype=torch.float32) if want_b else None
+    dB = torch.zeros(Bm.shape[0], r, device=xd.device, dtype=torch.float32)
+    ops.wgrad(dy_t, t, dB, dbias=db, alpha=scaling)
+    dA = torch.zeros(r, A.shape[1], device=xd.device, dtype=torch.float32)
+    ops.wgrad(q, xd, dA, alpha=scaling)
+    return dA, dB, db
+
+
+class LoraAttnHalfFn(torch.autograd.Function):
+    """x1 = x + proj(attention(q, k, v)(LN1 x)) with LinearLoRA on q, k, v and the output projection (reference lora.py:115-199 inside an
+    OpenAI-CLIP residual block, model.py:195-201) as ONE autograd node.  Same arithmetic as LayerNormFn -> 3 x LoraLinearFn -> AttentionFn ->
+    LoraLinearFn; what changes is the schedule:
+      * q, k, v share ONE frozen GEMM (N = 3D) and ONE data-gradient GEMM (K = 3D) — a third of the launches and M tails, and the three
+        gradients of h are summed inside the launches instead of by two autograd adds;
+      * the attention backward writes its fused [M, 3D] gradient straight into that GEMM's operand;
+      * the LayerNorm backward adds the residual gradient and publishes the T copy for the block below.
+    Parameters: W* frozen; b*, A*, B* trainable (bias: reference quirk SURVEY C-4)."""
+
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, eps, heads, mask, scaling, p_drop, direct, wq, bq, aq, Bq, wk, bk, ak, Bk, wv, bv, av, Bv, wo, bo, ao, Bo):
+        shape = x.shape
+        D = shape[-1]
+        Bsz, L = shape[0], shape[1]
+        x2 = x.contiguous().view(-1, D)
+        M, dt = x2.shape[0], compute_dtype()
+        r = aq.shape[0]
+        rp = _rank_pad(r)
+        h = _empty((M, D), dt, x2)
+        ops.layernorm_fwd(x2, ln_w, ln_b, eps, y_t=h)
+        downs = [_lora_down(h, A, p_drop, rp) for A in (aq, ak, av)]
+        qkv = _empty((M, 3 * D), dt, x2)
+        bcat = torch.cat([b.detach() for b in (bq, bk, bv)]) if bq is not None else None
+        ops.gemm(h, WEIGHTS.get_cat((wq, wk, wv), dt), bias=bcat, out_t=qkv)
+        for i, (Bm, (t, _, _)) in enumerate(zip((Bq, Bk, Bv), downs)):
+            sl = qkv[:, i * D:(i + 1) * D]
+            ops.gemm(t, WEIGHTS.get(Bm, dt, pad_cols_to=rp), alpha=scaling, resid_t=sl, out_t=sl)
+        a = _empty((M, D), dt, x2)
+        lse = torch.empty(Bsz, heads, L, device=x.device, dtype=torch.float32)
+        ops.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], a, Bsz, heads, L, lse=lse, mask=mask)
+        to, ado, seed_o = _lora_down(a, ao, p_drop, rp)
+        x1 = torch.empty_like(x2)
+        ops.gemm(a, WEIGHTS.get(wo, dt), bias=bo, resid=x2, out32=x1)
+        ops.gemm(to, WEIGHTS.get(Bo, dt, pad_cols_to=rp), alpha=scaling, resid=x1, out32=x1)
+        ctx.save_for_backward(x2, ln_w, qkv, a, lse, to, ado, *[d[0] for d in downs], *[d[1] for d in downs], wq, wk, wv, wo)
+        ctx.meta = (eps, shape, heads, mask, scaling, p_drop, [d[2] for d in downs] + [seed_o], rp)
+        ctx.params = (bq, aq, Bq, bk, ak, Bk, bv, av, Bv, bo, ao, Bo)                # the Parameter objects: .grad is looked up at BACKWARD time
+        ctx.direct = direct
+        return x1.view(shape)
+
+    @staticmethod
+    def backward(ctx, dx1):
+        x2, ln_w, qkv, a, lse, to, ado, tq, tk, tv, hq, hk, hv, wq, wk, wv, wo = ctx.saved_tensors
+        eps, shape, heads, mask, scaling, p_drop, seeds, rp = ctx.meta
+        bq, aq, Bq, bk, ak, Bk, bv, av, Bv, bo, ao, Bo = ctx.params
+        M, D = x2.shape
+        Bsz, L = shape[0], shape[1]
+        dt = qkv.dtype
+        trainable = [p for p in ctx.params if p is not None and p.requires_grad]
+        direct = ctx.direct and all(_is_flat_grad(p) for p in trainable)
+        dx1 = dx1.contiguous().view(M, D)
+        dy_t = t_copy_of(dx1, dt)
+        drop = lambda i: ("acc", p_drop, seeds[i]) if p_drop > 0 else None
+        # ---- output projection
+        da = _empty((M, D), dt, x2)
+        ops.gemm(dy_t, WEIGHTS.get(wo, dt, transpose=True), out_t=da)
+        qo = _empty((M, rp), dt, x2)
+        ops.gemm(dy_t, WEIGHTS.get(Bo, dt, transpose=True, pad_cols_to=rp), out_t=qo)
+        ops.gemm(qo, WEIGHTS.get(ao, dt, transpose=True, pad_rows_to=rp), alpha=scaling, resid_t=da, out_t=da, drop=drop(3))
+        g_o = _lora_grads(dy_t, to, ado, qo, ao, Bo, bo, scaling, direct)
+        # ---- attention
+        dqkv = _empty((M, 3 * D), dt, x2)
+        ops.attn_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], a, da, lse, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], Bsz, heads, L, mask=mask)
+        # ---- q, k, v
+        dh = _empty((M, D), dt, x2)
+        ops.gemm(dqkv, WEIGHTS.get_cat((wq, wk, wv), dt, transpose=True), out_t=dh)
+        grads = []
+        for i, (bias, A, Bm, t, hd) in enumerate(((bq, aq, Bq, tq, hq), (bk, ak, Bk, tk, hk), (bv, av, Bv, tv, hv))):
+            dsl = dqkv[:, i * D:(i + 1) * D]
+            qi = _empty((M, rp), dt, x2)
+            ops.gemm(dsl, WEIGHTS.get(Bm, dt, transpose=True, pad_cols_to=rp), out_t=qi)
+            ops.gemm(qi, WEIGHTS.get(A, dt, transpose=True, pad_rows_to=rp), alpha=scaling, resid_t=dh, out_t=dh, drop=drop(i))
+            grads.append(_lora_grads(dsl, t, hd, qi, A, Bm, bias, scaling, direct))
+        grads.append(g_o)
+        # ---- LayerNorm: dx = dx1 + LN'(dh); the T copy goes to the block below (its MLP half starts with a data-gradient GEMM)
+        dx = torch.empty_like(x2)
+        dx_t = _empty((M, D), dt, x2) if dt != torch.float32 else None
+        ops.layernorm_bwd(dh, x2, ln_w, eps, dres=dx1, dx32=dx, dx_t=dx_t)
+        publish_t_copy(dx, dx_t)
+        flat = []
+        for dA, dB, db in grads:                                                    # order of the inputs: (w, b, A, B) per projection
+            flat += [None, db, dA, dB]
+        return (dx.view(shape), None, None, None, None, None, None, None, None, *flat)
 
 
 def _pad_cols(p, dt, transpose=False, rows=False):

@@ -220,6 +220,8 @@ def gemm_kernel_name(cfg, mask, dtype):
         return f"gemm_tn_ring_kernel<{tn},{bm},256,2,4,64,{nbuf},{m}>", "gemm_tn_ring_kernelI" + tc + "".join(mi(v) for v in (bm, 256, 2, 4, 64, nbuf, m, 0)) + "E"
     if cfg == 16:
         return "gemm_skinny64_kernel", "gemm_skinny64_kernel"
+    if cfg == 23:
+        return "gemm_wide64_kernel", "gemm_wide64_kernel"
     shape = {1: (256, 256, 2, 4), 2: (256, 128, 4, 2), 3: (128, 128, 2, 2), 4: (256, 64, 4, 1), 5: (128, 64, 2, 1), 21: (32, 64, 2, 2)}.get(cfg)
     if shape:
         return f"gemm_tn_kernel<{tn},{','.join(map(str, shape))}>", "gemm_tn_kernelI" + tc + "".join(mi(v) for v in shape) + "E"
@@ -319,6 +321,13 @@ def _gemm_one(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None
     d.A, d.W = _p(a.t if is_kb(a) else a), _p(w)
     d.N = w.shape[0]
     base_cfg = (tile_cfg & 255) or auto_tile_cfg(d.M, d.N, d.K, a.element_size())
+    # mirror of wide64_ok() in csrc/gemm.hip: the K = 64 read-modify-write stream (LoRA rank update / its data gradient) takes row-major W
+    if ((tile_cfg & 255) == 0 and base_cfg == 14 and a.dtype == torch.bfloat16 and d.K == 64 and d.N % 64 == 0 and d.N * 144 <= 160 * 1024 and not is_kb(a)
+            and not is_kb(out_t) and act is None and dact is None and aux_out is None and out_group == 0 and resid_mod == 0 and rowsum is None and lnfold is None
+            and resid_ln is None and (drop is None or drop[0] == "acc")
+            and ((out_t is not None and out32 is None and resid is None and (resid_t is not None or drop is not None))
+                 or (out32 is not None and out_t is None and resid_t is None and (resid is not None or drop is not None)))):
+        base_cfg = 23
     if (PERSIST_STORE_ONLY and base_cfg == 8 and resid is None and resid_t is None and out32 is None and rowsum is None and out_group == 0
             and alpha == 1.0 and d.K * a.element_size() >= 1024):
         base_cfg, tile_cfg = 12, (tile_cfg & ~255) | 12
@@ -389,7 +398,7 @@ def _gemm_one(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None
         nbytes = esz * (d.M * d.K + d.N * d.K) + d.M * d.N * (esz * sum(t is not None for t in (aux_in, aux_out, resid_t, out_t))
                                                              + 4 * sum(t is not None for t in (resid, out32)))
         mask = epi_mask_of(d)
-        if not (tile_cfg & 255):
+        if not (tile_cfg & 255) and base_cfg != 23:
             base_cfg = auto_tile_cfg(d.M, d.N, d.K, esz, mask)
         GEMM_PROFILE.append((e0, e1, d.M, d.N, d.K, a.dtype, base_cfg, nbytes, mask))
         return

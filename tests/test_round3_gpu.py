@@ -339,3 +339,79 @@ def test_wgrad_into_the_unpadded_gradient_and_padded_factor_packs():
         with torch.no_grad():
             A.mul_(2.0)                                                   # the version counter moves: the next get() refreshes in place
         assert torch.equal(UF.WEIGHTS.get(A, dt, pad_rows_to=64).row, (2.0 * Ap).to(dt))
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("p_drop", [0.0, 0.2])
+def test_lora_attention_half_as_one_node_equals_the_composition(mode, p_drop):
+    """PlainMultiheadAttentionLoRA.block_half (LoraAttnHalfFn: one frozen GEMM and one data-gradient GEMM for q, k, v, gradients of h summed
+    inside the launches) against LayerNormFn -> 3 x LoraLinearFn -> AttentionFn -> LoraLinearFn under the same dropout seeds: output, input
+    gradient and every factor / bias gradient."""
+    from uia_hip import functional as UF
+    from src.adapters.lora import PlainMultiheadAttentionLoRA
+    dt = {"fp32": torch.float32, "bf16": torch.bfloat16}[mode]
+    UF.set_compute_dtype(dt)
+    g = torch.Generator().manual_seed(23)
+    B, L, D, H, r = 3, 50, 128, 2, 8
+    mha = torch.nn.MultiheadAttention(D, H)
+    mod = PlainMultiheadAttentionLoRA(mha, enable_lora=["q", "k", "v", "o"], r=r, lora_alpha=16, dropout_rate=p_drop)
+    ln = torch.nn.LayerNorm(D)
+    with torch.no_grad():
+        for k, p in list(mod.named_parameters()) + list(ln.named_parameters()):
+            p.copy_((1.0 if k == "weight" and p.dim() == 1 else 0.0) + 0.15 * torch.randn(p.shape, generator=g))
+    mod, ln = mod.to(dev()).train(), ln.to(dev())
+    for p in ln.parameters():
+        p.requires_grad_(False)
+    x = torch.randn(B, L, D, generator=g).to(dev())
+    dy = torch.randn(B, L, D, generator=g).to(dev())
+    names = [k for k, p in mod.named_parameters() if p.requires_grad]
+
+    def run(fused):
+        for p in mod.parameters():
+            p.grad = None
+        UF.set_dropout_seed(31)
+        UF.clear_t_copies()
+        xx = x.clone().requires_grad_(True)
+        if fused:
+            y = mod.block_half(xx, ln, B, L, None)
+        else:
+            h = UF.LayerNormFn.apply(xx, ln.weight, ln.bias, ln.eps).view(B * L, D)
+            y = mod.rows_forward(h, B, L, None, resid32=xx.view(B * L, D)).view(B, L, D)
+        y.backward(dy)
+        return y.detach(), xx.grad.detach(), {k: dict(mod.named_parameters())[k].grad.detach().clone() for k in names}
+
+    y0, dx0, g0 = run(False)
+    y1, dx1, g1 = run(True)
+    tol = 1e-5 if mode == "fp32" else 2e-2
+    assert rel(y1, y0) < tol and rel(dx1, dx0) < tol
+    assert sorted(g1) == sorted(g0) and len(g1) == 12
+    for k in names:
+        assert rel(g1[k], g0[k]) < tol, k
+
+
+@pytest.mark.parametrize("M,N", [(32896, 1024), (2500, 640), (2049, 128)])
+def test_k64_stream_kernel_equals_the_tiled_kernel(M, N):
+    """Tile cfg 23 (K = 64 read-modify-write stream: the LoRA rank update and its data gradient) against the 128 x 256 tiles of cfg 14 with the
+    run-time epilogue: T residual -> T output in place, fp32 residual -> fp32 output in place, alpha, bias, dropout on the accumulator."""
+    from uia_hip import ops
+    g = torch.Generator(device="cpu").manual_seed(M + N)
+    dt = torch.bfloat16
+    t = torch.randn(M, 64, generator=g).to(dev()).to(dt)
+    w = (torch.randn(N, 64, generator=g) * 0.2).to(dev()).to(dt)
+    bias = torch.randn(N, generator=g).to(dev())
+    y_t = torch.randn(M, N, generator=g).to(dev()).to(dt)
+    y32 = torch.randn(M, N, generator=g).to(dev())
+    for kw in ({}, {"bias": bias}, {"drop": ("acc", 0.1, 4242)}):
+        outs = []
+        for cfg in (14, 23, 0):
+            a, b = y_t.clone(), y32.clone()
+            ops.gemm(t, w, alpha=1.5, resid_t=a, out_t=a, tile_cfg=cfg, **kw)
+            ops.gemm(t, w, alpha=1.5, resid=b, out32=b, tile_cfg=cfg, **kw)
+            torch.cuda.synchronize()
+            outs.append((a, b))
+        for a, b in outs[1:]:
+            assert torch.equal(a, outs[0][0]) and torch.equal(b, outs[0][1]), sorted(kw)
+    want = y32 + 1.5 * (t.float() @ w.float().T)
+    got = y32.clone()
+    ops.gemm(t, w, alpha=1.5, resid=got, out32=got)
+    assert rel(got, want) < 1e-5
