@@ -1559,6 +1559,8 @@ int launch_ring(hipStream_t stream, const UiaGemmParams& p, bool specialise, int
             UIA_EPI_CASE(EPI_BIAS | EPI_OUTT | EPI_LNFOLD);                                          // QKV
             UIA_EPI_CASE(EPI_BIAS | EPI_GELU | EPI_OUTT | EPI_LNFOLD);                               // fc1, frozen tower
             UIA_EPI_CASE(EPI_BIAS | EPI_GELU | EPI_AUX_OUT | EPI_OUTT | EPI_LNFOLD);                 // fc1 with the pre-activation stashed
+            UIA_EPI_CASE(EPI_QUICK | EPI_BIAS | EPI_GELU | EPI_OUTT | EPI_LNFOLD);                   // fc1 of a frozen OpenAI-CLIP block (CLIPSeg's backbone)
+            UIA_EPI_CASE(EPI_QUICK | EPI_BIAS | EPI_GELU | EPI_AUX_OUT | EPI_OUTT | EPI_LNFOLD);
 #undef UIA_EPI_CASE
             default: break;
         }
@@ -1838,7 +1840,9 @@ int launch_typed(hipStream_t stream, const UiaGemmParams& p, int cfg_in) {
     // cfg: 0 = auto. Tile choice is a pure speed knob (results are identical for every config
     // up to fp32 summation order inside a K-step, which does not depend on the tile).
     if (cfg == 0) {
-        if (p.N <= 64) cfg = ((p.M > 2048 || p.drop_where == 1) && skinny64_ok(p, (int)sizeof(T))) ? 16 : 4;
+        if (p.N <= 64) cfg = ((p.M > 2048 || p.drop_where == 1) && skinny64_ok(p, (int)sizeof(T))) ? 16
+                                 : ((p.M > 2048 && sizeof(T) == 2 && p.K >= 1024) ? 14 : 4);   // a W image too large for the stream kernel's LDS (CLIPSeg's K = 2048
+                                                                                                // reductions): the 3-deep ring streams A faster than the 2-buffer tiles (33 vs 42 us)
         else if (p.M <= 2048) cfg = (sizeof(T) == 4 && ((p.M + 127) / 128) * ((p.N + 127) / 128) < 64) ? 21 : 3;
             // fp32 MFMA issues 256 FLOP per clock per CU: the 8-12 workgroups of a [256, 512-768] head projection on 128 x 128 tiles were bound
             // by their own CUs' matrix pipes (69 us at K = 768); 32 x 64 tiles spread the same MFMA sequence per element over 64-96 CUs

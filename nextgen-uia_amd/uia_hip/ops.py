@@ -25,7 +25,8 @@ _SPECIALISED = {EPI_BIAS | EPI_RESID | EPI_OUT32, EPI_BIAS | EPI_RESIDT | EPI_OU
                 EPI_BIAS | EPI_GELU | EPI_AUX_OUT | EPI_OUTT,
                 EPI_QUICK | EPI_BIAS | EPI_GELU | EPI_OUTT, EPI_QUICK | EPI_DGELU | EPI_OUTT, EPI_QUICK | EPI_BIAS | EPI_GELU | EPI_AUX_OUT | EPI_OUTT,
                 EPI_BIAS | EPI_RESID | EPI_OUT32 | EPI_OUTT | EPI_ROWSUM, EPI_BIAS | EPI_RESID | EPI_RESID_LN | EPI_OUT32 | EPI_OUTT | EPI_ROWSUM,
-                EPI_BIAS | EPI_OUTT | EPI_LNFOLD, EPI_BIAS | EPI_GELU | EPI_OUTT | EPI_LNFOLD, EPI_BIAS | EPI_GELU | EPI_AUX_OUT | EPI_OUTT | EPI_LNFOLD}
+                EPI_BIAS | EPI_OUTT | EPI_LNFOLD, EPI_BIAS | EPI_GELU | EPI_OUTT | EPI_LNFOLD, EPI_BIAS | EPI_GELU | EPI_AUX_OUT | EPI_OUTT | EPI_LNFOLD,
+                EPI_QUICK | EPI_BIAS | EPI_GELU | EPI_OUTT | EPI_LNFOLD, EPI_QUICK | EPI_BIAS | EPI_GELU | EPI_AUX_OUT | EPI_OUTT | EPI_LNFOLD}
 
 
 def epi_mask_of(d):
@@ -46,7 +47,9 @@ def auto_tile_cfg(M, N, K=None, esz=2, mask=EPI_GENERIC):
     """Mirror of launch_typed() in csrc/gemm.hip (which kernel instantiation a shape runs on)."""
     if N <= 64:
         stream64 = N == 64 and M > 2048 and esz == 2 and K is not None and K % 32 == 0 and 64 * (2 * K + 16) <= 160 * 1024
-        return 16 if (stream64 and mask in (EPI_OUTT, EPI_BIAS | EPI_OUTT)) else 4
+        if stream64 and mask in (EPI_OUTT, EPI_BIAS | EPI_OUTT):
+            return 16
+        return 14 if (M > 2048 and esz == 2 and K is not None and K >= 1024) else 4
     if M <= 2048:
         return 21 if (esz == 4 and ((M + 127) // 128) * ((N + 127) // 128) < 64) else 3
     if K is not None and K * esz <= 128:
