@@ -47,7 +47,7 @@ def auto_tile_cfg(M, N, K=None, esz=2, mask=EPI_GENERIC):
     """Mirror of launch_typed() in csrc/gemm.hip (which kernel instantiation a shape runs on)."""
     if N <= 64:
         stream64 = N == 64 and M > 2048 and esz == 2 and K is not None and K % 32 == 0 and 64 * (2 * K + 16) <= 160 * 1024
-        if stream64 and mask in (EPI_OUTT, EPI_BIAS | EPI_OUTT):
+        if stream64 and mask in (EPI_OUTT, EPI_BIAS | EPI_OUTT, EPI_GENERIC):      # EPI_GENERIC = not known yet (the first look, before the descriptor is filled)
             return 16
         return 14 if (M > 2048 and esz == 2 and K is not None and K >= 1024) else 4
     if M <= 2048:

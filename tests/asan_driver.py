@@ -61,9 +61,23 @@ d.A = FAKE
 d.dact = 1
 expect_fail(lib.uia_gemm(None, 1, C.byref(d), 0), "dact needs aux_in")
 d.dact = 0
-for cfg in (0, 1, 3, 8, 12, 13, 14):                                    # valid descriptor: validation passes, the launch finds no device
+d.drop_where = 3
+expect_fail(lib.uia_gemm(None, 1, C.byref(d), 0), "drop_where=3")
+d.drop_where, d.drop_p = 2, 1.0
+expect_fail(lib.uia_gemm(None, 1, C.byref(d), 0), "outside [0, 1)")
+d.drop_where, d.drop_p = 1, 0.1                                         # dropout on the A operand is the N = 64 stream kernel's: N = 128 here
+expect_fail(lib.uia_gemm(None, 1, C.byref(d), 0), "drop_where = 1")
+expect_fail(lib.uia_gemm(None, 0, C.byref(d), 0), "dropout on the A operand needs bf16")
+d.drop_where, d.a_drop_out = 0, FAKE
+expect_fail(lib.uia_gemm(None, 1, C.byref(d), 0), "a_drop_out without drop_where")
+d.a_drop_out, d.drop_p = None, 0.0
+expect_fail(lib.uia_gemm(None, 0, C.byref(d), 23), "tile cfg 23 is the bf16")
+for cfg in (0, 1, 3, 8, 12, 13, 14, 21, 23):                                # valid descriptor: validation passes, the launch finds no device
     expect_fail(lib.uia_gemm(None, 1, C.byref(d), cfg))
 expect_fail(lib.uia_wgrad(None, 1, 100, 48, 64, FAKE, 64, FAKE, 64, 1.0, FAKE, None), "multiples of 64")
+expect_fail(lib.uia_wgrad_ex(None, 1, 100, 64, 64, FAKE, 64, FAKE, 64, 1.0, FAKE, 0, 16, 64, None), "ldw=0")
+expect_fail(lib.uia_wgrad_ex(None, 1, 100, 64, 64, FAKE, 64, FAKE, 64, 1.0, FAKE, 16, 65, 16, None), "valid extent")
+expect_fail(lib.uia_wgrad_ex(None, 1, 100, 64, 64, FAKE, 64, FAKE, 64, 1.0, FAKE, 8, 64, 16, None), "valid extent")
 a = mod.AttnDesc()
 expect_fail(lib.uia_attn_fwd(None, 1, None), "null descriptor")
 expect_fail(lib.uia_attn_fwd(None, 1, C.byref(a)), "empty problem")
