@@ -70,6 +70,7 @@ def parse():
     ap.add_argument("--wgrad-side-stream", action="store_true", help="A/B knob: the adapters' weight-gradient launches on a second HIP stream beside the data-gradient chain")
     ap.add_argument("--mona-fused", action="store_true", help="A/B knob: the adapter forward as ONE launch (uia_mona_fused_fwd) instead of pre, project1, spatial, project2")
     ap.add_argument("--no-tail-split", action="store_true", help="A/B knob: no half-height tiles for the M tail of a launch")
+    ap.add_argument("--no-tail-split-k", action="store_true", help="A/B knob: the M tail launches run their whole K chain (default: long-K tails of a few tiles are split over K)")
     ap.add_argument("--no-half-height-short-k", action="store_true", help="A/B knob: N <= 768, K <= 768 launches with a ragged last round as main + tail launches (round 2) "
                     "instead of one launch on half-height tiles")
     ap.add_argument("--global-loss", action="store_true", help="opt-in: InfoNCE over the global batch (all-gathered features) instead of "
@@ -335,6 +336,7 @@ def main():
     UF.set_deferred_text_ln(not args.no_deferred_text_ln)
     UF.set_ln_fold(not args.no_ln_fold)
     ops.KBLOCK_W, ops.TAIL_SPLIT, ops.K64_CFG14 = not args.no_kblock_w, not args.no_tail_split, not args.no_k64_cfg14
+    ops.TAIL_SPLIT_K = not args.no_tail_split_k
     ops.KBLOCK_ACT = not args.no_kblock_act
     ops.HALF_HEIGHT_SHORT_K = not args.no_half_height_short_k
     ops.MONA_FUSED = args.mona_fused

@@ -115,6 +115,12 @@ typedef struct uia_gemm_desc {
     float drop_p;
     uint64_t drop_seed;
     void* a_drop_out;
+    /* SPLIT K for launches of a few tiles and a long K (the M tail of a large GEMM: its cost is the latency of the K chain, not work).  Two calls with
+     * the SAME descriptor on tile config 13 (half-height tiles, run-time epilogue): 13 | slices << 16 | 1 << 22 runs one workgroup per (tile, K slice),
+     * each adding its raw fp32 accumulators into the tile's image in splitk_ws (hardware float atomics); 13 | slices << 16 | 2 << 22 reads the image,
+     * zeroes it again and runs the epilogue.  splitk_ws: tiles · 128·256 floats (tiles = ceil(M/128)·ceil(N/256)), 16-byte aligned, caller-owned,
+     * ZERO before the first use (the launches keep it zero between uses).  The slice partials meet in no fixed order: last-bit run-to-run variation. */
+    float* splitk_ws;
 } uia_gemm_desc;
 int uia_gemm(void* stream, int dtype, const uia_gemm_desc* d, int tile_cfg /* 0 = auto */);
 

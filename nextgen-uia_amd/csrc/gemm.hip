@@ -1001,8 +1001,8 @@ int launch_pp(hipStream_t stream, const UiaGemmParams& p) {
 //   sub-tile t-1, whose final ds_reads (group 1, wall slot 2·t·SPT-1) were retired before that slot's barrier.
 // 64-byte rows use the 4-entry swizzle table {0,3,2,1} indexed by (row>>2)&3 (A) / the 16-row block of the
 // permuted W rows: conflict-free ds_read_b128 for both fragment patterns.
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int NBUF, int EPI, int LOOP = 0>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_tn_ring_kernel(const UiaGemmParams p, const int xflags) {   // 2 waves per SIMD: one 8-wave
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int NBUF, int EPI, int LOOP = 0, bool SK = false>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_tn_ring_kernel(const UiaGemmParams p, const int xflags, const int sk_info) {   // 2 waves per SIMD: one 8-wave
                                                                                                                             // workgroup, or two 4-wave ones, per CU
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NW = WAVES_M * WAVES_N;
@@ -1035,12 +1035,23 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_tn_ring_kernel
     }
 #endif
     const int tiles_n = (p.N + BN - 1) / BN;
-    const int nwg = gridDim.x;
-    int bid = blockIdx.x;
+    // SPLIT K (sk_info = slices << 2 | phase; the M tail of a launch: a few dozen tiles whose cost is the latency of their K chain, not work).
+    //   phase 1: the grid holds `slices` workgroups per tile; each runs its share of the sub-tiles and adds its raw accumulators into the tile's
+    //            image in p.splitk_ws (hardware fp32 atomics; the image is zero between uses), no epilogue;
+    //   phase 2: one workgroup per tile, no K loop: the accumulators are that image (zeroed again behind the read), then the epilogue as usual.
+    // Each output element is still ONE fp32 sum over K; the order in which the slice partials meet is not fixed (results vary in the last bit
+    // from run to run: tails only, opt-out ops.TAIL_SPLIT_K).
+    // A compile-time variant (SK; instantiated for the tail config with the run-time epilogue only): with the branches in every instantiation the
+    // step's main launches lost 1 ms (46.6 vs 45.5 ms, same box, alternating runs).
+    const int sk_phase = SK ? (sk_info & 3) : 0, sk_n = SK ? (sk_info >> 2) : 1;
+    int nwg = gridDim.x;
+    int bid = blockIdx.x, ks = 0;
+    if (SK && sk_phase == 1) { ks = bid % sk_n; bid /= sk_n; nwg /= sk_n; }
     {
         const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
+    const int tile_id = bid;
     // Tile order inside an XCD's run (xflags & 255 = GM): GM == 0 walks all column panels of one row panel, then the next row
     // panel; GM > 0 walks GROUPS of GM row panels column by column, rows fastest, so that the ~32 tiles an XCD has in flight
     // form a GM x (32/GM) block: (GM + 32/GM) operand panels per K slice instead of (32/tiles_n + tiles_n), and consecutive
@@ -1136,11 +1147,21 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_tn_ring_kernel
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int ntl = (p.K * ESZ) / BKB;                                       // sub-tiles
+    const int ntl_all = (p.K * ESZ) / BKB;                                   // sub-tiles
+    int t0 = 0, ntl = ntl_all;
+    if (!SK) {
+    } else if (sk_phase == 1) {
+        const int per = (ntl_all + sk_n - 1) / sk_n;
+        t0 = ks * per;
+        ntl = ntl_all - t0 < per ? ntl_all - t0 : per;
+        ntl = ntl < 0 ? 0 : ntl;
+    } else if (sk_phase == 2) {
+        ntl = 0;
+    }
     // part = which 1/SPT of this wave's pieces of sub-tile t (the DMA issue is spread over the wave's LOAD slots)
     auto stage = [&](int t, int part) {
         char* base = smem + (t % NBUF) * BUF_BYTES;
-        const size_t koffA = (size_t)t * kstepA, koffW = (size_t)t * kstepW;
+        const size_t koffA = (size_t)(t + t0) * kstepA, koffW = (size_t)(t + t0) * kstepW;
 #pragma unroll
         for (int i = 0; i < GPT; ++i) {
             if (i * SPT / GPT != part && SPT > 1) continue;
@@ -1320,6 +1341,34 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_tn_ring_kernel
 #ifdef UIA_GEMM_STAMPS
     t_loop = __builtin_amdgcn_s_memtime();
 #endif
+    if (SK && sk_phase != 0) {
+        // The slices of a tile ADD their raw accumulators into ONE tile-sized fp32 image with hardware float atomics ([tile][wave][MT·NT·4][lane]:
+        // 256 contiguous bytes per instruction); the second launch reads it and leaves it zeroed for the next use.  (Slices stored side by side and
+        // summed by the second launch made that launch 26 us for four workgroups reading 4 x 128 KB each: it gave back what the first one gained.)
+        constexpr size_t WAVE_FLOATS = (size_t)MT * NT * 256;
+        float* ws = p.splitk_ws + ((size_t)tile_id * NW + wave) * WAVE_FLOATS + lane;
+        if (sk_phase == 1) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) unsafeAtomicAdd(ws + ((i * NT + j) * 4 + r) * 64, acc[i][j][r]);
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = ws[((i * NT + j) * 4 + r) * 64];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ws[((i * NT + j) * 4 + r) * 64] = 0.f;
+    }
     gemm_epilogue_lds<T, MT, NT, WTM, WTN, EPI>(p, acc, smem, wave, lane, m0, n0, wm, wn,
                                                 LNROW ? (float*)(smem + NW * EpiPatch<MT, WTN>::BYTES_PER_WAVE + wave * (WTM * 8)) : nullptr,
                                                 LNROW ? lnpre : nullptr);
@@ -1334,17 +1383,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_tn_ring_kernel
 #endif
 }
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int NBUF, int EPI, int LOOP = 0>
-int launch_ring_epi(hipStream_t stream, const UiaGemmParams& p, int xflags) {
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int NBUF, int EPI, int LOOP = 0, bool SK = false>
+int launch_ring_epi(hipStream_t stream, const UiaGemmParams& p, int xflags, int sk_info = 0) {
     constexpr bool LNROW = EPI == EPI_GENERIC || (EPI & (EPI_LNFOLD | EPI_RESID_LN)) != 0;      // + one (rstd, -mean·rstd) / (mean, rstd) pair per tile row per column of waves
     constexpr int EPB = WAVES_M * WAVES_N * EpiPatch<BM / WAVES_M / 16, BN / WAVES_N>::BYTES_PER_WAVE + (LNROW ? WAVES_N * BM * 8 : 0);
     constexpr int LDS = NBUF * (BM + BN) * BKB > EPB ? NBUF * (BM + BN) * BKB : EPB;
     static_assert(LDS <= 160 * 1024, "LDS budget");
-    auto kern = gemm_tn_ring_kernel<T, BM, BN, WAVES_M, WAVES_N, BKB, NBUF, EPI, LOOP>;
+    auto kern = gemm_tn_ring_kernel<T, BM, BN, WAVES_M, WAVES_N, BKB, NBUF, EPI, LOOP, SK>;
     static UiaDevOnce attr_once;
     UIA_ENSURE_LDS_ATTR(attr_once, kern, LDS);
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(64 * WAVES_M * WAVES_N), LDS, stream, p, xflags);
+    const int grid = (SK && (sk_info & 3) == 1) ? tiles * (sk_info >> 2) : tiles;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES_M * WAVES_N), LDS, stream, p, xflags, sk_info);
     UIA_CHECK_LAUNCH();
     return 0;
 }
@@ -1537,7 +1587,10 @@ inline int epi_mask_of(const UiaGemmParams& p) {
 }
 
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int NBUF, int LOOP = 0>
-int launch_ring(hipStream_t stream, const UiaGemmParams& p, bool specialise, int xflags) {
+int launch_ring(hipStream_t stream, const UiaGemmParams& p, bool specialise, int xflags, int sk_info = 0) {
+    if constexpr (BM == 128 && BN == 256 && NBUF == 4 && LOOP == 0) {          // tile cfg 13 only
+        if (sk_info != 0) return launch_ring_epi<T, BM, BN, WAVES_M, WAVES_N, BKB, NBUF, EPI_GENERIC, LOOP, true>(stream, p, xflags, sk_info);
+    }
     if (specialise) {
         switch (epi_mask_of(p)) {    // the six masks of a training step, by time spent (tools/gemm_census.py)
 #define UIA_EPI_CASE(MASK) case (MASK): return launch_ring_epi<T, BM, BN, WAVES_M, WAVES_N, BKB, NBUF, (MASK), LOOP>(stream, p, xflags)
@@ -1836,6 +1889,22 @@ int launch_typed(hipStream_t stream, const UiaGemmParams& p, int cfg_in) {
     // bits 8.. of the tile argument carry experiment knobs for the ring kernels (tile-order group size, diagnostic layouts);
     // 0 there = the launcher's own choice.
     int cfg = cfg_in & 255, xflags = cfg_in >> 8;
+    int sk_info = 0;
+#if !defined(UIA_GEMM_EXP) && !defined(UIA_GEMM_STAMPS)
+    // bits 16-21: K slices, bits 22-23: split-K phase (1 = partial sums of one slice per workgroup into splitk_ws, 2 = sum of the slices + epilogue)
+    {
+        const int slices = (cfg_in >> 16) & 63, phase = (cfg_in >> 22) & 3;
+        xflags &= 255;
+        if (phase != 0) {
+            if (phase == 3 || slices < 2 || cfg != 13 || !p.splitk_ws || (uintptr_t)p.splitk_ws % 16 != 0 || p.K * (int)sizeof(T) / 64 < slices) {
+                uia_set_error("uia_gemm: split K needs phase 1 or 2, 2..63 slices (at most one per 64 bytes of K), the half-height tail config (tile cfg 13) and a 16-byte aligned splitk_ws; "
+                              "got phase %d, %d slices, tile cfg %d", phase, slices, cfg);
+                return -1;
+            }
+            sk_info = (slices << 2) | phase;
+        }
+    }
+#endif
     const int gm_req = xflags & 255;                           // tile-order group: 0 = the launcher's choice, 255 = none (row-panel-major)
     // cfg: 0 = auto. Tile choice is a pure speed knob (results are identical for every config
     // up to fp32 summation order inside a K-step, which does not depend on the tile).
@@ -1909,7 +1978,7 @@ int launch_typed(hipStream_t stream, const UiaGemmParams& p, int cfg_in) {
         case 18: return launch_ring<T, 128, 256, 1, 4, 64, 3>(stream, p, true, xflags);   // 128 x 256 tiles
 #endif
         case 14: return launch_ring<T, 128, 256, 2, 4, 64, 3>(stream, p, true, xflags);   // 3-deep ring: 72 KB of LDS, two workgroups per CU
-        case 13: return launch_ring<T, 128, 256, 2, 4, 64, 4>(stream, p, true, xflags);   // half-height tiles: the M tail of a launch whose last round
+        case 13: return launch_ring<T, 128, 256, 2, 4, 64, 4>(stream, p, true, xflags, sk_info);   // half-height tiles: the M tail of a launch whose last round
                                                                                          // would leave most CUs idle (host splits the rows, ops.gemm)
         default: uia_set_error("uia_gemm: unknown tile config %d", cfg); return -1;
     }

@@ -64,6 +64,8 @@ K64_CFG14 = True         # single-K-step GEMMs on the two-workgroups-per-CU half
 TILE_GROUP = {}          # experiment knob: {N: row panels per tile-order group} overriding the launcher's choice for ring launches with that N
 HALF_HEIGHT_SHORT_K = True   # N <= 768, K <= 768 (bf16) launches whose 256-row tiling leaves a ragged last round run on half-height tiles (cfg 14) in one launch
 TAIL_SPLIT = True        # split off the M tail of a launch whose last round of 256x256 tiles would leave most CUs idle
+TAIL_SPLIT_K = True      # ... and run that tail split over K when it is a few tiles with a long K chain (two launches: slice partials, then sum + epilogue)
+_SPLITK_WS = {}
 _NCU = {}
 
 
@@ -72,6 +74,27 @@ def num_cus(device=None):
     if dev not in _NCU:
         _NCU[dev] = torch.cuda.get_device_properties(dev).multi_processor_count
     return _NCU[dev]
+
+
+def tail_k_slices(rows, N, K, esz, ncu):
+    """K slices for the half-height tail launch (tile cfg 13) of `rows` rows, or 0.  A tail of t tiles keeps t of the CUs busy for the whole K chain
+    (ViT-L/14's 128-row tails: 4 tiles, 64 us at K = 4096); sliced over K it uses s·t CUs for 1/s of the chain, at the price of a second launch
+    that sums the slices.  Worth it for at most a quarter of the CUs' worth of tiles and from 4 KiB of K per row; at least 1 KiB of K per slice."""
+    tiles = -(-rows // 128) * -(-N // 256)
+    kb = K * esz
+    if not TAIL_SPLIT_K or esz != 2 or kb < 4096 or 4 * tiles > ncu:           # 81 tiles x 3 slices (the headline step's tails) measured level: the sum launch eats the gain
+        return 0
+    s = min(ncu // tiles, kb // 1024, 16)
+    return s if s >= 2 else 0
+
+
+def splitk_workspace(floats, device):
+    """fp32 scratch of the split-K tail launches: one per (device, stream) — consecutive launches of a stream are ordered, two streams are not."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+    t = _SPLITK_WS.get(key)
+    if t is None or t.numel() < floats:
+        t = _SPLITK_WS[key] = torch.zeros(max(floats, 1 << 20), device=device, dtype=torch.float32)     # zero once: the launches leave it zero
+    return t
 
 
 def tail_split_rows(M, N, ncu, bm=256, bn=256):
@@ -288,11 +311,13 @@ def gemm(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None, res
             tile_cfg, m_main = 14, M
         if m_main < M:
             cut = lambda t, lo, hi: None if t is None else (t.row_range(lo, hi) if is_kb(t) else t[lo:hi])
-            for lo, hi, cfg in ((0, m_main, 8), (m_main, M, 13)):
+            slices = tail_k_slices(M - m_main, N, Ka, a.element_size(), num_cus(a.device.index))
+            ws = splitk_workspace(-(-(M - m_main) // 128) * -(-N // 256) * 128 * 256, a.device) if slices else None
+            for lo, hi, cfg in ((0, m_main, 8),) + (((m_main, M, 13 | slices << 16 | 1 << 22), (m_main, M, 13 | slices << 16 | 2 << 22)) if slices else ((m_main, M, 13),)):
                 _gemm_one(cut(a, lo, hi), w, bias=bias, act=act, dact=dact, aux_in=cut(aux_in, lo, hi), aux_out=cut(aux_out, lo, hi), resid=cut(resid, lo, hi),
                           resid_t=cut(resid_t, lo, hi), out_t=cut(out_t, lo, hi), out32=cut(out32, lo, hi), alpha=alpha, tile_cfg=cfg,
                           resid_ln=None if resid_ln is None else (resid_ln[0][lo:hi],) + tuple(resid_ln[1:]), rowsum=cut(rowsum, lo, hi),
-                          lnfold=None if lnfold is None else (lnfold[0][lo:hi],) + tuple(lnfold[1:]))
+                          lnfold=None if lnfold is None else (lnfold[0][lo:hi],) + tuple(lnfold[1:]), splitk_ws=ws if cfg >> 16 else None)
             return
     _gemm_one(a, w, bias=bias, act=act, dact=dact, aux_in=aux_in, aux_out=aux_out, resid=resid, resid_mod=resid_mod, resid_row_off=resid_row_off,
               resid_t=resid_t, out_group=out_group, out_t=out_t, out32=out32, alpha=alpha, tile_cfg=tile_cfg, resid_ln=resid_ln,
@@ -300,8 +325,10 @@ def gemm(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None, res
 
 
 def _gemm_one(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None, resid=None, resid_mod=0, resid_row_off=0,
-              resid_t=None, out_group=0, out_t=None, out32=None, alpha=1.0, tile_cfg=0, resid_ln=None, rowsum=None, lnfold=None, drop=None):
+              resid_t=None, out_group=0, out_t=None, out32=None, alpha=1.0, tile_cfg=0, resid_ln=None, rowsum=None, lnfold=None, drop=None, splitk_ws=None):
     d = GemmDesc()
+    if splitk_ws is not None:
+        d.splitk_ws = _p(splitk_ws)
     if drop is not None:
         d.drop_where, d.drop_p, d.drop_seed = {"a": 1, "acc": 2}[drop[0]], float(drop[1]), int(drop[2]) & 0xFFFFFFFFFFFFFFFF
         if len(drop) > 3 and drop[3] is not None:

@@ -415,3 +415,48 @@ def test_k64_stream_kernel_equals_the_tiled_kernel(M, N):
     got = y32.clone()
     ops.gemm(t, w, alpha=1.5, resid=got, out32=got)
     assert rel(got, want) < 1e-5
+
+
+@pytest.mark.parametrize("M,N,K,slices", [(700, 768, 3072, 3), (128, 1024, 4096, 8), (333, 520, 2048, 5)])
+def test_split_k_tail_launch_equals_the_whole_k_launch(M, N, K, slices):
+    """The M tail of a large GEMM as two launches (K slices into a workspace, then sum + epilogue) against the same tiles with the whole K chain:
+    every epilogue the step's tails use — fp32 residual, plain, GELU with stash, folded LayerNorm, GELU', row sums.  One fp32 sum per element
+    either way; only its association differs."""
+    from uia_hip import ops
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    dt = torch.bfloat16
+    a = torch.randn(M, K, generator=g).to(dev()).to(dt)
+    w = ops.PackedW((torch.randn(N, K, generator=g) * K ** -0.5).to(dev()).to(dt))
+    bias = torch.randn(N, generator=g).to(dev())
+    resid = torch.randn(M, N, generator=g).to(dev())
+    aux = (torch.randn(M, N, generator=g) * 1.5).to(dev()).to(dt)
+    sums_in = ops.rowsum_from_float(torch.stack([resid.sum(1), (resid * resid).sum(1)], 1))
+    csum = w.row.float().sum(1).contiguous()
+    ws = torch.zeros(-(-M // 128) * -(-N // 256) * 128 * 256, device=dev())          # zero before the first use; every pair of launches leaves it zero
+
+    def run(kind, split):
+        o32 = torch.full((M, N), float("nan"), device=dev())
+        ot = torch.full((M, N), float("nan"), device=dev(), dtype=dt)
+        ax = torch.full((M, N), float("nan"), device=dev(), dtype=dt)
+        rs = torch.zeros(M, 2, device=dev(), dtype=torch.int64)
+        kw = {"resid32": dict(bias=bias, resid=resid, out32=o32), "plain": dict(out_t=ot), "gelu_stash_fold": dict(bias=bias, act="gelu", aux_out=ax, out_t=ot, lnfold=(sums_in, csum, N, 1e-5)),
+              "dgelu": dict(dact="gelu", aux_in=aux, out_t=ot), "producer": dict(bias=bias, resid=resid, out32=o32, out_t=ot, rowsum=rs)}[kind]
+        if split:
+            for phase in (1, 2):
+                ops._gemm_one(a, w, tile_cfg=13 | slices << 16 | phase << 22, splitk_ws=ws, **kw)
+        else:
+            ops._gemm_one(a, w, tile_cfg=13, **kw)
+        torch.cuda.synchronize()
+        return o32, ot, ax, ops.rowsum_to_float(rs)
+
+    for kind in ("resid32", "plain", "gelu_stash_fold", "dgelu", "producer"):
+        ref, got = run(kind, False), run(kind, True)
+        for name, x, y in zip(("out32", "outT", "aux_out", "rowsum"), got, ref):
+            if torch.isnan(y).all():
+                assert torch.isnan(x).all(), (kind, name)
+                continue
+            assert not torch.isnan(x).any(), (kind, name)
+            assert rel(x, y) < (1e-2 if x.dtype == dt else 2e-5), (kind, name, rel(x, y))
+    assert float(ws.abs().max()) == 0.0
+    with pytest.raises(ops.UiaError, match="split K"):
+        ops._gemm_one(a, w, out_t=torch.empty(M, N, device=dev(), dtype=dt), tile_cfg=3 | slices << 16 | 1 << 22, splitk_ws=ws)
