@@ -1648,8 +1648,8 @@ int launch_persist(hipStream_t stream, const UiaGemmParams& p) {
 // into registers (16 rows x 64 contiguous bytes per instruction, CH instructions in flight per wave) and W as the MFMA A operand,
 // so that a lane ends up with four consecutive outputs of one row.  The 256 x 64 tile config had 197 workgroups for 256 CUs, each
 // streaming its rows through a double-buffered LDS ring with a barrier per K step: 35 / 34 us inside the step; this one 31 / 26 (14 at HBM rate).
-template <int CH>      // K steps (32 columns each) whose A fragments a wave requests before it starts multiplying
-__global__ __launch_bounds__(512) void gemm_skinny64_kernel(const UiaGemmParams p) {
+template <int CH, int NWV = 8>      // CH: K steps (32 columns each) whose A fragments a wave requests before it starts multiplying; NWV: waves per workgroup
+__global__ __launch_bounds__(64 * NWV) void gemm_skinny64_kernel(const UiaGemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int K = p.K, KS = K >> 5;
     const int ldw_b = 2 * K + 16;                          // row stride of the W image: +16 B staggers the rows over the banks
@@ -1657,7 +1657,7 @@ __global__ __launch_bounds__(512) void gemm_skinny64_kernel(const UiaGemmParams 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     {
         const int cpr = K >> 3;                            // 16-byte chunks per row of W
-        for (int c = tid; c < 64 * cpr; c += 512) {
+        for (int c = tid; c < 64 * cpr; c += 64 * NWV) {
             const int r = c / cpr, cc = c - r * cpr;
             *(uint4*)(smem + r * ldw_b + cc * 16) = *(const uint4*)((const char*)p.W + ((size_t)r * p.ldw) * 2 + cc * 16);
         }
@@ -1673,7 +1673,7 @@ __global__ __launch_bounds__(512) void gemm_skinny64_kernel(const UiaGemmParams 
     const uint32_t drop_th = dropout_thresh16(p.drop_p);
     const float drop_inv = 1.0f / (1.0f - p.drop_p);
     const int ntiles = (p.M + 15) >> 4;
-    for (int tile = blockIdx.x * 8 + wave; tile < ntiles; tile += gridDim.x * 8) {
+    for (int tile = blockIdx.x * NWV + wave; tile < ntiles; tile += gridDim.x * NWV) {
         const int m = 16 * tile + li;
         const int mc = m < p.M ? m : p.M - 1;
         const char* arow = (const char*)p.A + ((size_t)mc * p.lda) * 2 + g * 16;
@@ -1731,6 +1731,21 @@ int launch_skinny64(hipStream_t stream, const UiaGemmParams& p) {
     const int ntiles = (p.M + 15) / 16;
     int grid = (ntiles + 7) / 8;
     grid = grid < ncu ? grid : ncu;
+    {   // Sixteen waves per CU when eight would need a second, partly filled pass over the tiles (M = 50 432: 3152 tiles for 2048 waves):
+        // every tile is then in flight at once (4 waves per SIMD at <= 128 VGPRs).
+        static UiaDevOnce once16;
+        const char* env = getenv("UIA_SKINNY_WAVES");
+        const int want = env ? atoi(env) : 0;
+        const bool two_pass = ntiles > 8 * ncu && ntiles <= 16 * ncu;
+        if ((want == 16 || (want == 0 && two_pass)) && !p.drop_where) {
+            UIA_ENSURE_LDS_ATTR(once16, (gemm_skinny64_kernel<8, 16>), 160 * 1024);
+            int g16 = (ntiles + 15) / 16;
+            g16 = g16 < ncu ? g16 : ncu;
+            hipLaunchKernelGGL((gemm_skinny64_kernel<8, 16>), dim3(g16), dim3(1024), lds, stream, p);
+            UIA_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     // eight K steps (8 KiB per wave) in flight: requesting a whole 768-wide row tile at once (24 steps, 160 VGPRs) measured slower
     // inside the step (34 / 30 us against 31 / 26 for the two Mona launches)
     hipLaunchKernelGGL(gemm_skinny64_kernel<8>, dim3(grid), dim3(512), lds, stream, p);
