@@ -70,6 +70,7 @@ def parse():
     ap.add_argument("--wgrad-side-stream", action="store_true", help="A/B knob: the adapters' weight-gradient launches on a second HIP stream beside the data-gradient chain")
     ap.add_argument("--mona-fused", action="store_true", help="A/B knob: the adapter forward as ONE launch (uia_mona_fused_fwd) instead of pre, project1, spatial, project2")
     ap.add_argument("--no-tail-split", action="store_true", help="A/B knob: no half-height tiles for the M tail of a launch")
+    ap.add_argument("--ring5", action="store_true", help="experiment knob: long-K / wide-N 256x256 launches on the 5-deep ring (tile cfg 24) instead of the 4-deep one")
     ap.add_argument("--no-tail-split-k", action="store_true", help="A/B knob: the M tail launches run their whole K chain (default: long-K tails of a few tiles are split over K)")
     ap.add_argument("--no-half-height-short-k", action="store_true", help="A/B knob: N <= 768, K <= 768 launches with a ragged last round as main + tail launches (round 2) "
                     "instead of one launch on half-height tiles")
@@ -217,7 +218,7 @@ def gemm_roofline(prof, prof_serial, args, ms_per_step, ops, torch):
 
     per_kernel = lambda c, m: (c, m if m in ops._SPECIALISED else ops.EPI_GENERIC)
     by_k, by_k_serial = group(prof, per_kernel), group(prof_serial, per_kernel)
-    fam, fam_serial = group(prof, lambda c, m: c in (8, 12, 13, 14)), group(prof_serial, lambda c, m: c in (8, 12, 13, 14))
+    fam, fam_serial = group(prof, lambda c, m: c in (8, 12, 13, 14, 24)), group(prof_serial, lambda c, m: c in (8, 12, 13, 14, 24))
     if not by_k:
         return None
     dom = max(by_k, key=lambda k: by_k[k][0])
@@ -337,6 +338,7 @@ def main():
     UF.set_ln_fold(not args.no_ln_fold)
     ops.KBLOCK_W, ops.TAIL_SPLIT, ops.K64_CFG14 = not args.no_kblock_w, not args.no_tail_split, not args.no_k64_cfg14
     ops.TAIL_SPLIT_K = not args.no_tail_split_k
+    ops.RING5 = args.ring5
     ops.KBLOCK_ACT = not args.no_kblock_act
     ops.HALF_HEIGHT_SHORT_K = not args.no_half_height_short_k
     ops.MONA_FUSED = args.mona_fused

@@ -1941,8 +1941,8 @@ int launch_typed(hipStream_t stream, const UiaGemmParams& p, int cfg_in) {
         uia_set_error("uia_gemm: dropout on the A operand (drop_where = 1) is the N = 64 stream kernel's (tile cfg 16: bf16, N == 64, M > 2048, bias + T output only), not tile cfg %d", cfg);
         return -1;
     }
-    const bool ring = cfg == 8 || cfg == 9 || cfg == 10 || cfg == 12 || cfg == 13 || cfg == 14 || cfg == 15 || (cfg >= 17 && cfg <= 20);
-    if ((p.a_kb_rows || p.outT_kb_rows) && !(cfg == 8 || cfg == 10 || cfg == 12 || cfg == 13 || cfg == 14 || cfg == 15 || (cfg >= 17 && cfg <= 20))) {
+    const bool ring = cfg == 8 || cfg == 9 || cfg == 10 || cfg == 12 || cfg == 13 || cfg == 14 || cfg == 15 || (cfg >= 17 && cfg <= 20) || cfg == 24;
+    if ((p.a_kb_rows || p.outT_kb_rows) && !(cfg == 8 || cfg == 10 || cfg == 12 || cfg == 13 || cfg == 14 || cfg == 15 || (cfg >= 17 && cfg <= 20) || cfg == 24)) {
         uia_set_error("uia_gemm: K-blocked activations (a_kb_rows / outT_kb_rows) need a ring tile config with 64-byte sub-tiles (8, 10, 13, 14), not %d", cfg);
         return -1;
     }
@@ -1992,6 +1992,7 @@ int launch_typed(hipStream_t stream, const UiaGemmParams& p, int cfg_in) {
         case 17: return launch_ring<T, 256, 128, 2, 2, 64, 3>(stream, p, true, xflags);   // 256 x 128 tiles (A panel re-read by the column neighbour)
         case 18: return launch_ring<T, 128, 256, 1, 4, 64, 3>(stream, p, true, xflags);   // 128 x 256 tiles
 #endif
+        case 24: return launch_ring<T, 256, 256, 2, 4, 64, 5>(stream, p, true, xflags);   // cfg 8 on a 5-deep ring (160 KB of LDS, four sub-tiles in flight): +4-5 % on long-K shapes in isolation, level inside the step: opt-in (ops.RING5)
         case 14: return launch_ring<T, 128, 256, 2, 4, 64, 3>(stream, p, true, xflags);   // 3-deep ring: 72 KB of LDS, two workgroups per CU
         case 13: return launch_ring<T, 128, 256, 2, 4, 64, 4>(stream, p, true, xflags, sk_info);   // half-height tiles: the M tail of a launch whose last round
                                                                                          // would leave most CUs idle (host splits the rows, ops.gemm)

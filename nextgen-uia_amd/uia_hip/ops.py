@@ -57,13 +57,14 @@ def auto_tile_cfg(M, N, K=None, esz=2, mask=EPI_GENERIC):
     return 8
 
 
-RING_CFGS = (8, 9, 10, 12, 13, 14)
+RING_CFGS = (8, 9, 10, 12, 13, 14, 24)
 PERSIST_STORE_ONLY = False   # experiment knob: 256x256 ring launches whose epilogue only stores T results run on the persistent variant (cfg 12)
 KBLOCK_W = True          # hand the ring kernels their weights K-blocked (PackedW.kblocked()); False = row-major everywhere
 K64_CFG14 = True         # single-K-step GEMMs on the two-workgroups-per-CU half-height config (False: 256x256 like every other large shape)
 TILE_GROUP = {}          # experiment knob: {N: row panels per tile-order group} overriding the launcher's choice for ring launches with that N
 HALF_HEIGHT_SHORT_K = True   # N <= 768, K <= 768 (bf16) launches whose 256-row tiling leaves a ragged last round run on half-height tiles (cfg 14) in one launch
 TAIL_SPLIT = True        # split off the M tail of a launch whose last round of 256x256 tiles would leave most CUs idle
+RING5 = False            # experiment knob: 256x256 launches with a long K loop or a wide N on the 5-deep ring (tile cfg 24: 160 KB of LDS, four sub-tiles in flight)
 TAIL_SPLIT_K = True      # ... and run that tail split over K when it is a few tiles with a long K chain (two launches: slice partials, then sum + epilogue)
 _SPLITK_WS = {}
 _NCU = {}
@@ -74,6 +75,13 @@ def num_cus(device=None):
     if dev not in _NCU:
         _NCU[dev] = torch.cuda.get_device_properties(dev).multi_processor_count
     return _NCU[dev]
+
+
+def big_tile_cfg(N, K, esz):
+    """8 or 24 for a launch auto_tile_cfg() puts on the 256x256 ring tiles.  Isolated, plain epilogue (tools/time_ring_depth.py) the fifth ring slot is
+    worth 4-5.5 % at K = 3072 and at 43 520 rows and 0.5-1.6 % at 65 536 x {2304, 3072} x 768 (and costs 7 % at N = 768, K = 768); inside the step, behind the
+    fused epilogues, it is level to slightly worse on every one of those launches (44.5-44.9 ms either way, three alternating pairs on one box): opt-in."""
+    return 24 if (RING5 and esz == 2 and (K * esz >= 2048 or N >= 2304)) else 8
 
 
 def tail_k_slices(rows, N, K, esz, ncu):
@@ -241,8 +249,8 @@ def gemm_kernel_name(cfg, mask, dtype):
     mi = lambda v: f"Li{v}E" if v >= 0 else f"Lin{-v}E"
     if cfg == 12:
         return f"gemm_tn_persist_kernel<{tn},{m}>", f"gemm_tn_persist_kernelI{tc}{mi(m)}E"
-    if cfg in (8, 13, 14):
-        bm, nbuf = (256, 4) if cfg == 8 else ((128, 4) if cfg == 13 else (128, 3))
+    if cfg in (8, 13, 14, 24):
+        bm, nbuf = (256, 4) if cfg == 8 else ((256, 5) if cfg == 24 else ((128, 4) if cfg == 13 else (128, 3)))
         return f"gemm_tn_ring_kernel<{tn},{bm},256,2,4,64,{nbuf},{m}>", "gemm_tn_ring_kernelI" + tc + "".join(mi(v) for v in (bm, 256, 2, 4, 64, nbuf, m, 0)) + "Lb0EE"
     if cfg == 16:
         return "gemm_skinny64_kernel", "gemm_skinny64_kernel"
@@ -313,7 +321,7 @@ def gemm(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None, res
             cut = lambda t, lo, hi: None if t is None else (t.row_range(lo, hi) if is_kb(t) else t[lo:hi])
             slices = tail_k_slices(M - m_main, N, Ka, a.element_size(), num_cus(a.device.index))
             ws = splitk_workspace(-(-(M - m_main) // 128) * -(-N // 256) * 128 * 256, a.device) if slices else None
-            for lo, hi, cfg in ((0, m_main, 8),) + (((m_main, M, 13 | slices << 16 | 1 << 22), (m_main, M, 13 | slices << 16 | 2 << 22)) if slices else ((m_main, M, 13),)):
+            for lo, hi, cfg in ((0, m_main, big_tile_cfg(N, Ka, a.element_size())),) + (((m_main, M, 13 | slices << 16 | 1 << 22), (m_main, M, 13 | slices << 16 | 2 << 22)) if slices else ((m_main, M, 13),)):
                 _gemm_one(cut(a, lo, hi), w, bias=bias, act=act, dact=dact, aux_in=cut(aux_in, lo, hi), aux_out=cut(aux_out, lo, hi), resid=cut(resid, lo, hi),
                           resid_t=cut(resid_t, lo, hi), out_t=cut(out_t, lo, hi), out32=cut(out32, lo, hi), alpha=alpha, tile_cfg=cfg,
                           resid_ln=None if resid_ln is None else (resid_ln[0][lo:hi],) + tuple(resid_ln[1:]), rowsum=cut(rowsum, lo, hi),
@@ -358,6 +366,9 @@ def _gemm_one(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None
             and ((out_t is not None and out32 is None and resid is None and (resid_t is not None or drop is not None))
                  or (out32 is not None and out_t is None and resid_t is None and (resid is not None or drop is not None)))):
         base_cfg = 23
+    if (tile_cfg & 255) == 0 and base_cfg == 8:
+        base_cfg = big_tile_cfg(d.N, d.K, a.element_size())
+        tile_cfg |= base_cfg
     if (PERSIST_STORE_ONLY and base_cfg == 8 and resid is None and resid_t is None and out32 is None and rowsum is None and out_group == 0
             and alpha == 1.0 and d.K * a.element_size() >= 1024):
         base_cfg, tile_cfg = 12, (tile_cfg & ~255) | 12
