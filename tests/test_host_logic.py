@@ -237,3 +237,22 @@ def test_kblocked_activation_policy_and_views():
         assert kb.t[k // 32, m, k % 32] == logical[m, k]
     sl = kb.row_range(2, 5)
     assert sl.rows == 3 and sl.t.stride(0) == M * 32 and sl.t.data_ptr() == buf.data_ptr() + 2 * 32 * 2
+
+
+def test_gemm_schedule_mirrors_are_pure_host_logic():
+    """The host-side mirrors of the launcher's tile choice (uia_hip.ops): which kernel a shape runs on, where the M tail is cut, when that tail is
+    split over K.  No GPU involved."""
+    from uia_hip import ops
+    assert ops.auto_tile_cfg(50432, 768, 768, 2) == 8 and ops.auto_tile_cfg(50432, 768, 64, 2) == 14
+    assert ops.auto_tile_cfg(50432, 64, 768, 2) == 16                       # N = 64 stream kernel (epilogue not known yet: optimistic)
+    assert ops.auto_tile_cfg(50432, 64, 768, 2, ops.EPI_BIAS | ops.EPI_OUTT) == 16
+    assert ops.auto_tile_cfg(25216, 64, 2048, 2) == 14                      # W image beyond the stream kernel's LDS: 3-deep ring
+    assert ops.auto_tile_cfg(256, 640, 768, 4) == 21 and ops.auto_tile_cfg(256, 640, 768, 2) == 3 and ops.auto_tile_cfg(2048, 4096, 768, 4) == 3
+    assert ops.tail_split_rows(50432, 768, 256) == 43520 and ops.tail_split_rows(65536, 768, 256) == 65536
+    assert ops.tail_split_rows(32896, 1024, 256) == 32768 and ops.tail_split_rows(32896, 4096, 256) == 32768
+    assert ops.tail_k_slices(128, 1024, 4096, 2, 256) == 8 and ops.tail_k_slices(128, 1024, 3072, 2, 256) == 6
+    assert ops.tail_k_slices(128, 4096, 1024, 2, 256) == 0 and ops.tail_k_slices(6912, 768, 3072, 2, 256) == 0 and ops.tail_k_slices(128, 1024, 4096, 4, 256) == 0
+    assert ops.big_tile_cfg(768, 3072, 2) == 8                              # the 5-deep ring is opt-in
+    m = ops.EPI_QUICK | ops.EPI_BIAS | ops.EPI_GELU | ops.EPI_OUTT
+    assert m in ops._SPECIALISED and (m | ops.EPI_LNFOLD) in ops._SPECIALISED and (ops.EPI_QUICK | ops.EPI_DGELU | ops.EPI_OUTT) in ops._SPECIALISED
+    assert ops.gemm_kernel_name(8, 977, __import__("torch").bfloat16)[1].endswith("Li977ELi0ELb0EE")

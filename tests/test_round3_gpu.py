@@ -460,3 +460,78 @@ def test_split_k_tail_launch_equals_the_whole_k_launch(M, N, K, slices):
     assert float(ws.abs().max()) == 0.0
     with pytest.raises(ops.UiaError, match="split K"):
         ops._gemm_one(a, w, out_t=torch.empty(M, N, device=dev(), dtype=dt), tile_cfg=3 | slices << 16 | 1 << 22, splitk_ws=ws)
+
+
+@pytest.mark.parametrize("with_bias", [False, True])
+def test_lora_gradients_straight_into_the_flat_buffer(with_bias):
+    """With the engine's FlatAdapterOptimizer the factors' .grad are views of ONE flat fp32 buffer and the LoRA nodes accumulate into them with
+    uia_wgrad_ex (no staging buffer, autograd gets None): the flat buffer after a backward must equal the gradients autograd returns without it,
+    through LoraAttnHalfFn and through LoraLinearFn, with the biases frozen (how the fine-tune scripts mark parameters) and trainable (quirk C-4)."""
+    from uia_hip import functional as UF
+    from uia_hip.engine import FlatAdapterOptimizer
+    from src.adapters.lora import LinearLoRA, PlainMultiheadAttentionLoRA
+    UF.set_compute_dtype(torch.bfloat16)
+    g = torch.Generator().manual_seed(29)
+    B, L, D, H, r = 2, 40, 128, 2, 8
+    mod = PlainMultiheadAttentionLoRA(torch.nn.MultiheadAttention(D, H), enable_lora=["q", "k", "v", "o"], r=r, lora_alpha=16, dropout_rate=0.1)
+    lin = LinearLoRA(torch.nn.Linear(D, 192), r=r, lora_alpha=16, dropout_rate=0.1)
+    ln = torch.nn.LayerNorm(D)
+    with torch.no_grad():
+        for k, p in list(mod.named_parameters()) + list(lin.named_parameters()):
+            p.copy_(0.15 * torch.randn(p.shape, generator=g))
+    mod, lin, ln = mod.to(dev()).train(), lin.to(dev()).train(), ln.to(dev())
+    for p in ln.parameters():
+        p.requires_grad_(False)
+    named = [(f"a.{k}", p) for k, p in mod.named_parameters()] + [(f"l.{k}", p) for k, p in lin.named_parameters()]
+    for k, p in named:
+        p.requires_grad_("lora" in k or (with_bias and k.endswith("bias")))
+    train = [(k, p) for k, p in named if p.requires_grad]
+    x = torch.randn(B, L, D, generator=g).to(dev())
+    dy = torch.randn(B, L, D, generator=g).to(dev())
+    dz = torch.randn(B * L, 192, generator=g).to(dev()).to(torch.bfloat16)
+
+    def run():
+        UF.set_dropout_seed(41)
+        UF.clear_t_copies()
+        y = mod.block_half(x.clone().requires_grad_(True), ln, B, L, None)
+        z = lin.apply_rows(y.detach().view(B * L, D).to(torch.bfloat16).requires_grad_(True))
+        torch.autograd.backward([y, z], [dy, dz])
+
+    for _, p in train:
+        p.grad = None
+    run()
+    want = {k: p.grad.detach().clone() for k, p in train}
+    assert all(v.abs().max() > 0 for v in want.values())
+    opt = FlatAdapterOptimizer(train, lr=1e-3)
+    opt.zero_grad()
+    assert all(UF._is_flat_grad(p) for _, p in train)
+    run()
+    assert opt.grad_views_intact()
+    for k, p in train:
+        assert rel(p.grad, want[k]) < 1e-5, k
+    run()                                                                  # accumulates: twice the gradient
+    for k, p in train:
+        assert rel(p.grad, 2 * want[k]) < 1e-5, k
+
+
+def test_tail_split_with_split_k_through_the_host_scheduler():
+    """ops.gemm at the ViT-L/14 + LoRA row count (32 896 = 128.5 panels of 256 rows): the host cuts a 128-row tail off the 256x256 launch and, at
+    K = 4096, runs that tail split over K (two launches through a zeroed workspace the launches keep zero) — against the un-split launch."""
+    from uia_hip import ops
+    g = torch.Generator(device="cpu").manual_seed(3)
+    M, N, K = 32896, 1024, 4096
+    assert ops.tail_split_rows(M, N, 256) == 32768 and ops.tail_k_slices(M - 32768, N, K, 2, 256) == 8
+    assert ops.tail_k_slices(6912, 768, 3072, 2, 256) == 0 and ops.tail_k_slices(128, 1024, 1024, 2, 256) == 0      # the headline step's 81-tile tails; short K
+    a = torch.randn(M, K, generator=g).to(dev()).to(torch.bfloat16)
+    w = ops.PackedW((torch.randn(N, K, generator=g) * K ** -0.5).to(dev()).to(torch.bfloat16))
+    bias = torch.randn(N, generator=g).to(dev())
+    resid = torch.randn(M, N, generator=g).to(dev())
+    o_ref, o = torch.empty(M, N, device=dev()), torch.empty(M, N, device=dev())
+    ops.gemm(a, w, bias=bias, resid=resid, out32=o_ref, tile_cfg=8)
+    for _ in range(2):                                                     # twice: the second use finds the workspace as the first left it
+        o.fill_(float("nan"))
+        ops.gemm(a, w, bias=bias, resid=resid, out32=o)
+        torch.cuda.synchronize()
+        assert torch.equal(o[:32768], o_ref[:32768])
+        assert rel(o[32768:], o_ref[32768:]) < 2e-5 and not torch.isnan(o).any()
+    assert all(float(t.abs().max()) == 0.0 for t in ops._SPLITK_WS.values())
