@@ -121,6 +121,15 @@ typedef struct uia_gemm_desc {
      * zeroes it again and runs the epilogue.  splitk_ws: tiles · 128·256 floats (tiles = ceil(M/128)·ceil(N/256)), 16-byte aligned, caller-owned,
      * ZERO before the first use (the launches keep it zero between uses).  The slice partials meet in no fixed order: last-bit run-to-run variation. */
     float* splitk_ws;
+    /* K EXTENSION: the LoRA rank update inside the frozen GEMM (y = x·Wᵀ + s·t·Bᵀ as ONE K loop over [x | t]·[W | s·B]ᵀ; lora.py:87).  K counts BOTH parts
+     * and W holds K columns; A supplies the first K − K2 of them (row-major, lda), A2 the last K2: a row-major [M, K2] operand (lda2) per group of
+     * a2_group_cols output columns, group g at A2 + g·a2_group_stride elements (a fused q | k | v projection has three; 0 = one operand for all columns).
+     * bf16, tile cfgs 8 / 13, K2 % 32 == 0, a2_group_cols % 256 == 0. */
+    const void* A2;
+    int64_t lda2;
+    int32_t K2;
+    int32_t a2_group_cols;
+    int64_t a2_group_stride;
 } uia_gemm_desc;
 int uia_gemm(void* stream, int dtype, const uia_gemm_desc* d, int tile_cfg /* 0 = auto */);
 

@@ -1001,7 +1001,7 @@ int launch_pp(hipStream_t stream, const UiaGemmParams& p) {
 //   sub-tile t-1, whose final ds_reads (group 1, wall slot 2·t·SPT-1) were retired before that slot's barrier.
 // 64-byte rows use the 4-entry swizzle table {0,3,2,1} indexed by (row>>2)&3 (A) / the 16-row block of the
 // permuted W rows: conflict-free ds_read_b128 for both fragment patterns.
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int NBUF, int EPI, int LOOP = 0, bool SK = false>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int NBUF, int EPI, int LOOP = 0, bool SK = false, bool A2X = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_tn_ring_kernel(const UiaGemmParams p, const int xflags, const int sk_info) {   // 2 waves per SIMD: one 8-wave
                                                                                                                             // workgroup, or two 4-wave ones, per CU
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1135,6 +1135,23 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_tn_ring_kernel
         srcW[i] = kbW ? (const char*)p.W + (size_t)gn * BKB + c * 16 : (const char*)p.W + ((size_t)gn * (size_t)p.ldw) * ESZ + c * 16;
     }
     const size_t kstepA = kbA ? (size_t)(p.a_kb_rows ? p.a_kb_rows : p.M) * BKB : (size_t)BKB, kstepW = kbW ? (size_t)p.N * BKB : (size_t)BKB;
+    // K EXTENSION (A2X; the LoRA rank update inside the frozen GEMM, lora.py:87): the last K2 columns of the K loop take their A rows from a second
+    // operand — t = drop(x)·Aᵀ, [M, K2] row-major, one per group of a2_group_cols output columns (q | k | v of a fused projection) — while W holds
+    // [W | s·B] over the whole K.  A compile-time variant: the step's other launches keep the kernel they had.
+    const char* srcA2[A2X ? A_PER_WAVE : 1];
+    int ntl1 = 0;
+    if constexpr (A2X) {
+        ntl1 = ((p.K - p.K2) * ESZ) / BKB;
+        const char* a2 = (const char*)p.A2 + (size_t)(p.a2_group_cols > 0 ? n0 / p.a2_group_cols : 0) * (size_t)p.a2_group_stride * ESZ;
+#pragma unroll
+        for (int i = 0; i < A_PER_WAVE; ++i) {
+            const int r = RPI * (wave + NW * i) + lane / CPR;
+            const int c = (lane % CPR) ^ swzA(r);
+            int gm = m0 + r;
+            gm = gm < p.M ? gm : p.M - 1;
+            srcA2[i] = a2 + ((size_t)gm * (size_t)p.lda2) * ESZ + c * 16;
+        }
+    }
     const int li = lane & 15, g = lane >> 4;
     const int rowA = wm * WTM + li;                                         // + 16·mt  (keeps (row>>1)&7 and (row>>2)&3)
     const int rowW = wn * WTN + (li >> 2) * 16 + (li & 3);                  // + 4·j
@@ -1165,8 +1182,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_tn_ring_kernel
 #pragma unroll
         for (int i = 0; i < GPT; ++i) {
             if (i * SPT / GPT != part && SPT > 1) continue;
-            if (i < A_PER_WAVE) glds16_asm(srcA[i] + koffA, base + (wave + NW * i) * 1024);
-            else glds16_asm(srcW[i - A_PER_WAVE] + koffW, base + A_BYTES + (wave + NW * (i - A_PER_WAVE)) * 1024);
+            if (i < A_PER_WAVE) {
+                if (A2X && t >= ntl1) glds16_asm(srcA2[i] + (size_t)(t - ntl1) * BKB, base + (wave + NW * i) * 1024);
+                else glds16_asm(srcA[i] + koffA, base + (wave + NW * i) * 1024);
+            } else glds16_asm(srcW[i - A_PER_WAVE] + koffW, base + A_BYTES + (wave + NW * (i - A_PER_WAVE)) * 1024);
         }
     };
     uint4 af[MT], wf[NT];
@@ -1383,13 +1402,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_tn_ring_kernel
 #endif
 }
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int NBUF, int EPI, int LOOP = 0, bool SK = false>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int NBUF, int EPI, int LOOP = 0, bool SK = false, bool A2X = false>
 int launch_ring_epi(hipStream_t stream, const UiaGemmParams& p, int xflags, int sk_info = 0) {
     constexpr bool LNROW = EPI == EPI_GENERIC || (EPI & (EPI_LNFOLD | EPI_RESID_LN)) != 0;      // + one (rstd, -mean·rstd) / (mean, rstd) pair per tile row per column of waves
     constexpr int EPB = WAVES_M * WAVES_N * EpiPatch<BM / WAVES_M / 16, BN / WAVES_N>::BYTES_PER_WAVE + (LNROW ? WAVES_N * BM * 8 : 0);
     constexpr int LDS = NBUF * (BM + BN) * BKB > EPB ? NBUF * (BM + BN) * BKB : EPB;
     static_assert(LDS <= 160 * 1024, "LDS budget");
-    auto kern = gemm_tn_ring_kernel<T, BM, BN, WAVES_M, WAVES_N, BKB, NBUF, EPI, LOOP, SK>;
+    auto kern = gemm_tn_ring_kernel<T, BM, BN, WAVES_M, WAVES_N, BKB, NBUF, EPI, LOOP, SK, A2X>;
     static UiaDevOnce attr_once;
     UIA_ENSURE_LDS_ATTR(attr_once, kern, LDS);
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
@@ -1590,6 +1609,16 @@ template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int NBU
 int launch_ring(hipStream_t stream, const UiaGemmParams& p, bool specialise, int xflags, int sk_info = 0) {
     if constexpr (BM == 128 && BN == 256 && NBUF == 4 && LOOP == 0) {          // tile cfg 13 only
         if (sk_info != 0) return launch_ring_epi<T, BM, BN, WAVES_M, WAVES_N, BKB, NBUF, EPI_GENERIC, LOOP, true>(stream, p, xflags, sk_info);
+    }
+    if constexpr (BN == 256 && NBUF == 4 && LOOP == 0 && BKB == 64 && sizeof(T) == 2) {      // tile cfgs 8 and 13: the K-extension variant, three masks + the run-time one
+        if (p.K2 > 0) {
+            switch (epi_mask_of(p)) {
+                case EPI_BIAS | EPI_OUTT: return launch_ring_epi<T, BM, BN, WAVES_M, WAVES_N, BKB, NBUF, (EPI_BIAS | EPI_OUTT), LOOP, false, true>(stream, p, xflags);
+                case EPI_OUTT: return launch_ring_epi<T, BM, BN, WAVES_M, WAVES_N, BKB, NBUF, (EPI_OUTT), LOOP, false, true>(stream, p, xflags);
+                case EPI_BIAS | EPI_RESID | EPI_OUT32: return launch_ring_epi<T, BM, BN, WAVES_M, WAVES_N, BKB, NBUF, (EPI_BIAS | EPI_RESID | EPI_OUT32), LOOP, false, true>(stream, p, xflags);
+                default: return launch_ring_epi<T, BM, BN, WAVES_M, WAVES_N, BKB, NBUF, EPI_GENERIC, LOOP, false, true>(stream, p, xflags);
+            }
+        }
     }
     if (specialise) {
         switch (epi_mask_of(p)) {    // the six masks of a training step, by time spent (tools/gemm_census.py)
@@ -1937,6 +1966,11 @@ int launch_typed(hipStream_t stream, const UiaGemmParams& p, int cfg_in) {
                                  // (cfg 12, the persistent variant, is +2-3.5 % on store-only epilogues in isolation, -15-25 % on the
                                  //  fp32-residual ones, and a net loss inside the two-stream training step: opt-in only.)
     }
+    if (p.K2 > 0 && (cfg_in & 255) == 0) cfg = p.M <= 2048 ? 13 : 8;       // the K extension lives on the 64-byte-sub-tile ring kernels
+    if (p.K2 > 0 && !(cfg == 8 || cfg == 13)) {
+        uia_set_error("uia_gemm: the K extension (A2 / K2) runs on tile cfgs 8 and 13, not %d", cfg);
+        return -1;
+    }
     if (p.drop_where == 1 && cfg != 16) {
         uia_set_error("uia_gemm: dropout on the A operand (drop_where = 1) is the N = 64 stream kernel's (tile cfg 16: bf16, N == 64, M > 2048, bias + T output only), not tile cfg %d", cfg);
         return -1;
@@ -2010,7 +2044,7 @@ int uia_gemm_launch(hipStream_t stream, int dtype, const UiaGemmParams& p, int c
     UIA_CHECK_ARG(p.K % bk == 0, "uia_gemm: K=%d must be a multiple of %d for this dtype", p.K, bk);
     UIA_CHECK_ARG(p.N % 8 == 0, "uia_gemm: N=%d must be a multiple of 8", p.N);
     UIA_CHECK_ARG(p.A && p.W, "uia_gemm: null operand");
-    UIA_CHECK_ARG((p.a_kb_rows || p.lda >= p.K) && p.ldw >= p.K, "uia_gemm: leading dimension smaller than K");
+    UIA_CHECK_ARG((p.a_kb_rows || p.lda >= p.K - (p.K2 > 0 ? p.K2 : 0)) && p.ldw >= p.K, "uia_gemm: leading dimension smaller than K");
     UIA_CHECK_ARG((p.a_kb_rows || (p.lda * esz) % 16 == 0) && (p.ldw * esz) % 16 == 0, "uia_gemm: rows must be 16-byte aligned");
     UIA_CHECK_ARG(((uintptr_t)p.A % 16) == 0 && ((uintptr_t)p.W % 16) == 0, "uia_gemm: operands must be 16-byte aligned");
     UIA_CHECK_ARG(p.outT || p.out32, "uia_gemm: no output");
@@ -2039,6 +2073,10 @@ int uia_gemm_launch(hipStream_t stream, int dtype, const UiaGemmParams& p, int c
                   "uia_gemm: dropout on the A operand needs bf16, row-major A, M*K <= 2^35 and a 16-byte aligned a_drop_out");
     UIA_CHECK_ARG(p.drop_where != 2 || (size_t)p.M * (size_t)p.N / 8 <= 0xFFFFFFFFull, "uia_gemm: dropout on the accumulator needs M*N <= 2^35");
     UIA_CHECK_ARG(p.drop_where == 1 || !p.a_drop_out, "uia_gemm: a_drop_out without drop_where = 1");
+    UIA_CHECK_ARG(p.K2 >= 0 && (p.K2 == 0 || (dtype == UIA_BF16 && p.A2 && p.K2 % 32 == 0 && p.K2 < p.K && p.lda2 >= p.K2 && (p.lda2 * 2) % 16 == 0 && (uintptr_t)p.A2 % 16 == 0 &&
+                                             p.a2_group_cols >= 0 && p.a2_group_cols % 256 == 0 && !p.a_kb_rows && p.lda >= p.K - p.K2)),
+                  "uia_gemm: the K extension needs bf16, a row-major A of K - K2 columns, a 16-byte aligned row-major A2 with K2 (a multiple of 32, < K) columns and "
+                  "column groups that are multiples of 256; got K=%d K2=%d lda2=%lld group=%d", p.K, p.K2, (long long)p.lda2, p.a2_group_cols);
     UIA_CHECK_ARG(!p.lnfold_sums || (p.lnfold_colsum && p.lnfold_dim > 0 && p.alpha == 1.0f && (uintptr_t)p.lnfold_sums % 16 == 0 && (uintptr_t)p.lnfold_colsum % 16 == 0),
                   "uia_gemm: lnfold_sums needs lnfold_colsum (16-byte aligned), lnfold_dim > 0 and alpha == 1");
     // every row the epilogue touches must hold N elements: a leading dimension below N would make row m's tail overwrite row m+1

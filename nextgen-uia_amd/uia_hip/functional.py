@@ -224,7 +224,7 @@ class _PackedParam:
     """All GEMM-operand forms of one small trainable matrix, refreshed in place by uia_pack_weights.  With `pads` = (rows_pad, cols_pad) the
     forms hold the matrix zero-padded to that extent (a LoRA factor's rank 16 -> 64): the buffers are zeroed once and every refresh writes the
     parameter's own elements only."""
-    __slots__ = ("ref", "version", "epoch", "dt", "row", "row_kb", "tr", "tr_kb", "fwd", "bwd", "src_ptr", "pads")
+    __slots__ = ("ref", "version", "epoch", "dt", "row", "row_kb", "tr", "tr_kb", "fwd", "bwd", "src_ptr", "pads", "extra")
 
     def __init__(self, p, dt, pads=None):
         R, Cc = p.shape
@@ -232,14 +232,19 @@ class _PackedParam:
         g = 64 // torch.empty(0, dtype=dt).element_size()
         mk = (lambda *shape: torch.zeros(shape, device=p.device, dtype=dt)) if pads is not None else (lambda *shape: torch.empty(shape, device=p.device, dtype=dt))
         self.ref, self.version, self.epoch, self.dt, self.src_ptr, self.pads = weakref.ref(p), -1, -1, dt, 0, pads
+        self.extra = []                    # further destinations refreshed with the parameter: (K-blocked view inside another buffer, rows_pad, cols_pad, scale)
         self.row, self.tr = mk(RP, CP), mk(CP, RP)
         self.row_kb = mk(CP // g, RP, g) if CP % g == 0 else None
         self.tr_kb = mk(RP // g, CP, g) if RP % g == 0 else None
         self.fwd, self.bwd = ops.PackedW(self.row, self.row_kb), ops.PackedW(self.tr, self.tr_kb)
 
-    def entry(self):
-        ent = (self.ref().detach(), self.row, self.row_kb, self.tr, self.tr_kb)
-        return ent if self.pads is None else ent + ((self.pads[0], self.pads[1], 1.0),)
+    def entries(self):
+        src = self.ref().detach()
+        ent = (src, self.row, self.row_kb, self.tr, self.tr_kb)
+        out = [ent if self.pads is None else ent + ((self.pads[0], self.pads[1], 1.0),)]
+        for view, rp, cp, scale in self.extra:
+            out.append((src, None, ops.RawDest(view), None, None, (rp, cp, scale)))
+        return out
 
 
 class WeightCache:
@@ -259,7 +264,7 @@ class WeightCache:
 
     def _repack(self, items):
         dt, dev = items[0].dt, items[0].row.device
-        entries = [it.entry() for it in items]
+        entries = [e for it in items for e in it.entries()]
         table, n, mx = ops.pack_table(entries, dev)
         ops.pack_weights(table, n, mx, dt)
         for it in items:
@@ -281,7 +286,7 @@ class WeightCache:
         groups = {}
         for it in live:
             groups.setdefault((it.dt, it.row.device), []).append(it)
-        if (len(groups) == 1 and self._table is not None and self._table[1] == len(live)
+        if (len(groups) == 1 and self._table is not None and self._table[1] == sum(1 + len(it.extra) for it in live)
                 and all(it.src_ptr == it.ref().data_ptr() for it in live)):
             table, n, mx, dt, _ = self._table                 # same set as last step: the resident table is still right
             ops.pack_weights(table, n, mx, dt)
@@ -338,6 +343,37 @@ class WeightCache:
             src = cat.t().contiguous() if transpose else cat
             out = ops.PackedW(src.to(dt).contiguous())
         self._c[key] = (vers, tuple(weakref.ref(w) for w in ws), out)
+        return out
+
+    def get_lora_ext(self, ws, Bs, scaling, dt, rp=64):
+        """[W | s·B] over K + rp columns, K-blocked, for the K-extension form of the LoRA rank update (uia_gemm_desc.A2 / K2): the frozen weights `ws`
+        stacked along N ([ΣN_i, K], converted once), behind them the factors `Bs` ([N_i, r] each, rank zero-padded to rp, scaled by s) in the last rp / g column
+        blocks.  The factor part is a destination of the batched uia_pack_weights launch (refreshed with the parameters, like their other forms)."""
+        key = (tuple(id(w) for w in ws), tuple(id(b) for b in Bs), dt, float(scaling), "ext")
+        vers = tuple(w._version for w in ws)
+        hit = self._c.get(key)
+        pads = [(b.shape[0], max(rp, b.shape[1])) for b in Bs]
+        if hit is not None and hit[0] == vers and all(r() is t for r, t in zip(hit[1], tuple(ws) + tuple(Bs))) and hit[2].kb.device == ws[0].device:
+            for b, pd in zip(Bs, pads):
+                self._packed_get(b, dt, False, pd)                 # refreshes every destination of a factor that changed outside the optimiser step
+            return hit[2]
+        g = 64 // torch.empty(0, dtype=dt).element_size()
+        Ntot, K = sum(w.shape[0] for w in ws), ws[0].shape[1]
+        assert K % g == 0 and rp % g == 0 and all(w.shape[1] == K for w in ws) and all(b.shape[0] == w.shape[0] for b, w in zip(Bs, ws))
+        with torch.no_grad():
+            kb = torch.zeros((K + rp) // g, Ntot, g, device=ws[0].device, dtype=dt)
+            kb[:K // g] = torch.cat([w.detach().float() for w in ws], 0).to(dt).view(Ntot, K // g, g).permute(1, 0, 2)
+        off = 0
+        for b, pd in zip(Bs, pads):
+            self._packed_get(b, dt, False, pd)
+            it = self._packed[id(b)]
+            it.extra = [e for e in it.extra if e[0].untyped_storage().data_ptr() != kb.untyped_storage().data_ptr()]
+            it.extra.append((kb[K // g:, off:off + b.shape[0], :], Ntot, rp, float(scaling)))
+            self._table = None
+            self._repack([it])
+            off += b.shape[0]
+        out = ops.ExtW(kb, Ntot, K + rp, rp)
+        self._c[key] = (vers, tuple(weakref.ref(t) for t in tuple(ws) + tuple(Bs)), out)
         return out
 
     def get(self, p, dt, transpose=False, pad_rows_to=None, pad_cols_to=None):
@@ -1020,12 +1056,12 @@ class LoraLinearFn(torch.autograd.Function):
         return dx, None, db, dA, dB, None, None, (dy if has_resid else None), None
 
 
-def _lora_down(x, A, p_drop, rp):
+def _lora_down(x, A, p_drop, rp, out=None):
     """t = drop(x)·Aᵀ ([M, rp]) and the dropped rows (for dA): the dropout rides in the N = 64 stream kernel's operand when that kernel takes
     the shape (bf16, rank padded to 64), otherwise as a pass of its own.  Returns (t, xd, seed)."""
     dt = x.dtype
     M, K = x.shape
-    t = _empty((M, rp), dt, x)
+    t = _empty((M, rp), dt, x) if out is None else out
     a_op = WEIGHTS.get(A, dt, pad_rows_to=rp)
     if p_drop <= 0:
         ops.gemm(x, a_op, out_t=t)
@@ -1078,20 +1114,30 @@ class LoraAttnHalfFn(torch.autograd.Function):
         rp = _rank_pad(r)
         h = _empty((M, D), dt, x2)
         ops.layernorm_fwd(x2, ln_w, ln_b, eps, y_t=h)
-        downs = [_lora_down(h, A, p_drop, rp) for A in (aq, ak, av)]
+        # K extension (bf16, rank padded to 64, ring kernels): the rank update s·t·Bᵀ rides in the frozen GEMM's K loop as 64 more columns of
+        # [x | t]·[W | s·B]ᵀ — no read-modify-write pass over the result (lora.py:87; ops.LORA_KEXT)
+        kext = ops.LORA_KEXT and dt == torch.bfloat16 and rp == 64 and x.is_cuda and ops.KBLOCK_W and D % 256 == 0 and M >= 256
+        t_all = _empty((3, M, rp), dt, x2) if kext else None
+        downs = [_lora_down(h, A, p_drop, rp, out=None if t_all is None else t_all[i]) for i, A in enumerate((aq, ak, av))]
         qkv = _empty((M, 3 * D), dt, x2)
         bcat = torch.cat([b.detach() for b in (bq, bk, bv)]) if bq is not None else None
-        ops.gemm(h, WEIGHTS.get_cat((wq, wk, wv), dt), bias=bcat, out_t=qkv)
-        for i, (Bm, (t, _, _)) in enumerate(zip((Bq, Bk, Bv), downs)):
-            sl = qkv[:, i * D:(i + 1) * D]
-            ops.gemm(t, WEIGHTS.get(Bm, dt, pad_cols_to=rp), alpha=scaling, resid_t=sl, out_t=sl)
+        if kext:
+            ops.gemm(h, WEIGHTS.get_lora_ext((wq, wk, wv), (Bq, Bk, Bv), scaling, dt, rp), bias=bcat, out_t=qkv, a2=(t_all, D))
+        else:
+            ops.gemm(h, WEIGHTS.get_cat((wq, wk, wv), dt), bias=bcat, out_t=qkv)
+            for i, (Bm, (t, _, _)) in enumerate(zip((Bq, Bk, Bv), downs)):
+                sl = qkv[:, i * D:(i + 1) * D]
+                ops.gemm(t, WEIGHTS.get(Bm, dt, pad_cols_to=rp), alpha=scaling, resid_t=sl, out_t=sl)
         a = _empty((M, D), dt, x2)
         lse = torch.empty(Bsz, heads, L, device=x.device, dtype=torch.float32)
         ops.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], a, Bsz, heads, L, lse=lse, mask=mask)
         to, ado, seed_o = _lora_down(a, ao, p_drop, rp)
         x1 = torch.empty_like(x2)
-        ops.gemm(a, WEIGHTS.get(wo, dt), bias=bo, resid=x2, out32=x1)
-        ops.gemm(to, WEIGHTS.get(Bo, dt, pad_cols_to=rp), alpha=scaling, resid=x1, out32=x1)
+        if kext:
+            ops.gemm(a, WEIGHTS.get_lora_ext((wo,), (Bo,), scaling, dt, rp), bias=bo, resid=x2, out32=x1, a2=(to, 0))
+        else:
+            ops.gemm(a, WEIGHTS.get(wo, dt), bias=bo, resid=x2, out32=x1)
+            ops.gemm(to, WEIGHTS.get(Bo, dt, pad_cols_to=rp), alpha=scaling, resid=x1, out32=x1)
         ctx.save_for_backward(x2, ln_w, qkv, a, lse, to, ado, *[d[0] for d in downs], *[d[1] for d in downs], wq, wk, wv, wo)
         ctx.meta = (eps, shape, heads, mask, scaling, p_drop, [d[2] for d in downs] + [seed_o], rp)
         ctx.params = (bq, aq, Bq, bk, ak, Bk, bv, av, Bv, bo, ao, Bo)                # the Parameter objects: .grad is looked up at BACKWARD time

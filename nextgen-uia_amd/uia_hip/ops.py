@@ -65,6 +65,7 @@ TILE_GROUP = {}          # experiment knob: {N: row panels per tile-order group}
 HALF_HEIGHT_SHORT_K = True   # N <= 768, K <= 768 (bf16) launches whose 256-row tiling leaves a ragged last round run on half-height tiles (cfg 14) in one launch
 TAIL_SPLIT = True        # split off the M tail of a launch whose last round of 256x256 tiles would leave most CUs idle
 RING5 = False            # experiment knob: 256x256 launches with a long K loop or a wide N on the 5-deep ring (tile cfg 24: 160 KB of LDS, four sub-tiles in flight)
+LORA_KEXT = True         # LoraAttnHalfFn: the rank update inside the frozen GEMM's K loop (uia_gemm_desc.A2 / K2) instead of a read-modify-write launch of its own
 TAIL_SPLIT_K = True      # ... and run that tail split over K when it is a few tiles with a long K chain (two launches: slice partials, then sum + epilogue)
 _SPLITK_WS = {}
 _NCU = {}
@@ -241,6 +242,23 @@ class PackedW:
         return self._kb
 
 
+class ExtW:
+    """A GEMM weight [N, K] that exists K-BLOCKED only ([K/g][N][g]) and whose last K2 columns pair with a second A operand (uia_gemm_desc.A2 / K2: the LoRA
+    rank update inside the frozen GEMM).  Built by functional.WEIGHTS.get_lora_ext."""
+    __slots__ = ("kb", "N", "K", "K2")
+
+    def __init__(self, kb, N, K, K2):
+        self.kb, self.N, self.K, self.K2 = kb, N, K, K2
+
+
+class RawDest:
+    """A uia_pack_weights destination that is a strided view inside a larger buffer (the kernel's rows_pad / cols_pad reproduce its strides)."""
+    __slots__ = ("view",)
+
+    def __init__(self, view):
+        self.view = view
+
+
 def gemm_kernel_name(cfg, mask, dtype):
     """(readable name, mangled fragment) of the instantiation a launch runs on.  rocprofv3 prints these kernels mangled
     (its demangler does not know the bf16 type code), so the fragment is what to grep for in profiles/*.csv."""
@@ -291,7 +309,7 @@ def _rowmajor(t, name):
 
 
 def gemm(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None, resid=None, resid_mod=0, resid_row_off=0,
-         resid_t=None, out_group=0, out_t=None, out32=None, alpha=1.0, tile_cfg=0, resid_ln=None, rowsum=None, lnfold=None, drop=None):
+         resid_t=None, out_group=0, out_t=None, out32=None, alpha=1.0, tile_cfg=0, resid_ln=None, rowsum=None, lnfold=None, drop=None, a2=None):
     """C = epilogue(alpha * a @ w.T).  a [M,K], w [N,K] (tensor or PackedW) share a dtype (bf16 | fp32); see include/uia_hip.h.
 
     Host-side scheduling on top of uia_gemm (results do not depend on it): with the automatic tile choice, a weight that came
@@ -303,6 +321,22 @@ def gemm(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None, res
     rows), or ("acc", p, seed): applied to alpha·acc of element (m, n) before the residual adds — the generator of ops.dropout in both cases.
     rowsum = zeroed int64 [M, 2] (ROWSUM_SCALE fixed point; rowsum_to_float converts): receives (Σ, Σ²) of the stored fp32 rows.  lnfold = (sums [M, 2], colsum [N], dim, eps): `a` holds RAW
     rows and `w` is pre-scaled by the LayerNorm weight; the epilogue applies the LayerNorm (include/uia_hip.h, uia_gemm_desc)."""
+    if isinstance(w, ExtW):
+        # K extension: w = [W | s·B] (K-blocked only), a2 = (t, group_cols): t [M, K2] or [G, M, K2] — one [M, K2] operand per group of output columns
+        if a2 is None or is_kb(a) or a.dtype != torch.bfloat16 or a.shape[1] != w.K - w.K2 or resid_mod or out_group or drop is not None:
+            raise UiaError("gemm: an ExtW weight needs a2 = (t, group_cols), a row-major bf16 `a` of K - K2 columns and a plain epilogue")
+        t2, gcols = a2
+        M = a.shape[0]
+        if t2.dtype != a.dtype or t2.shape[-1] != w.K2 or t2.shape[-2] != M or t2.stride(-1) != 1 or t2.stride(-2) != w.K2 or (t2.dim() == 3 and t2.shape[0] * gcols != w.N):
+            raise UiaError(f"gemm: a2 operand {tuple(t2.shape)} does not match [groups, {M}, {w.K2}] with {w.N} columns in groups of {gcols}")
+        m_main = tail_split_rows(M, w.N, num_cus(a.device.index)) if (TAIL_SPLIT and tile_cfg == 0 and M > 2048) else M
+        cut = lambda t, lo, hi: None if t is None else t[lo:hi]
+        for lo, hi, cfg in (((0, m_main, 8), (m_main, M, 13)) if m_main < M else ((0, M, tile_cfg or (8 if M > 2048 else 13)),)):
+            _gemm_one(a[lo:hi], w, bias=bias, act=act, dact=dact, aux_in=cut(aux_in, lo, hi), aux_out=cut(aux_out, lo, hi), resid=cut(resid, lo, hi),
+                      resid_t=cut(resid_t, lo, hi), out_t=cut(out_t, lo, hi), out32=cut(out32, lo, hi), alpha=alpha, tile_cfg=cfg,
+                      resid_ln=None if resid_ln is None else (resid_ln[0][lo:hi],) + tuple(resid_ln[1:]), rowsum=cut(rowsum, lo, hi),
+                      lnfold=None if lnfold is None else (lnfold[0][lo:hi],) + tuple(lnfold[1:]), a2=(t2[..., lo:hi, :], gcols))
+        return
     packed = w if isinstance(w, PackedW) else None
     wrow = packed.row if packed is not None else w
     M, N = (a.rows if is_kb(a) else a.shape[0]), wrow.shape[0]
@@ -333,10 +367,15 @@ def gemm(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None, res
 
 
 def _gemm_one(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None, resid=None, resid_mod=0, resid_row_off=0,
-              resid_t=None, out_group=0, out_t=None, out32=None, alpha=1.0, tile_cfg=0, resid_ln=None, rowsum=None, lnfold=None, drop=None, splitk_ws=None):
+              resid_t=None, out_group=0, out_t=None, out32=None, alpha=1.0, tile_cfg=0, resid_ln=None, rowsum=None, lnfold=None, drop=None, splitk_ws=None, a2=None):
     d = GemmDesc()
     if splitk_ws is not None:
         d.splitk_ws = _p(splitk_ws)
+    ext = w if isinstance(w, ExtW) else None
+    if ext is not None:
+        t2, gcols = a2
+        d.A2, d.lda2, d.K2 = t2.data_ptr(), t2.stride(-2), ext.K2
+        d.a2_group_cols, d.a2_group_stride = (gcols, t2.stride(0)) if t2.dim() == 3 else (0, 0)
     if drop is not None:
         d.drop_where, d.drop_p, d.drop_seed = {"a": 1, "acc": 2}[drop[0]], float(drop[1]), int(drop[2]) & 0xFFFFFFFFFFFFFFFF
         if len(drop) > 3 and drop[3] is not None:
@@ -347,18 +386,25 @@ def _gemm_one(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None
     packed = w if isinstance(w, PackedW) else None
     if packed is not None:
         w = packed.row
-    d.ldw = _rowmajor(w, "w")
-    if is_kb(a):
-        d.M, d.K, d.a_kb_rows = _kb_dims(a, "gemm a")
-        d.lda = d.K
+    if ext is not None:
+        # W exists K-blocked only and spans K = (columns of a) + K2; the launch runs on the ring tiles it was given (8 / 13)
+        d.lda, d.ldw, d.M, d.K, d.N = _rowmajor(a, "a"), ext.K, a.shape[0], ext.K, ext.N
+        d.A, d.W, d.w_kblocked = _p(a), _p(ext.kb), 1
+        base_cfg = (tile_cfg & 255) or (8 if d.M > 2048 else 13)
+        tile_cfg = (tile_cfg & ~255) | base_cfg
     else:
-        d.lda = _rowmajor(a, "a")
-        d.M, d.K = a.shape[0], a.shape[1]
-    if a.dtype != w.dtype or d.K != w.shape[1]:
-        raise UiaError(f"gemm operand mismatch: a {(d.M, d.K)} {a.dtype}, w {tuple(w.shape)} {w.dtype}")
-    d.A, d.W = _p(a.t if is_kb(a) else a), _p(w)
-    d.N = w.shape[0]
-    base_cfg = (tile_cfg & 255) or auto_tile_cfg(d.M, d.N, d.K, a.element_size())
+        d.ldw = _rowmajor(w, "w")
+        if is_kb(a):
+            d.M, d.K, d.a_kb_rows = _kb_dims(a, "gemm a")
+            d.lda = d.K
+        else:
+            d.lda = _rowmajor(a, "a")
+            d.M, d.K = a.shape[0], a.shape[1]
+        if a.dtype != w.dtype or d.K != w.shape[1]:
+            raise UiaError(f"gemm operand mismatch: a {(d.M, d.K)} {a.dtype}, w {tuple(w.shape)} {w.dtype}")
+        d.A, d.W = _p(a.t if is_kb(a) else a), _p(w)
+        d.N = w.shape[0]
+        base_cfg = (tile_cfg & 255) or auto_tile_cfg(d.M, d.N, d.K, a.element_size())
     # mirror of wide64_ok() in csrc/gemm.hip: the K = 64 read-modify-write stream (LoRA rank update / its data gradient) takes row-major W
     if ((tile_cfg & 255) == 0 and base_cfg == 14 and a.dtype == torch.bfloat16 and d.K == 64 and d.N % 64 == 0 and d.N * 144 <= 160 * 1024 and not is_kb(a)
             and not is_kb(out_t) and act is None and dact is None and aux_out is None and out_group == 0 and resid_mod == 0 and rowsum is None and lnfold is None
@@ -552,7 +598,10 @@ def pack_table(entries, device):
         assert RP >= R and CP >= Cc
         d.src, d.rows, d.cols, d.rows_pad, d.cols_pad, d.scale = _p(src), R, Cc, RP, CP, float(scale)
         for name, t in (("row", row), ("row_kb", row_kb), ("tr", tr), ("tr_kb", tr_kb)):
-            if t is not None:
+            if isinstance(t, RawDest):
+                assert t.view.device == src.device
+                setattr(d, name, t.view.data_ptr())
+            elif t is not None:
                 assert t.is_contiguous() and t.numel() == RP * CP and t.device == src.device
                 setattr(d, name, _p(t))
         max_elems = max(max_elems, R * Cc)
