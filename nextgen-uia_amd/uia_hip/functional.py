@@ -988,7 +988,11 @@ class LoraLinearFn(torch.autograd.Function):
         r = A.shape[0]
         y32 = torch.empty(M, N, device=x.device, dtype=torch.float32) if resid32 is not None else None
         y_t = _empty((M, N), dt, x) if resid32 is None else None
-        ops.gemm(x, WEIGHTS.get(weight, dt), bias=bias, resid=resid32, out32=y32, out_t=y_t)
+        # K extension (ops.LORA_KEXT): t first, then ONE launch [x | t]·[W | s·B]ᵀ; otherwise the frozen GEMM and a rank-update launch onto its result
+        kext = (r > 0 and ops.LORA_KEXT and dt == torch.bfloat16 and _rank_pad(r) == 64 and x.is_cuda and ops.KBLOCK_W and x.is_contiguous() and M >= 256
+                and K % 32 == 0 and N % 8 == 0)
+        if not kext:
+            ops.gemm(x, WEIGHTS.get(weight, dt), bias=bias, resid=resid32, out32=y32, out_t=y_t)
         seed = 0
         xd = x
         t = None
@@ -1006,11 +1010,14 @@ class LoraLinearFn(torch.autograd.Function):
                 ops.gemm(x, a_op.row, out_t=t, drop=("a", p_drop, seed, xd))
             else:
                 ops.gemm(xd, a_op, out_t=t)
-            bmat = WEIGHTS.get(Bm, dt, pad_cols_to=rp)                              # [N, rp]
-            if y32 is not None:
-                ops.gemm(t, bmat, alpha=scaling, resid=y32, out32=y32)
+            if kext:
+                ops.gemm(x, WEIGHTS.get_lora_ext((weight,), (Bm,), scaling, dt, rp), bias=bias, resid=resid32, out32=y32, out_t=y_t, a2=(t, 0))
             else:
-                ops.gemm(t, bmat, alpha=scaling, resid_t=y_t, out_t=y_t)
+                bmat = WEIGHTS.get(Bm, dt, pad_cols_to=rp)                          # [N, rp]
+                if y32 is not None:
+                    ops.gemm(t, bmat, alpha=scaling, resid=y32, out32=y32)
+                else:
+                    ops.gemm(t, bmat, alpha=scaling, resid_t=y_t, out_t=y_t)
         ctx.save_for_backward(xd, t if t is not None else x.new_empty(0), weight, A, Bm)
         ctx.meta = (scaling, p_drop, seed, r, bias is not None, resid32 is not None)
         ctx.direct_params = (A, Bm, bias) if direct else None                       # the Parameter objects: .grad is looked up at BACKWARD time

@@ -585,3 +585,40 @@ def test_k_extension_gemm_equals_frozen_gemm_plus_rank_update(M):
     assert rel(o, want) < 2e-3
     with pytest.raises(ops.UiaError):
         ops.gemm(x, ext, bias=bias, out_t=y)                              # no second operand
+
+
+@pytest.mark.parametrize("resid", [False, True])
+def test_linear_lora_with_the_rank_update_in_the_k_loop_equals_the_two_launch_form(resid):
+    """LoraLinearFn with ops.LORA_KEXT (one launch [x | t]·[W | s·B]ᵀ) against the frozen GEMM followed by the rank-update launch, same dropout seed:
+    output (T, and fp32 with the fused residual), input gradient and the factor gradients — at a row count with a split M tail (2 x 256·128 + 100)."""
+    from uia_hip import functional as UF
+    from uia_hip import ops
+    from src.adapters.lora import LinearLoRA
+    UF.set_compute_dtype(torch.bfloat16)
+    g = torch.Generator().manual_seed(61)
+    M, I, O, r = 65636, 256, 512, 16
+    mod = LinearLoRA(torch.nn.Linear(I, O), r=r, lora_alpha=32, dropout_rate=0.1)
+    with torch.no_grad():
+        for k, p in mod.named_parameters():
+            p.copy_(0.05 * torch.randn(p.shape, generator=g))
+    mod = mod.to(dev()).train()
+    x = torch.randn(M, I, generator=g).to(dev()).to(torch.bfloat16)
+    res = torch.randn(M, O, generator=g).to(dev()) if resid else None
+    dy = torch.randn(M, O, generator=g).to(dev())
+    dy = dy if resid else dy.to(torch.bfloat16)
+    outs = []
+    for kext in (False, True):
+        ops.LORA_KEXT = kext
+        try:
+            for p in mod.parameters():
+                p.grad = None
+            UF.set_dropout_seed(9)
+            xx = x.clone().requires_grad_(True)
+            y = mod.apply_rows(xx, res)
+            y.backward(dy)
+            outs.append((y.detach(), xx.grad.detach(), mod.w_lora_A.grad.detach().clone(), mod.w_lora_B.grad.detach().clone()))
+        finally:
+            ops.LORA_KEXT = True
+    for name, a, b in zip(("y", "dx", "dA", "dB"), outs[1], outs[0]):
+        assert rel(a, b) < 1e-2, name
+    assert torch.equal(outs[1][1], outs[0][1])                             # the backward does not depend on the forward's form
