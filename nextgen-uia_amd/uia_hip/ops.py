@@ -269,7 +269,7 @@ def gemm_kernel_name(cfg, mask, dtype):
         return f"gemm_tn_persist_kernel<{tn},{m}>", f"gemm_tn_persist_kernelI{tc}{mi(m)}E"
     if cfg in (8, 13, 14, 24):
         bm, nbuf = (256, 4) if cfg == 8 else ((256, 5) if cfg == 24 else ((128, 4) if cfg == 13 else (128, 3)))
-        return f"gemm_tn_ring_kernel<{tn},{bm},256,2,4,64,{nbuf},{m}>", "gemm_tn_ring_kernelI" + tc + "".join(mi(v) for v in (bm, 256, 2, 4, 64, nbuf, m, 0)) + "Lb0EE"
+        return f"gemm_tn_ring_kernel<{tn},{bm},256,2,4,64,{nbuf},{m}>", "gemm_tn_ring_kernelI" + tc + "".join(mi(v) for v in (bm, 256, 2, 4, 64, nbuf, m, 0)) + "Lb0ELb0EE"
     if cfg == 16:
         return "gemm_skinny64_kernel", "gemm_skinny64_kernel"
     if cfg == 23:

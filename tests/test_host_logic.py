@@ -255,4 +255,4 @@ def test_gemm_schedule_mirrors_are_pure_host_logic():
     assert ops.big_tile_cfg(768, 3072, 2) == 8                              # the 5-deep ring is opt-in
     m = ops.EPI_QUICK | ops.EPI_BIAS | ops.EPI_GELU | ops.EPI_OUTT
     assert m in ops._SPECIALISED and (m | ops.EPI_LNFOLD) in ops._SPECIALISED and (ops.EPI_QUICK | ops.EPI_DGELU | ops.EPI_OUTT) in ops._SPECIALISED
-    assert ops.gemm_kernel_name(8, 977, __import__("torch").bfloat16)[1].endswith("Li977ELi0ELb0EE")
+    assert ops.gemm_kernel_name(8, 977, __import__("torch").bfloat16)[1].endswith("Li977ELi0ELb0ELb0EE")
