@@ -195,17 +195,19 @@ __device__ __forceinline__ uint32_t uia_hash32(uint32_t x) {
     return x;
 }
 // Eight consecutive elements per draw (the LoRA input dropout: uia_dropout, the N = 64 stream kernel's A operand, the run-time GEMM
-// epilogue): bit e of the result = keep element 8·grp + e.  Five hashes per group instead of three per element — the stand-alone pass
+// epilogue): bit e of the result = keep element 8·grp + e.  Two hashes per group instead of three per element — the stand-alone pass
 // was bound by its integer arithmetic (34 us for 134 MB), and a fused mask must not cost more than the pass it replaces.
 // thresh16 = round(p · 65536): the drop probability is quantised to 1/65536.
 __device__ __forceinline__ uint32_t dropout_keep8(uint64_t seed, uint32_t grp, uint32_t thresh16) {
-    const uint32_t base = uia_hash32(grp ^ (uint32_t)seed) + (uint32_t)(seed >> 32);
+    // two full mixes of (group, seed), then three xorshift32 steps: v_mul_lo_u32 runs at a quarter of the integer rate, and with a full mix per
+    // 32-bit word the mask cost 12 us of the 40 us x·Aᵀ launch that carries it
+    uint32_t h = uia_hash32(uia_hash32(grp ^ (uint32_t)seed) + (uint32_t)(seed >> 32));
     uint32_t m = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const uint32_t h = uia_hash32(base + (uint32_t)q * 0x9E3779B9U);
         m |= ((h & 0xFFFFu) >= thresh16 ? 1u : 0u) << (2 * q);
         m |= ((h >> 16) >= thresh16 ? 1u : 0u) << (2 * q + 1);
+        h ^= h << 13; h ^= h >> 17; h ^= h << 5;
     }
     return m;
 }
