@@ -1174,26 +1174,32 @@ class LoraAttnHalfFn(torch.autograd.Function):
         # ---- attention
         dqkv = _empty((M, 3 * D), dt, x2)
         ops.attn_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], a, da, lse, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], Bsz, heads, L, mask=mask)
-        # ---- q, k, v
-        dh = _empty((M, D), dt, x2)
-        ops.gemm(dqkv, WEIGHTS.get_cat((wq, wk, wv), dt, transpose=True), out_t=dh)
+        # ---- q, k, v  (the first block of a tower with a frozen embedding has nobody to hand dx to: no data-gradient GEMM, no LayerNorm backward)
+        need_dx = ctx.needs_input_grad[0]
+        dh = _empty((M, D), dt, x2) if need_dx else None
+        if need_dx:
+            ops.gemm(dqkv, WEIGHTS.get_cat((wq, wk, wv), dt, transpose=True), out_t=dh)
         grads = []
         for i, (bias, A, Bm, t, hd) in enumerate(((bq, aq, Bq, tq, hq), (bk, ak, Bk, tk, hk), (bv, av, Bv, tv, hv))):
             dsl = dqkv[:, i * D:(i + 1) * D]
             qi = _empty((M, rp), dt, x2)
             ops.gemm(dsl, WEIGHTS.get(Bm, dt, transpose=True, pad_cols_to=rp), out_t=qi)
-            ops.gemm(qi, WEIGHTS.get(A, dt, transpose=True, pad_rows_to=rp), alpha=scaling, resid_t=dh, out_t=dh, drop=drop(i))
+            if need_dx:
+                ops.gemm(qi, WEIGHTS.get(A, dt, transpose=True, pad_rows_to=rp), alpha=scaling, resid_t=dh, out_t=dh, drop=drop(i))
             grads.append(_lora_grads(dsl, t, hd, qi, A, Bm, bias, scaling, direct))
         grads.append(g_o)
         # ---- LayerNorm: dx = dx1 + LN'(dh); the T copy goes to the block below (its MLP half starts with a data-gradient GEMM)
-        dx = torch.empty_like(x2)
-        dx_t = _empty((M, D), dt, x2) if dt != torch.float32 else None
-        ops.layernorm_bwd(dh, x2, ln_w, eps, dres=dx1, dx32=dx, dx_t=dx_t)
-        publish_t_copy(dx, dx_t)
+        dx = None
+        if need_dx:
+            dx = torch.empty_like(x2)
+            dx_t = _empty((M, D), dt, x2) if dt != torch.float32 else None
+            ops.layernorm_bwd(dh, x2, ln_w, eps, dres=dx1, dx32=dx, dx_t=dx_t)
+            publish_t_copy(dx, dx_t)
+            dx = dx.view(shape)
         flat = []
         for dA, dB, db in grads:                                                    # order of the inputs: (w, b, A, B) per projection
             flat += [None, db, dA, dB]
-        return (dx.view(shape), None, None, None, None, None, None, None, None, *flat)
+        return (dx, None, None, None, None, None, None, None, None, *flat)
 
 
 def _pad_cols(p, dt, transpose=False, rows=False):

@@ -622,3 +622,36 @@ def test_linear_lora_with_the_rank_update_in_the_k_loop_equals_the_two_launch_fo
     for name, a, b in zip(("y", "dx", "dA", "dB"), outs[1], outs[0]):
         assert rel(a, b) < 1e-2, name
     assert torch.equal(outs[1][1], outs[0][1])                             # the backward does not depend on the forward's form
+
+
+def test_lora_attention_half_without_an_input_gradient():
+    """First block of a tower behind a frozen embedding: x does not require a gradient, the node skips the data-gradient GEMM and the LayerNorm
+    backward and must still produce the factor gradients of the run in which x does require one."""
+    from uia_hip import functional as UF
+    from src.adapters.lora import PlainMultiheadAttentionLoRA
+    UF.set_compute_dtype(torch.bfloat16)
+    g = torch.Generator().manual_seed(71)
+    B, L, D, H, r = 3, 33, 128, 2, 8
+    mod = PlainMultiheadAttentionLoRA(torch.nn.MultiheadAttention(D, H), enable_lora=["q", "k", "v", "o"], r=r, lora_alpha=16, dropout_rate=0.1)
+    ln = torch.nn.LayerNorm(D)
+    with torch.no_grad():
+        for k, p in mod.named_parameters():
+            p.copy_(0.1 * torch.randn(p.shape, generator=g))
+    mod, ln = mod.to(dev()).train(), ln.to(dev())
+    for p in ln.parameters():
+        p.requires_grad_(False)
+    x = torch.randn(B, L, D, generator=g).to(dev())
+    dy = torch.randn(B, L, D, generator=g).to(dev())
+    got = []
+    for need in (True, False):
+        for p in mod.parameters():
+            p.grad = None
+        UF.set_dropout_seed(5)
+        UF.clear_t_copies()
+        xx = x.clone().requires_grad_(need)
+        mod.block_half(xx, ln, B, L, None).backward(dy)
+        assert (xx.grad is not None) == need
+        got.append({k: p.grad.detach().clone() for k, p in mod.named_parameters() if p.grad is not None})
+    assert sorted(got[0]) == sorted(got[1]) and len(got[0]) == 12
+    for k in got[0]:
+        assert torch.equal(got[0][k], got[1][k]), k
