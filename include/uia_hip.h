@@ -171,6 +171,11 @@ typedef struct uia_attn_desc {
 } uia_attn_desc;
 int uia_attn_fwd(void* stream, int dtype, const uia_attn_desc* d);
 int uia_attn_bwd(void* stream, int dtype, const uia_attn_desc* d);
+/* Same backward with an explicit kernel configuration (bf16, dh = 64; ignored otherwise): 0 = the library's choice (what uia_attn_bwd
+ * runs), 1 = the lock-step 8-wave kernel (dS crosses LDS once per 32-query block), 2 / 3 / 4 = the barrier-free unit kernel (waves pull
+ * key-tile and query-tile units from an LDS counter; no product of one wave is read by another) with 8 waves and V in LDS / 4 waves and
+ * V fragments from global memory (two heads per CU up to 208 tokens) / 8 waves and V from global memory.  For A/B timing and tests. */
+int uia_attn_bwd_cfg(void* stream, int dtype, const uia_attn_desc* d, int cfg);
 
 /* ---------------------------------------------------------------------------------------------
  * LayerNorm over fp32 rows (model.py:163-169; timm / HF LayerNorm [third-party]).

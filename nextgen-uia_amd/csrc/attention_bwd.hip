@@ -66,6 +66,17 @@ __device__ __forceinline__ float row16_sum(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));   // row_mirror
     return v;
 }
+typedef __attribute__((address_space(3))) const char* lptr;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+__device__ __forceinline__ uint4 lds_u4(lptr p) { return __builtin_bit_cast(uint4, *(__attribute__((address_space(3))) const u32x4*)p); }
+__device__ __forceinline__ f32x4 lds_f4(lptr p) { return *(__attribute__((address_space(3))) const f32x4*)p; }
+__device__ __forceinline__ float lds_f1(lptr p) { return *(__attribute__((address_space(3))) const float*)p; }
+__device__ __forceinline__ bf16x8 tr_pair(lptr lo_addr, lptr hi_addr) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)lo_addr);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)hi_addr);
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
 __device__ __forceinline__ s16x4 lds_tr16(const char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
 }
@@ -460,6 +471,430 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void attn_bwd_bf16_kernel(const Uia
 }
 
 // ------------------------------------------------------------------------------------------
+// Round 4: the barrier-free form.  The kernel above crosses dS through LDS once per 32-query block, so its eight waves meet at a barrier
+// seven to nine times per head with 13 / 17 key tiles dealt over them (tools/abwd_stamps.sh: 53 % of the wave cycles parked).  Here no
+// product of one wave is ever read by another: a head is 2·LT independent UNITS that the waves of the workgroup pull from an LDS counter —
+//   KEY(kt): the wave owns a 16-key tile, keeps its K / V fragments and dKᵀ / dVᵀ in registers and sweeps the 32-query blocks:
+//            S = Q·Kᵀ, dP − δ = dO·Vᵀ − δ (key on the lane; −δ is the initial accumulator), P, dS in registers, dVᵀ += dOᵀ·P, dKᵀ += Qᵀ·dS
+//   QRY(qt): the wave owns a 16-query tile, keeps its Q / dO fragments and dQᵀ in registers and sweeps the 32-key blocks:
+//            S' = K·Qᵀ, dP' − δ = V·dOᵀ − δ (QUERY on the lane, so lse and δ are lane constants), dS' in registers, dQᵀ += Kᵀ·dS'
+// i.e. seven MFMA products per (tile, block) pair instead of five and the exponentials twice, for no LDS store, no barrier and no
+// lock-step in the sweep.  One barrier per head (after staging).  dS is kept without the softmax scale; dK and dQ take it once at the end.
+// LDS: per 16-row tile [Q tile | dO tile] (4 KiB) and [K tile | V tile], so that every read of a block is ONE running address register
+// plus an immediate (the first build spent more VALU on LDS addresses than on the softmax); statistics per tile [lse·log2e | −δ].
+// Tile swizzle: 16-byte chunk c of row r at chunk c ^ (r & 6) — conflict-free for the ds_read_b128 row reads AND the ds_read_b64_tr_b16
+// transposed reads (tools/lds_swizzle_search.py; the (r >> 1) & 7 of the kernels above is 2-way on every transposed read: rows r and
+// r + 2 of a 4-row group land in the same banks, a quarter of the LDS cycles in SQ_LDS_BANK_CONFLICT).
+// V only ever feeds row reads: the VLDS = false forms take its fragments from global memory (L2) and a 197-token head fits TWICE on a
+// CU (2 × 81.5 KB): one head's staging and stores run beside the other's sweep.
+struct ctrue { static constexpr bool value = true; };
+struct cfalse { static constexpr bool value = false; };
+template <int V> struct cint { static constexpr int value = V; };
+
+template <int NW, bool VLDS>
+__global__ __launch_bounds__(64 * NW, 2) void attn_bwd_units_kernel(const UiaAttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KVS = VLDS ? 4096 : 2048;                    // bytes per 16-key tile of the K (| V) region
+    const int L = p.L;
+    const int LT = (L + 15) >> 4, NP = (LT + 1) >> 1;
+    // LDS-address-space pointers: a read is then one running 32-bit register + an immediate (through generic pointers the compiler
+    // re-derived every address with a v_add per read)
+    char* QGg = smem;                                          // [LT][Q tile 2 KiB | dO tile 2 KiB]
+    char* KVg = QGg + LT * 4096;                               // [LT][K tile 2 KiB (| V tile 2 KiB)]
+    char* STg = KVg + LT * KVS;                                // [LT][lse·log2e of 16 rows | −δ of 16 rows]  (fp32)
+    int* queue = (int*)(STg + LT * 128);
+    const lptr QG = (lptr)smem, KV = QG + LT * 4096, ST = KV + LT * KVS;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef ABWD_STAMPS
+    // diagnostic build: [0] staging (to the barrier), [1] / [2] cycles in KEY / QRY units, [3] / [4] how many of each, [5] whole kernel
+    const unsigned long long st_begin = STAMP();
+    unsigned long long st_u[2] = {0, 0}, st_n[2] = {0, 0}, st_pro = 0, st_loop = 0, st_iter = 0;
+#endif
+    const int b = blockIdx.x / p.H, h = blockIdx.x - b * p.H;
+    const size_t row0 = (size_t)b * L;
+    const size_t rs = (size_t)p.ld_qkv * 2, rso = (size_t)p.lddo * 2, rsO = (size_t)p.ldo * 2;
+    const char* qb = (const char*)p.q + (row0 * p.ld_qkv + (size_t)h * 64) * 2;
+    const char* kb = (const char*)p.k + (row0 * p.ld_qkv + (size_t)h * 64) * 2;
+    const char* vb = (const char*)p.v + (row0 * p.ld_qkv + (size_t)h * 64) * 2;
+    const char* gb = (const char*)p.dout + (row0 * p.lddo + (size_t)h * 64) * 2;
+    const char* ob = (const char*)p.out + (row0 * p.ldo + (size_t)h * 64) * 2;
+    const int li = lane & 15, g = lane >> 4;
+    int klen = L;
+    if (p.mask_kind == UIA_MASK_KEYPAD && p.keylen) { klen = p.keylen[b]; klen = klen < 1 ? 1 : (klen > L ? L : klen); }
+    klen = __builtin_amdgcn_readfirstlane(klen);
+    const bool causal = p.mask_kind == UIA_MASK_CAUSAL;
+
+    // ---- staging.  δ = rowsum(dO ⊙ O) and lse come straight from global memory, eight lanes per row, ALL passes requested before the first
+    //      use (one pass at a time was one memory round trip per pass: 21.7 K cycles of staging against 8.4 K); then the images by LDS-DMA
+    //      (1 KiB pieces of 8 rows, inverse-swizzled source).
+    {
+        constexpr int RPP = NW * 8, MAXP = (288 + RPP - 1) / RPP;
+        bf16x8 gv[MAXP], ov[MAXP];
+        float lv[MAXP];
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i) {
+            const int r = i * RPP + (tid >> 3), part = tid & 7;
+            if (i * RPP < 16 * LT) {
+                const int gr = r < L ? r : L - 1;
+                gv[i] = *(const bf16x8*)(gb + gr * rso + part * 16);
+                ov[i] = *(const bf16x8*)(p.out_kb_rows ? (const char*)p.out + (((size_t)(2 * h + (part >> 2)) * (size_t)p.out_kb_rows + row0 + gr) << 6) + (part & 3) * 16
+                                                       : ob + gr * rsO + part * 16);
+                lv[i] = p.lse[((size_t)b * p.H + h) * L + gr];
+            }
+        }
+        const int npieces = 2 * LT;
+        for (int q = wave; q < npieces; q += NW) {
+            const int r = 8 * q + (lane >> 3);
+            const int gr = r < L ? r : L - 1;
+            const int c = ((lane & 7) ^ (r & 6)) * 16;           // tile swizzle: 16-byte chunk c of row r sits at chunk c ^ (r & 6)
+            const int t = q >> 1, half = (q & 1) * 1024;
+            glds16(kb + gr * rs + c, KVg + t * KVS + half);
+            glds16(qb + gr * rs + c, QGg + t * 4096 + half);
+            glds16(gb + gr * rso + c, QGg + t * 4096 + 2048 + half);
+            if (VLDS) glds16(vb + gr * rs + c, KVg + t * KVS + 2048 + half);
+        }
+        if (tid == 0) *queue = 0;
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i) {
+            const int r = i * RPP + (tid >> 3), part = tid & 7;
+            if (i * RPP < 16 * LT) {
+                float d = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) d = fmaf((float)gv[i][e], (float)ov[i][e], d);
+                d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
+                d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
+                d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x141, 0xF, 0xF, false));   // row_half_mirror
+                if (part == 0 && r < 16 * LT) {
+                    float* st = (float*)(STg + (r >> 4) * 128) + (r & 15);
+                    st[0] = r < L ? lv[i] * 1.44269504088896341f : 0.f;
+                    st[16] = r < L ? -d : 0.f;
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+#ifdef ABWD_STAMPS
+    st_pro = STAMP() - st_begin;
+#endif
+
+    const float sc = p.scale * 1.44269504088896341f;
+    const int offR0 = li * 128 + ((g ^ (li & 6)) << 4);        // row read: row li of a tile, chunk g; the second k-half is chunk g + 4
+    const int offR1 = offR0 ^ 64;
+    const int qq = li >> 2, pp = li & 3;
+    const int trow = 4 * g + qq;                               // transposed read: group g supplies rows 4g + qq of a tile
+    const int tsw = trow & 6;
+    int toff[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) toff[dt] = trow * 128 + (((2 * dt + (pp >> 1)) ^ tsw) << 4) + 8 * (pp & 1);
+    const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    const uint4 zero_u4 = uint4{0u, 0u, 0u, 0u};
+
+    for (;;) {
+        int unit = 0;
+        if (lane == 0) unit = atomicAdd(queue, 1);
+        unit = __builtin_amdgcn_readfirstlane(unit);
+        if (unit >= 2 * LT) break;
+#ifdef ABWD_STAMPS
+        const unsigned long long st_u0 = STAMP();
+#endif
+        if (unit < LT) {
+            // =============================== KEY unit: key tile kt, sweep over 32-query blocks
+            const int kt = unit;
+            const int key = 16 * kt + li;
+            uint4 kf[2], vf[2];
+            kf[0] = lds_u4(KV + kt * KVS + offR0);
+            kf[1] = lds_u4(KV + kt * KVS + offR1);
+            if (VLDS) {
+                vf[0] = lds_u4(KV + kt * KVS + 2048 + offR0);
+                vf[1] = lds_u4(KV + kt * KVS + 2048 + offR1);
+            } else {
+                const int gk = key < L ? key : L - 1;
+                vf[0] = *(const uint4*)(vb + gk * rs + g * 16);
+                vf[1] = *(const uint4*)(vb + gk * rs + g * 16 + 64);
+            }
+            f32x4 dVt[4], dKt[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) { dVt[dt] = zero4; dKt[dt] = zero4; }
+            const int ub_lo = 16 * kt >= klen ? NP : (causal ? kt >> 1 : 0);      // a fully padded key tile: zeros
+            const bool key_ok = key < klen;
+            // running addresses of the current block: rows (two k-halves), transposed reads (four d-tiles), statistics
+            lptr r0 = QG + ub_lo * 8192 + offR0;
+            lptr r1 = QG + ub_lo * 8192 + offR1;
+            lptr tp0 = QG + ub_lo * 8192 + toff[0];
+            lptr tp1 = QG + ub_lo * 8192 + toff[1];
+            lptr tp2 = QG + ub_lo * 8192 + toff[2];
+            lptr tp3 = QG + ub_lo * 8192 + toff[3];
+            lptr sp = ST + ub_lo * 256 + 16 * g;
+            // opaque to the optimiser: kept as "region base (scalar) + lane offset" it re-adds the base in front of every read
+            asm volatile("" : "+v"(r0), "+v"(r1), "+v"(tp0), "+v"(tp1), "+v"(tp2), "+v"(tp3), "+v"(sp));
+            // Software pipeline over the blocks, inside ONE wave (its instructions issue in order: S/dP -> exponentials -> dV/dK back to back
+            // left the matrix pipe idle during the exponentials and the vector ALU idle during the products, 37 % of the sweep in issue stalls):
+            // iteration ub runs the exponentials of block ub BETWEEN the S / dP products of block ub + 1 (one MFMA, four VALU, ...), then
+            // requests the rows of block ub + 2 and issues dV / dK of block ub.  At the top of iteration ub: s, dp = S, dP − δ of block ub;
+            // ls = lse of block ub; qf / gf = rows of block ub + 1 and dl = −δ of block ub + 1 (when it exists).
+            // A block past the end (odd LT: the second query tile of the last block) reads the bytes behind the region — finite, never used.
+            uint4 qf[2][2], gf[2][2];
+            f32x4 ls[2], dl[2], s[2], dp[2];
+            auto load_rows = [&](int ahead) {
+                qf[0][0] = lds_u4(r0 + ahead);        gf[0][0] = lds_u4(r0 + ahead + 2048);
+                qf[0][1] = lds_u4(r1 + ahead);        gf[0][1] = lds_u4(r1 + ahead + 2048);
+                qf[1][0] = lds_u4(r0 + ahead + 4096); gf[1][0] = lds_u4(r0 + ahead + 6144);
+                qf[1][1] = lds_u4(r1 + ahead + 4096); gf[1][1] = lds_u4(r1 + ahead + 6144);
+            };
+            auto load_ls = [&](int ahead) { ls[0] = lds_f4(sp + ahead); ls[1] = lds_f4(sp + ahead + 128); };
+            auto load_dl = [&](int ahead) { dl[0] = lds_f4(sp + ahead + 64); dl[1] = lds_f4(sp + ahead + 192); };
+            auto products = [&](int hq) {              // S and dP − δ of query tile hq of the block whose rows are in qf / gf
+                s[hq] = mma(qf[hq][0], kf[0], zero4);   dp[hq] = mma(gf[hq][0], vf[0], dl[hq]);
+                s[hq] = mma(qf[hq][1], kf[1], s[hq]);   dp[hq] = mma(gf[hq][1], vf[1], dp[hq]);
+            };
+            // KIND: 0 = every (query, key) of the block valid, 1 = per-element tests, 2 = the block's second query tile does not exist
+            auto key_block = [&](auto kind_c, auto next_c, int ub) {
+                constexpr int KIND = decltype(kind_c)::value;
+                constexpr bool HASNEXT = decltype(next_c)::value;
+                constexpr int HI = KIND == 2 ? 0 : 4096;
+                bf16x8 gT[4], qT[4];
+                qT[0] = tr_pair(tp0, tp0 + HI); gT[0] = tr_pair(tp0 + 2048, tp0 + 2048 + HI);
+                qT[1] = tr_pair(tp1, tp1 + HI); gT[1] = tr_pair(tp1 + 2048, tp1 + 2048 + HI);
+                qT[2] = tr_pair(tp2, tp2 + HI); gT[2] = tr_pair(tp2 + 2048, tp2 + 2048 + HI);
+                qT[3] = tr_pair(tp3, tp3 + HI); gT[3] = tr_pair(tp3 + 2048, tp3 + 2048 + HI);
+                __builtin_amdgcn_sched_barrier(0);
+                bf16x8 pf, sf;
+                auto softmax = [&](int hq) {            // P and dS of query tile hq from s / dp (in place: the tile's accumulators die here)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float pv = __builtin_amdgcn_exp2f(fmaf(s[hq][r], sc, -ls[hq][r]));
+                        float dsv = pv * dp[hq][r];
+                        if constexpr (KIND != 0) {
+                            const int qrow = 32 * ub + 16 * hq + 4 * g + r;
+                            const bool ok = qrow < L && key_ok && (!causal || key <= qrow);
+                            pv = ok ? pv : 0.f;
+                            dsv = ok ? dsv : 0.f;
+                        }
+                        pf[4 * hq + r] = (bf16_t)pv;
+                        sf[4 * hq + r] = (bf16_t)dsv;
+                    }
+                };
+                softmax(0);
+                if constexpr (HASNEXT) products(0);                    // next block, first query tile: between the second tile's exponentials
+                if constexpr (KIND == 2) {
+#pragma unroll
+                    for (int e = 4; e < 8; ++e) { pf[e] = (bf16_t)0.f; sf[e] = (bf16_t)0.f; }
+                } else {
+                    softmax(1);
+                }
+                if constexpr (HASNEXT) {
+                    products(1);
+                    __builtin_amdgcn_sched_group_barrier(0x002, KIND == 0 ? 16 : 28, 0);     // tile 0's exponentials
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   // one MFMA of the next block's first tile
+                        __builtin_amdgcn_sched_group_barrier(0x002, KIND == 0 ? 4 : 7, 0);   // a quarter of tile 1's exponentials
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (HASNEXT) {
+                    // rows of block ub + 2 (of block ub + 1 again when there is none: in bounds, never used), −δ with them; lse of block ub + 1
+                    const int more = ub + 2 < NP ? 1 : 0;
+                    load_ls(256);
+                    load_rows(8192 + 8192 * more);
+                    load_dl(256 + 256 * more);
+                }
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    dVt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gT[dt], pf, dVt[dt], 0, 0, 0);
+                    dKt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT[dt], sf, dKt[dt], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                r0 += 8192; r1 += 8192; tp0 += 8192; tp1 += 8192; tp2 += 8192; tp3 += 8192; sp += 256;
+            };
+            if (ub_lo < NP) {
+                const int last = NP - 1, nfull = LT >> 1;               // nfull = blocks with both query tiles
+                // blocks [f0, f1) need no mask: whole query rows (32ub + 32 <= L), a whole key tile, and below the causal diagonal
+                int f0 = causal ? (16 * kt + 46) >> 5 : 0, f1 = L >> 5;
+                f0 = f0 < ub_lo ? ub_lo : f0;
+                f1 = f1 > nfull ? nfull : f1;
+                if (16 * kt + 16 > klen || f0 > f1) { f0 = nfull; f1 = nfull; }
+                load_rows(0); load_ls(0); load_dl(0);
+                products(0); products(1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (ub_lo + 1 < NP) { load_rows(8192); load_dl(256); }
+                int ub = ub_lo;
+#pragma unroll 1
+                for (; ub < f0 && ub < last; ++ub) key_block(cint<1>{}, ctrue{}, ub);
+#ifdef ABWD_STAMPS
+                const unsigned long long st_l0 = STAMP(); const int ub_s = ub;
+#endif
+#pragma unroll 1
+                for (; ub < f1 && ub < last; ++ub) key_block(cint<0>{}, ctrue{}, ub);
+#ifdef ABWD_STAMPS
+                st_loop += STAMP() - st_l0; st_iter += ub - ub_s;
+#endif
+#pragma unroll 1
+                for (; ub < last; ++ub) key_block(cint<1>{}, ctrue{}, ub);
+                if (LT & 1) key_block(cint<2>{}, cfalse{}, last);
+                else if (last >= f0 && last < f1) key_block(cint<0>{}, cfalse{}, last);
+                else key_block(cint<1>{}, cfalse{}, last);
+            }
+            if (key < L) {          // lane owns key 16kt + li, d = 16dt + 4g + r
+                bf16_t* krow = (bf16_t*)p.dk + (row0 + key) * p.ld_dqkv + (size_t)h * 64 + 4 * g;
+                bf16_t* vrow = (bf16_t*)p.dv + (row0 + key) * p.ld_dqkv + (size_t)h * 64 + 4 * g;
+                const size_t kbo = ((size_t)(2 * h) * (size_t)p.dqkv_kb_rows + row0 + key) * 32 + 4 * g, kbp = (size_t)p.dqkv_kb_rows * 32;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    store4(p.dqkv_kb_rows ? (bf16_t*)p.dk + kbo + (dt >> 1) * kbp + 16 * (dt & 1) : krow + 16 * dt, dKt[dt] * p.scale);
+                    store4(p.dqkv_kb_rows ? (bf16_t*)p.dv + kbo + (dt >> 1) * kbp + 16 * (dt & 1) : vrow + 16 * dt, dVt[dt]);
+                }
+            }
+        } else {
+            // =============================== QRY unit: query tile qt, sweep over 32-key blocks (same pipeline)
+            const int qt = unit - LT;
+            const int qrow = 16 * qt + li;
+            uint4 qf[2], gf[2];
+            qf[0] = lds_u4(QG + qt * 4096 + offR0);        qf[1] = lds_u4(QG + qt * 4096 + offR1);
+            gf[0] = lds_u4(QG + qt * 4096 + 2048 + offR0); gf[1] = lds_u4(QG + qt * 4096 + 2048 + offR1);
+            const float lq = lds_f1(ST + qt * 128 + 4 * li);
+            const float nd = lds_f1(ST + qt * 128 + 64 + 4 * li);
+            const f32x4 nd4 = f32x4{nd, nd, nd, nd};
+            f32x4 dQt[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) dQt[dt] = zero4;
+            int kend = klen;
+            if (causal && 16 * qt + 16 < kend) kend = 16 * qt + 16;
+            const int KB = (kend + 31) >> 5;                            // key blocks that hold a valid key (>= 1)
+            lptr r0 = KV + offR0;
+            lptr r1 = KV + offR1;
+            lptr tp0 = KV + toff[0];
+            lptr tp1 = KV + toff[1];
+            lptr tp2 = KV + toff[2];
+            lptr tp3 = KV + toff[3];
+            asm volatile("" : "+v"(r0), "+v"(r1), "+v"(tp0), "+v"(tp1), "+v"(tp2), "+v"(tp3));
+            const char* vp = vb + (size_t)li * rs + g * 16;            // VLDS = false: V rows of the block from global memory
+            uint4 ka[2][2], va[2][2];
+            f32x4 s[2], dp[2];
+            auto load_kv = [&](int ahead_blocks, int kbk) {
+                const int ahead = ahead_blocks * 2 * KVS;
+                ka[0][0] = lds_u4(r0 + ahead); ka[0][1] = lds_u4(r1 + ahead);
+                ka[1][0] = lds_u4(r0 + ahead + KVS); ka[1][1] = lds_u4(r1 + ahead + KVS);
+                if (VLDS) {
+                    va[0][0] = lds_u4(r0 + ahead + 2048); va[0][1] = lds_u4(r1 + ahead + 2048);
+                    va[1][0] = lds_u4(r0 + ahead + KVS + 2048); va[1][1] = lds_u4(r1 + ahead + KVS + 2048);
+                } else {
+                    const int kb0 = 32 * (kbk + ahead_blocks);
+                    if (kb0 + 32 <= L) {
+                        const char* v0 = vp + (size_t)kb0 * rs;
+                        va[0][0] = *(const uint4*)v0; va[0][1] = *(const uint4*)(v0 + 64);
+                        va[1][0] = *(const uint4*)(v0 + 16 * rs); va[1][1] = *(const uint4*)(v0 + 16 * rs + 64);
+                    } else {
+                        int k0 = kb0 + li, k1 = k0 + 16;
+                        k0 = k0 < L ? k0 : L - 1; k1 = k1 < L ? k1 : L - 1;
+                        const char* v0 = vb + (size_t)k0 * rs + g * 16;
+                        const char* v1 = vb + (size_t)k1 * rs + g * 16;
+                        va[0][0] = *(const uint4*)v0; va[0][1] = *(const uint4*)(v0 + 64);
+                        va[1][0] = *(const uint4*)v1; va[1][1] = *(const uint4*)(v1 + 64);
+                    }
+                }
+            };
+            auto products = [&](int hk) {              // S' and dP' − δ of key tile hk of the block whose rows are in ka / va
+                s[hk] = mma(ka[hk][0], qf[0], zero4);   dp[hk] = mma(va[hk][0], gf[0], nd4);
+                s[hk] = mma(ka[hk][1], qf[1], s[hk]);   dp[hk] = mma(va[hk][1], gf[1], dp[hk]);
+            };
+            auto qry_block = [&](auto kind_c, auto next_c, int kbk) {
+                constexpr int KIND = decltype(kind_c)::value;
+                constexpr bool HASNEXT = decltype(next_c)::value;
+                constexpr int HI = KIND == 2 ? 0 : KVS;
+                bf16x8 kT[4];
+                kT[0] = tr_pair(tp0, tp0 + HI); kT[1] = tr_pair(tp1, tp1 + HI);
+                kT[2] = tr_pair(tp2, tp2 + HI); kT[3] = tr_pair(tp3, tp3 + HI);
+                __builtin_amdgcn_sched_barrier(0);
+                bf16x8 sf;
+                auto softmax = [&](int hk) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float pv = __builtin_amdgcn_exp2f(fmaf(s[hk][r], sc, -lq));
+                        float dsv = pv * dp[hk][r];
+                        if constexpr (KIND != 0) {
+                            const int keyv = 32 * kbk + 16 * hk + 4 * g + r;
+                            const bool ok = keyv < klen && (!causal || keyv <= qrow);
+                            dsv = ok ? dsv : 0.f;
+                        }
+                        sf[4 * hk + r] = (bf16_t)dsv;
+                    }
+                };
+                softmax(0);
+                if constexpr (HASNEXT) products(0);
+                if constexpr (KIND == 2) {
+#pragma unroll
+                    for (int e = 4; e < 8; ++e) sf[e] = (bf16_t)0.f;
+                } else {
+                    softmax(1);
+                }
+                if constexpr (HASNEXT) {
+                    products(1);
+                    __builtin_amdgcn_sched_group_barrier(0x002, KIND == 0 ? 14 : 22, 0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, KIND == 0 ? 4 : 6, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (HASNEXT) load_kv(kbk + 2 < KB ? 2 : 1, kbk);         // block kbk + 2 (kbk + 1 again when there is none)
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) dQt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT[dt], sf, dQt[dt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                r0 += 2 * KVS; r1 += 2 * KVS; tp0 += 2 * KVS; tp1 += 2 * KVS; tp2 += 2 * KVS; tp3 += 2 * KVS;
+            };
+            {
+                const int last = KB - 1;
+                const bool tail_last = 2 * last + 1 >= LT;              // the last swept block's second key tile does not exist
+                // key blocks [0, f1) need no mask: all 32 keys valid and at or below the tile's first query under the causal mask
+                int f1 = causal ? (16 * qt + 1) >> 5 : klen >> 5;
+                f1 = f1 > (klen >> 5) ? klen >> 5 : f1;
+                f1 = f1 > (LT >> 1) ? LT >> 1 : f1;
+                load_kv(0, 0);
+                products(0); products(1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (1 < KB) load_kv(1, 0);
+                int kbk = 0;
+#pragma unroll 1
+                for (; kbk < f1 && kbk < last; ++kbk) qry_block(cint<0>{}, ctrue{}, kbk);
+#pragma unroll 1
+                for (; kbk < last; ++kbk) qry_block(cint<1>{}, ctrue{}, kbk);
+                if (tail_last) qry_block(cint<2>{}, cfalse{}, last);
+                else if (last < f1) qry_block(cint<0>{}, cfalse{}, last);
+                else qry_block(cint<1>{}, cfalse{}, last);
+            }
+            if (qrow < L) {         // lane owns query 16qt + li, d = 16dt + 4g + r
+                bf16_t* drow = (bf16_t*)p.dq + (row0 + qrow) * p.ld_dqkv + (size_t)h * 64 + 4 * g;
+                const size_t kbo = ((size_t)(2 * h) * (size_t)p.dqkv_kb_rows + row0 + qrow) * 32 + 4 * g, kbp = (size_t)p.dqkv_kb_rows * 32;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+                    store4(p.dqkv_kb_rows ? (bf16_t*)p.dq + kbo + (dt >> 1) * kbp + 16 * (dt & 1) : drow + 16 * dt, dQt[dt] * p.scale);
+            }
+        }
+#ifdef ABWD_STAMPS
+        st_u[unit < LT ? 0 : 1] += STAMP() - st_u0; st_n[unit < LT ? 0 : 1] += 1;
+#endif
+    }
+#ifdef ABWD_STAMPS
+    if (blockIdx.x == 1500 && lane == 0 && wave < 8) {
+        unsigned long long* o = uia_abwd_stamps + wave * 8;
+        o[0] = st_pro; o[1] = st_u[0]; o[2] = st_u[1]; o[3] = st_n[0]; o[4] = st_n[1]; o[5] = STAMP() - st_begin; o[6] = st_loop; o[7] = st_iter;
+    }
+#endif
+}
+// + slack behind the statistics: the pipeline requests one block ahead without asking whether its second tile exists, so the bytes of one
+// (non-existent) K / V tile behind the K region and of a few statistics rows must lie inside the allocation (they are never used)
+__host__ __device__ constexpr int units_lds_bytes(int LT, bool vlds) {
+    const int kvs = vlds ? 4096 : 2048, need = kvs + 64 - LT * 128;
+    return LT * 4096 + LT * kvs + LT * 128 + 16 + (need > 1024 ? need : 1024);
+}
+
+
+// ------------------------------------------------------------------------------------------
 // fp32 parity path.  Sweep 0: dQ (thread per query; K,V in LDS).  Sweeps 1,2: dV then dK
 // (thread per key; Q,dO in LDS).
 __global__ __launch_bounds__(256) void attn_bwd_f32_kernel(const UiaAttnParams p) {
@@ -573,9 +1008,22 @@ int launch_bf16(hipStream_t stream, const UiaAttnParams& p) {
     return 0;
 }
 
+template <int NW, bool VLDS>
+int launch_units(hipStream_t stream, const UiaAttnParams& p) {
+    const int LT = (p.L + 15) / 16;
+    auto kern = attn_bwd_units_kernel<NW, VLDS>;
+    static UiaDevOnce attr_once;
+    static_assert(units_lds_bytes(18, true) <= 160 * 1024, "LDS budget");
+    UIA_ENSURE_LDS_ATTR(attr_once, kern, units_lds_bytes(18, VLDS));
+    hipLaunchKernelGGL(kern, dim3(p.B * p.H), dim3(64 * NW), units_lds_bytes(LT, VLDS), stream, p);
+    UIA_CHECK_LAUNCH();
+    return 0;
+}
+
 }  // namespace
 
-int uia_attn_bwd_launch(hipStream_t stream, int dtype, const UiaAttnParams& p) {
+int uia_attn_bwd_launch(hipStream_t stream, int dtype, const UiaAttnParams& p, int cfg) {
+    UIA_CHECK_ARG(cfg >= 0 && cfg <= 4, "uia_attn_bwd: unknown kernel configuration %d", cfg);
     UIA_CHECK_ARG(dtype == UIA_BF16 || dtype == UIA_F32, "uia_attn_bwd: bad dtype %d", dtype);
     UIA_CHECK_ARG(p.B > 0 && p.H > 0 && p.L > 0, "uia_attn_bwd: empty problem");
     UIA_CHECK_ARG(p.scale > 0.f && p.scale < 3.0e38f, "uia_attn_bwd: scale must be positive and finite (matches the forward's lse), got %g", (double)p.scale);
@@ -602,6 +1050,12 @@ int uia_attn_bwd_launch(hipStream_t stream, int dtype, const UiaAttnParams& p) {
     }
     UIA_CHECK_ARG(p.L <= 288, "uia_attn_bwd: bf16 path keeps Q, K, dO of a head in LDS: L=%d exceeds 288", p.L);
     const int LT = (p.L + 15) / 16;
+    // cfg 0 = the default choice; 1 = the lock-step 8-wave kernel of rounds 1-3; 2 / 3 / 4 = the barrier-free unit kernel with
+    // 8 waves and V in LDS / 4 waves and V fragments from global memory (two heads per CU up to 208 tokens) / 8 waves, V from global
+    if (cfg == 0) cfg = 2;
+    if (cfg == 2) return launch_units<8, true>(stream, p);
+    if (cfg == 3) return launch_units<4, false>(stream, p);
+    if (cfg == 4) return launch_units<8, false>(stream, p);
     if (LT <= 8) return launch_bf16<8>(stream, p);
     if (LT <= 16) return launch_bf16<16>(stream, p);
     return launch_bf16<18>(stream, p);

@@ -27,7 +27,11 @@ int uia_attn_fwd(void* stream, int dtype, const uia_attn_desc* d) {
 }
 int uia_attn_bwd(void* stream, int dtype, const uia_attn_desc* d) {
     NEED(d, "uia_attn_bwd");
-    return uia_attn_bwd_launch((hipStream_t)stream, dtype, *d);
+    return uia_attn_bwd_launch((hipStream_t)stream, dtype, *d, 0);
+}
+int uia_attn_bwd_cfg(void* stream, int dtype, const uia_attn_desc* d, int cfg) {
+    NEED(d, "uia_attn_bwd_cfg");
+    return uia_attn_bwd_launch((hipStream_t)stream, dtype, *d, cfg);
 }
 int uia_layernorm_fwd(void* stream, int dtype, int M, int D, int64_t ldx, const float* x, const float* gamma, const float* beta, float eps, void* yT, float* y32) {
     return uia_layernorm_fwd_launch((hipStream_t)stream, dtype, M, D, ldx, x, gamma, beta, eps, yT, y32, nullptr);

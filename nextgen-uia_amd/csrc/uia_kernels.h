@@ -12,7 +12,7 @@ typedef uia_attn_desc UiaAttnParams;
 
 int uia_gemm_launch(hipStream_t stream, int dtype, const UiaGemmParams& p, int cfg);
 int uia_attn_fwd_launch(hipStream_t stream, int dtype, const UiaAttnParams& p);
-int uia_attn_bwd_launch(hipStream_t stream, int dtype, const UiaAttnParams& p);
+int uia_attn_bwd_launch(hipStream_t stream, int dtype, const UiaAttnParams& p, int cfg = 0);
 int uia_layernorm_fwd_launch(hipStream_t stream, int dtype, int M, int D, long ldx, const float* x, const float* gamma, const float* beta,
                              float eps, void* yT, float* y32, float* stats);
 int uia_layernorm_bwd_launch(hipStream_t stream, int dtype, int M, int D, long ldx, const void* dy, const float* x, const float* gamma, float eps,

@@ -73,6 +73,7 @@ PROTOTYPES = {
     "uia_wgrad_ex": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, vp, i64, f32, vp, i64, C.c_int, C.c_int, vp]),
     "uia_attn_fwd": (C.c_int, [vp, C.c_int, C.POINTER(AttnDesc)]),
     "uia_attn_bwd": (C.c_int, [vp, C.c_int, C.POINTER(AttnDesc)]),
+    "uia_attn_bwd_cfg": (C.c_int, [vp, C.c_int, C.POINTER(AttnDesc), C.c_int]),
     "uia_layernorm_fwd": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, i64, vp, vp, vp, f32, vp, vp]),
     "uia_layernorm_fwd_stats": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, i64, vp, vp, vp, f32, vp, vp, vp]),
     "uia_layernorm_bwd": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, i64, vp, vp, vp, f32, vp, vp, vp]),

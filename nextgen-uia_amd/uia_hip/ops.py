@@ -538,7 +538,10 @@ def attn_fwd(q, k, v, out, B, H, L, lse=None, mask=None, keylen=None, scale=None
     check(lib().uia_attn_fwd(_stream(), _code(q.dtype), C.byref(d)), "uia_attn_fwd")
 
 
-def attn_bwd(q, k, v, out, dout, lse, dq, dk, dv, B, H, L, mask=None, keylen=None, scale=None, dh=64):
+ATTN_BWD_CFG = 0     # uia_attn_bwd_cfg's kernel configuration (0 = the library's choice); tools and tests switch it for A/B runs
+
+
+def attn_bwd(q, k, v, out, dout, lse, dq, dk, dv, B, H, L, mask=None, keylen=None, scale=None, dh=64, cfg=None):
     d = _attn_desc(q, k, v, out, lse, B, H, L, mask, keylen, scale, dh)
     d.dout, d.lddo = _p(dout), dout.stride(-2)
     if is_kb(dq):                                      # the fused [B*L, 3*H*dh] gradient, K-blocked (dk, dv are then None): A operand of the QKV dgrad
@@ -550,7 +553,11 @@ def attn_bwd(q, k, v, out, dout, lse, dq, dk, dv, B, H, L, mask=None, keylen=Non
     else:
         d.dq, d.dk, d.dv, d.ld_dqkv = _p(dq), _p(dk), _p(dv), dq.stride(-2)
         assert dk.stride(-2) == dq.stride(-2) == dv.stride(-2)
-    check(lib().uia_attn_bwd(_stream(), _code(q.dtype), C.byref(d)), "uia_attn_bwd")
+    cfg = ATTN_BWD_CFG if cfg is None else cfg
+    if cfg:
+        check(lib().uia_attn_bwd_cfg(_stream(), _code(q.dtype), C.byref(d), int(cfg)), "uia_attn_bwd_cfg")
+    else:
+        check(lib().uia_attn_bwd(_stream(), _code(q.dtype), C.byref(d)), "uia_attn_bwd")
 
 
 def layernorm_fwd(x, gamma, beta, eps, y_t=None, y32=None, rows=None, ldx=None, stats=None):

@@ -1,0 +1,112 @@
+"""-m gpu, round 4: the barrier-free attention backward (csrc/attention_bwd.hip, attn_bwd_units_kernel; uia_attn_bwd_cfg 2 / 3 / 4) against
+torch's fp32 softmax attention (autograd) on the same operands — every mask kind, ragged lengths, the production head counts — and its
+K-blocked inputs / outputs against its own row-major launch, bit for bit.  Reference op: /root/reference/src/adapters/lora.py:188,
+src/third_party/openai_clip/model.py:197 (autograd through SDPA / nn.MultiheadAttention)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+CFGS = [1, 2, 3, 4]
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def _reference(qkv, dout, B, H, L, mask, keylen):
+    D = H * 64
+    qf = qkv.float().view(B, L, 3, H, 64).permute(2, 0, 3, 1, 4).contiguous().requires_grad_(True)   # [3,B,H,L,64]
+    s = qf[0] @ qf[1].transpose(-1, -2) / 8.0
+    if mask == "causal":
+        s = s + torch.full((L, L), float("-inf"), device=dev()).triu_(1)
+    if mask == "keypad":
+        ar = torch.arange(L, device=dev())
+        s = s.masked_fill(ar[None, None, None, :] >= keylen[:, None, None, None], float("-inf"))
+    ref = torch.softmax(s, -1) @ qf[2]
+    ref.backward(dout.float().view(B, L, H, 64).permute(0, 2, 1, 3))
+    return qf.grad.permute(1, 3, 0, 2, 4).reshape(B * L, 3 * D)
+
+
+@pytest.mark.parametrize("cfg", CFGS)
+@pytest.mark.parametrize("L,mask", [(197, "none"), (77, "causal"), (256, "keypad"), (17, "none"), (50, "keypad"), (257, "none"), (130, "causal"),
+                                    (16, "none"), (2, "none"), (208, "keypad"), (272, "none"), (33, "causal")])
+def test_attention_bwd_every_kernel_configuration(cfg, L, mask):
+    from uia_hip import ops
+    torch.manual_seed(2 + L)
+    B, H, D = 3, 4, 256
+    qkv = (torch.randn(B * L, 3 * D, device=dev()) * 1.5).bfloat16()
+    q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+    keylen = torch.tensor([L, max(1, L // 3), max(2, L - 5)], device=dev(), dtype=torch.int32) if mask == "keypad" else None
+    out = torch.empty(B * L, D, device=dev(), dtype=torch.bfloat16)
+    lse = torch.empty(B, H, L, device=dev())
+    ops.attn_fwd(q, k, v, out, B, H, L, lse=lse, mask=mask, keylen=keylen)
+    dout = torch.randn(B * L, D, device=dev()).bfloat16()
+    g = _reference(qkv, dout, B, H, L, mask, keylen)
+    dqkv = torch.full((B * L, 3 * D), float("nan"), device=dev(), dtype=torch.bfloat16)     # every element must be written
+    ops.attn_bwd(q, k, v, out, dout, lse, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], B, H, L, mask=mask, keylen=keylen, cfg=cfg)
+    assert bool(torch.isfinite(dqkv.float()).all())
+    for i, name in enumerate("qkv"):
+        assert rel(dqkv[:, i * D:(i + 1) * D], g[:, i * D:(i + 1) * D]) < 2.5e-2, name
+    if mask == "keypad":        # padded keys receive exactly zero gradient
+        for bi in range(B):
+            kl = int(keylen[bi])
+            assert float(dqkv[bi * L + kl:(bi + 1) * L, D:].float().abs().max() if kl < L else 0.0) == 0.0
+
+
+@pytest.mark.parametrize("cfg", [2, 3, 4])
+@pytest.mark.parametrize("L,mask", [(197, "none"), (256, "keypad"), (257, "none")])
+def test_attention_bwd_production_head_count(cfg, L, mask):
+    """B = 8, H = 12 (ViT-B / BERT-base head count; 257 = ViT-L/14 tokens)"""
+    from uia_hip import ops
+    torch.manual_seed(7 + L)
+    B, H = 8, 12
+    D = H * 64
+    qkv = (torch.randn(B * L, 3 * D, device=dev()) * 1.2).bfloat16()
+    q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+    keylen = torch.randint(24, 129, (B,), device=dev(), dtype=torch.int32) if mask == "keypad" else None
+    out = torch.empty(B * L, D, device=dev(), dtype=torch.bfloat16)
+    lse = torch.empty(B, H, L, device=dev())
+    ops.attn_fwd(q, k, v, out, B, H, L, lse=lse, mask=mask, keylen=keylen)
+    dout = torch.randn(B * L, D, device=dev()).bfloat16()
+    g = _reference(qkv, dout, B, H, L, mask, keylen)
+    dqkv = torch.full((B * L, 3 * D), float("nan"), device=dev(), dtype=torch.bfloat16)
+    ops.attn_bwd(q, k, v, out, dout, lse, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], B, H, L, mask=mask, keylen=keylen, cfg=cfg)
+    for i, name in enumerate("qkv"):
+        assert rel(dqkv[:, i * D:(i + 1) * D], g[:, i * D:(i + 1) * D]) < 2.5e-2, name
+    # the legacy kernel on the same operands: both are bf16 roundings of the same fp32 sums
+    d1 = torch.empty_like(dqkv)
+    ops.attn_bwd(q, k, v, out, dout, lse, d1[:, :D], d1[:, D:2 * D], d1[:, 2 * D:], B, H, L, mask=mask, keylen=keylen, cfg=1)
+    assert rel(dqkv, d1) < 1.5e-2
+
+
+@pytest.mark.parametrize("cfg", [2, 3, 4])
+@pytest.mark.parametrize("L,mask", [(197, None), (256, "keypad"), (50, "causal")])
+def test_attention_bwd_kblocked_tensors(cfg, L, mask):
+    """O read K-blocked, the fused dq / dk / dv written K-blocked: the same values as the row-major launch of the same kernel, bit for bit;
+    and a second launch reproduces the first (no atomics, the unit queue only changes which wave computes what)"""
+    from uia_hip import ops
+    from tests.test_lnfold_gpu import _from_kb
+    B, H, D = 3, 4, 256
+    g = torch.Generator().manual_seed(L)
+    qkv = (torch.randn(B * L, 3 * D, generator=g) * 0.5).to(dev()).bfloat16()
+    q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+    keylen = torch.tensor([L, max(1, L // 3), max(1, L - 7)], dtype=torch.int32, device=dev()) if mask == "keypad" else None
+    out = torch.empty(B * L, D, device=dev(), dtype=torch.bfloat16)
+    lse = torch.empty(B, H, L, device=dev())
+    ops.attn_fwd(q, k, v, out, B, H, L, lse=lse, mask=mask, keylen=keylen)
+    big = ops.kb_empty(B * L + 40, D, torch.bfloat16, dev())
+    okb = big.row_range(8, 8 + B * L)
+    ops.attn_fwd(q, k, v, okb, B, H, L, lse=torch.empty_like(lse), mask=mask, keylen=keylen)
+    do = torch.randn(B * L, D, generator=g).to(dev()).bfloat16()
+    dqkv, again = torch.empty_like(qkv), torch.empty_like(qkv)
+    ops.attn_bwd(q, k, v, out, do, lse, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], B, H, L, mask=mask, keylen=keylen, cfg=cfg)
+    ops.attn_bwd(q, k, v, out, do, lse, again[:, :D], again[:, D:2 * D], again[:, 2 * D:], B, H, L, mask=mask, keylen=keylen, cfg=cfg)
+    dkb = ops.kb_empty(B * L, 3 * D, torch.bfloat16, dev())
+    ops.attn_bwd(q, k, v, okb, do, lse, dkb, None, None, B, H, L, mask=mask, keylen=keylen, cfg=cfg)
+    assert torch.equal(again, dqkv)
+    assert torch.equal(_from_kb(dkb), dqkv)
