@@ -28,6 +28,7 @@ for _p in (ROOT, os.path.join(ROOT, "nextgen-uia_amd")):
 # algorithmic work per image-caption pair: 69.95 GF image tower fwd+bwd (+Mona) + 45.90 GF text fwd
 GFLOP_PER_PAIR = 115.86
 PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+TRAFFIC_FILE = "r04_traffic_pmc.json"   # tools/pmc_traffic.sh on the tree that is benchmarked; tests/test_host_logic.py checks that every instantiation is in it
 
 
 def parse():
@@ -42,10 +43,12 @@ def parse():
     ap.add_argument("--variant", default="freq_enhanced", help="Mona variant (reference default: biomedclip/finetune.py:76)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--overlap-text", action="store_true", help="run the frozen text tower on a second HIP stream beside encode_image (+2 % pairs/s); "
-                    "off by default so that the per-launch HIP-event durations behind `roofline` are not inflated by the other stream's kernels "
-                    "and agree with the rocprofv3 summary of the same command")
-    ap.add_argument("--no-overlap-text", action="store_true", help=argparse.SUPPRESS)        # former spelling of the default
+    ap.add_argument("--overlap-text", action="store_true", help=argparse.SUPPRESS)           # the default since round 4 (kept so that old command lines still parse)
+    ap.add_argument("--no-overlap-text", action="store_true", help="run the frozen text tower on the image tower's stream.  Default (round 4): on a second HIP "
+                    "stream beside encode_image, as the entry points do (contrastive_step(overlap_text=True), +2.5 % pairs/s); `roofline` then comes from one "
+                    "extra untimed step with both towers on ONE stream, where a launch's HIP events see only that launch (and agree with rocprofv3)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the two secondary lines (BASELINE configs[3] and the per-GPU shape of configs[4], 10 steps each, "
+                    "no CPU leg) that the default single-GPU run prints under `secondary`")
     ap.add_argument("--also-streams", type=int, default=3, help="after the timed region, time 5 more steps with the batch's towers cut into this many slices on as many "
                     "HIP streams and report them beside the headline as `multi_stream` (0 = skip); the headline itself stays on --streams")
     ap.add_argument("--streams", type=int, default=1, help="cut each rank's batch into this many slices whose towers run on as many HIP streams (same batch, "
@@ -218,22 +221,24 @@ def gemm_roofline(prof, prof_serial, args, ms_per_step, ops, torch):
         return rows
 
     per_kernel = lambda c, m: (c, m if m in ops._SPECIALISED else ops.EPI_GENERIC)
-    by_k, by_k_serial = group(prof, per_kernel), group(prof_serial, per_kernel)
-    fam, fam_serial = group(prof, lambda c, m: c in (8, 12, 13, 14, 24)), group(prof_serial, lambda c, m: c in (8, 12, 13, 14, 24))
+    multi = prof_serial is not prof
+    by_k_inflight, fam_inflight = group(prof, per_kernel), group(prof, lambda c, m: c in (8, 12, 13, 14, 24))
+    # more than one stream in the timed step: the kernel's rate comes from the serialised extra step (a launch's events then bracket that launch only)
+    by_k, fam = group(prof_serial, per_kernel), group(prof_serial, lambda c, m: c in (8, 12, 13, 14, 24))
     if not by_k:
         return None
     dom = max(by_k, key=lambda k: by_k[k][0])
     tsec, flops, n, algo_bytes = by_k[dom]
     achieved = flops / tsec * 1e-12
-    ts, fs, ns, _ = by_k_serial.get(dom, (tsec, flops, n, algo_bytes))
+    ts, fs, ns, _ = by_k_inflight.get(dom, (tsec, flops, n, algo_bytes))
     kname, kmangled = ops.gemm_kernel_name(dom[0], dom[1], dt)
-    traffic, traffic_src = None, None
-    tdir = os.path.join(ROOT, "profiles")
-    for cand in ("r03_traffic_pmc.json", "r02_traffic_pmc.json", "r01_g_traffic_pmc.json"):
-        tpath = os.path.join(tdir, cand)
-        if os.path.exists(tpath):
-            break
-    if args.config == "mona" and args.dtype == "bf16" and args.batch == 256 and os.path.exists(tpath):
+    traffic, traffic_src, traffic_err = None, None, None
+    tpath = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
+    if not (args.config == "mona" and args.dtype == "bf16" and args.batch == 256):
+        traffic_err = "PMC passes exist for the headline workload only (mona, bf16, 256 per GPU)"
+    elif not os.path.exists(tpath):
+        traffic_err = f"profiles/{TRAFFIC_FILE} is missing: run tools/pmc_traffic.sh on the GPU box and commit its summary.json under that name"
+    else:
         # HBM bytes per launch of this kernel from rocprofv3 PMC passes over the same workload (tools/pmc_traffic.sh):
         # FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies the 128-B requests of wide coalesced
         # reads at 64 B, so it is doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact for 16-B stores.
@@ -243,8 +248,11 @@ def gemm_roofline(prof, prof_serial, args, ms_per_step, ops, torch):
             traffic = round((2.0 * f["sum"] / f["launches"] + w["sum"] / w["launches"]) * 1024)
             traffic_src = (f"profiles/{os.path.basename(tpath)} (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, same "
                            "workload, measured in the round the file name carries; FETCH_SIZE doubled per the gfx950 note of the microarchitecture guide)")
+        else:
+            # a renamed instantiation (a new template parameter) must not turn into a silent null again (BENCH_r03)
+            traffic_err = f"kernel {kmangled} is not in profiles/{TRAFFIC_FILE}: the instantiation was renamed after the PMC passes; re-run tools/pmc_traffic.sh"
     ft, ff, fn, _ = fam.get(True, (tsec, flops, n, 0.0))
-    fts, ffs, fns, _ = fam_serial.get(True, (ts, fs, ns, 0.0))
+    fts, ffs, fns, _ = fam_inflight.get(True, (ts, fs, ns, 0.0))
     # in-kernel clock under sustained GEMM load (s_memtime / s_memrealtime, profiles/r03_a_inkernel_clock.txt): 1.51-1.65 GHz on this pool's
     # devices against the 2.4 GHz the 2.5 PF datasheet peak is quoted at; `frac` stays against the datasheet peak
     load_clock = {"measured_GHz": [1.51, 1.65], "source": "profiles/r03_a_inkernel_clock.txt (test_gemm_stamps: s_memtime / s_memrealtime x 100 MHz per workgroup, after 6-12 k warm launches)",
@@ -252,19 +260,20 @@ def gemm_roofline(prof, prof_serial, args, ms_per_step, ops, torch):
                   "frac_of_that_peak": [round(achieved / (peak * 1.65 / 2.4), 4), round(achieved / (peak * 1.51 / 2.4), 4)]} if args.dtype == "bf16" else None
     roof = {"bound": "mfma", "kernel": kname, "kernel_in_rocprof_csv": kmangled, "achieved": round(achieved, 1), "peak": peak,
             "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "bytes per launch (HBM, PMC)",
-            "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(algo_bytes / n), "launches_per_step": n,
+            "traffic_source": traffic_src, "traffic_error": traffic_err, "algorithmic_bytes_per_launch": round(algo_bytes / n), "launches_per_step": n,
             "avg_launch_us": round(tsec / n * 1e6, 2), "flop_per_launch_avg": round(flops / n),
             "share_of_step": round(tsec / (ms_per_step * 1e-3), 3), "load_clock": load_clock,
-            "note": ("HIP events around every launch of this kernel, on the launch stream, during one extra step of the same loop right after the timed region" +
-                     ("; more than one HIP stream: a launch's duration includes time shared with the other stream's kernels "
-                      "(see standalone)" if (args.overlap_text or getattr(args, "streams", 1) > 1) else "")),
+            "note": ("HIP events around every launch of this kernel, on the launch stream, during one extra step right after the timed region" +
+                     (": that step runs both towers on ONE stream (the timed steps use more than one; a launch's events would then include time "
+                      "shared with the other stream's kernels - those figures are under `in_timed_configuration`)" if multi else " of the same loop")),
             "gemm_family": {"kernels": "gemm_tn_ring_kernel<...,EPI> (+ gemm_tn_persist_kernel when selected), all epilogue masks",
                             "launches_per_step": fn, "achieved": round(ff / ft * 1e-12, 1), "frac": round(ff / ft * 1e-12 / peak, 4),
                             "ms_per_step": round(ft * 1e3, 3)},
             "per_shape": shape_table(prof_serial)}
-    if args.overlap_text or getattr(args, "streams", 1) > 1:
-        roof["standalone"] = {"achieved": round(fs / ts * 1e-12, 1), "frac": round(fs / ts * 1e-12 / peak, 4), "avg_launch_us": round(ts / ns * 1e6, 2),
-                              "family_achieved": round(ffs / fts * 1e-12, 1), "how": "one extra untimed step with both towers on one stream"}
+    if multi:
+        roof["in_timed_configuration"] = {"achieved": round(fs / ts * 1e-12, 1), "frac": round(fs / ts * 1e-12 / peak, 4), "avg_launch_us": round(ts / ns * 1e6, 2),
+                                          "family_achieved": round(ffs / fts * 1e-12, 1),
+                                          "how": "the same events during a step with the streams of the timed region: durations include the other stream's kernels"}
     return roof
 
 
@@ -325,6 +334,7 @@ def main():
     from uia_hip import ops
     from uia_hip.engine import FlatAdapterOptimizer, contrastive_step, init_data_parallel
 
+    args.overlap_text = not args.no_overlap_text and args.streams == 1 and args.config == "mona"
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -357,11 +367,39 @@ def main():
         traceback.print_exc()
         sys.stderr.flush()
         os._exit(13)
+    if rank == 0 and world == 1 and args.config == "mona" and not args.no_secondary:
+        out["secondary"] = secondary_lines(args, device)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         ops.comm_destroy()
         torch.distributed.destroy_process_group()
+
+
+def secondary_lines(args, device):
+    """BASELINE configs[3] and the per-GPU shape of configs[4] inside the default line (the driver runs only the default command): 10 timed steps
+    each, no CPU leg, the same keys as `python bench.py --config clipseg|vitl_lora` prints, cut to what a reader needs."""
+    import copy
+    import gc
+    import torch
+    from uia_hip import functional as UF
+    lines = {}
+    for cfg, fn in (("clipseg", bench_clipseg), ("vitl_lora", bench_vitl_lora)):
+        a = copy.copy(args)
+        a.config, a.batch, a.steps, a.warmup, a.no_cpu_baseline, a.overlap_text, a.streams = cfg, 128, 10, 3, True, False, 1
+        UF.clear_t_copies()
+        gc.collect()
+        torch.cuda.empty_cache()
+        try:
+            o = fn(a, 0, 1, device)
+            r = o.get("roofline") or {}
+            lines[cfg] = {"metric": o["metric"], "value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"], "steps": o["steps"], "warmup": o["warmup"],
+                          "dtype": o["dtype"], "data": o["data"], "config": o["config"], "loss": o["loss"],
+                          "roofline": {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "launches_per_step", "avg_launch_us",
+                                                             "share_of_step", "whole_step_frac_of_peak", "gemm_family")}}
+        except Exception as e:                      # a secondary line must never cost the headline
+            lines[cfg] = {"error": f"{type(e).__name__}: {e}"}
+    return lines
 
 
 def bench_mona(args, rank, world, device):
@@ -415,8 +453,8 @@ def bench_mona(args, rank, world, device):
             dtm = float(tm[0])
         multi = {"hip_streams": args.also_streams, "steps": 5, "ms_per_step": round(dtm / 5 * 1e3, 3), "value": round(world * args.batch * 5 / dtm, 2),
                  "loss": round(float(lm), 5), "how": "engine.contrastive_step(streams=S): S batch slices on S streams, one InfoNCE over all pairs; untimed in `value`"}
-        # and the entry points' default: the frozen text tower on a second stream beside the image tower (contrastive_step(overlap_text=True))
-        stepo = lambda: contrastive_step(model, criterion, opt, images, ids, overlap_text=True, global_loss=args.global_loss)
+        # and the other form of the text tower (headline: second stream beside the image tower, the entry points' default; here: the one it is not)
+        stepo = lambda: contrastive_step(model, criterion, opt, images, ids, overlap_text=not args.overlap_text, global_loss=args.global_loss)
         for _ in range(2):
             stepo()
         if world > 1:
@@ -431,7 +469,7 @@ def bench_mona(args, rank, world, device):
             to = torch.tensor([dto], device=device, dtype=torch.float64)
             torch.distributed.all_reduce(to, op=torch.distributed.ReduceOp.MAX)
             dto = float(to[0])
-        multi["text_tower_on_second_stream"] = {"steps": 5, "ms_per_step": round(dto / 5 * 1e3, 3), "value": round(world * args.batch * 5 / dto, 2), "loss": round(float(lo), 5)}
+        multi["text_tower_on_second_stream" if not args.overlap_text else "text_tower_on_the_same_stream"] = {"steps": 5, "ms_per_step": round(dto / 5 * 1e3, 3), "value": round(world * args.batch * 5 / dto, 2), "loss": round(float(lo), 5)}
     if rank != 0:
         return None
     ms = elapsed / args.steps * 1e3
@@ -456,7 +494,8 @@ def bench_mona(args, rank, world, device):
                                   "InfoNCE, clip+AdamW; random-init weights",
                       "mona_variant": args.variant, "batch_per_gpu": args.batch, "global_batch": args.batch * world, "image": "3x224x224",
                       "text_len": 256, "text_positions_computed": "valid tokens only (opt-in --unpad-text)" if args.unpad_text else "all 256",
-                      "parallelism": f"dp{world}", "text_tower_stream": "second stream" if args.overlap_text else "same stream",
+                      "parallelism": f"dp{world}", "text_tower_stream": ("second HIP stream beside the image tower (the entry points' default); roofline from one extra step with both towers on one stream"
+                                            if args.overlap_text else "same stream"),
                       "hip_streams": (f"{args.streams}: the batch's towers run as {args.streams} slices on {args.streams} HIP streams, one InfoNCE over all pairs" if args.streams > 1 else 1),
                       "contrastive_batch": "global (opt-in)" if args.global_loss else "per-rank (reference-equivalent)", "mona_dropout": 0.1,
                       "bert_dropout_emulated": False,

@@ -1940,6 +1940,10 @@ int launch_typed(hipStream_t stream, const UiaGemmParams& p, int cfg_in) {
         const int slices = (cfg_in >> 16) & 63, phase = (cfg_in >> 22) & 3;
         xflags &= 255;
         if (phase != 0) {
+            if (p.K2 > 0) {      // the split-K variant of the ring kernel has no K-extension operand: it would read K columns of A and ignore A2
+                uia_set_error("uia_gemm: split K (phase %d) cannot be combined with the K extension (A2 / K2 = %d)", phase, p.K2);
+                return -1;
+            }
             if (phase == 3 || slices < 2 || cfg != 13 || !p.splitk_ws || (uintptr_t)p.splitk_ws % 16 != 0 || p.K * (int)sizeof(T) / 64 < slices) {
                 uia_set_error("uia_gemm: split K needs phase 1 or 2, 2..63 slices (at most one per 64 bytes of K), the half-height tail config (tile cfg 13) and a 16-byte aligned splitk_ws; "
                               "got phase %d, %d slices, tile cfg %d", phase, slices, cfg);

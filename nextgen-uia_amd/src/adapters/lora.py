@@ -146,8 +146,10 @@ class PlainMultiheadAttentionLoRA(nn.Module):
         (model.py:195-201): one autograd node when q, k, v and the output projection all carry LoRA factors of one rank, scaling and dropout
         (how inject_lora_to_clip builds them); the composition of rows_forward otherwise."""
         ps = (self.q_proj, self.k_proj, self.v_proj, self.proj)
+        # ... and a frozen LayerNorm: the fused node returns no gradient for ln.weight / ln.bias (a user who unfreezes the norms gets the composed path)
         uniform = (all(m.r > 0 for m in ps) and len({(m.r, m.scaling, m._drop_p()) for m in ps}) == 1
-                   and len({m.bias is None for m in ps}) == 1 and self.head_dim == 64)
+                   and len({m.bias is None for m in ps}) == 1 and self.head_dim == 64
+                   and not ln.weight.requires_grad and not ln.bias.requires_grad)
         if not uniform:
             D = xb.shape[-1]
             h = UF.LayerNormFn.apply(xb, ln.weight, ln.bias, ln.eps).view(B * L, D)

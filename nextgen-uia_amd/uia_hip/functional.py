@@ -46,10 +46,20 @@ def set_ln_fold(flag):
     _STATE["ln_fold"] = bool(flag)
 
 
+def set_deterministic(flag):
+    """True: nothing on the FORWARD path sums through float atomics — the split-K form of few-tile M tails (ops.TAIL_SPLIT_K, the ViT-L/14 + LoRA
+    step's 128-row tails) is turned off, so features are bit-reproducible from run to run.  (Weight GRADIENTS still add up through float
+    atomics in uia_wgrad and the Mona row kernels; their last bits vary either way.)"""
+    _STATE["deterministic"] = bool(flag)
+    ops.TAIL_SPLIT_K = not flag
+
+
 def ln_fold_enabled(dt, rows=None):
     """rows: the fold is a large-batch optimisation and is only applied where its GEMMs run on the ring kernels (more than 2048 rows);
     below that nothing is gained.  (The row sums are 64-bit fixed-point integer atomics — exact and order-free, so the folded forward is
-    bit-reproducible; the first version used float atomics and was not: DESIGN.md §4.)"""
+    bit-reproducible wherever no split-K tail runs — the headline step has none; the few-tile 128-row tails of ViT-L/14 (ops.TAIL_SPLIT_K)
+    sum their K slices with float atomics: set_deterministic(True) removes them.  The first version of the fold used float atomics and was
+    not reproducible at all: DESIGN.md §4.)"""
     return dt != torch.float32 and _STATE.get("ln_fold", True) and (rows is None or rows > _STATE.get("ln_fold_min_rows", 2048))
 
 
@@ -260,7 +270,20 @@ class WeightCache:
         self._c = {}
         self.epoch = 0
         self._packed = {}                  # id(p) -> _PackedParam
+        self._ext_of = {}                  # storage pointer of an ExtW's K-blocked buffer -> weakref(ExtW): the pack launch rewrites its factor columns
         self._table = None                 # (device table, n, max_elems, dtype, [entries kept alive])
+
+    def _refreshed(self, items):
+        """one event for everything the pack launch just wrote: the operand forms of `items` and the factor columns inside the ExtW buffers"""
+        ready = ops.Ready()
+        for it in items:
+            it.fwd.refreshed(ready)
+            it.bwd.refreshed(ready)
+            for view, _, _, _ in it.extra:
+                ext = self._ext_of.get(view.untyped_storage().data_ptr())
+                ext = ext() if ext is not None else None
+                if ext is not None:
+                    ext.ready = ready
 
     def _repack(self, items):
         dt, dev = items[0].dt, items[0].row.device
@@ -269,6 +292,7 @@ class WeightCache:
         ops.pack_weights(table, n, mx, dt)
         for it in items:
             it.version, it.epoch, it.src_ptr = it.ref()._version, self.epoch, it.ref().data_ptr()
+        self._refreshed(items)
         return table, n, mx, dt, entries
 
     def bump(self):
@@ -292,6 +316,7 @@ class WeightCache:
             ops.pack_weights(table, n, mx, dt)
             for it in live:
                 it.version, it.epoch = it.ref()._version, self.epoch
+            self._refreshed(live)
         else:
             self._table = None
             for items in groups.values():
@@ -303,7 +328,12 @@ class WeightCache:
         it = self._packed.get(id(p))
         want = tuple(pads) if pads is not None else tuple(p.shape)
         if it is None or it.ref() is not p or it.dt != dt or it.row.device != p.device or tuple(it.row.shape) != want or it.pads != pads:
+            old = it
             it = _PackedParam(p, dt, pads)
+            if old is not None and old.ref() is p and old.dt == dt and old.row.device == p.device:
+                # the same parameter asked for in another padded form: the factor columns it feeds inside cached ExtW buffers stay its
+                # destinations (dropping them left a stale s·B in the K-extension forward), minus those whose ExtW is gone
+                it.extra = [e for e in old.extra if (self._ext_of.get(e[0].untyped_storage().data_ptr()) or (lambda: None))() is not None]
             self._packed[id(p)] = it
             self._table = None
         if it.version != p._version or it.epoch != self.epoch:
@@ -326,7 +356,8 @@ class WeightCache:
             bias = (w32 @ ln_b.detach().float())
             if b is not None:
                 bias = bias + b.detach().float()
-        out = (ops.PackedW(wf), colsum, bias.contiguous())
+            bias = bias.contiguous()
+        out = (ops.PackedW(wf), colsum, bias)       # constructed last: its event covers colsum and bias too
         self._c[key] = (vers, weakref.ref(w), out, weakref.ref(ln_w))
         return out
 
@@ -336,7 +367,7 @@ class WeightCache:
         key = (tuple(id(w) for w in ws), dt, transpose, "cat")
         vers = tuple(w._version for w in ws)
         hit = self._c.get(key)
-        if hit is not None and hit[0] == vers and all(r() is w for r, w in zip(hit[1], ws)) and hit[2].row.device == ws[0].device:
+        if hit is not None and hit[0] == vers and all(r() is w for r, w in zip(hit[1], ws)) and hit[2].device == ws[0].device:
             return hit[2]
         with torch.no_grad():
             cat = torch.cat([w.detach().float() for w in ws], 0)
@@ -353,7 +384,7 @@ class WeightCache:
         vers = tuple(w._version for w in ws)
         hit = self._c.get(key)
         pads = [(b.shape[0], max(rp, b.shape[1])) for b in Bs]
-        if hit is not None and hit[0] == vers and all(r() is t for r, t in zip(hit[1], tuple(ws) + tuple(Bs))) and hit[2].kb.device == ws[0].device:
+        if hit is not None and hit[0] == vers and all(r() is t for r, t in zip(hit[1], tuple(ws) + tuple(Bs))) and hit[2].device == ws[0].device:
             for b, pd in zip(Bs, pads):
                 self._packed_get(b, dt, False, pd)                 # refreshes every destination of a factor that changed outside the optimiser step
             return hit[2]
@@ -373,6 +404,8 @@ class WeightCache:
             self._repack([it])
             off += b.shape[0]
         out = ops.ExtW(kb, Ntot, K + rp, rp)
+        self._ext_of = {k: r for k, r in self._ext_of.items() if r() is not None}
+        self._ext_of[kb.untyped_storage().data_ptr()] = weakref.ref(out)
         self._c[key] = (vers, tuple(weakref.ref(t) for t in tuple(ws) + tuple(Bs)), out)
         return out
 
@@ -384,7 +417,7 @@ class WeightCache:
             return self._packed_get(p, dt, transpose, pads)
         key = (id(p), dt, transpose, pad_rows_to, pad_cols_to)
         hit = self._c.get(key)
-        if hit is not None and hit[0] == p._version and hit[1]() is p and hit[2].row.device == p.device and (not p.requires_grad or hit[3] == self.epoch):
+        if hit is not None and hit[0] == p._version and hit[1]() is p and hit[2].device == p.device and (not p.requires_grad or hit[3] == self.epoch):
             return hit[2]
         src = p.detach()
         if src.dim() != 2:

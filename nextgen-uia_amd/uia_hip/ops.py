@@ -66,7 +66,9 @@ HALF_HEIGHT_SHORT_K = True   # N <= 768, K <= 768 (bf16) launches whose 256-row 
 TAIL_SPLIT = True        # split off the M tail of a launch whose last round of 256x256 tiles would leave most CUs idle
 RING5 = False            # experiment knob: 256x256 launches with a long K loop or a wide N on the 5-deep ring (tile cfg 24: 160 KB of LDS, four sub-tiles in flight)
 LORA_KEXT = True         # LoraAttnHalfFn: the rank update inside the frozen GEMM's K loop (uia_gemm_desc.A2 / K2) instead of a read-modify-write launch of its own
-TAIL_SPLIT_K = True      # ... and run that tail split over K when it is a few tiles with a long K chain (two launches: slice partials, then sum + epilogue)
+TAIL_SPLIT_K = True      # ... and run that tail split over K when it is a few tiles with a long K chain (two launches: slice partials, then sum + epilogue).
+                         # Its slices meet through hardware float atomics: the rows of such a tail (<= 1/4 of the CUs busy: the ViT-L/14 + LoRA step, not the
+                         # headline) vary in the last bit from run to run; set_deterministic(True) in functional turns it off.
 _SPLITK_WS = {}
 _NCU = {}
 
@@ -104,6 +106,11 @@ def splitk_workspace(floats, device):
     if t is None or t.numel() < floats:
         t = _SPLITK_WS[key] = torch.zeros(max(floats, 1 << 20), device=device, dtype=torch.float32)     # zero once: the launches leave it zero
     return t
+
+
+def drop_splitk_workspace(device):
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+    _SPLITK_WS.pop(key, None)
 
 
 def tail_split_rows(M, N, ncu, bm=256, bn=256):
@@ -218,37 +225,89 @@ def _kb_dims(kb, name):
     return t.shape[1], t.shape[0] * g, t.stride(0) // g          # rows, columns, rows of the whole tensor (plane stride)
 
 
+class Ready:
+    """The stream that filled a cached device buffer and the event that orders every OTHER stream behind the fill (the weight
+    caches are filled by whichever stream misses first; a hit from another stream — contrastive_step(streams=S), the text tower's side
+    stream — launched GEMMs on a buffer whose cast / pack / transpose could still be in flight).  sync() is a set lookup on the filling
+    stream and on every stream that has waited once."""
+    __slots__ = ("event", "seen")
+
+    def __init__(self):
+        st = torch.cuda.current_stream()
+        self.event = torch.cuda.Event()
+        self.event.record(st)
+        self.seen = {st.cuda_stream}
+
+    def sync(self):
+        st = torch.cuda.current_stream()
+        if st.cuda_stream not in self.seen:
+            st.wait_event(self.event)
+            self.seen.add(st.cuda_stream)
+
+
 class PackedW:
     """A GEMM weight [N, K] in the compute dtype, with its K-blocked twin [K/g][N][g] (g = 64 bytes of elements) built on first
-    use by a ring-kernel launch.  Layout plumbing only (a strided copy); which one a launch takes is decided in gemm()."""
-    __slots__ = ("row", "_kb")
+    use by a ring-kernel launch.  Layout plumbing only (a strided copy); which one a launch takes is decided in gemm().
+    Construct it AFTER the kernels that fill `row` (and `kb`) were enqueued: it records the event other streams wait for."""
+    __slots__ = ("_row", "_kb", "ready", "kb_ready")
 
     def __init__(self, row, kb=None):
-        self.row, self._kb = row, kb
+        self._row, self._kb = row, kb
+        self.ready = Ready() if row.is_cuda else None
+        self.kb_ready = self.ready
+
+    def refreshed(self, ready):
+        """the buffers were rewritten in place (uia_pack_weights after an optimiser step)"""
+        self.ready = self.kb_ready = ready
+
+    @property
+    def row(self):
+        if self.ready is not None:
+            self.ready.sync()
+        return self._row
 
     @property
     def shape(self):
-        return self.row.shape
+        return self._row.shape
 
     @property
     def dtype(self):
-        return self.row.dtype
+        return self._row.dtype
+
+    @property
+    def device(self):
+        return self._row.device
 
     def kblocked(self):
         if self._kb is None:
-            N, K = self.row.shape
-            g = 64 // self.row.element_size()
-            self._kb = self.row.view(N, K // g, g).permute(1, 0, 2).contiguous()
+            row = self.row                                       # orders this stream behind the fill of `row`
+            N, K = row.shape
+            g = 64 // row.element_size()
+            self._kb = row.view(N, K // g, g).permute(1, 0, 2).contiguous()
+            self.kb_ready = Ready() if row.is_cuda else None
+        elif self.kb_ready is not None:
+            self.kb_ready.sync()
         return self._kb
 
 
 class ExtW:
     """A GEMM weight [N, K] that exists K-BLOCKED only ([K/g][N][g]) and whose last K2 columns pair with a second A operand (uia_gemm_desc.A2 / K2: the LoRA
     rank update inside the frozen GEMM).  Built by functional.WEIGHTS.get_lora_ext."""
-    __slots__ = ("kb", "N", "K", "K2")
+    __slots__ = ("_kb", "N", "K", "K2", "ready", "__weakref__")
 
     def __init__(self, kb, N, K, K2):
-        self.kb, self.N, self.K, self.K2 = kb, N, K, K2
+        self._kb, self.N, self.K, self.K2 = kb, N, K, K2
+        self.ready = Ready() if kb.is_cuda else None
+
+    @property
+    def kb(self):
+        if self.ready is not None:
+            self.ready.sync()
+        return self._kb
+
+    @property
+    def device(self):
+        return self._kb.device
 
 
 class RawDest:
@@ -355,11 +414,16 @@ def gemm(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None, res
             cut = lambda t, lo, hi: None if t is None else (t.row_range(lo, hi) if is_kb(t) else t[lo:hi])
             slices = tail_k_slices(M - m_main, N, Ka, a.element_size(), num_cus(a.device.index))
             ws = splitk_workspace(-(-(M - m_main) // 128) * -(-N // 256) * 128 * 256, a.device) if slices else None
-            for lo, hi, cfg in ((0, m_main, big_tile_cfg(N, Ka, a.element_size())),) + (((m_main, M, 13 | slices << 16 | 1 << 22), (m_main, M, 13 | slices << 16 | 2 << 22)) if slices else ((m_main, M, 13),)):
-                _gemm_one(cut(a, lo, hi), w, bias=bias, act=act, dact=dact, aux_in=cut(aux_in, lo, hi), aux_out=cut(aux_out, lo, hi), resid=cut(resid, lo, hi),
-                          resid_t=cut(resid_t, lo, hi), out_t=cut(out_t, lo, hi), out32=cut(out32, lo, hi), alpha=alpha, tile_cfg=cfg,
-                          resid_ln=None if resid_ln is None else (resid_ln[0][lo:hi],) + tuple(resid_ln[1:]), rowsum=cut(rowsum, lo, hi),
-                          lnfold=None if lnfold is None else (lnfold[0][lo:hi],) + tuple(lnfold[1:]), splitk_ws=ws if cfg >> 16 else None)
+            try:
+                for lo, hi, cfg in ((0, m_main, big_tile_cfg(N, Ka, a.element_size())),) + (((m_main, M, 13 | slices << 16 | 1 << 22), (m_main, M, 13 | slices << 16 | 2 << 22)) if slices else ((m_main, M, 13),)):
+                    _gemm_one(cut(a, lo, hi), w, bias=bias, act=act, dact=dact, aux_in=cut(aux_in, lo, hi), aux_out=cut(aux_out, lo, hi), resid=cut(resid, lo, hi),
+                              resid_t=cut(resid_t, lo, hi), out_t=cut(out_t, lo, hi), out32=cut(out32, lo, hi), alpha=alpha, tile_cfg=cfg,
+                              resid_ln=None if resid_ln is None else (resid_ln[0][lo:hi],) + tuple(resid_ln[1:]), rowsum=cut(rowsum, lo, hi),
+                              lnfold=None if lnfold is None else (lnfold[0][lo:hi],) + tuple(lnfold[1:]), splitk_ws=ws if cfg >> 16 else None)
+            except Exception:
+                if slices:      # phase 2 is what re-zeroes the shared scratch: an error between the two launches must not leave partial sums behind
+                    drop_splitk_workspace(a.device)
+                raise
             return
     _gemm_one(a, w, bias=bias, act=act, dact=dact, aux_in=aux_in, aux_out=aux_out, resid=resid, resid_mod=resid_mod, resid_row_off=resid_row_off,
               resid_t=resid_t, out_group=out_group, out_t=out_t, out32=out32, alpha=alpha, tile_cfg=tile_cfg, resid_ln=resid_ln,

@@ -58,6 +58,23 @@ def test_descriptor_struct_sizes_match_c_layout():
                    ctypes.sizeof(_lib.MonaFusedDesc), _lib.MonaFusedDesc.t_out.offset]
 
 
+def test_integration_md_ctypes_stub_is_the_real_descriptor():
+    """INTEGRATION.md quotes a ctypes mirror of uia_gemm_desc for outside users: its field list must be _lib.GemmDesc's, name for name and
+    type for type (round 3's copy was 80 bytes short: a maintainer binding with it would have handed uia_gemm a struct whose tail — ln_flag,
+    a_drop_out, splitk_ws, A2 — is whatever follows it in memory)."""
+    import re
+    from uia_hip import _lib
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    body = text[text.index("class GemmDesc(C.Structure):"):text.index("lib.uia_gemm.restype")]
+    body = "\n".join(line.split("#")[0] for line in body.splitlines())
+    quoted = re.findall(r'\("(\w+)",\s*C\.(c_\w+)\)', body)
+    quoted = [(n, getattr(ctypes, t)) for n, t in quoted]           # c_int64 and c_long are one type on LP64: compare the types, not their names
+    real = list(_lib.GemmDesc._fields_)
+    assert quoted == real, f"INTEGRATION.md GemmDesc differs from _lib.GemmDesc: {[(a, b) for a, b in zip(quoted, real) if a != b][:3]} (lengths {len(quoted)} / {len(real)})"
+    m = re.search(r"sizeof == (\d+)", text)
+    assert m and int(m.group(1)) == ctypes.sizeof(_lib.GemmDesc)
+
+
 def test_error_path_without_gpu():
     from uia_hip import _lib
     lib = _lib.lib()

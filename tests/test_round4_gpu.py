@@ -110,3 +110,22 @@ def test_attention_bwd_kblocked_tensors(cfg, L, mask):
     ops.attn_bwd(q, k, v, okb, do, lse, dkb, None, None, B, H, L, mask=mask, keylen=keylen, cfg=cfg)
     assert torch.equal(again, dqkv)
     assert torch.equal(_from_kb(dkb), dqkv)
+
+
+def test_parity_at_a_quarter_of_the_benchmark_batch_vs_oracle():
+    """configs[1] at B = 64 (12 608 image-token rows, 16 384 text positions: every launch on the kernels and tile configs the benchmark
+    batch runs, ring GEMMs, folded LayerNorms, K-blocked activations), bf16, against oracle/train_ref's arithmetic on the host cores:
+    features AND contrastive logits (the quantity BASELINE.json's north_star bounds) inside 1e-2, loss, whole gradient direction.
+    (tools/parity_at_bench_batch.py holds the B = 256 run: profiles/r04_*_parity_bench_batch.json.)  ~20 s of CPU work."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("parity_at_bench_batch", os.path.join(root, "tools", "parity_at_bench_batch.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    r = mod.run_case(64, "freq_enhanced", False, 16, max(1, min(32, os.cpu_count() or 1)))
+    assert r["image_features_rel"] < 1e-2 and r["text_features_rel"] < 1e-2, r
+    assert r["logits_rel"] < 1e-2, r
+    assert abs(r["loss"] - r["loss_ref"]) < 2e-3 * max(1.0, abs(r["loss_ref"])), r
+    assert r["grad_cosine"] > 0.99 and r["grad_rel_l2"] < 0.15, r
+    assert not r["ln_fold_guard_tripped"]

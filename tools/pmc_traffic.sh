@@ -7,7 +7,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/traffic
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 420 rocprofv3 --pmc $c --output-format csv -d $OUT -o $c -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --also-streams 0 > $OUT/$c.log 2>&1
+  timeout 420 rocprofv3 --pmc $c --output-format csv -d $OUT -o $c -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --also-streams 0 --no-overlap-text --no-secondary > $OUT/$c.log 2>&1
   tail -1 $OUT/$c.log | cut -c1-160
 done
 python3 - <<PY
@@ -15,7 +15,7 @@ import csv, glob, json, collections, re
 def short(name):
     # rocprofv3 leaves these names mangled: "_ZN12_GLOBAL__N_119gemm_tn_ring_kernelIDF16bLi256E...Li81EEEv13uia_gemm_desc"
     # -> "gemm_tn_ring_kernelIDF16bLi256E...Li81EE" (the fragment bench.py reports as roofline.kernel_in_rocprof_csv)
-    m = re.search(r"(gemm_tn_[a-z_]*kernelI(?:DF16b|f)(?:Lin?[0-9]+E)+E)", name)
+    m = re.search(r"(gemm_tn_[a-z_]*kernelI(?:DF16b|f)(?:Lin?[0-9]+E|Lb[01]E)+E)", name)
     return m.group(1) if m else None
 out = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
