@@ -495,6 +495,7 @@ template <int NW, bool VLDS>
 __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_units_kernel(const UiaAttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KVS = VLDS ? 4096 : 2048;                    // bytes per 16-key tile of the K (| V) region
+    constexpr bool KGLOBAL = false, QGLOBAL = false;           // every operand fragment comes from the head's LDS images
     const int L = p.L;
     const int LT = (L + 15) >> 4, NP = (LT + 1) >> 1;
     // LDS-address-space pointers: a read is then one running 32-bit register + an immediate (through generic pointers the compiler
@@ -590,7 +591,6 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_units_kernel(const UiaAtt
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) toff[dt] = trow * 128 + (((2 * dt + (pp >> 1)) ^ tsw) << 4) + 8 * (pp & 1);
     const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
-    const uint4 zero_u4 = uint4{0u, 0u, 0u, 0u};
 
     for (;;) {
         int unit = 0;
@@ -601,279 +601,11 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_units_kernel(const UiaAtt
         const unsigned long long st_u0 = STAMP();
 #endif
         if (unit < LT) {
-            // =============================== KEY unit: key tile kt, sweep over 32-query blocks
             const int kt = unit;
-            const int key = 16 * kt + li;
-            uint4 kf[2], vf[2];
-            kf[0] = lds_u4(KV + kt * KVS + offR0);
-            kf[1] = lds_u4(KV + kt * KVS + offR1);
-            if (VLDS) {
-                vf[0] = lds_u4(KV + kt * KVS + 2048 + offR0);
-                vf[1] = lds_u4(KV + kt * KVS + 2048 + offR1);
-            } else {
-                const int gk = key < L ? key : L - 1;
-                vf[0] = *(const uint4*)(vb + gk * rs + g * 16);
-                vf[1] = *(const uint4*)(vb + gk * rs + g * 16 + 64);
-            }
-            f32x4 dVt[4], dKt[4];
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) { dVt[dt] = zero4; dKt[dt] = zero4; }
-            const int ub_lo = 16 * kt >= klen ? NP : (causal ? kt >> 1 : 0);      // a fully padded key tile: zeros
-            const bool key_ok = key < klen;
-            // running addresses of the current block: rows (two k-halves), transposed reads (four d-tiles), statistics
-            lptr r0 = QG + ub_lo * 8192 + offR0;
-            lptr r1 = QG + ub_lo * 8192 + offR1;
-            lptr tp0 = QG + ub_lo * 8192 + toff[0];
-            lptr tp1 = QG + ub_lo * 8192 + toff[1];
-            lptr tp2 = QG + ub_lo * 8192 + toff[2];
-            lptr tp3 = QG + ub_lo * 8192 + toff[3];
-            lptr sp = ST + ub_lo * 256 + 16 * g;
-            // opaque to the optimiser: kept as "region base (scalar) + lane offset" it re-adds the base in front of every read
-            asm volatile("" : "+v"(r0), "+v"(r1), "+v"(tp0), "+v"(tp1), "+v"(tp2), "+v"(tp3), "+v"(sp));
-            // Software pipeline over the blocks, inside ONE wave (its instructions issue in order: S/dP -> exponentials -> dV/dK back to back
-            // left the matrix pipe idle during the exponentials and the vector ALU idle during the products, 37 % of the sweep in issue stalls):
-            // iteration ub runs the exponentials of block ub BETWEEN the S / dP products of block ub + 1 (one MFMA, four VALU, ...), then
-            // requests the rows of block ub + 2 and issues dV / dK of block ub.  At the top of iteration ub: s, dp = S, dP − δ of block ub;
-            // ls = lse of block ub; qf / gf = rows of block ub + 1 and dl = −δ of block ub + 1 (when it exists).
-            // A block past the end (odd LT: the second query tile of the last block) reads the bytes behind the region — finite, never used.
-            uint4 qf[2][2], gf[2][2];
-            f32x4 ls[2], dl[2], s[2], dp[2];
-            auto load_rows = [&](int ahead) {
-                qf[0][0] = lds_u4(r0 + ahead);        gf[0][0] = lds_u4(r0 + ahead + 2048);
-                qf[0][1] = lds_u4(r1 + ahead);        gf[0][1] = lds_u4(r1 + ahead + 2048);
-                qf[1][0] = lds_u4(r0 + ahead + 4096); gf[1][0] = lds_u4(r0 + ahead + 6144);
-                qf[1][1] = lds_u4(r1 + ahead + 4096); gf[1][1] = lds_u4(r1 + ahead + 6144);
-            };
-            auto load_ls = [&](int ahead) { ls[0] = lds_f4(sp + ahead); ls[1] = lds_f4(sp + ahead + 128); };
-            auto load_dl = [&](int ahead) { dl[0] = lds_f4(sp + ahead + 64); dl[1] = lds_f4(sp + ahead + 192); };
-            auto products = [&](int hq) {              // S and dP − δ of query tile hq of the block whose rows are in qf / gf
-                s[hq] = mma(qf[hq][0], kf[0], zero4);   dp[hq] = mma(gf[hq][0], vf[0], dl[hq]);
-                s[hq] = mma(qf[hq][1], kf[1], s[hq]);   dp[hq] = mma(gf[hq][1], vf[1], dp[hq]);
-            };
-            // KIND: 0 = every (query, key) of the block valid, 1 = per-element tests, 2 = the block's second query tile does not exist
-            auto key_block = [&](auto kind_c, auto next_c, int ub) {
-                constexpr int KIND = decltype(kind_c)::value;
-                constexpr bool HASNEXT = decltype(next_c)::value;
-                constexpr int HI = KIND == 2 ? 0 : 4096;
-                bf16x8 gT[4], qT[4];
-                qT[0] = tr_pair(tp0, tp0 + HI); gT[0] = tr_pair(tp0 + 2048, tp0 + 2048 + HI);
-                qT[1] = tr_pair(tp1, tp1 + HI); gT[1] = tr_pair(tp1 + 2048, tp1 + 2048 + HI);
-                qT[2] = tr_pair(tp2, tp2 + HI); gT[2] = tr_pair(tp2 + 2048, tp2 + 2048 + HI);
-                qT[3] = tr_pair(tp3, tp3 + HI); gT[3] = tr_pair(tp3 + 2048, tp3 + 2048 + HI);
-                __builtin_amdgcn_sched_barrier(0);
-                bf16x8 pf, sf;
-                auto softmax = [&](int hq) {            // P and dS of query tile hq from s / dp (in place: the tile's accumulators die here)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float pv = __builtin_amdgcn_exp2f(fmaf(s[hq][r], sc, -ls[hq][r]));
-                        float dsv = pv * dp[hq][r];
-                        if constexpr (KIND != 0) {
-                            const int qrow = 32 * ub + 16 * hq + 4 * g + r;
-                            const bool ok = qrow < L && key_ok && (!causal || key <= qrow);
-                            pv = ok ? pv : 0.f;
-                            dsv = ok ? dsv : 0.f;
-                        }
-                        pf[4 * hq + r] = (bf16_t)pv;
-                        sf[4 * hq + r] = (bf16_t)dsv;
-                    }
-                };
-                softmax(0);
-                if constexpr (HASNEXT) products(0);                    // next block, first query tile: between the second tile's exponentials
-                if constexpr (KIND == 2) {
-#pragma unroll
-                    for (int e = 4; e < 8; ++e) { pf[e] = (bf16_t)0.f; sf[e] = (bf16_t)0.f; }
-                } else {
-                    softmax(1);
-                }
-                if constexpr (HASNEXT) {
-                    products(1);
-                    __builtin_amdgcn_sched_group_barrier(0x002, KIND == 0 ? 16 : 28, 0);     // tile 0's exponentials
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   // one MFMA of the next block's first tile
-                        __builtin_amdgcn_sched_group_barrier(0x002, KIND == 0 ? 4 : 7, 0);   // a quarter of tile 1's exponentials
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (HASNEXT) {
-                    // rows of block ub + 2 (of block ub + 1 again when there is none: in bounds, never used), −δ with them; lse of block ub + 1
-                    const int more = ub + 2 < NP ? 1 : 0;
-                    load_ls(256);
-                    load_rows(8192 + 8192 * more);
-                    load_dl(256 + 256 * more);
-                }
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    dVt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gT[dt], pf, dVt[dt], 0, 0, 0);
-                    dKt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT[dt], sf, dKt[dt], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                r0 += 8192; r1 += 8192; tp0 += 8192; tp1 += 8192; tp2 += 8192; tp3 += 8192; sp += 256;
-            };
-            if (ub_lo < NP) {
-                const int last = NP - 1, nfull = LT >> 1;               // nfull = blocks with both query tiles
-                // blocks [f0, f1) need no mask: whole query rows (32ub + 32 <= L), a whole key tile, and below the causal diagonal
-                int f0 = causal ? (16 * kt + 46) >> 5 : 0, f1 = L >> 5;
-                f0 = f0 < ub_lo ? ub_lo : f0;
-                f1 = f1 > nfull ? nfull : f1;
-                if (16 * kt + 16 > klen || f0 > f1) { f0 = nfull; f1 = nfull; }
-                load_rows(0); load_ls(0); load_dl(0);
-                products(0); products(1);
-                __builtin_amdgcn_sched_barrier(0);
-                if (ub_lo + 1 < NP) { load_rows(8192); load_dl(256); }
-                int ub = ub_lo;
-#pragma unroll 1
-                for (; ub < f0 && ub < last; ++ub) key_block(cint<1>{}, ctrue{}, ub);
-#ifdef ABWD_STAMPS
-                const unsigned long long st_l0 = STAMP(); const int ub_s = ub;
-#endif
-#pragma unroll 1
-                for (; ub < f1 && ub < last; ++ub) key_block(cint<0>{}, ctrue{}, ub);
-#ifdef ABWD_STAMPS
-                st_loop += STAMP() - st_l0; st_iter += ub - ub_s;
-#endif
-#pragma unroll 1
-                for (; ub < last; ++ub) key_block(cint<1>{}, ctrue{}, ub);
-                if (LT & 1) key_block(cint<2>{}, cfalse{}, last);
-                else if (last >= f0 && last < f1) key_block(cint<0>{}, cfalse{}, last);
-                else key_block(cint<1>{}, cfalse{}, last);
-            }
-            if (key < L) {          // lane owns key 16kt + li, d = 16dt + 4g + r
-                bf16_t* krow = (bf16_t*)p.dk + (row0 + key) * p.ld_dqkv + (size_t)h * 64 + 4 * g;
-                bf16_t* vrow = (bf16_t*)p.dv + (row0 + key) * p.ld_dqkv + (size_t)h * 64 + 4 * g;
-                const size_t kbo = ((size_t)(2 * h) * (size_t)p.dqkv_kb_rows + row0 + key) * 32 + 4 * g, kbp = (size_t)p.dqkv_kb_rows * 32;
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    store4(p.dqkv_kb_rows ? (bf16_t*)p.dk + kbo + (dt >> 1) * kbp + 16 * (dt & 1) : krow + 16 * dt, dKt[dt] * p.scale);
-                    store4(p.dqkv_kb_rows ? (bf16_t*)p.dv + kbo + (dt >> 1) * kbp + 16 * (dt & 1) : vrow + 16 * dt, dVt[dt]);
-                }
-            }
+#include "attention_bwd_key_unit.inc"
         } else {
-            // =============================== QRY unit: query tile qt, sweep over 32-key blocks (same pipeline)
             const int qt = unit - LT;
-            const int qrow = 16 * qt + li;
-            uint4 qf[2], gf[2];
-            qf[0] = lds_u4(QG + qt * 4096 + offR0);        qf[1] = lds_u4(QG + qt * 4096 + offR1);
-            gf[0] = lds_u4(QG + qt * 4096 + 2048 + offR0); gf[1] = lds_u4(QG + qt * 4096 + 2048 + offR1);
-            const float lq = lds_f1(ST + qt * 128 + 4 * li);
-            const float nd = lds_f1(ST + qt * 128 + 64 + 4 * li);
-            const f32x4 nd4 = f32x4{nd, nd, nd, nd};
-            f32x4 dQt[4];
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) dQt[dt] = zero4;
-            int kend = klen;
-            if (causal && 16 * qt + 16 < kend) kend = 16 * qt + 16;
-            const int KB = (kend + 31) >> 5;                            // key blocks that hold a valid key (>= 1)
-            lptr r0 = KV + offR0;
-            lptr r1 = KV + offR1;
-            lptr tp0 = KV + toff[0];
-            lptr tp1 = KV + toff[1];
-            lptr tp2 = KV + toff[2];
-            lptr tp3 = KV + toff[3];
-            asm volatile("" : "+v"(r0), "+v"(r1), "+v"(tp0), "+v"(tp1), "+v"(tp2), "+v"(tp3));
-            const char* vp = vb + (size_t)li * rs + g * 16;            // VLDS = false: V rows of the block from global memory
-            uint4 ka[2][2], va[2][2];
-            f32x4 s[2], dp[2];
-            auto load_kv = [&](int ahead_blocks, int kbk) {
-                const int ahead = ahead_blocks * 2 * KVS;
-                ka[0][0] = lds_u4(r0 + ahead); ka[0][1] = lds_u4(r1 + ahead);
-                ka[1][0] = lds_u4(r0 + ahead + KVS); ka[1][1] = lds_u4(r1 + ahead + KVS);
-                if (VLDS) {
-                    va[0][0] = lds_u4(r0 + ahead + 2048); va[0][1] = lds_u4(r1 + ahead + 2048);
-                    va[1][0] = lds_u4(r0 + ahead + KVS + 2048); va[1][1] = lds_u4(r1 + ahead + KVS + 2048);
-                } else {
-                    const int kb0 = 32 * (kbk + ahead_blocks);
-                    if (kb0 + 32 <= L) {
-                        const char* v0 = vp + (size_t)kb0 * rs;
-                        va[0][0] = *(const uint4*)v0; va[0][1] = *(const uint4*)(v0 + 64);
-                        va[1][0] = *(const uint4*)(v0 + 16 * rs); va[1][1] = *(const uint4*)(v0 + 16 * rs + 64);
-                    } else {
-                        int k0 = kb0 + li, k1 = k0 + 16;
-                        k0 = k0 < L ? k0 : L - 1; k1 = k1 < L ? k1 : L - 1;
-                        const char* v0 = vb + (size_t)k0 * rs + g * 16;
-                        const char* v1 = vb + (size_t)k1 * rs + g * 16;
-                        va[0][0] = *(const uint4*)v0; va[0][1] = *(const uint4*)(v0 + 64);
-                        va[1][0] = *(const uint4*)v1; va[1][1] = *(const uint4*)(v1 + 64);
-                    }
-                }
-            };
-            auto products = [&](int hk) {              // S' and dP' − δ of key tile hk of the block whose rows are in ka / va
-                s[hk] = mma(ka[hk][0], qf[0], zero4);   dp[hk] = mma(va[hk][0], gf[0], nd4);
-                s[hk] = mma(ka[hk][1], qf[1], s[hk]);   dp[hk] = mma(va[hk][1], gf[1], dp[hk]);
-            };
-            auto qry_block = [&](auto kind_c, auto next_c, int kbk) {
-                constexpr int KIND = decltype(kind_c)::value;
-                constexpr bool HASNEXT = decltype(next_c)::value;
-                constexpr int HI = KIND == 2 ? 0 : KVS;
-                bf16x8 kT[4];
-                kT[0] = tr_pair(tp0, tp0 + HI); kT[1] = tr_pair(tp1, tp1 + HI);
-                kT[2] = tr_pair(tp2, tp2 + HI); kT[3] = tr_pair(tp3, tp3 + HI);
-                __builtin_amdgcn_sched_barrier(0);
-                bf16x8 sf;
-                auto softmax = [&](int hk) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float pv = __builtin_amdgcn_exp2f(fmaf(s[hk][r], sc, -lq));
-                        float dsv = pv * dp[hk][r];
-                        if constexpr (KIND != 0) {
-                            const int keyv = 32 * kbk + 16 * hk + 4 * g + r;
-                            const bool ok = keyv < klen && (!causal || keyv <= qrow);
-                            dsv = ok ? dsv : 0.f;
-                        }
-                        sf[4 * hk + r] = (bf16_t)dsv;
-                    }
-                };
-                softmax(0);
-                if constexpr (HASNEXT) products(0);
-                if constexpr (KIND == 2) {
-#pragma unroll
-                    for (int e = 4; e < 8; ++e) sf[e] = (bf16_t)0.f;
-                } else {
-                    softmax(1);
-                }
-                if constexpr (HASNEXT) {
-                    products(1);
-                    __builtin_amdgcn_sched_group_barrier(0x002, KIND == 0 ? 14 : 22, 0);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, KIND == 0 ? 4 : 6, 0);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (HASNEXT) load_kv(kbk + 2 < KB ? 2 : 1, kbk);         // block kbk + 2 (kbk + 1 again when there is none)
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) dQt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT[dt], sf, dQt[dt], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                r0 += 2 * KVS; r1 += 2 * KVS; tp0 += 2 * KVS; tp1 += 2 * KVS; tp2 += 2 * KVS; tp3 += 2 * KVS;
-            };
-            {
-                const int last = KB - 1;
-                const bool tail_last = 2 * last + 1 >= LT;              // the last swept block's second key tile does not exist
-                // key blocks [0, f1) need no mask: all 32 keys valid and at or below the tile's first query under the causal mask
-                int f1 = causal ? (16 * qt + 1) >> 5 : klen >> 5;
-                f1 = f1 > (klen >> 5) ? klen >> 5 : f1;
-                f1 = f1 > (LT >> 1) ? LT >> 1 : f1;
-                load_kv(0, 0);
-                products(0); products(1);
-                __builtin_amdgcn_sched_barrier(0);
-                if (1 < KB) load_kv(1, 0);
-                int kbk = 0;
-#pragma unroll 1
-                for (; kbk < f1 && kbk < last; ++kbk) qry_block(cint<0>{}, ctrue{}, kbk);
-#pragma unroll 1
-                for (; kbk < last; ++kbk) qry_block(cint<1>{}, ctrue{}, kbk);
-                if (tail_last) qry_block(cint<2>{}, cfalse{}, last);
-                else if (last < f1) qry_block(cint<0>{}, cfalse{}, last);
-                else qry_block(cint<1>{}, cfalse{}, last);
-            }
-            if (qrow < L) {         // lane owns query 16qt + li, d = 16dt + 4g + r
-                bf16_t* drow = (bf16_t*)p.dq + (row0 + qrow) * p.ld_dqkv + (size_t)h * 64 + 4 * g;
-                const size_t kbo = ((size_t)(2 * h) * (size_t)p.dqkv_kb_rows + row0 + qrow) * 32 + 4 * g, kbp = (size_t)p.dqkv_kb_rows * 32;
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt)
-                    store4(p.dqkv_kb_rows ? (bf16_t*)p.dq + kbo + (dt >> 1) * kbp + 16 * (dt & 1) : drow + 16 * dt, dQt[dt] * p.scale);
-            }
+#include "attention_bwd_qry_unit.inc"
         }
 #ifdef ABWD_STAMPS
         st_u[unit < LT ? 0 : 1] += STAMP() - st_u0; st_n[unit < LT ? 0 : 1] += 1;
@@ -886,6 +618,212 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_units_kernel(const UiaAtt
     }
 #endif
 }
+// ------------------------------------------------------------------------------------------
+// The persistent form of the unit kernel: one 8-wave workgroup per CU walks the (batch, head) pairs, and the staging of a head — a third of
+// the unit kernel's time, at the ≈ 11 B/clk a CU can pull from memory — runs under the sweeps of its neighbours.  A head is two phases with
+// one LDS buffer each:
+//   P1(n): KEY units of head n on the Q / dO image of buffer A; meanwhile the K / V image of head n lands in buffer B
+//          (the units' own 16-key K / V fragments come straight from global memory: 4 loads per unit);
+//   P2(n): QRY units of head n on buffer B; meanwhile the Q / dO image of head n + 1 lands in buffer A and its O rows and lse in regions
+//          of their own (the units' Q / dO fragments from global memory); then δ(n + 1) from the landed dO and O images, and P1(n + 1).
+// Three barriers per head (end of P1, end of P2, after δ), no spinning on LDS words; statistics are double-buffered.
+// (A single queue per head with "buffer B landed" / "buffer A free" words instead of the barrier between the phases was built and measured:
+//  the three waves that find no KEY unit in the second round do start QRY units early, and every unit gets 15-40 % slower beside the other
+//  kind and the DMA — 227-235 us per ViT-B layer against 265 with the barrier and 238 for the plain unit kernel, which stays the default;
+//  tools/abwu_variants.sh: no single ingredient of the sweeps is worth more than 10 % of the kernel.)
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 2) void attn_bwd_persist_kernel(const UiaAttnParams p, const int nheads) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr bool VLDS = true, KGLOBAL = true, QGLOBAL = true;
+    constexpr int KVS = 4096;
+    const int L = p.L;
+    const int LT = (L + 15) >> 4, NP = (LT + 1) >> 1;
+    char* QGg = smem;                                          // buffer A: [LT][Q tile | dO tile]
+    char* KVg = QGg + LT * 4096;                               // buffer B: [LT][K tile | V tile]
+    char* STg = KVg + LT * KVS;                                // 2 x [LT][lse·log2e | −δ]
+    char* OBg = STg + 2 * LT * 128;                            // [LT][O tile] (same swizzle), for δ of the head that is being staged
+    float* lseb = (float*)(OBg + LT * 2048);                   // [16·LT] lse of that head
+    int* ctr = (int*)(lseb + ((16 * LT + 63) & ~63));          // unit queues of the two phases (lse lands in whole 64-row pieces)
+    const lptr QG = (lptr)smem, KV = QG + LT * 4096;
+    const lptr STb = KV + LT * KVS;
+    lptr ST = STb;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef ABWD_STAMPS
+    const unsigned long long st_begin = STAMP();
+    unsigned long long st_u[2] = {0, 0}, st_n[2] = {0, 0}, st_pro = 0, st_loop = 0, st_iter = 0, st_bar = 0;
+#endif
+    const int li = lane & 15, g = lane >> 4;
+    const bool causal = p.mask_kind == UIA_MASK_CAUSAL;
+    const size_t rs = (size_t)p.ld_qkv * 2, rso = (size_t)p.lddo * 2, rsO = (size_t)p.ldo * 2;
+    const float sc = p.scale * 1.44269504088896341f;
+    const int offR0 = li * 128 + ((g ^ (li & 6)) << 4);
+    const int offR1 = offR0 ^ 64;
+    const int qq = li >> 2, pp = li & 3;
+    const int trow = 4 * g + qq;
+    const int tsw = trow & 6;
+    int toff[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) toff[dt] = trow * 128 + (((2 * dt + (pp >> 1)) ^ tsw) << 4) + 8 * (pp & 1);
+    const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // the head the units work on ...
+    int b = 0, h = 0, klen = L;
+    size_t row0 = 0;
+    const char *qb = nullptr, *kb = nullptr, *vb = nullptr, *gb = nullptr;
+    auto set_head = [&](int n) {
+        b = n / p.H; h = n - b * p.H;
+        row0 = (size_t)b * L;
+        qb = (const char*)p.q + (row0 * p.ld_qkv + (size_t)h * 64) * 2;
+        kb = (const char*)p.k + (row0 * p.ld_qkv + (size_t)h * 64) * 2;
+        vb = (const char*)p.v + (row0 * p.ld_qkv + (size_t)h * 64) * 2;
+        gb = (const char*)p.dout + (row0 * p.lddo + (size_t)h * 64) * 2;
+        klen = L;
+        if (p.mask_kind == UIA_MASK_KEYPAD && p.keylen) { klen = p.keylen[b]; klen = klen < 1 ? 1 : (klen > L ? L : klen); }
+        klen = __builtin_amdgcn_readfirstlane(klen);
+    };
+    // ... and the staging of a head n (its own address arithmetic: it runs one phase ahead of the units): Q / dO image into buffer A, the O rows
+    // and lse that δ needs into their own LDS regions (held in registers across P2 they cost the sweep 25 VGPRs and spills)
+    auto stage_qg = [&](int n) {
+        const int nb = n / p.H, nh = n - nb * p.H;
+        const size_t nrow0 = (size_t)nb * L;
+        const char* nq = (const char*)p.q + (nrow0 * p.ld_qkv + (size_t)nh * 64) * 2;
+        const char* ng = (const char*)p.dout + (nrow0 * p.lddo + (size_t)nh * 64) * 2;
+        const char* no = (const char*)p.out + (nrow0 * p.ldo + (size_t)nh * 64) * 2;
+        for (int q = wave; q < 2 * LT; q += NW) {
+            const int r = 8 * q + (lane >> 3);
+            const int gr = r < L ? r : L - 1;
+            const int c = ((lane & 7) ^ (r & 6)) * 16;
+            const int t = q >> 1, half = (q & 1) * 1024;
+            glds16(nq + gr * rs + c, QGg + t * 4096 + half);
+            glds16(ng + gr * rso + c, QGg + t * 4096 + 2048 + half);
+            glds16(p.out_kb_rows ? (const char*)p.out + (((size_t)(2 * nh + (c >> 6)) * (size_t)p.out_kb_rows + nrow0 + gr) << 6) + (c & 63) : no + gr * rsO + c,
+                   OBg + q * 1024);
+        }
+        for (int i = wave; i * 64 < 16 * LT; i += NW) {
+            int r = 64 * i + lane;
+            r = r < L ? r : L - 1;
+            glds4((const char*)(p.lse + ((size_t)nb * p.H + nh) * L + r), (char*)(lseb + 64 * i));
+        }
+    };
+    auto stage_kv = [&]() {                                   // K / V image of the CURRENT head into buffer B
+        for (int q = wave; q < 2 * LT; q += NW) {
+            const int r = 8 * q + (lane >> 3);
+            const int gr = r < L ? r : L - 1;
+            const int c = ((lane & 7) ^ (r & 6)) * 16;
+            const int t = q >> 1, half = (q & 1) * 1024;
+            glds16(kb + gr * rs + c, KVg + t * KVS + half);
+            glds16(vb + gr * rs + c, KVg + t * KVS + 2048 + half);
+        }
+    };
+    auto delta = [&](char* st_dst) {                          // δ = rowsum(dO ⊙ O) from the landed images: eight lanes per row, 16 bytes of each
+        for (int r0 = 0; r0 < 16 * LT; r0 += NW * 8) {
+            const int r = r0 + (tid >> 3), part = tid & 7;
+            if (r < 16 * LT) {
+                const int off = (r & 15) * 128 + ((part ^ (r & 6)) << 4);
+                const bf16x8 gv = *(const bf16x8*)(QGg + (r >> 4) * 4096 + 2048 + off);
+                const bf16x8 ovv = *(const bf16x8*)(OBg + (r >> 4) * 2048 + off);
+                float d = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) d = fmaf((float)gv[e], (float)ovv[e], d);
+                d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0xB1, 0xF, 0xF, false));
+                d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x4E, 0xF, 0xF, false));
+                d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x141, 0xF, 0xF, false));
+                if (part == 0) {
+                    float* st = (float*)(st_dst + (r >> 4) * 128) + (r & 15);
+                    st[0] = r < L ? lseb[r] * 1.44269504088896341f : 0.f;
+                    st[16] = r < L ? -d : 0.f;
+                }
+            }
+        }
+    };
+    auto next_unit = [&](int which) {
+        int u = 0;
+        if (lane == 0) u = atomicAdd(ctr + which, 1);
+        return __builtin_amdgcn_readfirstlane(u);
+    };
+    auto seam = [&]() {                                       // everything this wave has in flight (LDS-DMA pieces, stores) has landed; then the workgroup
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+
+    int n = blockIdx.x;
+    if (n >= nheads) return;
+    stage_qg(n);
+    if (tid == 0) { ctr[0] = 0; ctr[1] = 0; }
+    seam();
+    delta(STg);
+    __syncthreads();
+    set_head(n);
+#ifdef ABWD_STAMPS
+    st_pro = STAMP() - st_begin;
+#endif
+    int cur = 0;
+    for (;;) {
+        ST = STb + cur * (LT * 128);
+        // ---- P1: KEY units on buffer A; the head's K / V image lands in buffer B
+        stage_kv();
+        for (;;) {
+            const int kt = next_unit(0);
+            if (kt >= LT) break;
+#ifdef ABWD_STAMPS
+            const unsigned long long st_u0 = STAMP();
+#endif
+#include "attention_bwd_key_unit.inc"
+#ifdef ABWD_STAMPS
+            st_u[0] += STAMP() - st_u0; st_n[0] += 1;
+#endif
+        }
+#ifdef ABWD_STAMPS
+        const unsigned long long st_b0 = STAMP();
+#endif
+        seam();                                               // buffer B landed, buffer A free
+#ifdef ABWD_STAMPS
+        st_bar += STAMP() - st_b0;
+#endif
+        // ---- P2: QRY units on buffer B; the next head's Q / dO / O images land in buffer A and the O region
+        const int nn = n + (int)gridDim.x;
+        const bool has_next = nn < nheads;
+        if (has_next) stage_qg(nn);
+        for (;;) {
+            const int qt = next_unit(1);
+            if (qt >= LT) break;
+#ifdef ABWD_STAMPS
+            const unsigned long long st_u0 = STAMP();
+#endif
+#include "attention_bwd_qry_unit.inc"
+#ifdef ABWD_STAMPS
+            st_u[1] += STAMP() - st_u0; st_n[1] += 1;
+#endif
+        }
+        if (!has_next) break;
+#ifdef ABWD_STAMPS
+        const unsigned long long st_b1 = STAMP();
+#endif
+        seam();                                               // buffer A landed; buffer B and the statistics of head n are free
+        delta(STg + (cur ^ 1) * (LT * 128));
+        if (tid == 0) { ctr[0] = 0; ctr[1] = 0; }
+        __syncthreads();
+#ifdef ABWD_STAMPS
+        st_bar += STAMP() - st_b1;
+#endif
+        n = nn;
+        set_head(n);
+        cur ^= 1;
+    }
+#ifdef ABWD_STAMPS
+    if (blockIdx.x == 100 && lane == 0 && wave < 8) {
+        unsigned long long* o = uia_abwd_stamps + wave * 8;
+        o[0] = st_pro; o[1] = st_u[0]; o[2] = st_u[1]; o[3] = st_n[0]; o[4] = st_n[1]; o[5] = STAMP() - st_begin; o[6] = st_bar; o[7] = st_iter;
+    }
+#endif
+}
+__host__ __device__ constexpr int persist_lds_bytes(int LT) {      // the regions behind buffer B absorb the pipeline's reads one tile past its end
+    return LT * 8192 + 2 * LT * 128 + LT * 2048 + ((16 * LT + 63) / 64) * 256 + 64 + 1024;
+}
+constexpr int PERSIST_LT_MAX = 15;                                  // 240 tokens: 159.7 KB
+
 // + slack behind the statistics: the pipeline requests one block ahead without asking whether its second tile exists, so the bytes of one
 // (non-existent) K / V tile behind the K region and of a few statistics rows must lie inside the allocation (they are never used)
 __host__ __device__ constexpr int units_lds_bytes(int LT, bool vlds) {
@@ -1020,10 +958,29 @@ int launch_units(hipStream_t stream, const UiaAttnParams& p) {
     return 0;
 }
 
+int launch_persist(hipStream_t stream, const UiaAttnParams& p) {
+    const int LT = (p.L + 15) / 16;
+    auto kern = attn_bwd_persist_kernel<8>;
+    static UiaDevOnce attr_once;
+    static_assert(persist_lds_bytes(PERSIST_LT_MAX) <= 160 * 1024, "LDS budget");
+    UIA_ENSURE_LDS_ATTR(attr_once, kern, persist_lds_bytes(PERSIST_LT_MAX));
+    int dev = 0, ncu = 0;
+    UIA_CHECK_HIP(hipGetDevice(&dev));
+    UIA_CHECK_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+    const int nheads = p.B * p.H;
+    // one workgroup per CU, and every workgroup the same number of heads where that divides (3072 heads on 256 CUs: 12 each)
+    int grid = nheads < ncu ? nheads : ncu;
+    const int per = (nheads + grid - 1) / grid;
+    grid = (nheads + per - 1) / per;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * 8), persist_lds_bytes(LT), stream, p, nheads);
+    UIA_CHECK_LAUNCH();
+    return 0;
+}
+
 }  // namespace
 
 int uia_attn_bwd_launch(hipStream_t stream, int dtype, const UiaAttnParams& p, int cfg) {
-    UIA_CHECK_ARG(cfg >= 0 && cfg <= 4, "uia_attn_bwd: unknown kernel configuration %d", cfg);
+    UIA_CHECK_ARG(cfg >= 0 && cfg <= 5, "uia_attn_bwd: unknown kernel configuration %d", cfg);
     UIA_CHECK_ARG(dtype == UIA_BF16 || dtype == UIA_F32, "uia_attn_bwd: bad dtype %d", dtype);
     UIA_CHECK_ARG(p.B > 0 && p.H > 0 && p.L > 0, "uia_attn_bwd: empty problem");
     UIA_CHECK_ARG(p.scale > 0.f && p.scale < 3.0e38f, "uia_attn_bwd: scale must be positive and finite (matches the forward's lse), got %g", (double)p.scale);
@@ -1052,10 +1009,16 @@ int uia_attn_bwd_launch(hipStream_t stream, int dtype, const UiaAttnParams& p, i
     const int LT = (p.L + 15) / 16;
     // cfg 0 = the default choice; 1 = the lock-step 8-wave kernel of rounds 1-3; 2 / 3 / 4 = the barrier-free unit kernel with
     // 8 waves and V in LDS / 4 waves and V fragments from global memory (two heads per CU up to 208 tokens) / 8 waves, V from global
+    // default: the unit kernel.  Its persistent form (cfg 5) hides the staging and gives the time back in barriers and slower units
+    // (265 vs 238 us per ViT-B layer with a barrier between the phases, 227-235 with LDS words instead: DESIGN.md §4 round 4)
     if (cfg == 0) cfg = 2;
     if (cfg == 2) return launch_units<8, true>(stream, p);
     if (cfg == 3) return launch_units<4, false>(stream, p);
     if (cfg == 4) return launch_units<8, false>(stream, p);
+    if (cfg == 5) {
+        UIA_CHECK_ARG(LT <= PERSIST_LT_MAX, "uia_attn_bwd: the persistent kernel holds at most %d tokens (L = %d)", 16 * PERSIST_LT_MAX, p.L);
+        return launch_persist(stream, p);
+    }
     if (LT <= 8) return launch_bf16<8>(stream, p);
     if (LT <= 16) return launch_bf16<16>(stream, p);
     return launch_bf16<18>(stream, p);
