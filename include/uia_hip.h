@@ -174,7 +174,8 @@ int uia_attn_bwd(void* stream, int dtype, const uia_attn_desc* d);
 /* Same backward with an explicit kernel configuration (bf16, dh = 64; ignored otherwise): 0 = the library's choice (what uia_attn_bwd
  * runs), 1 = the lock-step 8-wave kernel (dS crosses LDS once per 32-query block), 2 / 3 / 4 = the barrier-free unit kernel (waves pull
  * key-tile and query-tile units from an LDS counter; no product of one wave is read by another) with 8 waves and V in LDS / 4 waves and
- * V fragments from global memory (two heads per CU up to 208 tokens) / 8 waves and V from global memory; 5 = the persistent form of
+ * V fragments from global memory (two heads per CU up to 208 tokens) / 8 waves and V from global memory (2 stages the O rows that δ needs
+ * through LDS up to 240 tokens; 6 = 2 with those operands from global memory at every length); 5 = the persistent form of
  * the unit kernel (one workgroup per CU walks the heads, the next head's operands land under the current head's sweeps; L <= 240).
  * For A/B timing and tests. */
 int uia_attn_bwd_cfg(void* stream, int dtype, const uia_attn_desc* d, int cfg);

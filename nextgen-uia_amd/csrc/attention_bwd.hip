@@ -491,7 +491,7 @@ struct ctrue { static constexpr bool value = true; };
 struct cfalse { static constexpr bool value = false; };
 template <int V> struct cint { static constexpr int value = V; };
 
-template <int NW, bool VLDS>
+template <int NW, bool VLDS, bool OLDS>
 __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_units_kernel(const UiaAttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KVS = VLDS ? 4096 : 2048;                    // bytes per 16-key tile of the K (| V) region
@@ -504,6 +504,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_units_kernel(const UiaAtt
     char* KVg = QGg + LT * 4096;                               // [LT][K tile 2 KiB (| V tile 2 KiB)]
     char* STg = KVg + LT * KVS;                                // [LT][lse·log2e of 16 rows | −δ of 16 rows]  (fp32)
     int* queue = (int*)(STg + LT * 128);
+    char* OBg = STg + LT * 128 + 64;                           // OLDS: [LT][O tile] + [16·LT] lse behind it, for δ (ahead of the slack)
+    float* lseb = (float*)(OBg + LT * 2048);
     const lptr QG = (lptr)smem, KV = QG + LT * 4096, ST = KV + LT * KVS;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -530,6 +532,62 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_units_kernel(const UiaAtt
     // ---- staging.  δ = rowsum(dO ⊙ O) and lse come straight from global memory, eight lanes per row, ALL passes requested before the first
     //      use (one pass at a time was one memory round trip per pass: 21.7 K cycles of staging against 8.4 K); then the images by LDS-DMA
     //      (1 KiB pieces of 8 rows, inverse-swizzled source).
+    if constexpr (OLDS) {
+        // δ from the LANDED dO image and an O image of its own (same swizzle) instead of a second trip of dO through the memory pipe: a CU pulls
+        // ≈ 11 B/clk, and the 26 KB of dO that δ used to re-read were a sixth of the head's staging (the persistent form does the same)
+        const int npieces = 2 * LT;
+        for (int q = wave; q < npieces; q += NW) {
+            const int r = 8 * q + (lane >> 3);
+            const int gr = r < L ? r : L - 1;
+            const int c = ((lane & 7) ^ (r & 6)) * 16;
+            const int t = q >> 1, half = (q & 1) * 1024;
+            glds16(gb + gr * rso + c, QGg + t * 4096 + 2048 + half);
+            glds16(p.out_kb_rows ? (const char*)p.out + (((size_t)(2 * h + (c >> 6)) * (size_t)p.out_kb_rows + row0 + gr) << 6) + (c & 63) : ob + gr * rsO + c,
+                   OBg + q * 1024);
+        }
+        for (int i = wave; i * 64 < 16 * LT; i += NW) {
+            int r = 64 * i + lane;
+            r = r < L ? r : L - 1;
+            glds4((const char*)(p.lse + ((size_t)b * p.H + h) * L + r), (char*)(lseb + 64 * i));
+        }
+        for (int q = wave; q < npieces; q += NW) {
+            const int r = 8 * q + (lane >> 3);
+            const int gr = r < L ? r : L - 1;
+            const int c = ((lane & 7) ^ (r & 6)) * 16;
+            const int t = q >> 1, half = (q & 1) * 1024;
+            glds16(kb + gr * rs + c, KVg + t * KVS + half);
+            glds16(qb + gr * rs + c, QGg + t * 4096 + half);
+            if (VLDS) glds16(vb + gr * rs + c, KVg + t * KVS + 2048 + half);
+        }
+        if (tid == 0) *queue = 0;
+        // dO, O, lse were requested first: wait for them only (this wave issued nk more pieces behind them), compute δ while K, Q, V land
+        const int nk = ((npieces - wave + NW - 1) / NW) * (VLDS ? 3 : 2);
+        if (nk >= 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        else if (nk >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int r0 = 0; r0 < 16 * LT; r0 += NW * 8) {
+            const int r = r0 + (tid >> 3), part = tid & 7;
+            if (r < 16 * LT) {
+                const int off = (r & 15) * 128 + ((part ^ (r & 6)) << 4);
+                const bf16x8 gv = *(const bf16x8*)(QGg + (r >> 4) * 4096 + 2048 + off);
+                const bf16x8 ovv = *(const bf16x8*)(OBg + (r >> 4) * 2048 + off);
+                float d = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) d = fmaf((float)gv[e], (float)ovv[e], d);
+                d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0xB1, 0xF, 0xF, false));
+                d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x4E, 0xF, 0xF, false));
+                d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x141, 0xF, 0xF, false));
+                if (part == 0) {
+                    float* st = (float*)(STg + (r >> 4) * 128) + (r & 15);
+                    st[0] = r < L ? lseb[r] * 1.44269504088896341f : 0.f;
+                    st[16] = r < L ? -d : 0.f;
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    } else
     {
         constexpr int RPP = NW * 8, MAXP = (288 + RPP - 1) / RPP;
         bf16x8 gv[MAXP], ov[MAXP];
@@ -826,10 +884,11 @@ constexpr int PERSIST_LT_MAX = 15;                                  // 240 token
 
 // + slack behind the statistics: the pipeline requests one block ahead without asking whether its second tile exists, so the bytes of one
 // (non-existent) K / V tile behind the K region and of a few statistics rows must lie inside the allocation (they are never used)
-__host__ __device__ constexpr int units_lds_bytes(int LT, bool vlds) {
+__host__ __device__ constexpr int units_lds_bytes(int LT, bool vlds, bool olds = false) {
     const int kvs = vlds ? 4096 : 2048, need = kvs + 64 - LT * 128;
-    return LT * 4096 + LT * kvs + LT * 128 + 16 + (need > 1024 ? need : 1024);
+    return LT * 4096 + LT * kvs + LT * 128 + 64 + (olds ? LT * 2048 + ((16 * LT + 63) / 64) * 256 + 1024 : (need > 1024 ? need : 1024));
 }
+constexpr int OLDS_LT_MAX = 15;                     // O image in LDS up to 240 tokens (13 tiles: 138 KB)
 
 
 // ------------------------------------------------------------------------------------------
@@ -946,14 +1005,15 @@ int launch_bf16(hipStream_t stream, const UiaAttnParams& p) {
     return 0;
 }
 
-template <int NW, bool VLDS>
+template <int NW, bool VLDS, bool OLDS>
 int launch_units(hipStream_t stream, const UiaAttnParams& p) {
     const int LT = (p.L + 15) / 16;
-    auto kern = attn_bwd_units_kernel<NW, VLDS>;
+    auto kern = attn_bwd_units_kernel<NW, VLDS, OLDS>;
     static UiaDevOnce attr_once;
-    static_assert(units_lds_bytes(18, true) <= 160 * 1024, "LDS budget");
-    UIA_ENSURE_LDS_ATTR(attr_once, kern, units_lds_bytes(18, VLDS));
-    hipLaunchKernelGGL(kern, dim3(p.B * p.H), dim3(64 * NW), units_lds_bytes(LT, VLDS), stream, p);
+    constexpr int LTM = OLDS ? OLDS_LT_MAX : 18;
+    static_assert(units_lds_bytes(LTM, true, OLDS) <= 160 * 1024, "LDS budget");
+    UIA_ENSURE_LDS_ATTR(attr_once, kern, units_lds_bytes(LTM, VLDS, OLDS));
+    hipLaunchKernelGGL(kern, dim3(p.B * p.H), dim3(64 * NW), units_lds_bytes(LT, VLDS, OLDS), stream, p);
     UIA_CHECK_LAUNCH();
     return 0;
 }
@@ -980,7 +1040,7 @@ int launch_persist(hipStream_t stream, const UiaAttnParams& p) {
 }  // namespace
 
 int uia_attn_bwd_launch(hipStream_t stream, int dtype, const UiaAttnParams& p, int cfg) {
-    UIA_CHECK_ARG(cfg >= 0 && cfg <= 5, "uia_attn_bwd: unknown kernel configuration %d", cfg);
+    UIA_CHECK_ARG(cfg >= 0 && cfg <= 6, "uia_attn_bwd: unknown kernel configuration %d", cfg);
     UIA_CHECK_ARG(dtype == UIA_BF16 || dtype == UIA_F32, "uia_attn_bwd: bad dtype %d", dtype);
     UIA_CHECK_ARG(p.B > 0 && p.H > 0 && p.L > 0, "uia_attn_bwd: empty problem");
     UIA_CHECK_ARG(p.scale > 0.f && p.scale < 3.0e38f, "uia_attn_bwd: scale must be positive and finite (matches the forward's lse), got %g", (double)p.scale);
@@ -1012,9 +1072,10 @@ int uia_attn_bwd_launch(hipStream_t stream, int dtype, const UiaAttnParams& p, i
     // default: the unit kernel.  Its persistent form (cfg 5) hides the staging and gives the time back in barriers and slower units
     // (265 vs 238 us per ViT-B layer with a barrier between the phases, 227-235 with LDS words instead: DESIGN.md §4 round 4)
     if (cfg == 0) cfg = 2;
-    if (cfg == 2) return launch_units<8, true>(stream, p);
-    if (cfg == 3) return launch_units<4, false>(stream, p);
-    if (cfg == 4) return launch_units<8, false>(stream, p);
+    if (cfg == 2) return LT <= OLDS_LT_MAX ? launch_units<8, true, true>(stream, p) : launch_units<8, true, false>(stream, p);
+    if (cfg == 6) return launch_units<8, true, false>(stream, p);       // cfg 2 with δ's operands from global memory at every length
+    if (cfg == 3) return launch_units<4, false, false>(stream, p);
+    if (cfg == 4) return launch_units<8, false, false>(stream, p);
     if (cfg == 5) {
         UIA_CHECK_ARG(LT <= PERSIST_LT_MAX, "uia_attn_bwd: the persistent kernel holds at most %d tokens (L = %d)", 16 * PERSIST_LT_MAX, p.L);
         return launch_persist(stream, p);

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
-CFGS = [1, 2, 3, 4, 5]
+CFGS = [1, 2, 3, 4, 5, 6]
 
 
 def dev():
