@@ -130,6 +130,23 @@ typedef struct uia_gemm_desc {
     int32_t K2;
     int32_t a2_group_cols;
     int64_t a2_group_stride;
+    /* THREE-BYTE fp32 tensors for the HBM-bound epilogues of a frozen post-LN tower (bf16 launches): a value x is kept as hi = bf16(x) (round to
+     * nearest: the T copy the next GEMM reads as its A operand anyway) plus lo = the next 8 mantissa bits as a signed byte,
+     *     float_bits(x) ≈ (hi_bits << 16) + (lo << 8)      (15 stored mantissa bits: 2^-16 relative),
+     * so a sub-layer sum costs 3 + 3 bytes per element in the epilogue that reads one and writes the next, instead of 4 + (4 + 2).
+     *   resid_lo8 != NULL: the residual is (residT, resid_lo8) in that form — residT row-major (ldrT) or, residT_kb_rows > 0, K-blocked like
+     *                      outT; `resid` must be NULL; resid_ln_* (stats / weight / bias / dim) then apply to the reconstructed rows.
+     *   out_lo8   != NULL: the result's low bytes go there (row-major, ld_out_lo), its hi plane is outT (required); out32 may be NULL.
+     *   resid_lo_kb_rows / out_lo_kb_rows > 0: that plane of low bytes is column-blocked like the K-blocked hi plane, 64 columns (64 bytes) per
+     *                      block with that many rows: byte (m, n) at ((n / 64)·rows + m)·64 + n % 64 — a 16-row pass of the epilogue then
+     *                      moves whole 128-byte lines instead of 64-byte pieces 768 bytes apart (N % 64 == 0). */
+    const int8_t* resid_lo8;
+    int64_t ld_resid_lo;
+    int64_t residT_kb_rows;
+    int8_t* out_lo8;
+    int64_t ld_out_lo;
+    int64_t resid_lo_kb_rows;
+    int64_t out_lo_kb_rows;
 } uia_gemm_desc;
 int uia_gemm(void* stream, int dtype, const uia_gemm_desc* d, int tile_cfg /* 0 = auto */);
 

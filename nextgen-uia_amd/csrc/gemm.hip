@@ -304,6 +304,8 @@ enum : int { EPI_BIAS = 1, EPI_AUX_OUT = 2, EPI_GELU = 4, EPI_DGELU = 8, EPI_RES
              EPI_ROWSUM = 512,            // rowsum_out: (Σ, Σ²) of the stored fp32 rows, for the LayerNorm folded into the consuming GEMM
              EPI_LNFOLD = 1024,           // lnfold_*: A held raw rows, the LayerNorm is applied to the accumulators
              EPI_QUICK = 2048,            // with EPI_GELU / EPI_DGELU: the activation is QuickGELU (OpenAI CLIP towers: ViT-L/14 + LoRA, CLIPSeg), not GELU
+             EPI_RESID_LO = 4096,         // the residual is a three-byte tensor: hi plane residT (bf16) + low bytes resid_lo8 (uia_gemm_desc.resid_lo8); resid_ln_* apply to it
+             EPI_OUT_LO = 8192,           // the result is written as a three-byte tensor: hi plane outT + low bytes out_lo8
              EPI_GENERIC = -1 };
 
 template <typename T, int MT, int NT, int WTM, int WTN, int EPI = EPI_GENERIC, bool PATCH16 = false>
@@ -313,8 +315,10 @@ __device__ __forceinline__ void gemm_epilogue_lds(const UiaGemmParams& p, f32x4 
     const bool f_bias = GEN ? p.bias != nullptr : (EPI & EPI_BIAS) != 0;
     const bool f_aux_out = GEN ? p.aux_out != nullptr : (EPI & EPI_AUX_OUT) != 0;
     const bool f_resid = GEN ? p.resid != nullptr : (EPI & EPI_RESID) != 0;
-    const bool f_residT = GEN ? p.residT != nullptr : (EPI & EPI_RESIDT) != 0;
-    const bool f_rln = GEN ? (p.resid != nullptr && p.resid_ln_stats != nullptr) : (EPI & EPI_RESID_LN) != 0;
+    const bool f_rlo = GEN ? p.resid_lo8 != nullptr : (EPI & EPI_RESID_LO) != 0;          // three-byte residual: residT is its hi plane, not a second residual
+    const bool f_olo = GEN ? p.out_lo8 != nullptr : (EPI & EPI_OUT_LO) != 0;
+    const bool f_residT = GEN ? (p.residT != nullptr && p.resid_lo8 == nullptr) : ((EPI & EPI_RESIDT) != 0 && (EPI & EPI_RESID_LO) == 0);
+    const bool f_rln = GEN ? ((p.resid != nullptr || p.resid_lo8 != nullptr) && p.resid_ln_stats != nullptr) : (EPI & EPI_RESID_LN) != 0;
     const bool f_out32 = GEN ? p.out32 != nullptr : (EPI & EPI_OUT32) != 0;
     const bool f_outT = GEN ? p.outT != nullptr : (EPI & EPI_OUTT) != 0;
     const bool f_rowsum = GEN ? p.rowsum_out != nullptr : (EPI & EPI_ROWSUM) != 0;
@@ -384,7 +388,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const UiaGemmParams& p, f32x4 
     // instead of straight into their atomics (the caller issues those after the tile's last store: an atomic stays in the in-order
     // vmcnt queue for thousands of cycles under load, and every later load of the wave would wait behind it).
     auto apply = [&](const f32x4& lo, const f32x4& hi, int m, const bf16x8* pre_aux = nullptr, const f32x4* pre_res = nullptr,
-                     const bf16x8* pre_rt = nullptr, float* os1 = nullptr, float* os2 = nullptr) {
+                     const bf16x8* pre_rt = nullptr, float* os1 = nullptr, float* os2 = nullptr, const uint2* pre_lo = nullptr) {
         const bool ok = m < p.M && col_ok;
         if (!f_rowsum && !ok) return;
         float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -428,9 +432,27 @@ __device__ __forceinline__ void gemm_epilogue_lds(const UiaGemmParams& p, f32x4 
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = (keep >> e) & 1u ? v[e] * inv_keep : 0.f;
         }
-        if (f_resid && UIA_EPI_LOADS) {
+        if ((f_resid || f_rlo) && UIA_EPI_LOADS) {
             float r[8];
-            if (pre_res) {
+            if (f_rlo) {
+                // three-byte residual: float bits = (hi_bits << 16) + (lo << 8), lo a signed byte (sign-magnitude floats are monotone as integers,
+                // so the integer sum is the value 'lo' steps of 2^-8 ulp(bf16) away from hi, across an exponent boundary too)
+                typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+                u16x8 hv;
+                uint2 lv;
+                if (pre_rt) { hv = __builtin_bit_cast(u16x8, *pre_rt); lv = *pre_lo; }
+                else {
+                    constexpr int G = 64 / (int)sizeof(T);
+                    const T* hp = p.residT_kb_rows ? residT + ((size_t)(n / G) * (size_t)p.residT_kb_rows + rrow) * G + (n % G) : residT + rrow * p.ldrT + n;
+                    hv = *(const u16x8*)hp;
+                    lv = *(const uint2*)(p.resid_lo_kb_rows ? p.resid_lo8 + (((size_t)(n >> 6) * (size_t)p.resid_lo_kb_rows + rrow) << 6) + (n & 63) : p.resid_lo8 + rrow * p.ld_resid_lo + n);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int lb = __builtin_amdgcn_sbfe((int)(e < 4 ? lv.x : lv.y), 8 * (e & 3), 8);
+                    r[e] = __builtin_bit_cast(float, ((unsigned)hv[e] << 16) + ((unsigned)lb << 8));
+                }
+            } else if (pre_res) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { r[e] = pre_res[0][e]; r[4 + e] = pre_res[1][e]; }
             } else {
@@ -459,6 +481,21 @@ __device__ __forceinline__ void gemm_epilogue_lds(const UiaGemmParams& p, f32x4 
             for (int e = 0; e < 8; ++e) v[e] += r[e];
         }
         if (f_out32 && UIA_EPI_STORES) store8(p.out32 + orow * p.ldo32 + n, v);
+        if (f_olo && UIA_EPI_STORES) {                    // low bytes of the three-byte result: ((bits + 0x80) >> 8) - (bf16 bits << 8), clamped to a signed byte
+            unsigned w[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const unsigned vb = __builtin_bit_cast(unsigned, v[e]);
+                const unsigned hb = (unsigned)__builtin_bit_cast(unsigned short, (bf16_t)v[e]);
+                int d = (int)((vb + 0x80u) >> 8) - (int)(hb << 8);
+                d = d < -127 ? -127 : (d > 127 ? 127 : d);
+                w[e] = (unsigned)d & 0xFFu;
+            }
+            uint2 pk;
+            pk.x = w[0] | (w[1] << 8) | (w[2] << 16) | (w[3] << 24);
+            pk.y = w[4] | (w[5] << 8) | (w[6] << 16) | (w[7] << 24);
+            *(uint2*)(p.out_lo_kb_rows ? p.out_lo8 + (((size_t)(n >> 6) * (size_t)p.out_lo_kb_rows + orow) << 6) + (n & 63) : p.out_lo8 + orow * p.ld_out_lo + n) = pk;
+        }
         if (f_outT && UIA_EPI_STORES) {
             if (p.outT_kb_rows) {                         // K-blocked for the GEMM that reads it as A: 64-byte column blocks, rows contiguous inside a block
                 constexpr int G = 64 / (int)sizeof(T);
@@ -515,7 +552,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const UiaGemmParams& p, f32x4 
 #ifdef UIA_NO_PREAUX
         constexpr bool PIPE = false;                       // A/B build (tests/test_gemm_stamps_nopre)
 #else
-        constexpr bool PIPE = !GEN && sizeof(T) == 2 && (EPI & (EPI_DGELU | EPI_RESID | EPI_RESIDT | EPI_ROWSUM)) != 0;
+        constexpr bool PIPE = !GEN && sizeof(T) == 2 && (EPI & (EPI_DGELU | EPI_RESID | EPI_RESIDT | EPI_ROWSUM | EPI_RESID_LO)) != 0;
 #endif
         constexpr int NPASS = ROWS / RPP, NPH = MT / GPP;
         // PACKED bounce (bf16, compile-time masks whose only outputs are T tensors and that read nothing: data gradients, QKV, fc1): the lane
@@ -617,11 +654,13 @@ __device__ __forceinline__ void gemm_epilogue_lds(const UiaGemmParams& p, f32x4 
             }
         } else
         if constexpr (PIPE && NPASS % 2 == 0) {
-            constexpr bool H_AUX = (EPI & EPI_DGELU) != 0, H_RES = (EPI & EPI_RESID) != 0, H_RT = (EPI & EPI_RESIDT) != 0, H_SUM = (EPI & EPI_ROWSUM) != 0;
+            constexpr bool H_AUX = (EPI & EPI_DGELU) != 0, H_RES = (EPI & EPI_RESID) != 0, H_LO = (EPI & EPI_RESID_LO) != 0, H_RT = (EPI & EPI_RESIDT) != 0 || H_LO,
+                           H_SUM = (EPI & EPI_ROWSUM) != 0;
             constexpr int CH = NPASS / 2, NCH = 2 * NPH;                 // passes per chunk, chunks per tile
             bf16x8 pa[2][H_AUX ? CH : 1];
             f32x4 pr[2][H_RES ? 2 * CH : 1];
             bf16x8 prt[2][H_RT ? CH : 1];
+            uint2 plo[2][H_LO ? CH : 1];
             float rs1[H_SUM ? NCH * CH : 1], rs2[H_SUM ? NCH * CH : 1];
             const int mrow = m0 + wm * WTM + rr;
             const int nc = col_ok ? n : 0;
@@ -633,7 +672,12 @@ __device__ __forceinline__ void gemm_epilogue_lds(const UiaGemmParams& p, f32x4 
                     const size_t mc = (size_t)(m < p.M ? m : p.M - 1);
                     if constexpr (H_AUX) pa[set][q] = *(const bf16x8*)((const bf16_t*)p.aux_in + mc * p.ldaux_in + nc);
                     if constexpr (H_RES) { const float* src = p.resid + mc * p.ldr + nc; pr[set][2 * q] = *(const f32x4*)src; pr[set][2 * q + 1] = *(const f32x4*)(src + 4); }
-                    if constexpr (H_RT) prt[set][q] = *(const bf16x8*)((const bf16_t*)p.residT + mc * p.ldrT + nc);
+                    if constexpr (H_LO) {
+                        const bf16_t* hp = p.residT_kb_rows ? (const bf16_t*)p.residT + ((size_t)(nc / 32) * (size_t)p.residT_kb_rows + mc) * 32 + (nc % 32)
+                                                            : (const bf16_t*)p.residT + mc * p.ldrT + nc;
+                        prt[set][q] = *(const bf16x8*)hp;
+                        plo[set][q] = *(const uint2*)(p.resid_lo_kb_rows ? p.resid_lo8 + (((size_t)(nc >> 6) * (size_t)p.resid_lo_kb_rows + mc) << 6) + (nc & 63) : p.resid_lo8 + mc * p.ld_resid_lo + nc);
+                    } else if constexpr (H_RT) prt[set][q] = *(const bf16x8*)((const bf16_t*)p.residT + mc * p.ldrT + nc);
                 }
             };
             issue(0, 0);
@@ -654,7 +698,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const UiaGemmParams& p, f32x4 
                     const int row = ((c & 1) * CH + q) * RPP + rr;
                     const f32x4 lo = *(const f32x4*)(stg + row * LDW + rc), hi = *(const f32x4*)(stg + row * LDW + rc + 4);
                     apply(lo, hi, mrow + (c * CH + q) * RPP, H_AUX ? &pa[set][q] : nullptr, H_RES ? &pr[set][2 * q] : nullptr, H_RT ? &prt[set][q] : nullptr,
-                          H_SUM ? &rs1[c * CH + q] : nullptr, H_SUM ? &rs2[c * CH + q] : nullptr);
+                          H_SUM ? &rs1[c * CH + q] : nullptr, H_SUM ? &rs2[c * CH + q] : nullptr, H_LO ? &plo[set][q] : nullptr);
                 }
                 if (c + 2 < NCH) issue(c + 2, set);
                 if ((c & 1) == 1) __builtin_amdgcn_wave_barrier();
@@ -1602,7 +1646,8 @@ inline int epi_mask_of(const UiaGemmParams& p) {
         (p.act && p.dact && p.act != p.dact)) return EPI_GENERIC;
     return (quick ? EPI_QUICK : 0) | (p.bias ? EPI_BIAS : 0) | (p.aux_out ? EPI_AUX_OUT : 0) | (p.act ? EPI_GELU : 0) | (p.dact ? EPI_DGELU : 0) | (p.resid ? EPI_RESID : 0) |
            ((p.resid && p.resid_ln_stats) ? EPI_RESID_LN : 0) | (p.rowsum_out ? EPI_ROWSUM : 0) | (p.lnfold_sums ? EPI_LNFOLD : 0) |
-           (p.residT ? EPI_RESIDT : 0) | (p.out32 ? EPI_OUT32 : 0) | (p.outT ? EPI_OUTT : 0);
+           ((p.residT && !p.resid_lo8) ? EPI_RESIDT : 0) | (p.out32 ? EPI_OUT32 : 0) | (p.outT ? EPI_OUTT : 0) |
+           (p.resid_lo8 ? EPI_RESID_LO : 0) | ((p.resid_lo8 && p.resid_ln_stats) ? EPI_RESID_LN : 0) | (p.out_lo8 ? EPI_OUT_LO : 0);
 }
 
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int NBUF, int LOOP = 0>
@@ -1638,6 +1683,7 @@ int launch_ring(hipStream_t stream, const UiaGemmParams& p, bool specialise, int
             // LayerNorm folded into its neighbours (bf16 step): producers write fp32 + T rows and their row sums, consumers normalise the accumulators
             UIA_EPI_CASE(EPI_BIAS | EPI_RESID | EPI_OUT32 | EPI_OUTT | EPI_ROWSUM);                  // proj / fc2 / Mona project2
             UIA_EPI_CASE(EPI_BIAS | EPI_RESID | EPI_RESID_LN | EPI_OUT32 | EPI_OUTT | EPI_ROWSUM);   // BERT sub-layer sums
+            UIA_EPI_CASE(EPI_BIAS | EPI_RESID_LO | EPI_RESID_LN | EPI_OUTT | EPI_OUT_LO | EPI_ROWSUM);   // the same on three-byte tensors (round 4): 6 epilogue bytes per element instead of 10
             UIA_EPI_CASE(EPI_BIAS | EPI_OUTT | EPI_LNFOLD);                                          // QKV
             UIA_EPI_CASE(EPI_BIAS | EPI_GELU | EPI_OUTT | EPI_LNFOLD);                               // fc1, frozen tower
             UIA_EPI_CASE(EPI_BIAS | EPI_GELU | EPI_AUX_OUT | EPI_OUTT | EPI_LNFOLD);                 // fc1 with the pre-activation stashed
@@ -1963,7 +2009,7 @@ int launch_typed(hipStream_t stream, const UiaGemmParams& p, int cfg_in) {
         else if (p.M <= 2048) cfg = (sizeof(T) == 4 && ((p.M + 127) / 128) * ((p.N + 127) / 128) < 64) ? 21 : 3;
             // fp32 MFMA issues 256 FLOP per clock per CU: the 8-12 workgroups of a [256, 512-768] head projection on 128 x 128 tiles were bound
             // by their own CUs' matrix pipes (69 us at K = 768); 32 x 64 tiles spread the same MFMA sequence per element over 64-96 CUs
-        else if (wide64_ok(p, (int)sizeof(T)) && (p.residT || p.resid || p.drop_where == 2)) cfg = 23;   // K = 64 read-modify-write stream (LoRA rank update)
+        else if (wide64_ok(p, (int)sizeof(T)) && (p.residT || p.resid || p.drop_where == 2) && !p.resid_lo8 && !p.out_lo8) cfg = 23;   // K = 64 read-modify-write stream (LoRA rank update)
         else if (p.K * (int)sizeof(T) <= 128) cfg = 14;   // one K step (Mona project2 / project1-dgrad, K = 64): nothing but prologue + epilogue, HBM-bound:
                                                           // half-height tiles, two workgroups per CU (70.9 vs 86.6 us and 20.0 vs 26.3 us at M = 50 432)
         else cfg = 8;            // 256x256 ping-pong, 4-deep 64-byte ring, LDS-staged epilogue: best measured on every large shape.
@@ -1982,6 +2028,10 @@ int launch_typed(hipStream_t stream, const UiaGemmParams& p, int cfg_in) {
     const bool ring = cfg == 8 || cfg == 9 || cfg == 10 || cfg == 12 || cfg == 13 || cfg == 14 || cfg == 15 || (cfg >= 17 && cfg <= 20) || cfg == 24;
     if ((p.a_kb_rows || p.outT_kb_rows) && !(cfg == 8 || cfg == 10 || cfg == 12 || cfg == 13 || cfg == 14 || cfg == 15 || (cfg >= 17 && cfg <= 20) || cfg == 24)) {
         uia_set_error("uia_gemm: K-blocked activations (a_kb_rows / outT_kb_rows) need a ring tile config with 64-byte sub-tiles (8, 10, 13, 14), not %d", cfg);
+        return -1;
+    }
+    if ((p.resid_lo8 || p.out_lo8) && !(cfg == 8 || cfg == 10 || cfg == 13 || cfg == 14 || cfg == 24)) {
+        uia_set_error("uia_gemm: three-byte tensors (resid_lo8 / out_lo8) are read and written by the LDS-patch epilogue of the ring tile configs (8, 10, 13, 14, 24), not %d", cfg);
         return -1;
     }
     if (p.w_kblocked && !ring) {
@@ -2055,13 +2105,20 @@ int uia_gemm_launch(hipStream_t stream, int dtype, const UiaGemmParams& p, int c
     UIA_CHECK_ARG(!p.outT || ((p.outT_kb_rows || p.ldo % 8 == 0) && (uintptr_t)p.outT % 16 == 0), "uia_gemm: outT alignment");
     UIA_CHECK_ARG(!p.out32 || (p.ldo32 % 4 == 0 && (uintptr_t)p.out32 % 16 == 0), "uia_gemm: out32 alignment");
     UIA_CHECK_ARG(!p.resid || (p.ldr % 4 == 0 && (uintptr_t)p.resid % 16 == 0), "uia_gemm: resid alignment");
-    UIA_CHECK_ARG(!p.residT || (p.ldrT % 8 == 0 && (uintptr_t)p.residT % 16 == 0), "uia_gemm: residT alignment");
+    UIA_CHECK_ARG(!p.residT || ((p.residT_kb_rows || p.ldrT % 8 == 0) && (uintptr_t)p.residT % 16 == 0), "uia_gemm: residT alignment");
+    // three-byte tensors: bf16 launches on the LDS-patch epilogues (ring tile configs); the hi planes are residT / outT
+    UIA_CHECK_ARG(!p.resid_lo8 || (dtype == UIA_BF16 && p.residT && !p.resid && (p.resid_lo_kb_rows ? (p.resid_lo_kb_rows >= p.M && p.N % 64 == 0) : (p.ld_resid_lo >= p.N && p.ld_resid_lo % 8 == 0)) && (uintptr_t)p.resid_lo8 % 8 == 0 &&
+                                  p.resid_mod == 0 && p.out_group == 0),
+                  "uia_gemm: resid_lo8 needs bf16, residT as the hi plane, no fp32 resid, 8-byte aligned rows of at least N bytes and no row remapping");
+    UIA_CHECK_ARG(p.residT_kb_rows == 0 || (p.resid_lo8 && p.residT_kb_rows >= p.M && (p.N * esz) % 64 == 0), "uia_gemm: residT_kb_rows needs resid_lo8, at least M rows and N*2 a multiple of 64");
+    UIA_CHECK_ARG(!p.out_lo8 || (dtype == UIA_BF16 && p.outT && (p.out_lo_kb_rows ? (p.out_lo_kb_rows >= p.M && p.N % 64 == 0) : (p.ld_out_lo >= p.N && p.ld_out_lo % 8 == 0)) && (uintptr_t)p.out_lo8 % 8 == 0 && p.out_group == 0),
+                  "uia_gemm: out_lo8 needs bf16, outT as the hi plane, 8-byte aligned rows of at least N bytes and no row remapping");
     UIA_CHECK_ARG(!p.bias || (uintptr_t)p.bias % 16 == 0, "uia_gemm: bias alignment");
     UIA_CHECK_ARG(!p.dact || p.aux_in, "uia_gemm: dact needs aux_in");
     UIA_CHECK_ARG(!p.aux_in || (p.ldaux_in % 8 == 0 && (uintptr_t)p.aux_in % 16 == 0), "uia_gemm: aux_in alignment");
     UIA_CHECK_ARG(!p.aux_out || (p.ldaux_out % 8 == 0 && (uintptr_t)p.aux_out % 16 == 0), "uia_gemm: aux_out alignment");
     UIA_CHECK_ARG(p.resid_mod == 0 || p.resid, "uia_gemm: resid_mod without resid");
-    UIA_CHECK_ARG(!p.resid_ln_stats || (p.resid && p.resid_ln_w && p.resid_ln_b), "uia_gemm: resid_ln_stats needs resid, resid_ln_w and resid_ln_b");
+    UIA_CHECK_ARG(!p.resid_ln_stats || ((p.resid || p.resid_lo8) && p.resid_ln_w && p.resid_ln_b), "uia_gemm: resid_ln_stats needs resid (or residT + resid_lo8), resid_ln_w and resid_ln_b");
     UIA_CHECK_ARG(!p.resid_ln_stats || ((uintptr_t)p.resid_ln_stats % 8 == 0 && (uintptr_t)p.resid_ln_w % 16 == 0 && (uintptr_t)p.resid_ln_b % 16 == 0),
                   "uia_gemm: resid_ln alignment");
     UIA_CHECK_ARG(p.a_kb_rows == 0 || p.a_kb_rows >= p.M, "uia_gemm: a_kb_rows=%lld < M=%d", (long long)p.a_kb_rows, p.M);
@@ -2089,7 +2146,7 @@ int uia_gemm_launch(hipStream_t stream, int dtype, const UiaGemmParams& p, int c
     UIA_CHECK_ARG(!p.aux_out || p.ldaux_out >= p.N, "uia_gemm: ldaux_out=%lld < N=%d", (long long)p.ldaux_out, p.N);
     UIA_CHECK_ARG(!p.aux_in || p.ldaux_in >= p.N, "uia_gemm: ldaux_in=%lld < N=%d", (long long)p.ldaux_in, p.N);
     UIA_CHECK_ARG(!p.resid || p.ldr >= p.N, "uia_gemm: ldr=%lld < N=%d", (long long)p.ldr, p.N);
-    UIA_CHECK_ARG(!p.residT || p.ldrT >= p.N, "uia_gemm: ldrT=%lld < N=%d", (long long)p.ldrT, p.N);
+    UIA_CHECK_ARG(!p.residT || p.residT_kb_rows || p.ldrT >= p.N, "uia_gemm: ldrT=%lld < N=%d", (long long)p.ldrT, p.N);
     if (dtype == UIA_BF16) return launch_typed<bf16_t>(stream, p, cfg);
     return launch_typed<float>(stream, p, cfg);
 }

@@ -36,7 +36,9 @@ class GemmDesc(C.Structure):
                 ("rowsum_out", vp), ("lnfold_sums", vp), ("lnfold_colsum", vp), ("lnfold_dim", i32), ("lnfold_eps", f32),
                 ("resid_ln_dim", i32), ("resid_ln_eps", f32), ("a_kb_rows", i64), ("outT_kb_rows", i64), ("ln_flag", vp), ("ln_flag_limit", f32),
                 ("drop_where", i32), ("drop_p", f32), ("drop_seed", C.c_uint64), ("a_drop_out", vp), ("splitk_ws", vp),
-                ("A2", vp), ("lda2", i64), ("K2", i32), ("a2_group_cols", i32), ("a2_group_stride", i64)]
+                ("A2", vp), ("lda2", i64), ("K2", i32), ("a2_group_cols", i32), ("a2_group_stride", i64),
+                ("resid_lo8", vp), ("ld_resid_lo", i64), ("residT_kb_rows", i64), ("out_lo8", vp), ("ld_out_lo", i64),
+                ("resid_lo_kb_rows", i64), ("out_lo_kb_rows", i64)]
 
 
 class AttnDesc(C.Structure):

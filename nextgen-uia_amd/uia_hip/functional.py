@@ -38,6 +38,12 @@ def set_deferred_text_ln(flag):
     _STATE["text_ln_deferred"] = bool(flag)
 
 
+def set_text_resid3(flag):
+    """bf16 mode with the LayerNorm fold (default on): the frozen post-LN text tower keeps its sub-layer sums as three-byte tensors — the bf16 T copy
+    plus one low byte per element (uia_gemm_desc.resid_lo8 / out_lo8; 15 stored mantissa bits) — instead of fp32 + T copy.  False: fp32 sums."""
+    _STATE["text_resid3"] = bool(flag)
+
+
 def set_ln_fold(flag):
     """bf16 mode only (default on): the frozen pre-/post-LN blocks fold each LayerNorm into the GEMMs on either side of it — the producing
     epilogue writes the T copy of the raw rows and their (Σ, Σ²), the consuming GEMM runs on those raw rows with a weight pre-scaled by
@@ -750,13 +756,16 @@ class LnResidual:
     (mean, rstd), LayerNorm weight, bias).  uia_gemm's epilogue applies the LayerNorm to the rows it reads (resid_ln_*), so the
     LayerNorm kernel writes only the T operand and 8 bytes of statistics per row instead of a second, fp32 copy of its output
     (201 MB per LayerNorm at 65536 x 768: 24 of them per step in the BERT tower)."""
-    __slots__ = ("raw", "stats", "w", "b", "dim", "eps")
+    __slots__ = ("raw", "stats", "w", "b", "dim", "eps", "hi", "lo")
 
-    def __init__(self, raw, stats, w, b, dim=None, eps=None):
+    def __init__(self, raw, stats, w, b, dim=None, eps=None, hi=None, lo=None):
         self.raw, self.stats, self.w, self.b = raw, stats, w, b
         self.dim, self.eps = dim, eps          # dim set: `stats` holds the row sums (Σ, Σ²) a producing GEMM left (set_ln_fold), not (mean, rstd)
+        self.hi, self.lo = hi, lo              # three-byte form (set_text_resid3): raw is None, the sum is its bf16 T copy `hi` + int8 low bytes `lo`
 
     def gemm_kw(self):
+        if self.lo is not None:
+            return dict(resid3=(self.hi, self.lo), resid_ln=(self.stats, self.w, self.b, self.dim, self.eps))
         if self.stats is None:
             return dict(resid=self.raw)
         if self.dim is None:
@@ -808,27 +817,45 @@ def post_ln_layer(res, x_t, L, B, heads, P, keylen, eps=1e-12, cu_seqlens=None, 
     else:
         ops.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], a, B, heads, L, mask="keypad", keylen=keylen)
     del qkv
-    s_a = torch.empty(M, D, device=x_t.device, dtype=torch.float32)
     F = P["intermediate.dense.weight"].shape[0]
     f = _act(M, F, dt, x_t, D)
+    # Three-byte sub-layer sums (set_text_resid3, default on with the fold): a sum leaves its GEMM as the bf16 T copy the next GEMM reads anyway
+    # plus one low byte per element, and enters the next sum's epilogue in that form — 6 epilogue bytes per element instead of 10 on the 23
+    # HBM-bound N = 768 launches of the tower (176 -> 145 us at K = 768, 320 -> 296 at K = 3072); 15 stored mantissa bits.
+    r3 = fold and _STATE.get("text_resid3", True) and dt == torch.bfloat16 and M > 2048        # the ring tile configs' epilogue reads and writes the form
     if fold:
         lw_a, lb_a = P["attention.output.LayerNorm.weight"], P["attention.output.LayerNorm.bias"]
         s_a_t = _act(M, D, dt, x_t, F)
-        ops.gemm(a, WEIGHTS.get(P["attention.output.dense.weight"], dt), bias=P["attention.output.dense.bias"], out32=s_a, out_t=s_a_t,
-                 rowsum=fold_sums[0], **res.gemm_kw())
-        res_a = LnResidual(s_a, fold_sums[0], lw_a, lb_a, D, eps)
+        if r3:
+            lo_a = torch.empty(M, D, device=x_t.device, dtype=torch.int8)
+            ops.gemm(a, WEIGHTS.get(P["attention.output.dense.weight"], dt), bias=P["attention.output.dense.bias"], out_t=s_a_t, out_lo=lo_a,
+                     rowsum=fold_sums[0], **res.gemm_kw())
+            res_a = LnResidual(None, fold_sums[0], lw_a, lb_a, D, eps, hi=s_a_t, lo=lo_a)
+        else:
+            s_a = torch.empty(M, D, device=x_t.device, dtype=torch.float32)
+            ops.gemm(a, WEIGHTS.get(P["attention.output.dense.weight"], dt), bias=P["attention.output.dense.bias"], out32=s_a, out_t=s_a_t,
+                     rowsum=fold_sums[0], **res.gemm_kw())
+            res_a = LnResidual(s_a, fold_sums[0], lw_a, lb_a, D, eps)
         w1, c1, b1 = WEIGHTS.get_lnfold(P["intermediate.dense.weight"], P["intermediate.dense.bias"], lw_a, lb_a, dt)
         ops.gemm(s_a_t, w1, bias=b1, act="gelu", out_t=f, lnfold=(fold_sums[0], c1, D, eps))
-        del s_a_t
+        if not r3:
+            del s_a_t
     else:
+        s_a = torch.empty(M, D, device=x_t.device, dtype=torch.float32)
         ops.gemm(a, WEIGHTS.get(P["attention.output.dense.weight"], dt), bias=P["attention.output.dense.bias"], out32=s_a,
                  **(dict(resid_t=x_t) if t_resid else res.gemm_kw()))
         x_t = _as_act(x_t, M, D, dt, 0)
         res_a = _post_ln(s_a, P["attention.output.LayerNorm.weight"], P["attention.output.LayerNorm.bias"], eps, x_t)
         ops.gemm(x_t, WEIGHTS.get(P["intermediate.dense.weight"], dt), bias=P["intermediate.dense.bias"], act="gelu", out_t=f)
-    s_o = res.raw                                     # the previous sub-layer sum was last read by the attention-output GEMM above: its storage takes the new sum
+    # the previous sub-layer sum was last read by the attention-output GEMM above: its storage takes the new sum
+    s_o = res.raw if res.raw is not None else torch.empty(M, D, device=x_t.device, dtype=torch.float32)
     if fold and fold_out:                             # the next layer folds this LayerNorm into its QKV GEMM: x_t becomes the T copy of the raw sum
         x_t = _as_act(x_t, M, D, dt, 3 * D)
+        if r3:
+            lo_o = res.lo if res.lo is not None else torch.empty(M, D, device=x_t.device, dtype=torch.int8)
+            ops.gemm(f, WEIGHTS.get(P["output.dense.weight"], dt), bias=P["output.dense.bias"], out_t=x_t, out_lo=lo_o, rowsum=fold_sums[1],
+                     **res_a.gemm_kw())
+            return LnResidual(None, fold_sums[1], P["output.LayerNorm.weight"], P["output.LayerNorm.bias"], D, eps, hi=x_t, lo=lo_o), x_t
         ops.gemm(f, WEIGHTS.get(P["output.dense.weight"], dt), bias=P["output.dense.bias"], out32=s_o, out_t=x_t, rowsum=fold_sums[1],
                  **res_a.gemm_kw())
         return LnResidual(s_o, fold_sums[1], P["output.LayerNorm.weight"], P["output.LayerNorm.bias"], D, eps), x_t

@@ -21,12 +21,14 @@ GEMM_PROFILE = None
 EPI_BIAS, EPI_AUX_OUT, EPI_GELU, EPI_DGELU, EPI_RESID, EPI_RESIDT, EPI_OUT32, EPI_OUTT, EPI_RESID_LN, EPI_GENERIC = 1, 2, 4, 8, 16, 32, 64, 128, 256, -1
 EPI_QUICK = 2048
 EPI_ROWSUM, EPI_LNFOLD = 512, 1024
+EPI_RESID_LO, EPI_OUT_LO = 4096, 8192      # three-byte tensors (bf16 hi plane + signed low byte): uia_gemm_desc.resid_lo8 / out_lo8
 _SPECIALISED = {EPI_BIAS | EPI_RESID | EPI_OUT32, EPI_BIAS | EPI_RESIDT | EPI_OUT32, EPI_BIAS | EPI_RESID | EPI_RESID_LN | EPI_OUT32, EPI_OUTT, EPI_BIAS | EPI_OUTT, EPI_BIAS | EPI_GELU | EPI_OUTT, EPI_DGELU | EPI_OUTT,
                 EPI_BIAS | EPI_GELU | EPI_AUX_OUT | EPI_OUTT,
                 EPI_QUICK | EPI_BIAS | EPI_GELU | EPI_OUTT, EPI_QUICK | EPI_DGELU | EPI_OUTT, EPI_QUICK | EPI_BIAS | EPI_GELU | EPI_AUX_OUT | EPI_OUTT,
                 EPI_BIAS | EPI_RESID | EPI_OUT32 | EPI_OUTT | EPI_ROWSUM, EPI_BIAS | EPI_RESID | EPI_RESID_LN | EPI_OUT32 | EPI_OUTT | EPI_ROWSUM,
                 EPI_BIAS | EPI_OUTT | EPI_LNFOLD, EPI_BIAS | EPI_GELU | EPI_OUTT | EPI_LNFOLD, EPI_BIAS | EPI_GELU | EPI_AUX_OUT | EPI_OUTT | EPI_LNFOLD,
-                EPI_QUICK | EPI_BIAS | EPI_GELU | EPI_OUTT | EPI_LNFOLD, EPI_QUICK | EPI_BIAS | EPI_GELU | EPI_AUX_OUT | EPI_OUTT | EPI_LNFOLD}
+                EPI_QUICK | EPI_BIAS | EPI_GELU | EPI_OUTT | EPI_LNFOLD, EPI_QUICK | EPI_BIAS | EPI_GELU | EPI_AUX_OUT | EPI_OUTT | EPI_LNFOLD,
+                EPI_BIAS | EPI_RESID_LO | EPI_RESID_LN | EPI_OUTT | EPI_OUT_LO | EPI_ROWSUM}
 
 
 def epi_mask_of(d):
@@ -38,8 +40,9 @@ def epi_mask_of(d):
         return EPI_GENERIC
     quick = _ACT["quick_gelu"] in (d.act, d.dact)
     m = ((EPI_QUICK if quick else 0) | (EPI_BIAS if d.bias else 0) | (EPI_AUX_OUT if d.aux_out else 0) | (EPI_GELU if d.act else 0) | (EPI_DGELU if d.dact else 0) |
-         (EPI_RESID if d.resid else 0) | (EPI_RESIDT if d.residT else 0) | (EPI_OUT32 if d.out32 else 0) | (EPI_OUTT if d.outT else 0) |
-         (EPI_RESID_LN if (d.resid and d.resid_ln_stats) else 0) | (EPI_ROWSUM if d.rowsum_out else 0) | (EPI_LNFOLD if d.lnfold_sums else 0))
+         (EPI_RESID if d.resid else 0) | (EPI_RESIDT if (d.residT and not d.resid_lo8) else 0) | (EPI_OUT32 if d.out32 else 0) | (EPI_OUTT if d.outT else 0) |
+         (EPI_RESID_LN if ((d.resid or d.resid_lo8) and d.resid_ln_stats) else 0) | (EPI_ROWSUM if d.rowsum_out else 0) | (EPI_LNFOLD if d.lnfold_sums else 0) |
+         (EPI_RESID_LO if d.resid_lo8 else 0) | (EPI_OUT_LO if d.out_lo8 else 0))
     return m
 
 
@@ -368,7 +371,8 @@ def _rowmajor(t, name):
 
 
 def gemm(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None, resid=None, resid_mod=0, resid_row_off=0,
-         resid_t=None, out_group=0, out_t=None, out32=None, alpha=1.0, tile_cfg=0, resid_ln=None, rowsum=None, lnfold=None, drop=None, a2=None):
+         resid_t=None, out_group=0, out_t=None, out32=None, alpha=1.0, tile_cfg=0, resid_ln=None, rowsum=None, lnfold=None, drop=None, a2=None,
+         resid3=None, out_lo=None):
     """C = epilogue(alpha * a @ w.T).  a [M,K], w [N,K] (tensor or PackedW) share a dtype (bf16 | fp32); see include/uia_hip.h.
 
     Host-side scheduling on top of uia_gemm (results do not depend on it): with the automatic tile choice, a weight that came
@@ -379,7 +383,12 @@ def gemm(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None, res
     drop = ("a", p, seed[, a_drop_out]): LoRA input dropout applied to `a` in flight (N = 64 stream kernel only; a_drop_out receives the dropped
     rows), or ("acc", p, seed): applied to alpha·acc of element (m, n) before the residual adds — the generator of ops.dropout in both cases.
     rowsum = zeroed int64 [M, 2] (ROWSUM_SCALE fixed point; rowsum_to_float converts): receives (Σ, Σ²) of the stored fp32 rows.  lnfold = (sums [M, 2], colsum [N], dim, eps): `a` holds RAW
-    rows and `w` is pre-scaled by the LayerNorm weight; the epilogue applies the LayerNorm (include/uia_hip.h, uia_gemm_desc)."""
+    rows and `w` is pre-scaled by the LayerNorm weight; the epilogue applies the LayerNorm (include/uia_hip.h, uia_gemm_desc).
+    Three-byte tensors (bf16, ring tile configs: M > 2048): resid3 = (hi, lo) is the residual as a bf16 hi plane (row-major or KBlocked) plus an int8
+    [M, N] plane of low bytes — float bits = (hi_bits << 16) + (lo << 8) — to which resid_ln then applies; out_lo = int8 [M, N] receives the low
+    bytes of the result, whose hi plane is out_t (three_byte_to_float converts)."""
+    if (resid3 is not None or out_lo is not None) and (isinstance(w, ExtW) or resid_mod or out_group or a.dtype != torch.bfloat16 if not is_kb(a) else a.t.dtype != torch.bfloat16):
+        raise UiaError("gemm: three-byte tensors (resid3 / out_lo) need bf16 operands and a plain epilogue (no row remapping, no K extension)")
     if isinstance(w, ExtW):
         # K extension: w = [W | s·B] (K-blocked only), a2 = (t, group_cols): t [M, K2] or [G, M, K2] — one [M, K2] operand per group of output columns
         if a2 is None or is_kb(a) or a.dtype != torch.bfloat16 or a.shape[1] != w.K - w.K2 or resid_mod or out_group or drop is not None:
@@ -419,7 +428,8 @@ def gemm(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None, res
                     _gemm_one(cut(a, lo, hi), w, bias=bias, act=act, dact=dact, aux_in=cut(aux_in, lo, hi), aux_out=cut(aux_out, lo, hi), resid=cut(resid, lo, hi),
                               resid_t=cut(resid_t, lo, hi), out_t=cut(out_t, lo, hi), out32=cut(out32, lo, hi), alpha=alpha, tile_cfg=cfg,
                               resid_ln=None if resid_ln is None else (resid_ln[0][lo:hi],) + tuple(resid_ln[1:]), rowsum=cut(rowsum, lo, hi),
-                              lnfold=None if lnfold is None else (lnfold[0][lo:hi],) + tuple(lnfold[1:]), splitk_ws=ws if cfg >> 16 else None)
+                              lnfold=None if lnfold is None else (lnfold[0][lo:hi],) + tuple(lnfold[1:]), splitk_ws=ws if cfg >> 16 else None,
+                              resid3=None if resid3 is None else (cut(resid3[0], lo, hi), cut(resid3[1], lo, hi)), out_lo=cut(out_lo, lo, hi))
             except Exception:
                 if slices:      # phase 2 is what re-zeroes the shared scratch: an error between the two launches must not leave partial sums behind
                     drop_splitk_workspace(a.device)
@@ -427,11 +437,12 @@ def gemm(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None, res
             return
     _gemm_one(a, w, bias=bias, act=act, dact=dact, aux_in=aux_in, aux_out=aux_out, resid=resid, resid_mod=resid_mod, resid_row_off=resid_row_off,
               resid_t=resid_t, out_group=out_group, out_t=out_t, out32=out32, alpha=alpha, tile_cfg=tile_cfg, resid_ln=resid_ln,
-              rowsum=rowsum, lnfold=lnfold, drop=drop)
+              rowsum=rowsum, lnfold=lnfold, drop=drop, resid3=resid3, out_lo=out_lo)
 
 
 def _gemm_one(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None, resid=None, resid_mod=0, resid_row_off=0,
-              resid_t=None, out_group=0, out_t=None, out32=None, alpha=1.0, tile_cfg=0, resid_ln=None, rowsum=None, lnfold=None, drop=None, splitk_ws=None, a2=None):
+              resid_t=None, out_group=0, out_t=None, out32=None, alpha=1.0, tile_cfg=0, resid_ln=None, rowsum=None, lnfold=None, drop=None, splitk_ws=None, a2=None,
+              resid3=None, out_lo=None):
     d = GemmDesc()
     if splitk_ws is not None:
         d.splitk_ws = _p(splitk_ws)
@@ -513,8 +524,8 @@ def _gemm_one(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None
         st, lw, lb = resid_ln[:3]
         if len(resid_ln) > 3:
             d.resid_ln_dim, d.resid_ln_eps = int(resid_ln[3]), float(resid_ln[4])
-        if resid is None or resid_mod or out_group:
-            raise UiaError("gemm resid_ln needs a plain fp32 resid (no row remapping)")
+        if (resid is None and resid3 is None) or resid_mod or out_group:
+            raise UiaError("gemm resid_ln needs a plain fp32 resid or a three-byte resid3 (no row remapping)")
         want_st = torch.int64 if len(resid_ln) > 3 else torch.float32       # row sums (fixed point) or (mean, rstd)
         if not (st.dtype == want_st and lw.dtype == lb.dtype == torch.float32 and st.is_contiguous() and st.numel() >= 2 * d.M and lw.numel() >= d.N and lb.numel() >= d.N):
             raise UiaError(f"gemm resid_ln: stats {tuple(st.shape)} / weight {tuple(lw.shape)} / bias {tuple(lb.shape)} do not cover [{d.M}, {d.N}]")
@@ -532,6 +543,40 @@ def _gemm_one(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None
         d.ln_flag, d.ln_flag_limit = _p(ln_flag(a.device)), LN_FLAG_LIMIT
     if resid_t is not None:
         d.residT, d.ldrT = _p(resid_t), _rowmajor(resid_t, "resid_t")
+    if resid3 is not None:
+        hi3, lo3 = resid3
+        if resid is not None or resid_t is not None:
+            raise UiaError("gemm: resid3 replaces resid / resid_t")
+        if is_kb(hi3):
+            rows, cols, plane = _kb_dims(hi3, "gemm resid3 hi plane")
+            if rows < d.M or cols != d.N or hi3.t.dtype != torch.bfloat16:
+                raise UiaError(f"gemm resid3 hi plane (K-blocked {tuple(hi3.t.shape)}) does not hold the [{d.M}, {d.N}] bf16 residual")
+            d.residT, d.ldrT, d.residT_kb_rows = _p(hi3.t), d.N, plane
+        else:
+            if hi3.dtype != torch.bfloat16 or hi3.dim() != 2 or hi3.shape[0] < d.M or hi3.shape[1] < d.N:
+                raise UiaError(f"gemm resid3 hi plane {tuple(hi3.shape)} {hi3.dtype} does not hold the [{d.M}, {d.N}] bf16 residual")
+            d.residT, d.ldrT = _p(hi3), _rowmajor(hi3, "resid3 hi plane")
+        if is_kb(lo3):                                   # low bytes in 64-column blocks: KBlocked over an int8 [N/64, rows, 64] tensor
+            rows, cols, plane = _kb_dims(lo3, "gemm resid3 low bytes")
+            if rows < d.M or cols != d.N or lo3.t.dtype != torch.int8:
+                raise UiaError(f"gemm resid3 low bytes (blocked {tuple(lo3.t.shape)}) do not hold the [{d.M}, {d.N}] int8 plane")
+            d.resid_lo8, d.ld_resid_lo, d.resid_lo_kb_rows = _p(lo3.t), d.N, plane
+        else:
+            if lo3.dtype != torch.int8 or lo3.dim() != 2 or lo3.shape[0] < d.M or lo3.shape[1] < d.N:
+                raise UiaError(f"gemm resid3 low bytes {tuple(lo3.shape)} {lo3.dtype} do not hold the [{d.M}, {d.N}] int8 plane")
+            d.resid_lo8, d.ld_resid_lo = _p(lo3), _rowmajor(lo3, "resid3 low bytes")
+    if out_lo is not None:
+        if out_t is None:
+            raise UiaError("gemm out_lo needs out_t (the hi plane)")
+        if is_kb(out_lo):
+            rows, cols, plane = _kb_dims(out_lo, "gemm out_lo")
+            if rows < d.M or cols != d.N or out_lo.t.dtype != torch.int8:
+                raise UiaError(f"gemm out_lo (blocked {tuple(out_lo.t.shape)}) does not hold the [{d.M}, {d.N}] int8 plane")
+            d.out_lo8, d.ld_out_lo, d.out_lo_kb_rows = _p(out_lo.t), d.N, plane
+        else:
+            if out_lo.dtype != torch.int8 or out_lo.dim() != 2 or out_lo.shape[0] < d.M or out_lo.shape[1] < d.N:
+                raise UiaError(f"gemm out_lo must be an int8 [{d.M}, {d.N}] plane")
+            d.out_lo8, d.ld_out_lo = _p(out_lo), _rowmajor(out_lo, "out_lo")
     if is_kb(out_t):
         d.outT, d.ldo, d.outT_kb_rows = _p(out_t.t), d.N, _kb_dims(out_t, "gemm out_t")[2]
     elif out_t is not None:
@@ -547,13 +592,31 @@ def _gemm_one(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None
         e1.record()
         esz = a.element_size()                  # algorithmic HBM bytes of this launch: every operand and result once
         nbytes = esz * (d.M * d.K + d.N * d.K) + d.M * d.N * (esz * sum(t is not None for t in (aux_in, aux_out, resid_t, out_t))
-                                                             + 4 * sum(t is not None for t in (resid, out32)))
+                                                             + 4 * sum(t is not None for t in (resid, out32)) + 3 * (resid3 is not None) + 1 * (out_lo is not None))
         mask = epi_mask_of(d)
         if not (tile_cfg & 255) and base_cfg != 23:
             base_cfg = auto_tile_cfg(d.M, d.N, d.K, esz, mask)
         GEMM_PROFILE.append((e0, e1, d.M, d.N, d.K, a.dtype, base_cfg, nbytes, mask))
         return
     check(lib().uia_gemm(_stream(), _code(a.dtype), C.byref(d), tile_cfg), "uia_gemm")
+
+
+def three_byte_to_float(hi, lo):
+    """The fp32 values of a three-byte tensor: hi = bf16 plane (row-major or KBlocked), lo = int8 plane; float bits = (hi_bits << 16) + (lo << 8)."""
+    h = hi.t.permute(1, 0, 2).reshape(hi.rows, hi.cols) if is_kb(hi) else hi
+    lo = lo.t.permute(1, 0, 2).reshape(lo.rows, lo.cols) if is_kb(lo) else lo
+    h = h[:lo.shape[0], :lo.shape[1]]
+    bits = (h.contiguous().view(torch.int16).to(torch.int32) << 16) + (lo.to(torch.int32) << 8)
+    return bits.view(torch.float32)
+
+
+def float_to_three_byte(x):
+    """(hi bf16, lo int8) of fp32 `x`, the arithmetic of the GEMM epilogue: hi = round-to-nearest bf16, lo = ((bits + 0x80) >> 8) - (hi_bits << 8) clamped to ±127."""
+    hi = x.bfloat16()
+    xb = x.contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+    hb = hi.contiguous().view(torch.int16).to(torch.int64) & 0xFFFF
+    d = ((xb + 0x80) >> 8) - (hb << 8)
+    return hi, d.clamp(-127, 127).to(torch.int8)
 
 
 def wgrad(a, b, dw, dbias=None, alpha=1.0):

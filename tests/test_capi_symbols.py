@@ -42,7 +42,7 @@ def test_descriptor_struct_sizes_match_c_layout():
     import subprocess
     import tempfile
     from uia_hip import _lib
-    assert ctypes.sizeof(_lib.GemmDesc) == 344 and ctypes.sizeof(_lib.PackDesc) == 64 and _lib.GemmDesc.a_drop_out.offset == 296
+    assert ctypes.sizeof(_lib.GemmDesc) == 400 and ctypes.sizeof(_lib.PackDesc) == 64 and _lib.GemmDesc.a_drop_out.offset == 296
     assert ctypes.sizeof(_lib.AttnDesc) == 160
     assert ctypes.sizeof(_lib.MonaSpatialDesc) % 8 == 0 and ctypes.sizeof(_lib.MonaSpatialDesc) == 296
     assert ctypes.sizeof(_lib.MonaFusedDesc) == 432 and _lib.MonaFusedDesc.D.offset == 296

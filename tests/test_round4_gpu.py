@@ -200,3 +200,80 @@ def test_clipseg_prompt_features_cache_hits_and_invalidates():
         model(images, input_ids=ids2)
         assert len(calls) == 4
         assert not torch.equal(d[:1], a[:1])
+
+
+def _kb(t):
+    from uia_hip import ops
+    g = 64 // t.element_size()
+    M, K = t.shape
+    return ops.KBlocked(t.view(M, K // g, g).permute(1, 0, 2).contiguous())
+
+
+def test_three_byte_conversion_helpers_roundtrip():
+    """float -> (bf16 hi, int8 lo) -> float keeps 15 mantissa bits (2^-16 relative), across exponent boundaries and signs"""
+    from uia_hip import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.cat([torch.randn(4096, generator=g) * 10 ** torch.randint(-6, 6, (4096,), generator=g).float(),
+                   torch.tensor([0.0, -0.0, 1.0, -1.0, 1.9999999, 2.0, -255.99998, 3.3895314e38, 1e-30])]).to(dev()).view(1, -1)
+    x = torch.nn.functional.pad(x, (0, (-x.shape[1]) % 8))
+    hi, lo = ops.float_to_three_byte(x)
+    back = ops.three_byte_to_float(hi, lo)
+    err = ((back - x).abs() / x.abs().clamp_min(1e-37)).max()
+    assert float(err) <= 2.0 ** -15 and bool((back.sign() == x.sign()).all() | (x == 0).all())
+
+
+@pytest.mark.parametrize("M,K,kb_hi,spec", [(4100, 768, True, True), (4100, 768, False, True), (65536, 768, True, True), (4100, 3072, True, False), (2560, 64, False, False)])
+def test_gemm_three_byte_residual_in_and_out(M, K, kb_hi, spec):
+    """uia_gemm_desc.resid_lo8 / out_lo8: the residual arrives as a bf16 hi plane (K-blocked or row-major) + low bytes and has the deferred
+    LayerNorm applied, the result leaves as hi plane + low bytes (+ row sums).  Against torch on the reconstructed operands, and against the
+    fp32-residual / fp32-output launch of the same GEMM (the compile-time mask of the text tower's sub-layer sums when `spec`, else the
+    run-time epilogue: no bias, fp32 output beside the low bytes)."""
+    from uia_hip import ops
+    torch.manual_seed(M + K)
+    N = 768
+    a = torch.randn(M, K, device=dev()).bfloat16()
+    w = (torch.randn(N, K, device=dev()) * K ** -0.5).bfloat16()
+    bias = torch.randn(N, device=dev()) if spec else None
+    prev = torch.randn(M, N, device=dev()) * 3 + 0.5
+    hi, lo = ops.float_to_three_byte(prev)
+    prev3 = ops.three_byte_to_float(hi, lo)                                   # what the kernel must reconstruct, exactly
+    assert float((prev3 - prev).abs().max() / prev.abs().max()) < 2.0 ** -15
+    stats = torch.stack([prev3.mean(1), (prev3.var(1, unbiased=False) + 1e-12).rsqrt()], 1).contiguous()
+    lw, lb = torch.randn(N, device=dev()), torch.randn(N, device=dev())
+    ref = a.float() @ w.float().T + (bias if bias is not None else 0) + ((prev3 - stats[:, :1]) * stats[:, 1:]) * lw + lb
+    out_t = ops.kb_empty(M, N, torch.bfloat16, dev()) if M > 2048 and spec else torch.empty(M, N, device=dev(), dtype=torch.bfloat16)
+    # low bytes: row-major, or in 64-column blocks beside a K-blocked hi plane (whole 128-byte lines per 16-row pass)
+    out_lo = ops.kb_empty(M, N, torch.int8, dev()) if kb_hi else torch.full((M, N), 99, device=dev(), dtype=torch.int8)
+    sums = torch.zeros(M, 2, device=dev(), dtype=torch.int64) if spec else None
+    o32 = None if spec else torch.empty(M, N, device=dev())
+    ops.gemm(a, w, bias=bias, resid3=(_kb(hi), _kb(lo)) if kb_hi else (hi, lo), resid_ln=(stats, lw, lb), out_t=out_t, out_lo=out_lo, rowsum=sums, out32=o32)
+    got = ops.three_byte_to_float(out_t, out_lo)
+    assert rel(got, ref) < 3e-5                                               # fp32 accumulation order + 2^-16 of the format
+    if o32 is not None:
+        assert rel(o32, ref) < 2e-5 and float(((got - o32).abs() / o32.abs().clamp_min(1e-3)).max()) < 2.0 ** -14
+    # the fp32 form of the same launch
+    o_ref32 = torch.empty(M, N, device=dev())
+    ops.gemm(a, w, bias=bias, resid=prev3.contiguous(), resid_ln=(stats, lw, lb), out32=o_ref32)
+    assert float(((got - o_ref32).abs() / o_ref32.abs().clamp_min(1e-3)).max()) < 2.0 ** -14
+    hi_rows = out_t.t.permute(1, 0, 2).reshape(M, N) if ops.is_kb(out_t) else out_t
+    assert torch.equal(hi_rows, o_ref32.bfloat16())                           # the hi plane IS the rounded result (the next GEMM's A operand)
+    if sums is not None:
+        s = ops.rowsum_to_float(sums)
+        assert rel(s[:, 0], o_ref32.sum(1)) < 1e-4 and rel(s[:, 1], (o_ref32 * o_ref32).sum(1)) < 1e-4
+
+
+def test_gemm_three_byte_arguments_are_validated():
+    from uia_hip import ops
+    from uia_hip._lib import UiaError
+    a = torch.zeros(4100, 128, device=dev(), dtype=torch.bfloat16)
+    w = torch.zeros(256, 128, device=dev(), dtype=torch.bfloat16)
+    hi, lo = torch.zeros(4100, 256, device=dev(), dtype=torch.bfloat16), torch.zeros(4100, 256, device=dev(), dtype=torch.int8)
+    out = torch.empty(4100, 256, device=dev(), dtype=torch.bfloat16)
+    with pytest.raises(UiaError):
+        ops.gemm(a, w, resid3=(hi, lo), resid=torch.zeros(4100, 256, device=dev()), out_t=out)          # two residuals
+    with pytest.raises(UiaError):
+        ops.gemm(a, w, out32=torch.empty(4100, 256, device=dev()), out_lo=lo)                             # low bytes without a hi plane
+    with pytest.raises(UiaError):
+        ops.gemm(a[:256], w, resid3=(hi[:256], lo[:256]), out_t=out[:256])                               # small M: not a ring tile config
+    with pytest.raises(UiaError):
+        ops.gemm(a.float(), w.float(), resid3=(hi, lo), out_t=out.float())                               # fp32 operands
