@@ -80,6 +80,7 @@ def parse():
                     "instead of one launch on half-height tiles")
     ap.add_argument("--no-text-resid3", action="store_true", help="A/B knob: the text tower's sub-layer sums as fp32 + bf16 copy (rounds 2-3) instead of three-byte tensors "
                     "(bf16 copy + one low byte per element: 6 epilogue bytes per element instead of 10 on its 23 N = 768 launches)")
+    ap.add_argument("--block-resid3", action="store_true", help="A/B knob (measured level, off by default): x1 / dx1 inside the frozen image blocks as three-byte tensors instead of fp32 + bf16 copy")
     ap.add_argument("--attn-bwd-cfg", type=int, default=0, help="A/B knob: kernel configuration of the bf16 attention backward (uia_attn_bwd_cfg: 0 = the library's choice, "
                     "1 = the lock-step kernel of rounds 1-3, 2 = barrier-free units, 5 = their persistent form)")
     ap.add_argument("--global-loss", action="store_true", help="opt-in: InfoNCE over the global batch (all-gathered features) instead of "
@@ -362,6 +363,7 @@ def main():
     UF.set_wgrad_side_stream(args.wgrad_side_stream)
     UF.set_fp32_heads(not args.bf16_heads)
     UF.set_text_resid3(not args.no_text_resid3)
+    UF.set_block_resid3(args.block_resid3)
     ops.PERSIST_STORE_ONLY = args.persist_store_only
     ops.TILE_GROUP = {int(k): int(v) for k, v in (kv.split("=") for kv in args.tile_group.split(",") if kv)}
     try:

@@ -209,6 +209,13 @@ int uia_layernorm_fwd_stats(void* stream, int dtype, int M, int D, int64_t ldx, 
                             float eps, void* yT, float* y32, float* stats);
 int uia_layernorm_bwd(void* stream, int dtype, int M, int D, int64_t ldx, const void* dy, const float* x, const float* gamma,
                       float eps, const float* dres, float* dx32, void* dxT);
+/* The same backward on THREE-BYTE tensors (bf16 launches, compact rows; the form is defined at uia_gemm_desc.resid_lo8): inside a frozen block
+ * the attention-half output x1 and its gradient dx1 never exist in fp32 — x1 leaves the output projection's epilogue as (T copy, low bytes) and
+ * is read here for the statistics; dx1 leaves this kernel as (dxT, dx_lo) and comes back as the next call's (dres_hi, dres_lo).
+ *   x_lo   != NULL: x is (x_hi, x_lo); x must be NULL; x_hi row-major [M, D] or, x_kb_rows > 0, K-blocked with that many rows per 32-column block.
+ *   dres_lo != NULL: dres is (dres_hi row-major, dres_lo); dres must be NULL.      dx_lo != NULL: the result is (dxT, dx_lo); dx32 may be NULL. */
+int uia_layernorm_bwd3(void* stream, int dtype, int M, int D, int64_t ldx, const void* dy, const float* x, const void* x_hi, const int8_t* x_lo, int64_t x_kb_rows,
+                       const float* gamma, float eps, const float* dres, const void* dres_hi, const int8_t* dres_lo, float* dx32, void* dxT, int8_t* dx_lo);
 
 /* ---------------------------------------------------------------------------------------------
  * Mona adapter, all four variants (src/adapters/mona.py:75-487; equations SURVEY.md Appendix E.1).

@@ -43,6 +43,10 @@ int uia_layernorm_fwd_stats(void* stream, int dtype, int M, int D, int64_t ldx, 
 int uia_layernorm_bwd(void* stream, int dtype, int M, int D, int64_t ldx, const void* dy, const float* x, const float* gamma, float eps, const float* dres, float* dx32, void* dxT) {
     return uia_layernorm_bwd_launch((hipStream_t)stream, dtype, M, D, ldx, dy, x, gamma, eps, dres, dx32, dxT);
 }
+int uia_layernorm_bwd3(void* stream, int dtype, int M, int D, int64_t ldx, const void* dy, const float* x, const void* x_hi, const int8_t* x_lo, int64_t x_kb_rows,
+                       const float* gamma, float eps, const float* dres, const void* dres_hi, const int8_t* dres_lo, float* dx32, void* dxT, int8_t* dx_lo) {
+    return uia_layernorm_bwd3_launch((hipStream_t)stream, dtype, M, D, ldx, dy, x, x_hi, x_lo, (long)x_kb_rows, gamma, eps, dres, dres_hi, dres_lo, dx32, dxT, dx_lo);
+}
 int uia_cast(void* stream, int dtype, size_t n, const float* src, void* dst, float scale) { return uia_cast_launch((hipStream_t)stream, dtype, n, src, dst, scale); }
 int uia_transpose_cast(void* stream, int dtype, int rows, int cols, const float* src, void* dst) { return uia_transpose_cast_launch((hipStream_t)stream, dtype, rows, cols, src, dst); }
 int uia_pack_weights(void* stream, int dtype, int n, const uia_pack_desc* descs_device, int max_elems) { return uia_pack_weights_launch((hipStream_t)stream, dtype, n, descs_device, max_elems); }

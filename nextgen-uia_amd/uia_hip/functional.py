@@ -38,6 +38,13 @@ def set_deferred_text_ln(flag):
     _STATE["text_ln_deferred"] = bool(flag)
 
 
+def set_block_resid3(flag):
+    """bf16 mode with the LayerNorm fold (opt-in, default OFF: level with fp32 + T copy inside the step): inside a frozen pre-LN block the attention
+    half's output x1 and its gradient dx1 are three-byte tensors (bf16 T copy + one low byte per element) between the GEMM epilogues and the
+    LayerNorm backward."""
+    _STATE["block_resid3"] = bool(flag)
+
+
 def set_text_resid3(flag):
     """bf16 mode with the LayerNorm fold (default on): the frozen post-LN text tower keeps its sub-layer sums as three-byte tensors — the bf16 T copy
     plus one low byte per element (uia_gemm_desc.resid_lo8 / out_lo8; 15 stored mantissa bits) — instead of fp32 + T copy.  False: fp32 sums."""
@@ -680,14 +687,26 @@ class VitBlockFn(torch.autograd.Function):
         a = _attn_act(M, D, dt, x, D) if D == 64 * spec.heads else _empty((M, D), dt, x)     # read by the output projection (and the backward kernel)
         lse = torch.empty(B, spec.heads, N, device=x.device, dtype=torch.float32) if train else None
         ops.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], a, B, spec.heads, N, lse=lse, mask=spec.mask)
-        x1 = torch.empty_like(x2d)
         F = spec.fc1[0].shape[0]
         f = _act(M, F, dt, x, D)                          # fc1's result is read by fc2 only
         pre = _empty((M, F), dt, x) if train else None
+        # x1 (the attention half's output) never leaves the block: with the fold it can be a THREE-BYTE tensor — the T copy fc1 reads anyway plus one
+        # low byte per element (set_block_resid3, bf16, ring tile configs) — instead of fp32 + T copy: the projection's epilogue writes 3 bytes per
+        # element instead of 6, fc2's reads 3 instead of 4, and so does the LayerNorm backward that recomputes its statistics (and 39 MB less per block
+        # are held for the backward at 256 images)
+        # MEASURED, NOT ADOPTED (default off): the two GEMM epilogues gain 0.16 ms per step, the two LayerNorm backwards lose 0.2 — their three planes
+        # (2-, 1- and 4-byte elements) cannot all be read with 16-byte accesses per lane, and the row kernel turns from byte- into access-bound
+        # (74.7 vs 69.0 us per launch, profiles/r04_c_ab_block_resid3.txt).
+        r3 = fold and _STATE.get("block_resid3", False) and dt == torch.bfloat16 and M > 2048
+        x1 = None if r3 else torch.empty_like(x2d)
+        lo1 = torch.empty(M, D, device=x.device, dtype=torch.int8) if r3 else None
         if fold:                                          # LN2 folded: proj leaves T rows + sums, fc1 normalises its accumulators
             sums1 = zero_sums(M, x.device)
             h1 = _as_act(h1, M, D, dt, F)
-            ops.gemm(a, WEIGHTS.get(spec.proj[0], dt), bias=spec.proj[1], resid=x2d, out32=x1, out_t=h1, rowsum=sums1)
+            if r3:
+                ops.gemm(a, WEIGHTS.get(spec.proj[0], dt), bias=spec.proj[1], resid=x2d, out_t=h1, out_lo=lo1, rowsum=sums1)
+            else:
+                ops.gemm(a, WEIGHTS.get(spec.proj[0], dt), bias=spec.proj[1], resid=x2d, out32=x1, out_t=h1, rowsum=sums1)
             w1, c1, b1 = WEIGHTS.get_lnfold(spec.fc1[0], spec.fc1[1], spec.ln2[0], spec.ln2[1], dt)
             ops.gemm(h1, w1, bias=b1, act=spec.act, aux_out=pre, out_t=f, lnfold=(sums1, c1, D, spec.eps))
         else:
@@ -696,22 +715,31 @@ class VitBlockFn(torch.autograd.Function):
             ops.layernorm_fwd(x1, spec.ln2[0], spec.ln2[1], spec.eps, y_t=h1)          # h1 buffer reused as h2
             ops.gemm(h1, WEIGHTS.get(spec.fc1[0], dt), bias=spec.fc1[1], act=spec.act, aux_out=pre, out_t=f)
         x2 = torch.empty_like(x)
+        res1 = dict(resid3=(h1, lo1)) if r3 else dict(resid=x1)
         if fold and spec.publish_out:
             sums2 = zero_sums(M, x.device)
-            h1 = _as_act(h1, M, D, dt, 3 * D)
-            ops.gemm(f, WEIGHTS.get(spec.fc2[0], dt), bias=spec.fc2[1], resid=x1, out32=x2.view(M, D), out_t=h1, rowsum=sums2)
-            publish_rows(x2, h1, sums2)
+            h2 = _act(M, D, dt, x, 3 * D) if r3 else _as_act(h1, M, D, dt, 3 * D)      # (three-byte: h1 is x1's hi plane and stays alive)
+            ops.gemm(f, WEIGHTS.get(spec.fc2[0], dt), bias=spec.fc2[1], out32=x2.view(M, D), out_t=h2, rowsum=sums2, **res1)
+            publish_rows(x2, h2, sums2)
         else:
-            ops.gemm(f, WEIGHTS.get(spec.fc2[0], dt), bias=spec.fc2[1], resid=x1, out32=x2.view(M, D))
+            ops.gemm(f, WEIGHTS.get(spec.fc2[0], dt), bias=spec.fc2[1], out32=x2.view(M, D), **res1)
         if train:
             ctx.a_kb = ops.is_kb(a)                       # save_for_backward takes tensors: the K-blocked wrapper is rebuilt in backward
-            ctx.save_for_backward(x, qkv, a.t if ctx.a_kb else a, lse, x1, pre)
+            ctx.r3, ctx.h1_kb = r3, bool(r3 and ops.is_kb(h1))
+            if r3:
+                ctx.save_for_backward(x, qkv, a.t if ctx.a_kb else a, lse, h1.t if ctx.h1_kb else h1, pre, lo1)
+            else:
+                ctx.save_for_backward(x, qkv, a.t if ctx.a_kb else a, lse, x1, pre)
             ctx.spec = spec
         return x2
 
     @staticmethod
     def backward(ctx, dx2):
-        x, qkv, a, lse, x1, pre = ctx.saved_tensors
+        if ctx.r3:
+            x, qkv, a, lse, h1, pre, lo1 = ctx.saved_tensors
+            x1 = (ops.KBlocked(h1) if ctx.h1_kb else h1, lo1)         # three-byte x1: (hi plane, low bytes)
+        else:
+            x, qkv, a, lse, x1, pre = ctx.saved_tensors
         if ctx.a_kb:
             a = ops.KBlocked(a)
         spec = ctx.spec
@@ -728,9 +756,15 @@ class VitBlockFn(torch.autograd.Function):
         dh = _empty((M, D), dt, x)
         ops.gemm(dpre, WEIGHTS.get(spec.fc1[0], dt, transpose=True), out_t=dh)
         del dpre
-        dx1 = torch.empty_like(x1)
-        dx1_t = _empty((M, D), dt, x) if dt != torch.float32 else dx1
-        ops.layernorm_bwd(dh, x1, spec.ln2[0], spec.eps, dres=dx2.view(M, D), dx32=dx1, dx_t=dx1_t if dt != torch.float32 else None)
+        if ctx.r3:                                                   # dx1 never leaves the block either: (T copy, low bytes), 3 bytes written instead of 4 + 2
+            dx1_t = _empty((M, D), dt, x)
+            dlo1 = torch.empty(M, D, device=x.device, dtype=torch.int8)
+            ops.layernorm_bwd(dh, x1, spec.ln2[0], spec.eps, dres=dx2.view(M, D), dx_t=dx1_t, dx_lo=dlo1)
+            dx1 = (dx1_t, dlo1)
+        else:
+            dx1 = torch.empty_like(x1)
+            dx1_t = _empty((M, D), dt, x) if dt != torch.float32 else dx1
+            ops.layernorm_bwd(dh, x1, spec.ln2[0], spec.eps, dres=dx2.view(M, D), dx32=dx1, dx_t=dx1_t if dt != torch.float32 else None)
         da = dh                                                                     # reuse
         ops.gemm(dx1_t, WEIGHTS.get(spec.proj[0], dt, transpose=True), out_t=da)
         dqkv = _attn_act(M, 3 * D, dt, x, D) if D == 64 * spec.heads else _empty((M, 3 * D), dt, x)   # read by the QKV dgrad GEMM only

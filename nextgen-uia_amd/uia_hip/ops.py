@@ -28,7 +28,8 @@ _SPECIALISED = {EPI_BIAS | EPI_RESID | EPI_OUT32, EPI_BIAS | EPI_RESIDT | EPI_OU
                 EPI_BIAS | EPI_RESID | EPI_OUT32 | EPI_OUTT | EPI_ROWSUM, EPI_BIAS | EPI_RESID | EPI_RESID_LN | EPI_OUT32 | EPI_OUTT | EPI_ROWSUM,
                 EPI_BIAS | EPI_OUTT | EPI_LNFOLD, EPI_BIAS | EPI_GELU | EPI_OUTT | EPI_LNFOLD, EPI_BIAS | EPI_GELU | EPI_AUX_OUT | EPI_OUTT | EPI_LNFOLD,
                 EPI_QUICK | EPI_BIAS | EPI_GELU | EPI_OUTT | EPI_LNFOLD, EPI_QUICK | EPI_BIAS | EPI_GELU | EPI_AUX_OUT | EPI_OUTT | EPI_LNFOLD,
-                EPI_BIAS | EPI_RESID_LO | EPI_RESID_LN | EPI_OUTT | EPI_OUT_LO | EPI_ROWSUM}
+                EPI_BIAS | EPI_RESID_LO | EPI_RESID_LN | EPI_OUTT | EPI_OUT_LO | EPI_ROWSUM,
+                EPI_BIAS | EPI_RESID | EPI_OUTT | EPI_OUT_LO | EPI_ROWSUM, EPI_BIAS | EPI_RESID_LO | EPI_OUT32}
 
 
 def epi_mask_of(d):
@@ -700,10 +701,27 @@ def layernorm_fwd(x, gamma, beta, eps, y_t=None, y32=None, rows=None, ldx=None, 
     check(lib().uia_layernorm_fwd(_stream(), dt, rows, D, ldx, _p(x), _p(gamma), _p(beta), eps, _p(y_t), _p(y32)), "uia_layernorm_fwd")
 
 
-def layernorm_bwd(dy, x, gamma, eps, dres=None, dx32=None, dx_t=None, rows=None, ldx=None):
+def layernorm_bwd(dy, x, gamma, eps, dres=None, dx32=None, dx_t=None, rows=None, ldx=None, dx_lo=None):
+    """dx = dres + LN'(dy) on rows of x.  x and dres may be three-byte tensors, passed as (hi, lo) tuples (hi bf16 row-major — x's hi plane may be
+    KBlocked — lo int8 [M, D]); dx_lo = int8 [M, D] makes the result a three-byte tensor whose hi plane is dx_t (dx32 may then be None)."""
     D = gamma.numel()
     rows = dy.numel() // D if rows is None else rows
     ldx = D if ldx is None else ldx
+    if isinstance(x, tuple) or isinstance(dres, tuple) or dx_lo is not None:
+        x_hi, x_lo = x if isinstance(x, tuple) else (None, None)
+        r_hi, r_lo = dres if isinstance(dres, tuple) else (None, None)
+        x_kb = 0
+        if is_kb(x_hi):
+            kr, kc, x_kb = _kb_dims(x_hi, "layernorm_bwd x hi plane")
+            if kr < rows or kc != D:
+                raise UiaError(f"layernorm_bwd: K-blocked x hi plane {tuple(x_hi.t.shape)} does not hold [{rows}, {D}]")
+            x_hi = x_hi.t
+        for name, t, dt_ in (("x hi", x_hi, torch.bfloat16), ("x lo", x_lo, torch.int8), ("dres hi", r_hi, torch.bfloat16), ("dres lo", r_lo, torch.int8), ("dx_lo", dx_lo, torch.int8)):
+            if t is not None and (t.dtype != dt_ or not t.is_contiguous() or t.numel() < rows * D):
+                raise UiaError(f"layernorm_bwd: {name} plane must be a contiguous {dt_} tensor of at least [{rows}, {D}], got {tuple(t.shape)} {t.dtype}")
+        check(lib().uia_layernorm_bwd3(_stream(), _code(dy.dtype), rows, D, ldx, _p(dy), None if isinstance(x, tuple) else _p(x), _p(x_hi), _p(x_lo), x_kb, _p(gamma), eps,
+                                       None if isinstance(dres, tuple) else _p(dres), _p(r_hi), _p(r_lo), _p(dx32), _p(dx_t), _p(dx_lo)), "uia_layernorm_bwd3")
+        return
     check(lib().uia_layernorm_bwd(_stream(), _code(dy.dtype), rows, D, ldx, _p(dy), _p(x), _p(gamma), eps, _p(dres), _p(dx32), _p(dx_t)), "uia_layernorm_bwd")
 
 

@@ -277,3 +277,63 @@ def test_gemm_three_byte_arguments_are_validated():
         ops.gemm(a[:256], w, resid3=(hi[:256], lo[:256]), out_t=out[:256])                               # small M: not a ring tile config
     with pytest.raises(UiaError):
         ops.gemm(a.float(), w.float(), resid3=(hi, lo), out_t=out.float())                               # fp32 operands
+
+
+@pytest.mark.parametrize("kb", [False, True])
+def test_layernorm_bwd_on_three_byte_tensors(kb):
+    """uia_layernorm_bwd3: x and dres arrive as (bf16 hi plane, low bytes), dx leaves as (T copy, low bytes): the same result as the fp32 launch
+    on the reconstructed operands — the T copies bit for bit, the reconstructed dx within 2^-15."""
+    from uia_hip import ops
+    torch.manual_seed(9)
+    M, D = 4100, 768
+    x = torch.randn(M, D, device=dev()) * 2 + 0.3
+    dres = torch.randn(M, D, device=dev())
+    dy = torch.randn(M, D, device=dev()).bfloat16()
+    gamma = torch.randn(D, device=dev())
+    xh, xl = ops.float_to_three_byte(x)
+    rh, rl = ops.float_to_three_byte(dres)
+    x3, r3 = ops.three_byte_to_float(xh, xl).contiguous(), ops.three_byte_to_float(rh, rl).contiguous()
+    dx_ref, dxt_ref = torch.empty(M, D, device=dev()), torch.empty(M, D, device=dev(), dtype=torch.bfloat16)
+    ops.layernorm_bwd(dy, x3, gamma, 1e-6, dres=r3, dx32=dx_ref, dx_t=dxt_ref)
+    dxt, dlo = torch.empty_like(dxt_ref), torch.empty(M, D, device=dev(), dtype=torch.int8)
+    ops.layernorm_bwd(dy, (_kb(xh) if kb else xh, xl), gamma, 1e-6, dres=(rh, rl), dx_t=dxt, dx_lo=dlo)
+    assert torch.equal(dxt, dxt_ref)
+    got = ops.three_byte_to_float(dxt, dlo)
+    assert float(((got - dx_ref).abs() / dx_ref.abs().clamp_min(1e-3)).max()) < 2.0 ** -14
+    # mixed: fp32 x, three-byte dres, fp32 + T output (the block's first LayerNorm)
+    dx2, dxt2 = torch.empty(M, D, device=dev()), torch.empty(M, D, device=dev(), dtype=torch.bfloat16)
+    ops.layernorm_bwd(dy, x3, gamma, 1e-6, dres=(rh, rl), dx32=dx2, dx_t=dxt2)
+    assert torch.equal(dx2, dx_ref) and torch.equal(dxt2, dxt_ref)
+
+
+def test_block_internal_three_byte_tensors_match_fp32_form():
+    """UF.set_block_resid3 (opt-in): x1 / dx1 of a frozen pre-LN block as three-byte tensors between the GEMM epilogues and the LayerNorm backward —
+    features and adapter gradients against the default (fp32 + T copy) on a batch that reaches the ring kernels."""
+    from uia_hip import functional as UF
+    from tests.test_lnfold_gpu import _toy
+    from src.losses import InfoNCELoss
+    model = _toy()
+    g = torch.Generator().manual_seed(5)
+    images = torch.rand(160, 3, 32, 32, generator=g).to(dev())            # 160 x 17 tokens = 2720 rows > 2048
+    ids = torch.randint(4, 120, (160, 12), generator=g)
+    ids[:, 0] = 2
+    ids = ids.to(dev())
+
+    def run(flag):
+        UF.set_compute_dtype(torch.bfloat16)
+        UF.set_block_resid3(flag)
+        UF.set_dropout_seed(5)
+        for p in model.parameters():
+            p.grad = None
+        fi, ft = model.encode_image(images), model.encode_text(ids)
+        InfoNCELoss(0.07)(fi, ft).backward()
+        UF.clear_t_copies()
+        return fi.detach().clone(), torch.cat([p.grad.flatten() for p in model.parameters() if p.requires_grad]).clone()
+
+    try:
+        f0, g0 = run(False)
+        f1, g1 = run(True)
+    finally:
+        UF.set_block_resid3(False)
+    assert rel(f1, f0) < 5e-3                                              # 15 stored mantissa bits against 24; bf16 results re-roll their last bits on any 1e-5 change upstream
+    assert float(torch.nn.functional.cosine_similarity(g1, g0, dim=0)) > 0.999
