@@ -708,29 +708,34 @@ __device__ __forceinline__ void gemm_epilogue_lds(const UiaGemmParams& p, f32x4 
                 // the tile's 2 x (rows of the workgroup) sums — the first form issued two 8-lane atomic instructions per row pass and wave column
                 // (256 instructions per 256 x 256 tile, 4 x the atomics; ~15 us of a 176 us launch).  Partials meet in a fixed order: still bit-reproducible.
                 static_assert(WTN == 64, "four wave columns");
-                constexpr int RW = 2 * WTM;                                   // floats a wave leaves: (Σ, Σ²) of its WTM rows
-                __builtin_amdgcn_wave_barrier();
-                float* ex = (float*)smem;                                     // the patches are dead: [waves][RW]
+                constexpr int RW = 2 * WTM;                                   // values a wave leaves: (Σ, Σ²) of its WTM rows
+                // each partial goes to fixed point on its own (exactly what its atomic would have added), the integers are summed: bit-identical to
+                // the in-line form, whatever the order
+                auto to_fixed = [&](float v, bool sq) -> long long {
+                    if (!(fabsf(v) < ROWSUM_PART_MAX)) {
+                        if (p.ln_flag) atomicOr(p.ln_flag, 2);
+                        v = fminf(fmaxf(v, sq ? 0.0f : -ROWSUM_PART_MAX), ROWSUM_PART_MAX);
+                    }
+                    return llrintf(v * ROWSUM_SCALE);
+                };
+                long long* ex = (long long*)smem;                             // the patches are dead: [waves][RW]
                 __syncthreads();                                              // every wave is done with its patch
                 if ((lane % LPR) == 0) {
 #pragma unroll
-                    for (int k = 0; k < NCH * CH; ++k) *(float2*)(ex + wave * RW + 2 * (k * RPP + rr)) = float2{rs1[k], rs2[k]};
+                    for (int k = 0; k < NCH * CH; ++k) {
+                        long long* d = ex + wave * RW + 2 * (k * RPP + rr);
+                        d[0] = to_fixed(rs1[k], false);
+                        d[1] = to_fixed(rs2[k], true);
+                    }
                 }
                 __syncthreads();
                 const int nwaves = (int)(blockDim.x >> 6), wm_n = nwaves / 4;  // wave rows of the workgroup
                 for (int idx = wave * 64 + lane; idx < wm_n * RW; idx += nwaves * 64) {
                     const int wmr = idx / RW, off = idx - wmr * RW;           // off = 2 * row + which
-                    const float* src = ex + (wmr * 4) * RW + off;
-                    float v = (src[0] + src[RW]) + (src[2 * RW] + src[3 * RW]);
+                    const long long* src = ex + (wmr * 4) * RW + off;
+                    const long long v = (src[0] + src[RW]) + (src[2 * RW] + src[3 * RW]);
                     const int m = m0 + wmr * WTM + (off >> 1);
-                    if (m < p.M) {
-                        const bool sq = off & 1;
-                        if (!(fabsf(v) < ROWSUM_PART_MAX)) {
-                            if (p.ln_flag) atomicOr(p.ln_flag, 2);
-                            v = fminf(fmaxf(v, sq ? 0.0f : -ROWSUM_PART_MAX), ROWSUM_PART_MAX);
-                        }
-                        atomicAdd((unsigned long long*)p.rowsum_out + 2 * (size_t)m + (off & 1), (unsigned long long)llrintf(v * ROWSUM_SCALE));
-                    }
+                    if (m < p.M) atomicAdd((unsigned long long*)p.rowsum_out + 2 * (size_t)m + (off & 1), (unsigned long long)v);
                 }
             }
         } else {
