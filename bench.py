@@ -74,6 +74,7 @@ def parse():
     ap.add_argument("--mona-fused", action="store_true", help="A/B knob: the adapter forward as ONE launch (uia_mona_fused_fwd) instead of pre, project1, spatial, project2")
     ap.add_argument("--no-tail-split", action="store_true", help="A/B knob: no half-height tiles for the M tail of a launch")
     ap.add_argument("--no-lora-kext", action="store_true", help="A/B knob: the LoRA rank update as a launch of its own (tile cfg 23) instead of inside the frozen GEMM's K loop")
+    ap.add_argument("--quad", action="store_true", help="experiment knob: 256x256 bf16 launches on the four-wave kernel (tile cfg 25, csrc/gemm_quad.hip) instead of the eight-wave ring kernel")
     ap.add_argument("--ring5", action="store_true", help="experiment knob: long-K / wide-N 256x256 launches on the 5-deep ring (tile cfg 24) instead of the 4-deep one")
     ap.add_argument("--no-tail-split-k", action="store_true", help="A/B knob: the M tail launches run their whole K chain (default: long-K tails of a few tiles are split over K)")
     ap.add_argument("--no-half-height-short-k", action="store_true", help="A/B knob: N <= 768, K <= 768 launches with a ragged last round as main + tail launches (round 2) "
@@ -355,6 +356,7 @@ def main():
     ops.KBLOCK_W, ops.TAIL_SPLIT, ops.K64_CFG14 = not args.no_kblock_w, not args.no_tail_split, not args.no_k64_cfg14
     ops.TAIL_SPLIT_K = not args.no_tail_split_k
     ops.RING5 = args.ring5
+    ops.QUAD = args.quad
     ops.LORA_KEXT = not args.no_lora_kext
     ops.KBLOCK_ACT = not args.no_kblock_act
     ops.HALF_HEIGHT_SHORT_K = not args.no_half_height_short_k

@@ -31,6 +31,9 @@ _SPECIALISED = {EPI_BIAS | EPI_RESID | EPI_OUT32, EPI_BIAS | EPI_RESIDT | EPI_OU
                 EPI_BIAS | EPI_RESID_LO | EPI_RESID_LN | EPI_OUTT | EPI_OUT_LO | EPI_ROWSUM,
                 EPI_BIAS | EPI_RESID | EPI_OUTT | EPI_OUT_LO | EPI_ROWSUM, EPI_BIAS | EPI_RESID_LO | EPI_OUT32}
 
+# the masks csrc/gemm_quad.hip instantiates (tile cfg 25); the rest run its run-time epilogue
+_QUAD_SPECIALISED = _SPECIALISED - {EPI_BIAS | EPI_RESIDT | EPI_OUT32, EPI_BIAS | EPI_RESID | EPI_RESID_LN | EPI_OUT32, EPI_BIAS | EPI_RESID | EPI_RESID_LN | EPI_OUT32 | EPI_OUTT | EPI_ROWSUM}
+
 
 def epi_mask_of(d):
     """Mirror of epi_mask_of() in csrc/gemm.hip: the compile-time epilogue instantiation a descriptor lands on."""
@@ -61,13 +64,14 @@ def auto_tile_cfg(M, N, K=None, esz=2, mask=EPI_GENERIC):
     return 8
 
 
-RING_CFGS = (8, 9, 10, 12, 13, 14, 24)
+RING_CFGS = (8, 9, 10, 12, 13, 14, 24, 25, 26)
 PERSIST_STORE_ONLY = False   # experiment knob: 256x256 ring launches whose epilogue only stores T results run on the persistent variant (cfg 12)
 KBLOCK_W = True          # hand the ring kernels their weights K-blocked (PackedW.kblocked()); False = row-major everywhere
 K64_CFG14 = True         # single-K-step GEMMs on the two-workgroups-per-CU half-height config (False: 256x256 like every other large shape)
 TILE_GROUP = {}          # experiment knob: {N: row panels per tile-order group} overriding the launcher's choice for ring launches with that N
 HALF_HEIGHT_SHORT_K = True   # N <= 768, K <= 768 (bf16) launches whose 256-row tiling leaves a ragged last round run on half-height tiles (cfg 14) in one launch
 TAIL_SPLIT = True        # split off the M tail of a launch whose last round of 256x256 tiles would leave most CUs idle
+QUAD = False             # 256x256 bf16 launches on the four-wave kernel (tile cfg 25, csrc/gemm_quad.hip: 128 x 128 per wave, one wave per SIMD) instead of cfg 8
 RING5 = False            # experiment knob: 256x256 launches with a long K loop or a wide N on the 5-deep ring (tile cfg 24: 160 KB of LDS, four sub-tiles in flight)
 LORA_KEXT = True         # LoraAttnHalfFn: the rank update inside the frozen GEMM's K loop (uia_gemm_desc.A2 / K2) instead of a read-modify-write launch of its own
 TAIL_SPLIT_K = True      # ... and run that tail split over K when it is a few tiles with a long K chain (two launches: slice partials, then sum + epilogue).
@@ -88,6 +92,8 @@ def big_tile_cfg(N, K, esz):
     """8 or 24 for a launch auto_tile_cfg() puts on the 256x256 ring tiles.  Isolated, plain epilogue (tools/time_ring_depth.py) the fifth ring slot is
     worth 4-5.5 % at K = 3072 and at 43 520 rows and 0.5-1.6 % at 65 536 x {2304, 3072} x 768 (and costs 7 % at N = 768, K = 768); inside the step, behind the
     fused epilogues, it is level to slightly worse on every one of those launches (44.5-44.9 ms either way, three alternating pairs on one box): opt-in."""
+    if QUAD and esz == 2:
+        return 25
     return 24 if (RING5 and esz == 2 and (K * esz >= 2048 or N >= 2304)) else 8
 
 
@@ -333,6 +339,9 @@ def gemm_kernel_name(cfg, mask, dtype):
     if cfg in (8, 13, 14, 24):
         bm, nbuf = (256, 4) if cfg == 8 else ((256, 5) if cfg == 24 else ((128, 4) if cfg == 13 else (128, 3)))
         return f"gemm_tn_ring_kernel<{tn},{bm},256,2,4,64,{nbuf},{m}>", "gemm_tn_ring_kernelI" + tc + "".join(mi(v) for v in (bm, 256, 2, 4, 64, nbuf, m, 0)) + "Lb0ELb0EE"
+    if cfg in (25, 26):
+        mq = m if (cfg == 25 and m in _QUAD_SPECIALISED) else EPI_GENERIC
+        return f"gemm_tn_quad_kernel<{mq},false>", f"gemm_tn_quad_kernelI{mi(mq)}Lb0EE"
     if cfg == 16:
         return "gemm_skinny64_kernel", "gemm_skinny64_kernel"
     if cfg == 23:

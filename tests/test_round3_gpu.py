@@ -135,7 +135,7 @@ def test_pipelined_epilogue_equals_inline_epilogue_bit_for_bit(M, N, K):
     """Round 3: the compile-time epilogue masks that read an operand or leave row sums (aux_in with GELU', fp32 / T residual, deferred-LayerNorm
     residual, row sums) request their rows a chunk ahead and issue the row-sum atomics after the last store.  Same arithmetic in the same order:
     on RAGGED shapes (last row panel and last column tile partial) every output must equal, bit for bit, what tile cfg 10 — the same ring kernel
-    with the run-time epilogue and its in-line loads — produces, on the 256-row tiles (8) and on both half-height configs (13, 14)."""
+    with the run-time epilogue and its in-line loads — produces, on the 256-row tiles (8), on both half-height configs (13, 14) and on the four-wave kernel of round 4 (25 / 26: two epilogue calls per wave tile)."""
     from uia_hip import ops
     g = torch.Generator(device="cpu").manual_seed(M + N + K)
     dt = torch.bfloat16
@@ -191,7 +191,7 @@ def test_pipelined_epilogue_equals_inline_epilogue_bit_for_bit(M, N, K):
     for kind in ("plain", "bias", "gelu", "gelu_stash", "lnfold_bias", "lnfold_gelu", "lnfold_gelu_stash", "qgelu", "qgelu_stash", "dqgelu",
                  "dgelu", "resid32", "residT", "fold_producer", "resid_ln", "resid_ln_sums_fold_producer"):
         ref = run(10, kind)
-        for cfg in (8, 13, 14):
+        for cfg in (8, 13, 14, 25, 26):                                  # 25 / 26: the four-wave kernel (round 4), compile-time and run-time epilogue
             got = run(cfg, kind)
             for name, x, y in zip(("out32", "outT", "rowsum"), got, ref):
                 same = torch.equal(x, y) if x.dtype == torch.int64 else torch.equal(torch.nan_to_num(x.float(), nan=-7.0), torch.nan_to_num(y.float(), nan=-7.0))

@@ -337,3 +337,55 @@ def test_block_internal_three_byte_tensors_match_fp32_form():
         UF.set_block_resid3(False)
     assert rel(f1, f0) < 5e-3                                              # 15 stored mantissa bits against 24; bf16 results re-roll their last bits on any 1e-5 change upstream
     assert float(torch.nn.functional.cosine_similarity(g1, g0, dim=0)) > 0.999
+
+
+# ------------------------------------------------------------------------------------------------ four waves of 128 x 128 (tile cfg 25, csrc/gemm_quad.hip)
+@pytest.mark.parametrize("M,N,K", [(65536, 768, 768), (4100, 2304, 3072), (2305, 776, 64), (257, 264, 128)])
+def test_four_wave_gemm_equals_the_ring_kernel_bit_for_bit(M, N, K):
+    """Tile cfg 25 runs the 256 x 256 tile on four waves of 128 x 128 (one per SIMD, accumulators pinned to the AGPRs, free-running K loop) and the
+    LDS-patch epilogue once per 64-column half.  Every output element is the same chain of MFMA K steps followed by the same epilogue arithmetic
+    as on the eight-wave ring kernel: plain store, K-blocked operands and result, three-byte residual in / three-byte result + row sums out, and
+    the K extension must all agree with cfg 8 bit for bit (ragged M / N included)."""
+    from uia_hip import ops
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    dt = torch.bfloat16
+    a = torch.randn(M, K, generator=g).to(dev()).to(dt)
+    w = ops.PackedW((torch.randn(N, K, generator=g) * K ** -0.5).to(dev()).to(dt))
+    bias = torch.randn(N, generator=g).to(dev())
+    outs = {}
+    for cfg in (8, 25):
+        o = torch.full((M, N), float("nan"), device=dev(), dtype=dt)
+        ops.gemm(a, w, bias=bias, act="gelu", out_t=o, tile_cfg=cfg)
+        outs[cfg] = o
+    assert torch.equal(outs[8], outs[25]) and not torch.isnan(outs[25].float()).any()
+    assert rel(outs[25], torch.nn.functional.gelu(a.float() @ w.row.float().T + bias)) < 1e-2
+    if N % 64 == 0 and K % 32 == 0 and M > 2048:
+        # K-blocked A and result; three-byte residual (deferred LayerNorm) in, three-byte result + row sums out
+        prev = torch.randn(M, N, generator=g).to(dev()) * 3 + 0.5
+        hi, lo = ops.float_to_three_byte(prev)
+        prev3 = ops.three_byte_to_float(hi, lo)
+        stats = torch.stack([prev3.mean(1), (prev3.var(1, unbiased=False) + 1e-12).rsqrt()], 1).contiguous()
+        lw, lb = torch.randn(N, generator=g).to(dev()), torch.randn(N, generator=g).to(dev())
+        res = {}
+        for cfg in (8, 25):
+            out_t, out_lo = ops.kb_empty(M, N, dt, dev()), ops.kb_empty(M, N, torch.int8, dev())
+            sums = torch.zeros(M, 2, device=dev(), dtype=torch.int64)
+            ops.gemm(_kb(a), w, bias=bias, resid3=(_kb(hi), _kb(lo)), resid_ln=(stats, lw, lb), out_t=out_t, out_lo=out_lo, rowsum=sums, tile_cfg=cfg)
+            res[cfg] = (out_t.t.clone(), out_lo.t.clone(), sums)
+        for x, y in zip(res[8], res[25]):
+            assert torch.equal(x, y)
+    if K >= 96 and N % 256 == 0:
+        # K extension: the last 64 columns of the K loop come from a second operand (LoRA rank update)
+        from uia_hip import functional as UF
+        D = K
+        ws = [torch.nn.Parameter((torch.randn(N // 3 if N % 768 == 0 else N, D, generator=g) * D ** -0.5).to(dev()), requires_grad=False) for _ in range(3 if N % 768 == 0 else 1)]
+        Bs = [torch.nn.Parameter((torch.randn(wi.shape[0], 16, generator=g) * 0.1).to(dev())) for wi in ws]
+        ext = UF.WEIGHTS.get_lora_ext(tuple(ws), tuple(Bs), 2.0, dt)
+        t_all = torch.zeros(len(ws), M, 64, device=dev(), dtype=dt)
+        t_all[:, :, :16] = torch.randn(len(ws), M, 16, generator=g).to(dev()).to(dt)
+        ys = {}
+        for cfg in (8, 25):
+            y = torch.full((M, N), float("nan"), device=dev(), dtype=dt)
+            ops.gemm(a, ext, bias=bias, out_t=y, a2=(t_all, ws[0].shape[0]) if len(ws) > 1 else (t_all[0], 0), tile_cfg=cfg)
+            ys[cfg] = y
+        assert torch.equal(ys[8], ys[25]) and not torch.isnan(ys[25].float()).any()
