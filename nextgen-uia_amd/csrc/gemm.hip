@@ -1033,7 +1033,9 @@ __global__ __launch_bounds__(64 * NWV) void gemm_skinny64_kernel(const UiaGemmPa
     const uint32_t drop_th = dropout_thresh16(p.drop_p);
     const float drop_inv = 1.0f / (1.0f - p.drop_p);
     const int ntiles = (p.M + 15) >> 4;
-    for (int tile = blockIdx.x * NWV + wave; tile < ntiles; tile += gridDim.x * NWV) {
+    // tiles are dealt wave-major: wave w of workgroup b starts at tile w·grid + b, so a launch with fewer tiles than wave slots still puts work on
+    // every CU (ViT-L/14: 2056 tiles — dealt workgroup-major they filled 129 of the 256 CUs, or left eight tiles for a second pass)
+    for (int tile = wave * gridDim.x + blockIdx.x; tile < ntiles; tile += gridDim.x * NWV) {
         const int m = 16 * tile + li;
         const int mc = m < p.M ? m : p.M - 1;
         const char* arow = (const char*)p.A + ((size_t)mc * p.lda) * 2 + g * 16;
@@ -1089,19 +1091,15 @@ int launch_skinny64(hipStream_t stream, const UiaGemmParams& p) {
     UIA_ENSURE_LDS_ATTR(once8, gemm_skinny64_kernel<8>, 160 * 1024);
     const int ncu = uia_num_cus();
     const int ntiles = (p.M + 15) / 16;
-    int grid = (ntiles + 7) / 8;
-    grid = grid < ncu ? grid : ncu;
-    {   // Sixteen waves per CU when eight would need a second, partly filled pass over the tiles (M = 50 432: 3152 tiles for 2048 waves):
-        // every tile is then in flight at once (4 waves per SIMD at <= 128 VGPRs).
+    const int grid = ntiles < ncu ? ntiles : ncu;
+    {   // Sixteen waves per CU when eight would need a second, partly filled pass over the tiles (M = 50 432: 3152 tiles for 2048 waves; ViT-L/14's
+        // M = 32 896: 2056): every tile is then in flight at once (4 waves per SIMD at <= 128 VGPRs), the dropout variant included.
         static UiaDevOnce once16;
         const char* env = getenv("UIA_SKINNY_WAVES");
         const int want = env ? atoi(env) : 0;
-        const bool two_pass = ntiles > 8 * ncu && ntiles <= 16 * ncu;
-        if ((want == 16 || (want == 0 && two_pass)) && !p.drop_where) {
+        if (want == 16 || (want == 0 && ntiles > 8 * ncu)) {
             UIA_ENSURE_LDS_ATTR(once16, (gemm_skinny64_kernel<8, 16>), 160 * 1024);
-            int g16 = (ntiles + 15) / 16;
-            g16 = g16 < ncu ? g16 : ncu;
-            hipLaunchKernelGGL((gemm_skinny64_kernel<8, 16>), dim3(g16), dim3(1024), lds, stream, p);
+            hipLaunchKernelGGL((gemm_skinny64_kernel<8, 16>), dim3(grid), dim3(1024), lds, stream, p);
             UIA_CHECK_LAUNCH();
             return 0;
         }

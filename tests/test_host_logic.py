@@ -1,11 +1,13 @@
 """CPU: host-side logic of the drop-in surface — names (the checkpoint wire format), injector behaviour, parameter counts,
 error behaviour, and the absence of any CPU fallback on the product path."""
 import math
+import os
 
 import numpy as np
 import pytest
 import torch
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TOY = dict(embed_dim=128, vision_cfg=dict(img_size=32, patch_size=8, embed_dim=128, depth=3, num_heads=2),
            text_cfg=dict(vocab_size=120, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
                          max_position_embeddings=40))
@@ -256,3 +258,29 @@ def test_gemm_schedule_mirrors_are_pure_host_logic():
     m = ops.EPI_QUICK | ops.EPI_BIAS | ops.EPI_GELU | ops.EPI_OUTT
     assert m in ops._SPECIALISED and (m | ops.EPI_LNFOLD) in ops._SPECIALISED and (ops.EPI_QUICK | ops.EPI_DGELU | ops.EPI_OUTT) in ops._SPECIALISED
     assert ops.gemm_kernel_name(8, 977, __import__("torch").bfloat16)[1].endswith("Li977ELi0ELb0ELb0EE")
+
+
+def test_committed_traffic_file_names_the_kernels_the_headline_step_runs():
+    """bench.py's roofline.traffic comes from profiles/<bench.TRAFFIC_FILE> (tools/pmc_traffic.sh), keyed by the mangled instantiation name.  VERDICT
+    r03: the round-3 file was generated before the last rename and bench printed traffic: null.  Host-side check that every 256 x 256 ring
+    instantiation the headline step (mona, bf16, LayerNorm folded, three-byte text residual) can put on top is a key of the committed file, so a
+    rename of a template argument or a new epilogue mask fails here, on the CPU, and not as a silent null on the GPU box."""
+    import importlib.util
+    import json
+    import torch
+    from uia_hip import ops
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    data = json.load(open(os.path.join(ROOT, "profiles", bench.TRAFFIC_FILE)))
+    assert set(data) == {"FETCH_SIZE", "WRITE_SIZE"}
+    headline = [ops.EPI_BIAS | ops.EPI_RESID_LO | ops.EPI_RESID_LN | ops.EPI_OUTT | ops.EPI_OUT_LO | ops.EPI_ROWSUM,     # text tower sub-layer sums (three-byte tensors)
+                ops.EPI_BIAS | ops.EPI_OUTT | ops.EPI_LNFOLD,                                                          # QKV with the folded LayerNorm
+                ops.EPI_BIAS | ops.EPI_GELU | ops.EPI_OUTT | ops.EPI_LNFOLD,                                           # fc1, frozen tower
+                ops.EPI_BIAS | ops.EPI_GELU | ops.EPI_AUX_OUT | ops.EPI_OUTT | ops.EPI_LNFOLD,                         # fc1 with the stash
+                ops.EPI_DGELU | ops.EPI_OUTT, ops.EPI_OUTT, ops.EPI_BIAS | ops.EPI_RESID | ops.EPI_OUT32]              # data gradients, fc2 / proj
+    for mask in headline:
+        frag = ops.gemm_kernel_name(8, mask, torch.bfloat16)[1]
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            assert frag in data[counter], (mask, frag, sorted(data[counter])[:3])
+            assert data[counter][frag]["launches"] > 0 and data[counter][frag]["sum"] > 0
