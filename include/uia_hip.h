@@ -289,6 +289,27 @@ typedef struct uia_mona_fused_desc {
 int uia_mona_fused_supported(int dtype, int D, int h, int w, int bott);
 int uia_mona_fused_fwd(void* stream, int dtype, const uia_mona_fused_desc* d);
 
+/* ---- LoRA rank update of a data gradient, up to three sources in one pass (csrc/lora_rank.hip) ----
+ * Replaces, in the backward of the reference's LinearLoRA (src/adapters/lora.py:78-90: result += dropout(x) @ A.T @ B.T * scaling, one nn.Dropout per
+ * wrapped Linear) applied to q, k and v of an OpenAI-CLIP block (inject_lora_to_clip, lora.py:115-199), the three read-modify-write launches
+ *     dh += mask_i * (alpha * Q_i @ W_i.T) / (1 - p)        Q_i = dy_i @ B_i  [M, 64] (rank zero-padded to 64),  W_i = A_i.T  [N, 64]
+ * by ONE pass over dh.  bf16; N % 256 == 0 and nsrc * N/4 * 144 bytes <= 160 KB (N <= 1024 with three sources).
+ *   Q        bf16 [nsrc][M][ldq >= 64]; source s starts q_stride elements after source s-1
+ *   W[s]     bf16 [N][ldw >= 64]
+ *   out      bf16 [M][ldo >= N], read and written in place
+ *   drop_p   0 = no dropout; otherwise mask_s is drawn per 8 output columns from (seed[s], (m*N + n) / 8) exactly as uia_dropout /
+ *            uia_gemm_desc.drop_where = 2 draw it for an [M, N] tensor, so the forward's masks are reproduced from the seeds alone */
+typedef struct uia_lora_rank_desc {
+    int32_t M, N, nsrc;
+    float alpha;
+    const void* Q; int64_t ldq, q_stride;
+    const void* W[3]; int64_t ldw;
+    void* out; int64_t ldo;
+    float drop_p;
+    uint64_t seed[3];
+} uia_lora_rank_desc;
+int uia_lora_rank_update(void* stream, int dtype, const uia_lora_rank_desc* d);
+
 /* ---------------------------------------------------------------------------------------------
  * Task heads of the feature-pyramid adapter (reference src/third_party/timm/clip_adapter.py:47-57, 118-160).
  * uia_upsample_bilinear_fwd: nn.Upsample((H,W), mode="bilinear", align_corners=False) of a token-major map

@@ -492,7 +492,7 @@ struct cfalse { static constexpr bool value = false; };
 template <int V> struct cint { static constexpr int value = V; };
 
 template <int NW, bool VLDS, bool OLDS>
-__global__ __launch_bounds__(64 * NW, 2) void attn_bwd_units_kernel(const UiaAttnParams p) {
+__global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void attn_bwd_units_kernel(const UiaAttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KVS = VLDS ? 4096 : 2048;                    // bytes per 16-key tile of the K (| V) region
     constexpr bool KGLOBAL = false, QGLOBAL = false;           // every operand fragment comes from the head's LDS images
@@ -1040,7 +1040,7 @@ int launch_persist(hipStream_t stream, const UiaAttnParams& p) {
 }  // namespace
 
 int uia_attn_bwd_launch(hipStream_t stream, int dtype, const UiaAttnParams& p, int cfg) {
-    UIA_CHECK_ARG(cfg >= 0 && cfg <= 6, "uia_attn_bwd: unknown kernel configuration %d", cfg);
+    UIA_CHECK_ARG(cfg >= 0 && cfg <= 8, "uia_attn_bwd: unknown kernel configuration %d", cfg);
     UIA_CHECK_ARG(dtype == UIA_BF16 || dtype == UIA_F32, "uia_attn_bwd: bad dtype %d", dtype);
     UIA_CHECK_ARG(p.B > 0 && p.H > 0 && p.L > 0, "uia_attn_bwd: empty problem");
     UIA_CHECK_ARG(p.scale > 0.f && p.scale < 3.0e38f, "uia_attn_bwd: scale must be positive and finite (matches the forward's lse), got %g", (double)p.scale);
@@ -1074,6 +1074,8 @@ int uia_attn_bwd_launch(hipStream_t stream, int dtype, const UiaAttnParams& p, i
     if (cfg == 0) cfg = 2;
     if (cfg == 2) return LT <= OLDS_LT_MAX ? launch_units<8, true, true>(stream, p) : launch_units<8, true, false>(stream, p);
     if (cfg == 6) return launch_units<8, true, false>(stream, p);       // cfg 2 with δ's operands from global memory at every length
+    if (cfg == 7) return LT <= OLDS_LT_MAX ? launch_units<12, true, true>(stream, p) : launch_units<12, true, false>(stream, p);   // three waves per SIMD (<= 168 VGPRs)
+    if (cfg == 8) return LT <= OLDS_LT_MAX ? launch_units<16, true, true>(stream, p) : launch_units<16, true, false>(stream, p);   // four (<= 128 VGPRs)
     if (cfg == 3) return launch_units<4, false, false>(stream, p);
     if (cfg == 4) return launch_units<8, false, false>(stream, p);
     if (cfg == 5) {

@@ -908,17 +908,6 @@ __global__ __launch_bounds__(512) void gemm_tn_persist_kernel(const UiaGemmParam
 #undef UIA_SLOT_END
 }
 
-inline int uia_num_cus() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                ? prop.multiProcessorCount : 256;
-    }
-    return n;
-}
-
 template <typename T, int EPI>
 int launch_persist_epi(hipStream_t stream, const UiaGemmParams& p) {
     constexpr int LDS = 4 * 512 * 64 + ((EPI == EPI_GENERIC || (EPI & EPI_LNFOLD) != 0) ? 4 * 256 * 8 : 0);

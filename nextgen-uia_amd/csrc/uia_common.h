@@ -57,6 +57,18 @@ struct UiaDevOnce {
         }                                                                                                          \
     } while (0)
 
+// compute units of the current device (cached on first use; 256 on MI355X)
+inline int uia_num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                ? prop.multiProcessorCount : 256;
+    }
+    return n;
+}
+
 // ---------------------------------------------------------------- element load/store
 __device__ __forceinline__ float to_f32(float x) { return x; }
 __device__ __forceinline__ float to_f32(bf16_t x) { return (float)x; }

@@ -59,6 +59,12 @@ class MonaSpatialDesc(C.Structure):
                 ("g_proj_w", vp), ("g_proj_b", vp), ("g_freq", vp), ("g_ne1_w", vp), ("g_ne1_b", vp), ("g_ne3_w", vp), ("g_ne3_b", vp), ("ws", vp)]
 
 
+class LoraRankDesc(C.Structure):
+    """uia_lora_rank_desc (include/uia_hip.h): out += sum_i drop_i(alpha * Q_i @ W_i.T), up to three rank-64 sources in one pass."""
+    _fields_ = [("M", i32), ("N", i32), ("nsrc", i32), ("alpha", f32), ("Q", vp), ("ldq", i64), ("q_stride", i64), ("W", vp * 3), ("ldw", i64),
+                ("out", vp), ("ldo", i64), ("drop_p", f32), ("seed", C.c_uint64 * 3)]
+
+
 class MonaFusedDesc(C.Structure):
     """uia_mona_fused_desc (include/uia_hip.h): the whole adapter forward of one image in one workgroup."""
     _fields_ = [("sp", MonaSpatialDesc), ("D", i32), ("eps", f32), ("x", vp), ("norm_w", vp), ("norm_b", vp), ("gamma", vp), ("gammax", vp),
@@ -79,6 +85,7 @@ PROTOTYPES = {
     "uia_layernorm_fwd": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, i64, vp, vp, vp, f32, vp, vp]),
     "uia_layernorm_fwd_stats": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, i64, vp, vp, vp, f32, vp, vp, vp]),
     "uia_layernorm_bwd": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, i64, vp, vp, vp, f32, vp, vp, vp]),
+    "uia_lora_rank_update": (C.c_int, [vp, C.c_int, C.POINTER(LoraRankDesc)]),
     "uia_layernorm_bwd3": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, i64, vp, vp, vp, vp, i64, vp, f32, vp, vp, vp, vp, vp, vp]),
     "uia_mona_pre_fwd": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, f32, vp]),
     "uia_mona_pre_bwd": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, i64]),

@@ -1274,13 +1274,19 @@ class LoraAttnHalfFn(torch.autograd.Function):
         if need_dx:
             ops.gemm(dqkv, WEIGHTS.get_cat((wq, wk, wv), dt, transpose=True), out_t=dh)
         grads = []
+        # the three rank terms Σ_i mask_i ⊙ (s·q_i·A_i) reach dh in ONE read-modify-write pass (uia_lora_rank_update) instead of one per projection
+        one_pass = need_dx and rp == 64 and x2.is_cuda and ops.LORA_RANK3 and ops.lora_rank_update_ok(3, D, dt)
+        q_all = _empty((3, M, rp), dt, x2)
         for i, (bias, A, Bm, t, hd) in enumerate(((bq, aq, Bq, tq, hq), (bk, ak, Bk, tk, hk), (bv, av, Bv, tv, hv))):
             dsl = dqkv[:, i * D:(i + 1) * D]
-            qi = _empty((M, rp), dt, x2)
+            qi = q_all[i]
             ops.gemm(dsl, WEIGHTS.get(Bm, dt, transpose=True, pad_cols_to=rp), out_t=qi)
-            if need_dx:
+            if need_dx and not one_pass:
                 ops.gemm(qi, WEIGHTS.get(A, dt, transpose=True, pad_rows_to=rp), alpha=scaling, resid_t=dh, out_t=dh, drop=drop(i))
             grads.append(_lora_grads(dsl, t, hd, qi, A, Bm, bias, scaling, direct))
+        if one_pass:
+            ats = [WEIGHTS.get(A, dt, transpose=True, pad_rows_to=rp) for A in (aq, ak, av)]
+            ops.lora_rank_update(q_all, [a.row if isinstance(a, ops.PackedW) else a for a in ats], dh, scaling, p_drop, seeds[:3])
         grads.append(g_o)
         # ---- LayerNorm: dx = dx1 + LN'(dh); the T copy goes to the block below (its MLP half starts with a data-gradient GEMM)
         dx = None

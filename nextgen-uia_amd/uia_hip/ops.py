@@ -9,7 +9,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import AttnDesc, GemmDesc, MonaFusedDesc, MonaSpatialDesc, PackDesc, UiaError, check, lib
+from ._lib import AttnDesc, GemmDesc, LoraRankDesc, MonaFusedDesc, MonaSpatialDesc, PackDesc, UiaError, check, lib
 
 _ACT = {None: 0, "none": 0, "gelu": 1, "quick_gelu": 2, "relu": 3}
 
@@ -71,6 +71,8 @@ K64_CFG14 = True         # single-K-step GEMMs on the two-workgroups-per-CU half
 TILE_GROUP = {}          # experiment knob: {N: row panels per tile-order group} overriding the launcher's choice for ring launches with that N
 HALF_HEIGHT_SHORT_K = True   # N <= 768, K <= 768 (bf16) launches whose 256-row tiling leaves a ragged last round run on half-height tiles (cfg 14) in one launch
 TAIL_SPLIT = True        # split off the M tail of a launch whose last round of 256x256 tiles would leave most CUs idle
+TAIL_SIDE_STREAM = True  # a SMALL M tail (at most a quarter of the CUs' worth of half-height tiles) runs on a side stream beside the main launch instead of behind it
+LORA_RANK3 = True        # q | k | v of a LoRA block: the three rank terms of the data gradient in one pass over it (uia_lora_rank_update) instead of three K = 64 launches
 QUAD = False             # 256x256 bf16 launches on the four-wave kernel (tile cfg 25, csrc/gemm_quad.hip: 128 x 128 per wave, one wave per SIMD) instead of cfg 8
 RING5 = False            # experiment knob: 256x256 launches with a long K loop or a wide N on the 5-deep ring (tile cfg 24: 160 KB of LDS, four sub-tiles in flight)
 LORA_KEXT = True         # LoraAttnHalfFn: the rank update inside the frozen GEMM's K loop (uia_gemm_desc.A2 / K2) instead of a read-modify-write launch of its own
@@ -78,6 +80,7 @@ TAIL_SPLIT_K = True      # ... and run that tail split over K when it is a few t
                          # Its slices meet through hardware float atomics: the rows of such a tail (<= 1/4 of the CUs busy: the ViT-L/14 + LoRA step, not the
                          # headline) vary in the last bit from run to run; set_deterministic(True) in functional turns it off.
 _SPLITK_WS = {}
+_TAIL_SIDE = {}
 _NCU = {}
 
 
@@ -116,6 +119,42 @@ def splitk_workspace(floats, device):
     if t is None or t.numel() < floats:
         t = _SPLITK_WS[key] = torch.zeros(max(floats, 1 << 20), device=device, dtype=torch.float32)     # zero once: the launches leave it zero
     return t
+
+
+class _TailFork:
+    """Fork / join around the tail launches of a split GEMM: `with fork:` enqueues on a side stream that starts where the caller's stream stands;
+    fork.join() makes the caller's stream wait for it.  ViT-L/14 at 128 pairs has M = 128·257 rows: 128 full row panels (exactly two rounds of
+    256 x 256 tiles at N = 1024) and ONE half panel, whose 4-16 tiles ran for 16 us per launch (x 2 with split K) BEHIND a 75-300 us main launch —
+    pure latency, 2.3 ms per step.  Beside the main launch they cost a few CUs a few microseconds."""
+
+    def __init__(self, device):
+        self.cur = torch.cuda.current_stream(device)
+        key = (device.index if device.index is not None else torch.cuda.current_device(), self.cur.cuda_stream)
+        e = _TAIL_SIDE.get(key)
+        if e is None:
+            e = _TAIL_SIDE[key] = (torch.cuda.Stream(device=device), torch.cuda.Event(), torch.cuda.Event())
+        self.side, self.ev_in, self.ev_out = e
+        self.ctx = None
+
+    def __enter__(self):
+        self.ev_in.record(self.cur)
+        self.side.wait_event(self.ev_in)
+        self.ctx = torch.cuda.stream(self.side)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        self.ev_out.record(self.side)
+        self.ctx.__exit__(*exc)
+        return False
+
+    def join(self):
+        self.cur.wait_event(self.ev_out)
+
+
+def small_tail(rows, N, ncu):
+    """True when the tail of `rows` rows is few enough half-height tiles to run beside the main launch (TAIL_SIDE_STREAM)."""
+    return TAIL_SIDE_STREAM and 4 * (-(-rows // 128) * -(-N // 256)) <= ncu
 
 
 def drop_splitk_workspace(device):
@@ -409,11 +448,22 @@ def gemm(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None, res
             raise UiaError(f"gemm: a2 operand {tuple(t2.shape)} does not match [groups, {M}, {w.K2}] with {w.N} columns in groups of {gcols}")
         m_main = tail_split_rows(M, w.N, num_cus(a.device.index)) if (TAIL_SPLIT and tile_cfg == 0 and M > 2048) else M
         cut = lambda t, lo, hi: None if t is None else t[lo:hi]
-        for lo, hi, cfg in (((0, m_main, 8), (m_main, M, 13)) if m_main < M else ((0, M, tile_cfg or (8 if M > 2048 else 13)),)):
+        def part(lo, hi, cfg):
             _gemm_one(a[lo:hi], w, bias=bias, act=act, dact=dact, aux_in=cut(aux_in, lo, hi), aux_out=cut(aux_out, lo, hi), resid=cut(resid, lo, hi),
                       resid_t=cut(resid_t, lo, hi), out_t=cut(out_t, lo, hi), out32=cut(out32, lo, hi), alpha=alpha, tile_cfg=cfg,
                       resid_ln=None if resid_ln is None else (resid_ln[0][lo:hi],) + tuple(resid_ln[1:]), rowsum=cut(rowsum, lo, hi),
                       lnfold=None if lnfold is None else (lnfold[0][lo:hi],) + tuple(lnfold[1:]), a2=(t2[..., lo:hi, :], gcols))
+        if m_main >= M:
+            part(0, M, tile_cfg or (8 if M > 2048 else 13))
+        elif a.is_cuda and small_tail(M - m_main, w.N, num_cus(a.device.index)):
+            fork = _TailFork(a.device)
+            with fork:
+                part(m_main, M, 13)
+            part(0, m_main, 8)
+            fork.join()
+        else:
+            part(0, m_main, 8)
+            part(m_main, M, 13)
         return
     packed = w if isinstance(w, PackedW) else None
     wrow = packed.row if packed is not None else w
@@ -432,18 +482,33 @@ def gemm(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None, res
         if m_main < M:
             cut = lambda t, lo, hi: None if t is None else (t.row_range(lo, hi) if is_kb(t) else t[lo:hi])
             slices = tail_k_slices(M - m_main, N, Ka, a.element_size(), num_cus(a.device.index))
-            ws = splitk_workspace(-(-(M - m_main) // 128) * -(-N // 256) * 128 * 256, a.device) if slices else None
-            try:
-                for lo, hi, cfg in ((0, m_main, big_tile_cfg(N, Ka, a.element_size())),) + (((m_main, M, 13 | slices << 16 | 1 << 22), (m_main, M, 13 | slices << 16 | 2 << 22)) if slices else ((m_main, M, 13),)):
-                    _gemm_one(cut(a, lo, hi), w, bias=bias, act=act, dact=dact, aux_in=cut(aux_in, lo, hi), aux_out=cut(aux_out, lo, hi), resid=cut(resid, lo, hi),
-                              resid_t=cut(resid_t, lo, hi), out_t=cut(out_t, lo, hi), out32=cut(out32, lo, hi), alpha=alpha, tile_cfg=cfg,
-                              resid_ln=None if resid_ln is None else (resid_ln[0][lo:hi],) + tuple(resid_ln[1:]), rowsum=cut(rowsum, lo, hi),
-                              lnfold=None if lnfold is None else (lnfold[0][lo:hi],) + tuple(lnfold[1:]), splitk_ws=ws if cfg >> 16 else None,
-                              resid3=None if resid3 is None else (cut(resid3[0], lo, hi), cut(resid3[1], lo, hi)), out_lo=cut(out_lo, lo, hi))
-            except Exception:
-                if slices:      # phase 2 is what re-zeroes the shared scratch: an error between the two launches must not leave partial sums behind
-                    drop_splitk_workspace(a.device)
-                raise
+
+            def part(lo, hi, cfg, ws=None):
+                _gemm_one(cut(a, lo, hi), w, bias=bias, act=act, dact=dact, aux_in=cut(aux_in, lo, hi), aux_out=cut(aux_out, lo, hi), resid=cut(resid, lo, hi),
+                          resid_t=cut(resid_t, lo, hi), out_t=cut(out_t, lo, hi), out32=cut(out32, lo, hi), alpha=alpha, tile_cfg=cfg,
+                          resid_ln=None if resid_ln is None else (resid_ln[0][lo:hi],) + tuple(resid_ln[1:]), rowsum=cut(rowsum, lo, hi),
+                          lnfold=None if lnfold is None else (lnfold[0][lo:hi],) + tuple(lnfold[1:]), splitk_ws=ws if cfg >> 16 else None,
+                          resid3=None if resid3 is None else (cut(resid3[0], lo, hi), cut(resid3[1], lo, hi)), out_lo=cut(out_lo, lo, hi))
+
+            def tail():      # on whichever stream is current: the split-K scratch belongs to (device, stream)
+                ws = splitk_workspace(-(-(M - m_main) // 128) * -(-N // 256) * 128 * 256, a.device) if slices else None
+                try:
+                    for cfg in ((13 | slices << 16 | 1 << 22, 13 | slices << 16 | 2 << 22) if slices else (13,)):
+                        part(m_main, M, cfg, ws)
+                except Exception:
+                    if slices:      # phase 2 is what re-zeroes the shared scratch: an error between the two launches must not leave partial sums behind
+                        drop_splitk_workspace(a.device)
+                    raise
+
+            if small_tail(M - m_main, N, num_cus(a.device.index)):
+                fork = _TailFork(a.device)
+                with fork:
+                    tail()
+                part(0, m_main, big_tile_cfg(N, Ka, a.element_size()))
+                fork.join()
+            else:
+                part(0, m_main, big_tile_cfg(N, Ka, a.element_size()))
+                tail()
             return
     _gemm_one(a, w, bias=bias, act=act, dact=dact, aux_in=aux_in, aux_out=aux_out, resid=resid, resid_mod=resid_mod, resid_row_off=resid_row_off,
               resid_t=resid_t, out_group=out_group, out_t=out_t, out32=out32, alpha=alpha, tile_cfg=tile_cfg, resid_ln=resid_ln,
@@ -981,6 +1046,41 @@ def comm_destroy():
 def dropout(src, dst, p, seed, accumulate=False):
     assert src.dtype == dst.dtype and src.is_contiguous() and dst.is_contiguous() and src.numel() == dst.numel()
     check(lib().uia_dropout(_stream(), _code(src.dtype), src.numel(), _p(src), _p(dst), p, int(seed) & 0xFFFFFFFFFFFFFFFF, int(accumulate)), "uia_dropout")
+
+
+def lora_rank_update_ok(n_src, N, dt):
+    """Shapes uia_lora_rank_update takes: bf16, N a multiple of 256, the sources' [N/4, 64] weight rows inside the LDS."""
+    return dt == torch.bfloat16 and 1 <= n_src <= 3 and N % 256 == 0 and n_src * (N // 4) * 144 <= 160 * 1024
+
+
+def lora_rank_update(q_all, ws, out, alpha, drop_p=0.0, seeds=()):
+    """out += sum_i drop_i(alpha * q_all[i] @ ws[i].T) in ONE read-modify-write pass over `out` (uia_lora_rank_update, csrc/lora_rank.hip).
+    q_all: T [n, M, 64] (contiguous); ws: n matrices T [N, 64] (A_i transposed, rank zero-padded to 64); out: T [M, N] row-major;
+    seeds: one per source when drop_p > 0 — the masks are those uia_dropout / gemm(drop=("acc", p, seed)) draw for an [M, N] tensor."""
+    n, M, r = q_all.shape
+    N = out.shape[1]
+    if not (q_all.is_contiguous() and r == 64 and out.shape[0] == M and len(ws) == n and lora_rank_update_ok(n, N, out.dtype) and q_all.dtype == out.dtype):
+        raise UiaError(f"lora_rank_update: q_all {tuple(q_all.shape)} {q_all.dtype}, out {tuple(out.shape)} {out.dtype}, {len(ws)} weights")
+    if drop_p > 0 and len(seeds) != n:
+        raise UiaError("lora_rank_update: one dropout seed per source")
+    d = LoraRankDesc()
+    d.M, d.N, d.nsrc, d.alpha = M, N, n, float(alpha)
+    d.Q, d.ldq, d.q_stride = _p(q_all), 64, M * 64
+    ldw = None
+    for i, w in enumerate(ws):
+        if w.dtype != out.dtype or tuple(w.shape) != (N, 64):
+            raise UiaError(f"lora_rank_update: weight {i} is {tuple(w.shape)} {w.dtype}, expected [{N}, 64] {out.dtype}")
+        l = _rowmajor(w, "w")
+        if ldw is not None and l != ldw:
+            raise UiaError("lora_rank_update: the weights must share one leading dimension")
+        ldw = l
+        d.W[i] = _p(w)
+    d.ldw = ldw
+    d.out, d.ldo = _p(out), _rowmajor(out, "out")
+    d.drop_p = float(drop_p)
+    for i in range(n if drop_p > 0 else 0):
+        d.seed[i] = int(seeds[i]) & 0xFFFFFFFFFFFFFFFF
+    check(lib().uia_lora_rank_update(_stream(), _code(out.dtype), C.byref(d)), "uia_lora_rank_update")
 
 
 def colsum(a, out):

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
-CFGS = [1, 2, 3, 4, 5, 6]
+CFGS = [1, 2, 3, 4, 5, 6, 7]
 
 
 def dev():
@@ -389,3 +389,43 @@ def test_four_wave_gemm_equals_the_ring_kernel_bit_for_bit(M, N, K):
             ops.gemm(a, ext, bias=bias, out_t=y, a2=(t_all, ws[0].shape[0]) if len(ws) > 1 else (t_all[0], 0), tile_cfg=cfg)
             ys[cfg] = y
         assert torch.equal(ys[8], ys[25]) and not torch.isnan(ys[25].float()).any()
+
+
+# ------------------------------------------------------------------------------------------------ LoRA: three rank terms in one pass (csrc/lora_rank.hip)
+@pytest.mark.parametrize("M,N,n,p", [(32896, 1024, 3, 0.25), (1000, 768, 3, 0.1), (517, 1024, 2, 0.0), (4100, 256, 1, 0.5)])
+def test_lora_rank_update_equals_the_sum_of_masked_rank_terms(M, N, n, p):
+    """uia_lora_rank_update: out += sum_i mask_i * (alpha * Q_i @ W_i.T) / (1 - p) with mask_i the mask uia_dropout draws for an [M, N] tensor from seed_i
+    (reference lora.py:78-90: one nn.Dropout per LinearLoRA, so q, k and v of a block each have their own).  Against the fp32 rank terms pushed through
+    uia_dropout with the same seeds; and, for one source, against the K = 64 stream launch it replaces (tile cfg 23, same mask)."""
+    from uia_hip import ops
+    g = torch.Generator(device="cpu").manual_seed(M + N + n)
+    dt = torch.bfloat16
+    q_all = torch.randn(n, M, 64, generator=g).to(dev()).to(dt)
+    ws = [(torch.randn(N, 64, generator=g) * 0.1).to(dev()).to(dt) for _ in range(n)]
+    out0 = torch.randn(M, N, generator=g).to(dev()).to(dt)
+    seeds = [1234567 + 77 * i for i in range(n)]
+    alpha = 2.0
+    want = out0.float()
+    for i in range(n):
+        u = alpha * (q_all[i].float() @ ws[i].float().T)
+        if p > 0:
+            ud = torch.empty_like(u)
+            ops.dropout(u.contiguous(), ud, p, seeds[i])
+            u = ud
+        want = want + u
+    out = out0.clone()
+    ops.lora_rank_update(q_all, ws, out, alpha, p, seeds)
+    torch.cuda.synchronize()
+    assert not torch.isnan(out.float()).any()
+    assert float((out.float() - want).abs().max()) <= 2.0 ** -7 * float(want.abs().max())           # one bf16 rounding of the sum
+    if p > 0:                                                                                        # the masks are the seeds': dropped positions keep out0 exactly
+        u0 = torch.empty(M, N, device=dev())
+        ops.dropout(torch.ones(M, N, device=dev()), u0, p, seeds[0])
+        if n == 1:
+            assert torch.equal(out[u0 == 0], out0[u0 == 0])
+    if n == 1:
+        ref = out0.clone()
+        ops.gemm(q_all[0], ws[0], alpha=alpha, resid_t=ref, out_t=ref, drop=("acc", p, seeds[0]) if p > 0 else None, tile_cfg=23)
+        assert float((out.float() - ref.float()).abs().max()) <= 2.0 ** -7 * float(ref.float().abs().max())
+    with pytest.raises(ops.UiaError):
+        ops.lora_rank_update(q_all, ws, out[:, :N - 64], alpha, p, seeds)

@@ -6,7 +6,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "nextgen-uia_amd")]
 import torch
 from uia_hip import ops
 
-CFGS = [int(c) for c in os.environ.get("UIA_ABWD_CFGS", "1,2,5").split(",")]
+CFGS = [int(c) for c in os.environ.get("ATTN_CFGS", "1,2,5,7").split(",")]
 
 
 def timed(f, n=20):
