@@ -1040,7 +1040,7 @@ int launch_persist(hipStream_t stream, const UiaAttnParams& p) {
 }  // namespace
 
 int uia_attn_bwd_launch(hipStream_t stream, int dtype, const UiaAttnParams& p, int cfg) {
-    UIA_CHECK_ARG(cfg >= 0 && cfg <= 8, "uia_attn_bwd: unknown kernel configuration %d", cfg);
+    UIA_CHECK_ARG(cfg >= 0 && cfg <= 7, "uia_attn_bwd: unknown kernel configuration %d", cfg);
     UIA_CHECK_ARG(dtype == UIA_BF16 || dtype == UIA_F32, "uia_attn_bwd: bad dtype %d", dtype);
     UIA_CHECK_ARG(p.B > 0 && p.H > 0 && p.L > 0, "uia_attn_bwd: empty problem");
     UIA_CHECK_ARG(p.scale > 0.f && p.scale < 3.0e38f, "uia_attn_bwd: scale must be positive and finite (matches the forward's lse), got %g", (double)p.scale);
@@ -1074,8 +1074,7 @@ int uia_attn_bwd_launch(hipStream_t stream, int dtype, const UiaAttnParams& p, i
     if (cfg == 0) cfg = 2;
     if (cfg == 2) return LT <= OLDS_LT_MAX ? launch_units<8, true, true>(stream, p) : launch_units<8, true, false>(stream, p);
     if (cfg == 6) return launch_units<8, true, false>(stream, p);       // cfg 2 with δ's operands from global memory at every length
-    if (cfg == 7) return LT <= OLDS_LT_MAX ? launch_units<12, true, true>(stream, p) : launch_units<12, true, false>(stream, p);   // three waves per SIMD (<= 168 VGPRs)
-    if (cfg == 8) return LT <= OLDS_LT_MAX ? launch_units<16, true, true>(stream, p) : launch_units<16, true, false>(stream, p);   // four (<= 128 VGPRs)
+    if (cfg == 7) return LT <= OLDS_LT_MAX ? launch_units<12, true, true>(stream, p) : launch_units<12, true, false>(stream, p);   // twelve waves, three per SIMD (<= 168 VGPRs, 25 spilled): 248 / 268 / 353 us against cfg 2's 220 / 217 / 348 (round 4: more waves do not buy what the unit loses; sixteen spill 230 registers)
     if (cfg == 3) return launch_units<4, false, false>(stream, p);
     if (cfg == 4) return launch_units<8, false, false>(stream, p);
     if (cfg == 5) {
