@@ -360,6 +360,10 @@ int uia_attn_small_launch(hipStream_t stream, int dtype, const UiaAttnParams& p,
     UIA_CHECK_ARG(p.dh == 16 || p.dh == 32, "uia_attn: head dim %d unsupported (16, 32 or 64)", p.dh);
     UIA_CHECK_ARG(!p.cu_seqlens, "uia_attn: packed sequences (cu_seqlens) need head dim 64");
     UIA_CHECK_ARG(p.L > 0 && p.L <= 1024 && p.B > 0 && p.H > 0, "uia_attn: bad shape");
+    {   // bf16, head dim 16, no mask: the MFMA kernels (attention_dh16.hip).  UIA_ATTN_DH16=0 keeps the scalar kernels below (A/B runs, parity cross-check).
+        static const bool mfma = []() { const char* e = getenv("UIA_ATTN_DH16"); return !(e && e[0] == '0'); }();
+        if (mfma && uia_attn_dh16_ok(dtype, p)) return uia_attn_dh16_launch(stream, p, bwd);
+    }
     const size_t lds = bwd ? ((size_t)2 * p.L * p.dh + 2 * p.L) * 4 : (size_t)2 * p.L * p.dh * 4;
     UIA_CHECK_ARG(lds <= 160 * 1024, "uia_attn: L=%d too long for the small-head path", p.L);
     const dim3 grid(p.B * p.H), block(256);

@@ -47,6 +47,8 @@ int uia_adamw_clip_launch(hipStream_t stream, size_t n, float* p, const float* g
 int uia_dropout_launch(hipStream_t stream, int dtype, size_t n, const void* src, void* dst, float p, uint64_t seed, int accumulate);
 int uia_colsum_launch(hipStream_t stream, int dtype, int M, int N, const void* A, long lda, float* out);
 int uia_attn_small_launch(hipStream_t stream, int dtype, const UiaAttnParams& p, bool bwd);
+bool uia_attn_dh16_ok(int dtype, const UiaAttnParams& p);                            // attention_dh16.hip: bf16, head dim 16, no mask, L <= 512 on the matrix cores
+int uia_attn_dh16_launch(hipStream_t stream, const UiaAttnParams& p, bool bwd);
 int uia_layernorm_bwd_affine_launch(hipStream_t stream, int dtype, int M, int D, const void* dy, const float* x, const float* gamma, float eps,
                                     const float* dres, float* dx32, float* g_gamma, float* g_beta);
 int uia_film_fwd_launch(hipStream_t stream, int B, int N, int C, const float* x, const float* mul, const float* add, float* y);

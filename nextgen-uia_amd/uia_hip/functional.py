@@ -637,6 +637,9 @@ def join_side_streams():
         cur.wait_stream(st)
 
 
+DIRECT_TRAIN = True     # LinearTrainFn / LayerNormAffineFn (fully trainable decoder and heads): weight gradients accumulated straight into the flat-buffer views (A/B: bench.py --no-direct-train-grads)
+
+
 def _is_flat_grad(p):
     g = p.grad
     return (getattr(p, "_uia_flat_grad", False) and g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.shape == p.shape
@@ -1373,6 +1376,9 @@ class LinearTrainFn(torch.autograd.Function):
                 stash = y                                       # ReLU: the post-activation is enough
         ctx.save_for_backward(x, weight, stash)
         ctx.meta = (act, bias is not None, resid32 is not None)
+        # the Parameter objects (when the operands ARE parameters, not views or concatenations of them): their .grad is looked up at BACKWARD time, and
+        # when it is a view of the engine's flat gradient buffer the weight gradient is accumulated straight into it (no zero fill, no AccumulateGrad add)
+        ctx.params = (weight if isinstance(weight, torch.nn.Parameter) else None, bias if isinstance(bias, torch.nn.Parameter) else None)
         return y
 
     @staticmethod
@@ -1392,6 +1398,11 @@ class LinearTrainFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = _empty((M, K), dt, x)
             ops.gemm(dy_t, WEIGHTS.get(weight, dt, transpose=True), out_t=dx)
+        pw, pb = ctx.params
+        if (DIRECT_TRAIN and pw is not None and _is_flat_grad(pw) and ctx.needs_input_grad[1] and
+                (not has_bias or (pb is not None and _is_flat_grad(pb) and ctx.needs_input_grad[2]))):
+            ops.wgrad(dy_t, x, pw.grad, pb.grad if has_bias else None)
+            return dx, None, None, None, (dy if has_resid else None), None
         dW = torch.zeros(N, K, device=x.device, dtype=torch.float32)
         db = torch.zeros(N, device=x.device, dtype=torch.float32) if has_bias else None
         ops.wgrad(dy_t, x, dW, db)
@@ -1409,6 +1420,7 @@ class LayerNormAffineFn(torch.autograd.Function):
         ops.layernorm_fwd(x2, w, b, eps, y32=y)
         ctx.save_for_backward(x2, w)
         ctx.meta = (eps, x.shape)
+        ctx.params = (w if isinstance(w, torch.nn.Parameter) else None, b if isinstance(b, torch.nn.Parameter) else None)
         return y.view(x.shape)
 
     @staticmethod
@@ -1416,6 +1428,10 @@ class LayerNormAffineFn(torch.autograd.Function):
         x2, w = ctx.saved_tensors
         eps, shape = ctx.meta
         dx = torch.empty_like(x2)
+        pw, pb = ctx.params
+        if DIRECT_TRAIN and pw is not None and pb is not None and _is_flat_grad(pw) and _is_flat_grad(pb) and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]:
+            ops.layernorm_bwd_affine(dy.contiguous().view(x2.shape).float(), x2, w, eps, dx, pw.grad, pb.grad)      # the kernel ADDS its per-block sums
+            return dx.view(shape), None, None, None
         gw, gb = torch.zeros_like(w, dtype=torch.float32), torch.zeros_like(w, dtype=torch.float32)
         ops.layernorm_bwd_affine(dy.contiguous().view(x2.shape).float(), x2, w, eps, dx, gw, gb)
         return dx.view(shape), gw, gb, None

@@ -429,3 +429,34 @@ def test_lora_rank_update_equals_the_sum_of_masked_rank_terms(M, N, n, p):
         assert float((out.float() - ref.float()).abs().max()) <= 2.0 ** -7 * float(ref.float().abs().max())
     with pytest.raises(ops.UiaError):
         ops.lora_rank_update(q_all, ws, out[:, :N - 64], alpha, p, seeds)
+
+
+# ------------------------------------------------------------------------------------------------ head dim 16 on the matrix cores (csrc/attention_dh16.hip)
+@pytest.mark.parametrize("B,H,L", [(2, 4, 485), (3, 2, 16), (1, 4, 100), (2, 1, 512), (5, 4, 33)])
+def test_head_dim_16_attention_on_mfma_vs_torch(B, H, L):
+    """CLIPSeg decoder attention (four heads of 16, 485 tokens; clipseg_adapter.py:73-98): the bf16 forward and backward run on v_mfma_f32_16x16x16_bf16
+    (csrc/attention_dh16.hip) instead of the scalar kernels.  Output, log-sum-exp and the three gradients against fp32 torch on the same bf16 inputs —
+    the tolerance is the bf16 rounding of P / dS as MFMA operands; ragged lengths exercise the key mask of the last tile and the padding queries."""
+    from uia_hip import ops
+    g = torch.Generator(device="cpu").manual_seed(B * 1000 + H * 100 + L)
+    D = H * 16
+    dt = torch.bfloat16
+    qkv = (torch.randn(B * L, 3 * D, generator=g) * 0.8).to(dev()).to(dt)
+    do = torch.randn(B * L, D, generator=g).to(dev()).to(dt)
+    out = torch.full((B * L, D), float("nan"), device=dev(), dtype=dt)
+    lse = torch.full((B, H, L), float("nan"), device=dev())
+    ops.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], out, B, H, L, lse=lse, dh=16)
+    qf, kf, vf = [t.float().view(B, L, H, 16).permute(0, 2, 1, 3).detach().requires_grad_(True) for t in (qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:])]
+    s = (qf @ kf.transpose(-1, -2)) * 0.25
+    ref = torch.softmax(s, -1) @ vf
+    ref_rows = ref.permute(0, 2, 1, 3).reshape(B * L, D)
+    assert not torch.isnan(out.float()).any() and not torch.isnan(lse).any()
+    assert rel(out, ref_rows) < 8e-3
+    assert float((lse - torch.logsumexp(s, -1)).abs().max()) < 2e-3
+    dqkv = torch.full((B * L, 3 * D), float("nan"), device=dev(), dtype=dt)
+    ops.attn_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], out, do, lse, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], B, H, L, dh=16)
+    ref.backward(do.float().view(B, L, H, 16).permute(0, 2, 1, 3))
+    assert not torch.isnan(dqkv.float()).any()
+    for i, t in enumerate((qf, kf, vf)):
+        want = t.grad.permute(0, 2, 1, 3).reshape(B * L, D)
+        assert rel(dqkv[:, i * D:(i + 1) * D], want) < 1.5e-2, ("dq", "dk", "dv")[i]
