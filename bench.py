@@ -75,6 +75,7 @@ def parse():
     ap.add_argument("--no-tail-split", action="store_true", help="A/B knob: no half-height tiles for the M tail of a launch")
     ap.add_argument("--no-tail-side-stream", action="store_true", help="A/B: small M tails of a split GEMM behind the main launch instead of beside it on a side stream")
     ap.add_argument("--no-direct-train-grads", action="store_true", help="A/B: the trainable decoder / head layers hand their weight gradients to autograd instead of accumulating them into the flat gradient buffer")
+    ap.add_argument("--no-lora-regen-drop", action="store_true", help="A/B: the LoRA forward writes the dropped input rows out for the dA weight-gradient launch instead of that launch regenerating the mask")
     ap.add_argument("--no-lora-rank3", action="store_true", help="A/B: the q | k | v rank terms of a LoRA block's data gradient as three K = 64 launches instead of one uia_lora_rank_update pass")
     ap.add_argument("--no-lora-kext", action="store_true", help="A/B knob: the LoRA rank update as a launch of its own (tile cfg 23) instead of inside the frozen GEMM's K loop")
     ap.add_argument("--quad", action="store_true", help="experiment knob: 256x256 bf16 launches on the four-wave kernel (tile cfg 25, csrc/gemm_quad.hip) instead of the eight-wave ring kernel")
@@ -362,6 +363,7 @@ def main():
     ops.QUAD = args.quad
     ops.LORA_KEXT = not args.no_lora_kext
     ops.LORA_RANK3 = not args.no_lora_rank3
+    ops.LORA_REGEN_DROP = not args.no_lora_regen_drop
     UF.DIRECT_TRAIN = not args.no_direct_train_grads
     ops.TAIL_SIDE_STREAM = not args.no_tail_side_stream
     ops.KBLOCK_ACT = not args.no_kblock_act

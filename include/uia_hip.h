@@ -160,6 +160,11 @@ int uia_wgrad(void* stream, int dtype, int M, int I, int J, const void* A, int64
  * parameter's own .grad without a padded staging buffer, its zero fill and its slice copy (lora.py:87). */
 int uia_wgrad_ex(void* stream, int dtype, int M, int I, int J, const void* A, int64_t lda, const void* B, int64_t ldb,
                  float alpha, float* dW, int64_t ldw, int i_valid, int j_valid, float* dbias_A);
+/* dW[I,J] += alpha * A.T @ drop(B): the LoRA factor gradient dA = s * q.T @ dropout(x) (lora.py:82-87) with the dropout REGENERATED while B is staged —
+ * B holds the un-dropped rows, a window of J columns starting at column drop_col0 of a [M, drop_ld] tensor whose mask uia_dropout /
+ * uia_gemm_desc.drop_where = 1 draw from (seed, element index / 8); the forward then need not write the dropped rows out.  bf16; extents as uia_wgrad_ex. */
+int uia_wgrad_drop(void* stream, int dtype, int M, int I, int J, const void* A, int64_t lda, const void* B, int64_t ldb,
+                   float alpha, float* dW, int64_t ldw, int i_valid, int j_valid, float drop_p, uint64_t seed, int64_t drop_ld, int drop_col0);
 
 /* ---------------------------------------------------------------------------------------------
  * softmax(q kᵀ·scale + mask) v, head dim 64, L <= 272, one workgroup per (batch, head).

@@ -25,6 +25,12 @@ int uia_wgrad_ex(void* stream, int dtype, int M, int I, int J, const void* A, in
     if (ldw <= 0) { uia_set_error("uia_wgrad_ex: ldw=%lld must be positive", (long long)ldw); return -1; }
     return uia_wgrad_launch((hipStream_t)stream, dtype, M, I, J, A, lda, B, ldb, alpha, dW, dbias_A, ldw, i_valid, j_valid);
 }
+int uia_wgrad_drop(void* stream, int dtype, int M, int I, int J, const void* A, int64_t lda, const void* B, int64_t ldb, float alpha, float* dW, int64_t ldw,
+                   int i_valid, int j_valid, float drop_p, uint64_t seed, int64_t drop_ld, int drop_col0) {
+    if (ldw <= 0) { uia_set_error("uia_wgrad_drop: ldw=%lld must be positive", (long long)ldw); return -1; }
+    if (!(drop_p > 0.f)) { uia_set_error("uia_wgrad_drop: drop_p=%f must be in (0, 1); uia_wgrad_ex is the form without dropout", (double)drop_p); return -1; }
+    return uia_wgrad_launch((hipStream_t)stream, dtype, M, I, J, A, lda, B, ldb, alpha, dW, nullptr, ldw, i_valid, j_valid, drop_p, seed, drop_ld, drop_col0);
+}
 int uia_attn_fwd(void* stream, int dtype, const uia_attn_desc* d) {
     NEED(d, "uia_attn_fwd");
     return uia_attn_fwd_launch((hipStream_t)stream, dtype, *d);

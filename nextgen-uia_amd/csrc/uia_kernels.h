@@ -29,7 +29,7 @@ int uia_fill_cls_launch(hipStream_t stream, int B, int N, int D, const float* cl
 int uia_embed_launch(hipStream_t stream, int rows, int L, int D, int vocab, int max_pos, const int64_t* ids, const float* table, const float* pos, const float* type0, float* out);
 int uia_gather_rows_launch(hipStream_t stream, int n, int D, const float* src, const int64_t* idx, float* dst);
 int uia_wgrad_launch(hipStream_t stream, int dtype, int M, int I, int J, const void* A, long lda, const void* B, long ldb, float alpha, float* dW, float* dbias,
-                     long ldw = 0, int i_valid = 0, int j_valid = 0);
+                     long ldw = 0, int i_valid = 0, int j_valid = 0, float drop_p = 0.f, uint64_t drop_seed = 0, long drop_ld = 0, int drop_col0 = 0);
 int uia_mona_pre_fwd_launch(hipStream_t stream, int dtype, int M, int D, const float* x, const float* nw, const float* nb, const float* gamma,
                             const float* gammax, float eps, void* u);
 int uia_mona_pre_bwd_launch(hipStream_t stream, int dtype, int M, int D, const void* du, const float* x, const float* dy, const float* nw,

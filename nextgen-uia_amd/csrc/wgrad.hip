@@ -36,9 +36,14 @@ constexpr int SLAB = 128;            // rows per LDS slab (32 per wave)
 constexpr int CHUNK_SLABS = WG_CHUNK_SLABS;       // slabs per workgroup → 512 rows per chunk
 
 // ---- bf16: slabs are [128][128 B] images, 32-B column groups swizzled by (row>>1)&3
+// DROPB (LoRA's dA = s·qᵀ·drop(x), lora.py:82-87): B holds the UN-dropped rows; the mask uia_dropout / uia_gemm's drop_where = 1 draw for the [M, drop_ld]
+// tensor B is a column window of is regenerated from (seed, element index / 8) while the slab is staged — a lane's 16-byte piece is exactly one draw —
+// so the forward does not have to write the dropped rows out for this launch (67 MB per LinearLoRA at ViT-L/14, 128 pairs).
+template <bool DROPB>
 __global__ __launch_bounds__(256) void wgrad_bf16_kernel(int M, int I, int J, const bf16_t* __restrict__ A, long lda,
                                                           const bf16_t* __restrict__ B, long ldb, float alpha,
-                                                          float* __restrict__ dW, float* __restrict__ dbias, long ldw, int i_valid, int j_valid) {
+                                                          float* __restrict__ dW, float* __restrict__ dbias, long ldw, int i_valid, int j_valid,
+                                                          float drop_p, unsigned long long drop_seed, long drop_ld, int drop_col0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* As = smem;                  // 16 KiB
     char* Bs = smem + SLAB * 128;     // 16 KiB
@@ -64,12 +69,45 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(int M, int I, int J, co
     f32x4 bacc[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     const bf16x8 ones = {(bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f};
 
+    const uint32_t drop_th = dropout_thresh16(drop_p);
+    const float drop_inv = 1.0f / (1.0f - drop_p);
     const int trow = 32 * wave + 4 * g + qq;          // lo rows; hi rows = +16
     const int tsw = (trow >> 1) & 3;                  // (+16 keeps (row>>1)&3)
     for (int sl = 0; sl < CHUNK_SLABS; ++sl) {
         const int m0 = m_begin + sl * SLAB;
         if (m0 >= M) break;
         __syncthreads();                               // previous slab fully consumed
+        if constexpr (DROPB) {
+            // all four pieces of the thread requested first, the four draws computed while they fly, then mask + ds_write (a plain load per piece in
+            // line with its hash exposed one round trip per piece: 31 us per launch against 21 for the LDS-DMA form)
+            uint4 raw[SLAB / 32];
+            uint32_t keep[SLAB / 32];
+#pragma unroll
+            for (int i = 0; i < SLAB / 32; ++i) {
+                const int q = wave + 4 * i, r = 8 * q + (lane >> 3);
+                int gm = m0 + r;
+                gm = gm < M ? gm : M - 1;
+                const int c = ((lane & 7) ^ (((r >> 1) & 3) << 1)) * 16;
+                glds16((const char*)(A + (size_t)gm * lda + (size_t)ti * 64) + c, As + q * 1024);
+                raw[i] = *(const uint4*)((const char*)(B + (size_t)gm * ldb + (size_t)tj * 64) + c);
+            }
+#pragma unroll
+            for (int i = 0; i < SLAB / 32; ++i) {
+                const int q = wave + 4 * i, r = 8 * q + (lane >> 3);
+                int gm = m0 + r;
+                gm = gm < M ? gm : M - 1;
+                const int c = ((lane & 7) ^ (((r >> 1) & 3) << 1)) * 16;
+                keep[i] = dropout_keep8(drop_seed, (uint32_t)(((size_t)gm * (size_t)drop_ld + (size_t)(drop_col0 + tj * 64 + (c >> 1))) >> 3), drop_th);
+            }
+#pragma unroll
+            for (int i = 0; i < SLAB / 32; ++i) {
+                const int q = wave + 4 * i;
+                bf16x8 v = __builtin_bit_cast(bf16x8, raw[i]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((keep[i] >> e) & 1u ? (float)v[e] * drop_inv : 0.f);     // what the N = 64 stream kernel writes, bit for bit
+                *(bf16x8*)(Bs + q * 1024 + lane * 16) = v;
+            }
+        } else {
         for (int q = wave; q < SLAB / 8; q += 4) {
             const int r = 8 * q + (lane >> 3);
             int gm = m0 + r;
@@ -77,6 +115,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(int M, int I, int J, co
             const int c = ((lane & 7) ^ (((r >> 1) & 3) << 1)) * 16;
             glds16((const char*)(A + (size_t)gm * lda + (size_t)ti * 64) + c, As + q * 1024);
             glds16((const char*)(B + (size_t)gm * ldb + (size_t)tj * 64) + c, Bs + q * 1024);
+        }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -218,7 +257,7 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(int M, int I, int J, con
 }  // namespace
 
 int uia_wgrad_launch(hipStream_t stream, int dtype, int M, int I, int J, const void* A, long lda, const void* B, long ldb, float alpha,
-                     float* dW, float* dbias, long ldw, int i_valid, int j_valid) {
+                     float* dW, float* dbias, long ldw, int i_valid, int j_valid, float drop_p, uint64_t drop_seed, long drop_ld, int drop_col0) {
     if (ldw == 0) { ldw = J; i_valid = I; j_valid = J; }              // the plain form: a dense [I, J] gradient
     UIA_CHECK_ARG(dtype == UIA_BF16 || dtype == UIA_F32, "uia_wgrad: bad dtype %d", dtype);
     UIA_CHECK_ARG(M > 0 && I > 0 && J > 0 && I % 64 == 0 && J % 64 == 0, "uia_wgrad: I=%d and J=%d must be multiples of 64 (M=%d)", I, J, M);
@@ -233,10 +272,20 @@ int uia_wgrad_launch(hipStream_t stream, int dtype, int M, int I, int J, const v
     const int lds = 4 * 4096 * 4;   // fp32 path: reduction buffer for four waves at once
     const int lds_bf16 = 2 * SLAB * 128;   // bf16 path: two 16 KiB slabs, re-used as a two-wave reduction buffer
     static UiaDevOnce once_bf16, once_f32;
-    UIA_ENSURE_LDS_ATTR(once_bf16, wgrad_bf16_kernel, lds_bf16);
+    UIA_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "uia_wgrad: drop_p=%f outside [0, 1)", (double)drop_p);
+    UIA_CHECK_ARG(drop_p == 0.f || (dtype == UIA_BF16 && drop_ld >= drop_col0 + J && drop_col0 >= 0 && drop_col0 % 8 == 0 && drop_ld % 8 == 0 && (size_t)M * (size_t)drop_ld / 8 <= 0xFFFFFFFFull),
+                  "uia_wgrad: dropout on the B operand needs bf16, a window of J columns at a multiple of 8 inside rows of drop_ld (a multiple of 8) elements, M*drop_ld <= 2^35");
+    UIA_ENSURE_LDS_ATTR(once_bf16, wgrad_bf16_kernel<false>, lds_bf16);
     UIA_ENSURE_LDS_ATTR(once_f32, wgrad_f32_kernel, lds);
     if (dtype == UIA_BF16)
-        hipLaunchKernelGGL(wgrad_bf16_kernel, grid, dim3(256), lds_bf16, stream, M, I, J, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, alpha, dW, dbias, ldw, i_valid, j_valid);
+        if (drop_p > 0.f) {
+            static UiaDevOnce once_drop;
+            UIA_ENSURE_LDS_ATTR(once_drop, wgrad_bf16_kernel<true>, lds_bf16);
+            hipLaunchKernelGGL(wgrad_bf16_kernel<true>, grid, dim3(256), lds_bf16, stream, M, I, J, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, alpha, dW, dbias, ldw, i_valid, j_valid,
+                               drop_p, (unsigned long long)drop_seed, drop_ld, drop_col0);
+        } else
+        hipLaunchKernelGGL(wgrad_bf16_kernel<false>, grid, dim3(256), lds_bf16, stream, M, I, J, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, alpha, dW, dbias, ldw, i_valid, j_valid,
+                           0.f, 0ull, 0l, 0);
     else
         hipLaunchKernelGGL(wgrad_f32_kernel, grid_f32, dim3(256), lds, stream, M, I, J, (const float*)A, lda, (const float*)B, ldb, alpha, dW, dbias, ldw, i_valid, j_valid);
     UIA_CHECK_LAUNCH();

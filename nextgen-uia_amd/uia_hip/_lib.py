@@ -78,6 +78,7 @@ PROTOTYPES = {
     "uia_version": (C.c_int, []),
     "uia_gemm": (C.c_int, [vp, C.c_int, C.POINTER(GemmDesc), C.c_int]),
     "uia_wgrad": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, vp, i64, f32, vp, vp]),
+    "uia_wgrad_drop": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, vp, i64, f32, vp, i64, C.c_int, C.c_int, f32, C.c_uint64, i64, C.c_int]),
     "uia_wgrad_ex": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, vp, i64, f32, vp, i64, C.c_int, C.c_int, vp]),
     "uia_attn_fwd": (C.c_int, [vp, C.c_int, C.POINTER(AttnDesc)]),
     "uia_attn_bwd": (C.c_int, [vp, C.c_int, C.POINTER(AttnDesc)]),

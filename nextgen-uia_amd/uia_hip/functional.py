@@ -1098,13 +1098,15 @@ class LoraLinearFn(torch.autograd.Function):
             t = _empty((M, rp), dt, x)
             a_op = WEIGHTS.get(A, dt, pad_rows_to=rp)
             fuse = p_drop > 0 and dt == torch.bfloat16 and rp == 64 and x.is_cuda and x.is_contiguous() and 64 * (2 * K + 16) <= 160 * 1024 and K % 32 == 0
+            regen = fuse and ops.LORA_REGEN_DROP and K % 64 == 0       # the dropped rows are never written: dA's launch regenerates the mask (ops.wgrad(drop=...))
             if p_drop > 0:
                 seed = _next_seed()
-                xd = torch.empty_like(x)
+                if not regen:
+                    xd = torch.empty_like(x)
                 if not fuse:
                     ops.dropout(x, xd, p_drop, seed)
             if fuse:
-                ops.gemm(x, a_op.row, out_t=t, drop=("a", p_drop, seed, xd))
+                ops.gemm(x, a_op.row, out_t=t, drop=("a", p_drop, seed, None if regen else xd))
             else:
                 ops.gemm(xd, a_op, out_t=t)
             if kext:
@@ -1117,6 +1119,7 @@ class LoraLinearFn(torch.autograd.Function):
                     ops.gemm(t, bmat, alpha=scaling, resid_t=y_t, out_t=y_t)
         ctx.save_for_backward(xd, t if t is not None else x.new_empty(0), weight, A, Bm)
         ctx.meta = (scaling, p_drop, seed, r, bias is not None, resid32 is not None)
+        ctx.regen = (p_drop, seed) if (r > 0 and regen) else None
         ctx.direct_params = (A, Bm, bias) if direct else None                       # the Parameter objects: .grad is looked up at BACKWARD time
         return y32 if y32 is not None else y_t
 
@@ -1149,12 +1152,12 @@ class LoraLinearFn(torch.autograd.Function):
                 ops.gemm(q, at, alpha=scaling, resid_t=dx, out_t=dx)
             if direct:
                 ops.wgrad(dy_t, t, pB.grad, dbias=gb, alpha=scaling)
-                ops.wgrad(q, xd, pA.grad, alpha=scaling)
+                ops.wgrad(q, xd, pA.grad, alpha=scaling, drop=ctx.regen)
             else:
                 dB = torch.zeros(N, r, device=xd.device, dtype=torch.float32)
                 ops.wgrad(dy_t, t, dB, dbias=gb, alpha=scaling)
                 dA = torch.zeros(r, K, device=xd.device, dtype=torch.float32)
-                ops.wgrad(q, xd, dA, alpha=scaling)
+                ops.wgrad(q, xd, dA, alpha=scaling, drop=ctx.regen)
         elif want_b:
             ops.colsum(dy_t, gb)
         return dx, None, db, dA, dB, None, None, (dy if has_resid else None), None
@@ -1171,29 +1174,36 @@ def _lora_down(x, A, p_drop, rp, out=None):
         ops.gemm(x, a_op, out_t=t)
         return t, x, 0
     seed = _next_seed()
-    xd = torch.empty_like(x)
     if dt == torch.bfloat16 and rp == 64 and x.is_cuda and x.is_contiguous() and 64 * (2 * K + 16) <= 160 * 1024 and K % 32 == 0:
+        if ops.LORA_REGEN_DROP and K % 64 == 0:
+            # the dropped rows are never written: dA's launch regenerates the mask from the seed while it stages x (ops.wgrad(drop=...));
+            # callers get x itself back and keep the seed
+            ops.gemm(x, a_op.row, out_t=t, drop=("a", p_drop, seed, None))
+            return t, x, seed
+        xd = torch.empty_like(x)
         ops.gemm(x, a_op.row, out_t=t, drop=("a", p_drop, seed, xd))
     else:
+        xd = torch.empty_like(x)
         ops.dropout(x, xd, p_drop, seed)
         ops.gemm(xd, a_op, out_t=t)
     return t, xd, seed
 
 
-def _lora_grads(dy_t, t, xd, q, A, Bm, bias, scaling, direct):
+def _lora_grads(dy_t, t, xd, q, A, Bm, bias, scaling, direct, regen=None):
     """dB = s·dyᵀ·t, dA = s·qᵀ·x̃ and, for a bias that trains (reference quirk C-4), db = Σ dy on the matrix cores of the dB launch: into the
     parameters' .grad (flat-buffer views) when `direct`, else returned."""
     r = A.shape[0]
     want_b = bias is not None and bias.requires_grad
+    # regen = (p, seed): `xd` is the UN-dropped input and the dA launch regenerates the forward's mask (ops.LORA_REGEN_DROP)
     if direct:
         ops.wgrad(dy_t, t, Bm.grad, dbias=bias.grad if want_b else None, alpha=scaling)
-        ops.wgrad(q, xd, A.grad, alpha=scaling)
+        ops.wgrad(q, xd, A.grad, alpha=scaling, drop=regen)
         return None, None, None
     db = torch.zeros(bias.numel(), device=xd.device, dtype=torch.float32) if want_b else None
     dB = torch.zeros(Bm.shape[0], r, device=xd.device, dtype=torch.float32)
     ops.wgrad(dy_t, t, dB, dbias=db, alpha=scaling)
     dA = torch.zeros(r, A.shape[1], device=xd.device, dtype=torch.float32)
-    ops.wgrad(q, xd, dA, alpha=scaling)
+    ops.wgrad(q, xd, dA, alpha=scaling, drop=regen)
     return dA, dB, db
 
 
@@ -1244,6 +1254,8 @@ class LoraAttnHalfFn(torch.autograd.Function):
             ops.gemm(to, WEIGHTS.get(Bo, dt, pad_cols_to=rp), alpha=scaling, resid=x1, out32=x1)
         ctx.save_for_backward(x2, ln_w, qkv, a, lse, to, ado, *[d[0] for d in downs], *[d[1] for d in downs], wq, wk, wv, wo)
         ctx.meta = (eps, shape, heads, mask, scaling, p_drop, [d[2] for d in downs] + [seed_o], rp)
+        # which of the four saved LoRA inputs are the UN-dropped tensors (h three times, a once): their dA launches regenerate the mask
+        ctx.regen = [p_drop > 0 and d[1] is h for d in downs] + [p_drop > 0 and ado is a]
         ctx.params = (bq, aq, Bq, bk, ak, Bk, bv, av, Bv, bo, ao, Bo)                # the Parameter objects: .grad is looked up at BACKWARD time
         ctx.direct = direct
         return x1.view(shape)
@@ -1267,7 +1279,7 @@ class LoraAttnHalfFn(torch.autograd.Function):
         qo = _empty((M, rp), dt, x2)
         ops.gemm(dy_t, WEIGHTS.get(Bo, dt, transpose=True, pad_cols_to=rp), out_t=qo)
         ops.gemm(qo, WEIGHTS.get(ao, dt, transpose=True, pad_rows_to=rp), alpha=scaling, resid_t=da, out_t=da, drop=drop(3))
-        g_o = _lora_grads(dy_t, to, ado, qo, ao, Bo, bo, scaling, direct)
+        g_o = _lora_grads(dy_t, to, ado, qo, ao, Bo, bo, scaling, direct, regen=(p_drop, seeds[3]) if ctx.regen[3] else None)
         # ---- attention
         dqkv = _empty((M, 3 * D), dt, x2)
         ops.attn_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], a, da, lse, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], Bsz, heads, L, mask=mask)
@@ -1286,7 +1298,7 @@ class LoraAttnHalfFn(torch.autograd.Function):
             ops.gemm(dsl, WEIGHTS.get(Bm, dt, transpose=True, pad_cols_to=rp), out_t=qi)
             if need_dx and not one_pass:
                 ops.gemm(qi, WEIGHTS.get(A, dt, transpose=True, pad_rows_to=rp), alpha=scaling, resid_t=dh, out_t=dh, drop=drop(i))
-            grads.append(_lora_grads(dsl, t, hd, qi, A, Bm, bias, scaling, direct))
+            grads.append(_lora_grads(dsl, t, hd, qi, A, Bm, bias, scaling, direct, regen=(p_drop, seeds[i]) if ctx.regen[i] else None))
         if one_pass:
             ats = [WEIGHTS.get(A, dt, transpose=True, pad_rows_to=rp) for A in (aq, ak, av)]
             ops.lora_rank_update(q_all, [a.row if isinstance(a, ops.PackedW) else a for a in ats], dh, scaling, p_drop, seeds[:3])

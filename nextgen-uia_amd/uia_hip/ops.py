@@ -72,6 +72,7 @@ TILE_GROUP = {}          # experiment knob: {N: row panels per tile-order group}
 HALF_HEIGHT_SHORT_K = True   # N <= 768, K <= 768 (bf16) launches whose 256-row tiling leaves a ragged last round run on half-height tiles (cfg 14) in one launch
 TAIL_SPLIT = True        # split off the M tail of a launch whose last round of 256x256 tiles would leave most CUs idle
 TAIL_SIDE_STREAM = True  # a SMALL M tail (at most a quarter of the CUs' worth of half-height tiles) runs on a side stream beside the main launch instead of behind it
+LORA_REGEN_DROP = True   # LoRA input dropout: the forward does not write the dropped rows; the dA weight-gradient launch regenerates the mask while it stages x (uia_wgrad_drop)
 LORA_RANK3 = True        # q | k | v of a LoRA block: the three rank terms of the data gradient in one pass over it (uia_lora_rank_update) instead of three K = 64 launches
 QUAD = False             # 256x256 bf16 launches on the four-wave kernel (tile cfg 25, csrc/gemm_quad.hip: 128 x 128 per wave, one wave per SIMD) instead of cfg 8
 RING5 = False            # experiment knob: 256x256 launches with a long K loop or a wide N on the 5-deep ring (tile cfg 24: 160 KB of LDS, four sub-tiles in flight)
@@ -694,12 +695,20 @@ def float_to_three_byte(x):
     return hi, d.clamp(-127, 127).to(torch.int8)
 
 
-def wgrad(a, b, dw, dbias=None, alpha=1.0):
+def wgrad(a, b, dw, dbias=None, alpha=1.0, drop=None):
     """dw[I,J] += alpha * a.T @ b   (a [M,I], b [M,J]); dbias[I] += a.sum(0).  dw/dbias fp32, pre-zeroed or accumulating.
     dw may be SMALLER than [I, J] (a LoRA factor's own [out, r] / [r, in] gradient under 64-padded operands): only its extent is accumulated."""
     lda, ldb = _rowmajor(a, "a"), _rowmajor(b, "b")
     assert a.dtype == b.dtype and a.shape[0] == b.shape[0] and dw.dtype == torch.float32 and dw.is_contiguous() and dw.dim() == 2
     I, J = a.shape[1], b.shape[1]
+    if drop is not None:
+        # drop = (p, seed): b holds the UN-dropped rows of a [M, J] tensor (row stride ldb); the mask the forward drew for it is regenerated in the staging
+        p, seed = drop
+        if dbias is not None or a.dtype != torch.bfloat16 or ldb != J:
+            raise UiaError("wgrad(drop=...): bf16, no bias, and b must be the whole dropped tensor (contiguous rows)")
+        check(lib().uia_wgrad_drop(_stream(), _code(a.dtype), a.shape[0], I, J, _p(a), lda, _p(b), ldb, alpha, _p(dw), dw.shape[1], dw.shape[0], dw.shape[1],
+                                   float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, J, 0), "uia_wgrad_drop")
+        return
     if tuple(dw.shape) == (I, J):
         check(lib().uia_wgrad(_stream(), _code(a.dtype), a.shape[0], I, J, _p(a), lda, _p(b), ldb, alpha, _p(dw), _p(dbias)), "uia_wgrad")
         return

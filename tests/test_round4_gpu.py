@@ -460,3 +460,72 @@ def test_head_dim_16_attention_on_mfma_vs_torch(B, H, L):
     for i, t in enumerate((qf, kf, vf)):
         want = t.grad.permute(0, 2, 1, 3).reshape(B * L, D)
         assert rel(dqkv[:, i * D:(i + 1) * D], want) < 1.5e-2, ("dq", "dk", "dv")[i]
+
+
+# ------------------------------------------------------------------------------------------------ LoRA input dropout regenerated by the dA launch
+@pytest.mark.parametrize("M,K,p", [(32896, 1024, 0.1), (1000, 768, 0.25), (130, 64, 0.5)])
+def test_wgrad_with_regenerated_dropout_equals_wgrad_on_the_dropped_rows(M, K, p):
+    """uia_wgrad_drop: dA = s * q.T @ dropout(x) with the mask regenerated from the seed while x is staged (reference lora.py:82-87) must equal, bit for
+    bit, uia_wgrad on the rows the N = 64 stream kernel writes out as its by-product (same mask, same rounding of the kept values, same MFMA order)."""
+    from uia_hip import ops
+    g = torch.Generator(device="cpu").manual_seed(M + K)
+    dt = torch.bfloat16
+    x = torch.randn(M, K, generator=g).to(dev()).to(dt)
+    q = torch.randn(M, 64, generator=g).to(dev()).to(dt)
+    a_w = (torch.randn(64, K, generator=g) * 0.05).to(dev()).to(dt)
+    seed = 987654321
+    t, xd = torch.empty(M, 64, device=dev(), dtype=dt), torch.empty_like(x)
+    if M > 2048:
+        ops.gemm(x, a_w, out_t=t, drop=("a", p, seed, xd))                   # the forward's launch and its by-product
+    else:
+        ops.dropout(x, xd, p, seed)
+    kept = (xd != 0).float().mean().item()
+    assert abs(kept - (1 - p)) < 0.02
+    for r in (16, 64):
+        want = torch.zeros(r, K, device=dev())
+        ops.wgrad(q, xd, want, alpha=2.0)
+        got = torch.zeros(r, K, device=dev())
+        ops.wgrad(q, x, got, alpha=2.0, drop=(p, seed))
+        torch.cuda.synchronize()
+        assert float(want.abs().max()) > 0
+        # the M chunks of a launch meet in fp32 atomics: the order is not fixed, the sum is the same up to the association
+        assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
+    with pytest.raises(ops.UiaError):
+        ops.wgrad(q, x[:, :K // 2], torch.zeros(16, K // 2, device=dev()), drop=(p, seed))     # a column window of a wider tensor: not this wrapper's form
+
+
+def test_lora_block_gradients_do_not_depend_on_where_the_dropout_mask_is_applied():
+    """LoraAttnHalfFn with ops.LORA_REGEN_DROP (the forward keeps the un-dropped LayerNorm output once; the four dA launches regenerate their masks) against
+    the form that writes the four dropped inputs out: same seeds -> same loss, same input gradient, the same factor gradients."""
+    from uia_hip import functional as UF
+    from uia_hip import ops
+    from src.third_party.openai_clip.model import ResidualAttentionBlock
+    from src.adapters.lora import PlainMultiheadAttentionLoRA
+    UF.set_compute_dtype(torch.bfloat16)
+    torch.manual_seed(5)
+    D, H, B, L = 256, 4, 40, 65
+    blk = ResidualAttentionBlock(D, H).to(dev())
+    for q in blk.parameters():
+        q.requires_grad_(False)
+    blk.attn = PlainMultiheadAttentionLoRA(blk.attn, r=16, lora_alpha=32, dropout_rate=0.2).to(dev())
+    for k, q in blk.named_parameters():
+        q.requires_grad_("lora" in k.lower())
+        if "lora_B" in k:
+            torch.nn.init.normal_(q, std=0.05)
+    blk.train()
+    x = torch.randn(L, B, D, device=dev(), requires_grad=True)
+    outs = []
+    for regen in (True, False):
+        ops.LORA_REGEN_DROP = regen
+        UF.set_dropout_seed(1234)
+        for q in blk.parameters():
+            q.grad = None
+        x.grad = None
+        y = blk(x)
+        (y.float() ** 2).mean().backward()
+        outs.append((y.detach().clone(), x.grad.clone(), {k: q.grad.clone() for k, q in blk.named_parameters() if q.grad is not None}))
+    ops.LORA_REGEN_DROP = True
+    (y0, gx0, g0), (y1, gx1, g1) = outs
+    assert torch.equal(y0, y1) and torch.equal(gx0, gx1)
+    for k in g0:
+        assert float((g0[k] - g1[k]).abs().max()) <= 1e-5 * float(g1[k].abs().max() + 1e-12), k
