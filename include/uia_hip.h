@@ -260,6 +260,12 @@ int uia_mona_pre_bwd(void* stream, int dtype, int M, int D, const void* du, cons
  * it is the A operand of the preceding block's fc2 data-gradient GEMM and of nothing else.
  * ws: caller-owned scratch of uia_mona_pre_bwd_workspace_bytes(M, D) bytes (per-workgroup partial rows of the four parameter
  * gradients, summed by a second small launch: a direct atomic add from every workgroup serialises on the same 4*D addresses) */
+/* The same with project1's data gradient inside (bf16, bottleneck 64, D % 64 == 0, D <= 768): du = dt @ W1 is computed per 16-row tile on the matrix cores
+ * from dt [M, 64] (the gradient wrt project1's output, mona.py:127) and w1t = project1.weight transposed, [D, 64] row-major, instead of being read
+ * from a [M, D] tensor a K = 64 GEMM launch wrote; identical results (same products, same bf16 rounding of du). */
+int uia_mona_pre_bwd_du(void* stream, int dtype, int M, int D, const void* dt, int64_t ldt, const void* w1t, int64_t ldw1, const float* x, const float* dy,
+                        const float* norm_w, const float* norm_b, const float* gamma, const float* gammax, float eps,
+                        float* dx32, void* dxT, float* g_gamma, float* g_gammax, float* g_norm_w, float* g_norm_b, float* ws, int64_t dxT_kb_rows);
 size_t uia_mona_pre_bwd_workspace_bytes(int M, int D);
 int uia_mona_spatial_fwd(void* stream, int dtype, const uia_mona_spatial_desc* d);
 int uia_mona_spatial_bwd(void* stream, int dtype, const uia_mona_spatial_desc* d);

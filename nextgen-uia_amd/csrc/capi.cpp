@@ -77,6 +77,13 @@ int uia_mona_pre_bwd(void* stream, int dtype, int M, int D, const void* du, cons
     return uia_mona_pre_bwd_launch((hipStream_t)stream, dtype, M, D, du, x, dy, norm_w, norm_b, gamma, gammax, eps, dx32, dxT, g_gamma, g_gammax,
                                    g_norm_w, g_norm_b, ws, (long)dxT_kb_rows);
 }
+int uia_mona_pre_bwd_du(void* stream, int dtype, int M, int D, const void* dt, int64_t ldt, const void* w1t, int64_t ldw1, const float* x, const float* dy,
+                        const float* norm_w, const float* norm_b, const float* gamma, const float* gammax, float eps, float* dx32, void* dxT, float* g_gamma,
+                        float* g_gammax, float* g_norm_w, float* g_norm_b, float* ws, int64_t dxT_kb_rows) {
+    if (!dt || !w1t) { uia_set_error("uia_mona_pre_bwd_du: null dt / w1t"); return -1; }
+    return uia_mona_pre_bwd_launch((hipStream_t)stream, dtype, M, D, nullptr, x, dy, norm_w, norm_b, gamma, gammax, eps, dx32, dxT, g_gamma, g_gammax,
+                                   g_norm_w, g_norm_b, ws, (long)dxT_kb_rows, dt, (long)ldt, w1t, (long)ldw1);
+}
 size_t uia_mona_pre_bwd_workspace_bytes(int M, int D) { return uia_mona_pre_bwd_ws_floats(M, D) * sizeof(float); }
 int uia_mona_spatial_fwd(void* stream, int dtype, const uia_mona_spatial_desc* d) {
     NEED(d, "uia_mona_spatial_fwd");

@@ -80,11 +80,16 @@ __global__ __launch_bounds__(256) void mona_pre_fwd_kernel(int M, int D, const f
 // so the row loop carries THREE column sums and needs two parameter vectors (γ·w and γx); the reduce kernel applies w, b, γ.
 // (The first version carried dγ, dγx, dw, db and read w, b, γ, γx per row: 184 VGPRs, two waves per SIMD, 159 us for 619 MB.)
 // NV = float4 per lane (D ≤ 256·NV): the common D = 768 runs with NV = 3.
-template <typename T, int NV, bool KB = false>
-__global__ __launch_bounds__(256) void mona_pre_bwd_kernel(int M, int D, const T* __restrict__ du, const float* __restrict__ x,
+// FUSE (round 4, bf16): du = dt·W1 — project1's data gradient, a K = 64 GEMM that wrote 77 MB for this kernel to read back — is computed HERE: the block
+// walks 16-row tiles; its four waves multiply the tile's dt rows [16 x 64] with W1ᵀ ([D, 64] row-major, L2-resident) on the matrix cores, a quarter of the
+// columns each, and leave the bf16 tile in LDS in the row layout the row passes read (MFMA with W1ᵀ as the A operand: a lane gets four consecutive columns
+// of one row — one 8-byte LDS store per tile); same products in the same order and the same rounding to bf16 as the GEMM launch it replaces.
+template <typename T, int NV, bool KB = false, bool FUSE = false>
+__global__ __launch_bounds__(256, FUSE ? 3 : 1) void mona_pre_bwd_kernel(int M, int D, const T* __restrict__ du, const float* __restrict__ x,
                                                             const float* __restrict__ dy, const float* __restrict__ nw,
                                                             const float* __restrict__ gamma, const float* __restrict__ gammax, float eps,
-                                                            float* __restrict__ dx32, T* __restrict__ dxT, float* __restrict__ ws, long dxT_kb) {
+                                                            float* __restrict__ dx32, T* __restrict__ dxT, float* __restrict__ ws, long dxT_kb,
+                                                            const T* __restrict__ dtp, long ldt, const T* __restrict__ w1t, long ldw1) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // wave-uniform row → scalar row pointers
     // KB: the T copy of dx is written K-blocked ([D/g][dxT_kb rows][g], g = 64 bytes of elements).  A compile-time variant: the address
@@ -110,14 +115,14 @@ __global__ __launch_bounds__(256) void mona_pre_bwd_kernel(int M, int D, const T
     // (two register sets, the loop is unrolled by two): at four waves per SIMD one row in flight per wave left HBM at 4.6 TB/s.
     auto issue = [&](int row, f32x4 (&v)[NV], f32x4 (&d)[NV], f32x4 (&o)[NV]) {
         const float* xr = x + (size_t)row * D;
-        const T* dur = du + (size_t)row * D;
+        const T* dur = FUSE ? nullptr : du + (size_t)row * D;
         const float* dyr = dy + (size_t)row * D;
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             const int c = lane + 64 * k;
             const bool ok = c < nv;
             v[k] = ok ? load4(xr + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
-            d[k] = ok ? load4(dur + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (!FUSE) d[k] = ok ? load4(dur + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
             if (want_dx) o[k] = ok ? load4(dyr + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
@@ -176,9 +181,62 @@ __global__ __launch_bounds__(256) void mona_pre_bwd_kernel(int M, int D, const T
             }
         }
     };
+    f32x4 vA[NV], dA[NV], oA[NV], vB[NV], dB[NV], oB[NV];
+    if constexpr (FUSE) {
+        char* du_s = smem + (size_t)8 * D * sizeof(float);             // [16][D] bf16: the tile's du rows, behind the reduction area and the parameter vectors
+        const int ntiles = (M + 15) >> 4;
+        const int li = lane & 15, g = lane >> 4;
+        const int cw = D >> 2;                                         // columns per wave in the MFMA phase (a multiple of 16: D % 64 == 0)
+        auto from_lds = [&](int rl, f32x4 (&d)[NV]) {
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const int c = lane + 64 * k;
+                d[k] = c < nv ? load4((const T*)(du_s + ((size_t)rl * D + 4 * c) * sizeof(T))) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        };
+        int tile = blockIdx.x;
+        if (tile < ntiles && 16 * tile + 4 * wave < M) issue(16 * tile + 4 * wave, vA, dA, oA);
+        for (; tile < ntiles; tile += gridDim.x) {
+            const int r0 = 16 * tile;
+            {   // ---- du tile on the matrix cores: D[i = column 4g + r][j = row li] = Σ_k W1ᵀ[col0 + i][k]·dt[r0 + j][k]
+                const int rr = r0 + li < M ? r0 + li : M - 1;
+                const T* dtr = dtp + (size_t)rr * ldt + 8 * g;
+                uint4 b0 = *(const uint4*)dtr, b1 = *(const uint4*)(dtr + 32);
+                if (r0 + li >= M) b0 = b1 = uint4{0u, 0u, 0u, 0u};
+                const T* wbase = w1t + (size_t)(wave * cw + li) * ldw1 + 8 * g;
+                for (int c0 = 0; c0 < cw; c0 += 64) {                  // four column tiles per batch: eight 16-byte loads in flight
+                    uint4 a[4][2];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const T* wr = wbase + (size_t)(c0 + 16 * c) * ldw1;
+                        a[c][0] = *(const uint4*)wr;
+                        a[c][1] = *(const uint4*)(wr + 32);
+                    }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[c][0]), __builtin_bit_cast(bf16x8, b0), f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[c][1]), __builtin_bit_cast(bf16x8, b1), acc, 0, 0, 0);
+                        store4((T*)(du_s + ((size_t)li * D + wave * cw + c0 + 16 * c + 4 * g) * sizeof(T)), acc);
+                    }
+                }
+            }
+            __syncthreads();
+            const int nt = tile + gridDim.x;
+            const int rw = r0 + 4 * wave;                              // this wave's four rows of the tile; the first row of its next tile is requested under the last one
+            const int rnext = nt < ntiles ? 16 * nt + 4 * wave : M;
+#pragma clang loop unroll(disable)
+            for (int i = 0; i < 4; i += 2) {                           // rolled: one copy of the two row passes (unrolled four times the kernel took 240 VGPRs)
+                const int ra = rw + i, rb = rw + i + 1, rc = i == 0 ? rw + 2 : rnext;
+                if (rb < M) issue(rb, vB, dB, oB);
+                if (ra < M) { from_lds(4 * wave + i, dA); process(ra, vA, dA, oA); }
+                if (rc < M) issue(rc, vA, dA, oA);
+                if (rb < M) { from_lds(4 * wave + i + 1, dB); process(rb, vB, dB, oB); }
+            }
+            __syncthreads();                                           // every wave is done with the tile's du rows
+        }
+    } else {
     const int rstep = gridDim.x * 4;
     int row = blockIdx.x * 4 + wave;
-    f32x4 vA[NV], dA[NV], oA[NV], vB[NV], dB[NV], oB[NV];
     if (row < M) issue(row, vA, dA, oA);
     while (row < M) {
         const int rowB = row + rstep;
@@ -188,6 +246,7 @@ __global__ __launch_bounds__(256) void mona_pre_bwd_kernel(int M, int D, const T
         row = rowB + rstep;
         if (row < M) issue(row, vA, dA, oA);
         process(rowB, vB, dB, oB);
+    }
     }
     // block reduction in two rounds through [2][3 sums][D] (waves 2,3 park, waves 0,1 add on top): 8·D floats of LDS with the parameter
     // vectors, so that four workgroups fit a CU beside the 120 VGPRs
@@ -1036,14 +1095,17 @@ size_t uia_mona_pre_bwd_ws_floats(int M, int D) { return (size_t)mona_pre_bwd_bl
 
 int uia_mona_pre_bwd_launch(hipStream_t stream, int dtype, int M, int D, const void* du, const float* x, const float* dy, const float* nw,
                             const float* nb, const float* gamma, const float* gammax, float eps, float* dx32, void* dxT, float* g_gamma,
-                            float* g_gammax, float* g_nw, float* g_nb, float* ws, long dxT_kb_rows) {
+                            float* g_gammax, float* g_nw, float* g_nb, float* ws, long dxT_kb_rows, const void* dt, long ldt, const void* w1t, long ldw1) {
     UIA_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 1024, "uia_mona_pre_bwd: unsupported shape M=%d D=%d", M, D);
     UIA_CHECK_ARG(dxT_kb_rows == 0 || (dxT && dxT_kb_rows >= M && (D * (dtype == UIA_BF16 ? 2 : 4)) % 64 == 0 && dxT_kb_rows * (long)D < (1L << 31)),
                   "uia_mona_pre_bwd: dxT_kb_rows=%ld needs dxT, at least M=%d rows and whole 64-byte column blocks", dxT_kb_rows, M);
-    UIA_CHECK_ARG(du && x && nw && nb && gamma && gammax && g_gamma && g_gammax && g_nw && g_nb && ws, "uia_mona_pre_bwd: null tensor");
+    const bool fuse = dt != nullptr;                     // du = dt·W1 computed by this launch (uia_mona_pre_bwd_du)
+    UIA_CHECK_ARG((du || fuse) && x && nw && nb && gamma && gammax && g_gamma && g_gammax && g_nw && g_nb && ws, "uia_mona_pre_bwd: null tensor");
+    UIA_CHECK_ARG(!fuse || (dtype == UIA_BF16 && w1t && D % 64 == 0 && D <= 768 && ldt >= 64 && ldt % 8 == 0 && ldw1 >= 64 && ldw1 % 8 == 0 && (uintptr_t)dt % 16 == 0 && (uintptr_t)w1t % 16 == 0),
+                  "uia_mona_pre_bwd_du: bf16, bottleneck 64 (dt [M, 64], W1ᵀ [D, 64], 16-byte aligned rows), D a multiple of 64 up to 768");
     UIA_CHECK_ARG(dy || !(dx32 || dxT), "uia_mona_pre_bwd: dx requested without dy");
     int blocks = mona_pre_bwd_blocks(M);
-    const size_t lds = (size_t)8 * D * sizeof(float);   // [2][3][D] reduction area + [2][D] parameter vectors
+    const size_t lds = (size_t)8 * D * sizeof(float) + (fuse ? (size_t)16 * D * 2 : 0);   // [2][3][D] reduction area + [2][D] parameter vectors (+ the du tile, [16][D] bf16)
     const int nvsel = D <= 256 ? 1 : (D <= 768 ? 3 : 4);
     // persistent grid: exactly as many workgroups as are resident at once (a second, partial round would leave most CUs idle at the end)
 #define UIA_PRE_BWD(TT, NVV) do {                                                                                                              \
@@ -1052,8 +1114,26 @@ int uia_mona_pre_bwd_launch(hipStream_t stream, int dtype, int M, int D, const v
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds) == hipSuccess && per_cu > 0 &&                               \
             hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&       \
             ncu > 0 && per_cu * ncu < blocks) blocks = per_cu * ncu;                                                                           \
-        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, stream, M, D, (const TT*)du, x, dy, nw, gamma, gammax, eps, dx32, (TT*)dxT, ws, dxT_kb_rows); \
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, stream, M, D, (const TT*)du, x, dy, nw, gamma, gammax, eps, dx32, (TT*)dxT, ws, dxT_kb_rows, \
+                           (const TT*)nullptr, 0l, (const TT*)nullptr, 0l);                                                                     \
     } while (0)
+    if (fuse) {
+        auto kern = dxT_kb_rows ? mona_pre_bwd_kernel<bf16_t, 3, true, true> : mona_pre_bwd_kernel<bf16_t, 3, false, true>;
+        static UiaDevOnce once_a, once_b;
+        if (dxT_kb_rows) UIA_ENSURE_LDS_ATTR(once_a, (mona_pre_bwd_kernel<bf16_t, 3, true, true>), 160 * 1024);
+        else UIA_ENSURE_LDS_ATTR(once_b, (mona_pre_bwd_kernel<bf16_t, 3, false, true>), 160 * 1024);
+        int per_cu = 0, dev = 0, ncu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds) == hipSuccess && per_cu > 0 && hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && ncu > 0 && per_cu * ncu < blocks) blocks = per_cu * ncu;
+        const int ntiles = (M + 15) / 16;
+        if (blocks > ntiles) blocks = ntiles;
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, stream, M, D, (const bf16_t*)nullptr, x, dy, nw, gamma, gammax, eps, dx32, (bf16_t*)dxT, ws, dxT_kb_rows,
+                           (const bf16_t*)dt, ldt, (const bf16_t*)w1t, ldw1);
+        UIA_CHECK_LAUNCH();
+        hipLaunchKernelGGL(mona_pre_reduce_kernel, dim3((3 * D + 255) / 256, PRE_RED_SPLIT), dim3(256), 0, stream, blocks, D, ws, nw, nb, gamma, g_gamma, g_gammax, g_nw, g_nb);
+        UIA_CHECK_LAUNCH();
+        return 0;
+    }
     if (dtype == UIA_BF16) { if (nvsel == 1) UIA_PRE_BWD(bf16_t, 1); else if (nvsel == 3) UIA_PRE_BWD(bf16_t, 3); else UIA_PRE_BWD(bf16_t, 4); }
     else if (dtype == UIA_F32) { if (nvsel == 1) UIA_PRE_BWD(float, 1); else if (nvsel == 3) UIA_PRE_BWD(float, 3); else UIA_PRE_BWD(float, 4); }
     else { uia_set_error("uia_mona_pre_bwd: bad dtype %d", dtype); return -1; }

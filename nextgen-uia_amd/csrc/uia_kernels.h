@@ -34,7 +34,8 @@ int uia_mona_pre_fwd_launch(hipStream_t stream, int dtype, int M, int D, const f
                             const float* gammax, float eps, void* u);
 int uia_mona_pre_bwd_launch(hipStream_t stream, int dtype, int M, int D, const void* du, const float* x, const float* dy, const float* nw,
                             const float* nb, const float* gamma, const float* gammax, float eps, float* dx32, void* dxT, float* g_gamma,
-                            float* g_gammax, float* g_nw, float* g_nb, float* ws, long dxT_kb_rows);
+                            float* g_gammax, float* g_nw, float* g_nb, float* ws, long dxT_kb_rows, const void* dt = nullptr, long ldt = 0,
+                            const void* w1t = nullptr, long ldw1 = 0);
 size_t uia_mona_pre_bwd_ws_floats(int M, int D);
 int uia_mona_spatial_fwd_launch(hipStream_t stream, int dtype, const uia_mona_spatial_desc& p);
 int uia_mona_spatial_bwd_launch(hipStream_t stream, int dtype, const uia_mona_spatial_desc& p);

@@ -593,14 +593,16 @@ class MonaFn(torch.autograd.Function):
         ops.mona_spatial_bwd(variant, B, h, w, t, sp, dd, dtt, sg, p_drop=p_drop, seed=seed, keep_mask=keep_mask)
         # project1: du = dt·W1 ; dW1 = dtᵀ·u ; db1 = Σ dt
         w1t = WEIGHTS.get(P["project1.weight"], dt, transpose=True)          # [D, bott]
-        du = _empty((M, D), dt, x)
+        fuse_du = x.is_cuda and ops.mona_pre_bwd_du_ok(M, D, bott, dt)       # du = dt·W1 inside the row kernel below: no [M, D] round trip
+        du = None if fuse_du else _empty((M, D), dt, x)
         if side is not None:
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 ops.wgrad(dtt, u, G["project1.weight"], G["project1.bias"])
             dtt.record_stream(side)
             u.record_stream(side)
-        ops.gemm(dtt, w1t, out_t=du)
+        if not fuse_du:
+            ops.gemm(dtt, w1t, out_t=du)
         if side is None:
             ops.wgrad(dtt, u, G["project1.weight"], G["project1.bias"])
         need_dx = ctx.needs_input_grad[0]
@@ -609,7 +611,8 @@ class MonaFn(torch.autograd.Function):
         # allow_kb): K-blocked when that launch runs on the ring kernels
         dx_t = _act(M, D, dt, x, 4 * D) if (need_dx and dt != torch.float32) else None
         ops.mona_pre_bwd(du, x, dy if need_dx else None, P["norm.weight"], P["norm.bias"], P["gamma"], P["gammax"], dx, dx_t,
-                         G["gamma"], G["gammax"], G["norm.weight"], G["norm.bias"])
+                         G["gamma"], G["gammax"], G["norm.weight"], G["norm.bias"],
+                         dt_w1t=(dtt, w1t.row if isinstance(w1t, ops.PackedW) else w1t) if fuse_du else None)
         if need_dx:
             publish_t_copy(dx, dx_t)
         grads = tuple(None if direct else (G[k] if ctx.needs_input_grad[7 + i] else None) for i, k in enumerate(names))

@@ -72,6 +72,7 @@ TILE_GROUP = {}          # experiment knob: {N: row panels per tile-order group}
 HALF_HEIGHT_SHORT_K = True   # N <= 768, K <= 768 (bf16) launches whose 256-row tiling leaves a ragged last round run on half-height tiles (cfg 14) in one launch
 TAIL_SPLIT = True        # split off the M tail of a launch whose last round of 256x256 tiles would leave most CUs idle
 TAIL_SIDE_STREAM = True  # a SMALL M tail (at most a quarter of the CUs' worth of half-height tiles) runs on a side stream beside the main launch instead of behind it
+MONA_PRE_BWD_DU = True   # Mona backward: project1's data gradient (K = 64) inside the pre-norm backward row kernel (uia_mona_pre_bwd_du) instead of a GEMM launch + a 77 MB round trip
 LORA_REGEN_DROP = True   # LoRA input dropout: the forward does not write the dropped rows; the dA weight-gradient launch regenerates the mask while it stages x (uia_wgrad_drop)
 LORA_RANK3 = True        # q | k | v of a LoRA block: the three rank terms of the data gradient in one pass over it (uia_lora_rank_update) instead of three K = 64 launches
 QUAD = False             # 256x256 bf16 launches on the four-wave kernel (tile cfg 25, csrc/gemm_quad.hip: 128 x 128 per wave, one wave per SIMD) instead of cfg 8
@@ -897,7 +898,13 @@ def mona_pre_fwd(x, norm_w, norm_b, gamma, gammax, u, eps=1e-5):
     check(lib().uia_mona_pre_fwd(_stream(), _code(u.dtype), x.numel() // D, D, _p(x), _p(norm_w), _p(norm_b), _p(gamma), _p(gammax), eps, _p(u)), "uia_mona_pre_fwd")
 
 
-def mona_pre_bwd(du, x, dy, norm_w, norm_b, gamma, gammax, dx32, dx_t, g_gamma, g_gammax, g_norm_w, g_norm_b, eps=1e-5):
+def mona_pre_bwd_du_ok(M, D, bott, dt):
+    """Shapes uia_mona_pre_bwd_du takes: bf16, bottleneck 64, D a multiple of 64 up to 768 (the row kernel's three-float4-per-lane instantiation)."""
+    return MONA_PRE_BWD_DU and dt == torch.bfloat16 and bott == 64 and D % 64 == 0 and 512 < D <= 768
+
+
+def mona_pre_bwd(du, x, dy, norm_w, norm_b, gamma, gammax, dx32, dx_t, g_gamma, g_gammax, g_norm_w, g_norm_b, eps=1e-5, dt_w1t=None):
+    """dt_w1t = (dt [M, 64], W1ᵀ [D, 64]) instead of du: project1's data gradient du = dt·W1 is computed inside the launch (uia_mona_pre_bwd_du)."""
     D = gamma.numel()
     M = x.numel() // D
     ws = torch.empty(lib().uia_mona_pre_bwd_workspace_bytes(M, D) // 4, device=x.device, dtype=torch.float32)
@@ -907,6 +914,14 @@ def mona_pre_bwd(du, x, dy, norm_w, norm_b, gamma, gammax, dx32, dx_t, g_gamma, 
         if rows != M or cols != D:
             raise UiaError(f"mona_pre_bwd dx_t (K-blocked {tuple(dx_t.t.shape)}) does not hold [{M}, {D}]")
         dx_t = dx_t.t
+    if dt_w1t is not None:
+        dtt, w1t = dt_w1t
+        if dtt.dtype != torch.bfloat16 or w1t.dtype != torch.bfloat16 or tuple(dtt.shape) != (M, 64) or tuple(w1t.shape) != (D, 64):
+            raise UiaError(f"mona_pre_bwd: dt {tuple(dtt.shape)} {dtt.dtype} / W1ᵀ {tuple(w1t.shape)} {w1t.dtype} must be bf16 [{M}, 64] / [{D}, 64]")
+        check(lib().uia_mona_pre_bwd_du(_stream(), _code(dtt.dtype), M, D, _p(dtt), _rowmajor(dtt, "dt"), _p(w1t), _rowmajor(w1t, "w1t"), _p(x), _p(dy), _p(norm_w),
+                                        _p(norm_b), _p(gamma), _p(gammax), eps, _p(dx32), _p(dx_t), _p(g_gamma), _p(g_gammax), _p(g_norm_w), _p(g_norm_b), _p(ws),
+                                        kb_rows), "uia_mona_pre_bwd_du")
+        return
     check(lib().uia_mona_pre_bwd(_stream(), _code(du.dtype), M, D, _p(du), _p(x), _p(dy), _p(norm_w), _p(norm_b), _p(gamma), _p(gammax),
                                  eps, _p(dx32), _p(dx_t), _p(g_gamma), _p(g_gammax), _p(g_norm_w), _p(g_norm_b), _p(ws), kb_rows), "uia_mona_pre_bwd")
 

@@ -529,3 +529,41 @@ def test_lora_block_gradients_do_not_depend_on_where_the_dropout_mask_is_applied
     assert torch.equal(y0, y1) and torch.equal(gx0, gx1)
     for k in g0:
         assert float((g0[k] - g1[k]).abs().max()) <= 1e-5 * float(g1[k].abs().max() + 1e-12), k
+
+
+# ------------------------------------------------------------------------------------------------ Mona: project1's data gradient inside the pre-norm backward
+@pytest.mark.parametrize("M,kb", [(50432, True), (50432, False), (1000, False), (37, False)])
+def test_mona_pre_bwd_with_the_k64_data_gradient_inside_equals_the_two_launches(M, kb):
+    """uia_mona_pre_bwd_du computes du = dt·W1 per 16-row tile on the matrix cores instead of reading the [M, D] tensor a K = 64 GEMM launch wrote
+    (reference mona.py:118-127: u = norm(x)·gamma + x·gammax; t = project1(u)).  Same products in the same order, same bf16 rounding of du: dx (fp32 and
+    its T copy, row-major or K-blocked) must be bit-identical to the two-launch form, the four parameter gradients equal up to the order of their fp32 sums."""
+    from uia_hip import ops
+    g = torch.Generator(device="cpu").manual_seed(M)
+    D, dt = 768, torch.bfloat16
+    x = torch.randn(M, D, generator=g).to(dev()) * 1.5 + 0.3
+    dy = torch.randn(M, D, generator=g).to(dev())
+    dtt = torch.randn(M, 64, generator=g).to(dev()).to(dt)
+    w1 = (torch.randn(64, D, generator=g) * 0.05).to(dev())                  # project1.weight [64, D]
+    w1t = w1.t().contiguous().to(dt)                                          # [D, 64]
+    nw, nb = (1 + 0.1 * torch.randn(D, generator=g)).to(dev()), (0.1 * torch.randn(D, generator=g)).to(dev())
+    gam, gamx = (0.5 * torch.randn(D, generator=g)).to(dev()), (1 + 0.1 * torch.randn(D, generator=g)).to(dev())
+    kb = kb and M > 2048
+
+    def run(fused):
+        dx = torch.full((M, D), float("nan"), device=dev())
+        dx_t = ops.kb_empty(M, D, dt, dev()) if kb else torch.full((M, D), float("nan"), device=dev(), dtype=dt)
+        G = [torch.zeros(D, device=dev()) for _ in range(4)]
+        if fused:
+            ops.mona_pre_bwd(None, x, dy, nw, nb, gam, gamx, dx, dx_t, *G, dt_w1t=(dtt, w1t))
+        else:
+            du = torch.empty(M, D, device=dev(), dtype=dt)
+            ops.gemm(dtt, w1t, out_t=du)
+            ops.mona_pre_bwd(du, x, dy, nw, nb, gam, gamx, dx, dx_t, *G)
+        torch.cuda.synchronize()
+        return dx, (dx_t.t.clone() if kb else dx_t), G
+
+    dx0, t0, G0 = run(False)
+    dx1, t1, G1 = run(True)
+    assert not torch.isnan(dx1).any() and torch.equal(dx0, dx1) and torch.equal(t0, t1)
+    for a, b in zip(G0, G1):
+        assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max() + 1e-12)
