@@ -252,6 +252,10 @@ typedef struct uia_mona_spatial_desc {
 size_t uia_mona_spatial_workspace_bytes(int B);
 int uia_mona_pre_fwd(void* stream, int dtype, int M, int D, const float* x, const float* norm_w, const float* norm_b,
                      const float* gamma, const float* gammax, float eps, void* u);
+/* uia_mona_pre_fwd with project1 inside (bf16, D = 768, bottleneck 64): also writes t = u @ w1.T + b1 (mona.py:126-127), w1 = project1.weight [64, D] row-major,
+ * t [M, ldt >= 64]; bit-identical to uia_mona_pre_fwd followed by uia_gemm on the N = 64 stream kernel. */
+int uia_mona_pre_fwd_t(void* stream, int dtype, int M, int D, const float* x, const float* norm_w, const float* norm_b, const float* gamma, const float* gammax,
+                       float eps, void* u, const void* w1, int64_t ldw1, const float* b1, void* t, int64_t ldt);
 int uia_mona_pre_bwd(void* stream, int dtype, int M, int D, const void* du, const float* x, const float* dy,
                      const float* norm_w, const float* norm_b, const float* gamma, const float* gammax, float eps,
                      float* dx32, void* dxT, float* g_gamma, float* g_gammax, float* g_norm_w, float* g_norm_b, float* ws,

@@ -77,6 +77,10 @@ int uia_mona_pre_bwd(void* stream, int dtype, int M, int D, const void* du, cons
     return uia_mona_pre_bwd_launch((hipStream_t)stream, dtype, M, D, du, x, dy, norm_w, norm_b, gamma, gammax, eps, dx32, dxT, g_gamma, g_gammax,
                                    g_norm_w, g_norm_b, ws, (long)dxT_kb_rows);
 }
+int uia_mona_pre_fwd_t(void* stream, int dtype, int M, int D, const float* x, const float* norm_w, const float* norm_b, const float* gamma, const float* gammax,
+                       float eps, void* u, const void* w1, int64_t ldw1, const float* b1, void* t, int64_t ldt) {
+    return uia_mona_pre_fwd_t_launch((hipStream_t)stream, dtype, M, D, x, norm_w, norm_b, gamma, gammax, eps, u, w1, (long)ldw1, b1, t, (long)ldt);
+}
 int uia_mona_pre_bwd_du(void* stream, int dtype, int M, int D, const void* dt, int64_t ldt, const void* w1t, int64_t ldw1, const float* x, const float* dy,
                         const float* norm_w, const float* norm_b, const float* gamma, const float* gammax, float eps, float* dx32, void* dxT, float* g_gamma,
                         float* g_gammax, float* g_norm_w, float* g_norm_b, float* ws, int64_t dxT_kb_rows) {

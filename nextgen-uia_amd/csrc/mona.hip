@@ -74,6 +74,79 @@ __global__ __launch_bounds__(256) void mona_pre_fwd_kernel(int M, int D, const f
     }
 }
 
+// The same with project1 inside (round 4, bf16, bottleneck 64, D = 768): t = u·W1ᵀ + b1 (mona.py:126-127) was the N = 64 stream kernel reading back the u this
+// kernel had just written.  Here a block walks 16-row tiles: every wave writes its four u rows to global memory (the backward's weight gradient reads them) AND
+// to a bf16 LDS tile; then wave w multiplies the tile with its sixteen rows of W1 — its 24 A fragments stay in registers for the whole launch (96 VGPRs: the
+// row pass needs 12) — in the k order of the stream kernel it replaces: t is bit-identical.  LDS rows are padded by 16 bytes: the sixteen rows of a
+// ds_read_b128 land on sixteen different bank quads.
+template <int KS>                                              // K steps of 32 columns: D = 32·KS
+__global__ __launch_bounds__(256) void mona_pre_fwd_t_kernel(int M, const float* __restrict__ x, const float* __restrict__ nw, const float* __restrict__ nb,
+                                                              const float* __restrict__ gamma, const float* __restrict__ gammax, float eps,
+                                                              bf16_t* __restrict__ u, const bf16_t* __restrict__ w1, long ldw1, const float* __restrict__ b1,
+                                                              bf16_t* __restrict__ t, long ldt) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int D = 32 * KS, NVF = D / 256, ROWB = 2 * D + 16;
+    static_assert(D % 256 == 0, "three float4 per lane and row");
+    const int lane = threadIdx.x & 63, li = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint4 wf[KS];                                              // W1 rows 16w + li (the MFMA A operand: rows = columns of t), bytes 64ks + 16g
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) wf[ks] = *(const uint4*)(w1 + (size_t)(16 * wave + li) * ldw1 + 32 * ks + 8 * g);
+    f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+    if (b1) bias = *(const f32x4*)(b1 + 16 * wave + 4 * g);
+    const int ntiles = (M + 15) >> 4;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int r0 = 16 * tile;
+#pragma unroll 1
+        for (int i = 0; i < 4; ++i) {
+            const int rl = 4 * wave + i, row = r0 + rl;
+            char* urow = smem + rl * ROWB;
+            if (row >= M) {                                    // rows past the end: zeros (their t rows are not stored)
+#pragma unroll
+                for (int k = 0; k < NVF; ++k) *(uint2*)(urow + 8 * (lane + 64 * k)) = uint2{0u, 0u};
+                continue;
+            }
+            const float* xr = x + (size_t)row * D;
+            f32x4 v[NVF];
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < NVF; ++k) { v[k] = load4(xr + 4 * (lane + 64 * k)); s += v[k][0] + v[k][1] + v[k][2] + v[k][3]; }      // the association of mona_pre_fwd_kernel: u is bit-identical
+            const float mean = wave_sum(s) / D;
+            float q = 0.f;
+#pragma unroll
+            for (int k = 0; k < NVF; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float d = v[k][e] - mean; q = fmaf(d, d, q); }
+            const float rstd = rsqrtf(wave_sum(q) / D + eps);
+#pragma unroll
+            for (int k = 0; k < NVF; ++k) {
+                const int c = lane + 64 * k;
+                const f32x4 w = load4(nw + 4 * c), b = load4(nb + 4 * c), gm = load4(gamma + 4 * c), gx = load4(gammax + 4 * c);
+                f32x4 y;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float n = fmaf((v[k][e] - mean) * rstd, w[e], b[e]);
+                    y[e] = fmaf(n, gm[e], v[k][e] * gx[e]);
+                }
+                store4(u + (size_t)row * D + 4 * c, y);
+                store4((bf16_t*)(urow + 8 * c), y);
+            }
+        }
+        __syncthreads();
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};                      // D[i = t column 16w + 4g + r][j = row li]
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const uint4 uf = *(const uint4*)(smem + li * ROWB + 64 * ks + 16 * g);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[ks]), __builtin_bit_cast(bf16x8, uf), acc, 0, 0, 0);
+        }
+        if (r0 + li < M) {
+            const f32x4 o = {acc[0] + bias[0], acc[1] + bias[1], acc[2] + bias[2], acc[3] + bias[3]};
+            store4(t + (size_t)(r0 + li) * ldt + 16 * wave + 4 * g, o);
+        }
+        __syncthreads();
+    }
+}
+
 // rows are dealt to waves in a grid-stride loop so that every wave keeps per-column partial sums in registers; one LDS reduction
 // and one partial row per block.  With u = n·γ + x·γx, n = x̂·w + b  (mona.py:118-124) the four parameter gradients are
 //     dγ = w·S1 + b·S0,   dw = γ·S1,   db = γ·S0,   dγx = S2      with  S0 = Σ_m du,  S1 = Σ_m du·x̂,  S2 = Σ_m du·x,
@@ -1073,6 +1146,24 @@ int check_spatial(const uia_mona_spatial_desc& p, bool bwd) {
 }
 
 }  // namespace
+
+int uia_mona_pre_fwd_t_launch(hipStream_t stream, int dtype, int M, int D, const float* x, const float* nw, const float* nb, const float* gamma,
+                              const float* gammax, float eps, void* u, const void* w1, long ldw1, const float* b1, void* t, long ldt) {
+    UIA_CHECK_ARG(dtype == UIA_BF16 && D == 768 && M > 0, "uia_mona_pre_fwd_t: bf16, D = 768 (got dtype %d, D = %d)", dtype, D);
+    UIA_CHECK_ARG(x && nw && nb && gamma && gammax && u && w1 && t && ldw1 >= D && ldw1 % 8 == 0 && ldt >= 64 && ldt % 4 == 0 && (uintptr_t)w1 % 16 == 0 && (uintptr_t)t % 8 == 0 &&
+                      (!b1 || (uintptr_t)b1 % 16 == 0),
+                  "uia_mona_pre_fwd_t: null tensor, or W1 [64, D] / t [M, 64] rows not 16- / 8-byte aligned");
+    constexpr int KS = 24;
+    const int lds = 16 * (2 * 32 * KS + 16);
+    const int ntiles = (M + 15) / 16;
+    int blocks = ntiles;
+    int per_cu = 0, dev = 0, ncu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mona_pre_fwd_t_kernel<KS>, 256, lds) == hipSuccess && per_cu > 0 && hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && ncu > 0 && per_cu * ncu < blocks) blocks = per_cu * ncu;
+    hipLaunchKernelGGL(mona_pre_fwd_t_kernel<KS>, dim3(blocks), dim3(256), lds, stream, M, x, nw, nb, gamma, gammax, eps, (bf16_t*)u, (const bf16_t*)w1, ldw1, b1, (bf16_t*)t, ldt);
+    UIA_CHECK_LAUNCH();
+    return 0;
+}
 
 int uia_mona_pre_fwd_launch(hipStream_t stream, int dtype, int M, int D, const float* x, const float* nw, const float* nb, const float* gamma,
                             const float* gammax, float eps, void* u) {

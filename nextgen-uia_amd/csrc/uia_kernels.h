@@ -32,6 +32,8 @@ int uia_wgrad_launch(hipStream_t stream, int dtype, int M, int I, int J, const v
                      long ldw = 0, int i_valid = 0, int j_valid = 0, float drop_p = 0.f, uint64_t drop_seed = 0, long drop_ld = 0, int drop_col0 = 0);
 int uia_mona_pre_fwd_launch(hipStream_t stream, int dtype, int M, int D, const float* x, const float* nw, const float* nb, const float* gamma,
                             const float* gammax, float eps, void* u);
+int uia_mona_pre_fwd_t_launch(hipStream_t stream, int dtype, int M, int D, const float* x, const float* nw, const float* nb, const float* gamma,
+                              const float* gammax, float eps, void* u, const void* w1, long ldw1, const float* b1, void* t, long ldt);
 int uia_mona_pre_bwd_launch(hipStream_t stream, int dtype, int M, int D, const void* du, const float* x, const float* dy, const float* nw,
                             const float* nb, const float* gamma, const float* gammax, float eps, float* dx32, void* dxT, float* g_gamma,
                             float* g_gammax, float* g_nw, float* g_nb, float* ws, long dxT_kb_rows, const void* dt = nullptr, long ldt = 0,

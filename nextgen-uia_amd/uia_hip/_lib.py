@@ -90,6 +90,7 @@ PROTOTYPES = {
     "uia_layernorm_bwd3": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, i64, vp, vp, vp, vp, i64, vp, f32, vp, vp, vp, vp, vp, vp]),
     "uia_mona_pre_fwd": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, f32, vp]),
     "uia_mona_pre_bwd": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, i64]),
+    "uia_mona_pre_fwd_t": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, f32, vp, vp, i64, vp, vp, i64]),
     "uia_mona_pre_bwd_du": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, i64]),
     "uia_mona_pre_bwd_workspace_bytes": (sz, [C.c_int, C.c_int]),
     "uia_mona_spatial_fwd": (C.c_int, [vp, C.c_int, C.POINTER(MonaSpatialDesc)]),

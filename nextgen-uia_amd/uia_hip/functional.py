@@ -530,10 +530,14 @@ class MonaFn(torch.autograd.Function):
             ctx.direct_params = tuple(params) if direct else None
             return y
         u = _empty((M, D), dt, x)
-        ops.mona_pre_fwd(x, P["norm.weight"], P["norm.bias"], P["gamma"], P["gammax"], u)
         w1 = WEIGHTS.get(P["project1.weight"], dt)
         t = _empty((M, bott), dt, x)
-        ops.gemm(u, w1, bias=P["project1.bias"], out_t=t)
+        if ops.MONA_PRE_FWD_T and x.is_cuda and dt == torch.bfloat16 and D == 768 and bott == 64:
+            # project1 inside the row kernel: t from the u tile in LDS, u itself still written for the backward's weight gradient
+            ops.mona_pre_fwd(x, P["norm.weight"], P["norm.bias"], P["gamma"], P["gammax"], u, proj1=(w1.row if isinstance(w1, ops.PackedW) else w1, P["project1.bias"], t))
+        else:
+            ops.mona_pre_fwd(x, P["norm.weight"], P["norm.bias"], P["gamma"], P["gammax"], u)
+            ops.gemm(u, w1, bias=P["project1.bias"], out_t=t)
         sp = {_SPATIAL_MAP[k]: v.detach().contiguous() for k, v in P.items() if k in _SPATIAL_MAP}
         d = _empty((M, bott), dt, x)
         seed = _next_seed() if (p_drop > 0 and keep_mask is None) else 0

@@ -72,6 +72,7 @@ TILE_GROUP = {}          # experiment knob: {N: row panels per tile-order group}
 HALF_HEIGHT_SHORT_K = True   # N <= 768, K <= 768 (bf16) launches whose 256-row tiling leaves a ragged last round run on half-height tiles (cfg 14) in one launch
 TAIL_SPLIT = True        # split off the M tail of a launch whose last round of 256x256 tiles would leave most CUs idle
 TAIL_SIDE_STREAM = True  # a SMALL M tail (at most a quarter of the CUs' worth of half-height tiles) runs on a side stream beside the main launch instead of behind it
+MONA_PRE_FWD_T = True    # Mona forward: project1 (768 -> 64) inside the pre-norm row kernel (uia_mona_pre_fwd_t) instead of the N = 64 stream launch reading u back
 MONA_PRE_BWD_DU = True   # Mona backward: project1's data gradient (K = 64) inside the pre-norm backward row kernel (uia_mona_pre_bwd_du) instead of a GEMM launch + a 77 MB round trip
 LORA_REGEN_DROP = True   # LoRA input dropout: the forward does not write the dropped rows; the dA weight-gradient launch regenerates the mask while it stages x (uia_wgrad_drop)
 LORA_RANK3 = True        # q | k | v of a LoRA block: the three rank terms of the data gradient in one pass over it (uia_lora_rank_update) instead of three K = 64 launches
@@ -893,8 +894,17 @@ def gather_rows(src, idx, dst):
 _SPATIAL_KEYS = ("conv1_w", "conv1_b", "conv2_w", "conv2_b", "conv3_w", "conv3_b", "proj_w", "proj_b", "freq", "ne1_w", "ne1_b", "ne3_w", "ne3_b")
 
 
-def mona_pre_fwd(x, norm_w, norm_b, gamma, gammax, u, eps=1e-5):
+def mona_pre_fwd(x, norm_w, norm_b, gamma, gammax, u, eps=1e-5, proj1=None):
+    """proj1 = (w1 [64, D] T row-major, b1 fp32 [64] or None, t [M, 64] T): project1 runs inside the launch (uia_mona_pre_fwd_t: bf16, D = 768)."""
     D = gamma.numel()
+    if proj1 is not None:
+        w1, b1, t = proj1
+        M = x.numel() // D
+        if u.dtype != torch.bfloat16 or w1.dtype != u.dtype or t.dtype != u.dtype or tuple(w1.shape) != (64, D) or tuple(t.shape) != (M, 64):
+            raise UiaError(f"mona_pre_fwd proj1: w1 {tuple(w1.shape)} / t {tuple(t.shape)} must be bf16 [64, {D}] / [{M}, 64]")
+        check(lib().uia_mona_pre_fwd_t(_stream(), _code(u.dtype), M, D, _p(x), _p(norm_w), _p(norm_b), _p(gamma), _p(gammax), eps, _p(u), _p(w1), _rowmajor(w1, "w1"),
+                                       _p(b1), _p(t), _rowmajor(t, "t")), "uia_mona_pre_fwd_t")
+        return
     check(lib().uia_mona_pre_fwd(_stream(), _code(u.dtype), x.numel() // D, D, _p(x), _p(norm_w), _p(norm_b), _p(gamma), _p(gammax), eps, _p(u)), "uia_mona_pre_fwd")
 
 

@@ -567,3 +567,29 @@ def test_mona_pre_bwd_with_the_k64_data_gradient_inside_equals_the_two_launches(
     assert not torch.isnan(dx1).any() and torch.equal(dx0, dx1) and torch.equal(t0, t1)
     for a, b in zip(G0, G1):
         assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max() + 1e-12)
+
+
+@pytest.mark.parametrize("M", [50432, 1000, 37])
+def test_mona_pre_fwd_with_project1_inside_equals_the_two_launches(M):
+    """uia_mona_pre_fwd_t: u = norm(x)·gamma + x·gammax AND t = project1(u) (reference mona.py:118-127) in one launch — the u tile goes through LDS to the
+    matrix cores in the k order of the N = 64 stream kernel: u and t bit-identical to uia_mona_pre_fwd + uia_gemm."""
+    from uia_hip import ops
+    g = torch.Generator(device="cpu").manual_seed(M + 1)
+    D, dt = 768, torch.bfloat16
+    x = torch.randn(M, D, generator=g).to(dev()) * 1.5 + 0.3
+    nw, nb = (1 + 0.1 * torch.randn(D, generator=g)).to(dev()), (0.1 * torch.randn(D, generator=g)).to(dev())
+    gam, gamx = (0.5 * torch.randn(D, generator=g)).to(dev()), (1 + 0.1 * torch.randn(D, generator=g)).to(dev())
+    w1 = (torch.randn(64, D, generator=g) * 0.05).to(dev()).to(dt)
+    b1 = torch.randn(64, generator=g).to(dev())
+    u0, t0 = torch.empty(M, D, device=dev(), dtype=dt), torch.empty(M, 64, device=dev(), dtype=dt)
+    ops.mona_pre_fwd(x, nw, nb, gam, gamx, u0)
+    ops.gemm(u0, w1, bias=b1, out_t=t0)
+    u1, t1 = torch.full((M, D), float("nan"), device=dev(), dtype=dt), torch.full((M, 64), float("nan"), device=dev(), dtype=dt)
+    ops.mona_pre_fwd(x, nw, nb, gam, gamx, u1, proj1=(w1, b1, t1))
+    torch.cuda.synchronize()
+    assert torch.equal(u0, u1) and not torch.isnan(t1.float()).any()
+    if M > 2048:
+        assert torch.equal(t0, t1)                                           # the stream kernel (tile cfg 16): the same MFMA chain
+    else:
+        assert rel(t1, t0) < 1e-2                                            # small M runs project1 on another tile config: equal up to the fp32 order
+    assert rel(t1, u0.float() @ w1.float().T + b1) < 1e-2
