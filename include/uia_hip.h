@@ -325,6 +325,24 @@ typedef struct uia_lora_rank_desc {
 } uia_lora_rank_desc;
 int uia_lora_rank_update(void* stream, int dtype, const uia_lora_rank_desc* d);
 
+/* LayerNorm + the down-projections of up to three LinearLoRA wrappers that share the input (q, k, v of an OpenAI-CLIP block; reference lora.py:82-87:
+ * dropout(x) @ A.T, one nn.Dropout per wrapper) in one launch:  h = LayerNorm(x) (written, bf16 [M, D]) and  T[s] = dropout_s(h) @ A[s][:16].T.
+ * bf16, D = 768 or 1024, rank <= 16 (A[s]: bf16 [>= 16, lda >= D], the first 16 rows are used); T: bf16 [nsrc][M][64] (t_stride elements between
+ * sources), columns 0..15 hold the products and 16..63 zeros (the K-extension operand of uia_gemm_desc.A2 is 64 wide).  drop_p = 0: no dropout; otherwise
+ * mask_s is the mask uia_gemm_desc.drop_where = 1 / uia_dropout draw for the [M, D] tensor h from seed[s] — uia_wgrad_drop regenerates it in the backward. */
+typedef struct uia_ln_lora_desc {
+    int32_t M, D, nsrc;
+    float eps;
+    const float* x; int64_t ldx;
+    const float *gamma, *beta;
+    void* h;
+    const void* A[3]; int64_t lda;
+    void* T; int64_t t_stride;
+    float drop_p;
+    uint64_t seed[3];
+} uia_ln_lora_desc;
+int uia_ln_lora_down(void* stream, int dtype, const uia_ln_lora_desc* d);
+
 /* ---------------------------------------------------------------------------------------------
  * Task heads of the feature-pyramid adapter (reference src/third_party/timm/clip_adapter.py:47-57, 118-160).
  * uia_upsample_bilinear_fwd: nn.Upsample((H,W), mode="bilinear", align_corners=False) of a token-major map

@@ -17,6 +17,10 @@ int uia_lora_rank_update(void* stream, int dtype, const uia_lora_rank_desc* d) {
     NEED(d, "uia_lora_rank_update");
     return uia_lora_rank_update_launch((hipStream_t)stream, dtype, *d);
 }
+int uia_ln_lora_down(void* stream, int dtype, const uia_ln_lora_desc* d) {
+    NEED(d, "uia_ln_lora_down");
+    return uia_ln_lora_down_launch((hipStream_t)stream, dtype, *d);
+}
 int uia_wgrad(void* stream, int dtype, int M, int I, int J, const void* A, int64_t lda, const void* B, int64_t ldb, float alpha, float* dW, float* dbias_A) {
     return uia_wgrad_launch((hipStream_t)stream, dtype, M, I, J, A, lda, B, ldb, alpha, dW, dbias_A);
 }

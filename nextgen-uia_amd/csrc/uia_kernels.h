@@ -21,6 +21,7 @@ int uia_layernorm_bwd3_launch(hipStream_t stream, int dtype, int M, int D, long 
                               long x_kb_rows, const float* gamma, float eps, const float* dres, const void* dres_hi, const int8_t* dres_lo, float* dx32,
                               void* dxT, int8_t* dx_lo);
 int uia_lora_rank_update_launch(hipStream_t stream, int dtype, const uia_lora_rank_desc& p);
+int uia_ln_lora_down_launch(hipStream_t stream, int dtype, const uia_ln_lora_desc& p);
 int uia_cast_launch(hipStream_t stream, int dtype, size_t n, const float* src, void* dst, float scale);
 int uia_transpose_cast_launch(hipStream_t stream, int dtype, int rows, int cols, const float* src, void* dst);
 int uia_pack_weights_launch(hipStream_t stream, int dtype, int n, const uia_pack_desc* descs_device, int max_elems);

@@ -65,6 +65,12 @@ class LoraRankDesc(C.Structure):
                 ("out", vp), ("ldo", i64), ("drop_p", f32), ("seed", C.c_uint64 * 3)]
 
 
+class LnLoraDesc(C.Structure):
+    """uia_ln_lora_desc (include/uia_hip.h): LayerNorm + up to three LoRA down-projections of its output in one launch."""
+    _fields_ = [("M", i32), ("D", i32), ("nsrc", i32), ("eps", f32), ("x", vp), ("ldx", i64), ("gamma", vp), ("beta", vp), ("h", vp), ("A", vp * 3), ("lda", i64),
+                ("T", vp), ("t_stride", i64), ("drop_p", f32), ("seed", C.c_uint64 * 3)]
+
+
 class MonaFusedDesc(C.Structure):
     """uia_mona_fused_desc (include/uia_hip.h): the whole adapter forward of one image in one workgroup."""
     _fields_ = [("sp", MonaSpatialDesc), ("D", i32), ("eps", f32), ("x", vp), ("norm_w", vp), ("norm_b", vp), ("gamma", vp), ("gammax", vp),
@@ -86,6 +92,7 @@ PROTOTYPES = {
     "uia_layernorm_fwd": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, i64, vp, vp, vp, f32, vp, vp]),
     "uia_layernorm_fwd_stats": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, i64, vp, vp, vp, f32, vp, vp, vp]),
     "uia_layernorm_bwd": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, i64, vp, vp, vp, f32, vp, vp, vp]),
+    "uia_ln_lora_down": (C.c_int, [vp, C.c_int, C.POINTER(LnLoraDesc)]),
     "uia_lora_rank_update": (C.c_int, [vp, C.c_int, C.POINTER(LoraRankDesc)]),
     "uia_layernorm_bwd3": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, i64, vp, vp, vp, vp, i64, vp, f32, vp, vp, vp, vp, vp, vp]),
     "uia_mona_pre_fwd": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, f32, vp]),

@@ -1234,12 +1234,19 @@ class LoraAttnHalfFn(torch.autograd.Function):
         r = aq.shape[0]
         rp = _rank_pad(r)
         h = _empty((M, D), dt, x2)
-        ops.layernorm_fwd(x2, ln_w, ln_b, eps, y_t=h)
         # K extension (bf16, rank padded to 64, ring kernels): the rank update s·t·Bᵀ rides in the frozen GEMM's K loop as 64 more columns of
         # [x | t]·[W | s·B]ᵀ — no read-modify-write pass over the result (lora.py:87; ops.LORA_KEXT)
         kext = ops.LORA_KEXT and dt == torch.bfloat16 and rp == 64 and x.is_cuda and ops.KBLOCK_W and D % 256 == 0 and M >= 256
         t_all = _empty((3, M, rp), dt, x2) if kext else None
-        downs = [_lora_down(h, A, p_drop, rp, out=None if t_all is None else t_all[i]) for i, A in enumerate((aq, ak, av))]
+        if (kext and x2.is_contiguous() and ops.ln_lora_down_ok(D, r, dt) and ak.shape[0] == r and av.shape[0] == r and (p_drop == 0 or ops.LORA_REGEN_DROP)):
+            # LayerNorm and the three down-projections in ONE launch: the h tile goes through LDS to the matrix cores, h is written once and never read back
+            seeds3 = [_next_seed() if p_drop > 0 else 0 for _ in range(3)]
+            a_rows = [WEIGHTS.get(A, dt, pad_rows_to=rp) for A in (aq, ak, av)]
+            ops.ln_lora_down(x2, ln_w, ln_b, eps, h, [a.row if isinstance(a, ops.PackedW) else a for a in a_rows], t_all, p_drop, seeds3)
+            downs = [(t_all[i], h, seeds3[i]) for i in range(3)]
+        else:
+            ops.layernorm_fwd(x2, ln_w, ln_b, eps, y_t=h)
+            downs = [_lora_down(h, A, p_drop, rp, out=None if t_all is None else t_all[i]) for i, A in enumerate((aq, ak, av))]
         qkv = _empty((M, 3 * D), dt, x2)
         bcat = torch.cat([b.detach() for b in (bq, bk, bv)]) if bq is not None else None
         if kext:

@@ -9,7 +9,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import AttnDesc, GemmDesc, LoraRankDesc, MonaFusedDesc, MonaSpatialDesc, PackDesc, UiaError, check, lib
+from ._lib import AttnDesc, GemmDesc, LnLoraDesc, LoraRankDesc, MonaFusedDesc, MonaSpatialDesc, PackDesc, UiaError, check, lib
 
 _ACT = {None: 0, "none": 0, "gelu": 1, "quick_gelu": 2, "relu": 3}
 
@@ -74,6 +74,7 @@ TAIL_SPLIT = True        # split off the M tail of a launch whose last round of 
 TAIL_SIDE_STREAM = True  # a SMALL M tail (at most a quarter of the CUs' worth of half-height tiles) runs on a side stream beside the main launch instead of behind it
 MONA_PRE_FWD_T = True    # Mona forward: project1 (768 -> 64) inside the pre-norm row kernel (uia_mona_pre_fwd_t) instead of the N = 64 stream launch reading u back
 MONA_PRE_BWD_DU = True   # Mona backward: project1's data gradient (K = 64) inside the pre-norm backward row kernel (uia_mona_pre_bwd_du) instead of a GEMM launch + a 77 MB round trip
+LN_LORA_DOWN = True      # LoRA block: LayerNorm and the q / k / v down-projections drop_i(h)·A_iᵀ in one launch (uia_ln_lora_down) instead of the LayerNorm kernel + three N = 64 launches reading h back
 LORA_REGEN_DROP = True   # LoRA input dropout: the forward does not write the dropped rows; the dA weight-gradient launch regenerates the mask while it stages x (uia_wgrad_drop)
 LORA_RANK3 = True        # q | k | v of a LoRA block: the three rank terms of the data gradient in one pass over it (uia_lora_rank_update) instead of three K = 64 launches
 QUAD = False             # 256x256 bf16 launches on the four-wave kernel (tile cfg 25, csrc/gemm_quad.hip: 128 x 128 per wave, one wave per SIMD) instead of cfg 8
@@ -1080,6 +1081,41 @@ def comm_destroy():
 def dropout(src, dst, p, seed, accumulate=False):
     assert src.dtype == dst.dtype and src.is_contiguous() and dst.is_contiguous() and src.numel() == dst.numel()
     check(lib().uia_dropout(_stream(), _code(src.dtype), src.numel(), _p(src), _p(dst), p, int(seed) & 0xFFFFFFFFFFFFFFFF, int(accumulate)), "uia_dropout")
+
+
+def ln_lora_down_ok(D, r, dt):
+    """Shapes uia_ln_lora_down takes: bf16, D = 768 or 1024, rank <= 16."""
+    return LN_LORA_DOWN and dt == torch.bfloat16 and D in (768, 1024) and 0 < r <= 16
+
+
+def ln_lora_down(x, gamma, beta, eps, h, a_rows, t_all, drop_p=0.0, seeds=()):
+    """h = LayerNorm(x) (T [M, D], written) and t_all[s] = dropout_s(h) @ a_rows[s][:16].T for up to three LoRA wrappers sharing the input, in one launch.
+    a_rows: T [>= 16, D] each (rank rows, zero-padded); t_all: T [n, M, 64] contiguous — columns 16..63 are written as zeros."""
+    n, M, w = t_all.shape
+    D = gamma.numel()
+    if not (t_all.is_contiguous() and w == 64 and len(a_rows) == n and tuple(h.shape) == (M, D) and h.is_contiguous() and x.dtype == torch.float32 and x.shape[-1] == D):
+        raise UiaError(f"ln_lora_down: x {tuple(x.shape)}, h {tuple(h.shape)}, t_all {tuple(t_all.shape)}")
+    if drop_p > 0 and len(seeds) != n:
+        raise UiaError("ln_lora_down: one dropout seed per source")
+    d = LnLoraDesc()
+    d.M, d.D, d.nsrc, d.eps = M, D, n, float(eps)
+    d.x, d.ldx = _p(x), _rowmajor(x, "x")
+    d.gamma, d.beta, d.h = _p(gamma), _p(beta), _p(h)
+    lda = None
+    for i, a in enumerate(a_rows):
+        if a.dtype != h.dtype or a.dim() != 2 or a.shape[0] < 16 or a.shape[1] != D:
+            raise UiaError(f"ln_lora_down: factor {i} is {tuple(a.shape)} {a.dtype}, expected [>= 16, {D}] {h.dtype}")
+        l = _rowmajor(a, "a")
+        if lda is not None and l != lda:
+            raise UiaError("ln_lora_down: the factors must share one leading dimension")
+        lda = l
+        d.A[i] = _p(a)
+    d.lda = lda
+    d.T, d.t_stride = _p(t_all), M * 64
+    d.drop_p = float(drop_p)
+    for i in range(n if drop_p > 0 else 0):
+        d.seed[i] = int(seeds[i]) & 0xFFFFFFFFFFFFFFFF
+    check(lib().uia_ln_lora_down(_stream(), _code(h.dtype), C.byref(d)), "uia_ln_lora_down")
 
 
 def lora_rank_update_ok(n_src, N, dt):

@@ -593,3 +593,40 @@ def test_mona_pre_fwd_with_project1_inside_equals_the_two_launches(M):
     else:
         assert rel(t1, t0) < 1e-2                                            # small M runs project1 on another tile config: equal up to the fp32 order
     assert rel(t1, u0.float() @ w1.float().T + b1) < 1e-2
+
+
+@pytest.mark.parametrize("M,D,n,p", [(32896, 1024, 3, 0.1), (1000, 768, 3, 0.25), (37, 1024, 1, 0.0), (530, 768, 2, 0.5)])
+def test_layernorm_with_the_lora_down_projections_inside_equals_the_separate_launches(M, D, n, p):
+    """uia_ln_lora_down: h = LayerNorm(x) and t_s = dropout_s(h)·A_sᵀ (reference lora.py:82-87 on q, k, v of a block) in one launch.  h must be bit-identical
+    to uia_layernorm_fwd; t_s equal to the N = 64 stream launch with the same seed up to the association of four K partials; columns 16..63 zero."""
+    from uia_hip import ops
+    g = torch.Generator(device="cpu").manual_seed(M + D + n)
+    dt = torch.bfloat16
+    x = torch.randn(M, D, generator=g).to(dev()) * 2 + 0.5
+    gw, gb = (1 + 0.1 * torch.randn(D, generator=g)).to(dev()), (0.1 * torch.randn(D, generator=g)).to(dev())
+    As = []
+    for _ in range(n):
+        a = torch.zeros(64, D)
+        a[:16] = torch.randn(16, D, generator=g) * 0.05
+        As.append(a.to(dev()).to(dt))
+    seeds = [1000003 + 17 * i for i in range(n)]
+    h0 = torch.empty(M, D, device=dev(), dtype=dt)
+    ops.layernorm_fwd(x, gw, gb, 1e-5, y_t=h0)
+    h1 = torch.full((M, D), float("nan"), device=dev(), dtype=dt)
+    t_all = torch.full((n, M, 64), float("nan"), device=dev(), dtype=dt)
+    ops.ln_lora_down(x, gw, gb, 1e-5, h1, As, t_all, p, seeds)
+    torch.cuda.synchronize()
+    assert torch.equal(h0, h1) and not torch.isnan(t_all.float()).any()
+    assert float(t_all[:, :, 16:].abs().max()) == 0.0
+    for i in range(n):
+        if p > 0:
+            hd = torch.empty_like(h0)
+            ops.dropout(h0, hd, p, seeds[i])
+        else:
+            hd = h0
+        want = hd.float() @ As[i][:16].float().T
+        assert rel(t_all[i, :, :16], want) < 6e-3, i
+        if M > 2048 and p > 0:                                              # the launch it replaces, same seed
+            t_ref = torch.empty(M, 64, device=dev(), dtype=dt)
+            ops.gemm(h0, As[i], out_t=t_ref, drop=("a", p, seeds[i], None))
+            assert rel(t_all[i], t_ref) < 6e-3
