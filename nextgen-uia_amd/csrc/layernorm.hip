@@ -95,7 +95,8 @@ __device__ __forceinline__ void three_byte_store4(bf16_t* hi, int8_t* lo, f32x4 
 // x: fp32 rows (x) or, x_lo != null, a three-byte tensor (x_hi row-major with D columns or K-blocked with x_kb_rows rows per 32-column block, x_lo
 // row-major [M, D]).  dres likewise (dres_hi row-major).  Output: dx32 and / or dxT (bf16 / fp32 T copy), or, dx_lo != null, dxT + dx_lo as a
 // three-byte tensor.
-template <typename T>
+// THREE: the three-byte forms are a compile-time variant — as run-time branches they cost the plain fp32 launch 17 % (98.7 -> 116-118 us per image-tower launch).
+template <typename T, bool THREE = false>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(int M, int D, long ldx, const T* __restrict__ dy, const float* __restrict__ x,
                                                       const float* __restrict__ gamma, float eps, const float* __restrict__ dres,
                                                       float* __restrict__ dx32, T* __restrict__ dxT,
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int M, int D, long ldx, con
         const int c = lane + 64 * k;
         v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (c < nv) {
-            if (x_lo) {
+            if (THREE && x_lo) {
                 const bf16_t* hp = x_kb_rows ? x_hi + ((size_t)((4 * c) >> 5) * (size_t)x_kb_rows + row) * 32 + ((4 * c) & 31) : x_hi + (size_t)row * D + 4 * c;
                 v[k] = three_byte_load4(hp, x_lo + (size_t)row * D + 4 * c);
             } else {
@@ -156,13 +157,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int M, int D, long ldx, con
         const int c = lane + 64 * k;
         if (c < nv) {
             f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (dres_lo) o = three_byte_load4(dres_hi + (size_t)row * D + 4 * c, dres_lo + (size_t)row * D + 4 * c);
+            if (THREE && dres_lo) o = three_byte_load4(dres_hi + (size_t)row * D + 4 * c, dres_lo + (size_t)row * D + 4 * c);
             else if (dres) o = load4(dres + (size_t)row * ldx + 4 * c);
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] += rstd * (g[k][e] - mg - v[k][e] * mgx);
             if (dx32) store4(dx32 + (size_t)row * ldx + 4 * c, o);
             if constexpr (sizeof(T) == 2) {
-                if (dx_lo) three_byte_store4((bf16_t*)dxT + (size_t)row * D + 4 * c, dx_lo + (size_t)row * D + 4 * c, o);
+                if (THREE && dx_lo) three_byte_store4((bf16_t*)dxT + (size_t)row * D + 4 * c, dx_lo + (size_t)row * D + 4 * c, o);
                 else if (dxT) store4(dxT + (size_t)row * ldx + 4 * c, o);
             } else {
                 if (dxT) store4(dxT + (size_t)row * ldx + 4 * c, o);
@@ -206,9 +207,11 @@ int uia_layernorm_bwd3_launch(hipStream_t stream, int dtype, int M, int D, long 
     UIA_CHECK_ARG(!dx_lo || (dxT && ((uintptr_t)dxT % 8) == 0 && ((uintptr_t)dx_lo % 4) == 0), "uia_layernorm_bwd: dx_lo needs dxT as the hi plane");
     UIA_CHECK_ARG(x_lo || x_kb_rows == 0, "uia_layernorm_bwd: x_kb_rows without a three-byte x");
     const dim3 grid((M + 3) / 4), block(256);
-    if (dtype == UIA_BF16) hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, grid, block, 0, stream, M, D, ldx, (const bf16_t*)dy, x, gamma, eps, dres, dx32, (bf16_t*)dxT,
-                                              (const bf16_t*)x_hi, x_lo, x_kb_rows, (const bf16_t*)dres_hi, dres_lo, dx_lo);
-    else if (dtype == UIA_F32) hipLaunchKernelGGL(ln_bwd_kernel<float>, grid, block, 0, stream, M, D, ldx, (const float*)dy, x, gamma, eps, dres, dx32, (float*)dxT,
+    if (dtype == UIA_BF16 && three) hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, true>), grid, block, 0, stream, M, D, ldx, (const bf16_t*)dy, x, gamma, eps, dres, dx32, (bf16_t*)dxT,
+                                                       (const bf16_t*)x_hi, x_lo, x_kb_rows, (const bf16_t*)dres_hi, dres_lo, dx_lo);
+    else if (dtype == UIA_BF16) hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, false>), grid, block, 0, stream, M, D, ldx, (const bf16_t*)dy, x, gamma, eps, dres, dx32, (bf16_t*)dxT,
+                                                   (const bf16_t*)nullptr, (const int8_t*)nullptr, 0L, (const bf16_t*)nullptr, (const int8_t*)nullptr, (int8_t*)nullptr);
+    else if (dtype == UIA_F32) hipLaunchKernelGGL((ln_bwd_kernel<float, false>), grid, block, 0, stream, M, D, ldx, (const float*)dy, x, gamma, eps, dres, dx32, (float*)dxT,
                                                   (const bf16_t*)nullptr, (const int8_t*)nullptr, 0L, (const bf16_t*)nullptr, (const int8_t*)nullptr, (int8_t*)nullptr);
     else { uia_set_error("uia_layernorm_bwd: bad dtype %d", dtype); return -1; }
     UIA_CHECK_LAUNCH();
