@@ -29,10 +29,12 @@ _SPECIALISED = {EPI_BIAS | EPI_RESID | EPI_OUT32, EPI_BIAS | EPI_RESIDT | EPI_OU
                 EPI_BIAS | EPI_OUTT | EPI_LNFOLD, EPI_BIAS | EPI_GELU | EPI_OUTT | EPI_LNFOLD, EPI_BIAS | EPI_GELU | EPI_AUX_OUT | EPI_OUTT | EPI_LNFOLD,
                 EPI_QUICK | EPI_BIAS | EPI_GELU | EPI_OUTT | EPI_LNFOLD, EPI_QUICK | EPI_BIAS | EPI_GELU | EPI_AUX_OUT | EPI_OUTT | EPI_LNFOLD,
                 EPI_BIAS | EPI_RESID_LO | EPI_RESID_LN | EPI_OUTT | EPI_OUT_LO | EPI_ROWSUM,
-                EPI_BIAS | EPI_RESID | EPI_OUTT | EPI_OUT_LO | EPI_ROWSUM, EPI_BIAS | EPI_RESID_LO | EPI_OUT32}
+                EPI_BIAS | EPI_RESID | EPI_OUTT | EPI_OUT_LO | EPI_ROWSUM, EPI_BIAS | EPI_RESID_LO | EPI_OUT32,
+                EPI_BIAS | EPI_RESID | EPI_RESID_LN | EPI_OUTT | EPI_OUT_LO | EPI_ROWSUM, EPI_BIAS | EPI_RESID_LO | EPI_RESID_LN | EPI_OUT32}
 
 # the masks csrc/gemm_quad.hip instantiates (tile cfg 25); the rest run its run-time epilogue
-_QUAD_SPECIALISED = _SPECIALISED - {EPI_BIAS | EPI_RESIDT | EPI_OUT32, EPI_BIAS | EPI_RESID | EPI_RESID_LN | EPI_OUT32, EPI_BIAS | EPI_RESID | EPI_RESID_LN | EPI_OUT32 | EPI_OUTT | EPI_ROWSUM}
+_QUAD_SPECIALISED = _SPECIALISED - {EPI_BIAS | EPI_RESIDT | EPI_OUT32, EPI_BIAS | EPI_RESID | EPI_RESID_LN | EPI_OUT32, EPI_BIAS | EPI_RESID | EPI_RESID_LN | EPI_OUT32 | EPI_OUTT | EPI_ROWSUM,
+                                    EPI_BIAS | EPI_RESID | EPI_RESID_LN | EPI_OUTT | EPI_OUT_LO | EPI_ROWSUM, EPI_BIAS | EPI_RESID_LO | EPI_RESID_LN | EPI_OUT32}
 
 
 def epi_mask_of(d):
@@ -84,6 +86,7 @@ TAIL_SPLIT_K = True      # ... and run that tail split over K when it is a few t
                          # Its slices meet through hardware float atomics: the rows of such a tail (<= 1/4 of the CUs busy: the ViT-L/14 + LoRA step, not the
                          # headline) vary in the last bit from run to run; set_deterministic(True) in functional turns it off.
 _SPLITK_WS = {}
+_TRACE_GENERIC = {} if __import__("os").environ.get("UIA_TRACE_GENERIC") else None
 _TAIL_SIDE = {}
 _NCU = {}
 
@@ -677,6 +680,10 @@ def _gemm_one(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None
             base_cfg = auto_tile_cfg(d.M, d.N, d.K, esz, mask)
         GEMM_PROFILE.append((e0, e1, d.M, d.N, d.K, a.dtype, base_cfg, nbytes, mask))
         return
+    if _TRACE_GENERIC is not None:             # UIA_TRACE_GENERIC=1: which large launches land on the run-time epilogue (a mask worth a compile-time instantiation?)
+        mask = epi_mask_of(d)
+        if mask not in _SPECIALISED and d.M > 2048:
+            _TRACE_GENERIC[(mask, d.M, d.N, d.K, base_cfg)] = _TRACE_GENERIC.get((mask, d.M, d.N, d.K, base_cfg), 0) + 1
     check(lib().uia_gemm(_stream(), _code(a.dtype), C.byref(d), tile_cfg), "uia_gemm")
 
 

@@ -630,3 +630,37 @@ def test_layernorm_with_the_lora_down_projections_inside_equals_the_separate_lau
             t_ref = torch.empty(M, 64, device=dev(), dtype=dt)
             ops.gemm(h0, As[i], out_t=t_ref, drop=("a", p, seeds[i], None))
             assert rel(t_all[i], t_ref) < 6e-3
+
+
+def test_text_tower_boundary_masks_equal_the_run_time_epilogue_bit_for_bit():
+    """The first and the last layer of the three-byte text tower use two more compile-time epilogue masks (fp32 LayerNorm rows in / three-byte sum + row sums
+    out; three-byte sum in / fp32 rows out).  Same arithmetic as the run-time epilogue (tile cfg 10) on a ragged shape: every output bit-identical."""
+    from uia_hip import ops
+    g = torch.Generator(device="cpu").manual_seed(77)
+    M, N, K, dt = 4353, 768, 128, torch.bfloat16
+    a = torch.randn(M, K, generator=g).to(dev()).to(dt)
+    w = ops.PackedW((torch.randn(N, K, generator=g) * K ** -0.5).to(dev()).to(dt))
+    bias = torch.randn(N, generator=g).to(dev())
+    prev = torch.randn(M, N, generator=g).to(dev()) * 2 + 0.3
+    stats = torch.stack([prev.mean(1), (prev.var(1, unbiased=False) + 1e-12).rsqrt()], 1).contiguous()
+    lw, lb = torch.randn(N, generator=g).to(dev()), torch.randn(N, generator=g).to(dev())
+    hi, lo = ops.float_to_three_byte(prev)
+
+    def first(cfg):                                                          # BIAS | RESID | RESID_LN | OUTT | OUT_LO | ROWSUM
+        ot, ol = torch.empty(M, N, device=dev(), dtype=dt), torch.full((M, N), 99, device=dev(), dtype=torch.int8)
+        rs = torch.zeros(M, 2, device=dev(), dtype=torch.int64)
+        ops.gemm(a, w, bias=bias, resid=prev, resid_ln=(stats, lw, lb), out_t=ot, out_lo=ol, rowsum=rs, tile_cfg=cfg)
+        return ot, ol, rs
+
+    def last(cfg):                                                           # BIAS | RESID_LO | RESID_LN | OUT32
+        o32 = torch.full((M, N), float("nan"), device=dev())
+        ops.gemm(a, w, bias=bias, resid3=(hi, lo), resid_ln=(stats, lw, lb), out32=o32, tile_cfg=cfg)
+        return (o32,)
+
+    for fn in (first, last):
+        ref, got = fn(10), fn(8)
+        torch.cuda.synchronize()
+        for x, y in zip(ref, got):
+            assert torch.equal(x, y), fn.__name__
+    want = a.float() @ w.row.float().T + bias + ((prev - stats[:, :1]) * stats[:, 1:]) * lw + lb
+    assert rel(ops.three_byte_to_float(*first(8)[:2]), want) < 3e-5
