@@ -146,8 +146,11 @@ int launch_rank(hipStream_t stream, const uia_lora_rank_desc& p) {
 // of the tile with the three wrappers' rank rows — their fragments stay in registers for the whole launch — applying wrapper s's dropout mask to the
 // tile fragment on the way (a 16-byte fragment is exactly one draw of dropout_keep8); the four K-partials meet in LDS.  Rank <= 16 (one MFMA row tile);
 // columns 16..63 of t are written as zeros (the K-extension operand of the frozen GEMM is 64 wide).
+#ifndef LNLD_MIN_WAVES
+#define LNLD_MIN_WAVES 1
+#endif
 template <int NVF, int NSRC>                                   // D = 256·NVF
-__global__ __launch_bounds__(256) void ln_lora_down_kernel(const uia_ln_lora_desc p) {
+__global__ __launch_bounds__(256, LNLD_MIN_WAVES) void ln_lora_down_kernel(const uia_ln_lora_desc p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int D = 256 * NVF, ROWB = 2 * D + 16, KSW = D / 128;                     // k steps (32 columns) per wave
     f32x4* red = (f32x4*)(smem + 16 * ROWB);                                           // [4 waves][NSRC][64 lanes]

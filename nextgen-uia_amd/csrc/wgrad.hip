@@ -39,8 +39,11 @@ constexpr int CHUNK_SLABS = WG_CHUNK_SLABS;       // slabs per workgroup → 512
 // DROPB (LoRA's dA = s·qᵀ·drop(x), lora.py:82-87): B holds the UN-dropped rows; the mask uia_dropout / uia_gemm's drop_where = 1 draw for the [M, drop_ld]
 // tensor B is a column window of is regenerated from (seed, element index / 8) while the slab is staged — a lane's 16-byte piece is exactly one draw —
 // so the forward does not have to write the dropped rows out for this launch (67 MB per LinearLoRA at ViT-L/14, 128 pairs).
+#ifndef WG_MIN_WAVES
+#define WG_MIN_WAVES 1
+#endif
 template <bool DROPB>
-__global__ __launch_bounds__(256) void wgrad_bf16_kernel(int M, int I, int J, const bf16_t* __restrict__ A, long lda,
+__global__ __launch_bounds__(256, DROPB ? 3 : WG_MIN_WAVES) void wgrad_bf16_kernel(int M, int I, int J, const bf16_t* __restrict__ A, long lda,
                                                           const bf16_t* __restrict__ B, long ldb, float alpha,
                                                           float* __restrict__ dW, float* __restrict__ dbias, long ldw, int i_valid, int j_valid,
                                                           float drop_p, unsigned long long drop_seed, long drop_ld, int drop_col0) {

@@ -4,7 +4,8 @@
 # Run on the GPU box: bash tools/mff_variants.sh
 cd $GRAFT_REPO_ROOT/nextgen-uia_amd/csrc
 mkdir -p /tmp/mff
-OBJS="attention_bwd.o attention_fwd.o decoder.o elementwise.o gemm.o gemm_quad.o lora_rank.o heads.o infonce.o layernorm.o mona.o optim.o wgrad.o error.o capi.o comm.o"
+OBJS=$(ls *.o | grep -v "^mona_fused.o$" | tr "
+" " ")     # every object of the library but the one rebuilt here
 for v in ${MFF_VARIANTS:-0 1 2 3 99}; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DMF_STOP=$v -c mona_fused.hip -o /tmp/mff/mf_$v.o 2>/dev/null
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/mff/lib_$v.so /tmp/mff/mf_$v.o $OBJS -L/opt/rocm/lib -lrccl

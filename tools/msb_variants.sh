@@ -3,7 +3,8 @@
 # return after phase k (results are WRONG in them) and times the kernel at the ViT-B/16 shape.  Run on the GPU box: bash tools/msb_variants.sh
 cd $GRAFT_REPO_ROOT/nextgen-uia_amd/csrc
 mkdir -p /tmp/msb
-OBJS="attention_bwd.o attention_fwd.o decoder.o elementwise.o gemm.o gemm_quad.o lora_rank.o heads.o infonce.o layernorm.o optim.o wgrad.o error.o capi.o comm.o"
+OBJS=$(ls *.o | grep -v "^mona.o$" | tr "
+" " ")     # every object of the library but the one rebuilt here
 for v in ${MSB_VARIANTS:-0 1 2 3 4 5 6 7 8 9 99}; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DMSB_STOP=$v -c mona.hip -o /tmp/msb/mona_$v.o 2>/dev/null
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/msb/lib_$v.so /tmp/msb/mona_$v.o $OBJS -L/opt/rocm/lib -lrccl

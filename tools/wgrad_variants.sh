@@ -2,7 +2,8 @@
 # Diagnostic builds of the skinny weight-gradient kernel (results WRONG in some) timed at the two Mona shapes.  GPU box: bash tools/wgrad_variants.sh
 cd $GRAFT_REPO_ROOT/nextgen-uia_amd/csrc
 mkdir -p /tmp/wgv
-OBJS="attention_bwd.o attention_fwd.o decoder.o elementwise.o gemm.o gemm_quad.o lora_rank.o heads.o infonce.o layernorm.o optim.o mona.o error.o capi.o comm.o"
+OBJS=$(ls *.o | grep -v "^wgrad.o$" | tr "
+" " ")     # every object of the library but the one rebuilt here
 for v in ${WG_VARIANTS:-BASE WG_NO_ATOMIC WG_NO_BIAS WG_CHUNK_SLABS=8 WG_CHUNK_SLABS=16 WG_CHUNK_SLABS=2}; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -D$v -c wgrad.hip -o /tmp/wgv/wgrad.o 2>/dev/null
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/wgv/lib.so /tmp/wgv/wgrad.o $OBJS -L/opt/rocm/lib -lrccl
