@@ -432,7 +432,7 @@ def test_lora_rank_update_equals_the_sum_of_masked_rank_terms(M, N, n, p):
 
 
 # ------------------------------------------------------------------------------------------------ head dim 16 on the matrix cores (csrc/attention_dh16.hip)
-@pytest.mark.parametrize("B,H,L", [(2, 4, 485), (3, 2, 16), (1, 4, 100), (2, 1, 512), (5, 4, 33)])
+@pytest.mark.parametrize("B,H,L", [(2, 4, 485), (3, 2, 16), (1, 4, 100), (2, 1, 512), (5, 4, 33), (2, 4, 1), (1, 1, 17)])
 def test_head_dim_16_attention_on_mfma_vs_torch(B, H, L):
     """CLIPSeg decoder attention (four heads of 16, 485 tokens; clipseg_adapter.py:73-98): the bf16 forward and backward run on v_mfma_f32_16x16x16_bf16
     (csrc/attention_dh16.hip) instead of the scalar kernels.  Output, log-sum-exp and the three gradients against fp32 torch on the same bf16 inputs —
