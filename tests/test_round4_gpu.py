@@ -664,3 +664,36 @@ def test_text_tower_boundary_masks_equal_the_run_time_epilogue_bit_for_bit():
             assert torch.equal(x, y), fn.__name__
     want = a.float() @ w.row.float().T + bias + ((prev - stats[:, :1]) * stats[:, 1:]) * lw + lb
     assert rel(ops.three_byte_to_float(*first(8)[:2]), want) < 3e-5
+
+
+# ------------------------------------------------------------------------------------------------ weight caches across streams
+def test_cold_weight_cache_filled_on_one_stream_is_safe_to_read_from_another():
+    """the operand forms of a weight (cast, transpose, K-blocked twin) are written by kernels enqueued on whichever stream misses first; a
+    second stream that hits the Python cache must not read them before they exist.  Real-size layer, COLD cache, and the filling stream kept busy so that
+    the fill is still queued when the other stream launches its GEMM: with the event of uia_hip.ops.Ready the result is right; without it the GEMM would
+    read an unwritten buffer."""
+    from uia_hip import functional as UF
+    from uia_hip import ops
+    dt = torch.bfloat16
+    g = torch.Generator(device="cpu").manual_seed(3)
+    w = torch.nn.Parameter((torch.randn(3072, 768, generator=g) * 768 ** -0.5).to(dev()), requires_grad=False)
+    a = torch.randn(4352, 768, generator=g).to(dev()).to(dt)
+    want = (a.float() @ w.detach().to(dt).float().T)
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    busy = torch.randn(8192, 8192, device=dev(), dtype=dt)
+    torch.cuda.synchronize()
+    for transpose in (False, True):
+        a_t = a if not transpose else torch.randn(4352, 3072, generator=g).to(dev()).to(dt)
+        ref = want if not transpose else a_t.float() @ w.detach().to(dt).float()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(sa):
+            for _ in range(6):
+                busy = (busy @ busy).clamp_(-1, 1)                       # ~10 ms of work in front of the fill
+            op = UF.WEIGHTS.get(w, dt, transpose=transpose)               # cold: cast / transpose / pack kernels queued on sa behind it
+        out = torch.full((a_t.shape[0], ref.shape[1]), float("nan"), device=dev(), dtype=dt)
+        with torch.cuda.stream(sb):
+            hit = UF.WEIGHTS.get(w, dt, transpose=transpose)              # Python-side cache hit from another stream
+            assert hit is op
+            ops.gemm(a_t, hit, out_t=out)
+        torch.cuda.synchronize()
+        assert not torch.isnan(out.float()).any() and rel(out, ref) < 1e-2
