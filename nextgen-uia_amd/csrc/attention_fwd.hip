@@ -20,6 +20,8 @@
 //   transposed in memory.
 // fp32 path (parity mode): plain VALU two-pass softmax, one query per thread.
 #include <type_traits>
+#include <stdio.h>
+#include <stdlib.h>
 #include "uia_common.h"
 #include "uia_kernels.h"
 
@@ -329,6 +331,11 @@ int launch_bf16(hipStream_t stream, const UiaAttnParams& p) {
     auto kern = attn_fwd_bf16_kernel<LT_MAX, NW>;
     static UiaDevOnce attr_once;
     UIA_ENSURE_LDS_ATTR(attr_once, kern, 2 * ((LT_MAX + 1) / 2) * 32 * 128);
+    if (getenv("UIA_ATTN_FWD_OCC")) {           // diagnostic: workgroups of this launch a CU can hold at once
+        int per_cu = -1;
+        const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64 * NW, lds);
+        fprintf(stderr, "attn_fwd<%d,%d>: %d threads, %d B of LDS -> %d workgroup(s) per CU (%s)\n", LT_MAX, NW, 64 * NW, lds, per_cu, hipGetErrorString(e));
+    }
     hipLaunchKernelGGL(kern, dim3(p.B * p.H), dim3(64 * NW), lds, stream, p);
     UIA_CHECK_LAUNCH();
     return 0;

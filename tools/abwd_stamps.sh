@@ -4,7 +4,7 @@
 cd $GRAFT_REPO_ROOT/nextgen-uia_amd/csrc
 mkdir -p /tmp/abwd
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-slp-vectorize -DABWD_STAMPS $ABWD_EXTRA -c attention_bwd.hip -o /tmp/abwd/attention_bwd_stamps.o || exit 1
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/abwd/lib_stamps.so /tmp/abwd/attention_bwd_stamps.o attention_fwd.o decoder.o elementwise.o gemm.o gemm_quad.o lora_rank.o attention_dh16.o heads.o infonce.o layernorm.o mona.o mona_fused.o optim.o wgrad.o error.o capi.o comm.o -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib || exit 1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/abwd/lib_stamps.so /tmp/abwd/attention_bwd_stamps.o $(ls *.o | grep -v '^attention_bwd.o$' | tr '\n' ' ') -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib || exit 1
 UIA_HIP_LIB=/tmp/abwd/lib_stamps.so python3 - <<PY
 import os, sys, ctypes, torch
 sys.path[:0] = ["$GRAFT_REPO_ROOT/nextgen-uia_amd"]

@@ -5,7 +5,7 @@ cd $GRAFT_REPO_ROOT/nextgen-uia_amd/csrc
 mkdir -p /tmp/abwd
 for v in BASE ABWD_NO_DQ ABWD_NO_VALU ABWD_NO_DVDK ABWD_NO_DELTA ABWD_PROLOGUE_ONLY; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -D$v -c attention_bwd.hip -o /tmp/abwd/attention_bwd_$v.o 2>/dev/null
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/abwd/lib_$v.so /tmp/abwd/attention_bwd_$v.o attention_fwd.o decoder.o elementwise.o gemm.o gemm_quad.o lora_rank.o attention_dh16.o heads.o infonce.o layernorm.o mona.o optim.o wgrad.o error.o capi.o comm.o -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/abwd/lib_$v.so /tmp/abwd/attention_bwd_$v.o $(ls *.o | grep -v '^attention_bwd.o$' | tr '\n' ' ') -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
   UIA_HIP_LIB=/tmp/abwd/lib_$v.so python3 - <<PY
 import sys, torch
 sys.path[:0] = ["$GRAFT_REPO_ROOT/nextgen-uia_amd"]

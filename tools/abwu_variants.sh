@@ -8,7 +8,7 @@ mkdir -p /tmp/abwu
 for v in BASE ABWU_NO_TR ABWU_NO_ROWS ABWU_NO_EXP ABWU_NO_DVDK ABWU_NO_SDP "ABWU_NO_TR -DABWU_NO_ROWS" "ABWU_NO_DVDK -DABWU_NO_SDP" "ABWU_NO_TR -DABWU_NO_ROWS -DABWU_NO_DVDK -DABWU_NO_SDP -DABWU_NO_EXP"; do
   tag=$(echo $v | tr -d ' ' | tr -d '-')
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-slp-vectorize -D$v -c attention_bwd.hip -o /tmp/abwu/a_$tag.o 2>/dev/null || { echo "build failed: $v"; continue; }
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/abwu/lib_$tag.so /tmp/abwu/a_$tag.o attention_fwd.o decoder.o elementwise.o gemm.o gemm_quad.o lora_rank.o attention_dh16.o heads.o infonce.o layernorm.o mona.o mona_fused.o optim.o wgrad.o error.o capi.o comm.o -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/abwu/lib_$tag.so /tmp/abwu/a_$tag.o $(ls *.o | grep -v '^attention_bwd.o$' | tr '\n' ' ') -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
   UIA_HIP_LIB=/tmp/abwu/lib_$tag.so python3 - <<PY
 import sys, torch
 sys.path[:0] = ["$GRAFT_REPO_ROOT/nextgen-uia_amd"]

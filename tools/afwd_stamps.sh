@@ -3,7 +3,7 @@
 cd $GRAFT_REPO_ROOT/nextgen-uia_amd/csrc
 mkdir -p /tmp/afwd
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DAFWD_STAMPS -c attention_fwd.hip -o /tmp/afwd/attention_fwd_stamps.o || exit 1
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/afwd/lib_stamps.so /tmp/afwd/attention_fwd_stamps.o attention_bwd.o decoder.o elementwise.o gemm.o gemm_quad.o lora_rank.o attention_dh16.o heads.o infonce.o layernorm.o mona.o optim.o wgrad.o error.o capi.o comm.o -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib || exit 1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/afwd/lib_stamps.so /tmp/afwd/attention_fwd_stamps.o $(ls *.o | grep -v '^attention_fwd.o$' | tr '\n' ' ') -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib || exit 1
 UIA_HIP_LIB=/tmp/afwd/lib_stamps.so python3 - <<PY
 import sys, ctypes, torch
 sys.path[:0] = ["$GRAFT_REPO_ROOT/nextgen-uia_amd"]
