@@ -28,9 +28,6 @@ __device__ __forceinline__ s16x4 pack4(float a, float b, float c, float d) {
     return __builtin_bit_cast(s16x4, v);
 }
 __device__ __forceinline__ s16x4 lds8(const char* p) { return *(const s16x4*)p; }
-// exchange across the four lanes that share li (lanes li, li + 16, li + 32, li + 48)
-__device__ __forceinline__ float xor16(float v) { return __shfl_xor(v, 16, 64); }
-__device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); }
 
 // row-major image [LP][16] bf16 (32-byte rows) of columns h·16 .. of `src`; rows >= L are zero
 __device__ __forceinline__ void stage_rows(char* dst, const bf16_t* src, long ld, int L, int LP, int tid, int nthr) {
@@ -88,8 +85,7 @@ __global__ __launch_bounds__(256) void attn_dh16_fwd_kernel(const UiaAttnParams 
                 }
             }
         }
-        m = fmaxf(m, xor16(m));
-        m = fmaxf(m, xor32(m));
+        m = rows_max(m);
         float sum = 0.f;
 #pragma unroll
         for (int t = 0; t < LT_MAX; ++t) {
@@ -98,8 +94,7 @@ __global__ __launch_bounds__(256) void attn_dh16_fwd_kernel(const UiaAttnParams 
                 for (int r = 0; r < 4; ++r) { s[t][r] = exp2f(s[t][r] - m); sum += s[t][r]; }
             }
         }
-        sum += xor16(sum);
-        sum += xor32(sum);
+        sum = rows_sum(sum);
         const float inv = 1.0f / sum;
         f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll

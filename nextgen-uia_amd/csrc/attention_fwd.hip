@@ -180,8 +180,7 @@ __global__ __launch_bounds__(64 * NW, NW >= 7 ? 4 : 1) void attn_fwd_bf16_kernel
                 for (int t = 4 * c; t < 4 * c + 4; ++t) s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
-        m = fmaxf(m, __shfl_xor(m, 16, 64));
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        m = rows_max(m);                                         // the four lanes that share this query (permlane swaps: no LDS trip)
 #ifdef AFWD_STAMPS
         asm volatile("" :: "v"(m));
         const unsigned long long st1 = __builtin_amdgcn_s_memtime();
@@ -201,8 +200,7 @@ __global__ __launch_bounds__(64 * NW, NW >= 7 ? 4 : 1) void attn_fwd_bf16_kernel
                     }
             }
         }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
+        sum = rows_sum(sum);
         const float inv = 1.0f / sum;
 #ifdef AFWD_STAMPS
         asm volatile("" :: "v"(inv));

@@ -105,8 +105,8 @@ __global__ __launch_bounds__(512) void mona_fused_fwd_kernel(const uia_mona_fuse
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { const float dlt = v[i][e] - x0; s1 += dlt; s2 = fmaf(dlt, dlt, s2); }
             }
-            s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
-            s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+            s1 = rows_sum(s1);
+            s2 = rows_sum(s2);
             const float m1 = s1 / D;
             const float mean = x0 + m1;
             const float rstd = rsqrtf(fmaxf(fmaf(-m1, m1, s2 / D), 0.f) + q.eps);
@@ -342,8 +342,8 @@ __global__ __launch_bounds__(512) void mona_fused_fwd_kernel(const uia_mona_fuse
                 }
             }
             if (q.rowsum_out) {
-                s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
-                s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+                s1 = rows_sum(s1);
+                s2 = rows_sum(s2);
                 if (g == 0 && ok) {
                     if (!(fabsf(s1) < ROWSUM_PART_MAX_F) || !(s2 < ROWSUM_PART_MAX_F)) {      // as uia_gemm's rowsum_out: clamp and flag, never wrap
                         if (q.ln_flag) atomicOr(q.ln_flag, 2);

@@ -185,15 +185,61 @@ __device__ __forceinline__ f32x2 dgelu_poly2(f32x2 x) {
 }
 
 // ---------------------------------------------------------------- wave reductions
+// On the VALU (round 4): __shfl_xor compiles to ds_bpermute_b32 — a trip through the LDS crossbar per step, six dependent trips per reduction, four
+// reductions per row of the LayerNorm backward.  gfx950 can do the whole butterfly without LDS: quad_perm / row mirrors (DPP) inside a row of 16 lanes,
+// v_permlane16_swap / v_permlane32_swap across rows.  Order: partners at distance 1, 2, then the other quad, the other half-row, the other row, the other
+// half-wave — every lane ends with the same sum (the values inside a group are identical before the group meets its mirror image).
+__device__ __forceinline__ float uia_dpp_quad_xor1(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)); }   // quad_perm [1,0,3,2]
+__device__ __forceinline__ float uia_dpp_quad_xor2(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)); }   // quad_perm [2,3,0,1]
+__device__ __forceinline__ float uia_dpp_half_mirror(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true)); }  // row_half_mirror
+__device__ __forceinline__ float uia_dpp_row_mirror(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true)); }   // row_mirror
+// rows_*: all-reduce over the four rows of 16 lanes (lanes li, li + 16, li + 32, li + 48): the other row of the pair, then the other pair.
+// v_permlane16_swap a, b: rows 1 and 3 of a change places with rows 0 and 2 of b; v_permlane32_swap: the upper half of a with the lower half of b — with
+// a = b = v the two registers then hold the two partners of every lane.  Inline asm: the builtin of this hipcc (7.2) returns the first register for BOTH
+// results (tools/scratch/dpp_test.hip shows it); the s_nop pairs are the wait states the hazard pass would have placed around a VALU lane permute.
+__device__ __forceinline__ void uia_swap16(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void uia_swap32(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ float rows_sum(float v) {
+    float a = v, b = v;
+    uia_swap16(a, b);
+    a += b;
+    b = a;
+    uia_swap32(a, b);
+    return a + b;
+}
+__device__ __forceinline__ float rows_max(float v) {
+    float a = v, b = v;
+    uia_swap16(a, b);
+    a = fmaxf(a, b);
+    b = a;
+    uia_swap32(a, b);
+    return fmaxf(a, b);
+}
 __device__ __forceinline__ float wave_sum(float v) {
+#ifdef UIA_WAVE_REDUCE_LDS
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
+#else
+    v += uia_dpp_quad_xor1(v);
+    v += uia_dpp_quad_xor2(v);
+    v += uia_dpp_half_mirror(v);
+    v += uia_dpp_row_mirror(v);
+    return rows_sum(v);
+#endif
 }
 __device__ __forceinline__ float wave_max(float v) {
+#ifdef UIA_WAVE_REDUCE_LDS
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
+#else
+    v = fmaxf(v, uia_dpp_quad_xor1(v));
+    v = fmaxf(v, uia_dpp_quad_xor2(v));
+    v = fmaxf(v, uia_dpp_half_mirror(v));
+    v = fmaxf(v, uia_dpp_row_mirror(v));
+    return rows_max(v);
+#endif
 }
 
 // ---------------------------------------------------------------- counter-based dropout RNG
