@@ -368,5 +368,6 @@ int uia_attn_fwd_launch(hipStream_t stream, int dtype, const UiaAttnParams& p) {
     const int LT = (p.L + 15) / 16;
     if (LT <= 5) return launch_bf16<5, 4>(stream, p);
     if (LT <= 13) return launch_bf16<13, 7>(stream, p);
+    if (LT <= 16) return launch_bf16<16, 8>(stream, p);      // BERT's 256 tokens: four chunks of four key tiles, no fifth (the 17-tile instantiation spills ten registers at 128)
     return launch_bf16<17, 8>(stream, p);
 }
