@@ -45,6 +45,9 @@ __device__ __forceinline__ void glds16(const char* gsrc, char* lds_wave_base) {
 __device__ __forceinline__ s16x4 lds_tr16(const char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
 }
+// the same through an LDS-space pointer: the fragment address is then the lane's base register + an immediate offset, not a generic pointer rebuilt per read
+typedef __attribute__((address_space(3))) char lds_char;
+__device__ __forceinline__ s16x4 lds_tr16(const lds_char* p) { return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p); }
 
 // ------------------------------------------------------------------------------------------
 // LT_MAX = max number of 16-key tiles (L ≤ 16·LT_MAX).  NP = 32-key blocks.
@@ -62,9 +65,9 @@ __global__ __launch_bounds__(64 * NW, NW >= 7 ? 4 : 1) void attn_fwd_bf16_kernel
     const int L = p.cu_seqlens ? p.cu_seqlens[bb + 1] - p.cu_seqlens[bb] : p.L;
     const int LT = (L + 15) >> 4;           // key / query tiles in use
     const int NP = (LT + 1) >> 1;
-    const int LPK = NP * 32;                // rows staged (multiple of 32)
-    char* Ks = smem;                        // [LPK][128 B], 16-B chunk swizzle (row>>1)&7
-    char* Vs = smem + LPK * 128;            // [LPK][128 B], 16-B chunk swizzle ((row>>1)&3)<<1
+    char* Ks = smem;                        // [16·4·ceil(LT/4)][128 B], 16-B chunk swizzle (row>>1)&7: whole chunks of four key tiles, so that a chunk that runs past
+                                            // the last tile still reads inside the allocation and every fragment address is the lane's base + a compile-time offset
+    char* Vs = smem + ((LT + 3) >> 2) * 4 * 2048;   // [32·NP][128 B], 16-B chunk swizzle ((row>>1)&3)<<1
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -128,6 +131,9 @@ __global__ __launch_bounds__(64 * NW, NW >= 7 ? 4 : 1) void attn_fwd_bf16_kernel
     const int qq = li >> 2, pp = li & 3;
     const int vrow0 = 4 * g + qq;                       // + 32u + 16hh  (multiples of 16 keep (row>>1)&3)
     const int vsw = (vrow0 >> 1) & 3;
+    const lds_char* vfrag[4];                          // column group dt of row vrow0: + 32·128·u (+ 16·128) per fragment, compile-time
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) vfrag[dt] = (const lds_char*)Vs + vrow0 * 128 + ((dt ^ vsw) << 5) + 8 * pp;
 
 #pragma unroll
     for (int qi = 0; qi < NQT; ++qi) {
@@ -151,9 +157,8 @@ __global__ __launch_bounds__(64 * NW, NW >= 7 ? 4 : 1) void attn_fwd_bf16_kernel
         // one key tile: scores of 16 keys for this lane's query.  TEST = false for chunks that lie entirely inside the valid keys of a
         // non-causal head: no per-element compare / select (the 197-token image heads spend 12 of their 13 tiles there).
         auto tile = [&](int t, auto test) {
-            const int tl = t < 2 * NP ? t : 2 * NP - 1;              // stay inside the LDS allocation
-            const uint4 k0 = *(const uint4*)(Ks + tl * 2048 + offK0);
-            const uint4 k1 = *(const uint4*)(Ks + tl * 2048 + (offK0 ^ 64));
+            const uint4 k0 = *(const uint4*)(Ks + t * 2048 + offK0);          // tiles past the staged ones hold garbage: their scores are discarded by the select
+            const uint4 k1 = *(const uint4*)(Ks + t * 2048 + (offK0 ^ 64));
             f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, k0), __builtin_bit_cast(bf16x8, q0), acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, k1), __builtin_bit_cast(bf16x8, q1), acc, 0, 0, 0);
@@ -222,7 +227,7 @@ __global__ __launch_bounds__(64 * NW, NW >= 7 ? 4 : 1) void attn_fwd_bf16_kernel
                 }
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
-                    const char* base = Vs + (32 * u + vrow0) * 128 + ((dt ^ vsw) << 5) + 8 * pp;
+                    const lds_char* base = vfrag[dt] + 32 * 128 * u;
                     const s16x4 lo = lds_tr16(base);
                     const s16x4 hi = lds_tr16(base + 16 * 128);
                     typedef __attribute__((ext_vector_type(8))) short s16x8;
@@ -325,10 +330,10 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const UiaAttnParams p
 template <int LT_MAX, int NW>
 int launch_bf16(hipStream_t stream, const UiaAttnParams& p) {
     const int LT = (p.L + 15) / 16, NP = (LT + 1) / 2;
-    const int lds = 2 * NP * 32 * 128;
+    const int lds = ((LT + 3) / 4) * 4 * 2048 + NP * 32 * 128;          // K in whole chunks of four tiles, V in pairs
     auto kern = attn_fwd_bf16_kernel<LT_MAX, NW>;
     static UiaDevOnce attr_once;
-    UIA_ENSURE_LDS_ATTR(attr_once, kern, 2 * ((LT_MAX + 1) / 2) * 32 * 128);
+    UIA_ENSURE_LDS_ATTR(attr_once, kern, ((LT_MAX + 3) / 4) * 4 * 2048 + ((LT_MAX + 1) / 2) * 32 * 128);
     if (getenv("UIA_ATTN_FWD_OCC")) {           // diagnostic: workgroups of this launch a CU can hold at once
         int per_cu = -1;
         const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64 * NW, lds);
