@@ -64,10 +64,9 @@ __global__ __launch_bounds__(64 * NW, NW >= 7 ? 4 : 1) void attn_fwd_bf16_kernel
     // packed (un-padded) sequences: this head's rows start at cu_seqlens[b] and there are cu[b+1]-cu[b] of them, all valid
     const int L = p.cu_seqlens ? p.cu_seqlens[bb + 1] - p.cu_seqlens[bb] : p.L;
     const int LT = (L + 15) >> 4;           // key / query tiles in use
-    const int NP = (LT + 1) >> 1;
     char* Ks = smem;                        // [16·4·ceil(LT/4)][128 B], 16-B chunk swizzle (row>>1)&7: whole chunks of four key tiles, so that a chunk that runs past
                                             // the last tile still reads inside the allocation and every fragment address is the lane's base + a compile-time offset
-    char* Vs = smem + ((LT + 3) >> 2) * 4 * 2048;   // [32·NP][128 B], 16-B chunk swizzle ((row>>1)&3)<<1
+    char* Vs = smem + ((LT + 3) >> 2) * 4 * 2048;   // [32·ceil(LT/2)][128 B], 16-B chunk swizzle ((row>>1)&3)<<1
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
