@@ -79,6 +79,8 @@ def parse():
     ap.add_argument("--no-mona-pre-bwd-du", action="store_true", help="A/B: project1's data gradient as a K = 64 GEMM launch in front of the Mona pre-norm backward instead of inside it")
     ap.add_argument("--no-mona-pre-fwd-t", action="store_true", help="A/B: project1 as the N = 64 stream launch behind the Mona pre-norm kernel instead of inside it")
     ap.add_argument("--no-ln-lora-down", action="store_true", help="A/B: the LoRA block's LayerNorm and its three down-projections as four launches instead of one (uia_ln_lora_down)")
+    ap.add_argument("--short-k-half-n", type=int, default=-1, help="experiment knob: short-K bf16 launches with N at or above this value run on half-height tiles (tile cfg 14); 0 = off, -1 = the library default")
+    ap.add_argument("--short-k-half-bytes", type=int, default=-1, help="experiment knob: the longest K row in bytes the --short-k-half-n rule applies to (-1 = the library default)")
     ap.add_argument("--no-lora-rank3", action="store_true", help="A/B: the q | k | v rank terms of a LoRA block's data gradient as three K = 64 launches instead of one uia_lora_rank_update pass")
     ap.add_argument("--no-lora-kext", action="store_true", help="A/B knob: the LoRA rank update as a launch of its own (tile cfg 23) instead of inside the frozen GEMM's K loop")
     ap.add_argument("--quad", action="store_true", help="experiment knob: 256x256 bf16 launches on the four-wave kernel (tile cfg 25, csrc/gemm_quad.hip) instead of the eight-wave ring kernel")
@@ -366,6 +368,10 @@ def main():
     ops.QUAD = args.quad
     ops.LORA_KEXT = not args.no_lora_kext
     ops.LORA_RANK3 = not args.no_lora_rank3
+    if args.short_k_half_n >= 0:
+        ops.SHORT_K_WIDE_HALF_N = args.short_k_half_n
+    if args.short_k_half_bytes >= 0:
+        ops.SHORT_K_WIDE_HALF_BYTES = args.short_k_half_bytes
     ops.LN_LORA_DOWN = not args.no_ln_lora_down
     ops.MONA_PRE_FWD_T = not args.no_mona_pre_fwd_t
     ops.MONA_PRE_BWD_DU = not args.no_mona_pre_bwd_du
