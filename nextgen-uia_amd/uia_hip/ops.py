@@ -71,6 +71,7 @@ PERSIST_STORE_ONLY = False   # experiment knob: 256x256 ring launches whose epil
 KBLOCK_W = True          # hand the ring kernels their weights K-blocked (PackedW.kblocked()); False = row-major everywhere
 K64_CFG14 = True         # single-K-step GEMMs on the two-workgroups-per-CU half-height config (False: 256x256 like every other large shape)
 TILE_GROUP = {}          # experiment knob: {N: row panels per tile-order group} overriding the launcher's choice for ring launches with that N
+SHORT_K_WIDE_HALF_STASH = True   # ... also for launches that write a second output (fc1 with the pre-activation stash)
 SHORT_K_WIDE_HALF_BYTES = 2048   # ... and the longest K row (bytes) it applies to (fc1 of ViT-B: 1536, of ViT-L/14: 2048)
 SHORT_K_WIDE_HALF_N = 3072   # N at and above which a short-K (K row <= SHORT_K_WIDE_HALF_BYTES) bf16 launch runs wholly on half-height tiles, two workgroups per CU (cfg 14); 0 = off (bench.py --short-k-half-n)
 HALF_HEIGHT_SHORT_K = True   # N <= 768, K <= 768 (bf16) launches whose 256-row tiling leaves a ragged last round run on half-height tiles (cfg 14) in one launch
@@ -482,7 +483,8 @@ def gemm(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None, res
         tile_cfg = 8
     if (TAIL_SPLIT and tile_cfg == 0 and out_group == 0 and resid_mod == 0 and a.is_cuda and drop is None and auto_tile_cfg(M, N, Ka, a.element_size()) == 8):
         m_main = tail_split_rows(M, N, num_cus(a.device.index))
-        if SHORT_K_WIDE_HALF_N and N >= SHORT_K_WIDE_HALF_N and Ka * a.element_size() <= SHORT_K_WIDE_HALF_BYTES and a.dtype == torch.bfloat16:
+        if (SHORT_K_WIDE_HALF_N and N >= SHORT_K_WIDE_HALF_N and Ka * a.element_size() <= SHORT_K_WIDE_HALF_BYTES and a.dtype == torch.bfloat16
+                and (SHORT_K_WIDE_HALF_STASH or aux_out is None)):
             # short K loop, wide N (fc1 and its GELU' data gradient: K = 768, N = 3072): a quarter of a 256 x 256 launch is prologue + epilogue + hand-over that
             # nothing overlaps (profiles/r04_d); on half-height tiles two workgroups share a CU and one's seam runs beside the other's K loop:
             # 385 -> 338 us at M = 65 536, 266 -> 252 at 50 432 in isolation (bias + GELU store), level at N = 2304
