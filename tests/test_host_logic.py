@@ -280,7 +280,12 @@ def test_committed_traffic_file_names_the_kernels_the_headline_step_runs():
                 ops.EPI_BIAS | ops.EPI_GELU | ops.EPI_AUX_OUT | ops.EPI_OUTT | ops.EPI_LNFOLD,                         # fc1 with the stash
                 ops.EPI_DGELU | ops.EPI_OUTT, ops.EPI_OUTT, ops.EPI_BIAS | ops.EPI_RESID | ops.EPI_OUT32]              # data gradients, fc2 / proj
     for mask in headline:
-        frag = ops.gemm_kernel_name(8, mask, torch.bfloat16)[1]
+        # 256 x 256 tiles (cfg 8), or — fc1 and its GELU' data gradient under ops.SHORT_K_WIDE_HALF_N — the half-height tiles of cfg 14
+        frags = [ops.gemm_kernel_name(cfg, mask, torch.bfloat16)[1] for cfg in (8, 14)]
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            assert frag in data[counter], (mask, frag, sorted(data[counter])[:3])
-            assert data[counter][frag]["launches"] > 0 and data[counter][frag]["sum"] > 0
+            hit = [f for f in frags if f in data[counter]]
+            assert hit, (mask, frags, sorted(data[counter])[:3])
+            assert all(data[counter][f]["launches"] > 0 and data[counter][f]["sum"] > 0 for f in hit)
+    # the kernel bench.py names as dominant must be there under the name bench.py derives
+    dom = ops.gemm_kernel_name(8, headline[0], torch.bfloat16)[1]
+    assert dom in data["FETCH_SIZE"] and dom in data["WRITE_SIZE"]
