@@ -82,6 +82,7 @@ def parse():
     ap.add_argument("--short-k-half-n", type=int, default=-1, help="experiment knob: short-K bf16 launches with N at or above this value run on half-height tiles (tile cfg 14); 0 = off, -1 = the library default")
     ap.add_argument("--short-k-half-bytes", type=int, default=-1, help="experiment knob: the longest K row in bytes the --short-k-half-n rule applies to (-1 = the library default)")
     ap.add_argument("--short-k-half-no-stash", action="store_true", help="experiment knob: the --short-k-half-n rule skips launches with an aux_out stash")
+    ap.add_argument("--half-height-short-k-always", action="store_true", help="experiment knob: N <= 768, K <= 768 launches on half-height tiles also without a ragged last round")
     ap.add_argument("--no-lora-rank3", action="store_true", help="A/B: the q | k | v rank terms of a LoRA block's data gradient as three K = 64 launches instead of one uia_lora_rank_update pass")
     ap.add_argument("--no-lora-kext", action="store_true", help="A/B knob: the LoRA rank update as a launch of its own (tile cfg 23) instead of inside the frozen GEMM's K loop")
     ap.add_argument("--quad", action="store_true", help="experiment knob: 256x256 bf16 launches on the four-wave kernel (tile cfg 25, csrc/gemm_quad.hip) instead of the eight-wave ring kernel")
@@ -372,6 +373,7 @@ def main():
     if args.short_k_half_n >= 0:
         ops.SHORT_K_WIDE_HALF_N = args.short_k_half_n
     ops.SHORT_K_WIDE_HALF_STASH = not args.short_k_half_no_stash
+    ops.HALF_HEIGHT_SHORT_K_ALWAYS = args.half_height_short_k_always
     if args.short_k_half_bytes >= 0:
         ops.SHORT_K_WIDE_HALF_BYTES = args.short_k_half_bytes
     ops.LN_LORA_DOWN = not args.no_ln_lora_down

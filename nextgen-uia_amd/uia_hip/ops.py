@@ -74,6 +74,7 @@ TILE_GROUP = {}          # experiment knob: {N: row panels per tile-order group}
 SHORT_K_WIDE_HALF_STASH = True   # ... also for launches that write a second output (fc1 with the pre-activation stash)
 SHORT_K_WIDE_HALF_BYTES = 2048   # ... and the longest K row (bytes) it applies to (fc1 of ViT-B: 1536, of ViT-L/14: 2048)
 SHORT_K_WIDE_HALF_N = 3072   # N at and above which a short-K (K row <= SHORT_K_WIDE_HALF_BYTES) bf16 launch runs wholly on half-height tiles, two workgroups per CU (cfg 14); 0 = off (bench.py --short-k-half-n)
+HALF_HEIGHT_SHORT_K_ALWAYS = False   # experiment knob: ... also when the 256-row tiling has no ragged last round (the text tower's N = 768, K = 768 sums at 65 536 rows)
 HALF_HEIGHT_SHORT_K = True   # N <= 768, K <= 768 (bf16) launches whose 256-row tiling leaves a ragged last round run on half-height tiles (cfg 14) in one launch
 TAIL_SPLIT = True        # split off the M tail of a launch whose last round of 256x256 tiles would leave most CUs idle
 TAIL_SIDE_STREAM = True  # a SMALL M tail (at most a quarter of the CUs' worth of half-height tiles) runs on a side stream beside the main launch instead of behind it
@@ -489,7 +490,7 @@ def gemm(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None, res
             # nothing overlaps (profiles/r04_d); on half-height tiles two workgroups share a CU and one's seam runs beside the other's K loop:
             # 385 -> 338 us at M = 65 536, 266 -> 252 at 50 432 in isolation (bias + GELU store), level at N = 2304
             tile_cfg, m_main = 14, M
-        if m_main < M and HALF_HEIGHT_SHORT_K and N <= 768 and Ka * a.element_size() <= 1536:
+        if (m_main < M or HALF_HEIGHT_SHORT_K_ALWAYS) and HALF_HEIGHT_SHORT_K and N <= 768 and Ka * a.element_size() <= 1536:
             # short K loops with a ragged last round (the image tower's output projection and its data gradient: 591 tiles on 256 CUs): the whole
             # launch on half-height tiles, two workgroups per CU (tile cfg 14), instead of a main launch + a half-height tail launch — 1182 half
             # tiles pack 2.31 rounds of 512, and one workgroup's epilogue runs beside its neighbour's K loop (round 3, isolated: 64 vs 62 + 21 us
