@@ -1350,6 +1350,8 @@ int launch_typed(hipStream_t stream, const UiaGemmParams& p, int cfg_in) {
 #ifdef UIA_GEMM_EXP
         case 19: return launch_ring<T, 256, 256, 2, 4, 64, 4, 3>(stream, p, true, xflags);   // cfg 8 with the last 8 MFMAs of a cluster behind the slot barrier
         case 20: return launch_ring<T, 256, 256, 2, 4, 64, 4, 4>(stream, p, true, xflags);   // ... the last 16
+#endif
+#if defined(UIA_GEMM_EXP) || defined(UIA_GEMM_CFG1718)
         // experiment (round 3): FOUR-wave workgroups, two per CU, so that one workgroup's epilogue runs beside the other's K loop
         case 17: return launch_ring<T, 256, 128, 2, 2, 64, 3>(stream, p, true, xflags);   // 256 x 128 tiles (A panel re-read by the column neighbour)
         case 18: return launch_ring<T, 128, 256, 1, 4, 64, 3>(stream, p, true, xflags);   // 128 x 256 tiles
