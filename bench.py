@@ -83,6 +83,7 @@ def parse():
     ap.add_argument("--short-k-half-bytes", type=int, default=-1, help="experiment knob: the longest K row in bytes the --short-k-half-n rule applies to (-1 = the library default)")
     ap.add_argument("--short-k-half-no-stash", action="store_true", help="experiment knob: the --short-k-half-n rule skips launches with an aux_out stash")
     ap.add_argument("--half-height-short-k-always", action="store_true", help="experiment knob: N <= 768, K <= 768 launches on half-height tiles also without a ragged last round")
+    ap.add_argument("--no-grad-resid3", action="store_true", help="A/B: the residual gradient between the image tower's backward Functions as fp32 + bf16 copy (rounds 1-3) instead of a three-byte tensor")
     ap.add_argument("--no-lora-rank3", action="store_true", help="A/B: the q | k | v rank terms of a LoRA block's data gradient as three K = 64 launches instead of one uia_lora_rank_update pass")
     ap.add_argument("--no-lora-kext", action="store_true", help="A/B knob: the LoRA rank update as a launch of its own (tile cfg 23) instead of inside the frozen GEMM's K loop")
     ap.add_argument("--quad", action="store_true", help="experiment knob: 256x256 bf16 launches on the four-wave kernel (tile cfg 25, csrc/gemm_quad.hip) instead of the eight-wave ring kernel")
@@ -389,6 +390,8 @@ def main():
     UF.set_wgrad_side_stream(args.wgrad_side_stream)
     UF.set_fp32_heads(not args.bf16_heads)
     UF.set_text_resid3(not args.no_text_resid3)
+    from uia_hip import engine as _engine
+    _engine.GRAD_RESID3 = not args.no_grad_resid3
     UF.set_block_resid3(args.block_resid3)
     ops.PERSIST_STORE_ONLY = args.persist_store_only
     ops.TILE_GROUP = {int(k): int(v) for k, v in (kv.split("=") for kv in args.tile_group.split(",") if kv)}

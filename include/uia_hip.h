@@ -218,9 +218,11 @@ int uia_layernorm_bwd(void* stream, int dtype, int M, int D, int64_t ldx, const 
  * the attention-half output x1 and its gradient dx1 never exist in fp32 — x1 leaves the output projection's epilogue as (T copy, low bytes) and
  * is read here for the statistics; dx1 leaves this kernel as (dxT, dx_lo) and comes back as the next call's (dres_hi, dres_lo).
  *   x_lo   != NULL: x is (x_hi, x_lo); x must be NULL; x_hi row-major [M, D] or, x_kb_rows > 0, K-blocked with that many rows per 32-column block.
- *   dres_lo != NULL: dres is (dres_hi row-major, dres_lo); dres must be NULL.      dx_lo != NULL: the result is (dxT, dx_lo); dx32 may be NULL. */
+ *   dres_lo != NULL: dres is (dres_hi, dres_lo); dres must be NULL; dres_hi row-major or, dres_kb_rows > 0, K-blocked like x_hi (the T copy a row kernel
+ *                    left for a ring GEMM is also the hi plane of the residual gradient).      dx_lo != NULL: the result is (dxT, dx_lo); dx32 may be NULL. */
 int uia_layernorm_bwd3(void* stream, int dtype, int M, int D, int64_t ldx, const void* dy, const float* x, const void* x_hi, const int8_t* x_lo, int64_t x_kb_rows,
-                       const float* gamma, float eps, const float* dres, const void* dres_hi, const int8_t* dres_lo, float* dx32, void* dxT, int8_t* dx_lo);
+                       const float* gamma, float eps, const float* dres, const void* dres_hi, const int8_t* dres_lo, int64_t dres_kb_rows, float* dx32, void* dxT,
+                       int8_t* dx_lo);
 
 /* ---------------------------------------------------------------------------------------------
  * Mona adapter, all four variants (src/adapters/mona.py:75-487; equations SURVEY.md Appendix E.1).
@@ -270,6 +272,12 @@ int uia_mona_pre_bwd(void* stream, int dtype, int M, int D, const void* du, cons
 int uia_mona_pre_bwd_du(void* stream, int dtype, int M, int D, const void* dt, int64_t ldt, const void* w1t, int64_t ldw1, const float* x, const float* dy,
                         const float* norm_w, const float* norm_b, const float* gamma, const float* gammax, float eps,
                         float* dx32, void* dxT, float* g_gamma, float* g_gammax, float* g_norm_w, float* g_norm_b, float* ws, int64_t dxT_kb_rows);
+/* uia_mona_pre_bwd_du on THREE-BYTE residual gradients (the form of uia_gemm_desc.resid_lo8; reference: the fp32 gradient autograd hands mona.py:151's residual add):
+ * dy arrives as (dy_hi bf16 row-major [M, D], dy_lo int8 [M, D]) — what uia_layernorm_bwd3 left as (dxT, dx_lo) — and dx leaves as (dxT, dx_lo), dxT row-major or,
+ * dxT_kb_rows > 0, K-blocked: 3 bytes read and 3 written per element of the stream instead of 4 and 4 + 2.  Same arithmetic as uia_mona_pre_bwd_du on the decoded values. */
+int uia_mona_pre_bwd_du3(void* stream, int dtype, int M, int D, const void* dt, int64_t ldt, const void* w1t, int64_t ldw1, const float* x, const void* dy_hi, const int8_t* dy_lo,
+                         const float* norm_w, const float* norm_b, const float* gamma, const float* gammax, float eps, void* dxT, int8_t* dx_lo, float* g_gamma,
+                         float* g_gammax, float* g_norm_w, float* g_norm_b, float* ws, int64_t dxT_kb_rows);
 size_t uia_mona_pre_bwd_workspace_bytes(int M, int D);
 int uia_mona_spatial_fwd(void* stream, int dtype, const uia_mona_spatial_desc* d);
 int uia_mona_spatial_bwd(void* stream, int dtype, const uia_mona_spatial_desc* d);

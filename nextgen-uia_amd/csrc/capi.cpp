@@ -58,8 +58,10 @@ int uia_layernorm_bwd(void* stream, int dtype, int M, int D, int64_t ldx, const 
     return uia_layernorm_bwd_launch((hipStream_t)stream, dtype, M, D, ldx, dy, x, gamma, eps, dres, dx32, dxT);
 }
 int uia_layernorm_bwd3(void* stream, int dtype, int M, int D, int64_t ldx, const void* dy, const float* x, const void* x_hi, const int8_t* x_lo, int64_t x_kb_rows,
-                       const float* gamma, float eps, const float* dres, const void* dres_hi, const int8_t* dres_lo, float* dx32, void* dxT, int8_t* dx_lo) {
-    return uia_layernorm_bwd3_launch((hipStream_t)stream, dtype, M, D, ldx, dy, x, x_hi, x_lo, (long)x_kb_rows, gamma, eps, dres, dres_hi, dres_lo, dx32, dxT, dx_lo);
+                       const float* gamma, float eps, const float* dres, const void* dres_hi, const int8_t* dres_lo, int64_t dres_kb_rows, float* dx32, void* dxT,
+                       int8_t* dx_lo) {
+    return uia_layernorm_bwd3_launch((hipStream_t)stream, dtype, M, D, ldx, dy, x, x_hi, x_lo, (long)x_kb_rows, gamma, eps, dres, dres_hi, dres_lo, (long)dres_kb_rows, dx32, dxT,
+                                     dx_lo);
 }
 int uia_cast(void* stream, int dtype, size_t n, const float* src, void* dst, float scale) { return uia_cast_launch((hipStream_t)stream, dtype, n, src, dst, scale); }
 int uia_transpose_cast(void* stream, int dtype, int rows, int cols, const float* src, void* dst) { return uia_transpose_cast_launch((hipStream_t)stream, dtype, rows, cols, src, dst); }
@@ -91,6 +93,13 @@ int uia_mona_pre_bwd_du(void* stream, int dtype, int M, int D, const void* dt, i
     if (!dt || !w1t) { uia_set_error("uia_mona_pre_bwd_du: null dt / w1t"); return -1; }
     return uia_mona_pre_bwd_launch((hipStream_t)stream, dtype, M, D, nullptr, x, dy, norm_w, norm_b, gamma, gammax, eps, dx32, dxT, g_gamma, g_gammax,
                                    g_norm_w, g_norm_b, ws, (long)dxT_kb_rows, dt, (long)ldt, w1t, (long)ldw1);
+}
+int uia_mona_pre_bwd_du3(void* stream, int dtype, int M, int D, const void* dt, int64_t ldt, const void* w1t, int64_t ldw1, const float* x, const void* dy_hi, const int8_t* dy_lo,
+                         const float* norm_w, const float* norm_b, const float* gamma, const float* gammax, float eps, void* dxT, int8_t* dx_lo, float* g_gamma,
+                         float* g_gammax, float* g_norm_w, float* g_norm_b, float* ws, int64_t dxT_kb_rows) {
+    if (!dt || !w1t || !dy_hi || !dy_lo || !dx_lo) { uia_set_error("uia_mona_pre_bwd_du3: null dt / w1t / dy_hi / dy_lo / dx_lo"); return -1; }
+    return uia_mona_pre_bwd_launch((hipStream_t)stream, dtype, M, D, nullptr, x, nullptr, norm_w, norm_b, gamma, gammax, eps, nullptr, dxT, g_gamma, g_gammax,
+                                   g_norm_w, g_norm_b, ws, (long)dxT_kb_rows, dt, (long)ldt, w1t, (long)ldw1, dy_hi, dy_lo, dx_lo);
 }
 size_t uia_mona_pre_bwd_workspace_bytes(int M, int D) { return uia_mona_pre_bwd_ws_floats(M, D) * sizeof(float); }
 int uia_mona_spatial_fwd(void* stream, int dtype, const uia_mona_spatial_desc* d) {

@@ -20,6 +20,7 @@
 // All of it is HBM/LDS-bound VALU work: thread = (channel = lane, pixel group = wave) so that every
 // LDS access of a wave is 64 consecutive floats (conflict-free) and boundary tests are wave-uniform.
 #include <stdlib.h>
+#include <type_traits>
 #include "uia_common.h"
 #include "uia_kernels.h"
 
@@ -157,12 +158,20 @@ __global__ __launch_bounds__(256) void mona_pre_fwd_t_kernel(int M, const float*
 // walks 16-row tiles; its four waves multiply the tile's dt rows [16 x 64] with W1ᵀ ([D, 64] row-major, L2-resident) on the matrix cores, a quarter of the
 // columns each, and leave the bf16 tile in LDS in the row layout the row passes read (MFMA with W1ᵀ as the A operand: a lane gets four consecutive columns
 // of one row — one 8-byte LDS store per tile); same products in the same order and the same rounding to bf16 as the GEMM launch it replaces.
-template <typename T, int NV, bool KB = false, bool FUSE = false>
-__global__ __launch_bounds__(256, FUSE ? 3 : 1) void mona_pre_bwd_kernel(int M, int D, const T* __restrict__ du, const float* __restrict__ x,
+// (Round 4, measured and removed: the three column sums in LDS with ds_add_f32 instead of 36 registers — 128 VGPRs, four waves per SIMD — took 664 us against 157:
+// a 64-lane LDS float atomic retires at ~190 cycles per instruction.  Without the sums at all the three-byte form runs in 128 us, tools/mpb_variants.sh.)
+// R3 (round 4, with FUSE): the residual gradient travels as a THREE-BYTE tensor (uia_gemm_desc.resid_lo8) on both sides — dy arrives as (dy_hi row-major, dy_lo),
+// dx leaves as (dxT, dx_lo) with dxT, row-major or K-blocked, as its hi plane: 3 bytes read and 3 written per element instead of 4 and 4 + 2.
+#ifndef MPB_WAVES
+#define MPB_WAVES 3
+#endif
+template <typename T, int NV, bool KB = false, bool FUSE = false, bool R3 = false>
+__global__ __launch_bounds__(256, FUSE ? MPB_WAVES : 1) void mona_pre_bwd_kernel(int M, int D, const T* __restrict__ du, const float* __restrict__ x,
                                                             const float* __restrict__ dy, const float* __restrict__ nw,
                                                             const float* __restrict__ gamma, const float* __restrict__ gammax, float eps,
                                                             float* __restrict__ dx32, T* __restrict__ dxT, float* __restrict__ ws, long dxT_kb,
-                                                            const T* __restrict__ dtp, long ldt, const T* __restrict__ w1t, long ldw1) {
+                                                            const T* __restrict__ dtp, long ldt, const T* __restrict__ w1t, long ldw1,
+                                                            const bf16_t* __restrict__ dy_hi, const int8_t* __restrict__ dy_lo, int8_t* __restrict__ dx_lo) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // wave-uniform row → scalar row pointers
     // KB: the T copy of dx is written K-blocked ([D/g][dxT_kb rows][g], g = 64 bytes of elements).  A compile-time variant: the address
@@ -180,26 +189,35 @@ __global__ __launch_bounds__(256, FUSE ? 3 : 1) void mona_pre_bwd_kernel(int M, 
         prm[D + i] = gammax[i];
     }
     __syncthreads();
-    const bool want_dx = dx32 != nullptr || dxT != nullptr;
+    struct Raw3 { uint2 h; unsigned l; };
+    using OT = std::conditional_t<R3, Raw3, f32x4>;             // a row's dy: fp32 values, or the raw planes of a three-byte tensor (three registers per float4)
+    const bool want_dx = R3 || dx32 != nullptr || dxT != nullptr;
     f32x4 a0[NV], a1[NV], a2[NV];
 #pragma unroll
     for (int k = 0; k < NV; ++k) a0[k] = a1[k] = a2[k] = f32x4{0.f, 0.f, 0.f, 0.f};
     // x, du and dy of a row are requested together, and the NEXT row of the wave is requested before the current one is processed
     // (two register sets, the loop is unrolled by two): at four waves per SIMD one row in flight per wave left HBM at 4.6 TB/s.
-    auto issue = [&](int row, f32x4 (&v)[NV], f32x4 (&d)[NV], f32x4 (&o)[NV]) {
+    auto issue = [&](int row, f32x4 (&v)[NV], f32x4 (&d)[NV], OT (&o)[NV]) {
         const float* xr = x + (size_t)row * D;
         const T* dur = FUSE ? nullptr : du + (size_t)row * D;
-        const float* dyr = dy + (size_t)row * D;
+        const float* dyr = R3 ? nullptr : dy + (size_t)row * D;
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             const int c = lane + 64 * k;
             const bool ok = c < nv;
             v[k] = ok ? load4(xr + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
             if constexpr (!FUSE) d[k] = ok ? load4(dur + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
-            if (want_dx) o[k] = ok ? load4(dyr + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (R3) {
+                // raw planes, decoded in process(): three registers in flight per float4 instead of four
+                const uint2 hraw = ok ? *(const uint2*)(dy_hi + (size_t)row * D + 4 * c) : uint2{0u, 0u};
+                const unsigned lraw = ok ? *(const unsigned*)(dy_lo + (size_t)row * D + 4 * c) : 0u;
+                o[k] = OT{hraw, lraw};
+            } else {
+                if (want_dx) o[k] = ok ? load4(dyr + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
         }
     };
-    auto process = [&](int row, f32x4 (&v)[NV], f32x4 (&d)[NV], f32x4 (&o)[NV]) {
+    auto process = [&](int row, f32x4 (&v)[NV], f32x4 (&d)[NV], OT (&o)[NV]) {
         int poff = 0;
         asm volatile("" : "+v"(poff));                            // keeps the parameter reads inside the loop
         const float* pr = prm + poff;
@@ -223,9 +241,11 @@ __global__ __launch_bounds__(256, FUSE ? 3 : 1) void mona_pre_bwd_kernel(int M, 
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float xhat = v[k][e] * rstd;
+#ifndef MPB_NO_ACC      // diagnostic builds (tools/mpb_variants.sh): the kernel without its 36 accumulator registers (gradients WRONG)
                 a0[k][e] += d[k][e];                                       // S0
                 a1[k][e] = fmaf(d[k][e], xhat, a1[k][e]);                  // S1
                 a2[k][e] = fmaf(d[k][e], v[k][e] + mean, a2[k][e]);        // S2 (x itself)
+#endif
                 const float gv = d[k][e] * pgw[e];                         // dL/dx̂
                 sg += gv;
                 sgx = fmaf(gv, xhat, sgx);
@@ -242,19 +262,28 @@ __global__ __launch_bounds__(256, FUSE ? 3 : 1) void mona_pre_bwd_kernel(int M, 
                 if (c < nv) {
                     const f32x4 pgw = *(const f32x4*)(pr + 4 * c), pgx = *(const f32x4*)(pr + D + 4 * c);
                     f32x4 r;
+                    f32x4 oo;
+                    if constexpr (R3) oo = three_byte_decode4(o[k].h, o[k].l);      // (o holds the raw planes as integers: bit-casting elements of a float ext_vector reads element 0 for every e, hipcc 7.2)
+                    else oo = o[k];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float gv = d[k][e] * pgw[e];
-                        r[e] = o[k][e] + fmaf(d[k][e], pgx[e], rstd * (gv - mg - v[k][e] * mgx));
+                        r[e] = oo[e] + fmaf(d[k][e], pgx[e], rstd * (gv - mg - v[k][e] * mgx));
                     }
-                    if (dx32r) store4(dx32r + 4 * c, r);
-                    if (KB) store4(dxT + ((size_t)(k * (64 / LPB)) * (size_t)dxT_kb + row) * KBG + kb_lane, r);
-                    else if (dxTr) store4(dxTr + 4 * c, r);
+                    if constexpr (R3) {
+                        bf16_t* hp = KB ? (bf16_t*)dxT + ((size_t)(k * (64 / LPB)) * (size_t)dxT_kb + row) * KBG + kb_lane : (bf16_t*)dxT + (size_t)row * D + 4 * c;
+                        three_byte_store4(hp, dx_lo + (size_t)row * D + 4 * c, r);
+                    } else {
+                        if (dx32r) store4(dx32r + 4 * c, r);
+                        if (KB) store4(dxT + ((size_t)(k * (64 / LPB)) * (size_t)dxT_kb + row) * KBG + kb_lane, r);
+                        else if (dxTr) store4(dxTr + 4 * c, r);
+                    }
                 }
             }
         }
     };
-    f32x4 vA[NV], dA[NV], oA[NV], vB[NV], dB[NV], oB[NV];
+    f32x4 vA[NV], dA[NV], vB[NV], dB[NV];
+    OT oA[NV], oB[NV];
     if constexpr (FUSE) {
         char* du_s = smem + (size_t)8 * D * sizeof(float);             // [16][D] bf16: the tile's du rows, behind the reduction area and the parameter vectors
         const int ntiles = (M + 15) >> 4;
@@ -1186,7 +1215,8 @@ size_t uia_mona_pre_bwd_ws_floats(int M, int D) { return (size_t)mona_pre_bwd_bl
 
 int uia_mona_pre_bwd_launch(hipStream_t stream, int dtype, int M, int D, const void* du, const float* x, const float* dy, const float* nw,
                             const float* nb, const float* gamma, const float* gammax, float eps, float* dx32, void* dxT, float* g_gamma,
-                            float* g_gammax, float* g_nw, float* g_nb, float* ws, long dxT_kb_rows, const void* dt, long ldt, const void* w1t, long ldw1) {
+                            float* g_gammax, float* g_nw, float* g_nb, float* ws, long dxT_kb_rows, const void* dt, long ldt, const void* w1t, long ldw1,
+                            const void* dy_hi, const int8_t* dy_lo, int8_t* dx_lo) {
     UIA_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 1024, "uia_mona_pre_bwd: unsupported shape M=%d D=%d", M, D);
     UIA_CHECK_ARG(dxT_kb_rows == 0 || (dxT && dxT_kb_rows >= M && (D * (dtype == UIA_BF16 ? 2 : 4)) % 64 == 0 && dxT_kb_rows * (long)D < (1L << 31)),
                   "uia_mona_pre_bwd: dxT_kb_rows=%ld needs dxT, at least M=%d rows and whole 64-byte column blocks", dxT_kb_rows, M);
@@ -1194,7 +1224,10 @@ int uia_mona_pre_bwd_launch(hipStream_t stream, int dtype, int M, int D, const v
     UIA_CHECK_ARG((du || fuse) && x && nw && nb && gamma && gammax && g_gamma && g_gammax && g_nw && g_nb && ws, "uia_mona_pre_bwd: null tensor");
     UIA_CHECK_ARG(!fuse || (dtype == UIA_BF16 && w1t && D % 64 == 0 && D <= 768 && ldt >= 64 && ldt % 8 == 0 && ldw1 >= 64 && ldw1 % 8 == 0 && (uintptr_t)dt % 16 == 0 && (uintptr_t)w1t % 16 == 0),
                   "uia_mona_pre_bwd_du: bf16, bottleneck 64 (dt [M, 64], W1ᵀ [D, 64], 16-byte aligned rows), D a multiple of 64 up to 768");
-    UIA_CHECK_ARG(dy || !(dx32 || dxT), "uia_mona_pre_bwd: dx requested without dy");
+    const bool r3 = dy_lo != nullptr || dx_lo != nullptr;
+    UIA_CHECK_ARG(!r3 || (fuse && dy_hi && dy_lo && dx_lo && dxT && !dy && !dx32 && (uintptr_t)dy_hi % 8 == 0 && (uintptr_t)dy_lo % 4 == 0 && (uintptr_t)dx_lo % 4 == 0 && (uintptr_t)dxT % 8 == 0),
+                  "uia_mona_pre_bwd_du3: three-byte residual gradients need the fused form, dy as (dy_hi, dy_lo) with no fp32 dy, and dx as (dxT, dx_lo) with no dx32");
+    UIA_CHECK_ARG(r3 || dy || !(dx32 || dxT), "uia_mona_pre_bwd: dx requested without dy");
     int blocks = mona_pre_bwd_blocks(M);
     const size_t lds = (size_t)8 * D * sizeof(float) + (fuse ? (size_t)16 * D * 2 : 0);   // [2][3][D] reduction area + [2][D] parameter vectors (+ the du tile, [16][D] bf16)
     const int nvsel = D <= 256 ? 1 : (D <= 768 ? 3 : 4);
@@ -1206,20 +1239,20 @@ int uia_mona_pre_bwd_launch(hipStream_t stream, int dtype, int M, int D, const v
             hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&       \
             ncu > 0 && per_cu * ncu < blocks) blocks = per_cu * ncu;                                                                           \
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, stream, M, D, (const TT*)du, x, dy, nw, gamma, gammax, eps, dx32, (TT*)dxT, ws, dxT_kb_rows, \
-                           (const TT*)nullptr, 0l, (const TT*)nullptr, 0l);                                                                     \
+                           (const TT*)nullptr, 0l, (const TT*)nullptr, 0l, (const bf16_t*)nullptr, (const int8_t*)nullptr, (int8_t*)nullptr);    \
     } while (0)
     if (fuse) {
-        auto kern = dxT_kb_rows ? mona_pre_bwd_kernel<bf16_t, 3, true, true> : mona_pre_bwd_kernel<bf16_t, 3, false, true>;
-        static UiaDevOnce once_a, once_b;
-        if (dxT_kb_rows) UIA_ENSURE_LDS_ATTR(once_a, (mona_pre_bwd_kernel<bf16_t, 3, true, true>), 160 * 1024);
-        else UIA_ENSURE_LDS_ATTR(once_b, (mona_pre_bwd_kernel<bf16_t, 3, false, true>), 160 * 1024);
+        auto kern = r3 ? (dxT_kb_rows ? mona_pre_bwd_kernel<bf16_t, 3, true, true, true> : mona_pre_bwd_kernel<bf16_t, 3, false, true, true>)
+                       : (dxT_kb_rows ? mona_pre_bwd_kernel<bf16_t, 3, true, true> : mona_pre_bwd_kernel<bf16_t, 3, false, true>);
+        static UiaDevOnce once[4];
+        UIA_ENSURE_LDS_ATTR(once[(r3 ? 2 : 0) + (dxT_kb_rows ? 1 : 0)], kern, 160 * 1024);
         int per_cu = 0, dev = 0, ncu = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds) == hipSuccess && per_cu > 0 && hipGetDevice(&dev) == hipSuccess &&
             hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && ncu > 0 && per_cu * ncu < blocks) blocks = per_cu * ncu;
         const int ntiles = (M + 15) / 16;
         if (blocks > ntiles) blocks = ntiles;
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, stream, M, D, (const bf16_t*)nullptr, x, dy, nw, gamma, gammax, eps, dx32, (bf16_t*)dxT, ws, dxT_kb_rows,
-                           (const bf16_t*)dt, ldt, (const bf16_t*)w1t, ldw1);
+                           (const bf16_t*)dt, ldt, (const bf16_t*)w1t, ldw1, (const bf16_t*)dy_hi, dy_lo, dx_lo);
         UIA_CHECK_LAUNCH();
         hipLaunchKernelGGL(mona_pre_reduce_kernel, dim3((3 * D + 255) / 256, PRE_RED_SPLIT), dim3(256), 0, stream, blocks, D, ws, nw, nb, gamma, g_gamma, g_gammax, g_nw, g_nb);
         UIA_CHECK_LAUNCH();

@@ -57,6 +57,48 @@ struct UiaDevOnce {
         }                                                                                                          \
     } while (0)
 
+#if defined(__HIPCC__)
+// Three-byte tensors (round 4; include/uia_hip.h, uia_gemm_desc.resid_lo8): a value is its bf16 hi plane + a signed low byte,
+// float bits = (hi_bits << 16) + (lo << 8).  Inside a frozen block the attention-half output x1 and its gradient dx1 travel in that form
+// between the GEMM epilogues and this kernel: 3 bytes read instead of 4, 3 written instead of 4 + 2.
+__device__ __forceinline__ f32x4 three_byte_load4(const bf16_t* hi, const int8_t* lo) {
+    typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
+    const u16x4 h = *(const u16x4*)hi;
+    const int l = *(const int*)lo;
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = __builtin_bit_cast(float, ((unsigned)h[e] << 16) + ((unsigned)__builtin_amdgcn_sbfe(l, 8 * e, 8) << 8));
+    return r;
+}
+__device__ __forceinline__ void three_byte_store4(bf16_t* hi, int8_t* lo, f32x4 v) {
+    unsigned w[4];
+    unsigned short hs[4];
+    const float f[4] = {v[0], v[1], v[2], v[3]};      // (bit-casting v[e] of the ext_vector inside the unrolled loop read element 0 for every e: hipcc 7.2)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const unsigned vb = __builtin_bit_cast(unsigned, f[e]);
+        hs[e] = __builtin_bit_cast(unsigned short, (bf16_t)f[e]);
+        int d = (int)((vb + 0x80u) >> 8) - (int)((unsigned)hs[e] << 8);
+        d = d < -127 ? -127 : (d > 127 ? 127 : d);
+        w[e] = (unsigned)d & 0xFFu;
+    }
+    uint2 hp;
+    hp.x = (unsigned)hs[0] | ((unsigned)hs[1] << 16);
+    hp.y = (unsigned)hs[2] | ((unsigned)hs[3] << 16);
+    *(uint2*)hi = hp;
+    *(unsigned*)lo = w[0] | (w[1] << 8) | (w[2] << 16) | (w[3] << 24);
+}
+
+__device__ __forceinline__ f32x4 three_byte_decode4(uint2 hraw, unsigned lraw) {
+    const unsigned h[4] = {hraw.x & 0xFFFFu, hraw.x >> 16, hraw.y & 0xFFFFu, hraw.y >> 16};
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = __builtin_bit_cast(float, (h[e] << 16) + ((unsigned)__builtin_amdgcn_sbfe((int)lraw, 8 * e, 8) << 8));
+    return r;
+}
+
+#endif
+
 // compute units of the current device (cached on first use; 256 on MI355X)
 inline int uia_num_cus() {
     static int n = 0;

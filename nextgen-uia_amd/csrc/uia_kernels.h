@@ -18,8 +18,8 @@ int uia_layernorm_fwd_launch(hipStream_t stream, int dtype, int M, int D, long l
 int uia_layernorm_bwd_launch(hipStream_t stream, int dtype, int M, int D, long ldx, const void* dy, const float* x, const float* gamma, float eps,
                              const float* dres, float* dx32, void* dxT);
 int uia_layernorm_bwd3_launch(hipStream_t stream, int dtype, int M, int D, long ldx, const void* dy, const float* x, const void* x_hi, const int8_t* x_lo,
-                              long x_kb_rows, const float* gamma, float eps, const float* dres, const void* dres_hi, const int8_t* dres_lo, float* dx32,
-                              void* dxT, int8_t* dx_lo);
+                              long x_kb_rows, const float* gamma, float eps, const float* dres, const void* dres_hi, const int8_t* dres_lo, long dres_kb_rows,
+                              float* dx32, void* dxT, int8_t* dx_lo);
 int uia_lora_rank_update_launch(hipStream_t stream, int dtype, const uia_lora_rank_desc& p);
 int uia_ln_lora_down_launch(hipStream_t stream, int dtype, const uia_ln_lora_desc& p);
 int uia_cast_launch(hipStream_t stream, int dtype, size_t n, const float* src, void* dst, float scale);
@@ -38,7 +38,7 @@ int uia_mona_pre_fwd_t_launch(hipStream_t stream, int dtype, int M, int D, const
 int uia_mona_pre_bwd_launch(hipStream_t stream, int dtype, int M, int D, const void* du, const float* x, const float* dy, const float* nw,
                             const float* nb, const float* gamma, const float* gammax, float eps, float* dx32, void* dxT, float* g_gamma,
                             float* g_gammax, float* g_nw, float* g_nb, float* ws, long dxT_kb_rows, const void* dt = nullptr, long ldt = 0,
-                            const void* w1t = nullptr, long ldw1 = 0);
+                            const void* w1t = nullptr, long ldw1 = 0, const void* dy_hi = nullptr, const int8_t* dy_lo = nullptr, int8_t* dx_lo = nullptr);
 size_t uia_mona_pre_bwd_ws_floats(int M, int D);
 int uia_mona_spatial_fwd_launch(hipStream_t stream, int dtype, const uia_mona_spatial_desc& p);
 int uia_mona_spatial_bwd_launch(hipStream_t stream, int dtype, const uia_mona_spatial_desc& p);

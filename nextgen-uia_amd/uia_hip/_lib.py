@@ -94,11 +94,12 @@ PROTOTYPES = {
     "uia_layernorm_bwd": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, i64, vp, vp, vp, f32, vp, vp, vp]),
     "uia_ln_lora_down": (C.c_int, [vp, C.c_int, C.POINTER(LnLoraDesc)]),
     "uia_lora_rank_update": (C.c_int, [vp, C.c_int, C.POINTER(LoraRankDesc)]),
-    "uia_layernorm_bwd3": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, i64, vp, vp, vp, vp, i64, vp, f32, vp, vp, vp, vp, vp, vp]),
+    "uia_layernorm_bwd3": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, i64, vp, vp, vp, vp, i64, vp, f32, vp, vp, vp, i64, vp, vp, vp]),
     "uia_mona_pre_fwd": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, f32, vp]),
     "uia_mona_pre_bwd": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, i64]),
     "uia_mona_pre_fwd_t": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, f32, vp, vp, i64, vp, vp, i64]),
     "uia_mona_pre_bwd_du": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, i64]),
+    "uia_mona_pre_bwd_du3": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, i64]),
     "uia_mona_pre_bwd_workspace_bytes": (sz, [C.c_int, C.c_int]),
     "uia_mona_spatial_fwd": (C.c_int, [vp, C.c_int, C.POINTER(MonaSpatialDesc)]),
     "uia_mona_spatial_bwd": (C.c_int, [vp, C.c_int, C.POINTER(MonaSpatialDesc)]),

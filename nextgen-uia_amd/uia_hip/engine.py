@@ -250,6 +250,21 @@ def _mb_streams(device, n):
     return _MB_STREAMS[key]
 
 
+GRAD_RESID3 = True      # the residual gradient between a frozen tower's backward Functions as a three-byte tensor (functional.publish_grad3); A/B: bench.py --no-grad-resid3
+
+
+def _hook_free(model):
+    """No forward / backward hooks anywhere in the model: nothing but the towers' own Functions reads the tensors between them (checked once per model)."""
+    ok = getattr(model, "_uia_hook_free", None)
+    if ok is None:
+        ok = not any(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or getattr(m, "_backward_pre_hooks", None) for m in model.modules())
+        try:
+            model._uia_hook_free = ok
+        except Exception:
+            pass
+    return ok
+
+
 def contrastive_step(model, criterion, opt, images, ids, micro_batches=1, lr=None, overlap_text=True, global_loss=False, streams=1):
     """One optimiser update: encode → InfoNCE → backward (→ all-reduce) → clip+AdamW.  Returns the loss tensor (device).
 
@@ -268,6 +283,7 @@ def contrastive_step(model, criterion, opt, images, ids, micro_batches=1, lr=Non
     lockstep — every CU in its K loop, then every CU in its HBM-bound epilogue; two chains side by side fill each other's phases and
     tails."""
     UF.clear_t_copies()
+    UF.set_grad_resid3(GRAD_RESID3 and _hook_free(model))
     opt.zero_grad()
     total = None
     mb = images.shape[0] // micro_batches

@@ -201,6 +201,77 @@ def clear_t_copies():
     _T_COPIES.clear()
     _ROWS.clear()
     _SUMS_ARENA.clear()
+    _G3.clear()
+
+
+# ------------------------------------------------------------------------------------------------
+# THREE-BYTE residual gradients between the backward Functions of a frozen tower (round 4).  The fp32 gradient of the residual stream is
+# written by one row kernel (4 B + its 2-byte T copy) and read back by the next (4 B), three times per layer; as a three-byte tensor
+# (ops / include/uia_hip.h: bf16 hi plane — the T copy itself — plus one low byte) the same hand-off is 3 B written and 3 B read.  autograd
+# still wants a tensor of the gradient's shape: it gets a TOKEN — one NaN float expanded to that shape, no memory — and the planes travel
+# in this registry under the token's address.  Only MonaFn and VitBlockFn produce and consume tokens, a producer hands one out only when its
+# forward saw that the tensor it is the gradient of came straight (through views) from the other Function (so the token's only reader is
+# that Function's backward), and anything else that reads a token reads NaN: a topology this does not cover fails loudly, not quietly.
+# Opt-in per step (set_grad_resid3; engine.contrastive_step turns it on for hook-free towers).
+_G3 = {}
+_G3_POOL = {}
+_G3_VIEWS = ("PermuteBackward0", "ViewBackward0", "UnsafeViewBackward0", "TransposeBackward0", "AliasBackward0", "ReshapeAliasBackward0")
+_G3_PARTNERS = ("MonaFnBackward", "VitBlockFnBackward")
+
+
+def set_grad_resid3(flag):
+    _STATE["grad_resid3"] = bool(flag)
+
+
+def grad_resid3_enabled():
+    return bool(_STATE.get("grad_resid3", False))
+
+
+def _g3_partner_feeds(x):
+    """True when x is the output of a MonaFn / VitBlockFn seen through view nodes only: the gradient this Function returns for x goes to that Function's backward."""
+    if not grad_resid3_enabled():
+        return False
+    fn = x.grad_fn
+    for _ in range(8):
+        if fn is None:
+            return False
+        name = type(fn).__name__
+        if name in _G3_PARTNERS:
+            return True
+        if name not in _G3_VIEWS or len(fn.next_functions) != 1:
+            return False
+        fn = fn.next_functions[0][0]
+    return False
+
+
+def publish_grad3(shape, device, hi, lo):
+    """Register the planes of a three-byte gradient and return the token autograd carries in its place."""
+    key = (device.type, device.index if device.index is not None else (torch.cuda.current_device() if device.type == "cuda" else 0))
+    pool = _G3_POOL.get(key)
+    if pool is None:
+        pool = _G3_POOL[key] = [torch.full((64,), float("nan"), device=device, dtype=torch.float32), 0]
+    i = pool[1]
+    pool[1] = (i + 1) % 64
+    tok = pool[0][i:i + 1].view((1,) * len(shape)).expand(shape)
+    if len(_G3) >= 64:
+        _G3.clear()
+    _G3[tok.data_ptr()] = (hi, lo, tok.numel())
+    return tok
+
+
+def grad3_of(g):
+    """(hi, lo) when g is a token of publish_grad3 (consumed), else None.  Call BEFORE anything touches g's values."""
+    if not _G3 or g.dim() == 0 or any(st != 0 for st in g.stride()):
+        return None
+    hit = _G3.pop(g.data_ptr(), None)
+    if hit is None or hit[2] != g.numel():
+        return None
+    return hit[0], hit[1]
+
+
+def grad3_decode(hi, lo):
+    """fp32 values of a three-byte gradient (slow path of a consumer that cannot take the planes: torch ops)."""
+    return ops.three_byte_to_float(hi, lo).contiguous()
 
 
 # Zeroed [M, 2] row-sum buffers for the producers of folded LayerNorms: slices of one arena that a single fill zeroes (a block needs two or
@@ -528,6 +599,7 @@ class MonaFn(torch.autograd.Function):
                 ctx.save_for_backward(x, u, t, d, keep_mask if keep_mask is not None else x.new_empty(0), *params)
             ctx.meta = (variant, hw, p_drop, seed, names, keep_mask is not None)
             ctx.direct_params = tuple(params) if direct else None
+            ctx.g3_out = dt == torch.bfloat16 and _g3_partner_feeds(x)
             return y
         u = _empty((M, D), dt, x)
         w1 = WEIGHTS.get(P["project1.weight"], dt)
@@ -553,6 +625,7 @@ class MonaFn(torch.autograd.Function):
         ctx.save_for_backward(x, u, t, d, keep_mask if keep_mask is not None else x.new_empty(0), *params)
         ctx.meta = (variant, hw, p_drop, seed, names, keep_mask is not None)
         ctx.direct_params = tuple(params) if direct else None      # the Parameter objects themselves: .grad is looked up at BACKWARD time
+        ctx.g3_out = dt == torch.bfloat16 and _g3_partner_feeds(x)
         return y
 
     @staticmethod
@@ -565,8 +638,15 @@ class MonaFn(torch.autograd.Function):
         h, w = hw
         M, dt = B * N, u.dtype
         bott = t.shape[1]
-        dy = dy.contiguous()
-        dy_t = t_copy_of(dy, dt).view(M, D)
+        g3 = grad3_of(dy)                                    # a three-byte gradient from the block behind this adapter: (T copy, low bytes)
+        fuse_du = x.is_cuda and ops.mona_pre_bwd_du_ok(M, D, bott, dt)
+        if g3 is not None and ops.is_kb(g3[0]):
+            dy, g3 = grad3_decode(*g3).view(B, N, D), None   # a K-blocked hi plane is no operand of this backward's launches: back to fp32 (torch ops; not a path the towers take)
+        if g3 is not None:
+            dy_t = g3[0].view(M, D)
+        else:
+            dy = dy.contiguous()
+            dy_t = t_copy_of(dy, dt).view(M, D)
         # Direct mode: accumulate straight into the flat-buffer .grad views (no fills, no adds, nothing returned to autograd).
         # It is an explicit opt-in of FlatAdapterOptimizer (engine.py marks its parameters), and the views are re-read HERE,
         # at backward time: if the caller dropped or replaced them in between (optimizer.zero_grad(set_to_none=True),
@@ -597,8 +677,7 @@ class MonaFn(torch.autograd.Function):
         ops.mona_spatial_bwd(variant, B, h, w, t, sp, dd, dtt, sg, p_drop=p_drop, seed=seed, keep_mask=keep_mask)
         # project1: du = dt·W1 ; dW1 = dtᵀ·u ; db1 = Σ dt
         w1t = WEIGHTS.get(P["project1.weight"], dt, transpose=True)          # [D, bott]
-        fuse_du = x.is_cuda and ops.mona_pre_bwd_du_ok(M, D, bott, dt)       # du = dt·W1 inside the row kernel below: no [M, D] round trip
-        du = None if fuse_du else _empty((M, D), dt, x)
+        du = None if fuse_du else _empty((M, D), dt, x)                      # fuse_du: du = dt·W1 inside the row kernel below, no [M, D] round trip
         if side is not None:
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -610,15 +689,24 @@ class MonaFn(torch.autograd.Function):
         if side is None:
             ops.wgrad(dtt, u, G["project1.weight"], G["project1.bias"])
         need_dx = ctx.needs_input_grad[0]
-        dx = torch.empty_like(x) if need_dx else None
         # the T copy of dx is the A operand of the preceding block's fc2 data-gradient GEMM (VitBlockFn.backward asks for it with
         # allow_kb): K-blocked when that launch runs on the ring kernels
         dx_t = _act(M, D, dt, x, 4 * D) if (need_dx and dt != torch.float32) else None
-        ops.mona_pre_bwd(du, x, dy if need_dx else None, P["norm.weight"], P["norm.bias"], P["gamma"], P["gammax"], dx, dx_t,
-                         G["gamma"], G["gammax"], G["norm.weight"], G["norm.bias"],
-                         dt_w1t=(dtt, w1t.row if isinstance(w1t, ops.PackedW) else w1t) if fuse_du else None)
-        if need_dx:
-            publish_t_copy(dx, dx_t)
+        w1t_rows = (dtt, w1t.row if isinstance(w1t, ops.PackedW) else w1t) if fuse_du else None
+        if need_dx and g3 is not None and fuse_du and getattr(ctx, "g3_out", False):
+            # three-byte in, three-byte out: dx never exists in fp32 — its T copy is the hi plane, one low byte per element beside it
+            dlo = torch.empty(M, D, device=x.device, dtype=torch.int8)
+            ops.mona_pre_bwd(None, x, g3, P["norm.weight"], P["norm.bias"], P["gamma"], P["gammax"], None, dx_t,
+                             G["gamma"], G["gammax"], G["norm.weight"], G["norm.bias"], dt_w1t=w1t_rows, dx_lo=dlo)
+            dx = publish_grad3(x.shape, x.device, dx_t, dlo)
+        else:
+            if need_dx and g3 is not None:                   # the block in front of this adapter does not take tokens: decode once, fp32 from here
+                dy = grad3_decode(*g3).view(B, N, D)
+            dx = torch.empty_like(x) if need_dx else None
+            ops.mona_pre_bwd(du, x, dy if need_dx else None, P["norm.weight"], P["norm.bias"], P["gamma"], P["gammax"], dx, dx_t,
+                             G["gamma"], G["gammax"], G["norm.weight"], G["norm.bias"], dt_w1t=w1t_rows)
+            if need_dx:
+                publish_t_copy(dx, dx_t)
         grads = tuple(None if direct else (G[k] if ctx.needs_input_grad[7 + i] else None) for i, k in enumerate(names))
         return (dx, None, None, None, None, None, None) + grads
 
@@ -741,10 +829,12 @@ class VitBlockFn(torch.autograd.Function):
             else:
                 ctx.save_for_backward(x, qkv, a.t if ctx.a_kb else a, lse, x1, pre)
             ctx.spec = spec
+            ctx.g3_out = dt == torch.bfloat16 and _g3_partner_feeds(x)
         return x2
 
     @staticmethod
     def backward(ctx, dx2):
+        g3 = grad3_of(dx2)                                            # a three-byte gradient from the adapter behind this block: (T copy, possibly K-blocked; low bytes)
         if ctx.r3:
             x, qkv, a, lse, h1, pre, lo1 = ctx.saved_tensors
             x1 = (ops.KBlocked(h1) if ctx.h1_kb else h1, lo1)         # three-byte x1: (hi plane, low bytes)
@@ -756,25 +846,31 @@ class VitBlockFn(torch.autograd.Function):
         B, N, D = x.shape
         M, dt = B * N, qkv.dtype
         F = pre.shape[1]
-        dx2 = dx2.contiguous()
-        dx2_t = t_copy_of(dx2, dt, allow_kb=True)
-        if not ops.is_kb(dx2_t):
-            dx2_t = dx2_t.view(M, D)
+        if g3 is not None:
+            dx2_t = g3[0] if ops.is_kb(g3[0]) else g3[0].view(M, D)
+            dres2 = (dx2_t, g3[1])
+        else:
+            dx2 = dx2.contiguous()
+            dx2_t = t_copy_of(dx2, dt, allow_kb=True)
+            if not ops.is_kb(dx2_t):
+                dx2_t = dx2_t.view(M, D)
+            dres2 = dx2.view(M, D)
+        g3_mode = g3 is not None or getattr(ctx, "g3_out", False)     # three-byte at either end: dx1, which never leaves the block, travels that way too
         # fc2 dgrad fused with act'(pre)
         dpre = _act(M, F, dt, x, D)                       # read by the fc1 dgrad GEMM only
         ops.gemm(dx2_t, WEIGHTS.get(spec.fc2[0], dt, transpose=True), dact=spec.act, aux_in=pre, out_t=dpre)
         dh = _empty((M, D), dt, x)
         ops.gemm(dpre, WEIGHTS.get(spec.fc1[0], dt, transpose=True), out_t=dh)
         del dpre
-        if ctx.r3:                                                   # dx1 never leaves the block either: (T copy, low bytes), 3 bytes written instead of 4 + 2
+        if ctx.r3 or g3_mode:                                        # dx1 never leaves the block either: (T copy, low bytes), 3 bytes written instead of 4 + 2
             dx1_t = _empty((M, D), dt, x)
             dlo1 = torch.empty(M, D, device=x.device, dtype=torch.int8)
-            ops.layernorm_bwd(dh, x1, spec.ln2[0], spec.eps, dres=dx2.view(M, D), dx_t=dx1_t, dx_lo=dlo1)
+            ops.layernorm_bwd(dh, x1, spec.ln2[0], spec.eps, dres=dres2, dx_t=dx1_t, dx_lo=dlo1)
             dx1 = (dx1_t, dlo1)
         else:
             dx1 = torch.empty_like(x1)
             dx1_t = _empty((M, D), dt, x) if dt != torch.float32 else dx1
-            ops.layernorm_bwd(dh, x1, spec.ln2[0], spec.eps, dres=dx2.view(M, D), dx32=dx1, dx_t=dx1_t if dt != torch.float32 else None)
+            ops.layernorm_bwd(dh, x1, spec.ln2[0], spec.eps, dres=dres2, dx32=dx1, dx_t=dx1_t if dt != torch.float32 else None)
         da = dh                                                                     # reuse
         ops.gemm(dx1_t, WEIGHTS.get(spec.proj[0], dt, transpose=True), out_t=da)
         dqkv = _attn_act(M, 3 * D, dt, x, D) if D == 64 * spec.heads else _empty((M, 3 * D), dt, x)   # read by the QKV dgrad GEMM only
@@ -783,8 +879,12 @@ class VitBlockFn(torch.autograd.Function):
         else:
             ops.attn_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], a, da, lse, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], B, spec.heads, N, mask=spec.mask)
         ops.gemm(dqkv, WEIGHTS.get(spec.qkv[0], dt, transpose=True), out_t=da)       # dh1 into the same buffer
-        dx = torch.empty_like(x)
         dx_t = _empty((M, D), dt, x) if dt != torch.float32 else None
+        if getattr(ctx, "g3_out", False):
+            dlo = torch.empty(M, D, device=x.device, dtype=torch.int8)
+            ops.layernorm_bwd(da, x.view(M, D), spec.ln1[0], spec.eps, dres=dx1, dx_t=dx_t, dx_lo=dlo)
+            return publish_grad3(x.shape, x.device, dx_t, dlo), None
+        dx = torch.empty_like(x)
         ops.layernorm_bwd(da, x.view(M, D), spec.ln1[0], spec.eps, dres=dx1, dx32=dx.view(M, D), dx_t=dx_t)
         publish_t_copy(dx, dx_t)
         return dx, None

@@ -813,17 +813,22 @@ def layernorm_bwd(dy, x, gamma, eps, dres=None, dx32=None, dx_t=None, rows=None,
     if isinstance(x, tuple) or isinstance(dres, tuple) or dx_lo is not None:
         x_hi, x_lo = x if isinstance(x, tuple) else (None, None)
         r_hi, r_lo = dres if isinstance(dres, tuple) else (None, None)
-        x_kb = 0
+        x_kb = r_kb = 0
         if is_kb(x_hi):
             kr, kc, x_kb = _kb_dims(x_hi, "layernorm_bwd x hi plane")
             if kr < rows or kc != D:
                 raise UiaError(f"layernorm_bwd: K-blocked x hi plane {tuple(x_hi.t.shape)} does not hold [{rows}, {D}]")
             x_hi = x_hi.t
+        if is_kb(r_hi):
+            kr, kc, r_kb = _kb_dims(r_hi, "layernorm_bwd dres hi plane")
+            if kr < rows or kc != D:
+                raise UiaError(f"layernorm_bwd: K-blocked dres hi plane {tuple(r_hi.t.shape)} does not hold [{rows}, {D}]")
+            r_hi = r_hi.t
         for name, t, dt_ in (("x hi", x_hi, torch.bfloat16), ("x lo", x_lo, torch.int8), ("dres hi", r_hi, torch.bfloat16), ("dres lo", r_lo, torch.int8), ("dx_lo", dx_lo, torch.int8)):
             if t is not None and (t.dtype != dt_ or not t.is_contiguous() or t.numel() < rows * D):
                 raise UiaError(f"layernorm_bwd: {name} plane must be a contiguous {dt_} tensor of at least [{rows}, {D}], got {tuple(t.shape)} {t.dtype}")
         check(lib().uia_layernorm_bwd3(_stream(), _code(dy.dtype), rows, D, ldx, _p(dy), None if isinstance(x, tuple) else _p(x), _p(x_hi), _p(x_lo), x_kb, _p(gamma), eps,
-                                       None if isinstance(dres, tuple) else _p(dres), _p(r_hi), _p(r_lo), _p(dx32), _p(dx_t), _p(dx_lo)), "uia_layernorm_bwd3")
+                                       None if isinstance(dres, tuple) else _p(dres), _p(r_hi), _p(r_lo), r_kb, _p(dx32), _p(dx_t), _p(dx_lo)), "uia_layernorm_bwd3")
         return
     check(lib().uia_layernorm_bwd(_stream(), _code(dy.dtype), rows, D, ldx, _p(dy), _p(x), _p(gamma), eps, _p(dres), _p(dx32), _p(dx_t)), "uia_layernorm_bwd")
 
@@ -931,8 +936,10 @@ def mona_pre_bwd_du_ok(M, D, bott, dt):
     return MONA_PRE_BWD_DU and dt == torch.bfloat16 and bott == 64 and D % 64 == 0 and 512 < D <= 768
 
 
-def mona_pre_bwd(du, x, dy, norm_w, norm_b, gamma, gammax, dx32, dx_t, g_gamma, g_gammax, g_norm_w, g_norm_b, eps=1e-5, dt_w1t=None):
-    """dt_w1t = (dt [M, 64], W1ᵀ [D, 64]) instead of du: project1's data gradient du = dt·W1 is computed inside the launch (uia_mona_pre_bwd_du)."""
+def mona_pre_bwd(du, x, dy, norm_w, norm_b, gamma, gammax, dx32, dx_t, g_gamma, g_gammax, g_norm_w, g_norm_b, eps=1e-5, dt_w1t=None, dx_lo=None):
+    """dt_w1t = (dt [M, 64], W1ᵀ [D, 64]) instead of du: project1's data gradient du = dt·W1 is computed inside the launch (uia_mona_pre_bwd_du).
+    Three-byte residual gradients (uia_mona_pre_bwd_du3, with dt_w1t only): dy = (hi bf16 [M, D] row-major, lo int8 [M, D]) and dx_lo = int8 [M, D] — the result
+    is then (dx_t, dx_lo) and dx32 must be None."""
     D = gamma.numel()
     M = x.numel() // D
     ws = torch.empty(lib().uia_mona_pre_bwd_workspace_bytes(M, D) // 4, device=x.device, dtype=torch.float32)
@@ -946,6 +953,17 @@ def mona_pre_bwd(du, x, dy, norm_w, norm_b, gamma, gammax, dx32, dx_t, g_gamma, 
         dtt, w1t = dt_w1t
         if dtt.dtype != torch.bfloat16 or w1t.dtype != torch.bfloat16 or tuple(dtt.shape) != (M, 64) or tuple(w1t.shape) != (D, 64):
             raise UiaError(f"mona_pre_bwd: dt {tuple(dtt.shape)} {dtt.dtype} / W1ᵀ {tuple(w1t.shape)} {w1t.dtype} must be bf16 [{M}, 64] / [{D}, 64]")
+        if isinstance(dy, tuple) or dx_lo is not None:
+            if not (isinstance(dy, tuple) and dx_lo is not None and dx32 is None and dx_t is not None):
+                raise UiaError("mona_pre_bwd: three-byte residual gradients need dy = (hi, lo), dx_lo and dx_t, and no dx32")
+            hi, lo = dy
+            for name, t_, dt_ in (("dy hi", hi, torch.bfloat16), ("dy lo", lo, torch.int8), ("dx_lo", dx_lo, torch.int8), ("dx_t", dx_t, torch.bfloat16)):
+                if t_.dtype != dt_ or not t_.is_contiguous() or t_.numel() < M * D:
+                    raise UiaError(f"mona_pre_bwd: {name} plane must be a contiguous {dt_} tensor of at least [{M}, {D}], got {tuple(t_.shape)} {t_.dtype}")
+            check(lib().uia_mona_pre_bwd_du3(_stream(), _code(dtt.dtype), M, D, _p(dtt), _rowmajor(dtt, "dt"), _p(w1t), _rowmajor(w1t, "w1t"), _p(x), _p(hi), _p(lo), _p(norm_w),
+                                             _p(norm_b), _p(gamma), _p(gammax), eps, _p(dx_t), _p(dx_lo), _p(g_gamma), _p(g_gammax), _p(g_norm_w), _p(g_norm_b), _p(ws),
+                                             kb_rows), "uia_mona_pre_bwd_du3")
+            return
         check(lib().uia_mona_pre_bwd_du(_stream(), _code(dtt.dtype), M, D, _p(dtt), _rowmajor(dtt, "dt"), _p(w1t), _rowmajor(w1t, "w1t"), _p(x), _p(dy), _p(norm_w),
                                         _p(norm_b), _p(gamma), _p(gammax), eps, _p(dx32), _p(dx_t), _p(g_gamma), _p(g_gammax), _p(g_norm_w), _p(g_norm_b), _p(ws),
                                         kb_rows), "uia_mona_pre_bwd_du")

@@ -289,3 +289,46 @@ def test_committed_traffic_file_names_the_kernels_the_headline_step_runs():
     # the kernel bench.py names as dominant must be there under the name bench.py derives
     dom = ops.gemm_kernel_name(8, headline[0], torch.bfloat16)[1]
     assert dom in data["FETCH_SIZE"] and dom in data["WRITE_SIZE"]
+
+
+def test_three_byte_gradient_tokens_travel_through_views_and_poison_other_readers():
+    """functional.publish_grad3 / grad3_of: the token autograd carries for a three-byte residual gradient is one NaN expanded to the gradient's shape — found again by
+    address behind any chain of views, consumed by the first lookup, and NaN to every reader that is not one of the two Functions (a topology the hand-off does not cover
+    fails loudly).  _g3_partner_feeds only accepts a MonaFn / VitBlockFn output seen through view nodes."""
+    import torch
+    from uia_hip import functional as UF
+    UF.clear_t_copies()
+    hi, lo = torch.zeros(6, 4, dtype=torch.bfloat16), torch.zeros(6, 4, dtype=torch.int8)
+    tok = UF.publish_grad3((2, 3, 4), torch.device("cpu"), hi, lo)
+    assert tuple(tok.shape) == (2, 3, 4) and tok.stride() == (0, 0, 0) and bool(torch.isnan(tok).all())
+    seen = tok.permute(1, 0, 2).permute(1, 0, 2)
+    assert UF.grad3_of(torch.zeros(2, 3, 4)) is None                      # an ordinary gradient
+    got = UF.grad3_of(seen)
+    assert got is not None and got[0] is hi and got[1] is lo
+    assert UF.grad3_of(seen) is None                                      # consumed
+    tok2 = UF.publish_grad3((2, 3, 4), torch.device("cpu"), hi, lo)
+    assert tok2.data_ptr() != tok.data_ptr()                              # consecutive hand-offs do not share an address
+    assert bool(torch.isnan(tok2 + 1.0).all())
+    UF.clear_t_copies()
+    assert UF.grad3_of(tok2) is None
+
+    class VitBlockFn(torch.autograd.Function):                           # same class name as the product's Function: its backward node is "VitBlockFnBackward"
+        @staticmethod
+        def forward(ctx, x):
+            return x * 2
+
+        @staticmethod
+        def backward(ctx, g):
+            return g * 2
+
+    x = torch.randn(2, 3, 4, requires_grad=True)
+    y = VitBlockFn.apply(x)
+    UF.set_grad_resid3(True)
+    try:
+        assert UF._g3_partner_feeds(y.permute(1, 0, 2).permute(1, 0, 2))
+        assert not UF._g3_partner_feeds(y + 0.0)                          # arithmetic in between would read the token
+        assert not UF._g3_partner_feeds(x)
+        UF.set_grad_resid3(False)
+        assert not UF._g3_partner_feeds(y)
+    finally:
+        UF.set_grad_resid3(False)

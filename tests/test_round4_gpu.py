@@ -161,6 +161,7 @@ def test_parity_at_a_quarter_of_the_benchmark_batch_vs_oracle():
     assert abs(r["loss"] - r["loss_ref"]) < 2e-3 * max(1.0, abs(r["loss_ref"])), r
     assert r["grad_cosine"] > 0.99 and r["grad_rel_l2"] < 0.15, r
     assert not r["ln_fold_guard_tripped"]
+    assert r["grad_resid3"]                       # the step ran as engine.contrastive_step runs it: three-byte residual gradients between the backward Functions
 
 
 def test_clipseg_prompt_features_cache_hits_and_invalidates():
@@ -567,6 +568,115 @@ def test_mona_pre_bwd_with_the_k64_data_gradient_inside_equals_the_two_launches(
     assert not torch.isnan(dx1).any() and torch.equal(dx0, dx1) and torch.equal(t0, t1)
     for a, b in zip(G0, G1):
         assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max() + 1e-12)
+
+
+@pytest.mark.parametrize("M,kb", [(50432, True), (4100, False), (37, False)])
+def test_mona_pre_bwd_on_three_byte_residual_gradients(M, kb):
+    """uia_mona_pre_bwd_du3: dy arrives as (bf16 hi plane, low bytes), dx leaves as (T copy — row-major or K-blocked —, low bytes).  Against uia_mona_pre_bwd_du on the
+    decoded dy: the reconstructed dx within 2^-14 of the fp32 result, the T copy the bf16 rounding of it, the parameter gradients up to their sum order."""
+    from uia_hip import ops
+    g = torch.Generator(device="cpu").manual_seed(M + 1)
+    D, dt = 768, torch.bfloat16
+    x = torch.randn(M, D, generator=g).to(dev()) * 1.5 + 0.3
+    dy = torch.randn(M, D, generator=g).to(dev())
+    dyh, dyl = ops.float_to_three_byte(dy)
+    dy3 = ops.three_byte_to_float(dyh, dyl).contiguous()
+    dtt = torch.randn(M, 64, generator=g).to(dev()).to(dt)
+    w1t = (torch.randn(64, D, generator=g) * 0.05).to(dev()).t().contiguous().to(dt)
+    nw, nb = (1 + 0.1 * torch.randn(D, generator=g)).to(dev()), (0.1 * torch.randn(D, generator=g)).to(dev())
+    gam, gamx = (0.5 * torch.randn(D, generator=g)).to(dev()), (1 + 0.1 * torch.randn(D, generator=g)).to(dev())
+    kb = kb and M > 2048
+    new_t = lambda: ops.kb_empty(M, D, dt, dev()) if kb else torch.full((M, D), float("nan"), device=dev(), dtype=dt)
+    dx0, t0, G0 = torch.empty(M, D, device=dev()), new_t(), [torch.zeros(D, device=dev()) for _ in range(4)]
+    ops.mona_pre_bwd(None, x, dy3, nw, nb, gam, gamx, dx0, t0, *G0, dt_w1t=(dtt, w1t))
+    t1, lo1, G1 = new_t(), torch.full((M, D), 99, device=dev(), dtype=torch.int8), [torch.zeros(D, device=dev()) for _ in range(4)]
+    ops.mona_pre_bwd(None, x, (dyh, dyl), nw, nb, gam, gamx, None, t1, *G1, dt_w1t=(dtt, w1t), dx_lo=lo1)
+    torch.cuda.synchronize()
+    got = ops.three_byte_to_float(t1, lo1)
+    assert float(((got - dx0).abs() / dx0.abs().clamp_min(1e-3)).max()) < 2.0 ** -14
+    # the hi plane IS the T copy: the bf16 rounding of the value it stands for, and — up to the last fp32 bit of two differently contracted instantiations — the fp32 form's copy
+    rows = lambda t: t.t.permute(1, 0, 2).reshape(t.rows, t.cols)[:M] if kb else t
+    assert torch.equal(rows(t1), got.bfloat16())
+    assert float((rows(t1) != rows(t0)).float().mean()) < 1e-3
+    for a, b in zip(G0, G1):
+        assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max() + 1e-12)
+    with pytest.raises(Exception):                                            # three-byte in without three-byte out is not a form the kernel has
+        ops.mona_pre_bwd(None, x, (dyh, dyl), nw, nb, gam, gamx, dx0, t1, *G1, dt_w1t=(dtt, w1t))
+
+
+def test_layernorm_bwd_takes_a_k_blocked_residual_gradient_plane():
+    """uia_layernorm_bwd3 with dres_kb_rows: the hi plane of the residual gradient is the K-blocked T copy the Mona backward left for the fc2 data-gradient GEMM."""
+    from uia_hip import ops
+    torch.manual_seed(21)
+    M, D = 4100, 768
+    x = torch.randn(M, D, device=dev()) * 2 + 0.3
+    dy = torch.randn(M, D, device=dev()).bfloat16()
+    gamma = torch.randn(D, device=dev())
+    rh, rl = ops.float_to_three_byte(torch.randn(M, D, device=dev()))
+    out = []
+    for hi in (rh, _kb(rh)):
+        dxt, dlo = torch.empty(M, D, device=dev(), dtype=torch.bfloat16), torch.empty(M, D, device=dev(), dtype=torch.int8)
+        ops.layernorm_bwd(dy, x, gamma, 1e-6, dres=(hi, rl), dx_t=dxt, dx_lo=dlo)
+        out.append((dxt, dlo))
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+
+
+def test_three_byte_residual_gradients_between_the_backward_functions():
+    """engine.GRAD_RESID3 / UF.set_grad_resid3: between MonaFn.backward and VitBlockFn.backward the residual gradient travels as (T copy, low bytes) under a NaN token
+    instead of fp32 + T copy.  ViT-B/16 + Mona at 12 images (2364 rows: the ring kernels and their K-blocked copies): the adapter gradients against the fp32 hand-off
+    (16 stored mantissa bits against 24 on a stream every GEMM reads in bf16 anyway), tokens actually used, nothing non-finite."""
+    import contextlib, io
+    from uia_hip import functional as UF
+    from src.adapters import inject_mona_variant_to_open_clip
+    from src.losses import InfoNCELoss
+    from src.third_party.biomedclip.model import create_biomedclip
+    model = create_biomedclip(seed=3)
+    for p in model.parameters():
+        p.requires_grad_(False)
+    with contextlib.redirect_stdout(io.StringIO()):
+        inject_mona_variant_to_open_clip(model, variant="freq_enhanced", bottleneck_dim=64)
+    g = torch.Generator().manual_seed(4)
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            if "mona" in k:
+                p.copy_((1.0 if k.endswith(("norm.weight", "gammax", "freq_filter")) else 0.0) + 0.05 * torch.randn(p.shape, generator=g))
+    for k, p in model.named_parameters():
+        p.requires_grad_("mona" in k)
+    model = model.to(dev()).train()
+    images = torch.rand(12, 3, 224, 224, generator=g).to(dev())
+    ids = torch.randint(4, 3000, (12, 256), generator=g)
+    ids[:, 40:] = 0
+    ids = ids.to(dev())
+    made = []
+    publish = UF.publish_grad3
+
+    def counting(*a, **k):
+        made.append(1)
+        return publish(*a, **k)
+
+    def run(flag):
+        UF.set_compute_dtype(torch.bfloat16)
+        UF.set_grad_resid3(flag)
+        UF.set_dropout_seed(7)
+        for p in model.parameters():
+            p.grad = None
+        fi, ft = model.encode_image(images), model.encode_text(ids)
+        InfoNCELoss(0.07)(fi, ft).backward()
+        UF.clear_t_copies()
+        return torch.cat([p.grad.flatten() for p in model.parameters() if p.requires_grad]).clone()
+
+    UF.publish_grad3 = counting
+    try:
+        g0 = run(False)
+        n0 = len(made)
+        g1 = run(True)
+    finally:
+        UF.publish_grad3 = publish
+        UF.set_grad_resid3(False)
+    assert n0 == 0 and len(made) >= 20                                     # 11 adapters + 11 blocks hand a token on (the last adapter gets fp32 from the head, the first block returns nothing)
+    assert bool(torch.isfinite(g1).all())
+    assert float(torch.nn.functional.cosine_similarity(g1, g0, dim=0)) > 0.9995
+    assert float((g1 - g0).norm() / g0.norm()) < 3e-2
 
 
 @pytest.mark.parametrize("M", [50432, 1000, 37])

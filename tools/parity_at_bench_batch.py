@@ -133,6 +133,9 @@ def run_case(B, variant, stress, chunk, threads, adapters="scaled"):
 
     dev = torch.device("cuda", 0)
     model = model.to(dev)
+    from uia_hip import engine
+    g3 = engine.GRAD_RESID3 and engine._hook_free(model)                  # what engine.contrastive_step (and bench.py) run with: three-byte residual gradients between the backward Functions
+    UF.set_grad_resid3(g3)
     with warnings.catch_warnings(record=True) as wlist:
         warnings.simplefilter("always")
         fi = model.encode_image(images.to(dev))
@@ -153,7 +156,7 @@ def run_case(B, variant, stress, chunk, threads, adapters="scaled"):
            "logits_spread_ref": float(lgr.max() - lgr.min()), "loss": float(loss), "loss_ref": lref,
            "grad_cosine": float(torch.dot(got, want) / (got.norm() * want.norm())), "grad_rel_l2": float((got - want).norm() / want.norm()),
            "grad_median_per_tensor_rel": sorted(per.values())[len(per) // 2], "grad_worst_per_tensor_rel": per[worst], "grad_worst_tensor": worst,
-           "ln_fold_guard_tripped": fold_tripped, "warnings": [str(w.message)[:120] for w in wlist if "uia_hip" in str(w.message)],
+           "grad_resid3": bool(g3), "ln_fold_guard_tripped": fold_tripped, "warnings": [str(w.message)[:120] for w in wlist if "uia_hip" in str(w.message)],
            "oracle_cpu_seconds": round(cpu_s, 1), "oracle_threads": threads}
     if fold_tripped:                                                      # what the guard buys: the same step on the stand-alone LayerNorm kernels
         UF.clear_t_copies()
