@@ -83,6 +83,7 @@ def parse():
     ap.add_argument("--short-k-half-bytes", type=int, default=-1, help="experiment knob: the longest K row in bytes the --short-k-half-n rule applies to (-1 = the library default)")
     ap.add_argument("--short-k-half-no-stash", action="store_true", help="experiment knob: the --short-k-half-n rule skips launches with an aux_out stash")
     ap.add_argument("--half-height-short-k-always", action="store_true", help="experiment knob: N <= 768, K <= 768 launches on half-height tiles also without a ragged last round")
+    ap.add_argument("--image-split", type=float, default=-1.0, help="scheduling knob: the image tower as two slices (this fraction of the images, the rest) on two HIP streams beside the text tower's; 0 = one slice, -1 = the engine's default")
     ap.add_argument("--no-grad-resid3", action="store_true", help="A/B: the residual gradient between the image tower's backward Functions as fp32 + bf16 copy (rounds 1-3) instead of a three-byte tensor")
     ap.add_argument("--no-lora-rank3", action="store_true", help="A/B: the q | k | v rank terms of a LoRA block's data gradient as three K = 64 launches instead of one uia_lora_rank_update pass")
     ap.add_argument("--no-lora-kext", action="store_true", help="A/B knob: the LoRA rank update as a launch of its own (tile cfg 23) instead of inside the frozen GEMM's K loop")
@@ -392,6 +393,8 @@ def main():
     UF.set_text_resid3(not args.no_text_resid3)
     from uia_hip import engine as _engine
     _engine.GRAD_RESID3 = not args.no_grad_resid3
+    if args.image_split >= 0:
+        _engine.IMAGE_SPLIT = args.image_split
     UF.set_block_resid3(args.block_resid3)
     ops.PERSIST_STORE_ONLY = args.persist_store_only
     ops.TILE_GROUP = {int(k): int(v) for k, v in (kv.split("=") for kv in args.tile_group.split(",") if kv)}
@@ -437,6 +440,11 @@ def secondary_lines(args, device):
         except Exception as e:                      # a secondary line must never cost the headline
             lines[cfg] = {"error": f"{type(e).__name__}: {e}"}
     return lines
+
+
+def _image_split_on(args):
+    from uia_hip import engine
+    return 0 < int(round(args.batch * engine.IMAGE_SPLIT)) < args.batch and args.batch >= 32
 
 
 def bench_mona(args, rank, world, device):
@@ -531,8 +539,9 @@ def bench_mona(args, rank, world, device):
                                   "InfoNCE, clip+AdamW; random-init weights",
                       "mona_variant": args.variant, "batch_per_gpu": args.batch, "global_batch": args.batch * world, "image": "3x224x224",
                       "text_len": 256, "text_positions_computed": "valid tokens only (opt-in --unpad-text)" if args.unpad_text else "all 256",
-                      "parallelism": f"dp{world}", "text_tower_stream": ("second HIP stream beside the image tower (the entry points' default); roofline from one extra step with both towers on one stream"
+                      "parallelism": f"dp{world}", "text_tower_stream": ("second HIP stream beside the image tower, whose two half-batch slices run on two streams (engine.IMAGE_SPLIT; the entry points' default); roofline from one extra step with everything on one stream"
                                             if args.overlap_text else "same stream"),
+                      "image_tower_slices": (2 if (args.overlap_text and args.streams == 1 and _image_split_on(args)) else 1),
                       "hip_streams": (f"{args.streams}: the batch's towers run as {args.streams} slices on {args.streams} HIP streams, one InfoNCE over all pairs" if args.streams > 1 else 1),
                       "contrastive_batch": "global (opt-in)" if args.global_loss else "per-rank (reference-equivalent)", "mona_dropout": 0.1,
                       "bert_dropout_emulated": False,

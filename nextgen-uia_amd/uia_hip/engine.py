@@ -265,7 +265,10 @@ def _hook_free(model):
     return ok
 
 
-def contrastive_step(model, criterion, opt, images, ids, micro_batches=1, lr=None, overlap_text=True, global_loss=False, streams=1):
+IMAGE_SPLIT = 0.5       # fraction of a micro-batch's images that form the FIRST of two image-tower slices on two streams (0 = one slice); see contrastive_step.  A/B: bench.py --image-split 0
+
+
+def contrastive_step(model, criterion, opt, images, ids, micro_batches=1, lr=None, overlap_text=True, global_loss=False, streams=1, image_split=None):
     """One optimiser update: encode → InfoNCE → backward (→ all-reduce) → clip+AdamW.  Returns the loss tensor (device).
 
     global_loss (opt-in, not the reference's semantics): the InfoNCE batch is the GLOBAL batch — features are all-gathered,
@@ -287,6 +290,8 @@ def contrastive_step(model, criterion, opt, images, ids, micro_batches=1, lr=Non
     opt.zero_grad()
     total = None
     mb = images.shape[0] // micro_batches
+    if image_split is None:
+        image_split = int(round(mb * IMAGE_SPLIT)) if mb >= 32 else 0
     cur = torch.cuda.current_stream()
     for i in range(micro_batches):
         im, tk = images[i * mb:(i + 1) * mb], ids[i * mb:(i + 1) * mb]
@@ -304,6 +309,26 @@ def contrastive_step(model, criterion, opt, images, ids, micro_batches=1, lr=Non
                 a.record_stream(cur)
                 b.record_stream(cur)
             fi, ft = torch.cat(fis, 0), torch.cat(fts, 0)
+        elif overlap_text and 0 < image_split < mb:
+            # round 4: the image tower as TWO slices on two streams, the text tower whole on a third.  Every kernel of the tower is per row, per image or per
+            # (image, head), so the slices are independent chains; a chain of dependent launches leaves CUs idle at every ragged last round and M tail (the
+            # backward has no text tower beside it to fill them), two chains fill each other's.  One InfoNCE over all pairs, as with streams = S; same loss and
+            # gradients (the weight gradients meet through the same float atomics).  Halves measured best (41.43 -> 40.78 ms; 0.86 / 0.14 — a first slice of whole
+            # 256-tile rounds — 41.09, thirds 41.16); slicing the text tower as well (streams = 3) is slower: its 768-tile launches are whole rounds already.
+            side = _side_stream(images.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                ft = model.encode_text(tk)
+            s2 = _mb_streams(images.device, 1)[0]
+            s2.wait_stream(cur)
+            with torch.cuda.stream(s2):
+                f2 = model.encode_image(im[image_split:])
+            f1 = model.encode_image(im[:image_split])
+            cur.wait_stream(s2)
+            f2.record_stream(cur)
+            fi = torch.cat([f1, f2], 0)
+            cur.wait_stream(side)
+            ft.record_stream(cur)
         elif overlap_text:
             side = _side_stream(images.device)
             side.wait_stream(cur)
@@ -320,6 +345,8 @@ def contrastive_step(model, criterion, opt, images, ids, micro_batches=1, lr=Non
             fi, ft = GatherFeaturesFn.apply(fi, rank, opt.world), GatherFeaturesFn.apply(ft, rank, opt.world)
         loss = criterion(fi, ft)
         (loss / micro_batches).backward()
+        if overlap_text and 0 < image_split < mb and not (streams > 1 and mb >= 2 * streams):
+            cur.wait_stream(_mb_streams(images.device, 1)[0])
         if streams > 1 and mb >= 2 * streams:
             for st in _mb_streams(images.device, streams):     # the adapters' weight gradients are side effects of the backward kernels (flat
                 cur.wait_stream(st)                            # buffer, direct mode): autograd's own end-of-backward sync does not know them

@@ -807,3 +807,29 @@ def test_cold_weight_cache_filled_on_one_stream_is_safe_to_read_from_another():
             ops.gemm(a_t, hit, out_t=out)
         torch.cuda.synchronize()
         assert not torch.isnan(out.float()).any() and rel(out, ref) < 1e-2
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_contrastive_step_with_the_image_tower_in_two_slices_equals_one_slice(mode):
+    """engine.contrastive_step(image_split=k) (engine.IMAGE_SPLIT, the default above 32 images): the image tower runs as two slices on two HIP streams beside the text
+    tower's stream, forward and backward; the loss is still one InfoNCE over all pairs — same loss, same gradients (float atomics reorder the weight-gradient sums)."""
+    from uia_hip import functional as UF
+    from uia_hip.engine import FlatAdapterOptimizer, contrastive_step
+    from src.losses import InfoNCELoss
+    from tests.test_round2_gpu import _toy_batch, _toy_model
+    UF.set_compute_dtype(torch.float32 if mode == "fp32" else torch.bfloat16)
+    images, ids = _toy_batch(23, B=8)
+    outs = []
+    for split in (0, 3):
+        model = _toy_model("hybrid", seed=13).to(dev())
+        opt = FlatAdapterOptimizer([(k, p) for k, p in model.named_parameters() if p.requires_grad], lr=1e-3)
+        UF.set_dropout_seed(7)
+        loss = contrastive_step(model, InfoNCELoss(0.07), opt, images.to(dev()), ids.to(dev()), overlap_text=True, image_split=split)
+        torch.cuda.synchronize()
+        outs.append((float(loss), opt.g.clone(), opt.grad_norm()))
+    UF.set_compute_dtype(torch.bfloat16)
+    tol = 1e-5 if mode == "fp32" else 2e-2
+    assert abs(outs[0][0] - outs[1][0]) < tol * max(1.0, abs(outs[0][0]))
+    g1, g2 = outs[0][1], outs[1][1]
+    assert float((g1 - g2).norm() / g1.norm()) < (1e-4 if mode == "fp32" else 5e-2), float((g1 - g2).norm() / g1.norm())
+    assert abs(outs[0][2] - outs[1][2]) < (1e-4 if mode == "fp32" else 5e-2) * outs[0][2]
