@@ -292,6 +292,7 @@ def contrastive_step(model, criterion, opt, images, ids, micro_batches=1, lr=Non
     mb = images.shape[0] // micro_batches
     if image_split is None:
         image_split = int(round(mb * IMAGE_SPLIT)) if mb >= 32 else 0
+    ops.CHAINS = 3 if (overlap_text and 0 < image_split < mb and not (streams > 1 and mb >= 2 * streams)) else 1      # forward AND backward of this step (ops.gemm's tail policy)
     cur = torch.cuda.current_stream()
     for i in range(micro_batches):
         im, tk = images[i * mb:(i + 1) * mb], ids[i * mb:(i + 1) * mb]
@@ -351,6 +352,7 @@ def contrastive_step(model, criterion, opt, images, ids, micro_batches=1, lr=Non
             for st in _mb_streams(images.device, streams):     # the adapters' weight gradients are side effects of the backward kernels (flat
                 cur.wait_stream(st)                            # buffer, direct mode): autograd's own end-of-backward sync does not know them
         total = loss.detach() if total is None else total + loss.detach()
+    ops.CHAINS = 1
     opt.all_reduce()
     opt.step(lr=lr, grad_scale=dp_grad_scale(opt.world, global_loss))
     return total / micro_batches

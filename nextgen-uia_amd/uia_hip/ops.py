@@ -76,6 +76,7 @@ SHORT_K_WIDE_HALF_BYTES = 2048   # ... and the longest K row (bytes) it applies 
 SHORT_K_WIDE_HALF_N = 3072   # N at and above which a short-K (K row <= SHORT_K_WIDE_HALF_BYTES) bf16 launch runs wholly on half-height tiles, two workgroups per CU (cfg 14); 0 = off (bench.py --short-k-half-n)
 HALF_HEIGHT_SHORT_K_ALWAYS = False   # experiment knob: ... also when the 256-row tiling has no ragged last round (the text tower's N = 768, K = 768 sums at 65 536 rows)
 HALF_HEIGHT_SHORT_K = True   # N <= 768, K <= 768 (bf16) launches whose 256-row tiling leaves a ragged last round run on half-height tiles (cfg 14) in one launch
+CHAINS = 1               # independent chains of launches the caller has in flight on different streams (engine.contrastive_step sets it for the step): > 1 relaxes TAIL_SPLIT
 TAIL_SPLIT = True        # split off the M tail of a launch whose last round of 256x256 tiles would leave most CUs idle
 TAIL_SIDE_STREAM = True  # a SMALL M tail (at most a quarter of the CUs' worth of half-height tiles) runs on a side stream beside the main launch instead of behind it
 MONA_PRE_FWD_T = True    # Mona forward: project1 (768 -> 64) inside the pre-norm row kernel (uia_mona_pre_fwd_t) instead of the N = 64 stream launch reading u back
@@ -490,12 +491,17 @@ def gemm(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None, res
             # nothing overlaps (profiles/r04_d); on half-height tiles two workgroups share a CU and one's seam runs beside the other's K loop:
             # 385 -> 338 us at M = 65 536, 266 -> 252 at 50 432 in isolation (bias + GELU store), level at N = 2304
             tile_cfg, m_main = 14, M
-        if (m_main < M or HALF_HEIGHT_SHORT_K_ALWAYS) and HALF_HEIGHT_SHORT_K and N <= 768 and Ka * a.element_size() <= 1536:
+        if (m_main < M or HALF_HEIGHT_SHORT_K_ALWAYS) and HALF_HEIGHT_SHORT_K and CHAINS <= 1 and N <= 768 and Ka * a.element_size() <= 1536:      # (with other chains beside it a ragged round costs nothing: 40.99 -> 40.73 ms without this rule there)
             # short K loops with a ragged last round (the image tower's output projection and its data gradient: 591 tiles on 256 CUs): the whole
             # launch on half-height tiles, two workgroups per CU (tile cfg 14), instead of a main launch + a half-height tail launch — 1182 half
             # tiles pack 2.31 rounds of 512, and one workgroup's epilogue runs beside its neighbour's K loop (round 3, isolated: 64 vs 62 + 21 us
             # for the plain data gradient, 92 vs 102 us per 43 520 rows for the fp32-residual producer).  Longer K loops lose on it.
             tile_cfg, m_main = 14, M
+        if m_main < M and CHAINS > 1 and not small_tail(M - m_main, N, num_cus(a.device.index)):
+            # several independent chains of launches share the chip (engine.contrastive_step: the image tower in two slices beside the text tower): a ragged last
+            # round is filled by the other chains' workgroups, and a tail launch BEHIND the main one only adds a launch (40.87 -> 40.70 ms).  Small tails still
+            # fork to the side stream: without that split the ViT-L/14 + LoRA step loses 2.4 ms (a handful of tiles as a whole extra round).
+            m_main = M
         if m_main < M:
             cut = lambda t, lo, hi: None if t is None else (t.row_range(lo, hi) if is_kb(t) else t[lo:hi])
             slices = tail_k_slices(M - m_main, N, Ka, a.element_size(), num_cus(a.device.index))

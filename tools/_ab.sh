@@ -1,12 +1,9 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-for i in 1 2 3; do
-  echo "default      $(bash tools/bench_ms.sh --no-secondary --also-streams 0)"
-  echo "split 0.5    $(bash tools/bench_ms.sh --no-secondary --also-streams 0 --image-split 0.5)"
-  echo "split 0.86   $(bash tools/bench_ms.sh --no-secondary --also-streams 0 --image-split 0.86)"
-  echo "split 0.33   $(bash tools/bench_ms.sh --no-secondary --also-streams 0 --image-split 0.33)"
-done
 for i in 1 2; do
-  echo "vitl default   $(bash tools/bench_ms.sh --config vitl_lora --steps 8)"
-  echo "vitl split 0.5 $(bash tools/bench_ms.sh --config vitl_lora --steps 8 --image-split 0.5)"
+  echo "default (chains)     $(bash tools/bench_ms.sh --no-secondary --also-streams 0)"
+  echo "chains no-hh-short-k $(bash tools/bench_ms.sh --no-secondary --also-streams 0 --no-half-height-short-k)"
+  echo "chains short-k-n 0   $(bash tools/bench_ms.sh --no-secondary --also-streams 0 --short-k-half-n 0)"
+  echo "chains both off      $(bash tools/bench_ms.sh --no-secondary --also-streams 0 --short-k-half-n 0 --no-half-height-short-k)"
+  echo "no-tail-split        $(bash tools/bench_ms.sh --no-secondary --also-streams 0 --no-tail-split)"
 done
