@@ -49,8 +49,8 @@ def parse():
                     "extra untimed step with both towers on ONE stream, where a launch's HIP events see only that launch (and agree with rocprofv3)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the two secondary lines (BASELINE configs[3] and the per-GPU shape of configs[4], 10 steps each, "
                     "no CPU leg) that the default single-GPU run prints under `secondary`")
-    ap.add_argument("--also-streams", type=int, default=3, help="after the timed region, time 5 more steps with the batch's towers cut into this many slices on as many "
-                    "HIP streams and report them beside the headline as `multi_stream` (0 = skip); the headline itself stays on --streams")
+    ap.add_argument("--also-streams", type=int, default=1, help="after the timed region, time 5 more steps each of two other forms of the step (everything on one stream; the text tower on "
+                    "valid tokens only) and report them beside the headline as `other_forms` (0 = skip)")
     ap.add_argument("--streams", type=int, default=1, help="cut each rank's batch into this many slices whose towers run on as many HIP streams (same batch, "
                     "same single InfoNCE over all pairs, same gradients: engine.contrastive_step(streams=...))")
     ap.add_argument("--cpu-batch", type=int, default=8)
@@ -477,44 +477,37 @@ def bench_mona(args, rank, world, device):
                                             streams=args.streams if overlap is not False else 1)
     elapsed, per_rank, final_loss, prof, prof_serial = timed_loop(step, args, world, device, ops, torch)
     multi = None
-    if args.also_streams > 1 and args.also_streams != args.streams:
-        # the same step with its towers as S batch slices on S HIP streams (same single InfoNCE, same gradients): what the chip gives when
-        # two or three dependent chains fill each other's lockstep phases and tails.  Reported beside the headline, not as it: with several
-        # streams a launch's HIP-event duration includes time shared with the other streams' kernels, and `roofline` would under-report.
-        stepm = lambda: contrastive_step(model, criterion, opt, images, ids, overlap_text=False, global_loss=args.global_loss, streams=args.also_streams)
-        for _ in range(2):
-            stepm()
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(5):
-            lm = stepm()
-        torch.cuda.synchronize()
-        dtm = time.perf_counter() - t0
-        if world > 1:
-            tm = torch.tensor([dtm], device=device, dtype=torch.float64)
-            torch.distributed.all_reduce(tm, op=torch.distributed.ReduceOp.MAX)
-            dtm = float(tm[0])
-        multi = {"hip_streams": args.also_streams, "steps": 5, "ms_per_step": round(dtm / 5 * 1e3, 3), "value": round(world * args.batch * 5 / dtm, 2),
-                 "loss": round(float(lm), 5), "how": "engine.contrastive_step(streams=S): S batch slices on S streams, one InfoNCE over all pairs; untimed in `value`"}
-        # and the other form of the text tower (headline: second stream beside the image tower, the entry points' default; here: the one it is not)
-        stepo = lambda: contrastive_step(model, criterion, opt, images, ids, overlap_text=not args.overlap_text, global_loss=args.global_loss)
-        for _ in range(2):
-            stepo()
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(5):
-            lo = stepo()
-        torch.cuda.synchronize()
-        dto = time.perf_counter() - t0
-        if world > 1:
-            to = torch.tensor([dto], device=device, dtype=torch.float64)
-            torch.distributed.all_reduce(to, op=torch.distributed.ReduceOp.MAX)
-            dto = float(to[0])
-        multi["text_tower_on_second_stream" if not args.overlap_text else "text_tower_on_the_same_stream"] = {"steps": 5, "ms_per_step": round(dto / 5 * 1e3, 3), "value": round(world * args.batch * 5 / dto, 2), "loss": round(float(lo), 5)}
+    if args.also_streams > 0:
+        # Two other forms of the same step, 5 steps each, reported beside the headline and never as it:
+        #   one_stream    — everything on one stream (the configuration the roofline block is measured on): what the streams are worth;
+        #   unpadded_text — the frozen text tower computes only the valid tokens of each caption (UF.set_unpad_text: same features, LESS work than the reference
+        #                   executes, which is why it is not the headline).
+        def extra(fn):
+            for _ in range(2):
+                fn()
+            if world > 1:
+                torch.distributed.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                lv = fn()
+            torch.cuda.synchronize()
+            dte = time.perf_counter() - t0
+            if world > 1:
+                te = torch.tensor([dte], device=device, dtype=torch.float64)
+                torch.distributed.all_reduce(te, op=torch.distributed.ReduceOp.MAX)
+                dte = float(te[0])
+            return {"steps": 5, "ms_per_step": round(dte / 5 * 1e3, 3), "value": round(world * args.batch * 5 / dte, 2), "loss": round(float(lv), 5)}
+
+        multi = {"how": "5 untimed-in-`value` steps each, same model and batch",
+                 "one_stream": extra(lambda: contrastive_step(model, criterion, opt, images, ids, overlap_text=False, global_loss=args.global_loss, image_split=0))}
+        if not args.unpad_text:
+            UF.set_unpad_text(True)
+            try:
+                multi["unpadded_text"] = extra(lambda: step(True))
+                multi["unpadded_text"]["note"] = "valid caption tokens only through the text tower (opt-in --unpad-text): identical features, less work than the reference executes"
+            finally:
+                UF.set_unpad_text(False)
     if rank != 0:
         return None
     ms = elapsed / args.steps * 1e3
@@ -549,7 +542,7 @@ def bench_mona(args, rank, world, device):
                       "gflop_per_pair_algorithmic": GFLOP_PER_PAIR},
            "loss": round(final_loss, 5), "roofline": roof}
     out.update(dist_fields(world, per_rank, args.steps, ops))
-    out["multi_stream"] = multi
+    out["other_forms"] = multi
     out["cpu_baseline"] = cpu_baseline(cpu_state, args.variant, args.cpu_batch, args.cpu_steps, wide=not args.no_cpu_wide) if cpu_state is not None else None
     return out
 
