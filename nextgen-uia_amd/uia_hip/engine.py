@@ -294,65 +294,67 @@ def contrastive_step(model, criterion, opt, images, ids, micro_batches=1, lr=Non
         image_split = int(round(mb * IMAGE_SPLIT)) if mb >= 32 else 0
     ops.CHAINS = 3 if (overlap_text and 0 < image_split < mb and not (streams > 1 and mb >= 2 * streams)) else 1      # forward AND backward of this step (ops.gemm's tail policy)
     cur = torch.cuda.current_stream()
-    for i in range(micro_batches):
-        im, tk = images[i * mb:(i + 1) * mb], ids[i * mb:(i + 1) * mb]
-        if streams > 1 and mb >= 2 * streams:
-            sts = _mb_streams(images.device, streams)
-            bounds = [mb * s // streams for s in range(streams + 1)]
-            fis, fts = [], []
-            for s, st in enumerate(sts):
-                st.wait_stream(cur)
-                with torch.cuda.stream(st):
-                    fis.append(model.encode_image(im[bounds[s]:bounds[s + 1]]))
-                    fts.append(model.encode_text(tk[bounds[s]:bounds[s + 1]]))
-            for st, a, b in zip(sts, fis, fts):
-                cur.wait_stream(st)
-                a.record_stream(cur)
-                b.record_stream(cur)
-            fi, ft = torch.cat(fis, 0), torch.cat(fts, 0)
-        elif overlap_text and 0 < image_split < mb:
-            # round 4: the image tower as TWO slices on two streams, the text tower whole on a third.  Every kernel of the tower is per row, per image or per
-            # (image, head), so the slices are independent chains; a chain of dependent launches leaves CUs idle at every ragged last round and M tail (the
-            # backward has no text tower beside it to fill them), two chains fill each other's.  One InfoNCE over all pairs, as with streams = S; same loss and
-            # gradients (the weight gradients meet through the same float atomics).  Halves measured best (41.43 -> 40.78 ms; 0.86 / 0.14 — a first slice of whole
-            # 256-tile rounds — 41.09, thirds 41.16); slicing the text tower as well (streams = 3) is slower: its 768-tile launches are whole rounds already.
-            side = _side_stream(images.device)
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
+    try:
+        for i in range(micro_batches):
+            im, tk = images[i * mb:(i + 1) * mb], ids[i * mb:(i + 1) * mb]
+            if streams > 1 and mb >= 2 * streams:
+                sts = _mb_streams(images.device, streams)
+                bounds = [mb * s // streams for s in range(streams + 1)]
+                fis, fts = [], []
+                for s, st in enumerate(sts):
+                    st.wait_stream(cur)
+                    with torch.cuda.stream(st):
+                        fis.append(model.encode_image(im[bounds[s]:bounds[s + 1]]))
+                        fts.append(model.encode_text(tk[bounds[s]:bounds[s + 1]]))
+                for st, a, b in zip(sts, fis, fts):
+                    cur.wait_stream(st)
+                    a.record_stream(cur)
+                    b.record_stream(cur)
+                fi, ft = torch.cat(fis, 0), torch.cat(fts, 0)
+            elif overlap_text and 0 < image_split < mb:
+                # round 4: the image tower as TWO slices on two streams, the text tower whole on a third.  Every kernel of the tower is per row, per image or per
+                # (image, head), so the slices are independent chains; a chain of dependent launches leaves CUs idle at every ragged last round and M tail (the
+                # backward has no text tower beside it to fill them), two chains fill each other's.  One InfoNCE over all pairs, as with streams = S; same loss and
+                # gradients (the weight gradients meet through the same float atomics).  Halves measured best (41.43 -> 40.78 ms; 0.86 / 0.14 — a first slice of whole
+                # 256-tile rounds — 41.09, thirds 41.16); slicing the text tower as well (streams = 3) is slower: its 768-tile launches are whole rounds already.
+                side = _side_stream(images.device)
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    ft = model.encode_text(tk)
+                s2 = _mb_streams(images.device, 1)[0]
+                s2.wait_stream(cur)
+                with torch.cuda.stream(s2):
+                    f2 = model.encode_image(im[image_split:])
+                f1 = model.encode_image(im[:image_split])
+                cur.wait_stream(s2)
+                f2.record_stream(cur)
+                fi = torch.cat([f1, f2], 0)
+                cur.wait_stream(side)
+                ft.record_stream(cur)
+            elif overlap_text:
+                side = _side_stream(images.device)
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    ft = model.encode_text(tk)
+                fi = model.encode_image(im)
+                cur.wait_stream(side)
+                ft.record_stream(cur)
+            else:
+                fi = model.encode_image(im)
                 ft = model.encode_text(tk)
-            s2 = _mb_streams(images.device, 1)[0]
-            s2.wait_stream(cur)
-            with torch.cuda.stream(s2):
-                f2 = model.encode_image(im[image_split:])
-            f1 = model.encode_image(im[:image_split])
-            cur.wait_stream(s2)
-            f2.record_stream(cur)
-            fi = torch.cat([f1, f2], 0)
-            cur.wait_stream(side)
-            ft.record_stream(cur)
-        elif overlap_text:
-            side = _side_stream(images.device)
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                ft = model.encode_text(tk)
-            fi = model.encode_image(im)
-            cur.wait_stream(side)
-            ft.record_stream(cur)
-        else:
-            fi = model.encode_image(im)
-            ft = model.encode_text(tk)
-        if global_loss:
-            rank, _, _ = dist_env()
-            fi, ft = GatherFeaturesFn.apply(fi, rank, opt.world), GatherFeaturesFn.apply(ft, rank, opt.world)
-        loss = criterion(fi, ft)
-        (loss / micro_batches).backward()
-        if overlap_text and 0 < image_split < mb and not (streams > 1 and mb >= 2 * streams):
-            cur.wait_stream(_mb_streams(images.device, 1)[0])
-        if streams > 1 and mb >= 2 * streams:
-            for st in _mb_streams(images.device, streams):     # the adapters' weight gradients are side effects of the backward kernels (flat
-                cur.wait_stream(st)                            # buffer, direct mode): autograd's own end-of-backward sync does not know them
-        total = loss.detach() if total is None else total + loss.detach()
-    ops.CHAINS = 1
+            if global_loss:
+                rank, _, _ = dist_env()
+                fi, ft = GatherFeaturesFn.apply(fi, rank, opt.world), GatherFeaturesFn.apply(ft, rank, opt.world)
+            loss = criterion(fi, ft)
+            (loss / micro_batches).backward()
+            if overlap_text and 0 < image_split < mb and not (streams > 1 and mb >= 2 * streams):
+                cur.wait_stream(_mb_streams(images.device, 1)[0])
+            if streams > 1 and mb >= 2 * streams:
+                for st in _mb_streams(images.device, streams):     # the adapters' weight gradients are side effects of the backward kernels (flat
+                    cur.wait_stream(st)                            # buffer, direct mode): autograd's own end-of-backward sync does not know them
+            total = loss.detach() if total is None else total + loss.detach()
+    finally:
+        ops.CHAINS = 1        # also when a launch raised: the policy must not leak into the caller's next launches
     opt.all_reduce()
     opt.step(lr=lr, grad_scale=dp_grad_scale(opt.world, global_loss))
     return total / micro_batches
