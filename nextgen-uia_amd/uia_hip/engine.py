@@ -355,6 +355,7 @@ def contrastive_step(model, criterion, opt, images, ids, micro_batches=1, lr=Non
             total = loss.detach() if total is None else total + loss.detach()
     finally:
         ops.CHAINS = 1        # also when a launch raised: the policy must not leak into the caller's next launches
+        UF.set_grad_resid3(False)      # tokens are a contract of THIS step's forward and backward; another loop in the process (segmentation heads on tapped blocks) starts without them
     opt.all_reduce()
     opt.step(lr=lr, grad_scale=dp_grad_scale(opt.world, global_loss))
     return total / micro_batches

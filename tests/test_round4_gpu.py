@@ -833,3 +833,36 @@ def test_contrastive_step_with_the_image_tower_in_two_slices_equals_one_slice(mo
     g1, g2 = outs[0][1], outs[1][1]
     assert float((g1 - g2).norm() / g1.norm()) < (1e-4 if mode == "fp32" else 5e-2), float((g1 - g2).norm() / g1.norm())
     assert abs(outs[0][2] - outs[1][2]) < (1e-4 if mode == "fp32" else 5e-2) * outs[0][2]
+
+
+def test_contrastive_step_leaves_the_three_byte_gradient_mode_off_and_skips_hooked_models():
+    """engine.contrastive_step turns functional.set_grad_resid3 on for its own forward + backward only — a later loop in the same process (tapped blocks feeding a
+    segmentation head) must not inherit tokens — and not at all for a model that carries module hooks (something else may read the tensors between the Functions)."""
+    from uia_hip import functional as UF
+    from uia_hip import engine
+    from src.losses import InfoNCELoss
+    from tests.test_round2_gpu import _toy_batch, _toy_model
+    UF.set_compute_dtype(torch.bfloat16)
+    images, ids = _toy_batch(29, B=8)
+    seen = []
+    orig = UF.set_grad_resid3
+
+    def spy(flag):
+        seen.append(bool(flag))
+        orig(flag)
+
+    UF.set_grad_resid3 = spy
+    try:
+        for hooked in (False, True):
+            model = _toy_model("freq_enhanced", seed=3).to(dev())
+            if hooked:
+                model.visual.trunk.blocks[1].register_forward_hook(lambda m, i, o: None)
+            opt = engine.FlatAdapterOptimizer([(k, p) for k, p in model.named_parameters() if p.requires_grad], lr=1e-3)
+            seen.clear()
+            engine.contrastive_step(model, InfoNCELoss(0.07), opt, images.to(dev()), ids.to(dev()))
+            torch.cuda.synchronize()
+            assert seen[0] == (engine.GRAD_RESID3 and not hooked) and seen[-1] is False
+            assert not UF.grad_resid3_enabled()
+            assert bool(torch.isfinite(opt.g).all())
+    finally:
+        UF.set_grad_resid3 = orig

@@ -18,11 +18,12 @@ model = model.cuda().train()
 opt = FlatAdapterOptimizer([(k, p) for k, p in model.named_parameters() if p.requires_grad], lr=1e-4, betas=(0.9, 0.95), weight_decay=0.01, max_norm=1.0)
 images, ids = bench.synthetic_batch(256, 0, torch.device("cuda", 0))
 crit = InfoNCELoss(0.07)
-for _ in range(3): contrastive_step(model, crit, opt, images, ids, overlap_text=False)
+OV = "--serial" not in sys.argv      # default: the entry points' configuration (text tower on its own stream, the image tower in two slices)
+for _ in range(3): contrastive_step(model, crit, opt, images, ids, overlap_text=OV)
 torch.cuda.synchronize()
 enq, tot = [], []
 for _ in range(5):
-    t0 = time.perf_counter(); contrastive_step(model, crit, opt, images, ids, overlap_text=False); t1 = time.perf_counter()
+    t0 = time.perf_counter(); contrastive_step(model, crit, opt, images, ids, overlap_text=OV); t1 = time.perf_counter()
     torch.cuda.synchronize(); t2 = time.perf_counter()
     enq.append(t1 - t0); tot.append(t2 - t0)
 print("enqueue ms", [round(x * 1e3, 1) for x in enq], "total ms", [round(x * 1e3, 1) for x in tot])
