@@ -265,6 +265,7 @@ def _hook_free(model):
     return ok
 
 
+IMAGE_SLICES = 2        # experiment knob: > 2 cuts the images behind the first slice into IMAGE_SLICES - 1 equal slices on as many streams
 IMAGE_SPLIT = 0.5       # fraction of a micro-batch's images that form the FIRST of two image-tower slices on two streams (0 = one slice); see contrastive_step.  A/B: bench.py --image-split 0
 
 
@@ -321,14 +322,18 @@ def contrastive_step(model, criterion, opt, images, ids, micro_batches=1, lr=Non
                 side.wait_stream(cur)
                 with torch.cuda.stream(side):
                     ft = model.encode_text(tk)
-                s2 = _mb_streams(images.device, 1)[0]
-                s2.wait_stream(cur)
-                with torch.cuda.stream(s2):
-                    f2 = model.encode_image(im[image_split:])
-                f1 = model.encode_image(im[:image_split])
-                cur.wait_stream(s2)
-                f2.record_stream(cur)
-                fi = torch.cat([f1, f2], 0)
+                cuts = [0, image_split] + ([image_split + (mb - image_split) * j // (IMAGE_SLICES - 1) for j in range(1, IMAGE_SLICES - 1)] if IMAGE_SLICES > 2 else []) + [mb]
+                extra = _mb_streams(images.device, len(cuts) - 2)
+                parts = [None] * (len(cuts) - 1)
+                for j, st in enumerate(extra):                       # slices 1.. on their own streams, slice 0 on the caller's
+                    st.wait_stream(cur)
+                    with torch.cuda.stream(st):
+                        parts[j + 1] = model.encode_image(im[cuts[j + 1]:cuts[j + 2]])
+                parts[0] = model.encode_image(im[:cuts[1]])
+                for j, st in enumerate(extra):
+                    cur.wait_stream(st)
+                    parts[j + 1].record_stream(cur)
+                fi = torch.cat(parts, 0)
                 cur.wait_stream(side)
                 ft.record_stream(cur)
             elif overlap_text:
@@ -348,7 +353,8 @@ def contrastive_step(model, criterion, opt, images, ids, micro_batches=1, lr=Non
             loss = criterion(fi, ft)
             (loss / micro_batches).backward()
             if overlap_text and 0 < image_split < mb and not (streams > 1 and mb >= 2 * streams):
-                cur.wait_stream(_mb_streams(images.device, 1)[0])
+                for st in _mb_streams(images.device, max(1, IMAGE_SLICES - 1)):
+                    cur.wait_stream(st)
             if streams > 1 and mb >= 2 * streams:
                 for st in _mb_streams(images.device, streams):     # the adapters' weight gradients are side effects of the backward kernels (flat
                     cur.wait_stream(st)                            # buffer, direct mode): autograd's own end-of-backward sync does not know them
