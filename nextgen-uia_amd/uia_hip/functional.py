@@ -261,7 +261,7 @@ def publish_grad3(shape, device, hi, lo):
 
 def grad3_of(g):
     """(hi, lo) when g is a token of publish_grad3 (consumed), else None.  Call BEFORE anything touches g's values."""
-    if not _G3 or g.dim() == 0 or any(st != 0 for st in g.stride()):
+    if not _G3 or g.dim() == 0 or any(st != 0 for st, n in zip(g.stride(), g.shape) if n > 1):      # (a dimension of size 1 keeps whatever stride it had: a one-image slice)
         return None
     hit = _G3.pop(g.data_ptr(), None)
     if hit is None or hit[2] != g.numel():

@@ -306,6 +306,8 @@ def test_three_byte_gradient_tokens_travel_through_views_and_poison_other_reader
     got = UF.grad3_of(seen)
     assert got is not None and got[0] is hi and got[1] is lo
     assert UF.grad3_of(seen) is None                                      # consumed
+    one = UF.publish_grad3((1, 6, 4), torch.device("cpu"), hi, lo)          # a one-image slice: the size-1 dimension keeps a non-zero stride
+    assert UF.grad3_of(one.permute(1, 0, 2)) is not None
     tok2 = UF.publish_grad3((2, 3, 4), torch.device("cpu"), hi, lo)
     assert tok2.data_ptr() != tok.data_ptr()                              # consecutive hand-offs do not share an address
     assert bool(torch.isnan(tok2 + 1.0).all())

@@ -820,19 +820,20 @@ def test_contrastive_step_with_the_image_tower_in_two_slices_equals_one_slice(mo
     UF.set_compute_dtype(torch.float32 if mode == "fp32" else torch.bfloat16)
     images, ids = _toy_batch(23, B=8)
     outs = []
-    for split in (0, 3):
+    for split, mbs in ((0, 1), (3, 1), (0, 2), (1, 2)):                  # the last two: two micro-batches of four pairs, whole and cut 1 + 3
         model = _toy_model("hybrid", seed=13).to(dev())
         opt = FlatAdapterOptimizer([(k, p) for k, p in model.named_parameters() if p.requires_grad], lr=1e-3)
         UF.set_dropout_seed(7)
-        loss = contrastive_step(model, InfoNCELoss(0.07), opt, images.to(dev()), ids.to(dev()), overlap_text=True, image_split=split)
+        loss = contrastive_step(model, InfoNCELoss(0.07), opt, images.to(dev()), ids.to(dev()), overlap_text=True, image_split=split, micro_batches=mbs)
         torch.cuda.synchronize()
         outs.append((float(loss), opt.g.clone(), opt.grad_norm()))
     UF.set_compute_dtype(torch.bfloat16)
     tol = 1e-5 if mode == "fp32" else 2e-2
-    assert abs(outs[0][0] - outs[1][0]) < tol * max(1.0, abs(outs[0][0]))
-    g1, g2 = outs[0][1], outs[1][1]
-    assert float((g1 - g2).norm() / g1.norm()) < (1e-4 if mode == "fp32" else 5e-2), float((g1 - g2).norm() / g1.norm())
-    assert abs(outs[0][2] - outs[1][2]) < (1e-4 if mode == "fp32" else 5e-2) * outs[0][2]
+    for a, b in ((0, 1), (2, 3)):
+        assert abs(outs[a][0] - outs[b][0]) < tol * max(1.0, abs(outs[a][0]))
+        g1, g2 = outs[a][1], outs[b][1]
+        assert float((g1 - g2).norm() / g1.norm()) < (1e-4 if mode == "fp32" else 5e-2), float((g1 - g2).norm() / g1.norm())
+        assert abs(outs[a][2] - outs[b][2]) < (1e-4 if mode == "fp32" else 5e-2) * outs[a][2]
 
 
 def test_contrastive_step_leaves_the_three_byte_gradient_mode_off_and_skips_hooked_models():
