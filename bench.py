@@ -84,6 +84,7 @@ def parse():
     ap.add_argument("--short-k-half-no-stash", action="store_true", help="experiment knob: the --short-k-half-n rule skips launches with an aux_out stash")
     ap.add_argument("--half-height-short-k-always", action="store_true", help="experiment knob: N <= 768, K <= 768 launches on half-height tiles also without a ragged last round")
     ap.add_argument("--image-split", type=float, default=-1.0, help="scheduling knob: the image tower as two slices (this fraction of the images, the rest) on two HIP streams beside the text tower's; 0 = one slice, -1 = the engine's default")
+    ap.add_argument("--text-slices", type=int, default=1, help="experiment knob: the text tower in this many slices on as many streams beside the image tower's slices")
     ap.add_argument("--image-slices", type=int, default=2, help="experiment knob: number of image-tower slices (streams) when --image-split is on")
     ap.add_argument("--no-grad-resid3", action="store_true", help="A/B: the residual gradient between the image tower's backward Functions as fp32 + bf16 copy (rounds 1-3) instead of a three-byte tensor")
     ap.add_argument("--no-lora-rank3", action="store_true", help="A/B: the q | k | v rank terms of a LoRA block's data gradient as three K = 64 launches instead of one uia_lora_rank_update pass")
@@ -397,6 +398,7 @@ def main():
     if args.image_split >= 0:
         _engine.IMAGE_SPLIT = args.image_split
     _engine.IMAGE_SLICES = args.image_slices
+    _engine.TEXT_SLICES = args.text_slices
     UF.set_block_resid3(args.block_resid3)
     ops.PERSIST_STORE_ONLY = args.persist_store_only
     ops.TILE_GROUP = {int(k): int(v) for k, v in (kv.split("=") for kv in args.tile_group.split(",") if kv)}

@@ -265,6 +265,7 @@ def _hook_free(model):
     return ok
 
 
+TEXT_SLICES = 1         # experiment knob: the (frozen, forward-only) text tower in this many equal slices on as many streams when the image tower is split
 IMAGE_SLICES = 2        # experiment knob: > 2 cuts the images behind the first slice into IMAGE_SLICES - 1 equal slices on as many streams
 IMAGE_SPLIT = 0.5       # fraction of a micro-batch's images that form the FIRST of two image-tower slices on two streams (0 = one slice); see contrastive_step.  A/B: bench.py --image-split 0
 
@@ -320,8 +321,18 @@ def contrastive_step(model, criterion, opt, images, ids, micro_batches=1, lr=Non
                 # 256-tile rounds — 41.09, thirds 41.16); slicing the text tower as well (streams = 3) is slower: its 768-tile launches are whole rounds already.
                 side = _side_stream(images.device)
                 side.wait_stream(cur)
-                with torch.cuda.stream(side):
-                    ft = model.encode_text(tk)
+                fts, tsides = None, []
+                if TEXT_SLICES > 1:                                  # experiment knob: the text tower in equal slices on as many streams as well
+                    tb = [mb * j // TEXT_SLICES for j in range(TEXT_SLICES + 1)]
+                    tsides = [side] + _mb_streams(images.device, 8 + TEXT_SLICES - 1)[:TEXT_SLICES - 1]
+                    fts = []
+                    for j, st in enumerate(tsides):
+                        st.wait_stream(cur)
+                        with torch.cuda.stream(st):
+                            fts.append(model.encode_text(tk[tb[j]:tb[j + 1]]))
+                else:
+                    with torch.cuda.stream(side):
+                        ft = model.encode_text(tk)
                 cuts = [0, image_split] + ([image_split + (mb - image_split) * j // (IMAGE_SLICES - 1) for j in range(1, IMAGE_SLICES - 1)] if IMAGE_SLICES > 2 else []) + [mb]
                 extra = _mb_streams(images.device, len(cuts) - 2)
                 parts = [None] * (len(cuts) - 1)
@@ -334,8 +345,14 @@ def contrastive_step(model, criterion, opt, images, ids, micro_batches=1, lr=Non
                     cur.wait_stream(st)
                     parts[j + 1].record_stream(cur)
                 fi = torch.cat(parts, 0)
-                cur.wait_stream(side)
-                ft.record_stream(cur)
+                if fts is not None:
+                    for st, f in zip(tsides, fts):
+                        cur.wait_stream(st)
+                        f.record_stream(cur)
+                    ft = torch.cat(fts, 0)
+                else:
+                    cur.wait_stream(side)
+                    ft.record_stream(cur)
             elif overlap_text:
                 side = _side_stream(images.device)
                 side.wait_stream(cur)
