@@ -84,6 +84,8 @@ def parse():
     ap.add_argument("--short-k-half-no-stash", action="store_true", help="experiment knob: the --short-k-half-n rule skips launches with an aux_out stash")
     ap.add_argument("--half-height-short-k-always", action="store_true", help="experiment knob: N <= 768, K <= 768 launches on half-height tiles also without a ragged last round")
     ap.add_argument("--image-split", type=float, default=-1.0, help="scheduling knob: the image tower as two slices (this fraction of the images, the rest) on two HIP streams beside the text tower's; 0 = one slice, -1 = the engine's default")
+    ap.add_argument("--no-text-ahead", action="store_true", help="A/B: the frozen text tower's stream waits for the previous step's backward and optimiser launches (default here: contrastive_step(inputs_ready=True) — "
+                    "the synthetic batch is resident in HBM before the timed region — so each step's text tower starts as soon as the host has enqueued it)")
     ap.add_argument("--text-slices", type=int, default=1, help="experiment knob: the text tower in this many slices on as many streams beside the image tower's slices")
     ap.add_argument("--image-slices", type=int, default=2, help="experiment knob: number of image-tower slices (streams) when --image-split is on")
     ap.add_argument("--no-grad-resid3", action="store_true", help="A/B: the residual gradient between the image tower's backward Functions as fp32 + bf16 copy (rounds 1-3) instead of a three-byte tensor")
@@ -478,7 +480,7 @@ def bench_mona(args, rank, world, device):
     UF.set_dropout_seed(1234 + rank)
 
     step = lambda overlap: contrastive_step(model, criterion, opt, images, ids, overlap_text=bool(overlap) and args.streams == 1, global_loss=args.global_loss,
-                                            streams=args.streams if overlap is not False else 1)
+                                            streams=args.streams if overlap is not False else 1, inputs_ready=not args.no_text_ahead)
     elapsed, per_rank, final_loss, prof, prof_serial = timed_loop(step, args, world, device, ops, torch)
     multi = None
     if args.also_streams > 0:
@@ -538,6 +540,8 @@ def bench_mona(args, rank, world, device):
                       "text_len": 256, "text_positions_computed": "valid tokens only (opt-in --unpad-text)" if args.unpad_text else "all 256",
                       "parallelism": f"dp{world}", "text_tower_stream": ("second HIP stream beside the image tower, whose two half-batch slices run on two streams (engine.IMAGE_SPLIT; the entry points' default); roofline from one extra step with everything on one stream"
                                             if args.overlap_text else "same stream"),
+                      "text_tower_start": ("as soon as enqueued (inputs resident, tower frozen: its stream does not wait for the previous step's backward / optimiser; every step computes its own text features)"
+                                           if (args.overlap_text and args.streams == 1 and not args.no_text_ahead) else "behind the previous step"),
                       "image_tower_slices": (2 if (args.overlap_text and args.streams == 1 and _image_split_on(args)) else 1),
                       "hip_streams": (f"{args.streams}: the batch's towers run as {args.streams} slices on {args.streams} HIP streams, one InfoNCE over all pairs" if args.streams > 1 else 1),
                       "contrastive_batch": "global (opt-in)" if args.global_loss else "per-rank (reference-equivalent)", "mona_dropout": 0.1,
@@ -654,7 +658,7 @@ def bench_vitl_lora(args, rank, world, device):
     images_d, ids_d = images.to(device), ids.to(device)
     crit = InfoNCELoss(0.07)
     UF.set_dropout_seed(3 + rank)
-    step = lambda overlap: contrastive_step(model, crit, opt, images_d, ids_d, overlap_text=overlap)
+    step = lambda overlap: contrastive_step(model, crit, opt, images_d, ids_d, overlap_text=overlap, inputs_ready=not args.no_text_ahead)
     elapsed, per_rank, final_loss, prof, prof_serial = timed_loop(step, args, world, device, ops, torch)
     if rank != 0:
         return None

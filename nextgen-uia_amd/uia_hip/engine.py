@@ -270,7 +270,18 @@ IMAGE_SLICES = 2        # experiment knob: > 2 cuts the images behind the first 
 IMAGE_SPLIT = 0.5       # fraction of a micro-batch's images that form the FIRST of two image-tower slices on two streams (0 = one slice); see contrastive_step.  A/B: bench.py --image-split 0
 
 
-def contrastive_step(model, criterion, opt, images, ids, micro_batches=1, lr=None, overlap_text=True, global_loss=False, streams=1, image_split=None):
+def _frozen_text(model):
+    ok = getattr(model, "_uia_frozen_text", None)
+    if ok is None:
+        ok = all(k.startswith("visual.") for k, p in model.named_parameters() if p.requires_grad)      # conservative: every trainable parameter lives in the image tower
+        try:
+            model._uia_frozen_text = ok
+        except Exception:
+            pass
+    return ok
+
+
+def contrastive_step(model, criterion, opt, images, ids, micro_batches=1, lr=None, overlap_text=True, global_loss=False, streams=1, image_split=None, inputs_ready=False):
     """One optimiser update: encode → InfoNCE → backward (→ all-reduce) → clip+AdamW.  Returns the loss tensor (device).
 
     global_loss (opt-in, not the reference's semantics): the InfoNCE batch is the GLOBAL batch — features are all-gathered,
@@ -320,7 +331,11 @@ def contrastive_step(model, criterion, opt, images, ids, micro_batches=1, lr=Non
                 # gradients (the weight gradients meet through the same float atomics).  Halves measured best (41.43 -> 40.78 ms; 0.86 / 0.14 — a first slice of whole
                 # 256-tile rounds — 41.09, thirds 41.16); slicing the text tower as well (streams = 3) is slower: its 768-tile launches are whole rounds already.
                 side = _side_stream(images.device)
-                side.wait_stream(cur)
+                if not (inputs_ready and _frozen_text(model)):
+                    side.wait_stream(cur)
+                # inputs_ready (the caller vouches that `ids` was complete before this call, e.g. a resident or double-buffered batch) and a frozen text tower: its
+                # stream does NOT wait for the caller's — nothing it reads is written by the previous step's backward or optimiser — so, the host running ahead of the
+                # GPU, this step's text tower starts beside the previous step's backward tail and optimiser launches instead of behind them.
                 fts, tsides = None, []
                 if TEXT_SLICES > 1:                                  # experiment knob: the text tower in equal slices on as many streams as well
                     tb = [mb * j // TEXT_SLICES for j in range(TEXT_SLICES + 1)]

@@ -867,3 +867,31 @@ def test_contrastive_step_leaves_the_three_byte_gradient_mode_off_and_skips_hook
             assert bool(torch.isfinite(opt.g).all())
     finally:
         UF.set_grad_resid3 = orig
+
+
+def test_text_tower_ahead_of_the_previous_step_gives_the_same_steps():
+    """contrastive_step(inputs_ready=True): with a frozen text tower and resident inputs its stream does not wait for the caller's, so step t+1's text tower may run beside step
+    t's backward and optimiser.  Three consecutive steps (the second and third read weights the first two updated — in the IMAGE tower only) give the same losses and the same
+    parameters as the serialised order."""
+    from uia_hip import functional as UF
+    from uia_hip.engine import FlatAdapterOptimizer, contrastive_step
+    from src.losses import InfoNCELoss
+    from tests.test_round2_gpu import _toy_batch, _toy_model
+    UF.set_compute_dtype(torch.float32)
+    images, ids = _toy_batch(31, B=8)
+    images, ids = images.to(dev()), ids.to(dev())
+    torch.cuda.synchronize()
+    outs = []
+    try:
+        for ahead in (False, True):
+            model = _toy_model("freq_enhanced", seed=17).to(dev())
+            opt = FlatAdapterOptimizer([(k, p) for k, p in model.named_parameters() if p.requires_grad], lr=1e-2)
+            UF.set_dropout_seed(3)
+            losses = [float(contrastive_step(model, InfoNCELoss(0.07), opt, images, ids, overlap_text=True, image_split=4, inputs_ready=ahead)) for _ in range(3)]
+            torch.cuda.synchronize()
+            outs.append((losses, torch.cat([p.detach().flatten() for p in model.parameters() if p.requires_grad]).clone()))
+    finally:
+        UF.set_compute_dtype(torch.bfloat16)
+    assert max(abs(a - b) for a, b in zip(*[o[0] for o in outs])) < 1e-5 and outs[0][0][2] != outs[0][0][0]
+    d = (outs[0][1] - outs[1][1]).abs()                                  # (AdamW turns the last-bit noise of the float-atomic gradient sums into lr-sized steps where a gradient is ~0)
+    assert float((d > 1e-3).float().mean()) < 1e-3 and float(d.mean()) < 1e-5
