@@ -89,6 +89,7 @@ def parse():
     ap.add_argument("--text-slices", type=int, default=1, help="experiment knob: the text tower in this many slices on as many streams beside the image tower's slices")
     ap.add_argument("--image-slices", type=int, default=2, help="experiment knob: number of image-tower slices (streams) when --image-split is on")
     ap.add_argument("--no-grad-resid3", action="store_true", help="A/B: the residual gradient between the image tower's backward Functions as fp32 + bf16 copy (rounds 1-3) instead of a three-byte tensor")
+    ap.add_argument("--no-lora-wgrad-group", action="store_true", help="A/B: the q | k | v weight gradients of a LoRA attention block as three launches each instead of one uia_wgrad_group launch")
     ap.add_argument("--no-lora-rank3", action="store_true", help="A/B: the q | k | v rank terms of a LoRA block's data gradient as three K = 64 launches instead of one uia_lora_rank_update pass")
     ap.add_argument("--no-lora-kext", action="store_true", help="A/B knob: the LoRA rank update as a launch of its own (tile cfg 23) instead of inside the frozen GEMM's K loop")
     ap.add_argument("--quad", action="store_true", help="experiment knob: 256x256 bf16 launches on the four-wave kernel (tile cfg 25, csrc/gemm_quad.hip) instead of the eight-wave ring kernel")
@@ -376,6 +377,7 @@ def main():
     ops.QUAD = args.quad
     ops.LORA_KEXT = not args.no_lora_kext
     ops.LORA_RANK3 = not args.no_lora_rank3
+    ops.LORA_WGRAD_GROUP = not args.no_lora_wgrad_group
     if args.short_k_half_n >= 0:
         ops.SHORT_K_WIDE_HALF_N = args.short_k_half_n
     ops.SHORT_K_WIDE_HALF_STASH = not args.short_k_half_no_stash

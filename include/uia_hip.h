@@ -165,6 +165,24 @@ int uia_wgrad_ex(void* stream, int dtype, int M, int I, int J, const void* A, in
  * uia_gemm_desc.drop_where = 1 draw from (seed, element index / 8); the forward then need not write the dropped rows out.  bf16; extents as uia_wgrad_ex. */
 int uia_wgrad_drop(void* stream, int dtype, int M, int I, int J, const void* A, int64_t lda, const void* B, int64_t ldb,
                    float alpha, float* dW, int64_t ldw, int i_valid, int j_valid, float drop_p, uint64_t seed, int64_t drop_ld, int drop_col0);
+/* Up to four weight gradients of ONE shape in one launch (the q | k | v factors of a LoRA attention block, lora.py:82-87 three times: three launches of short-lived workgroups
+ * were three latencies).  Problem g: dW[g][i_valid, j_valid] += alpha * A[g].T @ drop_g(B[g]) (+ dbias_A[g] += column sums of A[g] where given, without dropout only); all problems
+ * share M, I, J, the leading dimensions, alpha, the valid extent and the dropout window; drop_p = 0: no dropout, else problem g's mask is drawn from drop_seed[g] as uia_wgrad_drop
+ * draws it.  bf16.  Same arithmetic per problem as uia_wgrad_ex / uia_wgrad_drop. */
+typedef struct uia_wgrad_group_desc {
+    int32_t n, M, I, J;
+    const void* A[4];
+    const void* B[4];
+    float* dW[4];
+    float* dbias_A[4];
+    int64_t lda, ldb, ldw;
+    int32_t i_valid, j_valid;
+    float alpha, drop_p;
+    uint64_t drop_seed[4];
+    int64_t drop_ld;
+    int32_t drop_col0, reserved;
+} uia_wgrad_group_desc;
+int uia_wgrad_group(void* stream, int dtype, const uia_wgrad_group_desc* d);
 
 /* ---------------------------------------------------------------------------------------------
  * softmax(q kᵀ·scale + mask) v, head dim 64, L <= 272, one workgroup per (batch, head).

@@ -29,6 +29,17 @@ int uia_wgrad_ex(void* stream, int dtype, int M, int I, int J, const void* A, in
     if (ldw <= 0) { uia_set_error("uia_wgrad_ex: ldw=%lld must be positive", (long long)ldw); return -1; }
     return uia_wgrad_launch((hipStream_t)stream, dtype, M, I, J, A, lda, B, ldb, alpha, dW, dbias_A, ldw, i_valid, j_valid);
 }
+int uia_wgrad_group(void* stream, int dtype, const uia_wgrad_group_desc* d) {
+    if (!d) { uia_set_error("uia_wgrad_group: null descriptor"); return -1; }
+    if (d->n < 1 || d->n > 4) { uia_set_error("uia_wgrad_group: n=%d outside 1..4", d->n); return -1; }
+    if (d->ldw <= 0) { uia_set_error("uia_wgrad_group: ldw=%lld must be positive", (long long)d->ldw); return -1; }
+    float* dW[4];
+    float* db[4];
+    for (int g = 0; g < 4; ++g) { dW[g] = d->dW[g]; db[g] = d->dbias_A[g]; }
+    if (d->drop_p > 0.f) for (int g = 0; g < d->n; ++g) if (db[g]) { uia_set_error("uia_wgrad_group: dbias with dropout on B is not a form of the kernel"); return -1; }
+    return uia_wgrad_group_launch((hipStream_t)stream, dtype, d->n, d->M, d->I, d->J, d->A, (long)d->lda, d->B, (long)d->ldb, d->alpha, dW, db, (long)d->ldw, d->i_valid, d->j_valid,
+                                  d->drop_p, d->drop_seed, (long)d->drop_ld, d->drop_col0);
+}
 int uia_wgrad_drop(void* stream, int dtype, int M, int I, int J, const void* A, int64_t lda, const void* B, int64_t ldb, float alpha, float* dW, int64_t ldw,
                    int i_valid, int j_valid, float drop_p, uint64_t seed, int64_t drop_ld, int drop_col0) {
     if (ldw <= 0) { uia_set_error("uia_wgrad_drop: ldw=%lld must be positive", (long long)ldw); return -1; }

@@ -29,6 +29,8 @@ int uia_im2col_launch(hipStream_t stream, int dtype, int B, int C, int H, int W,
 int uia_fill_cls_launch(hipStream_t stream, int B, int N, int D, const float* cls, const float* pos0, float* x);
 int uia_embed_launch(hipStream_t stream, int rows, int L, int D, int vocab, int max_pos, const int64_t* ids, const float* table, const float* pos, const float* type0, float* out);
 int uia_gather_rows_launch(hipStream_t stream, int n, int D, const float* src, const int64_t* idx, float* dst);
+int uia_wgrad_group_launch(hipStream_t stream, int dtype, int n, int M, int I, int J, const void* const* A, long lda, const void* const* B, long ldb, float alpha,
+                            float* const* dW, float* const* dbias, long ldw, int i_valid, int j_valid, float drop_p, const uint64_t* drop_seed, long drop_ld, int drop_col0);
 int uia_wgrad_launch(hipStream_t stream, int dtype, int M, int I, int J, const void* A, long lda, const void* B, long ldb, float alpha, float* dW, float* dbias,
                      long ldw = 0, int i_valid = 0, int j_valid = 0, float drop_p = 0.f, uint64_t drop_seed = 0, long drop_ld = 0, int drop_col0 = 0);
 int uia_mona_pre_fwd_launch(hipStream_t stream, int dtype, int M, int D, const float* x, const float* nw, const float* nb, const float* gamma,

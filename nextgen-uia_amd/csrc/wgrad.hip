@@ -42,12 +42,25 @@ constexpr int CHUNK_SLABS = WG_CHUNK_SLABS;       // slabs per workgroup → 512
 #ifndef WG_MIN_WAVES
 #define WG_MIN_WAVES 1
 #endif
+// Up to four problems of one shape per launch (uia_wgrad_group: the q | k | v factors of a LoRA block — three launches of ~1200 short workgroups each were three
+// latencies; blockIdx.y picks the problem).
+struct WgradGroups {
+    const bf16_t* A[4];
+    const bf16_t* B[4];
+    float* dW[4];
+    float* dbias[4];
+    unsigned long long seed[4];
+};
+
 template <bool DROPB>
-__global__ __launch_bounds__(256, DROPB ? 3 : WG_MIN_WAVES) void wgrad_bf16_kernel(int M, int I, int J, const bf16_t* __restrict__ A, long lda,
-                                                          const bf16_t* __restrict__ B, long ldb, float alpha,
-                                                          float* __restrict__ dW, float* __restrict__ dbias, long ldw, int i_valid, int j_valid,
-                                                          float drop_p, unsigned long long drop_seed, long drop_ld, int drop_col0) {
+__global__ __launch_bounds__(256, DROPB ? 3 : WG_MIN_WAVES) void wgrad_bf16_kernel(int M, int I, int J, const WgradGroups gp, long lda, long ldb, float alpha,
+                                                          long ldw, int i_valid, int j_valid, float drop_p, long drop_ld, int drop_col0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const bf16_t* __restrict__ A = gp.A[blockIdx.y];
+    const bf16_t* __restrict__ B = gp.B[blockIdx.y];
+    float* __restrict__ dW = gp.dW[blockIdx.y];
+    float* __restrict__ dbias = gp.dbias[blockIdx.y];
+    const unsigned long long drop_seed = gp.seed[blockIdx.y];
     char* As = smem;                  // 16 KiB
     char* Bs = smem + SLAB * 128;     // 16 KiB
     const int tid = threadIdx.x, lane = tid & 63;
@@ -259,19 +272,24 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(int M, int I, int J, con
 
 }  // namespace
 
-int uia_wgrad_launch(hipStream_t stream, int dtype, int M, int I, int J, const void* A, long lda, const void* B, long ldb, float alpha,
-                     float* dW, float* dbias, long ldw, int i_valid, int j_valid, float drop_p, uint64_t drop_seed, long drop_ld, int drop_col0) {
+int uia_wgrad_group_launch(hipStream_t stream, int dtype, int n, int M, int I, int J, const void* const* A, long lda, const void* const* B, long ldb, float alpha,
+                            float* const* dW, float* const* dbias, long ldw, int i_valid, int j_valid, float drop_p, const uint64_t* drop_seed, long drop_ld, int drop_col0) {
     if (ldw == 0) { ldw = J; i_valid = I; j_valid = J; }              // the plain form: a dense [I, J] gradient
     UIA_CHECK_ARG(dtype == UIA_BF16 || dtype == UIA_F32, "uia_wgrad: bad dtype %d", dtype);
+    UIA_CHECK_ARG(n >= 1 && n <= 4 && (n == 1 || dtype == UIA_BF16), "uia_wgrad_group: 1..4 problems per launch (bf16), got %d", n);
     UIA_CHECK_ARG(M > 0 && I > 0 && J > 0 && I % 64 == 0 && J % 64 == 0, "uia_wgrad: I=%d and J=%d must be multiples of 64 (M=%d)", I, J, M);
-    UIA_CHECK_ARG(A && B && dW, "uia_wgrad: null tensor");
     const int esz = dtype == UIA_BF16 ? 2 : 4;
-    UIA_CHECK_ARG((lda * esz) % 16 == 0 && (ldb * esz) % 16 == 0 && (uintptr_t)A % 16 == 0 && (uintptr_t)B % 16 == 0, "uia_wgrad: alignment");
+    UIA_CHECK_ARG((lda * esz) % 16 == 0 && (ldb * esz) % 16 == 0, "uia_wgrad: alignment");
     UIA_CHECK_ARG(lda >= I && ldb >= J, "uia_wgrad: leading dimension too small");
     UIA_CHECK_ARG(i_valid > 0 && i_valid <= I && j_valid > 0 && j_valid <= J && ldw >= j_valid, "uia_wgrad: valid extent %d x %d (ldw %ld) outside the padded %d x %d", i_valid, j_valid, ldw, I, J);
+    WgradGroups gp = {};
+    for (int g = 0; g < n; ++g) {
+        UIA_CHECK_ARG(A[g] && B[g] && dW[g] && (uintptr_t)A[g] % 16 == 0 && (uintptr_t)B[g] % 16 == 0, "uia_wgrad: null or misaligned tensor (problem %d)", g);
+        gp.A[g] = (const bf16_t*)A[g]; gp.B[g] = (const bf16_t*)B[g]; gp.dW[g] = dW[g]; gp.dbias[g] = dbias ? dbias[g] : nullptr; gp.seed[g] = drop_seed ? drop_seed[g] : 0;
+    }
     const int chunks = (M + SLAB * CHUNK_SLABS - 1) / (SLAB * CHUNK_SLABS);
     const dim3 grid_f32((I / 64) * (J / 64), chunks);
-    const dim3 grid(8 * ((chunks + 7) / 8) * (I / 64) * (J / 64));          // bf16 kernel: 1-D, chunks dealt to XCDs (see the kernel)
+    const dim3 grid(8 * ((chunks + 7) / 8) * (I / 64) * (J / 64), n);       // bf16 kernel: x = chunks dealt to XCDs (see the kernel), y = problem
     const int lds = 4 * 4096 * 4;   // fp32 path: reduction buffer for four waves at once
     const int lds_bf16 = 2 * SLAB * 128;   // bf16 path: two 16 KiB slabs, re-used as a two-wave reduction buffer
     static UiaDevOnce once_bf16, once_f32;
@@ -284,13 +302,17 @@ int uia_wgrad_launch(hipStream_t stream, int dtype, int M, int I, int J, const v
         if (drop_p > 0.f) {
             static UiaDevOnce once_drop;
             UIA_ENSURE_LDS_ATTR(once_drop, wgrad_bf16_kernel<true>, lds_bf16);
-            hipLaunchKernelGGL(wgrad_bf16_kernel<true>, grid, dim3(256), lds_bf16, stream, M, I, J, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, alpha, dW, dbias, ldw, i_valid, j_valid,
-                               drop_p, (unsigned long long)drop_seed, drop_ld, drop_col0);
+            hipLaunchKernelGGL(wgrad_bf16_kernel<true>, grid, dim3(256), lds_bf16, stream, M, I, J, gp, lda, ldb, alpha, ldw, i_valid, j_valid, drop_p, drop_ld, drop_col0);
         } else
-        hipLaunchKernelGGL(wgrad_bf16_kernel<false>, grid, dim3(256), lds_bf16, stream, M, I, J, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, alpha, dW, dbias, ldw, i_valid, j_valid,
-                           0.f, 0ull, 0l, 0);
+        hipLaunchKernelGGL(wgrad_bf16_kernel<false>, grid, dim3(256), lds_bf16, stream, M, I, J, gp, lda, ldb, alpha, ldw, i_valid, j_valid, 0.f, 0l, 0);
     else
-        hipLaunchKernelGGL(wgrad_f32_kernel, grid_f32, dim3(256), lds, stream, M, I, J, (const float*)A, lda, (const float*)B, ldb, alpha, dW, dbias, ldw, i_valid, j_valid);
+        hipLaunchKernelGGL(wgrad_f32_kernel, grid_f32, dim3(256), lds, stream, M, I, J, (const float*)A[0], lda, (const float*)B[0], ldb, alpha, dW[0], dbias ? dbias[0] : nullptr, ldw, i_valid, j_valid);
     UIA_CHECK_LAUNCH();
     return 0;
+}
+
+int uia_wgrad_launch(hipStream_t stream, int dtype, int M, int I, int J, const void* A, long lda, const void* B, long ldb, float alpha,
+                     float* dW, float* dbias, long ldw, int i_valid, int j_valid, float drop_p, uint64_t drop_seed, long drop_ld, int drop_col0) {
+    UIA_CHECK_ARG(A && B && dW, "uia_wgrad: null tensor");
+    return uia_wgrad_group_launch(stream, dtype, 1, M, I, J, &A, lda, &B, ldb, alpha, &dW, &dbias, ldw, i_valid, j_valid, drop_p, &drop_seed, drop_ld, drop_col0);
 }

@@ -59,6 +59,13 @@ class MonaSpatialDesc(C.Structure):
                 ("g_proj_w", vp), ("g_proj_b", vp), ("g_freq", vp), ("g_ne1_w", vp), ("g_ne1_b", vp), ("g_ne3_w", vp), ("g_ne3_b", vp), ("ws", vp)]
 
 
+class WgradGroupDesc(C.Structure):
+    """include/uia_hip.h: uia_wgrad_group_desc"""
+    _fields_ = [("n", C.c_int32), ("M", C.c_int32), ("I", C.c_int32), ("J", C.c_int32), ("A", C.c_void_p * 4), ("B", C.c_void_p * 4), ("dW", C.c_void_p * 4),
+                ("dbias_A", C.c_void_p * 4), ("lda", C.c_int64), ("ldb", C.c_int64), ("ldw", C.c_int64), ("i_valid", C.c_int32), ("j_valid", C.c_int32),
+                ("alpha", C.c_float), ("drop_p", C.c_float), ("drop_seed", C.c_uint64 * 4), ("drop_ld", C.c_int64), ("drop_col0", C.c_int32), ("reserved", C.c_int32)]
+
+
 class LoraRankDesc(C.Structure):
     """uia_lora_rank_desc (include/uia_hip.h): out += sum_i drop_i(alpha * Q_i @ W_i.T), up to three rank-64 sources in one pass."""
     _fields_ = [("M", i32), ("N", i32), ("nsrc", i32), ("alpha", f32), ("Q", vp), ("ldq", i64), ("q_stride", i64), ("W", vp * 3), ("ldw", i64),
@@ -85,6 +92,7 @@ PROTOTYPES = {
     "uia_gemm": (C.c_int, [vp, C.c_int, C.POINTER(GemmDesc), C.c_int]),
     "uia_wgrad": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, vp, i64, f32, vp, vp]),
     "uia_wgrad_drop": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, vp, i64, f32, vp, i64, C.c_int, C.c_int, f32, C.c_uint64, i64, C.c_int]),
+    "uia_wgrad_group": (C.c_int, [vp, C.c_int, vp]),
     "uia_wgrad_ex": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, vp, i64, f32, vp, i64, C.c_int, C.c_int, vp]),
     "uia_attn_fwd": (C.c_int, [vp, C.c_int, C.POINTER(AttnDesc)]),
     "uia_attn_bwd": (C.c_int, [vp, C.c_int, C.POINTER(AttnDesc)]),

@@ -1406,13 +1406,27 @@ class LoraAttnHalfFn(torch.autograd.Function):
         # the three rank terms Σ_i mask_i ⊙ (s·q_i·A_i) reach dh in ONE read-modify-write pass (uia_lora_rank_update) instead of one per projection
         one_pass = need_dx and rp == 64 and x2.is_cuda and ops.LORA_RANK3 and ops.lora_rank_update_ok(3, D, dt)
         q_all = _empty((3, M, rp), dt, x2)
-        for i, (bias, A, Bm, t, hd) in enumerate(((bq, aq, Bq, tq, hq), (bk, ak, Bk, tk, hk), (bv, av, Bv, tv, hv))):
+        trio = ((bq, aq, Bq, tq, hq), (bk, ak, Bk, tk, hk), (bv, av, Bv, tv, hv))
+        # the three dB launches and the three dA launches as ONE launch each (uia_wgrad_group): same shapes, same strides, per-problem pointers and dropout seeds
+        grouped = (direct and ops.LORA_WGRAD_GROUP and x2.is_cuda and dt == torch.bfloat16 and rp == 64 and len({bool(r_) for r_ in ctx.regen[:3]}) == 1
+                   and all(t_.shape == tq.shape and t_.stride() == tq.stride() for t_ in (tk, tv)) and all(h_.shape == hq.shape and h_.stride() == hq.stride() for h_ in (hk, hv))
+                   and all(P_.shape == Bq.shape for P_ in (Bk, Bv)) and all(P_.shape == aq.shape for P_ in (ak, av))
+                   and len({(b_ is not None and b_.requires_grad) for b_ in (bq, bk, bv)}) == 1)
+        for i, (bias, A, Bm, t, hd) in enumerate(trio):
             dsl = dqkv[:, i * D:(i + 1) * D]
             qi = q_all[i]
             ops.gemm(dsl, WEIGHTS.get(Bm, dt, transpose=True, pad_cols_to=rp), out_t=qi)
             if need_dx and not one_pass:
                 ops.gemm(qi, WEIGHTS.get(A, dt, transpose=True, pad_rows_to=rp), alpha=scaling, resid_t=dh, out_t=dh, drop=drop(i))
-            grads.append(_lora_grads(dsl, t, hd, qi, A, Bm, bias, scaling, direct, regen=(p_drop, seeds[i]) if ctx.regen[i] else None))
+            if not grouped:
+                grads.append(_lora_grads(dsl, t, hd, qi, A, Bm, bias, scaling, direct, regen=(p_drop, seeds[i]) if ctx.regen[i] else None))
+        if grouped:
+            want_b = bq is not None and bq.requires_grad
+            ops.wgrad_group([dqkv[:, i * D:(i + 1) * D] for i in range(3)], [tq, tk, tv], [Bq.grad, Bk.grad, Bv.grad],
+                            dbias_list=[bq.grad, bk.grad, bv.grad] if want_b else None, alpha=scaling)
+            ops.wgrad_group([q_all[i] for i in range(3)], [hq, hk, hv], [aq.grad, ak.grad, av.grad], alpha=scaling,
+                            drop=(p_drop, seeds[:3]) if ctx.regen[0] else None)
+            grads += [(None, None, None)] * 3
         if one_pass:
             ats = [WEIGHTS.get(A, dt, transpose=True, pad_rows_to=rp) for A in (aq, ak, av)]
             ops.lora_rank_update(q_all, [a.row if isinstance(a, ops.PackedW) else a for a in ats], dh, scaling, p_drop, seeds[:3])

@@ -9,7 +9,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import AttnDesc, GemmDesc, LnLoraDesc, LoraRankDesc, MonaFusedDesc, MonaSpatialDesc, PackDesc, UiaError, check, lib
+from ._lib import AttnDesc, GemmDesc, LnLoraDesc, LoraRankDesc, MonaFusedDesc, MonaSpatialDesc, PackDesc, UiaError, WgradGroupDesc, check, lib
 
 _ACT = {None: 0, "none": 0, "gelu": 1, "quick_gelu": 2, "relu": 3}
 
@@ -741,6 +741,41 @@ def wgrad(a, b, dw, dbias=None, alpha=1.0, drop=None):
     assert dw.shape[0] <= I and dw.shape[1] <= J and (dbias is None or dbias.numel() >= dw.shape[0])
     check(lib().uia_wgrad_ex(_stream(), _code(a.dtype), a.shape[0], I, J, _p(a), lda, _p(b), ldb, alpha, _p(dw), dw.shape[1], dw.shape[0], dw.shape[1],
                              _p(dbias)), "uia_wgrad_ex")
+
+
+LORA_WGRAD_GROUP = True   # LoRA attention block: the dB (and the dA) weight gradients of q, k and v in ONE launch each (uia_wgrad_group) instead of three; A/B: bench.py --no-lora-wgrad-group
+
+
+def wgrad_group(a_list, b_list, dw_list, dbias_list=None, alpha=1.0, drop=None):
+    """dw_list[g][I', J'] += alpha * a_list[g].T @ b_list[g] for up to four problems of one shape in one launch (uia_wgrad_group); dbias_list[g] += a_list[g].sum(0) where given.
+    drop = (p, seeds): b_list[g] holds UN-dropped rows of a contiguous [M, J] tensor and problem g's mask is regenerated from seeds[g] (as wgrad(drop=...) does)."""
+    n = len(a_list)
+    a0, b0, w0 = a_list[0], b_list[0], dw_list[0]
+    if not (1 <= n <= 4 and len(b_list) == n and len(dw_list) == n and a0.dtype == torch.bfloat16):
+        raise UiaError("wgrad_group: 1..4 bf16 problems")
+    lda, ldb = _rowmajor(a0, "a"), _rowmajor(b0, "b")
+    M, I, J = a0.shape[0], a0.shape[1], b0.shape[1]
+    d = WgradGroupDesc()
+    d.n, d.M, d.I, d.J, d.lda, d.ldb, d.ldw = n, M, I, J, lda, ldb, w0.shape[1]
+    d.i_valid, d.j_valid, d.alpha = w0.shape[0], w0.shape[1], alpha
+    for g in range(n):
+        a, b, w = a_list[g], b_list[g], dw_list[g]
+        if (a.dtype != torch.bfloat16 or b.dtype != torch.bfloat16 or tuple(a.shape) != (M, I) or tuple(b.shape) != (M, J) or _rowmajor(a, "a") != lda or _rowmajor(b, "b") != ldb
+                or w.dtype != torch.float32 or not w.is_contiguous() or w.shape != w0.shape or w.shape[0] > I or w.shape[1] > J):
+            raise UiaError(f"wgrad_group: problem {g} does not have the shape / strides / dtypes of problem 0")
+        d.A[g], d.B[g], d.dW[g] = a.data_ptr(), b.data_ptr(), w.data_ptr()
+        db = dbias_list[g] if dbias_list is not None else None
+        if db is not None:
+            assert db.dtype == torch.float32 and db.numel() >= w.shape[0]
+            d.dbias_A[g] = db.data_ptr()
+    if drop is not None:
+        p_, seeds = drop
+        if ldb != J or (dbias_list is not None and any(x is not None for x in dbias_list)):
+            raise UiaError("wgrad_group(drop=...): no bias, and each b must be the whole dropped tensor (contiguous rows)")
+        d.drop_p, d.drop_ld, d.drop_col0 = float(p_), J, 0
+        for g in range(n):
+            d.drop_seed[g] = int(seeds[g]) & 0xFFFFFFFFFFFFFFFF
+    check(lib().uia_wgrad_group(_stream(), _code(a0.dtype), C.byref(d)), "uia_wgrad_group")
 
 
 def _attn_desc(q, k, v, out, lse, B, H, L, mask, keylen, scale, dh=64):

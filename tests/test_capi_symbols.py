@@ -49,13 +49,15 @@ def test_descriptor_struct_sizes_match_c_layout():
     # ... and the same numbers from the C compiler itself (sizes and the offset of the last field of the GEMM descriptor)
     with tempfile.TemporaryDirectory() as td:
         src, exe = os.path.join(td, "s.c"), os.path.join(td, "s")
-        open(src, "w").write('#include <stdio.h>\n#include <stddef.h>\n#include "uia_hip.h"\nint main(void){ printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(uia_gemm_desc), '
+        open(src, "w").write('#include <stdio.h>\n#include <stddef.h>\n#include "uia_hip.h"\nint main(void){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(uia_gemm_desc), '
                              'sizeof(uia_attn_desc), sizeof(uia_mona_spatial_desc), offsetof(uia_gemm_desc, ln_flag_limit), sizeof(uia_mona_fused_desc), '
-                             'offsetof(uia_mona_fused_desc, t_out), sizeof(uia_lora_rank_desc), offsetof(uia_lora_rank_desc, seed)); return 0; }\n')
+                             'offsetof(uia_mona_fused_desc, t_out), sizeof(uia_lora_rank_desc), offsetof(uia_lora_rank_desc, seed), sizeof(uia_wgrad_group_desc), '
+                             'offsetof(uia_wgrad_group_desc, drop_seed), offsetof(uia_wgrad_group_desc, drop_col0)); return 0; }\n')
         subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), "-o", exe, src], check=True)
         got = [int(v) for v in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()]
     assert got == [ctypes.sizeof(_lib.GemmDesc), ctypes.sizeof(_lib.AttnDesc), ctypes.sizeof(_lib.MonaSpatialDesc), _lib.GemmDesc.ln_flag_limit.offset,
-                   ctypes.sizeof(_lib.MonaFusedDesc), _lib.MonaFusedDesc.t_out.offset, ctypes.sizeof(_lib.LoraRankDesc), _lib.LoraRankDesc.seed.offset]
+                   ctypes.sizeof(_lib.MonaFusedDesc), _lib.MonaFusedDesc.t_out.offset, ctypes.sizeof(_lib.LoraRankDesc), _lib.LoraRankDesc.seed.offset,
+                   ctypes.sizeof(_lib.WgradGroupDesc), _lib.WgradGroupDesc.drop_seed.offset, _lib.WgradGroupDesc.drop_col0.offset]
 
 
 def test_integration_md_ctypes_stub_is_the_real_descriptor():

@@ -895,3 +895,54 @@ def test_text_tower_ahead_of_the_previous_step_gives_the_same_steps():
     assert max(abs(a - b) for a, b in zip(*[o[0] for o in outs])) < 1e-5 and outs[0][0][2] != outs[0][0][0]
     d = (outs[0][1] - outs[1][1]).abs()                                  # (AdamW turns the last-bit noise of the float-atomic gradient sums into lr-sized steps where a gradient is ~0)
     assert float((d > 1e-3).float().mean()) < 1e-3 and float(d.mean()) < 1e-5
+
+
+@pytest.mark.parametrize("p_drop", [0.2, 0.0])
+def test_grouped_lora_weight_gradients_equal_the_separate_launches(p_drop):
+    """uia_wgrad_group (ops.LORA_WGRAD_GROUP): the dB launches of q, k, v as one launch and their dA launches — each regenerating its own dropout mask — as another
+    (reference lora.py:82-87 three times).  Same products per problem as uia_wgrad_ex / uia_wgrad_drop: the flat gradient buffer equals the six-launch form up to the
+    order of the float atomics."""
+    from uia_hip import functional as UF
+    from uia_hip import ops
+    from uia_hip.engine import FlatAdapterOptimizer
+    from src.third_party.openai_clip.model import ResidualAttentionBlock
+    from src.adapters.lora import PlainMultiheadAttentionLoRA
+    UF.set_compute_dtype(torch.bfloat16)
+    torch.manual_seed(6)
+    D, H, B, L = 256, 4, 40, 65
+    blk = ResidualAttentionBlock(D, H).to(dev())
+    for q in blk.parameters():
+        q.requires_grad_(False)
+    blk.attn = PlainMultiheadAttentionLoRA(blk.attn, r=16, lora_alpha=32, dropout_rate=p_drop).to(dev())
+    for k, q in blk.named_parameters():
+        q.requires_grad_("lora" in k.lower())
+        if "lora_B" in k:
+            torch.nn.init.normal_(q, std=0.05)
+    blk.train()
+    opt = FlatAdapterOptimizer([(k, q) for k, q in blk.named_parameters() if q.requires_grad], lr=1e-3)
+    x = torch.randn(L, B, D, device=dev(), requires_grad=True)
+    calls, outs = [], []
+    real = ops.wgrad_group
+
+    def counting(*a, **k):
+        calls.append(1)
+        return real(*a, **k)
+
+    ops.wgrad_group = counting
+    try:
+        for grouped in (True, False):
+            ops.LORA_WGRAD_GROUP = grouped
+            UF.set_dropout_seed(99)
+            opt.zero_grad()
+            x.grad = None
+            n0 = len(calls)
+            (blk(x).float() ** 2).mean().backward()
+            torch.cuda.synchronize()
+            outs.append((opt.g.clone(), x.grad.clone(), len(calls) - n0))
+    finally:
+        ops.wgrad_group = real
+        ops.LORA_WGRAD_GROUP = True
+    (g0, gx0, n_g), (g1, gx1, n_s) = outs
+    assert n_g == 2 and n_s == 0
+    assert torch.equal(gx0, gx1)
+    assert float(g1.abs().max()) > 0 and float((g0 - g1).abs().max()) <= 1e-5 * float(g1.abs().max())
