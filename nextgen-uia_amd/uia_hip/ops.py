@@ -300,10 +300,10 @@ class Ready:
         self.seen = {st.cuda_stream}
 
     def sync(self):
-        st = torch.cuda.current_stream()
-        if st.cuda_stream not in self.seen:
-            st.wait_event(self.event)
-            self.seen.add(st.cuda_stream)
+        rs = raw_stream()
+        if rs not in self.seen:
+            torch.cuda.current_stream().wait_event(self.event)
+            self.seen.add(rs)
 
 
 class PackedW:
@@ -419,10 +419,21 @@ def _p(t):
     return t.data_ptr()
 
 
+_HIP_OK = []
+
+
+def raw_stream():
+    """Handle of the current stream of the current device.  torch.cuda.current_stream() costs ~8 us of Python per call (device-index helpers, is_available, an
+    os.environ lookup, a Stream object); every launch and every cached-weight hit asks — 390 times per CLIPSeg step, 3 ms of an 11 ms host-bound step.  Two C calls."""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+
+
 def _stream():
-    if not torch.cuda.is_available():
-        raise UiaError("uia ops need an MI355X (HIP) device: there is no CPU fallback for the hot path")
-    return torch.cuda.current_stream().cuda_stream
+    if not _HIP_OK:
+        if not torch.cuda.is_available():
+            raise UiaError("uia ops need an MI355X (HIP) device: there is no CPU fallback for the hot path")
+        _HIP_OK.append(True)
+    return raw_stream()
 
 
 def _rowmajor(t, name):
@@ -885,6 +896,9 @@ def transpose_cast(src, dst):
     check(lib().uia_transpose_cast(_stream(), _code(dst.dtype), src.shape[0], src.shape[1], _p(src), _p(dst)), "uia_transpose_cast")
 
 
+_PIN_RING, _PIN_SLOTS, _PIN_SLOT = {}, 512, 4096
+
+
 def pack_table(entries, device):
     """Device-resident uia_pack_desc table for `entries` = [(src fp32 [R, C], row, row_kb, tr, tr_kb[, (rows_pad, cols_pad, scale)])] (None = form
     not wanted).  With the optional sixth element the destinations hold rows_pad x cols_pad elements (zero padding kept by the caller: the
@@ -906,6 +920,22 @@ def pack_table(entries, device):
                 assert t.is_contiguous() and t.numel() == RP * CP and t.device == src.device
                 setattr(d, name, _p(t))
         max_elems = max(max_elems, R * Cc)
+    nbytes = C.sizeof(arr)
+    dev = torch.device(device)
+    if dev.type == "cuda" and nbytes <= _PIN_SLOT:
+        # through a ring of PINNED host slots and an asynchronous copy: a pageable host-to-device copy waits for the stream, and a step that builds derived weights
+        # (CLIPSeg's decoder: concatenated q | k | v, conv kernels as GEMM weights — new tensors every step) paid that wait six times (1.4 ms of a host-bound 10 ms step).
+        # 512 slots: the host cannot run 512 pack launches ahead of the device.
+        key = dev.index if dev.index is not None else torch.cuda.current_device()
+        ring = _PIN_RING.get(key)
+        if ring is None:
+            ring = _PIN_RING[key] = [torch.empty(_PIN_SLOTS, _PIN_SLOT, dtype=torch.uint8).pin_memory(), 0]
+        slot = ring[0][ring[1]]
+        ring[1] = (ring[1] + 1) % _PIN_SLOTS
+        C.memmove(slot.data_ptr(), C.addressof(arr), nbytes)
+        table = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        table.copy_(slot[:nbytes], non_blocking=True)
+        return table, len(entries), max_elems
     raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone()
     return raw.to(device), len(entries), max_elems
 
