@@ -34,3 +34,16 @@ N = 5
 for _ in range(N): l = contrastive_step(model, crit, opt, images, ids)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / N
 print(f"ViT-L/14 + LoRA r=16, bs={B} bf16: {dt*1e3:.2f} ms/step, {B/dt:.1f} pairs/s, loss {float(l):.4f}, peak mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB")
+
+# host side: how long the enqueue of one step takes against the step, and the top Python frames
+import cProfile, pstats
+enq, tot = [], []
+for _ in range(4):
+    t0 = time.perf_counter(); contrastive_step(model, crit, opt, images, ids); t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+    enq.append(round((t1 - t0) * 1e3, 1)); tot.append(round((t2 - t0) * 1e3, 1))
+print("enqueue ms", enq, "total ms", tot)
+if "--profile" in sys.argv:
+    pr = cProfile.Profile(); pr.enable()
+    for _ in range(3): contrastive_step(model, crit, opt, images, ids)
+    pr.disable(); torch.cuda.synchronize()
+    pstats.Stats(pr).sort_stats("tottime").print_stats(22)
