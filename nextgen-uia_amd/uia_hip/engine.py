@@ -254,15 +254,12 @@ GRAD_RESID3 = True      # the residual gradient between a frozen tower's backwar
 
 
 def _hook_free(model):
-    """No forward / backward hooks anywhere in the model: nothing but the towers' own Functions reads the tensors between them (checked once per model)."""
-    ok = getattr(model, "_uia_hook_free", None)
-    if ok is None:
-        ok = not any(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or getattr(m, "_backward_pre_hooks", None) for m in model.modules())
-        try:
-            model._uia_hook_free = ok
-        except Exception:
-            pass
-    return ok
+    """No forward / backward hooks anywhere in the model: nothing but the towers' own Functions reads the tensors between them.  Looked at every step (a hook registered
+    after the first step must switch the three-byte hand-off off): ~400 modules, three dict truth tests each."""
+    for m in model.modules():
+        if m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or getattr(m, "_backward_pre_hooks", None):
+            return False
+    return True
 
 
 TEXT_SLICES = 1         # experiment knob: the (frozen, forward-only) text tower in this many equal slices on as many streams when the image tower is split
@@ -271,14 +268,8 @@ IMAGE_SPLIT = 0.5       # fraction of a micro-batch's images that form the FIRST
 
 
 def _frozen_text(model):
-    ok = getattr(model, "_uia_frozen_text", None)
-    if ok is None:
-        ok = all(k.startswith("visual.") for k, p in model.named_parameters() if p.requires_grad)      # conservative: every trainable parameter lives in the image tower
-        try:
-            model._uia_frozen_text = ok
-        except Exception:
-            pass
-    return ok
+    """Every trainable parameter lives in the image tower (conservative; looked at every step the caller passes inputs_ready — a tower unfrozen later must bring the wait back)."""
+    return all(k.startswith("visual.") for k, p in model.named_parameters() if p.requires_grad)
 
 
 def contrastive_step(model, criterion, opt, images, ids, micro_batches=1, lr=None, overlap_text=True, global_loss=False, streams=1, image_split=None, inputs_ready=False):
