@@ -45,8 +45,11 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap-text", action="store_true", help=argparse.SUPPRESS)           # the default since round 4 (kept so that old command lines still parse)
     ap.add_argument("--no-overlap-text", action="store_true", help="run the frozen text tower on the image tower's stream.  Default (round 4): on a second HIP "
-                    "stream beside encode_image, as the entry points do (contrastive_step(overlap_text=True), +2.5 % pairs/s); `roofline` then comes from one "
+                    "stream beside encode_image (engine.contrastive_micro(overlap_text=True), also what the fine-tune entry points run; +2.5 % pairs/s); `roofline` then comes from one "
                     "extra untimed step with both towers on ONE stream, where a launch's HIP events see only that launch (and agree with rocprofv3)")
+    ap.add_argument("--no-entry-point", action="store_true", help="skip the `entry_point` form: the fine-tune CLI (src/models/biomedclip/finetune.py --method mona --synthetic, bs 256, "
+                    "one update per batch) run as a child process after the timed region, its steady-state ms per update printed beside the headline")
+    ap.add_argument("--entry-steps", type=int, default=60, help="updates per epoch of the entry-point run (3 epochs; the first is warm-up)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the two secondary lines (BASELINE configs[3] and the per-GPU shape of configs[4], 10 steps each, "
                     "no CPU leg) that the default single-GPU run prints under `secondary`")
     ap.add_argument("--also-streams", type=int, default=1, help="after the timed region, time 5 more steps each of two other forms of the step (everything on one stream; the text tower on "
@@ -363,6 +366,13 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
+    if not args.batch:
+        args.batch = 256 if args.config == "mona" else 128
+    args.entry_point_result = None
+    if world == 1 and args.config == "mona" and not args.no_entry_point and not args.no_overlap_text and args.streams == 1:
+        # FIRST, before this process has touched the GPU (a program started from a process with a live HIP runtime is not allowed on this pool, and the two would share the
+        # device): the fine-tune CLI as a child process, run to completion; its figure is attached to the line below
+        args.entry_point_result = entry_point_form(args, f"cuda:{local}")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if not args.batch:
@@ -419,8 +429,9 @@ def main():
         out["secondary"] = secondary_lines(args, device)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if ops.comm_world_initialised():
         ops.comm_destroy()
+    if world > 1:
         torch.distributed.destroy_process_group()
 
 
@@ -444,10 +455,45 @@ def secondary_lines(args, device):
             lines[cfg] = {"metric": o["metric"], "value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"], "steps": o["steps"], "warmup": o["warmup"],
                           "dtype": o["dtype"], "data": o["data"], "config": o["config"], "loss": o["loss"],
                           "roofline": {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "launches_per_step", "avg_launch_us",
-                                                             "share_of_step", "whole_step_frac_of_peak", "gemm_family")}}
+                                                             "share_of_step", "whole_step_frac_of_peak", "gflop_per_image_executed", "whole_step_frac_of_peak_executed", "executed_note", "gemm_family")}}
         except Exception as e:                      # a secondary line must never cost the headline
             lines[cfg] = {"error": f"{type(e).__name__}: {e}"}
     return lines
+
+
+def entry_point_form(args, device):
+    """The north-star boundary itself, timed: `python src/models/biomedclip/finetune.py --method mona --synthetic --batch_size 256 --accumulation_steps 1` as a CHILD
+    process (its loader workers fork before it touches the GPU), three epochs of --entry-steps updates; the first epoch is warm-up, the figure is the wall time of the
+    other two (first micro-batch enqueued -> device idle after the last update, engine.ContrastiveLoop / DevicePrefetcher) over their updates.  Same engine functions
+    as the timed region above (contrastive_micro + guarded accumulate / update); on top of them the real loader: batches generated by worker processes, pinned, copied
+    host-to-device on a copy stream, tokenised on the host."""
+    import subprocess
+    import tempfile
+    script = os.path.join(ROOT, "nextgen-uia_amd", "src", "models", "biomedclip", "finetune.py")
+    with tempfile.TemporaryDirectory() as td:
+        stats = os.path.join(td, "stats.json")
+        cmd = [sys.executable, script, "--method", "mona", "--mona_variant", args.variant, "--synthetic", "--synthetic_train", str(args.batch * args.entry_steps),
+               "--synthetic_val", str(args.batch), "--batch_size", str(args.batch), "--accumulation_steps", "1", "--epochs", "3", "--patience", "99", "--dtype", args.dtype,
+               "--exp", "bench_entry_point", "--device", str(device), "--stats_json", stats]
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, cwd=td, capture_output=True, text=True, timeout=420)
+        except subprocess.TimeoutExpired:
+            return {"error": "the entry-point child process did not finish in 420 s", "command": " ".join(cmd[1:])}
+        except OSError as e:
+            return {"error": f"could not start the entry-point child process: {e}", "command": " ".join(cmd[1:])}
+        wall = time.perf_counter() - t0
+        if r.returncode != 0 or not os.path.exists(stats):
+            return {"error": f"exit code {r.returncode}", "stderr_tail": r.stderr[-1500:], "command": " ".join(cmd[1:])}
+        out = json.load(open(stats))
+    steady = out["epochs"][1:]
+    ms = sum(e["ms"] for e in steady) / max(1, sum(e["updates"] for e in steady))
+    return {"ms_per_step": round(ms, 3), "value": round(args.batch / ms * 1e3, 2), "unit": "images/s", "vs_headline_ms": None,
+            "epochs": [{"ms": round(e["ms"], 1), "updates": e["updates"]} for e in out["epochs"]], "updates": out["updates"], "last_train_loss": round(out["last_train"], 5),
+            "child_wall_s": round(wall, 1),
+            "what": "src/models/biomedclip/finetune.py main() as a child process: synthetic pairs from loader workers -> pinned staging -> copy stream -> engine.ContrastiveLoop "
+                    "(contrastive_micro + device-guarded accumulate / clip + AdamW, cosine LR on the device) ; epochs 2-3 of 3, wall time per optimiser update",
+            "command": "python " + " ".join(os.path.relpath(c, ROOT) if c == script else c for c in cmd[1:-1]) + " <tmp>"}
 
 
 def _image_split_on(args):
@@ -476,7 +522,7 @@ def bench_mona(args, rank, world, device):
     model.train()                                                    # Mona dropout p=0.1 active (finetune.py:218)
     opt = FlatAdapterOptimizer([(k, p) for k, p in model.named_parameters() if p.requires_grad], lr=1e-4, betas=(0.9, 0.95),
                                weight_decay=0.01, max_norm=1.0)
-    init_data_parallel(opt)
+    init_data_parallel(opt, force_comm=True)                 # world 1 too: the one-rank RCCL communicator, so that the N = 1 line already times uia_allreduce_sum
     criterion = InfoNCELoss(0.07)
     images, ids = synthetic_batch(args.batch, rank, device)
     UF.set_dropout_seed(1234 + rank)
@@ -540,7 +586,7 @@ def bench_mona(args, rank, world, device):
                                   "InfoNCE, clip+AdamW; random-init weights",
                       "mona_variant": args.variant, "batch_per_gpu": args.batch, "global_batch": args.batch * world, "image": "3x224x224",
                       "text_len": 256, "text_positions_computed": "valid tokens only (opt-in --unpad-text)" if args.unpad_text else "all 256",
-                      "parallelism": f"dp{world}", "text_tower_stream": ("second HIP stream beside the image tower, whose two half-batch slices run on two streams (engine.IMAGE_SPLIT; the entry points' default); roofline from one extra step with everything on one stream"
+                      "parallelism": f"dp{world}", "text_tower_stream": ("second HIP stream beside the image tower, whose two half-batch slices run on two streams (engine.IMAGE_SPLIT: engine.contrastive_micro, the function the fine-tune entry points call per loader batch — `entry_point` below is that CLI timed); roofline from one extra step with everything on one stream"
                                             if args.overlap_text else "same stream"),
                       "text_tower_start": ("as soon as enqueued (inputs resident, tower frozen: its stream does not wait for the previous step's backward / optimiser; every step computes its own text features)"
                                            if (args.overlap_text and args.streams == 1 and not args.no_text_ahead) else "behind the previous step"),
@@ -553,6 +599,11 @@ def bench_mona(args, rank, world, device):
            "loss": round(final_loss, 5), "roofline": roof}
     out.update(dist_fields(world, per_rank, args.steps, ops))
     out["other_forms"] = multi
+    ep = getattr(args, "entry_point_result", None)
+    if ep is not None:
+        if "ms_per_step" in ep:
+            ep["vs_headline_ms"] = round(ep["ms_per_step"] / ms, 4)
+        out["entry_point"] = ep
     out["cpu_baseline"] = cpu_baseline(cpu_state, args.variant, args.cpu_batch, args.cpu_steps, wide=not args.no_cpu_wide) if cpu_state is not None else None
     return out
 
@@ -567,6 +618,9 @@ def bench_clipseg(args, rank, world, device):
     from src.models.clipseg import segmentation as S
     from src.losses.dice import DiceCELoss
     GF = 36.5
+    # executed per image in the steady state: blocks 10-11 of the frozen ViT are never run (their outputs reach nothing: clipseg_adapter.py extract layers 3/6/9),
+    # and the one prompt's text features are a cached constant of the run: 29.31 (ViT blocks 0-9 + patch embed) + 0.45 + 0.90 (decoder fwd + bwd)
+    GF_EXEC = 29.31 + 0.45 + 0.90
     sargs = S.get_args(["--synthetic", "--batch_size", str(args.batch)])
     sargs.device = str(device)
     torch.manual_seed(0)
@@ -574,7 +628,7 @@ def bench_clipseg(args, rank, world, device):
         model = S.prepare_model(sargs)
     cpu_state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()} if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
     opt = FlatAdapterOptimizer([(n, p) for n, p in model.named_parameters() if p.requires_grad], lr=1e-4, betas=(0.9, 0.999), max_norm=0.0)
-    init_data_parallel(opt)
+    init_data_parallel(opt, force_comm=True)                 # world 1 too: the one-rank RCCL communicator, so that the N = 1 line already times uia_allreduce_sum
     crit = DiceCELoss()
     images, labels = S.synthetic_batch(args.batch, 224, 1 + rank, str(device))
     prompt = S.busi_prompt.to(device).repeat(args.batch, 1)
@@ -597,6 +651,9 @@ def bench_clipseg(args, rank, world, device):
     roof = gemm_roofline(prof, prof_serial, args, ms, ops, torch)
     if roof is not None:
         roof["whole_step_frac_of_peak"] = round(value / world * GF * 1e-3 / peak, 4)
+        roof["gflop_per_image_executed"] = round(GF_EXEC, 2)
+        roof["whole_step_frac_of_peak_executed"] = round(value / world * GF_EXEC * 1e-3 / peak, 4)
+        roof["executed_note"] = "ViT blocks 10-11 (5.8 GF) are skipped and the prompt tower (5.96 GF per distinct prompt) is cached: the algorithmic count includes both, the executed one neither"
     out = {"metric": "images/sec fwd+bwd CLIPSeg ViT-B/16 + FiLM decoder bs=128 (BASELINE configs[3]; secondary line)", "value": round(value, 2),
            "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
@@ -647,7 +704,7 @@ def bench_vitl_lora(args, rank, world, device):
     trainable_names = [k for k, p in model.named_parameters() if p.requires_grad]
     model = model.to(device).train()
     opt = FlatAdapterOptimizer([(k, p) for k, p in model.named_parameters() if p.requires_grad], lr=1e-4, betas=(0.9, 0.95), weight_decay=0.01, max_norm=1.0)
-    init_data_parallel(opt)
+    init_data_parallel(opt, force_comm=True)                 # world 1 too: the one-rank RCCL communicator, so that the N = 1 line already times uia_allreduce_sum
     g = torch.Generator().manual_seed(1 + rank)
     B = args.batch
     images = torch.rand(B, 3, 224, 224, generator=g)
@@ -670,6 +727,9 @@ def bench_vitl_lora(args, rank, world, device):
     roof = gemm_roofline(prof, prof_serial, args, ms, ops, torch)
     if roof is not None:
         roof["whole_step_frac_of_peak"] = round(value / world * GF * 1e-3 / peak, 4)
+        roof["gflop_per_image_executed"] = GF
+        roof["whole_step_frac_of_peak_executed"] = roof["whole_step_frac_of_peak"]
+        roof["executed_note"] = "nothing is skipped or cached in this step: LoRA in rank form is what SURVEY's 335 GF counts, the text tower runs all 77 positions every step"
     out = {"metric": "images/sec fwd+bwd ViT-L/14 + LoRA r=16, 128 pairs/GPU (per-GPU shape of BASELINE configs[4]; secondary line)", "value": round(value, 2),
            "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",

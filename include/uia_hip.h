@@ -470,6 +470,23 @@ int uia_infonce_fwd_bwd(void* stream, int B, int E, const float* img, const floa
 int uia_adamw_clip_step(void* stream, size_t n, float* p, const float* g, float* m, float* v, float lr, float beta1, float beta2,
                         float eps, float weight_decay, float max_norm, int step, float grad_scale, float* ws2);
 
+/* Guarded forms for loops that never read the loss on the host (round 5).  The reference decides per micro-batch on the host
+ * (src/models/biomedclip/finetune.py:281-285: a non-finite loss skips the backward AND the update check of that iteration);
+ * these take the same two decisions on the device.
+ *   uia_grad_accum_guarded: mb[0..n) is the staging buffer one micro-batch's backward wrote; when *loss is finite it is added to
+ *     acc[0..n), mb is zeroed either way.  acc has n + 4 floats: acc[n] = 0 (finite) / 1 (not) for THIS micro-batch — all-reduced
+ *     with the gradients it becomes "ranks whose boundary micro-batch was non-finite".  stats[0] += loss (finite only);
+ *     ctl (4 x int32): [0] updates applied, [1] micro-batches accumulated, [2] micro-batches skipped, [3] updates skipped;
+ *     ok_log (optional): ok_log[log_index] = 1 / 0 for the host's end-of-epoch log.
+ *   uia_adamw_clip_step_guarded: one clip + AdamW update from acc when acc[n] == 0, acc zeroed in the same pass (zero_grad);
+ *     otherwise nothing but acc *= skip_scale (1/world under data parallelism: the summed buffer becomes this rank's share again).
+ *     The update index t = ctl[0] lives on the device: lr = lr_min + (lr - lr_min)(1 + cos(pi t / t_max))/2 (CosineAnnealingLR,
+ *     finetune.py:255; t_max = 0: constant lr) and the bias corrections use step t + 1, so a skipped update does not advance
+ *     the schedule.  ws8: 8 floats of device scratch; ws8[0] returns the squared gradient norm, ws8[1] whether the update ran. */
+int uia_grad_accum_guarded(void* stream, size_t n, float* acc, float* mb, const float* loss, float* stats, int32_t* ctl, uint8_t* ok_log, int64_t log_index);
+int uia_adamw_clip_step_guarded(void* stream, size_t n, float* p, float* acc, float* m, float* v, float lr, float lr_min, int t_max, float beta1, float beta2,
+                                float eps, float weight_decay, float max_norm, float grad_scale, float skip_scale, float* ws8, int32_t* ctl);
+
 /* ---------------------------------------------------------------------------------------------
  * Data-parallel exchange (new: the reference is single-process, finetune.py:287-302 accumulates
  * instead).  RCCL all-reduce on the caller's stream; the unique id travels through the host.

@@ -135,6 +135,13 @@ int uia_adamw_clip_step(void* stream, size_t n, float* p, const float* g, float*
                         float weight_decay, float max_norm, int step, float grad_scale, float* ws2) {
     return uia_adamw_clip_launch((hipStream_t)stream, n, p, g, m, v, lr, beta1, beta2, eps, weight_decay, max_norm, step, grad_scale, ws2);
 }
+int uia_grad_accum_guarded(void* stream, size_t n, float* acc, float* mb, const float* loss, float* stats, int32_t* ctl, uint8_t* ok_log, int64_t log_index) {
+    return uia_grad_accum_guarded_launch((hipStream_t)stream, n, acc, mb, loss, stats, (int*)ctl, ok_log, (long)log_index);
+}
+int uia_adamw_clip_step_guarded(void* stream, size_t n, float* p, float* acc, float* m, float* v, float lr, float lr_min, int t_max, float beta1, float beta2,
+                                float eps, float weight_decay, float max_norm, float grad_scale, float skip_scale, float* ws8, int32_t* ctl) {
+    return uia_adamw_clip_guarded_launch((hipStream_t)stream, n, p, acc, m, v, lr, lr_min, t_max, beta1, beta2, eps, weight_decay, max_norm, grad_scale, skip_scale, ws8, (int*)ctl);
+}
 
 int uia_dropout(void* stream, int dtype, size_t n, const void* src, void* dst, float p, uint64_t seed, int accumulate) {
     return uia_dropout_launch((hipStream_t)stream, dtype, n, src, dst, p, seed, accumulate);

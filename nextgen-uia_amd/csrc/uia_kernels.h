@@ -50,6 +50,9 @@ int uia_infonce_launch(hipStream_t stream, int B, int E, const float* img, const
                        float* dimg, float* dtxt, float* ws, size_t ws_floats);
 int uia_adamw_clip_launch(hipStream_t stream, size_t n, float* p, const float* g, float* m, float* v, float lr, float beta1, float beta2,
                           float eps, float weight_decay, float max_norm, int step, float grad_scale, float* ws);
+int uia_grad_accum_guarded_launch(hipStream_t stream, size_t n, float* acc, float* mb, const float* loss, float* stats, int* ctl, unsigned char* ok_log, long log_index);
+int uia_adamw_clip_guarded_launch(hipStream_t stream, size_t n, float* p, float* acc, float* m, float* v, float lr, float lr_min, int t_max, float beta1,
+                                  float beta2, float eps, float weight_decay, float max_norm, float grad_scale, float skip_scale, float* ws8, int* ctl);
 int uia_dropout_launch(hipStream_t stream, int dtype, size_t n, const void* src, void* dst, float p, uint64_t seed, int accumulate);
 int uia_colsum_launch(hipStream_t stream, int dtype, int M, int N, const void* A, long lda, float* out);
 int uia_attn_small_launch(hipStream_t stream, int dtype, const UiaAttnParams& p, bool bwd);

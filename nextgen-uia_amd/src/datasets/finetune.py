@@ -94,18 +94,55 @@ class DataModule:
                                "which is outside this build)")
         self.train_sampler = self.val_sampler = None
 
+    MAX_WORKERS = 6         # loader processes per rank (the reference's --num_workers default is 8; a one-GPU job's CPU share on the MI355X boxes is 16)
+
     def _loader(self, ds, shuffle):
+        nw = max(0, min(int(getattr(self.args, "num_workers", 0) or 0), self.MAX_WORKERS if shuffle else 2))     # the validation loader: two workers
+        if nw and torch.cuda.is_initialized():
+            # worker processes are forked, and a child forked from a process with a live HIP runtime inherits its device handles: fork before the GPU is touched (the entry
+            # points build the DataModule and call start_workers() first) or load in-process
+            import logging
+            logging.info("loader: the GPU is already initialised in this process; loading in-process (num_workers=0)")
+            nw = 0
+        if nw:
+            # every in-flight batch of a worker sits in /dev/shm until the consumer has copied it: never plan for more than half of what is free there
+            import shutil
+            per_batch = self.args.batch_size * 3 * self.args.img_size ** 2 * 4
+            try:
+                room = shutil.disk_usage("/dev/shm").free // 2
+            except OSError:
+                room = 0
+            nw = max(0, min(nw, room // max(1, 3 * per_batch)))
+        kw = dict(num_workers=nw, drop_last=True)
+        if nw:
+            kw.update(persistent_workers=True, prefetch_factor=2)
         if self.world > 1:
             sampler = RankShardSampler(len(ds), self.rank, self.world, shuffle=shuffle, seed=getattr(self.args, "seed", 0))
-            return DataLoader(ds, batch_size=self.args.batch_size, sampler=sampler, num_workers=0, drop_last=True), sampler
-        return DataLoader(ds, batch_size=self.args.batch_size, shuffle=shuffle, num_workers=0, drop_last=True), None
+            return DataLoader(ds, batch_size=self.args.batch_size, sampler=sampler, **kw), sampler
+        return DataLoader(ds, batch_size=self.args.batch_size, shuffle=shuffle, **kw), None
+
+    def start_workers(self):
+        """Fork the loaders' worker processes NOW — the entry points call this before the process has touched the GPU, so that no child is forked from a process
+        with a live HIP runtime.  (Persistent workers: every later iter(loader) re-uses them.)"""
+        for loader in getattr(self, "_loaders", []):
+            if loader.num_workers > 0 and len(loader) > 0:
+                iter(loader)
+
+    def shutdown(self):
+        for loader in getattr(self, "_loaders", []):
+            it = getattr(loader, "_iterator", None)
+            if it is not None and hasattr(it, "_shutdown_workers"):
+                it._shutdown_workers()
+            loader._iterator = None
 
     def train_dataloader(self):
         loader, self.train_sampler = self._loader(self.train, True)
+        self._loaders = getattr(self, "_loaders", []) + [loader]
         return loader
 
     def val_dataloader(self):
         loader, self.val_sampler = self._loader(self.val, False)
+        self._loaders = getattr(self, "_loaders", []) + [loader]
         return loader
 
     def set_epoch(self, epoch):

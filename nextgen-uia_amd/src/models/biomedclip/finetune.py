@@ -19,6 +19,7 @@ import math
 import os
 import random
 import sys
+import time
 from pathlib import Path
 
 sys.path.insert(0, str(Path(__file__).resolve().parents[3]))
@@ -32,7 +33,7 @@ from src.losses import InfoNCELoss
 from src.third_party.biomedclip.model import SyntheticTokenizer, create_biomedclip
 from src.utils.tools import model_summary, parse_config, setup_logging
 from uia_hip import functional as UF
-from uia_hip.engine import FlatAdapterOptimizer, all_ranks_agree, bind_device, cosine_lr, init_data_parallel, sum_over_ranks
+from uia_hip.engine import ContrastiveLoop, DevicePrefetcher, FlatAdapterOptimizer, bind_device, dist_env, init_data_parallel, sum_over_ranks
 
 
 def get_args(argv=None):
@@ -63,7 +64,7 @@ def get_args(argv=None):
     p.add_argument("--weight_decay", type=float, default=0.01)
     p.add_argument("--beta1_adam", type=float, default=0.9)
     p.add_argument("--beta2_adam", type=float, default=0.95)
-    p.add_argument("--device", type=str, default="cuda:0" if torch.cuda.is_available() else "cpu")
+    p.add_argument("--device", type=str, default="cuda:0" if torch.cuda.device_count() > 0 else "cpu")       # device_count() does not initialise the GPU: the loader workers fork first
     p.add_argument("--patience", type=int, default=10)
     p.add_argument("--accumulation_steps", type=int, default=4)
     p.add_argument("--grad_clip", type=float, default=1.0)
@@ -75,6 +76,7 @@ def get_args(argv=None):
     p.add_argument("--data_pt", type=str, default=None, help=".pt with {'images': [N,3,S,S], 'texts': [str]}")
     p.add_argument("--ckpt_path", type=str, default=None, help="open_clip BiomedCLIP state dict (.pt); random init if absent")
     p.add_argument("--model_config", type=str, default=None, help="python dict literal overriding the BiomedCLIP geometry (tests)")
+    p.add_argument("--stats_json", type=str, default=None, help="write train()'s return value (per-epoch wall time and update counts included) to this file")
     return p.parse_args(argv)
 
 
@@ -138,14 +140,20 @@ def _save_checkpoint(model, args, save_path):
 
 
 def train(args):
-    rank, _, world = bind_device(args)                         # data parallel: cuda:LOCAL_RANK before anything is allocated
+    """The loop of reference :211-361 on the measured step: every loader batch goes through engine.ContrastiveLoop.micro (contrastive_micro: text tower on its
+    own stream, image tower in two slices, three-byte residual gradients; guarded accumulate) and every accumulation boundary through the device-guarded
+    clip + AdamW — the same functions bench.py times.  The host reads nothing per batch: the non-finite skip (:281-285) is decided on the device, the epoch's
+    loss sum / counts / skipped indices come back in ONE read at the end of the epoch, batches arrive through a double-buffered prefetcher."""
+    rank, _, world = dist_env()
+    dm = dataset_finetune.DataModule(args, rank=rank, world=world)
+    trainloader, valloader = dm.train_dataloader(), dm.val_dataloader()
+    dm.start_workers()                                         # loader worker processes are forked BEFORE this process touches the GPU
+    bind_device(args)                                          # data parallel: cuda:LOCAL_RANK before anything is allocated
     UF.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
     UF.set_dropout_seed(args.seed + 7919 * rank)                # ranks draw different dropout masks, like different micro-batches
     model, tokenizer = prepare_model(args)
     model.train()
     logging.info(model_summary({"model": model}))
-    dm = dataset_finetune.DataModule(args, rank=rank, world=world)
-    trainloader, valloader = dm.train_dataloader(), dm.val_dataloader()
     criterion = InfoNCELoss(temperature=args.temperature)
     opt = FlatAdapterOptimizer([(n, p) for n, p in model.named_parameters() if p.requires_grad], lr=args.lr,
                                betas=(args.beta1_adam, args.beta2_adam), weight_decay=args.weight_decay, max_norm=args.grad_clip)
@@ -154,41 +162,39 @@ def train(args):
     updates_per_epoch = math.ceil(len(trainloader) / args.accumulation_steps)
     total_updates = updates_per_epoch * args.epochs
     logging.info(f"Gradient accumulation steps: {args.accumulation_steps}; updates per epoch: {updates_per_epoch}; world: {world}")
+    loop = ContrastiveLoop(model, criterion, opt, accumulation_steps=args.accumulation_steps, lr=args.lr, lr_min=args.lr_min, total_updates=total_updates)
+    train_pf = DevicePrefetcher(trainloader, tokenizer, args.device)
+    val_pf = DevicePrefetcher(valloader, tokenizer, args.device)
 
-    update_count, best_loss, best_epoch, patience = 0, float("inf"), 0, 0
-    avg_train = 0.0
-    opt.zero_grad()
+    best_loss, best_epoch, patience = float("inf"), 0, 0
+    avg_train, update_count, epoch_ms = 0.0, 0, []
+    dm.set_epoch(0)
+    batches = iter(train_pf)                                    # the producer starts now: the first batches are resident when the epoch begins
     for epoch in range(args.epochs):
         model.train()
-        dm.set_epoch(epoch)
-        ep_loss, ep_n = 0.0, 0
-        for batch_idx, (images, texts) in enumerate(trainloader):
-            images = images.to(args.device)
-            tokens = tokenizer(list(texts)).to(args.device)
-            loss = criterion(model.encode_image(images), model.encode_text(tokens))
-            # reference :281-285 skips a non-finite micro-batch (and with it the update check of that iteration).  Under data
-            # parallelism the decision is COLLECTIVE: a rank that skipped alone would miss opt.all_reduce() below while the
-            # others wait in it, so every rank skips when any rank's loss is non-finite (same control flow everywhere).
-            if not all_ranks_agree(bool(torch.isfinite(loss))):
-                logging.warning(f"Non-finite loss detected at batch {batch_idx} in epoch {epoch + 1}, skipping batch")
-                continue
-            (loss / args.accumulation_steps).backward()
-            ep_loss += loss.item()
-            ep_n += 1
-            if ((batch_idx + 1) % args.accumulation_steps == 0) or (batch_idx + 1 == len(trainloader)):
-                opt.all_reduce()
-                update_count += 1
-                opt.step(lr=cosine_lr(args.lr, args.lr_min, update_count - 1, total_updates))
-                opt.zero_grad()
-                UF.clear_t_copies()
+        loop.begin_epoch(len(trainloader))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for batch_idx, (images, tokens, ready) in enumerate(batches):
+            loop.micro(images, tokens, batch_idx, ready=ready)
+        g = loop.end_epoch()                                     # the epoch's one host read (reference: loss.item() per batch, :290)
+        epoch_ms.append({"ms": (time.perf_counter() - t0) * 1e3, "updates": g["updates"] - update_count, "batches": len(trainloader)})
+        update_count = g["updates"]
+        for i in g["skipped_batches"]:
+            logging.warning(f"Non-finite loss detected at batch {i} in epoch {epoch + 1}, skipping batch")
+        ep_loss, ep_n = g["loss_sum"], g["epoch_accumulated"]
+        if epoch + 1 < args.epochs:                              # next epoch's first batches load while this epoch validates
+            dm.set_epoch(epoch + 1)
+            batches = iter(train_pf)
         model.eval()
-        val_loss, val_n = 0.0, 0
+        vstat = torch.zeros(2, device=args.device)
         with torch.no_grad():
-            for images, texts in valloader:
-                loss = criterion(model.encode_image(images.to(args.device)), model.encode_text(tokenizer(list(texts)).to(args.device)))
-                if torch.isfinite(loss):
-                    val_loss += loss.item()
-                    val_n += 1
+            for images, tokens, ready in val_pf:
+                torch.cuda.current_stream().wait_event(ready)
+                loss = criterion(model.encode_image(images), model.encode_text(tokens))
+                ok = torch.isfinite(loss)
+                vstat += torch.stack([torch.where(ok, loss, torch.zeros_like(loss)), ok.to(loss.dtype)])
+        val_loss, val_n = vstat.tolist()
         # every rank evaluated its own shard: the epoch's figures are the sums over ranks, so that the checkpoint / patience /
         # early-stop decisions below are identical on every rank (a rank that stopped alone would strand the others)
         val_loss, val_n, ep_loss, ep_n = sum_over_ranks(val_loss, val_n, ep_loss, ep_n)
@@ -205,12 +211,13 @@ def train(args):
             logging.info(f"\nEarly stopping at epoch {epoch + 1} as validation loss did not improve for {args.patience} epochs.")
             break
     logging.info(f"\n✓ Training completed! Best validation loss: {best_loss:.4f} at epoch {best_epoch + 1}")
+    dm.shutdown()
     if world > 1:
         from uia_hip import ops
         import torch.distributed as dist
         dist.barrier()
         ops.comm_destroy()
-    return {"best_val": best_loss, "updates": update_count, "last_train": avg_train, "rank": rank, "world": world}
+    return {"best_val": best_loss, "updates": update_count, "last_train": avg_train, "rank": rank, "world": world, "epochs": epoch_ms}
 
 
 def main(argv=None):
@@ -221,7 +228,12 @@ def main(argv=None):
     args.train_snapshot_path = f"runs/{args.exp}"
     os.makedirs(args.train_snapshot_path, exist_ok=True)
     setup_logging(args, args.train_snapshot_path)
-    return train(args)
+    out = train(args)
+    if args.stats_json and out.get("rank", 0) == 0:
+        import json
+        with open(args.stats_json, "w") as f:
+            json.dump(out, f)
+    return out
 
 
 if __name__ == "__main__":

@@ -13,6 +13,7 @@ import logging
 import os
 import random
 import sys
+import time
 from pathlib import Path
 
 sys.path.insert(0, str(Path(__file__).resolve().parents[3]))
@@ -26,7 +27,7 @@ from src.losses import InfoNCELoss
 from src.third_party.open_clip.model import SyntheticClipTokenizer, create_metaclip
 from src.utils.tools import model_summary, parse_config, setup_logging
 from uia_hip import functional as UF
-from uia_hip.engine import FlatAdapterOptimizer, all_ranks_agree, bind_device, cosine_lr, init_data_parallel, sum_over_ranks
+from uia_hip.engine import ContrastiveLoop, DevicePrefetcher, FlatAdapterOptimizer, bind_device, dist_env, init_data_parallel, sum_over_ranks
 
 
 def get_args(argv=None):
@@ -50,7 +51,7 @@ def get_args(argv=None):
     p.add_argument("--weight_decay", type=float, default=0.01)
     p.add_argument("--beta1_adam", type=float, default=0.9)
     p.add_argument("--beta2_adam", type=float, default=0.95)
-    p.add_argument("--device", type=str, default="cuda:0" if torch.cuda.is_available() else "cpu")
+    p.add_argument("--device", type=str, default="cuda:0" if torch.cuda.device_count() > 0 else "cpu")       # device_count() does not initialise the GPU: the loader workers fork first
     p.add_argument("--patience", type=int, default=10)
     # additions of this build
     p.add_argument("--dtype", type=str, default="bf16", choices=["bf16", "fp32"])
@@ -81,55 +82,61 @@ def prepare_model(args):
     return model, tokenizer
 
 
-def _features(model, tokenizer, images, texts, device):
-    fi = model.encode_image(images.to(device))
-    ft = model.encode_text(tokenizer(list(texts)).to(device))
+def _normalise(fi, ft):
+    """reference metaclip/finetune.py:147-148: the entry point L2-normalises both feature matrices before the loss"""
     return fi / fi.norm(dim=-1, keepdim=True), ft / ft.norm(dim=-1, keepdim=True)
 
 
 def train(args):
-    rank, _, world = bind_device(args)                         # data parallel: cuda:LOCAL_RANK before anything is allocated
+    """reference metaclip/finetune.py:98-215 on the measured step (engine.ContrastiveLoop with one micro-batch per update, the reference has no accumulation here): no host
+    read per batch; the non-finite skip (:153-155: no backward, no optimiser step, no scheduler step, iter_num not advanced) is the device-guarded update."""
+    rank, _, world = dist_env()
+    dm = dataset_finetune.DataModule(args, rank=rank, world=world)
+    trainloader, valloader = dm.train_dataloader(), dm.val_dataloader()
+    dm.start_workers()                                         # loader worker processes are forked BEFORE this process touches the GPU
+    bind_device(args)                                          # data parallel: cuda:LOCAL_RANK before anything is allocated
     UF.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
     UF.set_dropout_seed(args.seed + 7919 * rank)
     model, tokenizer = prepare_model(args)
     model.train()
     logging.info(model_summary({"model": model}))
-    dm = dataset_finetune.DataModule(args, rank=rank, world=world)
-    trainloader, valloader = dm.train_dataloader(), dm.val_dataloader()
     criterion = InfoNCELoss(temperature=args.temperature)
     opt = FlatAdapterOptimizer([(n, p) for n, p in model.named_parameters() if p.requires_grad], lr=args.lr,
                                betas=(args.beta1_adam, args.beta2_adam), weight_decay=args.weight_decay, max_norm=1.0)
     if world > 1:
         init_data_parallel(opt)
     max_iters = len(trainloader) * args.epochs
+    loop = ContrastiveLoop(model, criterion, opt, accumulation_steps=1, lr=args.lr, lr_min=args.lr_min, total_updates=max_iters, features=_normalise)
+    train_pf = DevicePrefetcher(trainloader, tokenizer, args.device)
+    val_pf = DevicePrefetcher(valloader, tokenizer, args.device)
     iter_num, best_loss, best_epoch, patience = 0, float("inf"), 0, 0
-    train_loss = 0.0
+    train_loss, epoch_ms = 0.0, []
+    dm.set_epoch(0)
+    batches = iter(train_pf)
     for epoch in range(args.epochs):
         model.train()
-        dm.set_epoch(epoch)
-        train_loss = 0.0
-        for images, texts in trainloader:
-            fi, ft = _features(model, tokenizer, images, texts, args.device)
-            loss = criterion(fi, ft)
-            if not all_ranks_agree(bool(torch.isfinite(loss))):      # collective decision: a lone skip would strand the other ranks in the all-reduce
-                logging.warning(f"Non-finite loss detected at iteration {iter_num}, skipping batch")
-                continue
-            opt.zero_grad()
-            loss.backward()
-            opt.all_reduce()
-            opt.step(lr=cosine_lr(args.lr, args.lr_min, iter_num, max_iters))
-            UF.clear_t_copies()
-            train_loss += loss.item()
-            iter_num += 1
-        train_loss /= max(1, len(trainloader))
+        loop.begin_epoch(len(trainloader))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for batch_idx, (images, tokens, ready) in enumerate(batches):
+            loop.micro(images, tokens, batch_idx, ready=ready)
+        g = loop.end_epoch()                                     # the epoch's one host read
+        epoch_ms.append({"ms": (time.perf_counter() - t0) * 1e3, "updates": g["updates"] - iter_num, "batches": len(trainloader)})
+        for _ in g["skipped_batches"]:
+            logging.warning(f"Non-finite loss detected at iteration {iter_num}, skipping batch")
+        iter_num = g["updates"]
+        train_loss = g["loss_sum"] / max(1, len(trainloader))
+        if epoch + 1 < args.epochs:
+            dm.set_epoch(epoch + 1)
+            batches = iter(train_pf)
         model.eval()
-        val_loss = 0.0
+        vsum = torch.zeros((), device=args.device)
         with torch.no_grad():
-            for images, texts in valloader:
-                loss = criterion(*_features(model, tokenizer, images, texts, args.device))
-                if torch.isfinite(loss):
-                    val_loss += loss.item()
-        val_loss /= max(1, len(valloader))
+            for images, tokens, ready in val_pf:
+                torch.cuda.current_stream().wait_event(ready)
+                loss = criterion(*_normalise(model.encode_image(images), model.encode_text(tokens)))
+                vsum += torch.where(torch.isfinite(loss), loss, torch.zeros_like(loss))
+        val_loss = float(vsum) / max(1, len(valloader))
         val_loss, train_loss = (v / world for v in sum_over_ranks(val_loss, train_loss))      # same figures, same decisions on every rank
         logging.info(f"Epoch {epoch + 1}/{args.epochs}: Train={train_loss:.4f}, Val={val_loss:.4f}, Best={best_loss:.4f}")
         if val_loss < best_loss:
@@ -144,12 +151,13 @@ def train(args):
             logging.info(f"Early stopping triggered at epoch {epoch + 1}")
             break
     logging.info(f"\n✓ Training completed! Best loss: {best_loss:.4f} (epoch {best_epoch + 1})")
+    dm.shutdown()
     if world > 1:
         from uia_hip import ops
         import torch.distributed as dist
         dist.barrier()
         ops.comm_destroy()
-    return {"best_val": best_loss, "iters": iter_num, "last_train": train_loss}
+    return {"best_val": best_loss, "iters": iter_num, "last_train": train_loss, "epochs": epoch_ms}
 
 
 def main(argv=None):

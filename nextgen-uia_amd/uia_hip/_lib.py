@@ -123,6 +123,8 @@ PROTOTYPES = {
     "uia_infonce_workspace_bytes": (sz, [C.c_int, C.c_int]),
     "uia_infonce_fwd_bwd": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, f32, f32, vp, vp, vp, vp, sz]),
     "uia_adamw_clip_step": (C.c_int, [vp, sz, vp, vp, vp, vp, f32, f32, f32, f32, f32, f32, C.c_int, f32, vp]),
+    "uia_grad_accum_guarded": (C.c_int, [vp, sz, vp, vp, vp, vp, vp, vp, i64]),
+    "uia_adamw_clip_step_guarded": (C.c_int, [vp, sz, vp, vp, vp, vp, f32, f32, C.c_int, f32, f32, f32, f32, f32, f32, f32, vp, vp]),
     "uia_comm_unique_id_bytes": (C.c_int, []),
     "uia_comm_get_unique_id": (C.c_int, [vp, C.c_int]),
     "uia_comm_init": (C.c_int, [C.c_int, C.c_int, vp, C.c_int]),

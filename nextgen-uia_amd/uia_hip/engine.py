@@ -40,6 +40,7 @@ class FlatLayout:
         self.numel = n
         self.p = torch.zeros(n, device=dev)
         self.g = torch.zeros(n, device=dev)
+        self.acc = torch.zeros(n + self.ALIGN, device=dev)     # guarded loops: the update cycle's accumulator; acc[n] = non-finite flag of the boundary micro-batch (travels through the all-reduce)
         self.m = torch.zeros(n, device=dev)
         self.v = torch.zeros(n, device=dev)
         with torch.no_grad():
@@ -113,6 +114,7 @@ class FlatAdapterOptimizer(FlatLayout):
         UF.join_side_streams()
         self._adopt_grads()
         self.steps += 1
+        self._last_guarded = False
         gs = dp_grad_scale(self.world) if grad_scale is None else grad_scale
         ops.adamw_clip_step(self.p, self.g, self.m, self.v, self.lr if lr is None else lr, self.betas, self.eps, self.weight_decay,
                             self.max_norm, self.steps, gs, self.ws)
@@ -121,7 +123,75 @@ class FlatAdapterOptimizer(FlatLayout):
             UF.poll_ln_flag(self.device)                       # the device; this reads the verdict without a host sync (one step late)
 
     def grad_norm(self):
-        return math.sqrt(float(self.ws[0]))
+        """‖g‖₂ of the last update (before clipping; one host read)."""
+        return math.sqrt(float(self.ws8[0] if getattr(self, "_last_guarded", False) else self.ws[0]))
+
+    # ---- guarded API (round 5): the loop never reads the loss on the host.  One micro-batch: backward into the .grad views (self.g, the staging
+    # buffer) -> accumulate(loss) adds it to self.acc when the loss is finite (device decision), zeroes self.g, leaves the flag in acc[n];
+    # at an update boundary: update() = all-reduce of self.acc (flag included) + the device-guarded clip + AdamW, which also zeroes acc.
+    def _guard_state(self):
+        if not hasattr(self, "ctl"):
+            self.ctl = torch.zeros(4, device=self.device, dtype=torch.int32)          # [updates applied, micro-batches accumulated, micro-batches skipped, updates skipped]
+            self.stats = torch.zeros(4, device=self.device)                           # [sum of finite losses since the last read, ...]
+            self.ws8 = torch.zeros(8, device=self.device)
+            self.ok_log = None
+            self.g.zero_()
+            self.acc.zero_()
+        return self.ctl
+
+    def start_log(self, n):
+        """An epoch's per-micro-batch finite flags (uint8, 2 = not run) for the end-of-epoch log; read with read_guard()."""
+        self._guard_state()
+        self.ok_log = torch.full((max(1, n),), 2, device=self.device, dtype=torch.uint8)
+
+    def accumulate(self, loss, log_index=None):
+        UF.join_side_streams()                                 # weight-gradient launches on the side stream write into self.g
+        self._adopt_grads()
+        self._guard_state()
+        ops.grad_accum_guarded(self.acc, self.g, loss.reshape(1), self.stats, self.ctl, self.ok_log if log_index is not None else None, log_index or 0)
+
+    def update(self, lr=None, lr_min=0.0, t_max=0, grad_scale=None):
+        """t_max > 0: cosine schedule from lr down to lr_min over t_max updates, indexed by the DEVICE's count of applied updates."""
+        self._guard_state()
+        if self.world > 1 or self.collective:
+            ops.allreduce_sum(self.acc)
+        self.steps += 1                                        # optimistic host count (the device's ctl[0] is the truth: read_guard())
+        self._last_guarded = True
+        if getattr(self, "snapshot_grads", False):             # tests / tools: the accumulated (all-reduced, unscaled) gradient of this update, which the update zeroes
+            self.last_g = self.acc[:self.numel].clone()
+        gs = dp_grad_scale(self.world) if grad_scale is None else grad_scale
+        ops.adamw_clip_step_guarded(self.p, self.acc, self.m, self.v, self.lr if lr is None else lr, lr_min, t_max, self.betas, self.eps, self.weight_decay,
+                                    self.max_norm, gs, 1.0 / self.world, self.ws8, self.ctl)
+        UF.WEIGHTS.bump()
+        if UF.ln_fold_enabled(UF.compute_dtype()):
+            UF.poll_ln_flag(self.device)
+        self._poll_norm()
+
+    def _poll_norm(self):
+        """The squared gradient norm of every guarded update, read WITHOUT a host sync (copied to pinned memory behind the update, examined one update
+        late).  A non-finite norm behind finite losses means the backward itself diverged — or a three-byte gradient token (functional.publish_grad3)
+        was read by something that is not its consumer: raise instead of training on NaN weights."""
+        prev = getattr(self, "_norm_poll", None)
+        if prev is not None:
+            prev[1].synchronize()                              # recorded a whole update ago
+            if float(prev[0][1]) != 0.0 and not math.isfinite(float(prev[0][0])):
+                raise FloatingPointError("uia_hip: the accumulated adapter gradient is non-finite although every accumulated loss was finite: the backward diverged "
+                                         "(or a three-byte gradient token reached a consumer that is not its partner Function — run with engine.GRAD_RESID3 = False)")
+        host = torch.empty(2, dtype=torch.float32, pin_memory=True)
+        host.copy_(self.ws8[:2], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._norm_poll = (host, ev)
+
+    def read_guard(self):
+        """One host sync: {updates, accumulated, skipped, updates_skipped, loss_sum, ok_log}; clears the loss sum and the log."""
+        self._guard_state()
+        c = self.ctl.tolist()
+        out = {"updates": c[0], "accumulated": c[1], "skipped": c[2], "updates_skipped": c[3], "loss_sum": float(self.stats[0]),
+               "ok_log": None if self.ok_log is None else self.ok_log.tolist()}
+        self.stats.zero_()
+        self.ok_log = None
+        return out
 
     def state_dict_named(self):
         return {k: p.detach().clone() for k, p in zip(self.names, self.params)}
@@ -272,119 +342,285 @@ def _frozen_text(model):
     return all(k.startswith("visual.") for k, p in model.named_parameters() if p.requires_grad)
 
 
-def contrastive_step(model, criterion, opt, images, ids, micro_batches=1, lr=None, overlap_text=True, global_loss=False, streams=1, image_split=None, inputs_ready=False):
-    """One optimiser update: encode → InfoNCE → backward (→ all-reduce) → clip+AdamW.  Returns the loss tensor (device).
+def _wait_inputs(stream, cur, ready):
+    """`stream` is about to read the caller's batch: behind the batch's own event when the caller handed one (a prefetching loader: the copy that filled the
+    batch), else behind everything the caller's stream has enqueued."""
+    if ready is not None:
+        stream.wait_event(ready)
+    else:
+        stream.wait_stream(cur)
 
-    global_loss (opt-in, not the reference's semantics): the InfoNCE batch is the GLOBAL batch — features are all-gathered,
-    every rank evaluates the same world·B × world·B loss, back-propagates the rows it owns, and the all-reduced parameter
-    gradient is the gradient of that one loss (no 1/world scaling).  Default: each rank's local loss, averaged (≡ the
-    reference's gradient accumulation).
 
-    overlap_text: the frozen text tower does not depend on the image tower, so it runs on a second HIP stream beside
-    encode_image (same kernels, same results); the streams join before the loss.
+def contrastive_micro(model, criterion, images, ids, overlap_text=True, global_loss=False, streams=1, image_split=None, inputs_ready=False, ready=None, world=1,
+                      loss_scale=1.0, features=None):
+    """Forward of both towers + InfoNCE + backward of ONE micro-batch: the gradients land in the trainable parameters' .grad (the flat optimiser's staging
+    buffer).  Returns the (unscaled) loss, a device scalar; nothing is read on the host.  Call between begin_update()/end_update() — contrastive_step and
+    ContrastiveLoop do.
 
-    streams = S > 1: the batch is cut into S slices whose towers (forward AND backward: autograd runs a node on the stream of its
-    forward) are enqueued on S HIP streams; the loss is still ONE InfoNCE over all B pairs, so features, loss and gradients are those
-    of the one-stream step (the weight gradients add up through the same float atomics).  Every kernel of the towers is per row, per
-    image or per (image, head): nothing but the loss couples the slices.  Why: a chain of dependent launches leaves the chip in
-    lockstep — every CU in its K loop, then every CU in its HBM-bound epilogue; two chains side by side fill each other's phases and
-    tails."""
-    UF.clear_t_copies()
-    UF.set_grad_resid3(GRAD_RESID3 and _hook_free(model))
-    opt.zero_grad()
-    total = None
-    mb = images.shape[0] // micro_batches
+    ready: an event after which `images` / `ids` are complete (DevicePrefetcher hands one per batch); with it, or with inputs_ready=True (the caller vouches
+    that the batch was complete before the call), a FROZEN text tower's stream does not wait for the caller's stream — nothing it reads is written by the
+    previous update — so, the host running ahead of the GPU, this micro-batch's text tower starts beside the previous backward's tail and the optimiser
+    launches instead of behind them.
+    features: optional (fi, ft) -> (fi, ft) applied before the loss (MetaCLIP's entry point normalises there, metaclip/finetune.py:92-97)."""
+    mb = images.shape[0]
     if image_split is None:
         image_split = int(round(mb * IMAGE_SPLIT)) if mb >= 32 else 0
-    ops.CHAINS = 3 if (overlap_text and 0 < image_split < mb and not (streams > 1 and mb >= 2 * streams)) else 1      # forward AND backward of this step (ops.gemm's tail policy)
+    sliced = streams > 1 and mb >= 2 * streams
+    split = overlap_text and 0 < image_split < mb and not sliced
+    ops.CHAINS = 3 if split else 1                               # forward AND backward of this micro-batch (ops.gemm's tail policy)
     cur = torch.cuda.current_stream()
+    im, tk = images, ids
+    ahead = (inputs_ready or ready is not None) and _frozen_text(model)
+    if ready is not None:
+        cur.wait_event(ready)
+    if sliced:
+        sts = _mb_streams(images.device, streams)
+        bounds = [mb * s // streams for s in range(streams + 1)]
+        fis, fts = [], []
+        for s, st in enumerate(sts):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                fis.append(model.encode_image(im[bounds[s]:bounds[s + 1]]))
+                fts.append(model.encode_text(tk[bounds[s]:bounds[s + 1]]))
+        for st, a, b in zip(sts, fis, fts):
+            cur.wait_stream(st)
+            a.record_stream(cur)
+            b.record_stream(cur)
+        fi, ft = torch.cat(fis, 0), torch.cat(fts, 0)
+    elif split:
+        # round 4: the image tower as TWO slices on two streams, the text tower whole on a third.  Every kernel of the tower is per row, per image or per
+        # (image, head), so the slices are independent chains; a chain of dependent launches leaves CUs idle at every ragged last round and M tail (the
+        # backward has no text tower beside it to fill them), two chains fill each other's.  One InfoNCE over all pairs; same loss and gradients (the weight
+        # gradients meet through the same float atomics).  Halves measured best (41.43 -> 40.78 ms; 0.86 / 0.14 — a first slice of whole 256-tile rounds —
+        # 41.09, thirds 41.16); slicing the text tower as well (streams = 3) is slower: its 768-tile launches are whole rounds already.
+        side = _side_stream(images.device)
+        if not ahead:
+            side.wait_stream(cur)
+        elif ready is not None:
+            side.wait_event(ready)
+        fts, tsides = None, []
+        if TEXT_SLICES > 1:                                  # experiment knob: the text tower in equal slices on as many streams as well
+            tb = [mb * j // TEXT_SLICES for j in range(TEXT_SLICES + 1)]
+            tsides = [side] + _mb_streams(images.device, 8 + TEXT_SLICES - 1)[:TEXT_SLICES - 1]
+            fts = []
+            for j, st in enumerate(tsides):
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    fts.append(model.encode_text(tk[tb[j]:tb[j + 1]]))
+        else:
+            with torch.cuda.stream(side):
+                ft = model.encode_text(tk)
+        cuts = [0, image_split] + ([image_split + (mb - image_split) * j // (IMAGE_SLICES - 1) for j in range(1, IMAGE_SLICES - 1)] if IMAGE_SLICES > 2 else []) + [mb]
+        extra = _mb_streams(images.device, len(cuts) - 2)
+        parts = [None] * (len(cuts) - 1)
+        for j, st in enumerate(extra):                       # slices 1.. on their own streams, slice 0 on the caller's
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                parts[j + 1] = model.encode_image(im[cuts[j + 1]:cuts[j + 2]])
+        parts[0] = model.encode_image(im[:cuts[1]])
+        for j, st in enumerate(extra):
+            cur.wait_stream(st)
+            parts[j + 1].record_stream(cur)
+        fi = torch.cat(parts, 0)
+        if fts is not None:
+            for st, f in zip(tsides, fts):
+                cur.wait_stream(st)
+                f.record_stream(cur)
+            ft = torch.cat(fts, 0)
+        else:
+            cur.wait_stream(side)
+            ft.record_stream(cur)
+    elif overlap_text:
+        side = _side_stream(images.device)
+        if not ahead:
+            side.wait_stream(cur)
+        elif ready is not None:
+            side.wait_event(ready)
+        with torch.cuda.stream(side):
+            ft = model.encode_text(tk)
+        fi = model.encode_image(im)
+        cur.wait_stream(side)
+        ft.record_stream(cur)
+    else:
+        fi = model.encode_image(im)
+        ft = model.encode_text(tk)
+    if features is not None:
+        fi, ft = features(fi, ft)
+    if global_loss:
+        rank, _, _ = dist_env()
+        fi, ft = GatherFeaturesFn.apply(fi, rank, world), GatherFeaturesFn.apply(ft, rank, world)
+    loss = criterion(fi, ft)
+    (loss * loss_scale if loss_scale != 1.0 else loss).backward()
+    if split:
+        for st in _mb_streams(images.device, max(1, IMAGE_SLICES - 1)):
+            cur.wait_stream(st)
+    if sliced:
+        for st in _mb_streams(images.device, streams):     # the adapters' weight gradients are side effects of the backward kernels (flat
+            cur.wait_stream(st)                            # buffer, direct mode): autograd's own end-of-backward sync does not know them
+    return loss.detach()
+
+
+def begin_update(model):
+    """Per-update registries and the three-byte gradient hand-off (tokens are a contract of ONE update's forwards and backwards)."""
+    UF.clear_t_copies()
+    UF.set_grad_resid3(GRAD_RESID3 and _hook_free(model))      # tokens are handed out only inside UF.linear_chain() scopes (the towers' own block loops)
+
+
+def end_update():
+    ops.CHAINS = 1        # also when a launch raised: the policy must not leak into the caller's next launches
+    UF.set_grad_resid3(False)      # another loop in the process (segmentation heads on tapped blocks) starts without tokens
+
+
+def contrastive_step(model, criterion, opt, images, ids, micro_batches=1, lr=None, overlap_text=True, global_loss=False, streams=1, image_split=None, inputs_ready=False,
+                     lr_min=0.0, t_max=0):
+    """One optimiser update: [encode -> InfoNCE -> backward -> guarded accumulate] x micro_batches (-> all-reduce) -> guarded clip + AdamW.  Returns the mean
+    loss (device scalar).  NO host read anywhere: the reference's non-finite skip (finetune.py:281-285) is decided on the device (FlatAdapterOptimizer.accumulate /
+    update).  This is the step bench.py times AND the step the fine-tune entry points run (ContrastiveLoop below calls the same two functions per loader batch).
+
+    global_loss (opt-in, not the reference's semantics): the InfoNCE batch is the GLOBAL batch — features are all-gathered, every rank evaluates the same
+    world·B x world·B loss, back-propagates the rows it owns, and the all-reduced parameter gradient is the gradient of that one loss (no 1/world scaling).
+    Default: each rank's local loss, averaged (== the reference's gradient accumulation).
+
+    overlap_text: the frozen text tower does not depend on the image tower, so it runs on a second HIP stream beside encode_image (same kernels, same
+    results); the streams join before the loss.  With images of at least 32 per micro-batch the image tower itself runs as two half-batch slices on two
+    streams (IMAGE_SPLIT): two chains of dependent launches fill each other's ragged last rounds and M tails.
+
+    streams = S > 1: the batch is cut into S slices whose towers (forward AND backward: autograd runs a node on the stream of its forward) are enqueued on S
+    HIP streams; the loss is still ONE InfoNCE over all B pairs."""
+    begin_update(model)
+    total = None
+    mb = images.shape[0] // micro_batches
     try:
         for i in range(micro_batches):
-            im, tk = images[i * mb:(i + 1) * mb], ids[i * mb:(i + 1) * mb]
-            if streams > 1 and mb >= 2 * streams:
-                sts = _mb_streams(images.device, streams)
-                bounds = [mb * s // streams for s in range(streams + 1)]
-                fis, fts = [], []
-                for s, st in enumerate(sts):
-                    st.wait_stream(cur)
-                    with torch.cuda.stream(st):
-                        fis.append(model.encode_image(im[bounds[s]:bounds[s + 1]]))
-                        fts.append(model.encode_text(tk[bounds[s]:bounds[s + 1]]))
-                for st, a, b in zip(sts, fis, fts):
-                    cur.wait_stream(st)
-                    a.record_stream(cur)
-                    b.record_stream(cur)
-                fi, ft = torch.cat(fis, 0), torch.cat(fts, 0)
-            elif overlap_text and 0 < image_split < mb:
-                # round 4: the image tower as TWO slices on two streams, the text tower whole on a third.  Every kernel of the tower is per row, per image or per
-                # (image, head), so the slices are independent chains; a chain of dependent launches leaves CUs idle at every ragged last round and M tail (the
-                # backward has no text tower beside it to fill them), two chains fill each other's.  One InfoNCE over all pairs, as with streams = S; same loss and
-                # gradients (the weight gradients meet through the same float atomics).  Halves measured best (41.43 -> 40.78 ms; 0.86 / 0.14 — a first slice of whole
-                # 256-tile rounds — 41.09, thirds 41.16); slicing the text tower as well (streams = 3) is slower: its 768-tile launches are whole rounds already.
-                side = _side_stream(images.device)
-                if not (inputs_ready and _frozen_text(model)):
-                    side.wait_stream(cur)
-                # inputs_ready (the caller vouches that `ids` was complete before this call, e.g. a resident or double-buffered batch) and a frozen text tower: its
-                # stream does NOT wait for the caller's — nothing it reads is written by the previous step's backward or optimiser — so, the host running ahead of the
-                # GPU, this step's text tower starts beside the previous step's backward tail and optimiser launches instead of behind them.
-                fts, tsides = None, []
-                if TEXT_SLICES > 1:                                  # experiment knob: the text tower in equal slices on as many streams as well
-                    tb = [mb * j // TEXT_SLICES for j in range(TEXT_SLICES + 1)]
-                    tsides = [side] + _mb_streams(images.device, 8 + TEXT_SLICES - 1)[:TEXT_SLICES - 1]
-                    fts = []
-                    for j, st in enumerate(tsides):
-                        st.wait_stream(cur)
-                        with torch.cuda.stream(st):
-                            fts.append(model.encode_text(tk[tb[j]:tb[j + 1]]))
-                else:
-                    with torch.cuda.stream(side):
-                        ft = model.encode_text(tk)
-                cuts = [0, image_split] + ([image_split + (mb - image_split) * j // (IMAGE_SLICES - 1) for j in range(1, IMAGE_SLICES - 1)] if IMAGE_SLICES > 2 else []) + [mb]
-                extra = _mb_streams(images.device, len(cuts) - 2)
-                parts = [None] * (len(cuts) - 1)
-                for j, st in enumerate(extra):                       # slices 1.. on their own streams, slice 0 on the caller's
-                    st.wait_stream(cur)
-                    with torch.cuda.stream(st):
-                        parts[j + 1] = model.encode_image(im[cuts[j + 1]:cuts[j + 2]])
-                parts[0] = model.encode_image(im[:cuts[1]])
-                for j, st in enumerate(extra):
-                    cur.wait_stream(st)
-                    parts[j + 1].record_stream(cur)
-                fi = torch.cat(parts, 0)
-                if fts is not None:
-                    for st, f in zip(tsides, fts):
-                        cur.wait_stream(st)
-                        f.record_stream(cur)
-                    ft = torch.cat(fts, 0)
-                else:
-                    cur.wait_stream(side)
-                    ft.record_stream(cur)
-            elif overlap_text:
-                side = _side_stream(images.device)
-                side.wait_stream(cur)
-                with torch.cuda.stream(side):
-                    ft = model.encode_text(tk)
-                fi = model.encode_image(im)
-                cur.wait_stream(side)
-                ft.record_stream(cur)
-            else:
-                fi = model.encode_image(im)
-                ft = model.encode_text(tk)
-            if global_loss:
-                rank, _, _ = dist_env()
-                fi, ft = GatherFeaturesFn.apply(fi, rank, opt.world), GatherFeaturesFn.apply(ft, rank, opt.world)
-            loss = criterion(fi, ft)
-            (loss / micro_batches).backward()
-            if overlap_text and 0 < image_split < mb and not (streams > 1 and mb >= 2 * streams):
-                for st in _mb_streams(images.device, max(1, IMAGE_SLICES - 1)):
-                    cur.wait_stream(st)
-            if streams > 1 and mb >= 2 * streams:
-                for st in _mb_streams(images.device, streams):     # the adapters' weight gradients are side effects of the backward kernels (flat
-                    cur.wait_stream(st)                            # buffer, direct mode): autograd's own end-of-backward sync does not know them
-            total = loss.detach() if total is None else total + loss.detach()
+            loss = contrastive_micro(model, criterion, images[i * mb:(i + 1) * mb], ids[i * mb:(i + 1) * mb], overlap_text=overlap_text, global_loss=global_loss,
+                                     streams=streams, image_split=image_split, inputs_ready=inputs_ready, world=opt.world, loss_scale=1.0 / micro_batches)
+            opt.accumulate(loss)
+            total = loss if total is None else total + loss
     finally:
-        ops.CHAINS = 1        # also when a launch raised: the policy must not leak into the caller's next launches
-        UF.set_grad_resid3(False)      # tokens are a contract of THIS step's forward and backward; another loop in the process (segmentation heads on tapped blocks) starts without them
-    opt.all_reduce()
-    opt.step(lr=lr, grad_scale=dp_grad_scale(opt.world, global_loss))
-    return total / micro_batches
+        end_update()
+    opt.update(lr=lr, lr_min=lr_min, t_max=t_max, grad_scale=dp_grad_scale(opt.world, global_loss))
+    return total / micro_batches if micro_batches > 1 else total
+
+
+class ContrastiveLoop:
+    """The fine-tune entry points' training loop body (reference src/models/biomedclip/finetune.py:272-310) on the measured step: per LOADER batch one
+    contrastive_micro + guarded accumulate, at every accumulation boundary (`(batch_idx + 1) % accumulation_steps == 0` or the loader's last batch, :297) one
+    guarded update — no host read of the loss, so the host runs ahead of the GPU exactly as in bench.py.  The reference's decisions that depended on the
+    loss value are taken on the device: a non-finite micro-batch contributes nothing, and when it is the boundary micro-batch the update check is skipped
+    with it (the `continue` at :285), the schedule not advancing.  end_epoch() is the one host sync per epoch: it returns the figures the reference
+    accumulated with loss.item() and the indices of the skipped batches for the reference's warning."""
+
+    def __init__(self, model, criterion, opt, accumulation_steps=1, lr=1e-4, lr_min=0.0, total_updates=0, features=None, global_loss=False):
+        self.model, self.criterion, self.opt = model, criterion, opt
+        self.acc_steps, self.lr, self.lr_min, self.t_max = max(1, int(accumulation_steps)), lr, lr_min, int(total_updates)
+        self.features, self.global_loss = features, global_loss
+        self._open = False
+
+    def begin_epoch(self, n_batches):
+        self.n_batches = n_batches
+        self.opt.start_log(n_batches)
+        self._acc0 = getattr(self, "_acc_seen", 0)
+
+    def micro(self, images, ids, batch_idx, ready=None, inputs_ready=False):
+        if not self._open:
+            begin_update(self.model)
+            self._open = True
+        try:
+            loss = contrastive_micro(self.model, self.criterion, images, ids, ready=ready, inputs_ready=inputs_ready, world=self.opt.world,
+                                     loss_scale=1.0 / self.acc_steps, features=self.features, global_loss=self.global_loss)
+            self.opt.accumulate(loss, log_index=batch_idx)
+        except BaseException:
+            end_update()
+            self._open = False
+            raise
+        if ((batch_idx + 1) % self.acc_steps == 0) or (batch_idx + 1 == self.n_batches):
+            end_update()
+            self._open = False
+            self.opt.update(lr=self.lr, lr_min=self.lr_min, t_max=self.t_max, grad_scale=dp_grad_scale(self.opt.world, self.global_loss))
+        return loss
+
+    def end_epoch(self):
+        if self._open:
+            end_update()
+            self._open = False
+        g = self.opt.read_guard()
+        g["skipped_batches"] = [i for i, ok in enumerate(g["ok_log"] or []) if ok == 0]
+        g["epoch_accumulated"] = g["accumulated"] - getattr(self, "_acc0", 0)      # finite micro-batches of THIS epoch (the counters on the device are cumulative)
+        self._acc_seen = g["accumulated"]
+        return g
+
+
+class DevicePrefetcher:
+    """Double-buffered loader: a background thread pulls (images, texts) batches from a DataLoader, tokenises, stages them in a ring of pinned host buffers
+    and copies them to a ring of device buffers on a COPY stream; the consumer gets (images, ids, event) — the batch is complete behind `event`, which is
+    what lets contrastive_micro start a frozen text tower without waiting for the previous update (its `ready` argument).  A device slot is reused only behind
+    an event the consumer's stream records when it asks for the next batch (every stream that read the slot has been joined into it by then)."""
+
+    def __init__(self, loader, tokenizer, device, depth=2):
+        import threading
+        self.loader, self.tokenizer, self.device, self.depth = loader, tokenizer, torch.device(device), max(1, depth)
+        self._threading = threading
+        self._slots = None
+        self._copy = torch.cuda.Stream(device=self.device)
+
+    def __len__(self):
+        return len(self.loader)
+
+    def _make_slots(self, images, ids):
+        n = self.depth + 2
+        self._slots = [{"h_im": torch.empty(images.shape, dtype=images.dtype, pin_memory=True), "h_id": torch.empty(ids.shape, dtype=ids.dtype, pin_memory=True),
+                        "d_im": torch.empty(images.shape, dtype=images.dtype, device=self.device), "d_id": torch.empty(ids.shape, dtype=ids.dtype, device=self.device),
+                        "free": None, "copied": None} for _ in range(n)]
+
+    def _producer(self, it, q):
+        try:
+            torch.cuda.set_device(self.device)
+            k = 0
+            for images, texts in it:
+                ids = self.tokenizer(list(texts))
+                if self._slots is None or self._slots[0]["h_im"].shape != images.shape or self._slots[0]["h_id"].shape != ids.shape:
+                    self._make_slots(images, ids)
+                sl = self._slots[k % len(self._slots)]
+                k += 1
+                if sl["copied"] is not None:
+                    sl["copied"].synchronize()                  # the pinned staging buffers are free once their copy has run
+                sl["h_im"].copy_(images)
+                sl["h_id"].copy_(ids)
+                with torch.cuda.stream(self._copy):
+                    if sl["free"] is not None:
+                        self._copy.wait_event(sl["free"])       # the consumer's last reader of this device slot
+                    sl["d_im"].copy_(sl["h_im"], non_blocking=True)
+                    sl["d_id"].copy_(sl["h_id"], non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(self._copy)
+                sl["copied"] = ev
+                q.put((sl, ev))
+            q.put(None)
+        except BaseException as e:                              # surfaces in the consumer
+            q.put(e)
+
+    def __iter__(self):
+        """Starts the producer NOW (not at the first next()): the first `depth` batches are loaded, staged and copied while the caller does something else."""
+        import queue
+        q = self._q = queue.Queue(maxsize=self.depth)
+        th = self._threading.Thread(target=self._producer, args=(iter(self.loader), q), daemon=True)
+        th.start()
+        return self._consume(th, q)
+
+    def _consume(self, th, q):
+        prev = None
+        while True:
+            if prev is not None:                                # the consumer has enqueued everything that reads the previous slot; recorded BEFORE the queue
+                ev = torch.cuda.Event()                         # frees a place: the producer may not reach this slot again until then
+                ev.record(torch.cuda.current_stream(self.device))
+                prev["free"] = ev
+                prev = None
+            item = q.get()
+            if item is None:
+                break
+            if isinstance(item, BaseException):
+                raise item
+            sl, ev = item
+            prev = sl
+            yield sl["d_im"], sl["d_id"], ev
+        th.join()

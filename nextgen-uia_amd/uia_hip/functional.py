@@ -227,9 +227,23 @@ def grad_resid3_enabled():
     return bool(_STATE.get("grad_resid3", False))
 
 
+class linear_chain:
+    """Scope of a tower's own block loop (forward_features / VisionTransformer.forward): inside it the residual stream is a plain chain block -> adapter -> block,
+    every block output has exactly ONE consumer, so a three-byte gradient token can stand in for its gradient.  Code that walks the blocks itself and taps
+    intermediate outputs (FPN heads, CLIPSeg's extract layers) never enters the scope and gets fp32 residual gradients (a token with a second
+    consumer would be ADDED to a real gradient by autograd)."""
+
+    def __enter__(self):
+        _STATE["chain_depth"] = _STATE.get("chain_depth", 0) + 1
+
+    def __exit__(self, *exc):
+        _STATE["chain_depth"] -= 1
+        return False
+
+
 def _g3_partner_feeds(x):
     """True when x is the output of a MonaFn / VitBlockFn seen through view nodes only: the gradient this Function returns for x goes to that Function's backward."""
-    if not grad_resid3_enabled():
+    if not grad_resid3_enabled() or _STATE.get("chain_depth", 0) <= 0:
         return False
     fn = x.grad_fn
     for _ in range(8):

@@ -459,7 +459,7 @@ def gemm(a, w, *, bias=None, act=None, dact=None, aux_in=None, aux_out=None, res
     Three-byte tensors (bf16, ring tile configs: M > 2048): resid3 = (hi, lo) is the residual as a bf16 hi plane (row-major or KBlocked) plus an int8
     [M, N] plane of low bytes — float bits = (hi_bits << 16) + (lo << 8) — to which resid_ln then applies; out_lo = int8 [M, N] receives the low
     bytes of the result, whose hi plane is out_t (three_byte_to_float converts)."""
-    if (resid3 is not None or out_lo is not None) and (isinstance(w, ExtW) or resid_mod or out_group or a.dtype != torch.bfloat16 if not is_kb(a) else a.t.dtype != torch.bfloat16):
+    if (resid3 is not None or out_lo is not None) and (isinstance(w, ExtW) or resid_mod or out_group or (a.t.dtype if is_kb(a) else a.dtype) != torch.bfloat16):
         raise UiaError("gemm: three-byte tensors (resid3 / out_lo) need bf16 operands and a plain epilogue (no row remapping, no K extension)")
     if isinstance(w, ExtW):
         # K extension: w = [W | s·B] (K-blocked only), a2 = (t, group_cols): t [M, K2] or [G, M, K2] — one [M, K2] operand per group of output columns
@@ -929,12 +929,18 @@ def pack_table(entries, device):
         key = dev.index if dev.index is not None else torch.cuda.current_device()
         ring = _PIN_RING.get(key)
         if ring is None:
-            ring = _PIN_RING[key] = [torch.empty(_PIN_SLOTS, _PIN_SLOT, dtype=torch.uint8).pin_memory(), 0]
-        slot = ring[0][ring[1]]
-        ring[1] = (ring[1] + 1) % _PIN_SLOTS
+            ring = _PIN_RING[key] = [torch.empty(_PIN_SLOTS, _PIN_SLOT, dtype=torch.uint8).pin_memory(), 0, [None] * _PIN_SLOTS]
+        i = ring[1]
+        slot = ring[0][i]
+        ring[1] = (i + 1) % _PIN_SLOTS
+        if ring[2][i] is not None:
+            ring[2][i].synchronize()        # the copy that last read this slot (512 pack launches ago: long done; a wait only if the host ran THAT far ahead — ADVICE r04)
         C.memmove(slot.data_ptr(), C.addressof(arr), nbytes)
         table = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         table.copy_(slot[:nbytes], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        ring[2][i] = ev
         return table, len(entries), max_elems
     raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone()
     return raw.to(device), len(entries), max_elems
@@ -1145,6 +1151,23 @@ def adamw_clip_step(p, g, m, v, lr, betas, eps, weight_decay, max_norm, step, gr
     for t in (p, g, m, v):
         assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == p.numel()
     check(lib().uia_adamw_clip_step(_stream(), p.numel(), _p(p), _p(g), _p(m), _p(v), lr, betas[0], betas[1], eps, weight_decay, max_norm, step, grad_scale, _p(ws2)), "uia_adamw_clip_step")
+
+
+def grad_accum_guarded(acc, mb, loss, stats, ctl, ok_log=None, log_index=0):
+    """acc [n + 4] += mb [n] when the device loss is finite; mb zeroed; acc[n] = this micro-batch's flag (include/uia_hip.h)."""
+    n = mb.numel()
+    assert acc.dtype == mb.dtype == loss.dtype == stats.dtype == torch.float32 and acc.numel() >= n + 4 and ctl.dtype == torch.int32 and ctl.numel() >= 4
+    assert ok_log is None or (ok_log.dtype == torch.uint8 and 0 <= log_index < ok_log.numel())
+    check(lib().uia_grad_accum_guarded(_stream(), n, _p(acc), _p(mb), _p(loss), _p(stats), _p(ctl), _p(ok_log), int(log_index)), "uia_grad_accum_guarded")
+
+
+def adamw_clip_step_guarded(p, acc, m, v, lr, lr_min, t_max, betas, eps, weight_decay, max_norm, grad_scale, skip_scale, ws8, ctl):
+    n = p.numel()
+    for t in (p, m, v):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n
+    assert acc.dtype == torch.float32 and acc.numel() >= n + 4 and ws8.numel() >= 8 and ctl.dtype == torch.int32 and ctl.numel() >= 4
+    check(lib().uia_adamw_clip_step_guarded(_stream(), n, _p(p), _p(acc), _p(m), _p(v), lr, lr_min, int(t_max), betas[0], betas[1], eps, weight_decay, max_norm,
+                                            grad_scale, skip_scale, _p(ws8), _p(ctl)), "uia_adamw_clip_step_guarded")
 
 
 def comm_unique_id():

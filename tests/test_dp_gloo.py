@@ -183,3 +183,55 @@ def test_dist_env_parsing(monkeypatch):
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         monkeypatch.delenv(k)
     assert dist_env() == (0, 0, 1)
+
+
+# ---- round 5: the device-guarded loop's exchange (engine.FlatAdapterOptimizer.accumulate / update): the non-finite flag of the boundary micro-batch travels in
+#      acc[n] through the SAME all-reduce as the gradients; a skipped update leaves sum/world on every rank so that the next all-reduce restores the sum.
+def _accum_guarded(lay, loss):
+    """torch restatement of uia_grad_accum_guarded (csrc/optim.hip) on the engine's own FlatLayout buffers."""
+    ok = bool(torch.isfinite(loss))
+    n = lay.numel
+    if ok:
+        lay.acc[:n] += lay.g
+    lay.g.zero_()
+    lay.acc[n] = 0.0 if ok else 1.0
+    return ok
+
+
+def _guarded_worker(rank, world, port, out):
+    from uia_hip.engine import FlatLayout, dp_grad_scale
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(7)
+    w = torch.nn.Parameter(torch.randn(37, generator=g))
+    lay = FlatLayout([("w", w)])
+    n = lay.numel
+    assert lay.acc.numel() == n + FlatLayout.ALIGN
+    grads = [[torch.randn(37, generator=g) for _ in range(2)] for _ in range(2)]           # [cycle][rank]
+    losses = [[1.0, float("nan")], [0.5, 0.7]]                                              # cycle 0: rank 1's boundary micro-batch is non-finite
+    decisions, sums = [], []
+    for cycle in range(2):
+        w.grad.copy_(grads[cycle][rank])                                                   # this rank's backward into the staging views
+        _accum_guarded(lay, torch.tensor(losses[cycle][rank]))
+        dist.all_reduce(lay.acc, op=dist.ReduceOp.SUM)                                     # ONE collective: gradients and flag together
+        run = float(lay.acc[n]) == 0.0
+        decisions.append(run)
+        if run:
+            sums.append(lay.acc[:n].clone() * dp_grad_scale(world))
+            lay.acc.zero_()
+        else:
+            lay.acc[:n] *= 1.0 / world                                                     # uia_adamw_clip_step_guarded's skip path
+    torch.save({"decisions": decisions, "sums": sums, "want": (grads[0][0] + grads[1][0] + grads[1][1]) * dp_grad_scale(world), "pad": n - 37}, os.path.join(out, f"g{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_dp2_guarded_skip_is_collective_and_keeps_the_accumulated_sum(tmp_path):
+    world, port = 2, 29811 + os.getpid() % 200
+    mp.spawn(_guarded_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(os.path.join(tmp_path, f"g{k}.pt")) for k in range(world)]
+    for k in range(world):
+        assert r[k]["decisions"] == [False, True]                          # both ranks skip the first update although only rank 1 saw the NaN; both run the second
+        got, want = r[k]["sums"][0], r[k]["want"]
+        assert torch.allclose(got[:37], want, rtol=1e-6, atol=1e-7)        # rank 0's finite micro-batch of the skipped cycle is still in the sum, rank 1's NaN one is not
+    assert torch.equal(r[0]["sums"][0], r[1]["sums"][0])

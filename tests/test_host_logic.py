@@ -327,9 +327,12 @@ def test_three_byte_gradient_tokens_travel_through_views_and_poison_other_reader
     y = VitBlockFn.apply(x)
     UF.set_grad_resid3(True)
     try:
-        assert UF._g3_partner_feeds(y.permute(1, 0, 2).permute(1, 0, 2))
-        assert not UF._g3_partner_feeds(y + 0.0)                          # arithmetic in between would read the token
-        assert not UF._g3_partner_feeds(x)
+        assert not UF._g3_partner_feeds(y.permute(1, 0, 2))               # outside a tower's own block loop (UF.linear_chain): a tapped output could have a second consumer
+        with UF.linear_chain():
+            assert UF._g3_partner_feeds(y.permute(1, 0, 2).permute(1, 0, 2))
+            assert not UF._g3_partner_feeds(y + 0.0)                      # arithmetic in between would read the token
+            assert not UF._g3_partner_feeds(x)
+        assert not UF._g3_partner_feeds(y)                                # the scope has ended
         UF.set_grad_resid3(False)
         assert not UF._g3_partner_feeds(y)
     finally:

@@ -1,0 +1,201 @@
+"""-m gpu, round 5: the training loop the fine-tune entry points and bench.py share (engine.contrastive_micro / ContrastiveLoop / DevicePrefetcher) and its
+device-side guards (uia_grad_accum_guarded / uia_adamw_clip_step_guarded) against the reference's host-side loop semantics
+(/root/reference/src/models/biomedclip/finetune.py:272-310: non-finite micro-batches `continue` past the backward AND the update check; clip_grad_norm_ ->
+AdamW -> CosineAnnealingLR once per cycle), restated with oracle/train_ref.clip_and_adamw."""
+import math
+
+import pytest
+import torch
+
+from oracle import train_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def _reference_loop(p0, grads, losses, acc_steps, lr, lr_min, t_max, betas, wd, max_norm):
+    """The reference's loop body over pre-computed (already 1/accumulation-scaled) micro-batch gradients: finetune.py:281-302."""
+    p = {"w": p0.clone()}
+    m, v = {"w": torch.zeros_like(p0)}, {"w": torch.zeros_like(p0)}
+    acc = torch.zeros_like(p0)
+    t, n_ok, n_bad, loss_sum, norms = 0, 0, 0, 0.0, []
+    N = len(grads)
+    for i in range(N):
+        if not math.isfinite(losses[i]):
+            n_bad += 1
+            continue                                              # :285 — also past the update check below
+        acc += grads[i]
+        loss_sum += losses[i]
+        n_ok += 1
+        if (i + 1) % acc_steps == 0 or i + 1 == N:
+            cur_lr = lr_min + (lr - lr_min) * (1 + math.cos(math.pi * t / t_max)) / 2 if t_max > 0 else lr
+            norms.append(train_ref.clip_and_adamw(p, {"w": acc}, m, v, t + 1, cur_lr, betas, 1e-8, wd, max_norm))
+            acc = torch.zeros_like(p0)
+            t += 1
+    return p["w"], m["w"], v["w"], acc, t, n_ok, n_bad, loss_sum, norms
+
+
+@pytest.mark.parametrize("bad", [(), (2,), (5,), (1, 2, 8), (11,), (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11)])
+def test_guarded_accumulate_and_update_follow_the_reference_loop(bad):
+    """uia_grad_accum_guarded + uia_adamw_clip_step_guarded driven exactly as ContrastiveLoop drives them, on synthetic gradients, against the reference's host loop:
+    a non-finite loss mid-cycle drops that micro-batch only; at a boundary (index 2, 5, 8, 11 with three accumulation steps) it also skips the update, the cycle
+    going on into the next one without advancing the cosine schedule; the very last batch of the loader is a boundary too."""
+    from uia_hip.engine import FlatLayout, FlatAdapterOptimizer
+    torch.manual_seed(3)
+    n, N, A = 1000, 12, 3
+    w = torch.nn.Parameter(torch.randn(n, device=dev()))
+    opt = FlatAdapterOptimizer([("w", w)], lr=3e-3, betas=(0.9, 0.95), weight_decay=0.01, max_norm=1.0)
+    p0 = opt.p.detach().cpu().clone()
+    grads = [torch.randn(n) * (0.02 if i % 2 else 0.3) for i in range(N)]           # some cycles clip (norm > 1), some do not
+    losses = [float("nan") if i in bad and i % 2 else (float("inf") if i in bad else 1.0 + 0.1 * i) for i in range(N)]
+    ref = _reference_loop(p0, grads, losses, A, 3e-3, 1e-5, 7, (0.9, 0.95), 0.01, 1.0)
+    opt.start_log(N)
+    for i in range(N):
+        opt.g.copy_(grads[i].to(dev()))                           # what one micro-batch's backward leaves in the staging buffer
+        opt.accumulate(torch.tensor(losses[i], device=dev()), log_index=i)
+        assert float(opt.g.abs().max()) == 0.0                    # zeroed either way
+        if (i + 1) % A == 0 or i + 1 == N:
+            opt.update(lr=3e-3, lr_min=1e-5, t_max=7)
+    g = opt.read_guard()
+    rp, rm, rv, racc, t, n_ok, n_bad, loss_sum, norms = ref
+    assert (g["updates"], g["accumulated"], g["skipped"]) == (t, n_ok, n_bad)
+    assert g["updates_skipped"] == sum(1 for i in range(N) if ((i + 1) % A == 0 or i + 1 == N) and i in bad)
+    assert g["ok_log"] == [0 if i in bad else 1 for i in range(N)]
+    assert abs(g["loss_sum"] - loss_sum) < 1e-4
+    for got, want in ((opt.p, rp), (opt.m, rm), (opt.v, rv), (opt.acc[:n], racc)):
+        assert torch.allclose(got.detach().cpu(), want, rtol=2e-5, atol=2e-7), float((got.detach().cpu() - want).abs().max())
+    if norms and (N - 1) not in bad:
+        assert abs(opt.grad_norm() - norms[-1]) < 1e-4 * norms[-1]
+
+
+def test_guarded_update_skip_rescales_the_summed_buffer_under_data_parallelism():
+    """A skipped update behind an all-reduce leaves the SUM over ranks in every rank's accumulator; uia_adamw_clip_step_guarded scales it by 1/world so that the
+    next all-reduce restores exactly that sum (engine.FlatAdapterOptimizer.update passes skip_scale = 1/world)."""
+    from uia_hip import ops
+    n = 260
+    p, m, v = torch.randn(n, device=dev()), torch.zeros(n, device=dev()), torch.zeros(n, device=dev())
+    acc = torch.randn(n + 4, device=dev())
+    acc[n:] = 0
+    acc[n] = 2.0                                                   # two ranks' boundary micro-batch was non-finite
+    want_acc, want_p = acc[:n].clone() * 0.125, p.clone()
+    ws8, ctl = torch.zeros(8, device=dev()), torch.zeros(4, device=dev(), dtype=torch.int32)
+    ops.adamw_clip_step_guarded(p, acc, m, v, 1e-3, 0.0, 0, (0.9, 0.95), 1e-8, 0.01, 1.0, 0.125, 0.125, ws8, ctl)
+    assert torch.equal(acc[:n], want_acc) and torch.equal(p, want_p) and ctl.tolist() == [0, 0, 0, 1] and float(ws8[1]) == 0.0
+    acc[n] = 0.0
+    ops.adamw_clip_step_guarded(p, acc, m, v, 1e-3, 0.0, 0, (0.9, 0.95), 1e-8, 0.01, 1.0, 0.125, 0.125, ws8, ctl)
+    assert float(acc[:n].abs().max()) == 0.0 and not torch.equal(p, want_p) and ctl.tolist() == [1, 0, 0, 1] and float(ws8[1]) == 1.0
+
+
+class _PoisonedCriterion(torch.nn.Module):
+    """InfoNCE whose loss is NaN on the chosen calls (what a diverged batch looks like to the loop)."""
+
+    def __init__(self, inner, bad_calls):
+        super().__init__()
+        self.inner, self.bad, self.calls = inner, set(bad_calls), 0
+
+    def forward(self, fi, ft):
+        loss = self.inner(fi, ft)
+        self.calls += 1
+        return loss * float("nan") if (self.calls - 1) in self.bad else loss
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_contrastive_loop_equals_contrastive_step_and_skips_like_the_reference(mode):
+    """(a) ContrastiveLoop.micro over two loader batches with accumulation 2 == contrastive_step(micro_batches=2) on their concatenation; (b) with a NaN loss on
+    batch 1 of [b0, b1, b2, b3] at accumulation 2 the reference accumulates b0, skips b1 AND its update check, accumulates b2 and b3 and updates once at b3 —
+    the same parameters as a run that only ever saw b0, b2, b3 in one cycle."""
+    from uia_hip import functional as UF
+    from uia_hip import engine
+    from src.losses import InfoNCELoss
+    from tests.test_round2_gpu import _toy_batch, _toy_model
+    UF.set_compute_dtype(torch.float32 if mode == "fp32" else torch.bfloat16)
+    try:
+        images, ids = _toy_batch(41, B=16)
+        images, ids = images.to(dev()), ids.to(dev())
+        flat = lambda model: torch.cat([p.detach().flatten() for p in model.parameters() if p.requires_grad]).clone()
+        mk = lambda: engine.FlatAdapterOptimizer([(k, p) for k, p in model.named_parameters() if p.requires_grad], lr=1e-2)
+
+        model = _toy_model("hybrid", seed=19).to(dev())
+        opt = mk()
+        UF.set_dropout_seed(5)
+        l_step = engine.contrastive_step(model, InfoNCELoss(0.07), opt, images[:8], ids[:8], micro_batches=2, overlap_text=True)
+        p_step = flat(model)
+
+        model = _toy_model("hybrid", seed=19).to(dev())
+        opt = mk()
+        UF.set_dropout_seed(5)
+        loop = engine.ContrastiveLoop(model, InfoNCELoss(0.07), opt, accumulation_steps=2, lr=1e-2)
+        loop.begin_epoch(2)
+        la = loop.micro(images[:4], ids[:4], 0)
+        lb = loop.micro(images[4:8], ids[4:8], 1)
+        g = loop.end_epoch()
+        assert (g["updates"], g["epoch_accumulated"], g["skipped_batches"]) == (1, 2, [])
+        tol = 1e-6 if mode == "fp32" else 2e-2
+        assert abs(float(l_step) - 0.5 * (float(la) + float(lb))) < tol * max(1.0, abs(float(l_step)))
+        d = (flat(model) - p_step).abs()
+        assert float((d > 1e-3).float().mean()) < (1e-3 if mode == "fp32" else 2e-2), float(d.max())
+
+        # (b)
+        model = _toy_model("hybrid", seed=19).to(dev())
+        opt = mk()
+        loop = engine.ContrastiveLoop(model, _PoisonedCriterion(InfoNCELoss(0.07), [1]), opt, accumulation_steps=2, lr=1e-2, lr_min=1e-4, total_updates=4)
+        loop.begin_epoch(4)
+        for i in range(4):
+            loop.micro(images[4 * i:4 * i + 4], ids[4 * i:4 * i + 4], i)
+        g = loop.end_epoch()
+        assert (g["updates"], g["accumulated"], g["skipped"], g["updates_skipped"], g["skipped_batches"]) == (1, 3, 1, 1, [1])
+        p_skip = flat(model)
+
+        model = _toy_model("hybrid", seed=19).to(dev())
+        opt = mk()
+        engine.begin_update(model)
+        try:
+            for i in (0, 2, 3):
+                loss = engine.contrastive_micro(model, InfoNCELoss(0.07), images[4 * i:4 * i + 4], ids[4 * i:4 * i + 4], loss_scale=0.5)
+                opt.accumulate(loss)
+        finally:
+            engine.end_update()
+        opt.update(lr=1e-2, lr_min=1e-4, t_max=4)
+        torch.cuda.synchronize()
+        d = (flat(model) - p_skip).abs()
+        assert float((d > 1e-3).float().mean()) < (1e-3 if mode == "fp32" else 2e-2), float(d.max())
+        assert float((p_skip - p_step).abs().max()) > 0           # and it did move
+    finally:
+        UF.set_compute_dtype(torch.bfloat16)
+
+
+def test_device_prefetcher_hands_over_every_batch_in_order_and_recycles_slots_safely():
+    """DevicePrefetcher over a loader of 9 batches with a ring of depth + 2 = 4 device slots, two epochs: every batch arrives once, in order, complete behind its
+    event — also when the consumer is slow (the producer must not overwrite a slot a consumer kernel still reads) and when it only looks at a batch later."""
+    from uia_hip.engine import DevicePrefetcher
+
+    class Loader:
+        def __init__(self, n):
+            self.n, self.epoch = n, 0
+
+        def __len__(self):
+            return self.n
+
+        def __iter__(self):
+            e = self.epoch
+            self.epoch += 1
+            for i in range(self.n):
+                yield torch.full((4, 3, 64, 64), float(100 * e + i)), [f"caption {100 * e + i}"] * 4
+
+    tok = lambda texts: torch.tensor([[int(t.split()[1]), 7, 7] for t in texts])
+    pf = DevicePrefetcher(Loader(9), tok, dev(), depth=2)
+    spin = torch.randn(2048, 2048, device=dev())
+    for epoch in range(2):
+        kept = []
+        for i, (im, ids, ready) in enumerate(pf):
+            torch.cuda.current_stream().wait_event(ready)
+            for _ in range(3):                                     # a slow consumer: the host is far ahead of the device when it asks for the next batch
+                spin = (spin @ spin).clamp_(-1, 1)
+            kept.append((im.mean().reshape(1), ids[:, 0].float().mean().reshape(1)))       # read on the consumer's stream BEHIND the slow kernels
+        assert len(kept) == 9
+        got = torch.cat([torch.cat(k) for k in kept]).cpu().view(9, 2)
+        want = torch.tensor([[100.0 * epoch + i] * 2 for i in range(9)])
+        assert torch.equal(got, want), got
