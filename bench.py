@@ -356,6 +356,11 @@ def dist_fields(world, per_rank, steps, ops):
 
 def main():
     args = parse()
+    # stdout carries ONE JSON line and nothing else: file descriptor 1 is pointed at stderr for the whole run (RCCL prints a version banner from C when a
+    # communicator is created, injectors print reference-compatible banners) and the line is written to the saved descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     from uia_hip import functional as UF
     from uia_hip import ops
@@ -428,7 +433,8 @@ def main():
     if rank == 0 and world == 1 and args.config == "mona" and not args.no_secondary:
         out["secondary"] = secondary_lines(args, device)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if ops.comm_world_initialised():
         ops.comm_destroy()
     if world > 1:

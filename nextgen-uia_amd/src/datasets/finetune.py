@@ -73,12 +73,27 @@ class RankShardSampler(torch.utils.data.Sampler):
         return self.per_rank
 
 
+class _TokenisingCollate:
+    """default_collate plus the caller's tokenizer applied to the caption list INSIDE the loader worker: batches arrive as (images, texts, token ids).  The reference
+    tokenises in the training loop (finetune.py:275 `tokenizer(texts)`); done there it would hold the interpreter lock of the process that enqueues the GPU work for
+    tens of milliseconds per batch."""
+
+    def __init__(self, tokenizer):
+        self.tokenizer = tokenizer
+
+    def __call__(self, samples):
+        images, texts = torch.utils.data.default_collate(samples)
+        return images, texts, self.tokenizer(list(texts))
+
+
 class DataModule:
-    def __init__(self, args, rank=None, world=None):
+    def __init__(self, args, rank=None, world=None, tokenizer=None):
         """rank / world default to the torch.distributed.run environment (RANK / WORLD_SIZE); world == 1 is the reference's
-        single-process loader (shuffle=True, drop_last=True, datasets/finetune.py:124-142)."""
+        single-process loader (shuffle=True, drop_last=True, datasets/finetune.py:124-142).  tokenizer (optional): applied to every batch's captions in the
+        loader workers; batches then carry the token ids as a third element."""
         import os
         self.args = args
+        self.collate = _TokenisingCollate(tokenizer) if tokenizer is not None else None
         self.rank = int(os.environ.get("RANK", 0)) if rank is None else rank
         self.world = int(os.environ.get("WORLD_SIZE", 1)) if world is None else world
         if getattr(args, "data_pt", None):
@@ -114,6 +129,8 @@ class DataModule:
                 room = 0
             nw = max(0, min(nw, room // max(1, 3 * per_batch)))
         kw = dict(num_workers=nw, drop_last=True)
+        if self.collate is not None:
+            kw.update(collate_fn=self.collate)
         if nw:
             kw.update(persistent_workers=True, prefetch_factor=2)
         if self.world > 1:

@@ -80,11 +80,16 @@ def get_args(argv=None):
     return p.parse_args(argv)
 
 
+def make_tokenizer(args):
+    cfg = parse_config(args.model_config) if args.model_config else None
+    return SyntheticTokenizer(256 if cfg is None else cfg["text_cfg"]["max_position_embeddings"])
+
+
 def prepare_model(args):
     cfg = parse_config(args.model_config) if args.model_config else None
     state = torch.load(args.ckpt_path, map_location="cpu") if args.ckpt_path else None
     model = create_biomedclip(state_dict=state, config=cfg, seed=args.seed)
-    tokenizer = SyntheticTokenizer(256 if cfg is None else cfg["text_cfg"]["max_position_embeddings"])
+    tokenizer = make_tokenizer(args)
     model.float()
     if args.method == "full":                                    # reference :134-157
         if not args.tune_text_encoder:
@@ -145,7 +150,9 @@ def train(args):
     clip + AdamW — the same functions bench.py times.  The host reads nothing per batch: the non-finite skip (:281-285) is decided on the device, the epoch's
     loss sum / counts / skipped indices come back in ONE read at the end of the epoch, batches arrive through a double-buffered prefetcher."""
     rank, _, world = dist_env()
-    dm = dataset_finetune.DataModule(args, rank=rank, world=world)
+    if not torch.cuda.is_initialized():                         # a fresh CLI process (not a caller that is already running other GPU / CPU work in this process)
+        torch.set_num_threads(max(1, min(4, torch.get_num_threads())))      # host tensor work here is one staging copy per batch; the default (every logical CPU of the node) oversubscribes a job's CPU share
+    dm = dataset_finetune.DataModule(args, rank=rank, world=world, tokenizer=make_tokenizer(args))
     trainloader, valloader = dm.train_dataloader(), dm.val_dataloader()
     dm.start_workers()                                         # loader worker processes are forked BEFORE this process touches the GPU
     bind_device(args)                                          # data parallel: cuda:LOCAL_RANK before anything is allocated

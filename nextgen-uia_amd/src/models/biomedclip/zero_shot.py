@@ -6,8 +6,8 @@ Kept from the reference: the command line (:31-72), adapter loading by parameter
 and the scoring rule (:176-222): class prototypes = L2-normalised text features of a prompt ensemble per class, logits[b, c] =
 mean over the class's prompts of 100 · <image feature, prompt feature>.  Host-side reporting (ROC figure, CSV, MONAI/
 torchmetrics accumulators, :224-290) is outside the hot path; this module returns accuracy, AUC and cross-entropy computed
-with a few torch ops.  The prompt ensembles are this build's own short lists (the reference's live in its prompt module and
-are data of that project); pass --prompts_json to use others.  Data: --synthetic or --data_pt {"images","labels"}.
+with a few torch ops.  The prompt ensembles are the reference's (src/models/zero_shot_prompt.py:29-54, carried as data: ten prompts per class, picked by
+--dataset as in reference :168-173); --prompts_json overrides them.  Data: --synthetic or --data_pt {"images","labels"}.
 """
 import argparse
 import json
@@ -21,13 +21,12 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[3]))
 import torch
 
 from src.adapters import inject_lora_to_biomedclip, inject_mona_variant_to_open_clip
+from src.models.zero_shot_prompt import ensemble_for
 from src.third_party.biomedclip.model import SyntheticTokenizer, create_biomedclip
 from src.utils.tools import parse_config, setup_logging
 from uia_hip import functional as UF
 
 LESION_TYPES = ("benign", "malignant")
-DEFAULT_PROMPTS = {c: [f"an ultrasound image of a {c} lesion", f"ultrasound scan showing a {c} tumor", f"a {c} nodule in an ultrasound image",
-                       f"this is a {c} mass"] for c in LESION_TYPES}
 
 
 def get_args(argv=None):
@@ -143,7 +142,7 @@ def ensemble_logits(model, images, text_feats):
 def test(args):
     UF.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
     model, tokenizer = prepare_model(args)
-    prompts = json.load(open(args.prompts_json)) if args.prompts_json else DEFAULT_PROMPTS
+    prompts = json.load(open(args.prompts_json)) if args.prompts_json else ensemble_for(args.dataset)
     text_feats = class_text_features(model, tokenizer, prompts, args.device)
     proto_sim = float(text_feats["benign"].mean(0) @ text_feats["malignant"].mean(0))
     if proto_sim > 0.95:

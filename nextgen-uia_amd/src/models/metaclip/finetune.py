@@ -64,12 +64,16 @@ def get_args(argv=None):
     return p.parse_args(argv)
 
 
+def make_tokenizer(args):
+    tc = ((parse_config(args.model_config) if args.model_config else None) or {}).get("text_cfg", {})
+    return SyntheticClipTokenizer(tc.get("context_length", 77), tc.get("vocab_size", 49408))
+
+
 def prepare_model(args):
     cfg = parse_config(args.model_config) if args.model_config else None
     state = torch.load(args.ckpt_path, map_location="cpu") if args.ckpt_path else None
     model = create_metaclip(state_dict=state, config=cfg, seed=args.seed)
-    tc = (cfg or {}).get("text_cfg", {})
-    tokenizer = SyntheticClipTokenizer(tc.get("context_length", 77), tc.get("vocab_size", 49408))
+    tokenizer = make_tokenizer(args)
     for p in model.parameters():
         p.requires_grad = False
     model, mona_count = inject_mona_variant_to_open_clip(model, variant=args.mona_variant, bottleneck_dim=args.mona_bottleneck,
@@ -91,7 +95,9 @@ def train(args):
     """reference metaclip/finetune.py:98-215 on the measured step (engine.ContrastiveLoop with one micro-batch per update, the reference has no accumulation here): no host
     read per batch; the non-finite skip (:153-155: no backward, no optimiser step, no scheduler step, iter_num not advanced) is the device-guarded update."""
     rank, _, world = dist_env()
-    dm = dataset_finetune.DataModule(args, rank=rank, world=world)
+    if not torch.cuda.is_initialized():                         # a fresh CLI process (not a caller that is already running other GPU / CPU work in this process)
+        torch.set_num_threads(max(1, min(4, torch.get_num_threads())))      # host tensor work here is one staging copy per batch; the default (every logical CPU of the node) oversubscribes a job's CPU share
+    dm = dataset_finetune.DataModule(args, rank=rank, world=world, tokenizer=make_tokenizer(args))
     trainloader, valloader = dm.train_dataloader(), dm.val_dataloader()
     dm.start_workers()                                         # loader worker processes are forked BEFORE this process touches the GPU
     bind_device(args)                                          # data parallel: cuda:LOCAL_RANK before anything is allocated

@@ -76,6 +76,11 @@ class FlatAdapterOptimizer(FlatLayout):
         super().__init__(named_params)
         assert self.device.type == "cuda", "the fused optimiser runs on the GPU only"
         self.ws = torch.zeros(2, device=self.device)
+        # guarded loops (accumulate / update below): [updates applied, micro-batches accumulated, micro-batches skipped, updates skipped], loss sum, scalars of the update
+        self.ctl = torch.zeros(4, device=self.device, dtype=torch.int32)
+        self.stats = torch.zeros(4, device=self.device)
+        self.ws8 = torch.zeros(8, device=self.device)
+        self.ok_log = None
         self.lr, self.betas, self.eps, self.weight_decay, self.max_norm = lr, betas, eps, weight_decay, max_norm
         self.steps = 0
         self.world = 1
@@ -129,30 +134,17 @@ class FlatAdapterOptimizer(FlatLayout):
     # ---- guarded API (round 5): the loop never reads the loss on the host.  One micro-batch: backward into the .grad views (self.g, the staging
     # buffer) -> accumulate(loss) adds it to self.acc when the loss is finite (device decision), zeroes self.g, leaves the flag in acc[n];
     # at an update boundary: update() = all-reduce of self.acc (flag included) + the device-guarded clip + AdamW, which also zeroes acc.
-    def _guard_state(self):
-        if not hasattr(self, "ctl"):
-            self.ctl = torch.zeros(4, device=self.device, dtype=torch.int32)          # [updates applied, micro-batches accumulated, micro-batches skipped, updates skipped]
-            self.stats = torch.zeros(4, device=self.device)                           # [sum of finite losses since the last read, ...]
-            self.ws8 = torch.zeros(8, device=self.device)
-            self.ok_log = None
-            self.g.zero_()
-            self.acc.zero_()
-        return self.ctl
-
     def start_log(self, n):
         """An epoch's per-micro-batch finite flags (uint8, 2 = not run) for the end-of-epoch log; read with read_guard()."""
-        self._guard_state()
         self.ok_log = torch.full((max(1, n),), 2, device=self.device, dtype=torch.uint8)
 
     def accumulate(self, loss, log_index=None):
         UF.join_side_streams()                                 # weight-gradient launches on the side stream write into self.g
         self._adopt_grads()
-        self._guard_state()
         ops.grad_accum_guarded(self.acc, self.g, loss.reshape(1), self.stats, self.ctl, self.ok_log if log_index is not None else None, log_index or 0)
 
     def update(self, lr=None, lr_min=0.0, t_max=0, grad_scale=None):
         """t_max > 0: cosine schedule from lr down to lr_min over t_max updates, indexed by the DEVICE's count of applied updates."""
-        self._guard_state()
         if self.world > 1 or self.collective:
             ops.allreduce_sum(self.acc)
         self.steps += 1                                        # optimistic host count (the device's ctl[0] is the truth: read_guard())
@@ -185,7 +177,6 @@ class FlatAdapterOptimizer(FlatLayout):
 
     def read_guard(self):
         """One host sync: {updates, accumulated, skipped, updates_skipped, loss_sum, ok_log}; clears the loss sum and the log."""
-        self._guard_state()
         c = self.ctl.tolist()
         out = {"updates": c[0], "accumulated": c[1], "skipped": c[2], "updates_skipped": c[3], "loss_sum": float(self.stats[0]),
                "ok_log": None if self.ok_log is None else self.ok_log.tolist()}
@@ -576,8 +567,9 @@ class DevicePrefetcher:
         try:
             torch.cuda.set_device(self.device)
             k = 0
-            for images, texts in it:
-                ids = self.tokenizer(list(texts))
+            for batch in it:
+                images, texts = batch[0], batch[1]
+                ids = batch[2] if len(batch) > 2 else self.tokenizer(list(texts))      # a DataModule built with the tokenizer has tokenised in its workers
                 if self._slots is None or self._slots[0]["h_im"].shape != images.shape or self._slots[0]["h_id"].shape != ids.shape:
                     self._make_slots(images, ids)
                 sl = self._slots[k % len(self._slots)]

@@ -67,3 +67,29 @@ def adapter_forward(images, P, A, task="seg", extract_layers=(0, 1, 2), heads=12
     if drop_mask is not None:
         pooled = pooled * drop_mask * 2.0                              # Dropout(0.5), inverted scaling
     return F.linear(pooled, A["cls_head.3.weight"], A["cls_head.3.bias"])
+
+
+def openai_adapter_forward(images, P, A, task="seg", extract_layers=(0, 1), heads=2, img_size=32, mona=None):
+    """CLIPAdapter over the OpenAI-layout tower — /root/reference/src/third_party/openai_clip/clip_adapter.py: extract_vit_features :60-90 (outputs of the
+    resblocks in `extract_layers`), forward :92-136 (as the timm class above), cls head :51-58 = pool -> Linear -> ReLU -> Dropout(0.1) -> Linear (eval: no
+    dropout).  P: CLIP state dict ("visual." keys); A: adapter state dict (reduces.{i}.*, blocks.{i}.{0,1,3}.*, seg_head.1.*, cls_head.{2,5}.*).
+    PINNED by tests/golden/clip_adapter_openai.npz, generated from the imported reference class (oracle/gen_golden_r05.py)."""
+    _, taps = vit_ref.openai_vit_forward(images, P, heads=heads, mona=mona, taps=list(extract_layers))
+    B = images.shape[0]
+    a = None
+    for lvl in range(len(extract_layers) - 1, -1, -1):
+        act = taps[lvl][:, 1:, :]
+        r = F.linear(act, A[f"reduces.{lvl}.weight"], A[f"reduces.{lvl}.bias"])
+        C = r.shape[-1]
+        h = F.layer_norm(r, (C,), A[f"blocks.{lvl}.0.weight"], A[f"blocks.{lvl}.0.bias"], 1e-5)
+        h = F.gelu(F.linear(h, A[f"blocks.{lvl}.1.weight"], A[f"blocks.{lvl}.1.bias"]))
+        h = F.linear(h, A[f"blocks.{lvl}.3.weight"], A[f"blocks.{lvl}.3.bias"])
+        a = h if a is None else h + a
+    g = int(math.sqrt(a.shape[1]))
+    a = a.permute(0, 2, 1).reshape(B, -1, g, g)
+    if task == "seg":
+        up = F.interpolate(a, size=(img_size, img_size), mode="bilinear", align_corners=False)
+        return F.conv2d(up, A["seg_head.1.weight"], A["seg_head.1.bias"])
+    pooled = a.mean(dim=(2, 3))
+    h = F.relu(F.linear(pooled, A["cls_head.2.weight"], A["cls_head.2.bias"]))
+    return F.linear(h, A["cls_head.5.weight"], A["cls_head.5.bias"])

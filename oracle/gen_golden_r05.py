@@ -1,0 +1,212 @@
+"""Round-5 fixtures from the IMPORTED reference (same rules as oracle/gen_golden.py: runs only in the build container, writes tests/golden/, the
+reference's code is never copied):
+
+    python oracle/gen_golden_r05.py
+
+  clip_adapter_openai.npz — the reference's CLIPAdapter (src/third_party/openai_clip/clip_adapter.py:6-165; seg and cls heads) over the reference's own CLIP
+      (src/third_party/openai_clip/model.py) at the toy geometry of openai_clip_base.npz, with freq_enhanced Mona adapters (bottleneck 64, last block) injected by the reference's injector
+      (src/adapters/mona.py:495) so that freeze_clip_backbone()'s "mona"-only rule and the gradient path THROUGH the tapped backbone are both in the vectors.
+  nextgen-uia_amd/src/models/zero_shot_prompts.json — the 10 + 10 prompt strings of src/models/zero_shot_prompt.py:29-54 as DATA (config 1 of BASELINE.json is defined on them).
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from oracle.gen_golden import REF, OUT, fill, fill_module, load_by_path, save          # noqa: E402
+
+
+def gen_clip_adapter():
+    from oracle import fpn_ref
+    sys.path.insert(0, REF)
+    model_mod = load_by_path("ref_clip_model", "src/third_party/openai_clip/model.py")
+    mona = load_by_path("ref_mona", "src/adapters/mona.py")
+    ca = load_by_path("ref_openai_clip_adapter", "src/third_party/openai_clip/clip_adapter.py")
+    torch.manual_seed(0)
+    clip = model_mod.CLIP(16, 32, 2, 128, 8, 8, 50, 64, 2, 2).float().eval()           # exactly gen_golden.gen_openai_clip's backbone: its weights are in openai_clip_base.npz
+    fill_module(clip, 0.31, 0.08)
+    with torch.no_grad():
+        for k, p in clip.named_parameters():
+            if k.endswith(("ln_1.weight", "ln_2.weight", "ln_pre.weight", "ln_post.weight", "ln_final.weight")):
+                p.add_(1.0)
+    for p in clip.parameters():
+        p.requires_grad_(False)
+    clip, cnt = mona.inject_mona_variant_to_clip(clip, variant="freq_enhanced", bottleneck_dim=64, num_layers=1)      # bottleneck 64: the geometry the HIP kernels take
+    clip.eval()
+    mp = [(k, p) for k, p in clip.named_parameters() if "mona" in k]
+    with torch.no_grad():
+        for n, (k, p) in enumerate(mp):
+            p.copy_(fill(tuple(p.shape), 0.37, float(n), 0.05))
+            if k.endswith(("norm.weight", "gammax")):
+                p.add_(1.0)
+    images = torch.from_numpy(np.random.RandomState(11).uniform(0, 1, (3, 3, 32, 32)).astype(np.float32))
+    out = {"count": np.int32(cnt)}
+    for k, p in mp:
+        out["p." + k] = p.detach().clone()
+    for task in ("seg", "cls"):
+        ad = ca.CLIPAdapter(clip, extract_layers=[0, 1], reduce_dim=64, num_classes=2, img_size=32, patch_size=8, task=task)
+        rs = np.random.RandomState(7)
+        with torch.no_grad():
+            for k, p_ in torch.nn.ModuleList([ad.reduces, ad.blocks, ad.seg_head, ad.cls_head]).named_parameters():
+                p_.copy_(torch.from_numpy((rs.standard_normal(p_.numel()) * 0.08).astype(np.float32).reshape(tuple(p_.shape))))
+            for blk in ad.blocks:
+                blk[0].weight.add_(1.0)
+        ad.eval()
+        ad.freeze_clip_backbone()
+        A = {k: v.detach().clone() for k, v in ad.state_dict().items() if not k.startswith("clip_model.")}
+        for p in ad.parameters():
+            p.grad = None
+        y = ad(images)
+        dy = torch.from_numpy(np.random.RandomState(13).standard_normal(tuple(y.shape)).astype(np.float32))
+        (y * dy).sum().backward()
+        P = {k: v.detach() for k, v in clip.state_dict().items()}
+        yo = fpn_ref.openai_adapter_forward(images, P, A, task=task, extract_layers=(0, 1), heads=2, img_size=32, mona=dict(variant="freq_enhanced", hw=(4, 4)))
+        assert float((yo - y).abs().max()) < 1e-4 * float(y.abs().max()), "oracle restatement deviates from the reference"
+        if task == "seg":
+            out.update({f"A.{k}": v for k, v in A.items()})
+        out[f"{task}.y"] = y.detach()
+        out[f"{task}.dy"] = dy
+        for k, p in ad.named_parameters():
+            if p.requires_grad and p.grad is not None:
+                out[f"{task}.g.{k}"] = p.grad.detach().clone()
+    save("clip_adapter_openai", images=images, **out)
+
+
+def gen_prompts():
+    zp = load_by_path("ref_zero_shot_prompt", "src/models/zero_shot_prompt.py")
+    data = {k: v for k, v in vars(zp).items() if not k.startswith("_") and isinstance(v, (list, tuple, dict, str))}
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "nextgen-uia_amd", "src", "models", "zero_shot_prompts.json"), "w") as f:      # product DATA
+        json.dump(data, f, indent=1, sort_keys=True)
+    print("wrote zero_shot_prompts.json", {k: (len(v) if hasattr(v, "__len__") else v) for k, v in data.items()})
+
+
+def gen_hip_shapes():
+    """The reference's adapters again, at geometries the HIP kernels take (Mona bottleneck 64 — the reference's default, mona.py:104 — and feature widths that are
+    multiples of 64; the round-1 fixtures use bottleneck 8 / width 32, which only the oracle can run): these vectors are compared with the HIP path DIRECTLY
+    (tests/test_golden_gpu.py), without the oracle in between."""
+    sys.path.insert(0, REF)
+    mona = load_by_path("ref_mona", "src/adapters/mona.py")
+    lora = load_by_path("ref_lora", "src/adapters/lora.py")
+    model_mod = load_by_path("ref_clip_model", "src/third_party/openai_clip/model.py")
+    losses = load_by_path("ref_losses", "src/losses/losses.py")
+    classes = {"baseline": mona.BaselineMona, "noise_aware": mona.NoiseAwareMona, "freq_enhanced": mona.FreqEnhancedMona, "hybrid": mona.HybridNoiseFreqMona}
+    D, b, N, B = 128, 64, 17, 2
+    for variant, cls in classes.items():
+        torch.manual_seed(0)
+        m = cls(D, b).eval()
+        fill_module(m, 0.37, 0.05)
+        with torch.no_grad():
+            for k, p in m.named_parameters():
+                if k.endswith(("norm.weight", "gammax")):
+                    p.add_(1.0)
+        arrays = {"p." + k: p.detach().clone() for k, p in m.named_parameters()}
+        # (1) eval, sequence-first [N, B, D] with a CLS token and a 4 x 4 grid
+        x = fill((N, B, D), 0.11, 0.0).requires_grad_(True)
+        y = m(x, (4, 4))
+        dy = fill((N, B, D), 0.05, 2.0)
+        (y * dy).sum().backward()
+        arrays.update({"eval.x": x.detach(), "eval.y": y.detach(), "eval.dy": dy, "eval.dx": x.grad.clone()})
+        arrays.update({"eval.g." + k: p.grad.clone() for k, p in m.named_parameters()})
+        # (2) training mode with a fixed keep mask in place of the module's dropout (batch-first [B, N, b], 1/0.9 scaling: mona.py p = 0.1)
+        m.zero_grad()
+        keep = (fill((B, N, b), 0.77, 1.0) > -0.6).float()
+
+        class FixedDrop(torch.nn.Module):
+            def forward(self, g):
+                return g * keep / 0.9
+        saved = m.dropout
+        m.dropout = FixedDrop()
+        x2 = (fill((N, B, D), 0.23, 1.0) * 2.0).requires_grad_(True)
+        y2 = m(x2, (4, 4))
+        (y2 * dy).sum().backward()
+        arrays.update({"drop.x": x2.detach(), "drop.y": y2.detach(), "drop.dy": dy, "drop.dx": x2.grad.clone(), "drop.keep": keep})
+        arrays.update({"drop.g." + k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+        m.dropout = saved
+        # (3) hw_shapes=None (mona.py:140-144): all 16 tokens on a 4 x 4 grid, no CLS
+        m.zero_grad()
+        x3 = fill((16, B, D), 0.13, 0.5).requires_grad_(True)
+        y3 = m(x3)
+        dy3 = fill((16, B, D), 0.07, 1.0)
+        (y3 * dy3).sum().backward()
+        arrays.update({"nohw.x": x3.detach(), "nohw.y": y3.detach(), "nohw.dy": dy3, "nohw.dx": x3.grad.clone()})
+        arrays.update({"nohw.g." + k: p.grad.clone() for k, p in m.named_parameters()})
+        save(f"ref_mona_{variant}_d128", **arrays)
+
+    # LinearLoRA (lora.py:57-90) at in 128 / out 192 / r 4, and the MHA replacement (lora.py:96-199) at width 128, 2 heads, r 4
+    lin = torch.nn.Linear(128, 192)
+    with torch.no_grad():
+        lin.weight.copy_(fill((192, 128), 0.37, 0.0, 0.1))
+        lin.bias.copy_(fill((192,), 0.37, 1.0, 0.1))
+    ll = lora.LinearLoRA(lin, r=4, lora_alpha=8, dropout_rate=0.0)
+    with torch.no_grad():
+        ll.w_lora_A.copy_(fill((4, 128), 0.37, 2.0, 0.1))
+        ll.w_lora_B.copy_(fill((192, 4), 0.37, 3.0, 0.1))
+    x = fill((10, 128), 0.11, 0.0).requires_grad_(True)
+    y = ll(x)
+    dy = fill((10, 192), 0.09, 0.7)
+    (y * dy).sum().backward()
+    save("ref_lora_linear_k128", x=x, y=y, dy=dy, dx=x.grad, W=ll.weight, b=ll.bias, A=ll.w_lora_A, B=ll.w_lora_B, dA=ll.w_lora_A.grad, dB=ll.w_lora_B.grad,
+         db=ll.bias.grad, scaling=np.float32(ll.scaling))
+    mha = torch.nn.MultiheadAttention(128, 2)
+    fill_module(mha, 0.29, 0.08)
+    pm = lora.PlainMultiheadAttentionLoRA(mha, enable_lora=["q", "k", "v", "o"], r=4, lora_alpha=8, dropout_rate=0.0)
+    with torch.no_grad():
+        for n, (k, p) in enumerate(pm.named_parameters()):
+            if "lora" in k:
+                p.copy_(fill(tuple(p.shape), 0.41, float(n), 0.1))
+    x = fill((9, 3, 128), 0.13, 0.5).requires_grad_(True)
+    y, _ = pm(x, x, x)
+    dy = fill((9, 3, 128), 0.07, 0.2)
+    (y * dy).sum().backward()
+    arrays = {"x_lbd": x, "y_lbd": y, "dy_lbd": dy, "dx_lbd": x.grad}
+    for k, p in pm.named_parameters():
+        arrays["p." + k] = p
+        if p.grad is not None:
+            arrays["g." + k] = p.grad
+    save("ref_lora_mha_d128", **arrays)
+
+    # OpenAI CLIP + Mona bottleneck 64 on the LAST resblock (inject_mona_variant_to_clip(num_layers=1)), backbone = openai_clip_base.npz
+    torch.manual_seed(0)
+    clip = model_mod.CLIP(16, 32, 2, 128, 8, 8, 50, 64, 2, 2).float().eval()
+    fill_module(clip, 0.31, 0.08)
+    with torch.no_grad():
+        for k, p in clip.named_parameters():
+            if k.endswith(("ln_1.weight", "ln_2.weight", "ln_pre.weight", "ln_post.weight", "ln_final.weight")):
+                p.add_(1.0)
+    img = fill((3, 3, 32, 32), 0.017, 0.0) * 0.5 + 0.5
+    ids = torch.tensor([[49, 3, 7, 11, 2, 0, 0, 0], [5, 49, 1, 1, 1, 1, 1, 1], [4, 9, 8, 7, 6, 5, 3, 49]])
+    for variant in classes:
+        torch.manual_seed(0)
+        c2 = model_mod.CLIP(16, 32, 2, 128, 8, 8, 50, 64, 2, 2).float().eval()
+        c2.load_state_dict(clip.state_dict())
+        for p in c2.parameters():
+            p.requires_grad_(False)
+        c2, cnt = mona.inject_mona_variant_to_clip(c2, variant=variant, bottleneck_dim=64, num_layers=1)
+        c2.eval()
+        mp = [(k, p) for k, p in c2.named_parameters() if "mona" in k]
+        with torch.no_grad():
+            for n, (k, p) in enumerate(mp):
+                p.copy_(fill(tuple(p.shape), 0.37, float(n), 0.05))
+                if k.endswith(("norm.weight", "gammax")):
+                    p.add_(1.0)
+        for k, p in mp:
+            p.requires_grad_(True)
+        fi = c2.encode_image(img)
+        with torch.no_grad():
+            ft = c2.encode_text(ids)
+        loss = losses.InfoNCELoss(0.07)(fi, ft)
+        loss.backward()
+        arrays = {"image_features": fi, "loss": loss, "count": np.int32(cnt)}
+        for k, p in mp:
+            arrays["p." + k] = p
+            arrays["g." + k] = p.grad
+        save(f"ref_openai_clip_mona_{variant}_b64", **arrays)
+
+
+if __name__ == "__main__":
+    gen_clip_adapter()
+    gen_prompts()
+    gen_hip_shapes()

@@ -337,3 +337,42 @@ def test_three_byte_gradient_tokens_travel_through_views_and_poison_other_reader
         assert not UF._g3_partner_feeds(y)
     finally:
         UF.set_grad_resid3(False)
+
+
+def test_zero_shot_prompt_ensembles_are_the_references_ten_per_class():
+    """src/models/zero_shot_prompt.py exposes the reference's names (reference zero_shot.py:22 imports them) with ten prompts per class and set (reference
+    zero_shot_prompt.py:2-54), and picks the ensemble by dataset name as reference zero_shot.py:168-173 does."""
+    import pytest
+    from src.models.zero_shot_prompt import BREAST_PROMPTS_ENSEMBLE, LN_PROMPTS_ENSEMBLE, ensemble_for
+    for ens, word in ((LN_PROMPTS_ENSEMBLE, "lymph node"), (BREAST_PROMPTS_ENSEMBLE, "nodule")):
+        assert sorted(ens) == ["benign", "malignant"]
+        for c in ens:
+            assert len(ens[c]) == 10 and len(set(ens[c])) == 10 and all(p.startswith(f"A {c} {word}") for p in ens[c])
+    assert ensemble_for("BUSI") is BREAST_PROMPTS_ENSEMBLE and ensemble_for("LN-INT") is LN_PROMPTS_ENSEMBLE and ensemble_for("busi_external") is BREAST_PROMPTS_ENSEMBLE
+    with pytest.raises(ValueError):
+        ensemble_for("thyroid")
+
+
+def test_clip_adapter_openai_layout_names_and_freeze_rule():
+    """CLIPAdapter (reference src/third_party/openai_clip/clip_adapter.py:6-165): state-dict keys of the heads as in the reference (`cls_head.2/.5`, not the timm class's
+    `cls_head.3`), feature_dim from the tower's width, and freeze_clip_backbone() keeping ONLY "mona" names trainable in the backbone (:138-150)."""
+    import torch
+    from src.adapters import inject_mona_variant_to_clip
+    from src.third_party.openai_clip.clip_adapter import CLIPAdapter
+    from src.third_party.openai_clip.model import CLIP
+    clip = CLIP(16, 32, 2, 128, 8, 8, 50, 64, 2, 2)
+    clip, n = inject_mona_variant_to_clip(clip, variant="freq_enhanced", bottleneck_dim=8)
+    for task in ("seg", "cls"):
+        ad = CLIPAdapter(clip, extract_layers=[0, 1], reduce_dim=64, num_classes=2, img_size=32, patch_size=8, task=task)
+        keys = {k for k in ad.state_dict() if not k.startswith("clip_model.")}
+        want = {f"reduces.{i}.{p}" for i in (0, 1) for p in ("weight", "bias")} | {f"blocks.{i}.{j}.{p}" for i in (0, 1) for j in (0, 1, 3) for p in ("weight", "bias")}
+        want |= {"seg_head.1.weight", "seg_head.1.bias", "cls_head.2.weight", "cls_head.2.bias", "cls_head.5.weight", "cls_head.5.bias"}
+        assert keys == want and ad.feature_dim == 128
+        ad.freeze_clip_backbone()
+        backbone = {k for k, p in ad.clip_model.named_parameters() if p.requires_grad}
+        assert backbone and all("mona" in k for k in backbone)
+        heads = {k for k, p in ad.named_parameters() if p.requires_grad and not k.startswith("clip_model.")}
+        assert {k.split(".")[0] for k in heads} >= {"reduces", "blocks", "seg_head" if task == "seg" else "cls_head"}      # (the other head is never frozen by the reference either)
+    import pytest
+    with pytest.raises(ValueError):
+        CLIPAdapter(clip, task="det").freeze_clip_backbone()

@@ -302,3 +302,38 @@ def test_dicece_hand_cases():
     # metric: prediction = all background on an image with foreground -> 0; empty ground truth -> NaN
     d = losses_ref.dice_metric(torch.cat([sat * -1, sat]), torch.cat([label, torch.zeros_like(label)]))
     assert float(d[0]) == 0.0 and math.isnan(float(d[1]))
+
+
+# ----------------------------------------------------------------------------- round-5 fixtures (oracle/gen_golden_r05.py)
+@pytest.mark.parametrize("task", ["seg", "cls"])
+def test_clip_adapter_openai_matches_reference(golden, task):
+    """oracle/fpn_ref.openai_adapter_forward against the reference's CLIPAdapter (src/third_party/openai_clip/clip_adapter.py:6-165): output and every gradient."""
+    from oracle import fpn_ref
+    base, g = golden("openai_clip_base"), golden("clip_adapter_openai")
+    P = params_of(base)
+    P.update({k: v.clone().requires_grad_(True) for k, v in params_of(g).items()})
+    A = {k[2:]: v.clone().requires_grad_(True) for k, v in g.items() if k.startswith("A.")}
+    y = fpn_ref.openai_adapter_forward(g["images"], P, A, task=task, extract_layers=(0, 1), heads=2, img_size=32, mona=dict(variant="freq_enhanced", hw=(4, 4)))
+    (y * g[f"{task}.dy"]).sum().backward()
+    close(y, g[f"{task}.y"], 1e-4, 1e-5)
+    gmax = max(float(v.abs().max()) for k, v in g.items() if k.startswith(f"{task}.g."))
+    for k, v in g.items():
+        if k.startswith(f"{task}.g."):
+            name = k[len(task) + 3:]
+            got = P[name[len("clip_model."):]].grad if name.startswith("clip_model.") else A[name].grad
+            assert float((got - v).abs().max()) < 1e-4 * max(float(v.abs().max()), 1e-2 * gmax), name
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("case", ["eval", "drop", "nohw"])
+def test_mona_at_bottleneck_64_matches_reference(golden, variant, case):
+    """The fixtures the HIP path is run on directly (tests/test_golden_gpu.py) also pin the oracle at that geometry (width 128, bottleneck 64)."""
+    g = golden(f"ref_mona_{variant}_d128")
+    P = {k: v.clone().requires_grad_(True) for k, v in params_of(g).items()}
+    x = g[f"{case}.x"].permute(1, 0, 2).contiguous().requires_grad_(True)
+    y = mona_ref.forward(x, P, variant, None if case == "nohw" else (4, 4), keep_mask=g["drop.keep"] if case == "drop" else None, p_drop=0.1)
+    y.backward(g[f"{case}.dy"].permute(1, 0, 2))
+    close(y, g[f"{case}.y"].permute(1, 0, 2))
+    close(x.grad, g[f"{case}.dx"].permute(1, 0, 2))
+    for k in P:
+        close(P[k].grad, g[f"{case}.g." + k], 1e-4, 1e-5)

@@ -432,7 +432,7 @@ def test_checkpoint_round_trip_into_zero_shot_vs_oracle(tmp_path, monkeypatch):
     fi = fi / fi.norm(dim=-1, keepdim=True)
     cols = []
     for c in zero_shot.LESION_TYPES:
-        ft = text_ref.bert_text_forward(tokenizer(zero_shot.DEFAULT_PROMPTS[c]), sd, heads=2)
+        ft = text_ref.bert_text_forward(tokenizer(zero_shot.ensemble_for(args.dataset)[c]), sd, heads=2)
         ft = ft / ft.norm(dim=-1, keepdim=True)
         cols.append((100.0 * fi @ ft.T).mean(dim=1))
     ref = torch.stack(cols, dim=1)
