@@ -495,7 +495,7 @@ def entry_point_form(args, device):
     steady = out["epochs"][1:]
     ms = sum(e["ms"] for e in steady) / max(1, sum(e["updates"] for e in steady))
     return {"ms_per_step": round(ms, 3), "value": round(args.batch / ms * 1e3, 2), "unit": "images/s", "vs_headline_ms": None,
-            "epochs": [{"ms": round(e["ms"], 1), "updates": e["updates"]} for e in out["epochs"]], "updates": out["updates"], "last_train_loss": round(out["last_train"], 5),
+            "epochs": [{k: (round(v, 1) if isinstance(v, float) else v) for k, v in e.items()} for e in out["epochs"]], "updates": out["updates"], "last_train_loss": round(out["last_train"], 5),
             "child_wall_s": round(wall, 1),
             "what": "src/models/biomedclip/finetune.py main() as a child process: synthetic pairs from loader workers -> pinned staging -> copy stream -> engine.ContrastiveLoop "
                     "(contrastive_micro + device-guarded accumulate / clip + AdamW, cosine LR on the device) ; epochs 2-3 of 3, wall time per optimiser update",

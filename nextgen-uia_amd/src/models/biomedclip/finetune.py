@@ -181,11 +181,16 @@ def train(args):
         model.train()
         loop.begin_epoch(len(trainloader))
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
+        t0, w0, enq, gw0 = time.perf_counter(), train_pf.wait_s, 0.0, getattr(opt, "gpu_wait_s", 0.0) + UF._STATE.get("gpu_wait_s", 0.0)
         for batch_idx, (images, tokens, ready) in enumerate(batches):
+            t1 = time.perf_counter()
             loop.micro(images, tokens, batch_idx, ready=ready)
+            enq += time.perf_counter() - t1
+        t2 = time.perf_counter()
         g = loop.end_epoch()                                     # the epoch's one host read (reference: loss.item() per batch, :290)
-        epoch_ms.append({"ms": (time.perf_counter() - t0) * 1e3, "updates": g["updates"] - update_count, "batches": len(trainloader)})
+        epoch_ms.append({"ms": (time.perf_counter() - t0) * 1e3, "updates": g["updates"] - update_count, "batches": len(trainloader),
+                         "loader_wait_ms": (train_pf.wait_s - w0) * 1e3, "enqueue_ms": enq * 1e3, "drain_ms": (time.perf_counter() - t2) * 1e3,
+                         "host_waited_for_gpu_ms": (getattr(opt, "gpu_wait_s", 0.0) + UF._STATE.get("gpu_wait_s", 0.0) - gw0) * 1e3})
         update_count = g["updates"]
         for i in g["skipped_batches"]:
             logging.warning(f"Non-finite loss detected at batch {i} in epoch {epoch + 1}, skipping batch")

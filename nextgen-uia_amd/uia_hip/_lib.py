@@ -156,6 +156,7 @@ PROTOTYPES = {
 }
 
 _lib = None
+_BLOCKING = ("uia_comm_init", "uia_comm_destroy", "uia_comm_get_unique_id")
 
 
 class UiaError(RuntimeError):
@@ -169,12 +170,21 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise UiaError(f"{LIB_PATH} not built: run `make -C nextgen-uia_amd/csrc` (hipcc --offload-arch=gfx950). "
                            "There is no CPU fallback for the uia hot path.")
-        handle = C.CDLL(LIB_PATH)
+        # PyDLL: the interpreter lock is NOT released around a call.  Every entry point but the communicator's set-up is an asynchronous enqueue of a few
+        # microseconds; releasing the lock ~600 times per training step hands it to whatever other thread wants it (a loader thread unpickling a batch) and the
+        # enqueuing thread then waits for it to come back each time (the fine-tune CLI measured 46 ms of wall time per step for 15 ms of CPU).  The calls that can
+        # block on other processes (RCCL bootstrap / teardown) go through a CDLL handle of the same library, which does release it.  UIA_CTYPES_RELEASE_GIL=1: the
+        # old behaviour, for A/B runs.
+        release = os.environ.get("UIA_CTYPES_RELEASE_GIL", "0") == "1"
+        handle = (C.CDLL if release else C.PyDLL)(LIB_PATH)
+        blocking = C.CDLL(LIB_PATH)
         _one_copy_of("librccl")                  # the library's RCCL must be the one PyTorch loaded (same SONAME: the loader re-uses it
         _one_copy_of("libamdhip64")              # when torch is imported first); two runtimes in one process would not share state
         for name, (res, args) in PROTOTYPES.items():
-            fn = getattr(handle, name)
+            fn = getattr(blocking if name in _BLOCKING else handle, name)
             fn.restype, fn.argtypes = res, args
+            if name in _BLOCKING:
+                setattr(handle, name, fn)
         _lib = handle
     return _lib
 

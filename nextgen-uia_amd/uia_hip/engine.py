@@ -11,6 +11,7 @@ its local mean loss, the flat gradient buffers are summed by one all-reduce, and
 """
 import math
 import os
+import time
 
 import torch
 
@@ -165,7 +166,9 @@ class FlatAdapterOptimizer(FlatLayout):
         was read by something that is not its consumer: raise instead of training on NaN weights."""
         prev = getattr(self, "_norm_poll", None)
         if prev is not None:
-            prev[1].synchronize()                              # recorded a whole update ago
+            t0 = time.perf_counter()
+            prev[1].synchronize()                              # recorded a whole update ago: returns at once unless the host is a full update ahead of the GPU
+            self.gpu_wait_s = getattr(self, "gpu_wait_s", 0.0) + time.perf_counter() - t0
             if float(prev[0][1]) != 0.0 and not math.isfinite(float(prev[0][0])):
                 raise FloatingPointError("uia_hip: the accumulated adapter gradient is non-finite although every accumulated loss was finite: the backward diverged "
                                          "(or a three-byte gradient token reached a consumer that is not its partner Function — run with engine.GRAD_RESID3 = False)")
@@ -551,42 +554,70 @@ class DevicePrefetcher:
         import threading
         self.loader, self.tokenizer, self.device, self.depth = loader, tokenizer, torch.device(device), max(1, depth)
         self._threading = threading
+        self.wait_s = 0.0
         self._slots = None
         self._copy = torch.cuda.Stream(device=self.device)
 
     def __len__(self):
         return len(self.loader)
 
-    def _make_slots(self, images, ids):
+    def _make_slots(self, images, ids, staging=True):
         n = self.depth + 2
-        self._slots = [{"h_im": torch.empty(images.shape, dtype=images.dtype, pin_memory=True), "h_id": torch.empty(ids.shape, dtype=ids.dtype, pin_memory=True),
+        self._slots = [{"h_im": None, "h_id": None,             # pinned staging buffers, made on first use (not needed when the loader's ring itself is pinned)
                         "d_im": torch.empty(images.shape, dtype=images.dtype, device=self.device), "d_id": torch.empty(ids.shape, dtype=ids.dtype, device=self.device),
                         "free": None, "copied": None} for _ in range(n)]
 
     def _producer(self, it, q):
         try:
             torch.cuda.set_device(self.device)
+            ring = getattr(getattr(self.loader, "collate_fn", None), "release", None) and self.loader.collate_fn       # datasets.finetune.SharedBatchRing
+            ring_dma = bool(ring is not None and ring.pin())    # host-to-device copies straight from the shared slot (registered as pinned memory)
+            pending = []                                        # (event of the copy, ring slot): handed back to the workers once the copy has run
             k = 0
             for batch in it:
-                images, texts = batch[0], batch[1]
-                ids = batch[2] if len(batch) > 2 else self.tokenizer(list(texts))      # a DataModule built with the tokenizer has tokenised in its workers
-                if self._slots is None or self._slots[0]["h_im"].shape != images.shape or self._slots[0]["h_id"].shape != ids.shape:
-                    self._make_slots(images, ids)
+                slot = None
+                if ring is not None and len(batch) == 3 and isinstance(batch[0], str) and batch[0] == ring.MARK:
+                    slot = batch[1]
+                    images, ids = ring.images[slot], ring.ids[slot]
+                else:
+                    images = batch[0]
+                    ids = batch[2] if len(batch) > 2 else self.tokenizer(list(batch[1]))      # a DataModule built with the tokenizer has tokenised in its workers
+                if self._slots is None or self._slots[0]["d_im"].shape != images.shape or self._slots[0]["d_id"].shape != ids.shape:
+                    self._make_slots(images, ids, staging=not (slot is not None and ring_dma))
                 sl = self._slots[k % len(self._slots)]
                 k += 1
-                if sl["copied"] is not None:
-                    sl["copied"].synchronize()                  # the pinned staging buffers are free once their copy has run
-                sl["h_im"].copy_(images)
-                sl["h_id"].copy_(ids)
+                if slot is not None and ring_dma:
+                    src_im, src_id = images, ids
+                else:
+                    if sl.get("h_im") is None:
+                        sl["h_im"], sl["h_id"] = torch.empty(images.shape, dtype=images.dtype, pin_memory=True), torch.empty(ids.shape, dtype=ids.dtype, pin_memory=True)
+                    if sl["copied"] is not None:
+                        sl["copied"].synchronize()              # the pinned staging buffers are free once their copy has run
+                    sl["h_im"].copy_(images)
+                    sl["h_id"].copy_(ids)
+                    src_im, src_id = sl["h_im"], sl["h_id"]
+                    if slot is not None:
+                        ring.release(slot)
+                        slot = None
                 with torch.cuda.stream(self._copy):
                     if sl["free"] is not None:
                         self._copy.wait_event(sl["free"])       # the consumer's last reader of this device slot
-                    sl["d_im"].copy_(sl["h_im"], non_blocking=True)
-                    sl["d_id"].copy_(sl["h_id"], non_blocking=True)
+                    sl["d_im"].copy_(src_im, non_blocking=True)
+                    sl["d_id"].copy_(src_id, non_blocking=True)
                     ev = torch.cuda.Event()
                     ev.record(self._copy)
                 sl["copied"] = ev
+                if slot is not None:
+                    pending.append((ev, slot))
+                while pending and (pending[0][0].query() or len(pending) >= max(2, ring.slots - 2 * getattr(self.loader, "num_workers", 0) - 1)):
+                    e, sidx = pending.pop(0)
+                    e.synchronize()
+                    ring.release(sidx)
+                del batch, images, ids
                 q.put((sl, ev))
+            for e, sidx in pending:
+                e.synchronize()
+                ring.release(sidx)
             q.put(None)
         except BaseException as e:                              # surfaces in the consumer
             q.put(e)
@@ -595,7 +626,8 @@ class DevicePrefetcher:
         """Starts the producer NOW (not at the first next()): the first `depth` batches are loaded, staged and copied while the caller does something else."""
         import queue
         q = self._q = queue.Queue(maxsize=self.depth)
-        th = self._threading.Thread(target=self._producer, args=(iter(self.loader), q), daemon=True)
+        first = self.loader.__dict__.pop("_uia_first_iter", None) if hasattr(self.loader, "__dict__") else None      # DataModule.start_workers() made it before the GPU was touched
+        th = self._threading.Thread(target=self._producer, args=(first if first is not None else iter(self.loader), q), daemon=True)
         th.start()
         return self._consume(th, q)
 
@@ -607,7 +639,9 @@ class DevicePrefetcher:
                 ev.record(torch.cuda.current_stream(self.device))
                 prev["free"] = ev
                 prev = None
+            t0 = time.perf_counter()
             item = q.get()
+            self.wait_s += time.perf_counter() - t0              # time the consumer stood still for the loader (0 when the pipeline keeps up)
             if item is None:
                 break
             if isinstance(item, BaseException):

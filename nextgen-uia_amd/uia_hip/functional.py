@@ -15,6 +15,8 @@ Residual stream, parameter gradients: fp32.  GEMM / attention operands: `T` = th
 import math
 import weakref
 
+import time
+
 import torch
 
 from . import ops
@@ -111,7 +113,9 @@ def poll_ln_flag(device=None, sync=False):
     seen = 0
     prev = _FOLD_POLL.pop(key, None)
     if prev is not None:
-        prev[1].synchronize()                                   # long done: it was recorded a whole step ago
+        t0 = time.perf_counter()
+        prev[1].synchronize()                                   # long done: it was recorded a whole step ago (unless the host is that far ahead of the GPU)
+        _STATE["gpu_wait_s"] = _STATE.get("gpu_wait_s", 0.0) + time.perf_counter() - t0
         seen |= int(prev[0][0])
     host = torch.empty(1, dtype=torch.int32, pin_memory=True)
     host.copy_(flag, non_blocking=True)                         # the bits are sticky (no per-step fill launch): reset_ln_flag() clears them
@@ -1080,7 +1084,16 @@ class ClsHeadFn(torch.autograd.Function):
         dt = compute_dtype()
         df = t_copy_of(dfeat.contiguous(), hdt)
         dh = _empty((B, D), hdt, x)
-        ops.gemm(df, WEIGHTS.get(w, hdt, transpose=not w_is_in_out), out_t=dh)
+        E = df.shape[1]
+        if E % 64:                                          # an embedding narrower than the GEMM's K granule (toy geometries: the reference's own test-size CLIP has 16): zero-padded contraction
+            Ep = (E + 63) // 64 * 64
+            dfp = df.new_zeros(B, Ep)
+            dfp[:, :E] = df
+            df = dfp
+            wt = WEIGHTS.get(w, hdt, transpose=not w_is_in_out, **({"pad_cols_to": Ep} if w_is_in_out else {"pad_rows_to": Ep}))
+        else:
+            wt = WEIGHTS.get(w, hdt, transpose=not w_is_in_out)
+        ops.gemm(df, wt, out_t=dh)
         if hdt != dt:                                       # the LayerNorm backward writes dx's T copy in the dtype of its dy: hand it a T copy of dh
             dh_t = _empty((B, D), dt, x)
             ops.cast(dh, dh_t)

@@ -789,11 +789,21 @@ def wgrad_group(a_list, b_list, dw_list, dbias_list=None, alpha=1.0, drop=None):
     check(lib().uia_wgrad_group(_stream(), _code(a0.dtype), C.byref(d)), "uia_wgrad_group")
 
 
-def _attn_desc(q, k, v, out, lse, B, H, L, mask, keylen, scale, dh=64):
+def _attn_desc(q, k, v, out, lse, B, H, L, mask, keylen, scale, dh=None):
     d = AttnDesc()
     for t in (q, k, v):
         if t.stride(-1) != 1 or t.dtype != q.dtype:
             raise UiaError("attention operands must be unit-stride in the last dim and share a dtype")
+    # the head dimension is what the operand views say it is: q holds H * dh columns (round 5: callers that left the old default of 64 with a 64-wide, two-head
+    # tower — the reference's own toy geometry, tests/golden/openai_clip_base.npz — had head 1 read and WRITE 64 columns past its rows)
+    width = q.shape[-1]
+    if width % H != 0 or (dh is not None and dh * H != width) or k.shape[-1] != width or v.shape[-1] != width:
+        raise UiaError(f"attention: q / k / v are {q.shape[-1]} / {k.shape[-1]} / {v.shape[-1]} columns wide for {H} heads" + (f" of dim {dh}" if dh is not None else ""))
+    dh = width // H
+    if dh not in (16, 32, 64):
+        raise UiaError(f"attention: head dim {dh} unsupported (16, 32 or 64): {width} columns over {H} heads")
+    if not is_kb(out) and out.shape[-1] != width:
+        raise UiaError(f"attention: out is {out.shape[-1]} columns wide, q / k / v {width}")
     d.q, d.k, d.v, d.ld_qkv = _p(q), _p(k), _p(v), q.stride(-2)
     assert k.stride(-2) == q.stride(-2) == v.stride(-2)
     if is_kb(out):                                     # K-blocked [B*L, H*dh] output (bf16, dh = 64): A operand of the output projection
@@ -811,7 +821,7 @@ def _attn_desc(q, k, v, out, lse, B, H, L, mask, keylen, scale, dh=64):
     return d
 
 
-def attn_fwd(q, k, v, out, B, H, L, lse=None, mask=None, keylen=None, scale=None, dh=64, cu_seqlens=None):
+def attn_fwd(q, k, v, out, B, H, L, lse=None, mask=None, keylen=None, scale=None, dh=None, cu_seqlens=None):
     """q,k,v: views whose element (b,l,h,d) is at base[(b*L+l)*ld + h*dh + d] (e.g. slices of the fused qkv).
     cu_seqlens (int32 [B+1], forward only): packed sequences — sequence b is rows cu[b]..cu[b+1]-1, L = the longest one."""
     d = _attn_desc(q, k, v, out, lse, B, H, L, mask, keylen, scale, dh)
@@ -824,8 +834,9 @@ def attn_fwd(q, k, v, out, B, H, L, lse=None, mask=None, keylen=None, scale=None
 ATTN_BWD_CFG = 0     # uia_attn_bwd_cfg's kernel configuration (0 = the library's choice); tools and tests switch it for A/B runs
 
 
-def attn_bwd(q, k, v, out, dout, lse, dq, dk, dv, B, H, L, mask=None, keylen=None, scale=None, dh=64, cfg=None):
+def attn_bwd(q, k, v, out, dout, lse, dq, dk, dv, B, H, L, mask=None, keylen=None, scale=None, dh=None, cfg=None):
     d = _attn_desc(q, k, v, out, lse, B, H, L, mask, keylen, scale, dh)
+    dh = d.dh
     d.dout, d.lddo = _p(dout), dout.stride(-2)
     if is_kb(dq):                                      # the fused [B*L, 3*H*dh] gradient, K-blocked (dk, dv are then None): A operand of the QKV dgrad
         rows, cols, d.dqkv_kb_rows = _kb_dims(dq, "attention dqkv")

@@ -376,3 +376,45 @@ def test_clip_adapter_openai_layout_names_and_freeze_rule():
     import pytest
     with pytest.raises(ValueError):
         CLIPAdapter(clip, task="det").freeze_clip_backbone()
+
+
+def test_shared_batch_ring_carries_every_batch_through_reused_slots():
+    """datasets.finetune.SharedBatchRing with real loader worker processes (CPU only: no pinning): every batch of two epochs arrives in order as (marker, slot, captions),
+    the slot holds exactly the samples default_collate would have stacked and the token ids the tokenizer gives for those captions, and the ring of 2·workers + 4 slots is
+    recycled (more batches than slots) without a worker ever writing into a slot the consumer has not released."""
+    import types
+    import torch
+    from src.datasets import finetune as F
+    from src.third_party.biomedclip.model import SyntheticTokenizer
+    args = types.SimpleNamespace(synthetic=True, synthetic_train=22 * 4, synthetic_val=8, img_size=16, seed=3, batch_size=4, num_workers=2, data_pt=None)
+    tok = SyntheticTokenizer(32)
+    dm = F.DataModule(args, rank=0, world=1, tokenizer=tok)
+    loader = dm.train_dataloader()
+    ring = loader.collate_fn
+    assert isinstance(ring, F.SharedBatchRing) and ring.slots == 8 and len(loader) == 22
+    dm.start_workers()
+    try:
+        it = loader.__dict__.pop("_uia_first_iter")
+        for epoch in range(2):
+            seen = []
+            held = []
+            for batch in (it if epoch == 0 else iter(loader)):
+                assert batch[0] == ring.MARK
+                slot, texts = batch[1], batch[2]
+                im, ids = ring.images[slot].clone(), ring.ids[slot].clone()
+                assert torch.equal(ids, tok(list(texts)))
+                seen.append((im, list(texts)))
+                held.append(slot)
+                if len(held) > 2:                                # the consumer keeps up to three slots (copies in flight) before handing one back
+                    ring.release(held.pop(0))
+            for s in held:
+                ring.release(s)
+            assert len(seen) == 22
+            # every sample of the dataset exactly once per epoch (shuffled), each image beside its own caption
+            ds = dm.train
+            got = {t: im_b[j] for im_b, texts in seen for j, t in enumerate(texts)}
+            for i in range(len(ds)):
+                img, text = ds[i]
+                assert text in got and torch.equal(got[text], img)
+    finally:
+        dm.shutdown()
