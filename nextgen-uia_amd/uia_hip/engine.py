@@ -298,9 +298,13 @@ class GatherFeaturesFn(torch.autograd.Function):
 _SIDE_STREAM = {}
 
 
+TEXT_STREAM_PRIORITY = int(os.environ.get("UIA_TEXT_PRIO", "0"))      # HIP stream priority of the text tower's stream (0 = default, -1 = high); experiment knob
+SLICE_STREAM_PRIORITY = int(os.environ.get("UIA_SLICE_PRIO", "0"))    # ... of the image tower's second-slice stream(s)
+
+
 def _side_stream(device):
     if device not in _SIDE_STREAM:
-        _SIDE_STREAM[device] = torch.cuda.Stream(device=device)
+        _SIDE_STREAM[device] = torch.cuda.Stream(device=device, priority=TEXT_STREAM_PRIORITY)
     return _SIDE_STREAM[device]
 
 
@@ -310,7 +314,7 @@ _MB_STREAMS = {}
 def _mb_streams(device, n):
     key = (device.index if device.index is not None else torch.cuda.current_device(), n)
     if key not in _MB_STREAMS:
-        _MB_STREAMS[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
+        _MB_STREAMS[key] = [torch.cuda.Stream(device=device, priority=SLICE_STREAM_PRIORITY) for _ in range(n)]
     return _MB_STREAMS[key]
 
 
