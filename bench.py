@@ -374,7 +374,11 @@ def main():
     if not args.batch:
         args.batch = 256 if args.config == "mona" else 128
     args.entry_point_result = None
-    if world == 1 and args.config == "mona" and not args.no_entry_point and not args.no_overlap_text and args.streams == 1:
+    profiled = "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.upper().startswith(("ROCPROF", "ROCP_")) for k in os.environ)
+    if profiled and not args.no_entry_point:
+        # under rocprofv3 the profiler's preloaded library has initialised the GPU before this program started, and a child would inherit the tool: no child process
+        args.entry_point_result = {"skipped": "running under rocprofv3: the entry-point child process is not started (pass --no-entry-point to silence)"}
+    elif world == 1 and args.config == "mona" and not args.no_entry_point and not args.no_overlap_text and args.streams == 1:
         # FIRST, before this process has touched the GPU (a program started from a process with a live HIP runtime is not allowed on this pool, and the two would share the
         # device): the fine-tune CLI as a child process, run to completion; its figure is attached to the line below
         args.entry_point_result = entry_point_form(args, f"cuda:{local}")

@@ -11,7 +11,7 @@ cd $GRAFT_REPO_ROOT
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
-  timeout 420 rocprofv3 --pmc $set --output-format csv -d $OUT -o pass$i -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --also-streams 0 --no-overlap-text --no-secondary $UIA_PMC_ARGS > $OUT/pass$i.log 2>&1
+  timeout 420 rocprofv3 --pmc $set --output-format csv -d $OUT -o pass$i -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --also-streams 0 --no-overlap-text --no-secondary --no-entry-point $UIA_PMC_ARGS > $OUT/pass$i.log 2>&1
   tail -1 $OUT/pass$i.log | cut -c1-120
 done
 python3 - <<PY

@@ -7,7 +7,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/traffic
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 420 rocprofv3 --pmc $c --output-format csv -d $OUT -o $c -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --also-streams 0 --no-overlap-text --no-secondary > $OUT/$c.log 2>&1
+  timeout 420 rocprofv3 --pmc $c --output-format csv -d $OUT -o $c -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --also-streams 0 --no-overlap-text --no-secondary --no-entry-point > $OUT/$c.log 2>&1
   tail -1 $OUT/$c.log | cut -c1-160
 done
 python3 - <<PY

@@ -8,6 +8,6 @@ for V in a b; do
   mkdir -p $OUT
   cd $GRAFT_REPO_ROOT
   FLAG=""; [ $V = b ] && FLAG="$AB_FLAGS"
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o step -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-overlap-text --no-secondary $FLAG > $OUT/bench.log 2>&1 || exit 1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o step -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-overlap-text --no-secondary --no-entry-point $FLAG > $OUT/bench.log 2>&1 || exit 1
   tail -1 $OUT/bench.log | cut -c1-160
 done
