@@ -91,19 +91,22 @@ def _normalise(fi, ft):
     return fi / fi.norm(dim=-1, keepdim=True), ft / ft.norm(dim=-1, keepdim=True)
 
 
-def train(args):
-    """reference metaclip/finetune.py:98-215 on the measured step (engine.ContrastiveLoop with one micro-batch per update, the reference has no accumulation here): no host
+def train(args, prepare=None, tokenizer_of=None):
+    """prepare / tokenizer_of: another model family's `prepare_model(args) -> (model, tokenizer)` / `make_tokenizer(args)` around the same loop (the reference's clip/ and
+    unimedclip/ entry points repeat it verbatim: src/models/clip/finetune.py:92-215).
+
+    reference metaclip/finetune.py:98-215 on the measured step (engine.ContrastiveLoop with one micro-batch per update, the reference has no accumulation here): no host
     read per batch; the non-finite skip (:153-155: no backward, no optimiser step, no scheduler step, iter_num not advanced) is the device-guarded update."""
     rank, _, world = dist_env()
     if not torch.cuda.is_initialized():                         # a fresh CLI process (not a caller that is already running other GPU / CPU work in this process)
         torch.set_num_threads(max(1, min(4, torch.get_num_threads())))      # host tensor work here is one staging copy per batch; the default (every logical CPU of the node) oversubscribes a job's CPU share
-    dm = dataset_finetune.DataModule(args, rank=rank, world=world, tokenizer=make_tokenizer(args))
+    dm = dataset_finetune.DataModule(args, rank=rank, world=world, tokenizer=(tokenizer_of or make_tokenizer)(args))
     trainloader, valloader = dm.train_dataloader(), dm.val_dataloader()
     dm.start_workers()                                         # loader worker processes are forked BEFORE this process touches the GPU
     bind_device(args)                                          # data parallel: cuda:LOCAL_RANK before anything is allocated
     UF.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
     UF.set_dropout_seed(args.seed + 7919 * rank)
-    model, tokenizer = prepare_model(args)
+    model, tokenizer = (prepare or prepare_model)(args)
     model.train()
     logging.info(model_summary({"model": model}))
     criterion = InfoNCELoss(temperature=args.temperature)

@@ -418,3 +418,16 @@ def test_shared_batch_ring_carries_every_batch_through_reused_slots():
                 assert text in got and torch.equal(got[text], img)
     finally:
         dm.shutdown()
+
+
+def test_openai_clip_finetune_cli_matches_the_reference_flags():
+    """src/models/clip/finetune.py keeps the reference's flags and defaults (reference src/models/clip/finetune.py:27-62)."""
+    from src.models.clip import finetune
+    a = finetune.get_args([])
+    want = dict(img_size=224, num_workers=8, strong_augs=False, weak_augs=False, mona_variant="noise_aware", exp="clip_finetune", ckpt="ckpt/ViT-B-16.pt", in_channels=3,
+                mona_bottleneck=64, mona_layers=None, temperature=0.07, seed=1, epochs=1000, batch_size=64, lr=1e-4, lr_min=1e-8, weight_decay=0.01, beta1_adam=0.9,
+                beta2_adam=0.95, patience=10)
+    for k, v in want.items():
+        assert getattr(a, k) == v, k
+    assert finetune._geometry(a) == (512, 224, 12, 768, 16, 77, 49408, 512, 8, 12)
+    assert finetune._geometry(finetune.get_args(["--model_config", "(64, 32, 2, 128, 8, 16, 100, 128, 2, 2)"])) == (64, 32, 2, 128, 8, 16, 100, 128, 2, 2)

@@ -303,3 +303,16 @@ def test_every_adapter_gradient_tensor_against_the_global_gradient_scale(variant
     assert r["image_features_rel"] < 1e-2 and r["text_features_rel"] < 1e-2 and r["logits_rel"] < 1e-2, r
     assert r["grad_cosine"] > 0.99 and r["grad_rel_l2"] < 0.15, r
     assert r["grad_worst_per_tensor_err_over_global_max"] < 0.15, r
+
+
+def test_openai_clip_finetune_entry_point(tmp_path, monkeypatch):
+    """src.models.clip.finetune (reference src/models/clip/finetune.py: the MetaCLIP loop around the OpenAI-layout CLIP + inject_mona_variant_to_clip, default variant
+    noise_aware): per-iteration updates on the measured step, best-val checkpoint of the "mona" parameters under the OpenAI key names (the checkpoint wire format)."""
+    from src.models.clip import finetune
+    monkeypatch.chdir(tmp_path)
+    out = finetune.main(["--synthetic", "--synthetic_train", "64", "--synthetic_val", "16", "--img_size", "32", "--batch_size", "16", "--epochs", "2", "--lr", "2e-3",
+                         "--dtype", "bf16", "--exp", "c", "--ckpt", "", "--model_config", "(64, 32, 2, 128, 8, 16, 4000, 128, 2, 2)"])
+    ck = torch.load(tmp_path / "runs" / "c" / "best_model.pth")
+    assert ck and all("mona" in k and k.startswith("visual.transformer.resblocks.") for k in ck) and "visual.transformer.resblocks.0.mona.gamma" in ck
+    assert any("noise_estimator" in k for k in ck)                       # the reference's default variant here is noise_aware (:40)
+    assert out["iters"] == 2 * 4 and math.isfinite(out["best_val"]) and len(out["epochs"]) == 2
