@@ -102,6 +102,7 @@ def parse():
                     "instead of one launch on half-height tiles")
     ap.add_argument("--no-text-resid3", action="store_true", help="A/B knob: the text tower's sub-layer sums as fp32 + bf16 copy (rounds 2-3) instead of three-byte tensors "
                     "(bf16 copy + one low byte per element: 6 epilogue bytes per element instead of 10 on its 23 N = 768 launches)")
+    ap.add_argument("--no-fwd-resid3", action="store_true", help="A/B knob: Mona adapters hand their output to the next frozen block as fp32 + bf16 copy (rounds 1-4) instead of a three-byte tensor")
     ap.add_argument("--block-resid3", action="store_true", help="A/B knob (measured level, off by default): x1 / dx1 inside the frozen image blocks as three-byte tensors instead of fp32 + bf16 copy")
     ap.add_argument("--attn-bwd-cfg", type=int, default=0, help="A/B knob: kernel configuration of the bf16 attention backward (uia_attn_bwd_cfg: 0 = the library's choice, "
                     "1 = the lock-step kernel of rounds 1-3, 2 = barrier-free units, 5 = their persistent form)")
@@ -280,6 +281,25 @@ def gemm_roofline(prof, prof_serial, args, ms_per_step, ops, torch):
             traffic_err = f"kernel {kmangled} is not in profiles/{TRAFFIC_FILE}: the instantiation was renamed after the PMC passes; re-run tools/pmc_traffic.sh"
     ft, ff, fn, _ = fam.get(True, (tsec, flops, n, 0.0))
     fts, ffs, fns, _ = fam_inflight.get(True, (ts, fs, ns, 0.0))
+
+    def union_seconds(events):
+        """Wall time during which at least one launch of the family was running: small M tails of a split launch run on a side stream BESIDE their main launch
+        (ops.TAIL_SIDE_STREAM), so the SUM of the launch durations counts that time twice (ViT-L/14: 128-row tails of 80-130 us beside every main launch)."""
+        fam_ev = [(e0, e1) for e0, e1, M, N, K, _dt, cfg, nb, mask in events if cfg in (8, 12, 13, 14, 24)]
+        if not fam_ev:
+            return None
+        base = fam_ev[0][0]
+        iv = sorted((base.elapsed_time(e0), base.elapsed_time(e1)) for e0, e1 in fam_ev)
+        total, cur_s, cur_e = 0.0, iv[0][0], iv[0][1]
+        for s_, e_ in iv[1:]:
+            if s_ > cur_e:
+                total += cur_e - cur_s
+                cur_s, cur_e = s_, e_
+            else:
+                cur_e = max(cur_e, e_)
+        return (total + cur_e - cur_s) * 1e-3
+
+    fu = union_seconds(prof_serial)
     # in-kernel clock under sustained GEMM load (s_memtime / s_memrealtime, profiles/r03_a_inkernel_clock.txt): 1.51-1.65 GHz on this pool's
     # devices against the 2.4 GHz the 2.5 PF datasheet peak is quoted at; `frac` stays against the datasheet peak
     load_clock = {"measured_GHz": [1.51, 1.65], "source": "profiles/r03_a_inkernel_clock.txt (test_gemm_stamps: s_memtime / s_memrealtime x 100 MHz per workgroup, after 6-12 k warm launches)",
@@ -295,7 +315,9 @@ def gemm_roofline(prof, prof_serial, args, ms_per_step, ops, torch):
                       "shared with the other stream's kernels - those figures are under `in_timed_configuration`)" if multi else " of the same loop")),
             "gemm_family": {"kernels": "gemm_tn_ring_kernel<...,EPI> (+ gemm_tn_persist_kernel when selected), all epilogue masks",
                             "launches_per_step": fn, "achieved": round(ff / ft * 1e-12, 1), "frac": round(ff / ft * 1e-12 / peak, 4),
-                            "ms_per_step": round(ft * 1e3, 3)},
+                            "ms_per_step": round(ft * 1e3, 3),
+                            "busy_ms_per_step": None if fu is None else round(fu * 1e3, 3), "frac_over_busy_time": None if fu is None else round(ff / fu * 1e-12 / peak, 4),
+                            "busy_note": "ms_per_step sums the launches' durations; busy_ms_per_step is the time at least one of them was running (M tails run beside their main launch on a side stream)"},
             "per_shape": shape_table(prof_serial)}
     if multi:
         roof["in_timed_configuration"] = {"achieved": round(fs / ts * 1e-12, 1), "frac": round(fs / ts * 1e-12 / peak, 4), "avg_launch_us": round(ts / ns * 1e6, 2),
@@ -423,6 +445,7 @@ def main():
     _engine.IMAGE_SLICES = args.image_slices
     _engine.TEXT_SLICES = args.text_slices
     UF.set_block_resid3(args.block_resid3)
+    UF.set_fwd_resid3(not args.no_fwd_resid3)
     ops.PERSIST_STORE_ONLY = args.persist_store_only
     ops.TILE_GROUP = {int(k): int(v) for k, v in (kv.split("=") for kv in args.tile_group.split(",") if kv)}
     try:

@@ -960,6 +960,7 @@ int launch_ring(hipStream_t stream, const UiaGemmParams& p, bool specialise, int
             UIA_EPI_CASE(EPI_BIAS | EPI_RESID_LO | EPI_OUT32);                                           // ... and enters fc2's epilogue as one
             UIA_EPI_CASE(EPI_BIAS | EPI_RESID | EPI_RESID_LN | EPI_OUTT | EPI_OUT_LO | EPI_ROWSUM);      // text tower, first layer: the embedding LayerNorm's fp32 rows in, a three-byte sum out
             UIA_EPI_CASE(EPI_BIAS | EPI_RESID_LO | EPI_RESID_LN | EPI_OUT32);                            // text tower, last layer: a three-byte sum in, fp32 rows out for the pooler
+            UIA_EPI_CASE(EPI_BIAS | EPI_RESID_LO | EPI_OUT32 | EPI_OUTT | EPI_ROWSUM);                   // image tower, output projection behind a Mona adapter (round 5): the block's input arrives as a three-byte tensor
             UIA_EPI_CASE(EPI_BIAS | EPI_OUTT | EPI_LNFOLD);                                          // QKV
             UIA_EPI_CASE(EPI_BIAS | EPI_GELU | EPI_OUTT | EPI_LNFOLD);                               // fc1, frozen tower
             UIA_EPI_CASE(EPI_BIAS | EPI_GELU | EPI_AUX_OUT | EPI_OUTT | EPI_LNFOLD);                 // fc1 with the pre-activation stashed

@@ -13,6 +13,7 @@ Residual stream, parameter gradients: fp32.  GEMM / attention operands: `T` = th
 (torch.bfloat16, or torch.float32 for the parity mode).
 """
 import math
+import os
 import weakref
 
 import time
@@ -21,7 +22,7 @@ import torch
 
 from . import ops
 
-_STATE = {"dtype": torch.bfloat16, "seed": 0x5EED, "calls": 0}
+_STATE = {"dtype": torch.bfloat16, "seed": 0x5EED, "calls": 0, "fwd_resid3": os.environ.get("UIA_FWD_RESID3", "1") != "0"}
 
 
 def set_compute_dtype(dt):
@@ -45,6 +46,15 @@ def set_block_resid3(flag):
     half's output x1 and its gradient dx1 are three-byte tensors (bf16 T copy + one low byte per element) between the GEMM epilogues and the
     LayerNorm backward."""
     _STATE["block_resid3"] = bool(flag)
+
+
+def set_fwd_resid3(flag):
+    """bf16 mode with the LayerNorm fold (default ON; A/B: bench.py --no-fwd-resid3): between a Mona adapter and the frozen block behind it the residual stream travels as a
+    three-byte tensor in the FORWARD too — the bf16 T copy the block's QKV GEMM reads anyway plus one low byte per element — instead of fp32 + T copy: project2's epilogue
+    writes 3 bytes per element instead of 6, the block's output projection reads 3 instead of 4 for its residual, and so does the LayerNorm backward that recomputes the
+    block's first normalisation (the block saves 3 bytes per element for it instead of 4).  Only inside a tower's own block loop (linear_chain) and only when the next consumer
+    is a plain frozen block: autograd carries a token (publish_fwd3), as for the three-byte gradients."""
+    _STATE["fwd_resid3"] = bool(flag)
 
 
 def set_text_resid3(flag):
@@ -206,6 +216,7 @@ def clear_t_copies():
     _ROWS.clear()
     _SUMS_ARENA.clear()
     _G3.clear()
+    _F3.clear()
 
 
 # ------------------------------------------------------------------------------------------------
@@ -231,6 +242,35 @@ def grad_resid3_enabled():
     return bool(_STATE.get("grad_resid3", False))
 
 
+# Forward twin of the gradient tokens below: a residual-stream VALUE handed from MonaFn to the next block's VitBlockFn as (hi plane, low bytes, row sums).
+_F3 = {}
+_F3_POOL = {}
+
+
+def publish_fwd3(shape, device, hi, lo, sums):
+    key = (device.type, device.index if device.index is not None else (torch.cuda.current_device() if device.type == "cuda" else 0))
+    pool = _F3_POOL.get(key)
+    if pool is None:
+        pool = _F3_POOL[key] = [torch.full((256,), float("nan"), device=device, dtype=torch.float32), 0]
+    i = pool[1]
+    pool[1] = (i + 1) % 256
+    tok = pool[0][i:i + 1].view((1,) * len(shape)).expand(shape)
+    if len(_F3) >= 256:
+        _F3.clear()
+    _F3[tok.data_ptr()] = (hi, lo, sums, tok.numel())
+    return tok
+
+
+def fwd3_of(x):
+    """(hi, lo, sums) when x is a token of publish_fwd3 (consumed), else None.  Call BEFORE anything touches x's values (x.contiguous() would materialise NaNs)."""
+    if not _F3 or x.dim() == 0 or any(st != 0 for st, n in zip(x.stride(), x.shape) if n > 1):
+        return None
+    hit = _F3.pop(x.data_ptr(), None)
+    if hit is None or hit[3] != x.numel():
+        return None
+    return hit[0], hit[1], hit[2]
+
+
 class linear_chain:
     """Scope of a tower's own block loop (forward_features / VisionTransformer.forward): inside it the residual stream is a plain chain block -> adapter -> block,
     every block output has exactly ONE consumer, so a three-byte gradient token can stand in for its gradient.  Code that walks the blocks itself and taps
@@ -239,10 +279,18 @@ class linear_chain:
 
     def __enter__(self):
         _STATE["chain_depth"] = _STATE.get("chain_depth", 0) + 1
+        return self
 
     def __exit__(self, *exc):
         _STATE["chain_depth"] -= 1
+        _STATE["fwd3_next_plain"] = False
         return False
+
+    @staticmethod
+    def next_is_plain_block(flag):
+        """The tower's loop says, before it runs block i, whether block i + 1 exists and is a plain frozen block (VitBlockFn): only then may block i's adapter hand its
+        output over as a three-byte forward token (set_fwd_resid3)."""
+        _STATE["fwd3_next_plain"] = bool(flag)
 
 
 def _g3_partner_feeds(x):
@@ -641,8 +689,15 @@ class MonaFn(torch.autograd.Function):
         y = torch.empty_like(x)
         if ln_fold_enabled(dt, M):             # the next block's first LayerNorm is folded into its QKV GEMM: leave it the T rows and their sums
             y_t, sums = _act(M, D, dt, x, 3 * D), zero_sums(M, x.device)          # read by the next block's QKV GEMM only
-            ops.gemm(d, w2, bias=P["project2.bias"], resid=x.view(M, D), out32=y.view(M, D), out_t=y_t, rowsum=sums)
-            publish_rows(y, y_t, sums)
+            if (dt == torch.bfloat16 and _STATE.get("fwd_resid3", True) and _STATE.get("fwd3_next_plain", False) and _STATE.get("chain_depth", 0) > 0 and M > 2048
+                    and x.is_cuda):
+                # the next block takes the sum as a THREE-BYTE tensor: its hi plane is the T copy, one low byte per element beside it; no fp32 rows are written
+                y_lo = torch.empty(M, D, device=x.device, dtype=torch.int8)
+                ops.gemm(d, w2, bias=P["project2.bias"], resid=x.view(M, D), out_t=y_t, out_lo=y_lo, rowsum=sums)
+                y = publish_fwd3(x.shape, x.device, y_t, y_lo, sums)
+            else:
+                ops.gemm(d, w2, bias=P["project2.bias"], resid=x.view(M, D), out32=y.view(M, D), out_t=y_t, rowsum=sums)
+                publish_rows(y, y_t, sums)
         else:
             ops.gemm(d, w2, bias=P["project2.bias"], resid=x.view(M, D), out32=y.view(M, D))
         ctx.save_for_backward(x, u, t, d, keep_mask if keep_mask is not None else x.new_empty(0), *params)
@@ -790,27 +845,34 @@ class VitBlockFn(torch.autograd.Function):
     def forward(ctx, x, spec):
         B, N, D = x.shape
         M, dt = B * N, compute_dtype()
-        x = x.contiguous()
-        x2d = x.view(M, D)
+        x3 = fwd3_of(x)                                   # the adapter in front handed its output over as a three-byte tensor (set_fwd_resid3): (hi = T rows, low bytes, row sums)
+        like = x3[1] if x3 is not None else x
+        if x3 is None:
+            x = x.contiguous()
+            x2d = x.view(M, D)
         train = ctx.needs_input_grad[0]
         fold = ln_fold_enabled(dt, M)
-        rows = take_rows(x, dt) if fold else None        # (T copy of x, row sums) left by the GEMM that produced x
-        qkv = _empty((M, 3 * D), dt, x)
+        if x3 is not None:
+            assert fold and dt == torch.bfloat16, "a three-byte forward token reached a block that cannot take it"
+            rows = (x3[0], x3[2])
+        else:
+            rows = take_rows(x, dt) if fold else None    # (T copy of x, row sums) left by the GEMM that produced x
+        qkv = _empty((M, 3 * D), dt, like)
         if rows is not None:                              # LN1 folded into the QKV GEMM
             wq, cq, bq = WEIGHTS.get_lnfold(spec.qkv[0], spec.qkv[1], spec.ln1[0], spec.ln1[1], dt)
             xin_t = rows[0] if ops.is_kb(rows[0]) else rows[0].view(M, D)
             ops.gemm(xin_t, wq, bias=bq, out_t=qkv, lnfold=(rows[1], cq, D, spec.eps))
-            h1 = xin_t                                    # its storage is free after this GEMM
+            h1 = _act(M, D, dt, like, spec.fc1[0].shape[0]) if x3 is not None else xin_t     # (fp32 x: the T copy's storage is free after this GEMM; three-byte x: it IS x's hi plane and lives on)
         else:
             h1 = _empty((M, D), dt, x)
             ops.layernorm_fwd(x2d, spec.ln1[0], spec.ln1[1], spec.eps, y_t=h1)
             ops.gemm(h1, WEIGHTS.get(spec.qkv[0], dt), bias=spec.qkv[1], out_t=qkv)
-        a = _attn_act(M, D, dt, x, D) if D == 64 * spec.heads else _empty((M, D), dt, x)     # read by the output projection (and the backward kernel)
-        lse = torch.empty(B, spec.heads, N, device=x.device, dtype=torch.float32) if train else None
+        a = _attn_act(M, D, dt, like, D) if D == 64 * spec.heads else _empty((M, D), dt, like)     # read by the output projection (and the backward kernel)
+        lse = torch.empty(B, spec.heads, N, device=like.device, dtype=torch.float32) if train else None
         ops.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], a, B, spec.heads, N, lse=lse, mask=spec.mask)
         F = spec.fc1[0].shape[0]
-        f = _act(M, F, dt, x, D)                          # fc1's result is read by fc2 only
-        pre = _empty((M, F), dt, x) if train else None
+        f = _act(M, F, dt, like, D)                          # fc1's result is read by fc2 only
+        pre = _empty((M, F), dt, like) if train else None
         # x1 (the attention half's output) never leaves the block: with the fold it can be a THREE-BYTE tensor — the T copy fc1 reads anyway plus one
         # low byte per element (set_block_resid3, bf16, ring tile configs) — instead of fp32 + T copy: the projection's epilogue writes 3 bytes per
         # element instead of 6, fc2's reads 3 instead of 4, and so does the LayerNorm backward that recomputes its statistics (and 39 MB less per block
@@ -819,15 +881,16 @@ class VitBlockFn(torch.autograd.Function):
         # (2-, 1- and 4-byte elements) cannot all be read with 16-byte accesses per lane, and the row kernel turns from byte- into access-bound
         # (74.7 vs 69.0 us per launch, profiles/r04_c_ab_block_resid3.txt).
         r3 = fold and _STATE.get("block_resid3", False) and dt == torch.bfloat16 and M > 2048
-        x1 = None if r3 else torch.empty_like(x2d)
-        lo1 = torch.empty(M, D, device=x.device, dtype=torch.int8) if r3 else None
+        x1 = None if r3 else torch.empty(M, D, device=like.device, dtype=torch.float32)
+        lo1 = torch.empty(M, D, device=like.device, dtype=torch.int8) if r3 else None
         if fold:                                          # LN2 folded: proj leaves T rows + sums, fc1 normalises its accumulators
-            sums1 = zero_sums(M, x.device)
-            h1 = _as_act(h1, M, D, dt, F)
+            sums1 = zero_sums(M, like.device)
+            h1 = _as_act(h1, M, D, dt, F) if x3 is None else h1
+            resx = dict(resid3=(x3[0], x3[1])) if x3 is not None else dict(resid=x2d)
             if r3:
-                ops.gemm(a, WEIGHTS.get(spec.proj[0], dt), bias=spec.proj[1], resid=x2d, out_t=h1, out_lo=lo1, rowsum=sums1)
+                ops.gemm(a, WEIGHTS.get(spec.proj[0], dt), bias=spec.proj[1], out_t=h1, out_lo=lo1, rowsum=sums1, **resx)
             else:
-                ops.gemm(a, WEIGHTS.get(spec.proj[0], dt), bias=spec.proj[1], resid=x2d, out32=x1, out_t=h1, rowsum=sums1)
+                ops.gemm(a, WEIGHTS.get(spec.proj[0], dt), bias=spec.proj[1], out32=x1, out_t=h1, rowsum=sums1, **resx)
             w1, c1, b1 = WEIGHTS.get_lnfold(spec.fc1[0], spec.fc1[1], spec.ln2[0], spec.ln2[1], dt)
             ops.gemm(h1, w1, bias=b1, act=spec.act, aux_out=pre, out_t=f, lnfold=(sums1, c1, D, spec.eps))
         else:
@@ -835,11 +898,11 @@ class VitBlockFn(torch.autograd.Function):
             h1 = _as_act(h1, M, D, dt, 0)                                              # row-major: the LayerNorm kernel writes it
             ops.layernorm_fwd(x1, spec.ln2[0], spec.ln2[1], spec.eps, y_t=h1)          # h1 buffer reused as h2
             ops.gemm(h1, WEIGHTS.get(spec.fc1[0], dt), bias=spec.fc1[1], act=spec.act, aux_out=pre, out_t=f)
-        x2 = torch.empty_like(x)
+        x2 = torch.empty(B, N, D, device=like.device, dtype=torch.float32)
         res1 = dict(resid3=(h1, lo1)) if r3 else dict(resid=x1)
         if fold and spec.publish_out:
-            sums2 = zero_sums(M, x.device)
-            h2 = _act(M, D, dt, x, 3 * D) if r3 else _as_act(h1, M, D, dt, 3 * D)      # (three-byte: h1 is x1's hi plane and stays alive)
+            sums2 = zero_sums(M, like.device)
+            h2 = _act(M, D, dt, like, 3 * D) if r3 else _as_act(h1, M, D, dt, 3 * D)      # (three-byte: h1 is x1's hi plane and stays alive)
             ops.gemm(f, WEIGHTS.get(spec.fc2[0], dt), bias=spec.fc2[1], out32=x2.view(M, D), out_t=h2, rowsum=sums2, **res1)
             publish_rows(x2, h2, sums2)
         else:
@@ -847,10 +910,13 @@ class VitBlockFn(torch.autograd.Function):
         if train:
             ctx.a_kb = ops.is_kb(a)                       # save_for_backward takes tensors: the K-blocked wrapper is rebuilt in backward
             ctx.r3, ctx.h1_kb = r3, bool(r3 and ops.is_kb(h1))
+            ctx.x3_kb = None if x3 is None else bool(ops.is_kb(x3[0]))       # three-byte block input: its two planes are what the LayerNorm backward recomputes from
+            ctx.xshape = (B, N, D)
+            xs = (x,) if x3 is None else ((x3[0].t if ctx.x3_kb else x3[0]), x3[1])
             if r3:
-                ctx.save_for_backward(x, qkv, a.t if ctx.a_kb else a, lse, h1.t if ctx.h1_kb else h1, pre, lo1)
+                ctx.save_for_backward(*xs, qkv, a.t if ctx.a_kb else a, lse, h1.t if ctx.h1_kb else h1, pre, lo1)
             else:
-                ctx.save_for_backward(x, qkv, a.t if ctx.a_kb else a, lse, x1, pre)
+                ctx.save_for_backward(*xs, qkv, a.t if ctx.a_kb else a, lse, x1, pre)
             ctx.spec = spec
             ctx.g3_out = dt == torch.bfloat16 and _g3_partner_feeds(x)
         return x2
@@ -858,15 +924,23 @@ class VitBlockFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dx2):
         g3 = grad3_of(dx2)                                            # a three-byte gradient from the adapter behind this block: (T copy, possibly K-blocked; low bytes)
+        saved = list(ctx.saved_tensors)
+        if ctx.x3_kb is None:
+            x = saved.pop(0)
+            xin = None
+        else:                                                          # three-byte block input (set_fwd_resid3): (hi plane, low bytes)
+            xh, xl = saved.pop(0), saved.pop(0)
+            xin = (ops.KBlocked(xh) if ctx.x3_kb else xh, xl)
+            x = xl                                                     # device / allocation reference below
         if ctx.r3:
-            x, qkv, a, lse, h1, pre, lo1 = ctx.saved_tensors
+            qkv, a, lse, h1, pre, lo1 = saved
             x1 = (ops.KBlocked(h1) if ctx.h1_kb else h1, lo1)         # three-byte x1: (hi plane, low bytes)
         else:
-            x, qkv, a, lse, x1, pre = ctx.saved_tensors
+            qkv, a, lse, x1, pre = saved
         if ctx.a_kb:
             a = ops.KBlocked(a)
         spec = ctx.spec
-        B, N, D = x.shape
+        B, N, D = ctx.xshape
         M, dt = B * N, qkv.dtype
         F = pre.shape[1]
         if g3 is not None:
@@ -903,12 +977,13 @@ class VitBlockFn(torch.autograd.Function):
             ops.attn_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], a, da, lse, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], B, spec.heads, N, mask=spec.mask)
         ops.gemm(dqkv, WEIGHTS.get(spec.qkv[0], dt, transpose=True), out_t=da)       # dh1 into the same buffer
         dx_t = _empty((M, D), dt, x) if dt != torch.float32 else None
+        xrows = xin if xin is not None else x.view(M, D)
         if getattr(ctx, "g3_out", False):
             dlo = torch.empty(M, D, device=x.device, dtype=torch.int8)
-            ops.layernorm_bwd(da, x.view(M, D), spec.ln1[0], spec.eps, dres=dx1, dx_t=dx_t, dx_lo=dlo)
-            return publish_grad3(x.shape, x.device, dx_t, dlo), None
-        dx = torch.empty_like(x)
-        ops.layernorm_bwd(da, x.view(M, D), spec.ln1[0], spec.eps, dres=dx1, dx32=dx.view(M, D), dx_t=dx_t)
+            ops.layernorm_bwd(da, xrows, spec.ln1[0], spec.eps, dres=dx1, dx_t=dx_t, dx_lo=dlo)
+            return publish_grad3((B, N, D), x.device, dx_t, dlo), None
+        dx = torch.empty(B, N, D, device=x.device, dtype=torch.float32)
+        ops.layernorm_bwd(da, xrows, spec.ln1[0], spec.eps, dres=dx1, dx32=dx.view(M, D), dx_t=dx_t)
         publish_t_copy(dx, dx_t)
         return dx, None
 

@@ -30,11 +30,13 @@ _SPECIALISED = {EPI_BIAS | EPI_RESID | EPI_OUT32, EPI_BIAS | EPI_RESIDT | EPI_OU
                 EPI_QUICK | EPI_BIAS | EPI_GELU | EPI_OUTT | EPI_LNFOLD, EPI_QUICK | EPI_BIAS | EPI_GELU | EPI_AUX_OUT | EPI_OUTT | EPI_LNFOLD,
                 EPI_BIAS | EPI_RESID_LO | EPI_RESID_LN | EPI_OUTT | EPI_OUT_LO | EPI_ROWSUM,
                 EPI_BIAS | EPI_RESID | EPI_OUTT | EPI_OUT_LO | EPI_ROWSUM, EPI_BIAS | EPI_RESID_LO | EPI_OUT32,
-                EPI_BIAS | EPI_RESID | EPI_RESID_LN | EPI_OUTT | EPI_OUT_LO | EPI_ROWSUM, EPI_BIAS | EPI_RESID_LO | EPI_RESID_LN | EPI_OUT32}
+                EPI_BIAS | EPI_RESID | EPI_RESID_LN | EPI_OUTT | EPI_OUT_LO | EPI_ROWSUM, EPI_BIAS | EPI_RESID_LO | EPI_RESID_LN | EPI_OUT32,
+                EPI_BIAS | EPI_RESID_LO | EPI_OUT32 | EPI_OUTT | EPI_ROWSUM}
 
 # the masks csrc/gemm_quad.hip instantiates (tile cfg 25); the rest run its run-time epilogue
 _QUAD_SPECIALISED = _SPECIALISED - {EPI_BIAS | EPI_RESIDT | EPI_OUT32, EPI_BIAS | EPI_RESID | EPI_RESID_LN | EPI_OUT32, EPI_BIAS | EPI_RESID | EPI_RESID_LN | EPI_OUT32 | EPI_OUTT | EPI_ROWSUM,
-                                    EPI_BIAS | EPI_RESID | EPI_RESID_LN | EPI_OUTT | EPI_OUT_LO | EPI_ROWSUM, EPI_BIAS | EPI_RESID_LO | EPI_RESID_LN | EPI_OUT32}
+                                    EPI_BIAS | EPI_RESID | EPI_RESID_LN | EPI_OUTT | EPI_OUT_LO | EPI_ROWSUM, EPI_BIAS | EPI_RESID_LO | EPI_RESID_LN | EPI_OUT32,
+                                    EPI_BIAS | EPI_RESID_LO | EPI_OUT32 | EPI_OUTT | EPI_ROWSUM}
 
 
 def epi_mask_of(d):

@@ -316,3 +316,73 @@ def test_openai_clip_finetune_entry_point(tmp_path, monkeypatch):
     assert ck and all("mona" in k and k.startswith("visual.transformer.resblocks.") for k in ck) and "visual.transformer.resblocks.0.mona.gamma" in ck
     assert any("noise_estimator" in k for k in ck)                       # the reference's default variant here is noise_aware (:40)
     assert out["iters"] == 2 * 4 and math.isfinite(out["best_val"]) and len(out["epochs"]) == 2
+
+
+# ------------------------------------------------------------------------------------------------ three-byte residual stream in the FORWARD (Mona -> next block)
+def test_forward_three_byte_handoff_between_adapter_and_block_equals_fp32_handoff():
+    """UF.set_fwd_resid3: inside the tower's own loop a Mona adapter hands its output to the next plain frozen block as (bf16 T copy, low byte, row sums) instead of fp32 rows.
+    ViT-B/16 geometry at depth 3, B = 12 (2364 rows: the ring kernels and the LayerNorm fold), bf16: features, loss and every adapter gradient agree with the fp32 hand-off to
+    the three-byte format's 2^-16 (far inside the bf16 step's own noise), tokens are really in use (the new epilogue mask runs), the LAST adapter still hands fp32 rows to the
+    CLS head, and a tower with a LoRA block in the chain gets no token in front of that block."""
+    from uia_hip import functional as UF
+    from uia_hip import ops
+    from src.adapters import inject_mona_variant_to_open_clip
+    from src.losses import InfoNCELoss
+    from src.third_party.biomedclip.model import create_biomedclip
+    UF.set_compute_dtype(torch.bfloat16)
+    cfg = dict(embed_dim=128, vision_cfg=dict(img_size=224, patch_size=16, embed_dim=768, depth=3, num_heads=12),
+               text_cfg=dict(vocab_size=30000, hidden_size=128, num_hidden_layers=1, num_attention_heads=2, intermediate_size=256, max_position_embeddings=32))
+    g = torch.Generator().manual_seed(5)
+    images = torch.rand(12, 3, 224, 224, generator=g).to(dev())
+    ids = torch.zeros(12, 32, dtype=torch.long)
+    ids[:, 0], ids[:, 1:6], ids[:, 6] = 2, torch.randint(1000, 30000, (12, 5), generator=g), 3
+    ids = ids.to(dev())
+    outs, masks = [], []
+    orig = ops._gemm_one
+    try:
+        for flag in (False, True):
+            UF.set_fwd_resid3(flag)
+            UF.clear_t_copies()
+            model = create_biomedclip(config=cfg, seed=2)
+            for p in model.parameters():
+                p.requires_grad_(False)
+            inject_mona_variant_to_open_clip(model, variant="hybrid", bottleneck_dim=64)
+            tg = torch.Generator().manual_seed(9)
+            with torch.no_grad():
+                for k, p in model.named_parameters():
+                    if "mona" in k and not k.endswith(("norm.weight", "gammax")):
+                        p.copy_(0.05 * torch.randn(p.shape, generator=tg))
+            for k, p in model.named_parameters():
+                p.requires_grad_("mona" in k)
+            model = model.to(dev()).eval()
+            seen = []
+
+            def spy(*a, **kw):
+                seen.append((kw.get("resid3") is not None, kw.get("out_lo") is not None))
+                return orig(*a, **kw)
+            ops._gemm_one = spy
+            fi = model.encode_image(images)
+            with torch.no_grad():
+                ft = model.encode_text(ids)
+            ops._gemm_one = orig
+            loss = InfoNCELoss(0.07)(fi, ft)
+            loss.backward()
+            torch.cuda.synchronize()
+            outs.append((fi.detach().float().cpu(), float(loss), {k: p.grad.detach().float().cpu().clone() for k, p in model.named_parameters() if p.requires_grad}))
+            masks.append(seen)
+    finally:
+        ops._gemm_one = orig
+        UF.set_fwd_resid3(True)
+        UF.clear_t_copies()
+    assert not any(r or o for r, o in masks[0])                       # fp32 hand-off: no three-byte operand anywhere in this tower
+    assert sum(1 for r, o in masks[1] if o) == 2 and sum(1 for r, o in masks[1] if r) == 2     # adapters 0 and 1 write three bytes, blocks 1 and 2 read them; adapter 2 feeds the CLS head in fp32
+    (f0, l0, g0), (f1, l1, g1) = outs
+    # the two hand-offs differ by 2^-16 per element at the boundary (tools/scratch/f3_probe.py: decode(hi, lo) against the fp32 rows 2.2e-5); behind three blocks of bf16 operands
+    # that perturbation re-rounds some of them: the features move by bf16 noise (max 2-3e-3, rms 1e-4), the SAME size either mode has against the oracle (profiles/r05_d)
+    assert float((f0 - f1).abs().max() / f0.abs().max()) < 6e-3 and float((f0 - f1).pow(2).mean().sqrt() / f0.abs().max()) < 1e-3 and abs(l0 - l1) < 2e-3 * max(1.0, abs(l0))
+    # gradients: the same bars the bf16 step is held to against the oracle (whole vector: direction and L2; every tensor on the global gradient scale)
+    a, b = torch.cat([g0[k].flatten() for k in g0]), torch.cat([g1[k].flatten() for k in g0])
+    assert float(torch.dot(a, b) / (a.norm() * b.norm())) > 0.99 and float((a - b).norm() / a.norm()) < 0.15
+    gmax = max(float(v.abs().max()) for v in g0.values())
+    for k in g0:
+        assert float((g0[k] - g1[k]).abs().max()) < 0.15 * gmax, k
