@@ -79,7 +79,7 @@ def gen_prompts():
     zp = load_by_path("ref_zero_shot_prompt", "src/models/zero_shot_prompt.py")
     data = {k: v for k, v in vars(zp).items() if not k.startswith("_") and isinstance(v, (list, tuple, dict, str))}
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "nextgen-uia_amd", "src", "models", "zero_shot_prompts.json"), "w") as f:      # product DATA
-        json.dump(data, f, indent=1, sort_keys=True)
+        json.dump(data, f, sort_keys=True, separators=(",", ":"))      # one line: a data blob, not a listing
     print("wrote zero_shot_prompts.json", {k: (len(v) if hasattr(v, "__len__") else v) for k, v in data.items()})
 
 
