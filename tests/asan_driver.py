@@ -109,6 +109,11 @@ expect_fail(lib.uia_mona_fused_fwd(None, 1, C.byref(f)), "null tensor")
 assert lib.uia_mona_fused_supported(1, 768, 14, 14, 64) == 1 and lib.uia_mona_fused_supported(1, 768, 16, 16, 64) == 0
 expect_fail(lib.uia_infonce_fwd_bwd(None, 0, 0, None, None, 1.0, 1.0, None, None, None, None, 0))
 expect_fail(lib.uia_adamw_clip_step(None, 0, None, None, None, None, 1e-3, 0.9, 0.95, 1e-8, 0.01, 1.0, 1, 1.0, None))
+# round 5: the guarded forms (null buffers, empty problem, negative log index / schedule length)
+expect_fail(lib.uia_grad_accum_guarded(None, 0, None, None, None, None, None, None, 0), "bad arguments")
+expect_fail(lib.uia_grad_accum_guarded(None, 16, 64, 64, 64, 64, 64, 64, -1), "bad arguments")
+expect_fail(lib.uia_adamw_clip_step_guarded(None, 0, None, None, None, None, 1e-3, 0.0, 0, 0.9, 0.95, 1e-8, 0.01, 1.0, 1.0, 1.0, None, None), "bad arguments")
+expect_fail(lib.uia_adamw_clip_step_guarded(None, 16, 64, 64, 64, 64, 1e-3, 0.0, -3, 0.9, 0.95, 1e-8, 0.01, 1.0, 1.0, 1.0, 64, 64), "bad arguments")
 # communicator: argument errors and use-before-init
 buf = C.create_string_buffer(8)
 expect_fail(lib.uia_comm_get_unique_id(buf, 8), "buffer too small")
