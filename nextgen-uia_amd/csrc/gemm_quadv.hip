@@ -1,0 +1,282 @@
+// gemm_quadv.hip — tile cfg 27: the 256 x 256 output tile on FOUR waves of 128 x 128 (as gemm_quad.hip, cfg 25), with the operands staged
+// global -> REGISTERS -> LDS instead of through LDS-DMA.
+//
+// Why (round 5): tools/gemm_square_yardstick.py puts the vendor library's kernel for these shapes (MT256x256x64, four waves, global reads into
+// registers, ds_write_b128, two tiles prefetched) 14-24 % ahead of every variant in this tree — at 8192^3, where prologue and epilogue do not
+// matter, 1.56-1.61 PF against 1.30-1.41 — so the gap is in the K loop.  Round 4's ablation of cfg 25 had the ingredients: MFMAs alone 117 us,
+// LDS-DMA alone 80, together 175: with ONE wave per SIMD nobody issues MFMAs while that wave issues a global_load_lds (60-185 cycles of issue per
+// 1 KiB piece, MI355X_MICROARCH.md cycle table; eight pieces per 64 MFMAs), which is why the eight-wave kernel needs its ping-pong and its two
+// barriers per 32-deep step.  A global_load_dwordx4 + ds_write_b128 pair moves the same 1 KiB for ~20-30 cycles of issue; what it costs is
+// registers, and a one-wave-per-SIMD kernel has them (512): 256 accumulators, two fragment sets (128), D x 32 staging registers.
+//
+// Structure per 32-deep K step t (64 MFMAs per wave = 1024 cycles of its SIMD's matrix pipe), eight groups of eight MFMAs:
+//   groups 0-3: ds_write the eight staged pieces of sub-tile t+1 into LDS buffer (t+1)&1, each followed by the global load of the same piece of
+//               sub-tile t+1+D into the registers just written out (D sub-tiles in flight in registers);
+//   then       s_waitcnt lgkmcnt(0) + s_barrier  (ONE barrier per step, in the middle of the MFMA chain: every wave's writes of t+1 are visible);
+//   groups 4-7: the sixteen fragment reads of sub-tile t+1 into the idle fragment set.
+// Buffer (t+1)&1 was last read (fragments of t-1) in the second half of step t-2, two barriers ago.
+// Same LDS images, swizzles, fragment addresses, accumulator layout and epilogue as cfg 25 / cfg 8: the K loop adds the same products in the same
+// order, so results are bit-identical to theirs.
+#include "gemm_epilogue.h"
+#include <type_traits>
+#include <cstdlib>
+
+namespace {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) u32x4* gptr_t;
+
+template <int EPI, int D, int ABL = 0>
+__global__ __launch_bounds__(256, 1) void gemm_tn_quadv_kernel(const UiaGemmParams p, const int xflags) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using T = bf16_t;
+    constexpr int BM = 256, BN = 256, NW = 4, WTM = 128, WTN = 128, MT = 8, NT = 8, BKB = 64, ESZ = 2;
+    constexpr int A_BYTES = BM * BKB, W_BYTES = BN * BKB, BUF_BYTES = A_BYTES + W_BYTES;
+    constexpr int RPI = 1024 / BKB, CPR = BKB / 16;                     // rows per 1 KiB piece, 16-byte chunks per row
+    constexpr int A_PER_WAVE = (BM / RPI) / NW, W_PER_WAVE = (BN / RPI) / NW, GPT = A_PER_WAVE + W_PER_WAVE;
+    static_assert(GPT == 8 && (D == 2 || D == 3), "eight 1 KiB pieces per wave and sub-tile; two or three sub-tiles in flight in registers");
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int tiles_n = (p.N + BN - 1) / BN;
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    int tm, tn;
+    {
+        const int gmv = xflags & 255;
+        if (gmv > 0) {
+            const int tiles_m = (p.M + BM - 1) / BM;
+            const int per_group = gmv * tiles_n;
+            const int grp_id = bid / per_group, first = grp_id * gmv;
+            const int gsz = tiles_m - first < gmv ? tiles_m - first : gmv;
+            const int r = bid - grp_id * per_group;
+            tn = r / gsz;
+            tm = first + (r - tn * gsz);
+        } else {
+            tm = bid / tiles_n;
+            tn = bid - tm * tiles_n;
+        }
+    }
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    constexpr bool LNROW = EPI == EPI_GENERIC || (EPI & (EPI_LNFOLD | EPI_RESID_LN)) != 0;
+    constexpr int LNR = WTM / 64;
+    float2 lnpre[LNR];
+#pragma unroll
+    for (int i = 0; i < LNR; ++i) lnpre[i] = float2{0.f, 1.f};
+    if (LNROW && p.lnfold_sums) {
+#pragma unroll
+        for (int i = 0; i < LNR; ++i) {
+            const int m = m0 + wm * WTM + lane + 64 * i;
+            if (m < p.M) lnpre[i] = rowsum_load(p.lnfold_sums, (size_t)m);
+        }
+    } else if (LNROW && p.resid_ln_stats && p.resid_mod == 0 && p.out_group == 0) {
+#pragma unroll
+        for (int i = 0; i < LNR; ++i) {
+            const int m = m0 + wm * WTM + lane + 64 * i;
+            if (m < p.M) lnpre[i] = p.resid_ln_dim > 0 ? rowsum_load(p.resid_ln_stats, (size_t)m) : *(const float2*)((const float*)p.resid_ln_stats + 2 * (size_t)m);
+        }
+    }
+
+    const bool kbA = p.a_kb_rows != 0, kbW = p.w_kblocked != 0;
+    auto swzA = [](int r) -> int { return (0x1230 >> (4 * ((r >> 2) & 3))) & 3; };
+    auto swzW = [](int rl) -> int { return (0x1230 >> (4 * ((rl >> 4) & 3))) & 3; };
+    // piece i of a sub-tile: LDS bytes [1024·q, 1024·(q+1)) of the A (i < 4) or W image, q = wave + 4·(i & 3); lane l fills bytes 16·l of it with source chunk
+    // (l % 4) ^ swz(row) of row 16·q + l / 4 (the swizzle lives in the SOURCE address, the LDS image is written linearly: as the LDS-DMA kernels do).  Neither
+    // swizzle depends on i, so a lane's eight source addresses are ONE 32-bit offset per operand plus wave-uniform terms (64 rows per piece, the K position),
+    // which a buffer load takes in a scalar register; rows past M / N fall outside the descriptor and read as zero (they are never stored).
+    const unsigned rowA = kbA ? (unsigned)BKB : (unsigned)p.lda * ESZ, rowW = kbW ? (unsigned)BKB : (unsigned)p.ldw * ESZ;
+    const __amdgpu_buffer_rsrc_t srdA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)(kbA ? (size_t)p.a_kb_rows * p.K * ESZ : ((size_t)(p.M - 1) * p.lda + p.K) * ESZ), 0x00020000);
+    const __amdgpu_buffer_rsrc_t srdW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (int)(kbW ? (size_t)p.N * p.K * ESZ : ((size_t)(p.N - 1) * p.ldw + p.K) * ESZ), 0x00020000);
+    unsigned voffA, voffW;
+    {
+        const int r = RPI * wave + lane / CPR;
+        voffA = (unsigned)(m0 + r) * rowA + (unsigned)(((lane % CPR) ^ swzA(r)) * 16);
+        voffW = (unsigned)(n0 + r) * rowW + (unsigned)(((lane % CPR) ^ swzW(r & 63)) * 16);
+    }
+    const unsigned kstepA = kbA ? (unsigned)p.a_kb_rows * BKB : (unsigned)BKB, kstepW = kbW ? (unsigned)p.N * BKB : (unsigned)BKB;
+    const int li = lane & 15, g = lane >> 4;
+    const int offA0 = (wm * WTM + li) * BKB + ((g ^ swzA(li)) << 4);
+    const int offW0 = A_BYTES + (wn * WTN + (li >> 2) * 16 + (li & 3)) * BKB + ((g ^ swzW((li >> 2) * 16)) << 4);
+    const int dst0 = wave * 1024 + lane * 16;                           // + 4096·(i & 3) (+ A_BYTES for the W pieces) + buffer
+
+    f32x4 acc[2][MT][4];                                   // [column half][row group][column group]
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int ntl = (p.K * ESZ) / BKB;
+    // sub-tiles past the last one are requested again from the last one (valid addresses, never multiplied): the loop body needs no tail variants
+    auto gload = [&](int t, int i) -> u32x4 {
+        const int tt = (ABL & 2) ? (t & 1) : t < ntl ? t : ntl - 1;
+        return i < A_PER_WAVE ? __builtin_amdgcn_raw_buffer_load_b128(srdA, voffA, (unsigned)tt * kstepA + (unsigned)(i * NW * RPI) * rowA, 0)
+                              : __builtin_amdgcn_raw_buffer_load_b128(srdW, voffW, (unsigned)tt * kstepW + (unsigned)((i - A_PER_WAVE) * NW * RPI) * rowW, 0);
+    };
+    auto lds_put = [&](int buf, int i, const u32x4& v) {
+        *(u32x4*)(smem + buf * BUF_BYTES + (i < A_PER_WAVE ? 0 : A_BYTES) + dst0 + (i & 3) * 4096) = v;
+    };
+    u32x4 G[D][GPT];
+    // prologue: sub-tiles 0 .. D-1 requested; 0 written out, its slot refilled with sub-tile D; fragments of 0 read
+#pragma unroll
+    for (int s = 0; s < D; ++s)
+#pragma unroll
+        for (int i = 0; i < GPT; ++i) G[s][i] = gload(s, i);
+#pragma unroll
+    for (int i = 0; i < GPT; ++i) lds_put(0, i, G[0][i]);
+#pragma unroll
+    for (int i = 0; i < GPT; ++i) G[0][i] = gload(D, i);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    auto mma = [](f32x4& c, const u32x4& w, const u32x4& a) { asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(w), "v"(a)); };
+    u32x4 af[2][MT], wf[2][NT];
+    auto read_a = [&](u32x4 (&a_)[MT], const char* buf, int i) { a_[i] = *(const u32x4*)(buf + offA0 + i * 16 * BKB); };
+    auto read_w = [&](u32x4 (&w_)[NT], const char* buf, int j) { w_[j] = *(const u32x4*)(buf + offW0 + (j >> 2) * 64 * BKB + (j & 3) * 4 * BKB); };
+#pragma unroll
+    for (int j = 0; j < NT; ++j) read_w(wf[0], smem, j);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) read_a(af[0], smem, i);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+
+    // TS = t mod 6 as a compile-time constant: fragment set TS & 1, staging slot (TS + 1) % D (6 is a multiple of 2 and of D).
+    // One memory instruction behind every second MFMA (a 16-cycle MFMA leaves its wave ~12 cycles of issue before the next one can start; a clump of four memory
+    // instructions ahead of eight MFMAs does not fit in that and idles the matrix pipe — ablation, profiles/r05_f_quadv_ablation.txt): MFMAs 0-14 carry the eight
+    // LDS writes of sub-tile t+1, 16-30 the eight global loads of sub-tile t+1+D into the registers just written out, 32 the barrier, 32-62 the sixteen fragment reads.
+    auto step = [&](auto ts_c, int t) {
+        constexpr int TS = decltype(ts_c)::value, cur = TS & 1, nxt = cur ^ 1, gs = (TS + 1) % D;
+        const char* nbuf = smem + nxt * BUF_BYTES;
+#pragma unroll
+        for (int m = 0; m < MT * NT; ++m) {
+            const int i = m >> 3, j = m & 7;
+            mma(acc[j >> 2][i][j & 3], wf[cur][j], af[cur][i]);
+            __builtin_amdgcn_sched_barrier(0);
+            // writes behind MFMAs 0, 4, .. 28; loads behind 3, 11, .. 59 (spread over the whole step: the CU's address unit takes ~16 cycles per 1 KiB request and serves
+            // all four waves); the barrier and the fragment reads behind 32, 34, .. 62
+            if (m < 32 && (m & 3) == 0) {
+                if (!(ABL & 4)) lds_put(nxt, m >> 2, G[gs][m >> 2]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if ((m & 7) == 3) {
+                if (!(ABL & 16)) G[gs][m >> 3] = gload(t + 1 + D, m >> 3);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (m >= 32 && !(m & 1)) {
+                if (m == 32) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (!(ABL & 1)) __builtin_amdgcn_s_barrier();
+                }
+                const int idx = (m - 32) >> 1;
+                if (!(ABL & 8)) {
+                    if (idx < NT) read_w(wf[nxt], nbuf, idx);
+                    else read_a(af[nxt], nbuf, idx - NT);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    int t = 0;
+    for (; t + 6 <= ntl; t += 6) {                         // the hot loop: six unconditional steps (conditional steps put 256 accumulators through phi copies)
+        step(std::integral_constant<int, 0>{}, t);
+        step(std::integral_constant<int, 1>{}, t + 1);
+        step(std::integral_constant<int, 2>{}, t + 2);
+        step(std::integral_constant<int, 3>{}, t + 3);
+        step(std::integral_constant<int, 4>{}, t + 4);
+        step(std::integral_constant<int, 5>{}, t + 5);
+    }
+    if (t < ntl) {                                         // K not a multiple of 192: up to five more steps
+        step(std::integral_constant<int, 0>{}, t);
+        if (t + 1 < ntl) step(std::integral_constant<int, 1>{}, t + 1);
+        if (t + 2 < ntl) step(std::integral_constant<int, 2>{}, t + 2);
+        if (t + 3 < ntl) step(std::integral_constant<int, 3>{}, t + 3);
+        if (t + 4 < ntl) step(std::integral_constant<int, 4>{}, t + 4);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");     // the requests past the last sub-tile; the last MFMAs' results are read by code the hazard pass cannot relate to them
+    __builtin_amdgcn_s_barrier();                          // every wave is out of the ring before the epilogue's patches overlay it
+
+    float* lnrow = LNROW ? (float*)(smem + NW * EpiPatch<MT, 64>::BYTES_PER_WAVE + wave * (WTM * 8)) : nullptr;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (h == 1 && (EPI == EPI_GENERIC || (EPI & EPI_ROWSUM) != 0)) __syncthreads();
+        gemm_epilogue_lds<T, MT, 4, WTM, 64, EPI, false, 2>(p, acc[h], smem, wave, lane, m0, n0, wm, 2 * wn + h, lnrow, LNROW ? lnpre : nullptr);
+    }
+}
+
+template <int EPI, int D, int ABL = 0>
+int launch_quadv_epi(hipStream_t stream, const UiaGemmParams& p, int xflags) {
+    constexpr bool LNROW = EPI == EPI_GENERIC || (EPI & (EPI_LNFOLD | EPI_RESID_LN)) != 0;
+    constexpr int EPB = 4 * EpiPatch<8, 64>::BYTES_PER_WAVE + (LNROW ? 4 * 128 * 8 : 0);
+    constexpr int RING = 2 * 512 * 64;
+    constexpr int LDS = RING > EPB ? RING : EPB;
+    static_assert(LDS <= 160 * 1024, "LDS budget");
+    auto kern = gemm_tn_quadv_kernel<EPI, D, ABL>;
+    static UiaDevOnce attr_once;
+    UIA_ENSURE_LDS_ATTR(attr_once, kern, LDS);
+    const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), LDS, stream, p, xflags);
+    UIA_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace
+
+// bf16, no K extension; the caller (uia_gemm_launch) has validated the descriptor.  depth = sub-tiles in flight in registers (2 or 3).
+int uia_gemm_quadv_launch(hipStream_t stream, const UiaGemmParams& p, bool specialise, int xflags, int depth) {
+    if (p.K2 > 0) { uia_set_error("uia_gemm: tile cfg 27 takes no K extension"); return -1; }
+    {
+        const size_t a_bytes = p.a_kb_rows ? (size_t)p.a_kb_rows * p.K * 2 : ((size_t)(p.M - 1) * p.lda + p.K) * 2, w_bytes = p.w_kblocked ? (size_t)p.N * p.K * 2 : ((size_t)(p.N - 1) * p.ldw + p.K) * 2;
+        if (a_bytes >= ((size_t)1 << 32) || w_bytes >= ((size_t)1 << 32)) { uia_set_error("uia_gemm: tile cfg 27 addresses its operands through 32-bit buffer offsets (A %zu bytes, W %zu bytes)", a_bytes, w_bytes); return -1; }
+    }
+    static const int abl = [] { const char* e = getenv("UIA_QUADV_ABLATE"); return e ? atoi(e) : 0; }();
+    if (abl) {                                             // timing ablations of the K loop (results are WRONG): tools/gemm_square_yardstick.py
+        switch (abl) {
+            case 1: return launch_quadv_epi<EPI_OUTT, 2, 1>(stream, p, xflags);
+            case 2: return launch_quadv_epi<EPI_OUTT, 2, 2>(stream, p, xflags);
+            case 4: return launch_quadv_epi<EPI_OUTT, 2, 4>(stream, p, xflags);
+            case 8: return launch_quadv_epi<EPI_OUTT, 2, 8>(stream, p, xflags);
+            case 16: return launch_quadv_epi<EPI_OUTT, 2, 16>(stream, p, xflags);
+            case 20: return launch_quadv_epi<EPI_OUTT, 2, 20>(stream, p, xflags);
+            case 29: return launch_quadv_epi<EPI_OUTT, 2, 29>(stream, p, xflags);
+            default: uia_set_error("uia_gemm: unknown ablation"); return -1;
+        }
+    }
+#define UIA_QV(MASK) case (MASK): return launch_quadv_epi<(MASK), 2>(stream, p, xflags)
+    if (depth == 3) {                                      // three sub-tiles in flight (tile cfg 28): plain epilogues only
+        if (specialise && epi_mask_of(p) == EPI_OUTT) return launch_quadv_epi<EPI_OUTT, 3>(stream, p, xflags);
+        return launch_quadv_epi<EPI_GENERIC, 3>(stream, p, xflags);
+    }
+    if (specialise) {
+        switch (epi_mask_of(p)) {                          // the masks of gemm_quad.hip (ops._QUAD_SPECIALISED)
+            UIA_QV(EPI_OUTT);
+            UIA_QV(EPI_BIAS | EPI_OUTT);
+            UIA_QV(EPI_BIAS | EPI_RESID | EPI_OUT32);
+            UIA_QV(EPI_BIAS | EPI_GELU | EPI_OUTT);
+            UIA_QV(EPI_DGELU | EPI_OUTT);
+            UIA_QV(EPI_BIAS | EPI_GELU | EPI_AUX_OUT | EPI_OUTT);
+            UIA_QV(EPI_QUICK | EPI_BIAS | EPI_GELU | EPI_OUTT);
+            UIA_QV(EPI_QUICK | EPI_DGELU | EPI_OUTT);
+            UIA_QV(EPI_QUICK | EPI_BIAS | EPI_GELU | EPI_AUX_OUT | EPI_OUTT);
+            UIA_QV(EPI_BIAS | EPI_RESID | EPI_OUT32 | EPI_OUTT | EPI_ROWSUM);
+            UIA_QV(EPI_BIAS | EPI_RESID_LO | EPI_RESID_LN | EPI_OUTT | EPI_OUT_LO | EPI_ROWSUM);
+            UIA_QV(EPI_BIAS | EPI_RESID | EPI_OUTT | EPI_OUT_LO | EPI_ROWSUM);
+            UIA_QV(EPI_BIAS | EPI_RESID_LO | EPI_OUT32);
+            UIA_QV(EPI_BIAS | EPI_OUTT | EPI_LNFOLD);
+            UIA_QV(EPI_BIAS | EPI_GELU | EPI_OUTT | EPI_LNFOLD);
+            UIA_QV(EPI_BIAS | EPI_GELU | EPI_AUX_OUT | EPI_OUTT | EPI_LNFOLD);
+            UIA_QV(EPI_QUICK | EPI_BIAS | EPI_GELU | EPI_OUTT | EPI_LNFOLD);
+            UIA_QV(EPI_QUICK | EPI_BIAS | EPI_GELU | EPI_AUX_OUT | EPI_OUTT | EPI_LNFOLD);
+            default: break;
+        }
+    }
+    return launch_quadv_epi<EPI_GENERIC, 2>(stream, p, xflags);
+#undef UIA_QV
+}

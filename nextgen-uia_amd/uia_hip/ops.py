@@ -68,7 +68,7 @@ def auto_tile_cfg(M, N, K=None, esz=2, mask=EPI_GENERIC):
     return 8
 
 
-RING_CFGS = (8, 9, 10, 12, 13, 14, 24, 25, 26)
+RING_CFGS = (8, 9, 10, 12, 13, 14, 24, 25, 26, 27, 28)
 PERSIST_STORE_ONLY = False   # experiment knob: 256x256 ring launches whose epilogue only stores T results run on the persistent variant (cfg 12)
 KBLOCK_W = True          # hand the ring kernels their weights K-blocked (PackedW.kblocked()); False = row-major everywhere
 K64_CFG14 = True         # single-K-step GEMMs on the two-workgroups-per-CU half-height config (False: 256x256 like every other large shape)
@@ -87,6 +87,7 @@ LN_LORA_DOWN = True      # LoRA block: LayerNorm and the q / k / v down-projecti
 LORA_REGEN_DROP = True   # LoRA input dropout: the forward does not write the dropped rows; the dA weight-gradient launch regenerates the mask while it stages x (uia_wgrad_drop)
 LORA_RANK3 = True        # q | k | v of a LoRA block: the three rank terms of the data gradient in one pass over it (uia_lora_rank_update) instead of three K = 64 launches
 QUAD = False             # 256x256 bf16 launches on the four-wave kernel (tile cfg 25, csrc/gemm_quad.hip: 128 x 128 per wave, one wave per SIMD) instead of cfg 8
+QUADV = False            # experiment knob: 256x256 bf16 launches on the four-wave register-staged kernel (tile cfg 27, csrc/gemm_quadv.hip) instead of cfg 8
 RING5 = False            # experiment knob: 256x256 launches with a long K loop or a wide N on the 5-deep ring (tile cfg 24: 160 KB of LDS, four sub-tiles in flight)
 LORA_KEXT = True         # LoraAttnHalfFn: the rank update inside the frozen GEMM's K loop (uia_gemm_desc.A2 / K2) instead of a read-modify-write launch of its own
 TAIL_SPLIT_K = True      # ... and run that tail split over K when it is a few tiles with a long K chain (two launches: slice partials, then sum + epilogue).
@@ -111,6 +112,8 @@ def big_tile_cfg(N, K, esz):
     fused epilogues, it is level to slightly worse on every one of those launches (44.5-44.9 ms either way, three alternating pairs on one box): opt-in."""
     if QUAD and esz == 2:
         return 25
+    if QUADV and esz == 2:
+        return 27
     return 24 if (RING5 and esz == 2 and (K * esz >= 2048 or N >= 2304)) else 8
 
 
@@ -395,6 +398,9 @@ def gemm_kernel_name(cfg, mask, dtype):
     if cfg in (25, 26):
         mq = m if (cfg == 25 and m in _QUAD_SPECIALISED) else EPI_GENERIC
         return f"gemm_tn_quad_kernel<{mq},false>", f"gemm_tn_quad_kernelI{mi(mq)}Lb0EE"
+    if cfg in (27, 28):
+        mq = m if (m in _QUAD_SPECIALISED and (cfg == 27 or m == EPI_OUTT)) else EPI_GENERIC
+        return f"gemm_tn_quadv_kernel<{mq},{cfg - 25},0>", f"gemm_tn_quadv_kernelI{mi(mq)}{mi(cfg - 25)}Li0EE"
     if cfg == 16:
         return "gemm_skinny64_kernel", "gemm_skinny64_kernel"
     if cfg == 23:

@@ -34,7 +34,11 @@ def spy(a, w, **kw):
     feats = [k for k in ("bias", "act", "dact", "aux_in", "aux_out", "resid", "resid_t", "out_t", "out32") if kw.get(k) is not None]
     if kw.get("resid_mod") or kw.get("out_group"): feats.append("rowmap")
     if kw.get("alpha", 1.0) != 1.0: feats.append("alpha")
-    log.append(((a.shape[0], w.shape[0], a.shape[1]), "+".join(feats), e0, e1))
+    for k in ("resid3", "out_lo", "rowsum", "lnfold", "resid_ln"):
+        if kw.get(k) is not None: feats.append(k)
+    M, K = (a.rows, a.cols) if ops.is_kb(a) else a.shape
+    N = getattr(w, "N", None) or w.shape[0]
+    log.append(((M, N, K), "+".join(feats), e0, e1))
 ops.gemm = spy
 UF.ops.gemm = spy
 contrastive_step(model, crit, opt, images, ids, overlap_text=False)

@@ -1,0 +1,9 @@
+#!/bin/bash
+# in-step A/B: the default tree against --quadv (256x256 bf16 launches on tile cfg 27), alternating, one box
+mkdir -p gpurun_out
+for r in 1 2; do
+  for v in "" "--quadv"; do
+    out=$(bash tools/bench_ms.sh --no-entry-point $v) || exit 1
+    echo "[$r] default $v -> $out" | tee -a gpurun_out/ab_quadv.txt
+  done
+done
