@@ -96,7 +96,7 @@ def parse():
     ap.add_argument("--no-lora-rank3", action="store_true", help="A/B: the q | k | v rank terms of a LoRA block's data gradient as three K = 64 launches instead of one uia_lora_rank_update pass")
     ap.add_argument("--no-lora-kext", action="store_true", help="A/B knob: the LoRA rank update as a launch of its own (tile cfg 23) instead of inside the frozen GEMM's K loop")
     ap.add_argument("--quad", action="store_true", help="experiment knob: 256x256 bf16 launches on the four-wave kernel (tile cfg 25, csrc/gemm_quad.hip) instead of the eight-wave ring kernel")
-    ap.add_argument("--quadv", action="store_true", help="experiment knob: 256x256 bf16 launches on the four-wave register-staged kernel (tile cfg 27, csrc/gemm_quadv.hip)")
+    ap.add_argument("--quadv", type=int, nargs="?", const=27, default=0, choices=(0, 27, 29), help="experiment knob: 256x256 bf16 launches on the four-wave register-staged kernel (tile cfg 27; 29 = its persistent grid; csrc/gemm_quadv.hip)")
     ap.add_argument("--ring5", action="store_true", help="experiment knob: long-K / wide-N 256x256 launches on the 5-deep ring (tile cfg 24) instead of the 4-deep one")
     ap.add_argument("--no-tail-split-k", action="store_true", help="A/B knob: the M tail launches run their whole K chain (default: long-K tails of a few tiles are split over K)")
     ap.add_argument("--no-half-height-short-k", action="store_true", help="A/B knob: N <= 768, K <= 768 launches with a ragged last round as main + tail launches (round 2) "

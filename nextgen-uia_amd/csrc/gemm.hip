@@ -1301,12 +1301,12 @@ int launch_typed(hipStream_t stream, const UiaGemmParams& p, int cfg_in) {
         uia_set_error("uia_gemm: dropout on the A operand (drop_where = 1) is the N = 64 stream kernel's (tile cfg 16: bf16, N == 64, M > 2048, bias + T output only), not tile cfg %d", cfg);
         return -1;
     }
-    const bool ring = cfg == 8 || cfg == 9 || cfg == 10 || cfg == 12 || cfg == 13 || cfg == 14 || cfg == 15 || (cfg >= 17 && cfg <= 20) || cfg == 24 || cfg == 25 || cfg == 26 || cfg == 27 || cfg == 28;
-    if ((p.a_kb_rows || p.outT_kb_rows) && !(cfg == 8 || cfg == 10 || cfg == 12 || cfg == 13 || cfg == 14 || cfg == 15 || (cfg >= 17 && cfg <= 20) || cfg == 24 || cfg == 25 || cfg == 26 || cfg == 27 || cfg == 28)) {
+    const bool ring = cfg == 8 || cfg == 9 || cfg == 10 || cfg == 12 || cfg == 13 || cfg == 14 || cfg == 15 || (cfg >= 17 && cfg <= 20) || cfg == 24 || cfg == 25 || cfg == 26 || cfg == 27 || cfg == 28 || cfg == 29;
+    if ((p.a_kb_rows || p.outT_kb_rows) && !(cfg == 8 || cfg == 10 || cfg == 12 || cfg == 13 || cfg == 14 || cfg == 15 || (cfg >= 17 && cfg <= 20) || cfg == 24 || cfg == 25 || cfg == 26 || cfg == 27 || cfg == 28 || cfg == 29)) {
         uia_set_error("uia_gemm: K-blocked activations (a_kb_rows / outT_kb_rows) need a ring tile config with 64-byte sub-tiles (8, 10, 13, 14), not %d", cfg);
         return -1;
     }
-    if ((p.resid_lo8 || p.out_lo8) && !(cfg == 8 || cfg == 10 || cfg == 13 || cfg == 14 || cfg == 24 || cfg == 25 || cfg == 26 || cfg == 27 || cfg == 28)) {
+    if ((p.resid_lo8 || p.out_lo8) && !(cfg == 8 || cfg == 10 || cfg == 13 || cfg == 14 || cfg == 24 || cfg == 25 || cfg == 26 || cfg == 27 || cfg == 28 || cfg == 29)) {
         uia_set_error("uia_gemm: three-byte tensors (resid_lo8 / out_lo8) are read and written by the LDS-patch epilogue of the ring tile configs (8, 10, 13, 14, 24), not %d", cfg);
         return -1;
     }
@@ -1365,8 +1365,9 @@ int launch_typed(hipStream_t stream, const UiaGemmParams& p, int cfg_in) {
             return uia_gemm_quad_launch(stream, p, cfg == 25, (xflags & 255) | (((cfg_in >> 16) & 7) << 8));   // bits 16-18: K-loop ablation (tools/time_quad.py --diag)
         case 27:                                                                          // four waves of 128 x 128, operands through registers (gemm_quadv.hip): two sub-tiles in flight; 28: three
         case 28:
+        case 29:                                                                          // 29: cfg 27 on a persistent grid, the next tile's first sub-tiles requested under the epilogue
             if (sizeof(T) != 2) { uia_set_error("uia_gemm: tile cfg %d is bf16 only", cfg); return -1; }
-            return uia_gemm_quadv_launch(stream, p, true, xflags & 255, cfg == 27 ? 2 : 3);
+            return uia_gemm_quadv_launch(stream, p, true, xflags & 255, cfg == 27 ? 2 : cfg == 28 ? 3 : 9);
         case 14: return launch_ring<T, 128, 256, 2, 4, 64, 3>(stream, p, true, xflags);   // 3-deep ring: 72 KB of LDS, two workgroups per CU
         case 13: return launch_ring<T, 128, 256, 2, 4, 64, 4>(stream, p, true, xflags, sk_info);   // half-height tiles: the M tail of a launch whose last round
                                                                                          // would leave most CUs idle (host splits the rows, ops.gemm)

@@ -203,12 +203,251 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_quadv_kernel(const UiaGemmPara
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");     // the requests past the last sub-tile; the last MFMAs' results are read by code the hazard pass cannot relate to them
     __builtin_amdgcn_s_barrier();                          // every wave is out of the ring before the epilogue's patches overlay it
 
+    if (ABL & 32) {                                        // no epilogue: every accumulator summed into one store per lane (what the tile costs without its output)
+        f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sacc += acc[h][i][j];
+        if (m0 < p.M && n0 < p.N) ((float*)p.outT)[((size_t)(m0 >> 8) * ((p.N + 255) >> 8) + (n0 >> 8)) * 256 + tid] = sacc.x + sacc.y + sacc.z + sacc.w;
+        return;
+    }
     float* lnrow = LNROW ? (float*)(smem + NW * EpiPatch<MT, 64>::BYTES_PER_WAVE + wave * (WTM * 8)) : nullptr;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         if (h == 1 && (EPI == EPI_GENERIC || (EPI & EPI_ROWSUM) != 0)) __syncthreads();
         gemm_epilogue_lds<T, MT, 4, WTM, 64, EPI, false, 2>(p, acc[h], smem, wave, lane, m0, n0, wm, 2 * wn + h, lnrow, LNROW ? lnpre : nullptr);
     }
+}
+
+// Tile cfg 29: the same K loop on a PERSISTENT grid (one workgroup per CU walking tiles b, b + grid, b + 2·grid, ...), two sub-tiles in flight.  Because the operands wait in
+// REGISTERS, not in the LDS ring the epilogue's patches overlay, the loop simply keeps requesting: the loads that the one-tile kernel clamps to the last sub-tile fetch the
+// NEXT tile's sub-tiles 0 and 1 here, they travel while the epilogue runs, and the next tile starts with its operands already on the CU — whatever the epilogue is (the
+// LDS-DMA persistent kernel, cfg 12, can do that for store-only epilogues at best).  Same arithmetic per element: bit-identical to cfgs 27 / 25 / 8.
+template <int EPI>
+__global__ __launch_bounds__(256, 1) void gemm_tn_quadvp_kernel(const UiaGemmParams p, const int xflags, const int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using T = bf16_t;
+    constexpr int BM = 256, BN = 256, NW = 4, WTM = 128, WTN = 128, MT = 8, NT = 8, BKB = 64, ESZ = 2, D = 2;
+    constexpr int A_BYTES = BM * BKB, W_BYTES = BN * BKB, BUF_BYTES = A_BYTES + W_BYTES;
+    constexpr int RPI = 1024 / BKB, CPR = BKB / 16;
+    constexpr int A_PER_WAVE = (BM / RPI) / NW, W_PER_WAVE = (BN / RPI) / NW, GPT = A_PER_WAVE + W_PER_WAVE;
+    static_assert(GPT == 8, "eight 1 KiB pieces per wave and sub-tile");
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = (p.N + BN - 1) / BN;
+
+    // virtual workgroup id -> tile origin: the one-tile kernel's order over ntiles ids (a persistent grid is a multiple of eight wide, so id & 7 stays the XCD)
+    auto tile_of = [&](int vb, int& m0_, int& n0_) {
+        const int xcd = vb & 7, q = ntiles >> 3, r = ntiles & 7;
+        const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vb >> 3);
+        const int gmv = xflags & 255;
+        int tm, tn;
+        if (gmv > 0) {
+            const int tiles_m = (p.M + BM - 1) / BM;
+            const int per_group = gmv * tiles_n;
+            const int grp_id = bid / per_group, first = grp_id * gmv;
+            const int gsz = tiles_m - first < gmv ? tiles_m - first : gmv;
+            const int rr = bid - grp_id * per_group;
+            tn = rr / gsz;
+            tm = first + (rr - tn * gsz);
+        } else {
+            tm = bid / tiles_n;
+            tn = bid - tm * tiles_n;
+        }
+        m0_ = tm * BM;
+        n0_ = tn * BN;
+    };
+
+    const bool kbA = p.a_kb_rows != 0, kbW = p.w_kblocked != 0;
+    auto swzA = [](int r) -> int { return (0x1230 >> (4 * ((r >> 2) & 3))) & 3; };
+    auto swzW = [](int rl) -> int { return (0x1230 >> (4 * ((rl >> 4) & 3))) & 3; };
+    const unsigned rowA = kbA ? (unsigned)BKB : (unsigned)p.lda * ESZ, rowW = kbW ? (unsigned)BKB : (unsigned)p.ldw * ESZ;
+    const __amdgpu_buffer_rsrc_t srdA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)(kbA ? (size_t)p.a_kb_rows * p.K * ESZ : ((size_t)(p.M - 1) * p.lda + p.K) * ESZ), 0x00020000);
+    const __amdgpu_buffer_rsrc_t srdW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (int)(kbW ? (size_t)p.N * p.K * ESZ : ((size_t)(p.N - 1) * p.ldw + p.K) * ESZ), 0x00020000);
+    const int r0 = RPI * wave + lane / CPR;
+    const unsigned cA = (unsigned)(((lane % CPR) ^ swzA(r0)) * 16), cW = (unsigned)(((lane % CPR) ^ swzW(r0 & 63)) * 16);
+    const unsigned kstepA = kbA ? (unsigned)p.a_kb_rows * BKB : (unsigned)BKB, kstepW = kbW ? (unsigned)p.N * BKB : (unsigned)BKB;
+    const int li = lane & 15, g = lane >> 4;
+    const int offA0 = (wm * WTM + li) * BKB + ((g ^ swzA(li)) << 4);
+    const int offW0 = A_BYTES + (wn * WTN + (li >> 2) * 16 + (li & 3)) * BKB + ((g ^ swzW((li >> 2) * 16)) << 4);
+    const int dst0 = wave * 1024 + lane * 16;
+    const int ntl = (p.K * ESZ) / BKB;                     // even: K is a multiple of 64 elements
+
+    int vb = blockIdx.x, m0, n0;
+    tile_of(vb, m0, n0);
+    unsigned voffA = (unsigned)(m0 + r0) * rowA + cA, voffW = (unsigned)(n0 + r0) * rowW + cW;
+    unsigned voffAn = voffA, voffWn = voffW;
+    bool has_next = false;
+
+    // sub-tile t of the current tile; past its end, sub-tile t - ntl of the next tile (or, on the last tile, the last sub-tile again: valid addresses, never multiplied)
+    auto gload = [&](auto tail_c, int t, int i) -> u32x4 {
+        constexpr bool TAIL = decltype(tail_c)::value;
+        const bool cur = !TAIL || t < ntl;
+        const int tt = cur ? t : has_next ? t - ntl : ntl - 1;
+        const unsigned va = cur ? voffA : voffAn, vw = cur ? voffW : voffWn;
+        return i < A_PER_WAVE ? __builtin_amdgcn_raw_buffer_load_b128(srdA, va, (unsigned)tt * kstepA + (unsigned)(i * NW * RPI) * rowA, 0)
+                              : __builtin_amdgcn_raw_buffer_load_b128(srdW, vw, (unsigned)tt * kstepW + (unsigned)((i - A_PER_WAVE) * NW * RPI) * rowW, 0);
+    };
+    auto lds_put = [&](int buf, int i, const u32x4& v) {
+        *(u32x4*)(smem + buf * BUF_BYTES + (i < A_PER_WAVE ? 0 : A_BYTES) + dst0 + (i & 3) * 4096) = v;
+    };
+    auto mma = [](f32x4& c, const u32x4& w, const u32x4& a) { asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(w), "v"(a)); };
+    auto read_a = [&](u32x4 (&a_)[MT], const char* buf, int i) { a_[i] = *(const u32x4*)(buf + offA0 + i * 16 * BKB); };
+    auto read_w = [&](u32x4 (&w_)[NT], const char* buf, int j) { w_[j] = *(const u32x4*)(buf + offW0 + (j >> 2) * 64 * BKB + (j & 3) * 4 * BKB); };
+
+    u32x4 G[D][GPT];
+#pragma unroll
+    for (int s = 0; s < D; ++s)
+#pragma unroll
+        for (int i = 0; i < GPT; ++i) G[s][i] = gload(std::false_type{}, s, i);
+
+    constexpr bool LNROW = EPI == EPI_GENERIC || (EPI & (EPI_LNFOLD | EPI_RESID_LN)) != 0;
+    constexpr int LNR = WTM / 64;
+    for (;;) {
+        {
+            const int nb = vb + (int)gridDim.x;
+            has_next = nb < ntiles;
+            if (has_next) {
+                int m0n, n0n;
+                tile_of(nb, m0n, n0n);
+                voffAn = (unsigned)(m0n + r0) * rowA + cA;
+                voffWn = (unsigned)(n0n + r0) * rowW + cW;
+            }
+        }
+        float2 lnpre[LNR];
+#pragma unroll
+        for (int i = 0; i < LNR; ++i) lnpre[i] = float2{0.f, 1.f};
+        if (LNROW && p.lnfold_sums) {
+#pragma unroll
+            for (int i = 0; i < LNR; ++i) {
+                const int m = m0 + wm * WTM + lane + 64 * i;
+                if (m < p.M) lnpre[i] = rowsum_load(p.lnfold_sums, (size_t)m);
+            }
+        } else if (LNROW && p.resid_ln_stats && p.resid_mod == 0 && p.out_group == 0) {
+#pragma unroll
+            for (int i = 0; i < LNR; ++i) {
+                const int m = m0 + wm * WTM + lane + 64 * i;
+                if (m < p.M) lnpre[i] = p.resid_ln_dim > 0 ? rowsum_load(p.resid_ln_stats, (size_t)m) : *(const float2*)((const float*)p.resid_ln_stats + 2 * (size_t)m);
+            }
+        }
+        f32x4 acc[2][MT][4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        // tile head: sub-tiles 0 and 1 are in G (requested by the prologue above or by the previous tile's last steps); 0 written out, its slot refilled with sub-tile 2
+#pragma unroll
+        for (int i = 0; i < GPT; ++i) lds_put(0, i, G[0][i]);
+#pragma unroll
+        for (int i = 0; i < GPT; ++i) G[0][i] = gload(std::true_type{}, D, i);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        u32x4 af[2][MT], wf[2][NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) read_w(wf[0], smem, j);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) read_a(af[0], smem, i);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+
+        // MODE 0: every request lies inside this tile; 1: requests past its end go to the next tile; 2: the last step — MFMAs only (sub-tile ntl is the NEXT tile's first,
+        // and the ring is about to become the epilogue's patches)
+        auto step = [&](auto ts_c, auto mode_c, int t) {
+            constexpr int TS = decltype(ts_c)::value, MODE = decltype(mode_c)::value, cur = TS & 1, nxt = cur ^ 1, gs = (TS + 1) % D;
+            const char* nbuf = smem + nxt * BUF_BYTES;
+#pragma unroll
+            for (int m = 0; m < MT * NT; ++m) {
+                const int i = m >> 3, j = m & 7;
+                mma(acc[j >> 2][i][j & 3], wf[cur][j], af[cur][i]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (MODE != 2) {
+                    if (m < 32 && (m & 3) == 0) {
+                        lds_put(nxt, m >> 2, G[gs][m >> 2]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if ((m & 7) == 3) {
+                        G[gs][m >> 3] = gload(std::integral_constant<bool, MODE == 1>{}, t + 1 + D, m >> 3);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (m >= 32 && !(m & 1)) {
+                        if (m == 32) {
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            __builtin_amdgcn_s_barrier();
+                        }
+                        const int idx = (m - 32) >> 1;
+                        if (idx < NT) read_w(wf[nxt], nbuf, idx);
+                        else read_a(af[nxt], nbuf, idx - NT);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        int t = 0;
+        for (; t + 2 + D < ntl; t += 2) {
+            step(I0{}, I0{}, t);
+            step(I1{}, I0{}, t + 1);
+        }
+        for (; t + 2 < ntl; t += 2) {
+            step(I0{}, I1{}, t);
+            step(I1{}, I1{}, t + 1);
+        }
+        step(I0{}, I1{}, t);
+        step(I1{}, I2{}, t + 1);
+        // The next tile's first two sub-tiles are taken off the scoreboard HERE (only loads are in flight: the wait is for them alone, and they were requested one to three
+        // steps ago).  Behind the epilogue the counter would hold its stores too, and on this ISA a wait for a load with stores in flight is a wait for everything.
+#pragma unroll
+        for (int s = 0; s < D; ++s)
+#pragma unroll
+            for (int i = 0; i < GPT; ++i) asm volatile("" : "+v"(G[s][i]));
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+        __builtin_amdgcn_s_barrier();                      // every wave is out of the ring before the epilogue's patches overlay it
+
+        float* lnrow = LNROW ? (float*)(smem + NW * EpiPatch<MT, 64>::BYTES_PER_WAVE + wave * (WTM * 8)) : nullptr;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (h == 1 && (EPI == EPI_GENERIC || (EPI & EPI_ROWSUM) != 0)) __syncthreads();
+            gemm_epilogue_lds<T, MT, 4, WTM, 64, EPI, false, 2>(p, acc[h], smem, wave, lane, m0, n0, wm, 2 * wn + h, lnrow, LNROW ? lnpre : nullptr);
+        }
+        if (!has_next) break;
+        // the patches are read out (a store issues with its data in hand) before the next tile's first sub-tile lands on them; NOT __syncthreads(): its fence would wait
+        // for the epilogue's stores, which are meant to drain under the next tile's first steps
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        vb += (int)gridDim.x;
+        tile_of(vb, m0, n0);
+        voffA = voffAn;
+        voffW = voffWn;
+    }
+}
+
+template <int EPI>
+int launch_quadvp_epi(hipStream_t stream, const UiaGemmParams& p, int xflags) {
+    constexpr bool LNROW = EPI == EPI_GENERIC || (EPI & (EPI_LNFOLD | EPI_RESID_LN)) != 0;
+    constexpr int EPB = 4 * EpiPatch<8, 64>::BYTES_PER_WAVE + (LNROW ? 4 * 128 * 8 : 0);
+    constexpr int RING = 2 * 512 * 64;
+    constexpr int LDS = RING > EPB ? RING : EPB;
+    static_assert(LDS <= 160 * 1024, "LDS budget");
+    auto kern = gemm_tn_quadvp_kernel<EPI>;
+    static UiaDevOnce attr_once;
+    UIA_ENSURE_LDS_ATTR(attr_once, kern, LDS);
+    const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+    const int ncu = uia_num_cus() & ~7;                    // a multiple of eight: virtual id & 7 stays the XCD
+    const int grid = tiles <= ncu || ncu < 8 ? tiles : ncu;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, stream, p, xflags, tiles);
+    UIA_CHECK_LAUNCH();
+    return 0;
 }
 
 template <int EPI, int D, int ABL = 0>
@@ -229,7 +468,7 @@ int launch_quadv_epi(hipStream_t stream, const UiaGemmParams& p, int xflags) {
 
 }  // namespace
 
-// bf16, no K extension; the caller (uia_gemm_launch) has validated the descriptor.  depth = sub-tiles in flight in registers (2 or 3).
+// bf16, no K extension; the caller (uia_gemm_launch) has validated the descriptor.  depth = sub-tiles in flight in registers (2 or 3); 9 = the persistent grid (two in flight).
 int uia_gemm_quadv_launch(hipStream_t stream, const UiaGemmParams& p, bool specialise, int xflags, int depth) {
     if (p.K2 > 0) { uia_set_error("uia_gemm: tile cfg 27 takes no K extension"); return -1; }
     {
@@ -246,10 +485,12 @@ int uia_gemm_quadv_launch(hipStream_t stream, const UiaGemmParams& p, bool speci
             case 16: return launch_quadv_epi<EPI_OUTT, 2, 16>(stream, p, xflags);
             case 20: return launch_quadv_epi<EPI_OUTT, 2, 20>(stream, p, xflags);
             case 29: return launch_quadv_epi<EPI_OUTT, 2, 29>(stream, p, xflags);
+            case 32: return launch_quadv_epi<EPI_OUTT, 2, 32>(stream, p, xflags);
+            case 61: return launch_quadv_epi<EPI_OUTT, 2, 61>(stream, p, xflags);
             default: uia_set_error("uia_gemm: unknown ablation"); return -1;
         }
     }
-#define UIA_QV(MASK) case (MASK): return launch_quadv_epi<(MASK), 2>(stream, p, xflags)
+#define UIA_QV(MASK) case (MASK): return depth == 9 ? launch_quadvp_epi<(MASK)>(stream, p, xflags) : launch_quadv_epi<(MASK), 2>(stream, p, xflags)
     if (depth == 3) {                                      // three sub-tiles in flight (tile cfg 28): plain epilogues only
         if (specialise && epi_mask_of(p) == EPI_OUTT) return launch_quadv_epi<EPI_OUTT, 3>(stream, p, xflags);
         return launch_quadv_epi<EPI_GENERIC, 3>(stream, p, xflags);
@@ -277,6 +518,6 @@ int uia_gemm_quadv_launch(hipStream_t stream, const UiaGemmParams& p, bool speci
             default: break;
         }
     }
-    return launch_quadv_epi<EPI_GENERIC, 2>(stream, p, xflags);
+    return depth == 9 ? launch_quadvp_epi<EPI_GENERIC>(stream, p, xflags) : launch_quadv_epi<EPI_GENERIC, 2>(stream, p, xflags);
 #undef UIA_QV
 }

@@ -68,7 +68,7 @@ def auto_tile_cfg(M, N, K=None, esz=2, mask=EPI_GENERIC):
     return 8
 
 
-RING_CFGS = (8, 9, 10, 12, 13, 14, 24, 25, 26, 27, 28)
+RING_CFGS = (8, 9, 10, 12, 13, 14, 24, 25, 26, 27, 28, 29)
 PERSIST_STORE_ONLY = False   # experiment knob: 256x256 ring launches whose epilogue only stores T results run on the persistent variant (cfg 12)
 KBLOCK_W = True          # hand the ring kernels their weights K-blocked (PackedW.kblocked()); False = row-major everywhere
 K64_CFG14 = True         # single-K-step GEMMs on the two-workgroups-per-CU half-height config (False: 256x256 like every other large shape)
@@ -113,7 +113,7 @@ def big_tile_cfg(N, K, esz):
     if QUAD and esz == 2:
         return 25
     if QUADV and esz == 2:
-        return 27
+        return QUADV if QUADV in (27, 29) else 27
     return 24 if (RING5 and esz == 2 and (K * esz >= 2048 or N >= 2304)) else 8
 
 
@@ -398,6 +398,9 @@ def gemm_kernel_name(cfg, mask, dtype):
     if cfg in (25, 26):
         mq = m if (cfg == 25 and m in _QUAD_SPECIALISED) else EPI_GENERIC
         return f"gemm_tn_quad_kernel<{mq},false>", f"gemm_tn_quad_kernelI{mi(mq)}Lb0EE"
+    if cfg == 29:
+        mq = m if m in _QUAD_SPECIALISED else EPI_GENERIC
+        return f"gemm_tn_quadvp_kernel<{mq}>", f"gemm_tn_quadvp_kernelI{mi(mq)}E"
     if cfg in (27, 28):
         mq = m if (m in _QUAD_SPECIALISED and (cfg == 27 or m == EPI_OUTT)) else EPI_GENERIC
         return f"gemm_tn_quadv_kernel<{mq},{cfg - 25},0>", f"gemm_tn_quadv_kernelI{mi(mq)}{mi(cfg - 25)}Li0EE"

@@ -394,7 +394,8 @@ def test_register_staged_gemm_equals_the_ring_kernel_bit_for_bit(M, N, K):
     """Tile cfgs 27 / 28 feed the four-wave 256 x 256 tile through buffer loads into registers and ds_write_b128 (two / three sub-tiles in flight) instead of LDS-DMA.
     The LDS images, fragment reads, accumulator layout and epilogue are those of cfgs 25 / 8, so every output must equal cfg 8's bit for bit: plain and fused epilogues,
     ragged M and N (rows past the end come back as zero from the buffer range check, never clamped addresses), K loops shorter than the unrolled six steps and not a
-    multiple of them, row-major and K-blocked operands, three-byte residual in / three-byte result + row sums out."""
+    multiple of them, row-major and K-blocked operands, three-byte residual in / three-byte result + row sums out.  Tile cfg 29 is cfg 27 on a persistent grid (the
+    65 536-row case gives every workgroup three tiles): the loads past a tile's last sub-tile fetch the next tile's first two while the epilogue runs."""
     from uia_hip import ops
     g = torch.Generator(device="cpu").manual_seed(M + N + K)
     dt = torch.bfloat16
@@ -402,13 +403,13 @@ def test_register_staged_gemm_equals_the_ring_kernel_bit_for_bit(M, N, K):
     w = ops.PackedW((torch.randn(N, K, generator=g) * K ** -0.5).to(dev()).to(dt))
     bias = torch.randn(N, generator=g).to(dev())
     outs = {}
-    for cfg in (8, 27, 28):
+    for cfg in (8, 27, 28, 29):
         o = torch.full((M, N), float("nan"), device=dev(), dtype=dt)
         ops.gemm(a, w, bias=bias, act="gelu", out_t=o, tile_cfg=cfg)
         p = torch.full((M, N), float("nan"), device=dev(), dtype=dt)
         ops.gemm(a, w, out_t=p, tile_cfg=cfg)
         outs[cfg] = (o, p)
-    for cfg in (27, 28):
+    for cfg in (27, 28, 29):
         for x, y in zip(outs[8], outs[cfg]):
             assert torch.equal(x, y) and not torch.isnan(y.float()).any(), cfg
     want = torch.nn.functional.gelu(a.float() @ w.row.float().T + bias)
@@ -417,11 +418,11 @@ def test_register_staged_gemm_equals_the_ring_kernel_bit_for_bit(M, N, K):
     wide = torch.randn(M, K + 64, generator=g).to(dev()).to(dt)
     av = wide[:, 32:32 + K]
     res = {}
-    for cfg in (8, 27):
+    for cfg in (8, 27, 29):
         o = torch.full((M, N), float("nan"), device=dev(), dtype=dt)
         ops.gemm(av, w, bias=bias, out_t=o, tile_cfg=cfg)
         res[cfg] = o
-    assert torch.equal(res[8], res[27])
+    assert torch.equal(res[8], res[27]) and torch.equal(res[8], res[29])
     if N % 64 == 0 and K % 32 == 0 and M > 2048:
         kb = lambda t: ops.KBlocked(t.view(t.shape[0], t.shape[1] // (64 // t.element_size()), 64 // t.element_size()).permute(1, 0, 2).contiguous())
         prev = torch.randn(M, N, generator=g).to(dev()) * 3 + 0.5
@@ -430,10 +431,11 @@ def test_register_staged_gemm_equals_the_ring_kernel_bit_for_bit(M, N, K):
         stats = torch.stack([prev3.mean(1), (prev3.var(1, unbiased=False) + 1e-12).rsqrt()], 1).contiguous()
         lw, lb = torch.randn(N, generator=g).to(dev()), torch.randn(N, generator=g).to(dev())
         res = {}
-        for cfg in (8, 27):
+        for cfg in (8, 27, 29):
             out_t, out_lo = ops.kb_empty(M, N, dt, dev()), ops.kb_empty(M, N, torch.int8, dev())
             sums = torch.zeros(M, 2, device=dev(), dtype=torch.int64)
             ops.gemm(kb(a), w, bias=bias, resid3=(kb(hi), kb(lo)), resid_ln=(stats, lw, lb), out_t=out_t, out_lo=out_lo, rowsum=sums, tile_cfg=cfg)
             res[cfg] = (out_t.t.clone(), out_lo.t.clone(), sums)
-        for x, y in zip(res[8], res[27]):
-            assert torch.equal(x, y)
+        for cfg in (27, 29):
+            for x, y in zip(res[8], res[cfg]):
+                assert torch.equal(x, y), cfg
