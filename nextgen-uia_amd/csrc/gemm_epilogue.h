@@ -606,9 +606,28 @@ __device__ __forceinline__ void gemm_epilogue_lds(const UiaGemmParams& p, f32x4 
                         bf16x8 r = {(bf16_t)lo[0], (bf16_t)lo[1], (bf16_t)lo[2], (bf16_t)lo[3], (bf16_t)hi[0], (bf16_t)hi[1], (bf16_t)hi[2], (bf16_t)hi[3]};
                         outv[hf] = r;
                     }
+#ifdef UIA_EPI_DIRECT
+                    // experiment build (tools/scratch/ab_direct.sh): the rounded values go to memory from the MFMA layout (a lane holds 16 consecutive columns of one row: two
+                    // 16-byte stores), no bounce.  Measured SLOWER, round 5: 65 536 x 2304 x 768 1052 -> 998 TF/s on cfg 8, 1083 -> 1029 on cfg 27, the step 40.1 -> 40.5-40.7 ms
+                    // (profiles/r05_f_quadv_ablation.txt): a store instruction of sixteen rows x four 16-byte pieces costs the CU's store path more than the bounce's LDS time.
+                    {
+                        T* dbase = which == 0 ? outT : aux_out;
+                        const int m = m0 + wm * WTM + mloc;
+                        if (m < p.M && UIA_EPI_STORES) {
+                            T* d = (which == 0 && p.outT_kb_rows) ? dbase + ((size_t)(nl / 32) * (size_t)p.outT_kb_rows + (size_t)m) * 32 + (nl % 32)
+                                                                  : dbase + (size_t)m * (which == 0 ? p.ldo : p.ldaux_out) + nl;
+                            if (lcol_ok) *(bf16x8*)d = outv[0];
+                            if (lcol_ok2) *(bf16x8*)(d + 8) = outv[1];
+                        }
+                    }
+                    continue;
+#endif
                     *(bf16x8*)(stb + (gi * 16 + li) * LDB + g * 32) = outv[0];
                     *(bf16x8*)(stb + (gi * 16 + li) * LDB + g * 32 + 16) = outv[1];
                 }
+#ifdef UIA_EPI_DIRECT
+                return;
+#endif
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
                 T* dstbase = which == 0 ? outT : aux_out;
