@@ -20,6 +20,10 @@ import os
 import sys
 import time
 
+# the hosts of this pool support dmabuf IPC only: without this RCCL (and any device-buffer hand-off between the ranks of one node) fails with
+# `hipIpcGetMemHandle: invalid argument`.  Read when the HSA runtime starts, i.e. at the first HIP call of the process — set it before anything can make one.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for _p in (ROOT, os.path.join(ROOT, "nextgen-uia_amd")):
     if _p not in sys.path:
