@@ -258,6 +258,22 @@ def test_gemm_schedule_mirrors_are_pure_host_logic():
     m = ops.EPI_QUICK | ops.EPI_BIAS | ops.EPI_GELU | ops.EPI_OUTT
     assert m in ops._SPECIALISED and (m | ops.EPI_LNFOLD) in ops._SPECIALISED and (ops.EPI_QUICK | ops.EPI_DGELU | ops.EPI_OUTT) in ops._SPECIALISED
     assert ops.gemm_kernel_name(8, 977, __import__("torch").bfloat16)[1].endswith("Li977ELi0ELb0ELb0EE")
+    # the register-staged four-wave kernels (csrc/gemm_quadv.hip) are opt-in: the knob moves the 256 x 256 bf16 launches, nothing else; masks they do not instantiate name the
+    # run-time epilogue, and the three-in-flight form (28) instantiates the plain store only
+    bf = __import__("torch").bfloat16
+    try:
+        ops.QUADV = 27
+        assert ops.big_tile_cfg(768, 3072, 2) == 27 and ops.big_tile_cfg(768, 3072, 4) == 8
+        ops.QUADV = 29
+        assert ops.big_tile_cfg(2304, 768, 2) == 29
+    finally:
+        ops.QUADV = False
+    assert ops.big_tile_cfg(768, 3072, 2) == 8
+    assert ops.gemm_kernel_name(27, ops.EPI_OUTT, bf) == ("gemm_tn_quadv_kernel<128,2,0>", "gemm_tn_quadv_kernelILi128ELi2ELi0EE")
+    assert ops.gemm_kernel_name(28, ops.EPI_BIAS | ops.EPI_OUTT, bf)[0] == "gemm_tn_quadv_kernel<-1,3,0>"
+    assert ops.gemm_kernel_name(29, ops.EPI_BIAS | ops.EPI_OUTT, bf) == ("gemm_tn_quadvp_kernel<129>", "gemm_tn_quadvp_kernelILi129EE")
+    assert ops.gemm_kernel_name(29, ops.EPI_BIAS | ops.EPI_RESIDT | ops.EPI_OUT32, bf)[0] == "gemm_tn_quadvp_kernel<-1>"
+    assert set((27, 28, 29)) <= set(ops.RING_CFGS)
 
 
 def test_committed_traffic_file_names_the_kernels_the_headline_step_runs():
