@@ -475,6 +475,9 @@ int uia_gemm_quadv_launch(hipStream_t stream, const UiaGemmParams& p, bool speci
         const size_t a_bytes = p.a_kb_rows ? (size_t)p.a_kb_rows * p.K * 2 : ((size_t)(p.M - 1) * p.lda + p.K) * 2, w_bytes = p.w_kblocked ? (size_t)p.N * p.K * 2 : ((size_t)(p.N - 1) * p.ldw + p.K) * 2;
         if (a_bytes >= ((size_t)1 << 32) || w_bytes >= ((size_t)1 << 32)) { uia_set_error("uia_gemm: tile cfg 27 addresses its operands through 32-bit buffer offsets (A %zu bytes, W %zu bytes)", a_bytes, w_bytes); return -1; }
     }
+#ifdef UIA_QUADV_ABLATIONS
+    // diagnostic build only (tools/scratch/quadv_ablate.sh builds a second library with -DUIA_QUADV_ABLATIONS): timing ablations of the K loop, selected by an
+    // environment variable; the results are WRONG by construction, so the shipped library does not contain them
     static const int abl = [] { const char* e = getenv("UIA_QUADV_ABLATE"); return e ? atoi(e) : 0; }();
     if (abl) {                                             // timing ablations of the K loop (results are WRONG): tools/gemm_square_yardstick.py
         switch (abl) {
@@ -490,6 +493,7 @@ int uia_gemm_quadv_launch(hipStream_t stream, const UiaGemmParams& p, bool speci
             default: uia_set_error("uia_gemm: unknown ablation"); return -1;
         }
     }
+#endif
 #define UIA_QV(MASK) case (MASK): return depth == 9 ? launch_quadvp_epi<(MASK)>(stream, p, xflags) : launch_quadv_epi<(MASK), 2>(stream, p, xflags)
     if (depth == 3) {                                      // three sub-tiles in flight (tile cfg 28): plain epilogues only
         if (specialise && epi_mask_of(p) == EPI_OUTT) return launch_quadv_epi<EPI_OUTT, 3>(stream, p, xflags);
