@@ -148,6 +148,10 @@ typedef struct uia_gemm_desc {
     int64_t resid_lo_kb_rows;
     int64_t out_lo_kb_rows;
 } uia_gemm_desc;
+/* tile_cfg: 0 = chosen from the shape (what every caller in this repo passes unless it runs an experiment).  Low byte = a kernel: 8 the 256 x 256 ring tile (eight
+ * waves, LDS-DMA), 13 / 14 its half-height forms, 12 persistent, 16 / 23 the N = 64 / K = 64 streams, 24 five-deep ring, 25 / 26 four waves of 128 x 128, 27 / 28 / 29 the same
+ * with operands staged through registers (two / three sub-tiles in flight / a persistent grid; bf16, no K extension, operands below 4 GiB), 1-5 / 21 small tiles; bits 8-15 =
+ * row panels per tile-order group (255 = none).  Every ring kernel returns bit-identical results for a given descriptor; an unsupported combination returns -1. */
 int uia_gemm(void* stream, int dtype, const uia_gemm_desc* d, int tile_cfg /* 0 = auto */);
 
 /* Parameter gradient of a Linear:  dW[I,J] += Σ_m A[m,I]ᵀ·B[m,J]  and optionally dbias[I] += Σ_m A[m,I]
