@@ -191,7 +191,7 @@ def test_pipelined_epilogue_equals_inline_epilogue_bit_for_bit(M, N, K):
     for kind in ("plain", "bias", "gelu", "gelu_stash", "lnfold_bias", "lnfold_gelu", "lnfold_gelu_stash", "qgelu", "qgelu_stash", "dqgelu",
                  "dgelu", "resid32", "residT", "fold_producer", "resid_ln", "resid_ln_sums_fold_producer"):
         ref = run(10, kind)
-        for cfg in (8, 13, 14, 25, 26):                                  # 25 / 26: the four-wave kernel (round 4), compile-time and run-time epilogue
+        for cfg in (8, 13, 14, 25, 26, 27, 28, 29):                      # 25 / 26: the four-wave kernel (round 4), compile-time and run-time epilogue; 27 / 28 / 29: its register-staged forms (round 5)
             got = run(cfg, kind)
             for name, x, y in zip(("out32", "outT", "rowsum"), got, ref):
                 same = torch.equal(x, y) if x.dtype == torch.int64 else torch.equal(torch.nan_to_num(x.float(), nan=-7.0), torch.nan_to_num(y.float(), nan=-7.0))
