@@ -409,6 +409,9 @@ def main():
         # FIRST, before this process has touched the GPU (a program started from a process with a live HIP runtime is not allowed on this pool, and the two would share the
         # device): the fine-tune CLI as a child process, run to completion; its figure is attached to the line below
         args.entry_point_result = entry_point_form(args, f"cuda:{local}")
+    args.clipseg_entry_point_result = None
+    if not profiled and world == 1 and not args.no_entry_point and ((args.config == "mona" and not args.no_secondary) or args.config == "clipseg"):
+        args.clipseg_entry_point_result = entry_point_clipseg(args, f"cuda:{local}", 128 if args.config == "mona" else args.batch)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if not args.batch:
@@ -492,7 +495,7 @@ def secondary_lines(args, device):
             o = fn(a, 0, 1, device)
             r = o.get("roofline") or {}
             lines[cfg] = {"metric": o["metric"], "value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"], "steps": o["steps"], "warmup": o["warmup"],
-                          "dtype": o["dtype"], "data": o["data"], "config": o["config"], "loss": o["loss"],
+                          "dtype": o["dtype"], "data": o["data"], "config": o["config"], "loss": o["loss"], **({"entry_point": o["entry_point"]} if "entry_point" in o else {}),
                           "roofline": {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "launches_per_step", "avg_launch_us",
                                                              "share_of_step", "whole_step_frac_of_peak", "gflop_per_image_executed", "whole_step_frac_of_peak_executed", "executed_note", "gemm_family")}}
         except Exception as e:                      # a secondary line must never cost the headline
@@ -532,6 +535,41 @@ def entry_point_form(args, device):
             "child_wall_s": round(wall, 1),
             "what": "src/models/biomedclip/finetune.py main() as a child process: synthetic pairs from loader workers -> pinned staging -> copy stream -> engine.ContrastiveLoop "
                     "(contrastive_micro + device-guarded accumulate / clip + AdamW, cosine LR on the device) ; epochs 2-3 of 3, wall time per optimiser update",
+            "command": "python " + " ".join(os.path.relpath(c, ROOT) if c == script else c for c in cmd[1:-1]) + " <tmp>"}
+
+
+def entry_point_clipseg(args, device, batch):
+    """BASELINE configs[3]'s boundary, timed: `python src/models/clipseg/segmentation.py --dataset BUSI --synthetic --batch_size 128` as a CHILD process — the
+    reference's loop (real loader workers -> shared ring -> copy stream -> engine.segmentation_step, cosine schedule, validation + test pass + best-Dice
+    checkpoint at the last epoch, then test()); three epochs of --entry-steps iterations, the first is warm-up, the figure is the wall time of the other two
+    over their iterations (validation is outside the epochs' clocks, as in the fine-tune form)."""
+    import subprocess
+    import tempfile
+    script = os.path.join(ROOT, "nextgen-uia_amd", "src", "models", "clipseg", "segmentation.py")
+    with tempfile.TemporaryDirectory() as td:
+        stats = os.path.join(td, "stats.json")
+        cmd = [sys.executable, script, "--dataset", "BUSI", "--synthetic", "--synthetic_train", str(batch * args.entry_steps), "--synthetic_val", str(batch),
+               "--synthetic_test", str(batch), "--batch_size", str(batch), "--epochs", "3", "--dtype", args.dtype, "--exp", "bench_entry_point_clipseg",
+               "--device", str(device), "--stats_json", stats]
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, cwd=td, capture_output=True, text=True, timeout=420)
+        except subprocess.TimeoutExpired:
+            return {"error": "the entry-point child process did not finish in 420 s", "command": " ".join(cmd[1:])}
+        except OSError as e:
+            return {"error": f"could not start the entry-point child process: {e}", "command": " ".join(cmd[1:])}
+        wall = time.perf_counter() - t0
+        if r.returncode != 0 or not os.path.exists(stats):
+            return {"error": f"exit code {r.returncode}", "stderr_tail": r.stderr[-1500:], "command": " ".join(cmd[1:])}
+        out = json.load(open(stats))
+    steady = out["epochs"][1:]
+    ms = sum(e["ms"] for e in steady) / max(1, sum(e["updates"] for e in steady))
+    return {"ms_per_step": round(ms, 3), "value": round(batch / ms * 1e3, 2), "unit": "images/s", "vs_line_ms": None,
+            "epochs": [{k: (round(v, 1) if isinstance(v, float) else v) for k, v in e.items()} for e in out["epochs"]], "iters": out["iters"],
+            "best_val_dice": out["best_val_dice"], "child_wall_s": round(wall, 1),
+            "what": "src/models/clipseg/segmentation.py main() as a child process: synthetic image/mask pairs from loader workers -> shared-memory ring -> copy stream -> "
+                    "engine.segmentation_step (the step this line times), cosine LR per iteration; epochs 2-3 of 3, wall time per iteration; validation, test pass, "
+                    "best-Dice checkpoint and test() run after the last epoch, outside the clock",
             "command": "python " + " ".join(os.path.relpath(c, ROOT) if c == script else c for c in cmd[1:-1]) + " <tmp>"}
 
 
@@ -666,20 +704,17 @@ def bench_clipseg(args, rank, world, device):
     with contextlib.redirect_stdout(sys.stderr):
         model = S.prepare_model(sargs)
     cpu_state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()} if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
-    opt = FlatAdapterOptimizer([(n, p) for n, p in model.named_parameters() if p.requires_grad], lr=1e-4, betas=(0.9, 0.999), max_norm=0.0)
+    opt = FlatAdapterOptimizer([(n, p) for n, p in model.named_parameters() if p.requires_grad], lr=sargs.lr, betas=(sargs.beta1, sargs.beta2),
+                               weight_decay=sargs.weight_decay, max_norm=0.0)          # the entry point's optimiser (reference clipseg/segmentation.py:121-126)
     init_data_parallel(opt, force_comm=True)                 # world 1 too: the one-rank RCCL communicator, so that the N = 1 line already times uia_allreduce_sum
-    crit = DiceCELoss()
+    crit = S.criterion
     images, labels = S.synthetic_batch(args.batch, 224, 1 + rank, str(device))
-    prompt = S.busi_prompt.to(device).repeat(args.batch, 1)
+    sargs.dataset = "BUSI"
+    prompt = S.get_prompt(sargs).to(device).repeat(args.batch, 1)          # the reference's BUSI prompt, 68 tokens (src/models/clipseg/prompt_ids.json)
+    from uia_hip.engine import segmentation_step
 
     def step(_overlap):
-        opt.zero_grad()
-        loss = crit(model(images, input_ids=prompt), labels)
-        loss.backward()
-        opt.all_reduce()
-        opt.step()
-        UF.clear_t_copies()
-        return loss
+        return segmentation_step(model, crit, opt, images, labels, input_ids=prompt)[0]      # the function the entry point calls per loader batch
 
     elapsed, per_rank, final_loss, prof, prof_serial = timed_loop(step, args, world, device, ops, torch)
     if rank != 0:
@@ -702,6 +737,11 @@ def bench_clipseg(args, rank, world, device):
                       "gflop_per_image_algorithmic": GF},
            "loss": round(final_loss, 5), "roofline": roof}
     out.update(dist_fields(world, per_rank, args.steps, ops))
+    ep = getattr(args, "clipseg_entry_point_result", None)
+    if ep is not None:
+        if "ms_per_step" in ep:
+            ep["vs_line_ms"] = round(ep["ms_per_step"] / ms, 4)
+        out["entry_point"] = ep
     out["cpu_baseline"] = None
     if cpu_state is not None:
         from oracle import clipseg_ref, losses_ref

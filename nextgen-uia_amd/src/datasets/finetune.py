@@ -86,10 +86,10 @@ class SharedBatchRing:
 
     MARK = "__uia_ring__"
 
-    def __init__(self, slots, batch, img_shape, ids_len, tokenizer):
+    def __init__(self, slots, batch, img_shape, ids_len, tokenizer, second_shape=None, second_dtype=torch.int64):
         import multiprocessing as mp
         self.images = torch.empty((slots, batch) + tuple(img_shape), dtype=torch.float32).share_memory_()
-        self.ids = torch.zeros((slots, batch, ids_len), dtype=torch.int64).share_memory_()
+        self.ids = torch.zeros((slots, batch) + (tuple(second_shape) if second_shape is not None else (ids_len,)), dtype=second_dtype).share_memory_()      # token ids, or the segmentation loaders' masks
         self.free = mp.get_context("fork").Queue()
         for i in range(slots):
             self.free.put(i)
@@ -122,6 +122,32 @@ class SharedBatchRing:
 
     def release(self, slot):
         self.free.put(slot)
+
+
+def ring_slots(nw):
+    """Slots a loader with nw worker processes needs: every batch a worker may have in flight (prefetch_factor 2 per worker) plus the consumer's pipeline."""
+    return 2 * nw + 4
+
+
+def plan_workers(nw, per_slot_bytes, owner=None):
+    """(workers, ring slots) that FIT: the ring of ring_slots(nw) batch-sized slots is allocated up front in /dev/shm (pages are committed on first touch, and a
+    write to a page that cannot be had raises SIGBUS, not an exception) — so the count is cut until the whole ring, plus the rings `owner` (a DataModule: it
+    builds two or three loaders) planned before it, fits into half of what is free; no room for even a one-worker ring means in-process loading (0, 0)."""
+    import shutil
+    if nw <= 0:
+        return 0, 0
+    planned = getattr(owner, "_shm_planned", 0)
+    try:
+        room = shutil.disk_usage("/dev/shm").free // 2 - planned
+    except OSError:
+        room = 0
+    while nw > 0 and ring_slots(nw) * per_slot_bytes > room:
+        nw -= 1
+    if nw == 0:
+        return 0, 0
+    if owner is not None:
+        owner._shm_planned = planned + ring_slots(nw) * per_slot_bytes
+    return nw, ring_slots(nw)
 
 
 class _TokenisingCollate:
@@ -170,21 +196,15 @@ class DataModule:
             import logging
             logging.info("loader: the GPU is already initialised in this process; loading in-process (num_workers=0)")
             nw = 0
+        slots = 0
         if nw:
-            # every in-flight batch of a worker sits in /dev/shm until the consumer has copied it: never plan for more than half of what is free there
-            import shutil
-            per_batch = self.args.batch_size * 3 * self.args.img_size ** 2 * 4
-            try:
-                room = shutil.disk_usage("/dev/shm").free // 2
-            except OSError:
-                room = 0
-            nw = max(0, min(nw, room // max(1, 3 * per_batch)))
+            # the ring of shared slots is sized from what it really allocates: images + token ids per slot, ring_slots(nw) of them, both loaders counted
+            ids_len = int(self.tokenizer(["x"]).shape[1]) if self.tokenizer is not None else 0
+            nw, slots = plan_workers(nw, self.args.batch_size * (3 * self.args.img_size ** 2 * 4 + ids_len * 8), owner=self)
         kw = dict(num_workers=nw, drop_last=True)
         if self.tokenizer is not None and nw:
-            # worker processes: batches travel through a ring of shared slots (SharedBatchRing); every batch a worker may have in flight (prefetch_factor per
-            # worker) plus the consumer's pipeline needs a slot
-            ids_len = int(self.tokenizer(["x"]).shape[1])
-            kw.update(collate_fn=SharedBatchRing(2 * nw + 4, self.args.batch_size, (3, self.args.img_size, self.args.img_size), ids_len, self.tokenizer))
+            # worker processes: batches travel through a ring of shared slots (SharedBatchRing)
+            kw.update(collate_fn=SharedBatchRing(slots, self.args.batch_size, (3, self.args.img_size, self.args.img_size), ids_len, self.tokenizer))
         elif self.tokenizer is not None:
             kw.update(collate_fn=_TokenisingCollate(self.tokenizer))
         if nw:

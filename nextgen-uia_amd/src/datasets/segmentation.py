@@ -1,0 +1,173 @@
+"""Image / mask data for the segmentation entry points (counterpart of /root/reference/src/datasets/segmentation.py).
+
+The reference reads PNG pairs listed in ../data/NextGen-UIA/segmentation/<dataset>/{train,val,test}.txt with PIL, augments them with torchvision (:14-156) and
+hands batches of (image float32 [B, 3, S, S] in [0, 1] — ONE grayscale channel repeated three times, :175, :199-200 — label float32 [B, 1, S, S] in {0, 1},
+file names) to the loop, `shuffle=True, drop_last=True` for training and neither for validation / test (:223-251).  PIL / torchvision I/O and augmentation are
+host-side work outside the hot path (and absent from the build image); what the hot path needs is that batch contract and the three splits.  `--synthetic`
+supplies them deterministically (U[0,1) grayscale images with a random-ellipse mask); `--data_pt` takes real data as a .pt file of
+{"images": [N, 1 or 3, S, S] uint8 / float, "labels": [N, 1, S, S], optional "names", optional "split": {"train": idx, "val": idx, "test": idx}}.
+
+Because the three channels are copies of one, a batch travels host -> device as ONE channel (float32) plus a uint8 mask — 32 MB instead of 103 MB at 128 images —
+through the same shared-memory slot ring the fine-tune loader uses, and `as_model_input` repeats the channel on the device (a 77 MB write at HBM rate).
+"""
+import torch
+from torch.utils.data import DataLoader, Dataset
+
+from src.datasets.finetune import RankShardSampler, SharedBatchRing, plan_workers
+
+
+def synthetic_sample(size, seed):
+    """One (image [1, S, S] float32, label [1, S, S] uint8) pair."""
+    g = torch.Generator().manual_seed(seed)
+    img = torch.rand(1, size, size, generator=g)
+    c = torch.rand(2, generator=g) * size * 0.5 + size * 0.25
+    r = torch.rand(2, generator=g) * size * 0.2 + size * 0.08
+    yy = torch.arange(size, dtype=torch.float32)[:, None]
+    xx = torch.arange(size, dtype=torch.float32)[None, :]
+    mask = ((yy - c[0]) / r[0]) ** 2 + ((xx - c[1]) / r[1]) ** 2 <= 1
+    return img, mask[None].to(torch.uint8)
+
+
+def synthetic_batch(B, size, seed, device):
+    """A resident batch (images [B, 3, S, S], labels [B, 1, S, S] float32) — bench.py's clipseg line and the biomedclip segmentation loop use it."""
+    g = torch.Generator().manual_seed(seed)
+    img = torch.rand(B, 1, size, size, generator=g).repeat(1, 3, 1, 1)
+    yy, xx = torch.meshgrid(torch.arange(size), torch.arange(size), indexing="ij")
+    c = torch.rand(B, 2, generator=g) * size * 0.5 + size * 0.25
+    r = torch.rand(B, 2, generator=g) * size * 0.2 + size * 0.08
+    mask = (((yy[None] - c[:, 0, None, None]) / r[:, 0, None, None]) ** 2 + ((xx[None] - c[:, 1, None, None]) / r[:, 1, None, None]) ** 2) <= 1
+    return img.to(device), mask[:, None].float().to(device)
+
+
+def as_model_input(images, labels, in_channels=3):
+    """Device side of the batch contract: the grayscale channel repeated (reference :199-200), the mask as float32."""
+    if images.shape[1] == 1 and in_channels == 3:
+        images = images.expand(-1, 3, -1, -1).contiguous()
+    return images.float(), labels.float()
+
+
+class SyntheticSegmentation(Dataset):
+    def __init__(self, n, img_size, seed, prefix):
+        self.n, self.img_size, self.seed, self.prefix = n, img_size, seed, prefix
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        img, lab = synthetic_sample(self.img_size, self.seed * 1000003 + i)
+        return img, lab, f"{self.prefix}_{i:05d}.png"
+
+
+class TensorSegmentation(Dataset):
+    def __init__(self, images, labels, names):
+        self.images, self.labels, self.names = images, labels, names
+
+    def __len__(self):
+        return len(self.names)
+
+    def __getitem__(self, i):
+        img = self.images[i]
+        img = img.float() / 255.0 if img.dtype == torch.uint8 else img.float()
+        return img[:1], (self.labels[i][:1] > 0).to(torch.uint8), self.names[i]      # the reference converts every image to one grayscale channel (:175)
+
+
+class SegBatchRing(SharedBatchRing):
+    """SharedBatchRing whose second tensor is the uint8 mask: a worker's collate writes [B, 1, S, S] images and masks into a free shared slot and returns
+    (mark, slot, names)."""
+
+    def __init__(self, slots, batch, img_size):
+        super().__init__(slots, batch, (1, img_size, img_size), 0, None, second_shape=(1, img_size, img_size), second_dtype=torch.uint8)
+
+    def __call__(self, samples):
+        names = [s[2] for s in samples]
+        if len(samples) != self.batch:                         # the ragged last batch of a validation / test split travels the ordinary way
+            return torch.stack([s[0] for s in samples]), torch.stack([s[1] for s in samples]), names
+        slot = self.free.get()
+        torch.stack([s[0] for s in samples], out=self.images[slot])
+        torch.stack([s[1] for s in samples], out=self.ids[slot])
+        return self.MARK, slot, names
+
+
+def _plain_collate(samples):
+    return torch.stack([s[0] for s in samples]), torch.stack([s[1] for s in samples]), [s[2] for s in samples]
+
+
+def second_of(batch):
+    """What engine.DevicePrefetcher copies beside the images: the masks."""
+    return batch[1]
+
+
+class DataModule:
+    MAX_WORKERS = 6
+
+    def __init__(self, args, rank=None, world=None):
+        import os
+        self.args = args
+        self.rank = int(os.environ.get("RANK", 0)) if rank is None else rank
+        self.world = int(os.environ.get("WORLD_SIZE", 1)) if world is None else world
+        if getattr(args, "data_pt", None):
+            blob = torch.load(args.data_pt)
+            n = len(blob["images"])
+            names = list(blob.get("names") or [f"{i:05d}.png" for i in range(n)])
+            split = blob.get("split")
+            if split is None:                                   # 70 / 10 / 20 in file order (the reference's lists are pre-shuffled text files, :210-216)
+                a, b = int(n * 0.7), int(n * 0.8)
+                split = {"train": list(range(a)), "val": list(range(a, b)), "test": list(range(b, n))}
+            mk = lambda idx: TensorSegmentation(blob["images"][idx], blob["labels"][idx], [names[i] for i in idx])
+            self.train_dataset, self.val_dataset, self.test_dataset = mk(split["train"]), mk(split["val"]), mk(split["test"])
+        elif getattr(args, "synthetic", False):
+            self.train_dataset = SyntheticSegmentation(args.synthetic_train, args.img_size, args.seed, "train")
+            self.val_dataset = SyntheticSegmentation(args.synthetic_val, args.img_size, args.seed + 1, "val")
+            self.test_dataset = SyntheticSegmentation(args.synthetic_test, args.img_size, args.seed + 2, "test")
+        else:
+            raise RuntimeError("no dataset: pass --synthetic or --data_pt (the reference's PIL/torchvision loaders read ../data/NextGen-UIA and are outside this build)")
+        self.train_sampler = None
+        self._loaders = []
+
+    def _loader(self, ds, train):
+        a = self.args
+        nw = max(0, min(int(getattr(a, "num_workers", 0) or 0), self.MAX_WORKERS if train else 2))
+        if nw and torch.cuda.is_initialized():
+            import logging
+            logging.info("loader: the GPU is already initialised in this process; loading in-process (num_workers=0)")
+            nw = 0
+        per_slot = a.batch_size * a.img_size ** 2 * 5          # one float32 channel + one uint8 mask
+        nw, slots = plan_workers(nw, per_slot, owner=self)
+        kw = dict(num_workers=nw, drop_last=train)              # reference :223-251
+        kw["collate_fn"] = SegBatchRing(slots, a.batch_size, a.img_size) if nw else _plain_collate
+        if nw:
+            kw.update(persistent_workers=True, prefetch_factor=2)
+        if train and self.world > 1:                            # every rank trains on its own shard; validation / test run whole on every rank (identical weights ->
+            sampler = RankShardSampler(len(ds), self.rank, self.world, shuffle=True, seed=getattr(a, "seed", 0), drop_last=True)    # identical decisions, no collective)
+            self.train_sampler = sampler
+            loader = DataLoader(ds, batch_size=a.batch_size, sampler=sampler, **kw)
+        else:
+            loader = DataLoader(ds, batch_size=a.batch_size, shuffle=train, **kw)
+        self._loaders.append(loader)
+        return loader
+
+    def train_dataloader(self):
+        return self._loader(self.train_dataset, True)
+
+    def val_dataloader(self):
+        return self._loader(self.val_dataset, False)
+
+    def test_dataloader(self):
+        return self._loader(self.test_dataset, False)
+
+    def start_workers(self):
+        """Fork the worker processes before the process touches the GPU (datasets.finetune.DataModule.start_workers)."""
+        for loader in self._loaders:
+            if loader.num_workers > 0 and len(loader) > 0:
+                loader._uia_first_iter = iter(loader)
+
+    def set_epoch(self, epoch):
+        if self.train_sampler is not None:
+            self.train_sampler.set_epoch(epoch)
+
+    def shutdown(self):
+        for loader in self._loaders:
+            it = getattr(loader, "_iterator", None)
+            if it is not None and hasattr(it, "_shutdown_workers"):
+                it._shutdown_workers()
+            loader._iterator = None

@@ -40,3 +40,15 @@ def dice_per_image(logits, label):
     out = 2 * inter / tot
     out[gt.flatten(1).sum(1) == 0] = float("nan")
     return out
+
+
+def iou_per_image(logits, label):
+    """compute_iou(one_hot(argmax), label, include_background=False, ignore_empty=True): n(P∩G) / n(P∪G) per image, NaN where the ground truth is empty
+    (reference src/utils/tools.py:17, :192)."""
+    pred = logits.argmax(dim=1) == 1
+    gt = label[:, 0] > 0
+    inter = (pred & gt).flatten(1).sum(1).double()
+    union = pred.flatten(1).sum(1).double() + gt.flatten(1).sum(1).double() - inter
+    out = inter / union
+    out[gt.flatten(1).sum(1) == 0] = float("nan")
+    return out

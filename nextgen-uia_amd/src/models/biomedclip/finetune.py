@@ -31,7 +31,7 @@ from src.adapters import inject_lora_to_biomedclip, inject_mona_variant_to_open_
 from src.datasets import finetune as dataset_finetune
 from src.losses import InfoNCELoss
 from src.third_party.biomedclip.model import SyntheticTokenizer, create_biomedclip
-from src.utils.tools import model_summary, parse_config, setup_logging
+from src.utils.tools import default_device, model_summary, parse_config, setup_logging
 from uia_hip import functional as UF
 from uia_hip.engine import ContrastiveLoop, DevicePrefetcher, FlatAdapterOptimizer, bind_device, dist_env, init_data_parallel, sum_over_ranks
 
@@ -64,7 +64,7 @@ def get_args(argv=None):
     p.add_argument("--weight_decay", type=float, default=0.01)
     p.add_argument("--beta1_adam", type=float, default=0.9)
     p.add_argument("--beta2_adam", type=float, default=0.95)
-    p.add_argument("--device", type=str, default="cuda:0" if torch.cuda.device_count() > 0 else "cpu")       # device_count() does not initialise the GPU: the loader workers fork first
+    p.add_argument("--device", type=str, default=default_device())       # decided without a HIP call: the loader workers fork first
     p.add_argument("--patience", type=int, default=10)
     p.add_argument("--accumulation_steps", type=int, default=4)
     p.add_argument("--grad_clip", type=float, default=1.0)
@@ -223,6 +223,8 @@ def train(args):
             logging.info(f"\nEarly stopping at epoch {epoch + 1} as validation loss did not improve for {args.patience} epochs.")
             break
     logging.info(f"\n✓ Training completed! Best validation loss: {best_loss:.4f} at epoch {best_epoch + 1}")
+    train_pf.close()                                           # an epoch prefetched ahead and abandoned by early stopping
+    val_pf.close()
     dm.shutdown()
     if world > 1:
         from uia_hip import ops

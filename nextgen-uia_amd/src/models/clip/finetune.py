@@ -25,7 +25,7 @@ from src.adapters import inject_mona_variant_to_clip
 from src.models.metaclip import finetune as _loop
 from src.third_party.open_clip.model import SyntheticClipTokenizer
 from src.third_party.openai_clip.model import CLIP, build_model
-from src.utils.tools import parse_config, setup_logging
+from src.utils.tools import default_device, parse_config, setup_logging
 
 
 def get_args(argv=None):
@@ -49,7 +49,7 @@ def get_args(argv=None):
     p.add_argument("--weight_decay", type=float, default=0.01)
     p.add_argument("--beta1_adam", type=float, default=0.9)
     p.add_argument("--beta2_adam", type=float, default=0.95)
-    p.add_argument("--device", type=str, default="cuda:0" if torch.cuda.device_count() > 0 else "cpu")       # device_count() does not initialise the GPU: the loader workers fork first
+    p.add_argument("--device", type=str, default=default_device())       # decided without a HIP call: the loader workers fork first
     p.add_argument("--patience", type=int, default=10)
     # additions of this build
     p.add_argument("--dtype", type=str, default="bf16", choices=["bf16", "fp32"])

@@ -25,7 +25,7 @@ from src.adapters import inject_mona_variant_to_open_clip
 from src.datasets import finetune as dataset_finetune
 from src.losses import InfoNCELoss
 from src.third_party.open_clip.model import SyntheticClipTokenizer, create_metaclip
-from src.utils.tools import model_summary, parse_config, setup_logging
+from src.utils.tools import default_device, model_summary, parse_config, setup_logging
 from uia_hip import functional as UF
 from uia_hip.engine import ContrastiveLoop, DevicePrefetcher, FlatAdapterOptimizer, bind_device, dist_env, init_data_parallel, sum_over_ranks
 
@@ -51,7 +51,7 @@ def get_args(argv=None):
     p.add_argument("--weight_decay", type=float, default=0.01)
     p.add_argument("--beta1_adam", type=float, default=0.9)
     p.add_argument("--beta2_adam", type=float, default=0.95)
-    p.add_argument("--device", type=str, default="cuda:0" if torch.cuda.device_count() > 0 else "cpu")       # device_count() does not initialise the GPU: the loader workers fork first
+    p.add_argument("--device", type=str, default=default_device())       # decided without a HIP call: the loader workers fork first
     p.add_argument("--patience", type=int, default=10)
     # additions of this build
     p.add_argument("--dtype", type=str, default="bf16", choices=["bf16", "fp32"])
@@ -115,7 +115,7 @@ def train(args, prepare=None, tokenizer_of=None):
     if world > 1:
         init_data_parallel(opt)
     max_iters = len(trainloader) * args.epochs
-    loop = ContrastiveLoop(model, criterion, opt, accumulation_steps=1, lr=args.lr, lr_min=args.lr_min, total_updates=max_iters, features=_normalise)
+    loop = ContrastiveLoop(model, criterion, opt, accumulation_steps=1, lr=args.lr, lr_min=args.lr_min, total_updates=max_iters, features=_normalise, discard_on_skip=True)      # zero_grad() before every backward in the reference (:160)
     train_pf = DevicePrefetcher(trainloader, tokenizer, args.device)
     val_pf = DevicePrefetcher(valloader, tokenizer, args.device)
     iter_num, best_loss, best_epoch, patience = 0, float("inf"), 0, 0
@@ -160,6 +160,8 @@ def train(args, prepare=None, tokenizer_of=None):
             logging.info(f"Early stopping triggered at epoch {epoch + 1}")
             break
     logging.info(f"\n✓ Training completed! Best loss: {best_loss:.4f} (epoch {best_epoch + 1})")
+    train_pf.close()                                           # an epoch prefetched ahead and abandoned by early stopping
+    val_pf.close()
     dm.shutdown()
     if world > 1:
         from uia_hip import ops

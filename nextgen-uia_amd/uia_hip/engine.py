@@ -143,9 +143,13 @@ class FlatAdapterOptimizer(FlatLayout):
         UF.join_side_streams()                                 # weight-gradient launches on the side stream write into self.g
         self._adopt_grads()
         ops.grad_accum_guarded(self.acc, self.g, loss.reshape(1), self.stats, self.ctl, self.ok_log if log_index is not None else None, log_index or 0)
+        self._staging_dirty = False                            # the kernel zeroed the staging buffer
 
-    def update(self, lr=None, lr_min=0.0, t_max=0, grad_scale=None):
-        """t_max > 0: cosine schedule from lr down to lr_min over t_max updates, indexed by the DEVICE's count of applied updates."""
+    def update(self, lr=None, lr_min=0.0, t_max=0, grad_scale=None, discard_on_skip=False):
+        """t_max > 0: cosine schedule from lr down to lr_min over t_max updates, indexed by the DEVICE's count of applied updates.
+        discard_on_skip: a skipped update ZEROES the accumulator (loops whose reference calls zero_grad() before every backward — metaclip/finetune.py:166,
+        clip/finetune.py — so that under data parallelism the finite ranks' gradients of a skipped iteration are not carried into the next update).
+        Default: the accumulator keeps the cycle's sum (biomedclip/finetune.py has no zero_grad without a step)."""
         if self.world > 1 or self.collective:
             ops.allreduce_sum(self.acc)
         self.steps += 1                                        # optimistic host count (the device's ctl[0] is the truth: read_guard())
@@ -154,7 +158,7 @@ class FlatAdapterOptimizer(FlatLayout):
             self.last_g = self.acc[:self.numel].clone()
         gs = dp_grad_scale(self.world) if grad_scale is None else grad_scale
         ops.adamw_clip_step_guarded(self.p, self.acc, self.m, self.v, self.lr if lr is None else lr, lr_min, t_max, self.betas, self.eps, self.weight_decay,
-                                    self.max_norm, gs, 1.0 / self.world, self.ws8, self.ctl)
+                                    self.max_norm, gs, 0.0 if discard_on_skip else 1.0 / self.world, self.ws8, self.ctl)
         UF.WEIGHTS.bump()
         if UF.ln_fold_enabled(UF.compute_dtype()):
             UF.poll_ln_flag(self.device)
@@ -350,7 +354,7 @@ def _wait_inputs(stream, cur, ready):
 
 
 def contrastive_micro(model, criterion, images, ids, overlap_text=True, global_loss=False, streams=1, image_split=None, inputs_ready=False, ready=None, world=1,
-                      loss_scale=1.0, features=None):
+                      loss_scale=1.0, features=None, opt=None):
     """Forward of both towers + InfoNCE + backward of ONE micro-batch: the gradients land in the trainable parameters' .grad (the flat optimiser's staging
     buffer).  Returns the (unscaled) loss, a device scalar; nothing is read on the host.  Call between begin_update()/end_update() — contrastive_step and
     ContrastiveLoop do.
@@ -448,6 +452,8 @@ def contrastive_micro(model, criterion, images, ids, overlap_text=True, global_l
         rank, _, _ = dist_env()
         fi, ft = GatherFeaturesFn.apply(fi, rank, world), GatherFeaturesFn.apply(ft, rank, world)
     loss = criterion(fi, ft)
+    if opt is not None:
+        opt._staging_dirty = True                              # until accumulate() has folded (and zeroed) the staging buffer
     (loss * loss_scale if loss_scale != 1.0 else loss).backward()
     if split:
         for st in _mb_streams(images.device, max(1, IMAGE_SLICES - 1)):
@@ -458,8 +464,12 @@ def contrastive_micro(model, criterion, images, ids, overlap_text=True, global_l
     return loss.detach()
 
 
-def begin_update(model):
-    """Per-update registries and the three-byte gradient hand-off (tokens are a contract of ONE update's forwards and backwards)."""
+def begin_update(model, opt=None):
+    """Per-update registries and the three-byte gradient hand-off (tokens are a contract of ONE update's forwards and backwards).  opt: the staging buffer (the
+    .grad views) is zeroed when the previous micro-batch did not reach accumulate() — an exception mid-backward, a caller's own backward — so that stale finite
+    gradients are never added to this update (accumulate() leaves the buffer zeroed and clears the flag)."""
+    if opt is not None and getattr(opt, "_staging_dirty", False):
+        opt.g.zero_()
     UF.clear_t_copies()
     UF.set_grad_resid3(GRAD_RESID3 and _hook_free(model))      # tokens are handed out only inside UF.linear_chain() scopes (the towers' own block loops)
 
@@ -485,13 +495,13 @@ def contrastive_step(model, criterion, opt, images, ids, micro_batches=1, lr=Non
 
     streams = S > 1: the batch is cut into S slices whose towers (forward AND backward: autograd runs a node on the stream of its forward) are enqueued on S
     HIP streams; the loss is still ONE InfoNCE over all B pairs."""
-    begin_update(model)
+    begin_update(model, opt)
     total = None
     mb = images.shape[0] // micro_batches
     try:
         for i in range(micro_batches):
             loss = contrastive_micro(model, criterion, images[i * mb:(i + 1) * mb], ids[i * mb:(i + 1) * mb], overlap_text=overlap_text, global_loss=global_loss,
-                                     streams=streams, image_split=image_split, inputs_ready=inputs_ready, world=opt.world, loss_scale=1.0 / micro_batches)
+                                     streams=streams, image_split=image_split, inputs_ready=inputs_ready, world=opt.world, loss_scale=1.0 / micro_batches, opt=opt)
             opt.accumulate(loss)
             total = loss if total is None else total + loss
     finally:
@@ -508,8 +518,8 @@ class ContrastiveLoop:
     with it (the `continue` at :285), the schedule not advancing.  end_epoch() is the one host sync per epoch: it returns the figures the reference
     accumulated with loss.item() and the indices of the skipped batches for the reference's warning."""
 
-    def __init__(self, model, criterion, opt, accumulation_steps=1, lr=1e-4, lr_min=0.0, total_updates=0, features=None, global_loss=False):
-        self.model, self.criterion, self.opt = model, criterion, opt
+    def __init__(self, model, criterion, opt, accumulation_steps=1, lr=1e-4, lr_min=0.0, total_updates=0, features=None, global_loss=False, discard_on_skip=False):
+        self.model, self.criterion, self.opt, self.discard_on_skip = model, criterion, opt, discard_on_skip
         self.acc_steps, self.lr, self.lr_min, self.t_max = max(1, int(accumulation_steps)), lr, lr_min, int(total_updates)
         self.features, self.global_loss = features, global_loss
         self._open = False
@@ -521,11 +531,11 @@ class ContrastiveLoop:
 
     def micro(self, images, ids, batch_idx, ready=None, inputs_ready=False):
         if not self._open:
-            begin_update(self.model)
+            begin_update(self.model, self.opt)
             self._open = True
         try:
             loss = contrastive_micro(self.model, self.criterion, images, ids, ready=ready, inputs_ready=inputs_ready, world=self.opt.world,
-                                     loss_scale=1.0 / self.acc_steps, features=self.features, global_loss=self.global_loss)
+                                     loss_scale=1.0 / self.acc_steps, features=self.features, global_loss=self.global_loss, opt=self.opt)
             self.opt.accumulate(loss, log_index=batch_idx)
         except BaseException:
             end_update()
@@ -534,7 +544,7 @@ class ContrastiveLoop:
         if ((batch_idx + 1) % self.acc_steps == 0) or (batch_idx + 1 == self.n_batches):
             end_update()
             self._open = False
-            self.opt.update(lr=self.lr, lr_min=self.lr_min, t_max=self.t_max, grad_scale=dp_grad_scale(self.opt.world, self.global_loss))
+            self.opt.update(lr=self.lr, lr_min=self.lr_min, t_max=self.t_max, grad_scale=dp_grad_scale(self.opt.world, self.global_loss), discard_on_skip=self.discard_on_skip)
         return loss
 
     def end_epoch(self):
@@ -548,19 +558,38 @@ class ContrastiveLoop:
         return g
 
 
+def segmentation_step(model, criterion, opt, images, labels, input_ids=None, lr=None):
+    """One iteration of the segmentation loops (reference src/models/clipseg/segmentation.py:138-148, biomedclip/segmentation.py:168-178): zero_grad -> forward ->
+    DiceCE -> backward (-> all-reduce of the decoder / head gradients) -> AdamW with the caller's learning rate.  No gradient clipping, no finiteness check —
+    the reference has neither here.  Nothing is read on the host.  The step `bench.py --config clipseg` times and the step the entry points run.  Returns
+    (loss, logits), both on the device."""
+    opt.zero_grad()
+    preds = model(images, input_ids=input_ids) if input_ids is not None else model(images)
+    loss = criterion(preds, labels)
+    loss.backward()
+    opt.all_reduce()
+    opt.step(lr=lr)
+    UF.clear_t_copies()
+    return loss.detach(), preds.detach()
+
+
 class DevicePrefetcher:
     """Double-buffered loader: a background thread pulls (images, texts) batches from a DataLoader, tokenises, stages them in a ring of pinned host buffers
     and copies them to a ring of device buffers on a COPY stream; the consumer gets (images, ids, event) — the batch is complete behind `event`, which is
     what lets contrastive_micro start a frozen text tower without waiting for the previous update (its `ready` argument).  A device slot is reused only behind
     an event the consumer's stream records when it asks for the next batch (every stream that read the slot has been joined into it by then)."""
 
-    def __init__(self, loader, tokenizer, device, depth=2):
+    def __init__(self, loader, tokenizer, device, depth=2, second=None):
+        """second: batch -> the tensor that travels beside the images (default: the token ids — batch[2] when the loader's workers tokenised, else
+        tokenizer(batch[1]); the segmentation loaders pass the masks)."""
         import threading
-        self.loader, self.tokenizer, self.device, self.depth = loader, tokenizer, torch.device(device), max(1, depth)
+        self.loader, self.tokenizer, self.device, self.depth, self.second = loader, tokenizer, torch.device(device), max(1, depth), second
         self._threading = threading
         self.wait_s = 0.0
         self._slots = None
         self._copy = torch.cuda.Stream(device=self.device)
+        self._stop = threading.Event()
+        self._live = None                                       # (producer thread, its queue) of the iteration in flight
 
     def __len__(self):
         return len(self.loader)
@@ -585,32 +614,40 @@ class DevicePrefetcher:
                     images, ids = ring.images[slot], ring.ids[slot]
                 else:
                     images = batch[0]
-                    ids = batch[2] if len(batch) > 2 else self.tokenizer(list(batch[1]))      # a DataModule built with the tokenizer has tokenised in its workers
-                if self._slots is None or self._slots[0]["d_im"].shape != images.shape or self._slots[0]["d_id"].shape != ids.shape:
+                    if self.second is not None:
+                        ids = self.second(batch)
+                    else:
+                        ids = batch[2] if len(batch) > 2 else self.tokenizer(list(batch[1]))      # a DataModule built with the tokenizer has tokenised in its workers
+                n = images.shape[0]
+                fits = (self._slots is not None and self._slots[0]["d_im"].shape[1:] == images.shape[1:] and self._slots[0]["d_id"].shape[1:] == ids.shape[1:]
+                        and n <= self._slots[0]["d_im"].shape[0] and self._slots[0]["d_im"].dtype == images.dtype and self._slots[0]["d_id"].dtype == ids.dtype)
+                if not fits:
                     self._make_slots(images, ids, staging=not (slot is not None and ring_dma))
-                sl = self._slots[k % len(self._slots)]
+                full = self._slots[k % len(self._slots)]
                 k += 1
+                sl = full if n == full["d_im"].shape[0] else self._view(full, n)      # a ragged last batch (validation / test splits) is a view of a full slot
                 if slot is not None and ring_dma:
                     src_im, src_id = images, ids
                 else:
-                    if sl.get("h_im") is None:
-                        sl["h_im"], sl["h_id"] = torch.empty(images.shape, dtype=images.dtype, pin_memory=True), torch.empty(ids.shape, dtype=ids.dtype, pin_memory=True)
-                    if sl["copied"] is not None:
-                        sl["copied"].synchronize()              # the pinned staging buffers are free once their copy has run
-                    sl["h_im"].copy_(images)
-                    sl["h_id"].copy_(ids)
-                    src_im, src_id = sl["h_im"], sl["h_id"]
+                    if full.get("h_im") is None:
+                        full["h_im"] = torch.empty(full["d_im"].shape, dtype=images.dtype, pin_memory=True)
+                        full["h_id"] = torch.empty(full["d_id"].shape, dtype=ids.dtype, pin_memory=True)
+                    if full["copied"] is not None:
+                        full["copied"].synchronize()            # the pinned staging buffers are free once their copy has run
+                    full["h_im"][:n].copy_(images)
+                    full["h_id"][:n].copy_(ids)
+                    src_im, src_id = full["h_im"][:n], full["h_id"][:n]
                     if slot is not None:
                         ring.release(slot)
                         slot = None
                 with torch.cuda.stream(self._copy):
-                    if sl["free"] is not None:
-                        self._copy.wait_event(sl["free"])       # the consumer's last reader of this device slot
+                    if full["free"] is not None:
+                        self._copy.wait_event(full["free"])     # the consumer's last reader of this device slot
                     sl["d_im"].copy_(src_im, non_blocking=True)
                     sl["d_id"].copy_(src_id, non_blocking=True)
                     ev = torch.cuda.Event()
                     ev.record(self._copy)
-                sl["copied"] = ev
+                full["copied"] = ev
                 if slot is not None:
                     pending.append((ev, slot))
                 while pending and (pending[0][0].query() or len(pending) >= max(2, ring.slots - 2 * getattr(self.loader, "num_workers", 0) - 1)):
@@ -618,21 +655,55 @@ class DevicePrefetcher:
                     e.synchronize()
                     ring.release(sidx)
                 del batch, images, ids
-                q.put((sl, ev))
+                if not self._put(q, (sl, ev)):
+                    break                                       # close(): the consumer is gone
             for e, sidx in pending:
                 e.synchronize()
                 ring.release(sidx)
-            q.put(None)
+            self._put(q, None)
         except BaseException as e:                              # surfaces in the consumer
-            q.put(e)
+            self._put(q, e)
+
+    def _put(self, q, item):
+        """q.put that gives up once close() was called (the consumer no longer takes anything)."""
+        import queue
+        while not self._stop.is_set():
+            try:
+                q.put(item, timeout=0.2)
+                return True
+            except queue.Full:
+                continue
+        return False
+
+    @staticmethod
+    def _view(full, n):
+        return {"d_im": full["d_im"][:n], "d_id": full["d_id"][:n], "_of": full}
+
+    def close(self):
+        """Stops the producer of the iteration in flight (an epoch abandoned by early stopping): no new batch is requested from the loader, ring slots
+        already taken are handed back, the thread is joined.  Safe to call at any time, also twice."""
+        live, self._live = self._live, None
+        if live is None:
+            return
+        th, q = live
+        self._stop.set()
+        while th.is_alive():
+            try:
+                q.get(timeout=0.05)                             # frees the place a blocked put is waiting for
+            except Exception:
+                pass
+            th.join(timeout=0.05)
+        self._stop.clear()
 
     def __iter__(self):
         """Starts the producer NOW (not at the first next()): the first `depth` batches are loaded, staged and copied while the caller does something else."""
         import queue
         q = self._q = queue.Queue(maxsize=self.depth)
         first = self.loader.__dict__.pop("_uia_first_iter", None) if hasattr(self.loader, "__dict__") else None      # DataModule.start_workers() made it before the GPU was touched
+        self.close()                                            # an abandoned earlier iteration
         th = self._threading.Thread(target=self._producer, args=(first if first is not None else iter(self.loader), q), daemon=True)
         th.start()
+        self._live = (th, q)
         return self._consume(th, q)
 
     def _consume(self, th, q):
@@ -651,6 +722,8 @@ class DevicePrefetcher:
             if isinstance(item, BaseException):
                 raise item
             sl, ev = item
-            prev = sl
+            prev = sl.get("_of", sl)
             yield sl["d_im"], sl["d_id"], ev
         th.join()
+        if self._live is not None and self._live[0] is th:
+            self._live = None

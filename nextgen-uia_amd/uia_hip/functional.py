@@ -293,6 +293,21 @@ class linear_chain:
         _STATE["fwd3_next_plain"] = bool(flag)
 
 
+def hook_free(*modules):
+    """No forward / forward-pre / backward hook on any of the modules or their submodules, and no global module hook: nothing but the towers' own Functions
+    reads the tensors handed between them.  A three-byte forward token is a stride-0 NaN placeholder to everyone but its consumer (an activation
+    tap or Grad-CAM hook on a block would read NaNs; a hook that returns a new tensor would feed them into the next block)."""
+    import torch.nn.modules.module as _mm
+    if _mm._global_forward_hooks or _mm._global_forward_pre_hooks or _mm._global_backward_hooks or getattr(_mm, "_global_backward_pre_hooks", None) \
+            or getattr(_mm, "_global_forward_hooks_always_called", None):
+        return False
+    for mod in modules:
+        for m in mod.modules():
+            if m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or getattr(m, "_backward_pre_hooks", None):
+                return False
+    return True
+
+
 def _g3_partner_feeds(x):
     """True when x is the output of a MonaFn / VitBlockFn seen through view nodes only: the gradient this Function returns for x goes to that Function's backward."""
     if not grad_resid3_enabled() or _STATE.get("chain_depth", 0) <= 0:

@@ -542,12 +542,14 @@ def test_clipseg_adapter_vs_oracle(mode):
 
 
 def test_clipseg_entry_point_trains_and_saves_decoder_checkpoint(tmp_path, monkeypatch):
+    """(round 6: the entry point is the reference's loop now — epochs over a loader, validation, test(); tests/test_round6_gpu.py covers the rest.)"""
     from src.models.clipseg import segmentation
     monkeypatch.chdir(tmp_path)
-    out = segmentation.main(["--synthetic", "--iters", "12", "--batch_size", "8", "--img_size", "64", "--lr", "1e-3", "--dtype", "fp32", "--exp", "t"])
+    out = segmentation.main(["--dataset", "BUSI", "--synthetic", "--synthetic_train", "32", "--synthetic_val", "8", "--synthetic_test", "8", "--epochs", "3", "--batch_size", "8",
+                             "--img_size", "64", "--lr", "1e-3", "--dtype", "fp32", "--exp", "t", "--num_workers", "0"])
     ck = torch.load(tmp_path / "runs" / "t" / "BUSI" / "train" / "best_model.pth")
     assert set(ck) == {"decoder"} and "layers.0.self_attn.q_proj.weight" in ck["decoder"] and "transposed_convolution.4.bias" in ck["decoder"]
-    assert out["iters"] == 12 and math.isfinite(out["loss"])
+    assert out["train"]["iters"] == 12 and math.isfinite(out["test"]["loss"])
 
 
 # ------------------------------------------------------------------------------------------------ FPN task heads
@@ -657,10 +659,10 @@ def test_biomedclip_segmentation_entry_point(tmp_path, monkeypatch):
                    "--batch_size", "16", "--accumulation_steps", "1", "--epochs", "1", "--dtype", "bf16", "--exp", "ft", "--model_config", cfg])
     out = segmentation.main(["--synthetic", "--synthetic_train", "32", "--synthetic_val", "16", "--img_size", "32", "--patch_size", "8", "--batch_size", "8",
                              "--epochs", "3", "--val_every", "1", "--lr", "2e-3", "--reduce_dim", "64", "--extract_layers", "0,1,2", "--dtype", "bf16",
-                             "--mona_weights", str(tmp_path / "runs" / "ft" / "best_model.pth"), "--exp", "seg", "--model_config", cfg])
+                             "--mona_weights", str(tmp_path / "runs" / "ft" / "best_model.pth"), "--exp", "seg", "--model_config", cfg, "--num_workers", "0"])
     assert out["iters"] == 3 * 4 and math.isfinite(out["last_loss"]) and 0.0 <= out["best_val_dice"] <= 1.0
     saved = tmp_path / "runs" / "seg" / "LN-INT" / "train" / "best_model.pth"
-    assert saved.exists() == (out["best_val_dice"] > 0.0)                  # reference: saved only when the validation Dice improves on 0
+    assert saved.exists()        # reference: saved when the validation Dice improves on 0; round 6: otherwise the last iterate, so that the test pass main() always runs has a checkpoint
     args = segmentation.get_args(["--synthetic", "--img_size", "32", "--patch_size", "8", "--reduce_dim", "64", "--extract_layers", "0,1,2",
                                   "--mona_weights", str(tmp_path / "runs" / "ft" / "best_model.pth"), "--model_config", cfg])
     ck = segmentation.checkpoint_dict(segmentation.prepare_model(args))

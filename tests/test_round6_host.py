@@ -1,0 +1,251 @@
+"""Round 6, host side (no GPU): the CLIPSeg entry point's reference surface — flags, prompts as data, get_prompt — the segmentation data module and its
+shared-memory ring, the metric accumulator, the /dev/shm planning of the loaders, and the oracle's BPE restatement where the reference's merges file is there."""
+import ast
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+
+
+# ------------------------------------------------------------------------------------------------ the CLI is part of the drop-in contract
+CLIPSEG_FLAGS = dict(exp="clipseg", dataset="LN-INT", img_size=224, patch_size=16, num_workers=8, strong_augs=True, weak_augs=True, version="ViT-B/16",
+                     ckpt="ckpt/ViT-B-16.pt", in_channels=3, num_classes=2, reduce_dim=512, seed=1, epochs=1000, batch_size=32, lr=1e-4, lr_min=1e-8,
+                     weight_decay=0.01, beta1=0.9, beta2=0.95, patience=15, test=False)
+BIOMED_SEG_FLAGS = dict(exp="biomedclip_seg", dataset="LN-INT", img_size=224, patch_size=16, num_workers=8, strong_augs=True, weak_augs=True, mona_variant="hybrid",
+                        mona_weights=None, in_channels=3, num_classes=2, reduce_dim=512, mona_bottleneck=64, mona_layers=None, lora_weights=None, lora_r=16,
+                        lora_alpha=32, seed=1, epochs=200, batch_size=32, lr=1e-4, lr_min=1e-8, weight_decay=0.01, beta1=0.9, beta2=0.95, patience=15, test=False)
+
+
+def test_clipseg_cli_matches_the_reference_flags_and_defaults():
+    """reference src/models/clipseg/segmentation.py:28-66 (VERDICT r05 missing #1: nine flags were absent, four defaults differed)."""
+    from src.models.clipseg import segmentation as S
+    a = S.get_args([])
+    for k, v in CLIPSEG_FLAGS.items():
+        assert getattr(a, k) == v, k
+    b = S.get_args(["--no-strong_augs", "--no-weak_augs", "--test", "--beta2", "0.999", "--version", "ViT-L/14"])
+    assert b.strong_augs is False and b.weak_augs is False and b.test is True and b.beta2 == 0.999 and b.version == "ViT-L/14"
+
+
+def test_biomedclip_segmentation_cli_matches_the_reference_flags_and_defaults():
+    from src.models.biomedclip import segmentation as S
+    a = S.get_args([])
+    for k, v in BIOMED_SEG_FLAGS.items():
+        assert getattr(a, k) == v, k
+
+
+def _argparse_table(path):
+    out = {}
+    for node in ast.walk(ast.parse(open(path).read())):
+        if isinstance(node, ast.Call) and isinstance(node.func, ast.Attribute) and node.func.attr == "add_argument" and node.args and isinstance(node.args[0], ast.Constant):
+            out[node.args[0].value] = {k.arg: ast.unparse(k.value) for k in node.keywords if k.arg in ("default", "action", "choices")}
+    return out
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="the reference tree exists in the build container only")
+@pytest.mark.parametrize("entry", ["biomedclip/finetune.py", "biomedclip/segmentation.py", "biomedclip/zero_shot.py", "clipseg/segmentation.py", "metaclip/finetune.py",
+                                   "clip/finetune.py"])
+def test_every_reference_flag_of_every_entry_point_is_there_with_its_default(entry):
+    """The argparse tables of reference and build compared syntactically (flag set, default / action / choices expressions); `--device` is the one deliberate
+    difference (decided without a HIP call, src/utils/tools.default_device)."""
+    ref = _argparse_table(os.path.join(REF, "src/models", entry))
+    got = _argparse_table(os.path.join(ROOT, "nextgen-uia_amd/src/models", entry))
+    assert ref, entry
+    for flag, kw in ref.items():
+        assert flag in got, (entry, flag)
+        if flag != "--device":
+            assert got[flag] == kw, (entry, flag, kw, got[flag])
+
+
+# ------------------------------------------------------------------------------------------------ prompts
+def test_prompts_are_the_reference_token_ids_as_data():
+    """SURVEY §8c printed the BUSI prompt from the imported reference: 68 tokens, [49406, 1465, 2326, 9475, 534, ..., 2498, 46092, 269, 49407]."""
+    from src.models.clipseg import prompt as P
+    b = P.busi_prompt
+    assert tuple(b.shape) == (1, 77) and b.dtype == torch.int32
+    ids = b[0].tolist()
+    assert ids[:5] == [49406, 1465, 2326, 9475, 534] and ids[64:68] == [2498, 46092, 269, 49407] and not any(ids[68:])
+    assert int(b[0].argmax()) == 67                              # EOT is the largest id: the pooling position (model.py:372)
+    for t, n in ((P.ln_prompt, 50), (P.thyroid_prompt, 61), (P.prostate_prompt, 50)):
+        row = t[0].tolist()
+        assert tuple(t.shape) == (1, 77) and row[0] == 49406 and row[n - 1] == 49407 and not any(row[n:]) and all(0 < v < 49406 for v in row[1:n - 1])
+    assert len({tuple(t[0].tolist()) for t in (P.ln_prompt, P.busi_prompt, P.thyroid_prompt, P.prostate_prompt)}) == 4
+
+
+def test_get_prompt_follows_the_reference_table():
+    from src.models.clipseg import prompt as P
+    from src.models.clipseg import segmentation as S
+    table = {"LN-INT": P.ln_prompt, "LN-EXT": P.ln_prompt, "BUSI": P.busi_prompt, "DDTI": P.thyroid_prompt, "TN3K": P.thyroid_prompt, "Prostate": P.prostate_prompt}
+    for name, want in table.items():
+        assert S.get_prompt(S.get_args(["--dataset", name])) is want
+    assert S.get_prompt(S.get_args(["--dataset", "nothing"])) is None          # reference :69-82 returns None for anything else
+    # the same prompt in every process and on every rank: no salted hash() anywhere on the path
+    src = open(os.path.join(ROOT, "nextgen-uia_amd/src/models/clipseg/segmentation.py")).read()
+    assert "hash(" not in src and "synthetic_prompt" not in src
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="the merges file is the reference's data and never leaves the build container")
+def test_bpe_restatement_reproduces_the_committed_ids():
+    from oracle.bpe_ref import BPE, EOT, SOT
+    from oracle.gen_prompt_ids import prompt_strings
+    bpe = BPE(os.path.join(REF, "src/third_party/openai_clip/bpe_simple_vocab_16e6.txt.gz"))
+    data = json.load(open(os.path.join(ROOT, "nextgen-uia_amd/src/models/clipseg/prompt_ids.json")))
+    for name, text in prompt_strings().items():
+        assert bpe.tokenize(text) == data["prompts"][name]["ids"], name
+    assert bpe.tokenize("a photo of a cat") == [SOT, 320, 1125, 539, 320, 2368, EOT] + [0] * 70         # the well-known CLIP example
+    with pytest.raises(RuntimeError):
+        bpe.tokenize("breast lesion " * 60)                       # clip.py:249-254: too long for the context, truncate=False
+    with pytest.raises(ValueError):
+        bpe.encode("café &amp; co")                         # outside what the restatement covers (ftfy / html entities)
+
+
+# ------------------------------------------------------------------------------------------------ data module + ring
+def _seg_args(**kw):
+    from src.models.clipseg import segmentation as S
+    a = S.get_args(["--synthetic", "--dataset", "BUSI"])
+    for k, v in kw.items():
+        setattr(a, k, v)
+    return a
+
+
+def test_segmentation_datamodule_batch_contract_and_splits():
+    """reference src/datasets/segmentation.py:223-251: train shuffled with drop_last, validation / test in order and whole; one grayscale channel + a binary mask."""
+    from src.datasets import segmentation as D
+    a = _seg_args(batch_size=8, img_size=32, synthetic_train=37, synthetic_val=11, synthetic_test=9, num_workers=0)
+    dm = D.DataModule(a, rank=0, world=1)
+    tr, va, te = dm.train_dataloader(), dm.val_dataloader(), dm.test_dataloader()
+    assert len(tr) == 4 and len(va) == 2 and len(te) == 2
+    im, lab, names = next(iter(tr))
+    assert tuple(im.shape) == (8, 1, 32, 32) and im.dtype == torch.float32 and 0 <= float(im.min()) and float(im.max()) < 1
+    assert tuple(lab.shape) == (8, 1, 32, 32) and lab.dtype == torch.uint8 and set(lab.unique().tolist()) <= {0, 1} and len(names) == 8
+    sizes = [b[0].shape[0] for b in va]
+    assert sizes == [8, 3]
+    x, y = D.as_model_input(im, lab, 3)
+    assert tuple(x.shape) == (8, 3, 32, 32) and x.is_contiguous() and torch.equal(x[:, 0], x[:, 2]) and y.dtype == torch.float32
+    names_te = [n for b in te for n in b[2]]
+    assert names_te == [f"test_{i:05d}.png" for i in range(9)]
+    # two ranks: disjoint train shards of equal length, the evaluation splits whole on both
+    d0, d1 = D.DataModule(a, rank=0, world=2), D.DataModule(a, rank=1, world=2)
+    l0, l1 = d0.train_dataloader(), d1.train_dataloader()
+    n0, n1 = [n for b in l0 for n in b[2]], [n for b in l1 for n in b[2]]
+    assert len(n0) == len(n1) == 16 and not set(n0) & set(n1)
+    assert len(d0.val_dataloader()) == len(d1.val_dataloader()) == 2
+
+
+def test_segmentation_ring_with_worker_processes_delivers_every_sample_once():
+    from src.datasets import segmentation as D
+    a = _seg_args(batch_size=4, img_size=16, synthetic_train=16, synthetic_val=10, synthetic_test=4, num_workers=2)
+    dm = D.DataModule(a, rank=0, world=1)
+    va = dm.val_dataloader()
+    ring = va.collate_fn
+    assert isinstance(ring, D.SegBatchRing) and ring.images.shape[1:] == (4, 1, 16, 16) and ring.ids.dtype == torch.uint8
+    try:
+        seen = {}
+        for batch in va:
+            if isinstance(batch[0], str) and batch[0] == ring.MARK:
+                _, slot, names = batch
+                im, lab = ring.images[slot].clone(), ring.ids[slot].clone()
+                ring.release(slot)
+            else:
+                im, lab, names = batch
+            for j, n in enumerate(names):
+                seen[n] = (im[j], lab[j])
+        assert len(seen) == 10
+        for i in range(10):
+            img, lab, name = dm.val_dataset[i]
+            assert torch.equal(seen[name][0], img) and torch.equal(seen[name][1], lab)
+    finally:
+        dm.shutdown()
+
+
+def test_loader_workers_are_cut_to_what_dev_shm_really_holds(monkeypatch):
+    """the ring allocates ring_slots(nw) batch-sized slots; the check must be made on that figure, summed over a DataModule's loaders."""
+    import shutil
+    from collections import namedtuple
+    from src.datasets import finetune as F
+    U = namedtuple("U", "total used free")
+    per = 100 << 20
+
+    class Owner:
+        pass
+    monkeypatch.setattr(shutil, "disk_usage", lambda p: U(0, 0, 2 * 20 * per))                        # half of it: room for 20 slots
+    o = Owner()
+    assert F.plan_workers(6, per, o) == (6, 16)                                                          # 2*6+4 = 16 slots fit
+    assert F.plan_workers(2, per, o) == (0, 0)                                                           # 4 slots are left; the smallest ring needs 6
+    o2 = Owner()
+    assert F.plan_workers(6, 2 * per, o2) == (3, 10)                                                     # 10 slots of 200 MB = the 2 000 MB that are there
+    monkeypatch.setattr(shutil, "disk_usage", lambda p: U(0, 0, 0))
+    assert F.plan_workers(4, per, Owner()) == (0, 0)
+    assert F.plan_workers(0, per, Owner()) == (0, 0)
+
+
+# ------------------------------------------------------------------------------------------------ metrics
+def test_metric_accumulator_reproduces_the_reference_statistics():
+    """reference src/utils/tools.py:146-206: per-image Dice / IoU of the arg-max mask (NaN where the ground truth is empty, dropped by np.isfinite), population std,
+    the loss as the mean of the per-BATCH criterion values."""
+    from src.utils.tools import MetricAccumulator
+    g = torch.Generator().manual_seed(3)
+    crit = lambda p, y: (p[:, 1] - y[:, 0]).abs().mean()
+    acc = MetricAccumulator(type="seg", criterion=crit, num_classes=2)
+    dice, iou, losses = [], [], []
+    for n in (5, 3):
+        preds = torch.randn(n, 2, 12, 12, generator=g)
+        labels = (torch.rand(n, 1, 12, 12, generator=g) > 0.6).float()
+        labels[0] = 0                                             # an empty ground truth per batch
+        acc.update(preds, labels)
+        losses.append(float(crit(preds, labels)))
+        for i in range(n):
+            p, y = preds[i].argmax(0) == 1, labels[i, 0] > 0
+            inter = float((p & y).sum())
+            dice.append(2 * inter / float(p.sum() + y.sum()) if y.any() else float("nan"))
+            iou.append(inter / float((p | y).sum()) if y.any() else float("nan"))
+    s = acc.compute()
+    d, j = np.array(dice), np.array(iou)
+    assert s["dice_mean"] == pytest.approx(np.mean(d[np.isfinite(d)]), rel=1e-12) and s["dice_std"] == pytest.approx(np.std(d[np.isfinite(d)]), rel=1e-12)
+    assert s["iou_mean"] == pytest.approx(np.mean(j[np.isfinite(j)]), rel=1e-12) and s["iou_std"] == pytest.approx(np.std(j[np.isfinite(j)]), rel=1e-12)
+    assert s["loss"] == pytest.approx(np.mean(losses), rel=1e-6)
+    assert all(math.isnan(s[k]) for k in ("hd95_mean", "hd95_std", "asd_mean", "asd_std"))
+    acc.reset()
+    assert math.isnan(acc.compute()["dice_mean"])
+    with pytest.raises(NotImplementedError):
+        MetricAccumulator(type="cls")
+
+
+def test_report_test_writes_the_reference_run_directory(tmp_path):
+    import logging
+    from types import SimpleNamespace
+    from src.utils.tools import fresh_viz_dir, report_test, setup_logging
+    args = SimpleNamespace(test_snapshot_path=str(tmp_path / "test"))
+    os.makedirs(args.test_snapshot_path)
+    setup_logging(args, args.test_snapshot_path)
+    best = tmp_path / "best_model.pth"
+    best.write_bytes(b"x")
+    fresh_viz_dir(args)
+    stats = dict(dice_mean=0.81234, dice_std=0.1, iou_mean=0.7, iou_std=0.05, hd95_mean=float("nan"), hd95_std=float("nan"), asd_mean=float("nan"), asd_std=float("nan"))
+    csv = report_test(args, stats, str(best))
+    for h in list(logging.getLogger().handlers):
+        logging.getLogger().removeHandler(h)
+    folder = os.path.dirname(csv)
+    assert os.path.basename(folder).endswith("_iou=70.00") and sorted(os.listdir(folder)) == ["best_model.pth", "log.log", "results.csv", "viz"]
+    assert open(csv).read().splitlines() == ["Metric,Mean,Std", "Dice,81.23,10.00", "IoU,70.00,5.00", "HD95,,", "ASD,,"]
+    assert not os.path.exists(os.path.join(args.test_snapshot_path, "log.log"))
+
+
+def test_default_device_makes_no_hip_call(monkeypatch):
+    from src.utils import tools
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: (_ for _ in ()).throw(AssertionError("HIP call")))
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: (_ for _ in ()).throw(AssertionError("HIP call")))
+    monkeypatch.setattr(os.path, "exists", lambda p: p == "/dev/kfd")
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES", raising=False)
+    monkeypatch.delenv("CUDA_VISIBLE_DEVICES", raising=False)
+    assert tools.default_device() == "cuda:0"
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
+    assert tools.default_device() == "cpu"
+    monkeypatch.setattr(os.path, "exists", lambda p: False)
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    assert tools.default_device() == "cpu"

@@ -1,0 +1,133 @@
+"""Does the loop LEARN at full geometry?  (the 1 200-update soak ends at ln 256 because random pairs carry no signal — a sign error in
+the update would look the same.)
+
+Learnable synthetic pairs: class c of a batch of B has an image whose c-th cell of an 8 x 8 grid is brighter than the noise around it, and a caption whose
+token ids are a function of c — the caption is a function of an image statistic (the arg-max cell).  Fresh noise every update, every class once per batch.
+ViT-B/16 + 12 Mona (freq_enhanced, the reference's initialisation) + BERT-base, random backbone, InfoNCE at tau 0.07, the reference's update (clip 1.0, AdamW
+0.9 / 0.95, wd 0.01), dropout off.
+
+  run_hip(B, updates, lr)      engine.contrastive_step, bf16 -> loss per update, the adapter's displacement p_T - p_0
+  run_oracle(B, updates, lr)   oracle/train_ref.py on the host cores (B = 8: ~2 s per update) -> the same
+
+tests/test_round6_gpu.py asserts: HIP at B = 64 descends below 0.7 x its first loss in 30 updates; HIP and oracle at B = 8 on the SAME data descend together
+(loss curves close, displacement vectors aligned).
+
+    python tools/descent_check.py [--batch 64] [--updates 30] [--lr 1e-3]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "nextgen-uia_amd")]
+import torch
+
+
+def batch_of(B, step, seed=7):
+    """(images [B, 3, 224, 224] fp32 in [0, 1], ids [B, 256] int64): row r holds class perm[r]."""
+    g = torch.Generator().manual_seed(seed * 100003 + step)
+    perm = torch.randperm(B, generator=g)
+    img = 0.5 * torch.rand(B, 1, 224, 224, generator=g)
+    ids = torch.zeros(B, 256, dtype=torch.long)
+    for r, c in enumerate(perm.tolist()):
+        y, x = (c // 8) * 28, (c % 8) * 28
+        img[r, 0, y:y + 28, x:x + 28] += 0.5
+        n = 12 + c % 5
+        ids[r, 0], ids[r, n - 1] = 2, 3
+        ids[r, 1:n - 1] = 1000 + (97 * c + 13 * torch.arange(n - 2)) % 28000
+    return img.repeat(1, 3, 1, 1).contiguous(), ids
+
+
+def build(seed=3):
+    from src.adapters import inject_mona_variant_to_open_clip
+    from src.third_party.biomedclip.model import create_biomedclip
+    model = create_biomedclip(seed=seed)
+    for p in model.parameters():
+        p.requires_grad_(False)
+    inject_mona_variant_to_open_clip(model, variant="freq_enhanced", bottleneck_dim=64)
+    for k, p in model.named_parameters():
+        p.requires_grad_("mona" in k)
+    return model.eval()
+
+
+def run_hip(B=64, updates=30, lr=1e-3, state=None):
+    from uia_hip import functional as UF
+    from uia_hip.engine import FlatAdapterOptimizer, contrastive_step
+    from src.losses import InfoNCELoss
+    UF.set_compute_dtype(torch.bfloat16)
+    dev = torch.device("cuda", 0)
+    model = build()
+    if state is not None:
+        model.load_state_dict(state)
+    model = model.to(dev)
+    named = [(k, p) for k, p in model.named_parameters() if p.requires_grad]
+    opt = FlatAdapterOptimizer(named, lr=lr, betas=(0.9, 0.95), weight_decay=0.01, max_norm=1.0)
+    p0 = opt.p.clone()
+    crit = InfoNCELoss(0.07)
+    losses = []
+    for t in range(updates):
+        im, ids = batch_of(B, t)
+        losses.append(contrastive_step(model, crit, opt, im.to(dev), ids.to(dev), lr=lr))
+    losses = [float(l) for l in losses]
+    g = opt.read_guard()
+    assert g["updates"] == updates and g["skipped"] == 0, g
+    return {"losses": losses, "delta": opt.unflatten((opt.p - p0).detach().cpu()), "names": opt.names}
+
+
+def run_oracle(B=8, updates=30, lr=1e-3, state=None, threads=None):
+    from oracle import train_ref
+    torch.set_num_threads(threads or max(1, min(32, os.cpu_count() or 1)))
+    model = build()
+    if state is not None:
+        model.load_state_dict(state)
+    P = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    trainable = [k for k, p in model.named_parameters() if p.requires_grad]
+    p0 = {k: P[k].clone() for k in trainable}
+    m, v = {k: torch.zeros_like(P[k]) for k in trainable}, {k: torch.zeros_like(P[k]) for k in trainable}
+    mona = dict(variant="freq_enhanced", hw=(14, 14))
+    losses = []
+    for t in range(updates):
+        im, ids = batch_of(B, t)
+        grads, loss = train_ref.grads_of(lambda Pq, a, b: train_ref.biomedclip_loss(Pq, a, b, mona=mona), P, trainable, [(im, ids)])
+        params = {k: P[k] for k in trainable}
+        train_ref.clip_and_adamw(params, grads, m, v, t + 1, lr, (0.9, 0.95), 1e-8, 0.01, 1.0)
+        losses.append(loss)
+    return {"losses": losses, "delta": {k: P[k] - p0[k] for k in trainable}, "names": trainable}
+
+
+def alignment(a, b):
+    """cosine and length ratio of two displacement dicts (keys of a)."""
+    x = torch.cat([a["delta"][k].flatten().float() for k in a["names"]])
+    y = torch.cat([b["delta"][k].flatten().float() for k in a["names"]])
+    return float(torch.dot(x, y) / (x.norm() * y.norm())), float(x.norm() / y.norm())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--updates", type=int, default=30)
+    ap.add_argument("--lr", type=float, default=1e-3)
+    ap.add_argument("--oracle-batch", type=int, default=8)
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "descent_check.json"))
+    args = ap.parse_args()
+    res = {"lr": args.lr, "updates": args.updates}
+    t0 = time.perf_counter()
+    big = run_hip(args.batch, args.updates, args.lr)
+    res[f"hip_B{args.batch}"] = {"losses": [round(l, 4) for l in big["losses"]], "ratio": big["losses"][-1] / big["losses"][0], "seconds": round(time.perf_counter() - t0, 1)}
+    print(json.dumps(res), flush=True)
+    if args.oracle_batch:
+        small = run_hip(args.oracle_batch, args.updates, args.lr)
+        t0 = time.perf_counter()
+        ref = run_oracle(args.oracle_batch, args.updates, args.lr)
+        cos, ratio = alignment(small, ref)
+        res[f"B{args.oracle_batch}"] = {"hip_losses": [round(l, 4) for l in small["losses"]], "oracle_losses": [round(l, 4) for l in ref["losses"]],
+                                        "displacement_cosine": cos, "displacement_norm_ratio": ratio, "oracle_seconds": round(time.perf_counter() - t0, 1)}
+    print(json.dumps(res), flush=True)
+    os.makedirs(os.path.dirname(args.out), exist_ok=True)
+    json.dump(res, open(args.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -2,7 +2,7 @@
 inject_lora_to_clip(r = 16, alpha = 32) on q, k, v, o of every block, bf16 mode, B = 32 (8 224 token rows: the 256-row ring tiles with their split-K M tail, the N = 64 and
 K = 64 stream kernels, the one-node attention half) against oracle/vit_ref.py on the host cores: features, the whole LoRA gradient (cosine, relative L2, median and worst
 per-tensor error).  Dropout off (the oracle takes no mask at model level; the kernels' masks are pinned by tests/test_round2_gpu.py and tests/test_round3_gpu.py).
-Run once on the GPU box; not part of `pytest -m gpu`.
+`run_case()` is what tests/test_round6_gpu.py calls inside `pytest -m gpu` (round 6: full-batch parity of the secondary configurations is driver-visible).
 
     python tools/parity_vitl_lora_batch.py [--batch 32] [--out gpurun_out/parity_vitl_lora_batch.json]
 """
@@ -23,16 +23,11 @@ def rel(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-12))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--batch", type=int, default=32)
-    ap.add_argument("--chunk", type=int, default=8)
-    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "parity_vitl_lora_batch.json"))
-    args = ap.parse_args()
+def run_case(batch=32, chunk=8, threads=None):
     from uia_hip import functional as UF
     from src.adapters import inject_lora_to_clip
     from src.third_party.openai_clip.model import CLIP
-    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    torch.set_num_threads(threads or max(1, min(32, os.cpu_count() or 1)))
     UF.set_compute_dtype(torch.bfloat16)
     g = torch.Generator().manual_seed(59)
     torch.manual_seed(59)
@@ -55,7 +50,7 @@ def main():
     for k, p in model.named_parameters():
         p.requires_grad_("lora" in k)
     model.eval()
-    B = args.batch
+    B = batch
     images = torch.rand(B, 3, 224, 224, generator=g)
     dfeat = torch.randn(B, 768, generator=g)                                  # a fixed cotangent: the loss is <features, dfeat>, summed over chunks exactly
     P = {k: v.detach().clone() for k, v in model.state_dict().items()}
@@ -65,9 +60,9 @@ def main():
     Pq.update(leaves)
     t0 = time.perf_counter()
     feats = []
-    for i in range(0, B, args.chunk):
-        f = vit_ref.openai_vit_forward(images[i:i + args.chunk], Pq, heads=16, lora=dict(r=16, alpha=32))
-        (f * dfeat[i:i + args.chunk]).sum().backward()
+    for i in range(0, B, chunk):
+        f = vit_ref.openai_vit_forward(images[i:i + chunk], Pq, heads=16, lora=dict(r=16, alpha=32))
+        (f * dfeat[i:i + chunk]).sum().backward()
         feats.append(f.detach())
     fr = torch.cat(feats)
     cpu_s = time.perf_counter() - t0
@@ -88,6 +83,17 @@ def main():
            "tensors_compared": len(per), "oracle_cpu_seconds": round(cpu_s, 1),
            "worst_six": [{"tensor": k, "rel": round(per[k], 4), "own_max_over_global_max": round(float(leaves[k].grad.abs().max()) / gmax, 5)}
                          for k in sorted(per, key=per.get, reverse=True)[:6]]}
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--chunk", type=int, default=8)
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "parity_vitl_lora_batch.json"))
+    args = ap.parse_args()
+    res = run_case(args.batch, args.chunk)
+    B = args.batch
     print(json.dumps(res), flush=True)
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     json.dump({f"clip_vit_l14_lora_r16_bf16_B{B}": res}, open(args.out, "w"), indent=1, sort_keys=True)
