@@ -120,6 +120,19 @@ class SharedBatchRing:
             self.pinned = ok
         return self.pinned
 
+    def unpin(self):
+        """hipHostUnregister the ring (DataModule.shutdown): a registration outlives the mapping it names — once the ring's shared memory is unmapped, later host
+        allocations land in the same address range, still 'registered', and the first host-to-device copy from them fails with hipErrorInvalidValue (round 6: the
+        CLIPSeg entry point builds a second model for test() in the process that trained)."""
+        if self.pinned:
+            try:
+                torch.cuda.synchronize()                           # every copy that reads a slot has run
+                for t in (self.images, self.ids):
+                    torch.cuda.cudart().cudaHostUnregister(t.data_ptr())
+            except (AttributeError, RuntimeError):
+                pass
+        self.pinned = None
+
     def release(self, slot):
         self.free.put(slot)
 
@@ -223,6 +236,8 @@ class DataModule:
 
     def shutdown(self):
         for loader in getattr(self, "_loaders", []):
+            if hasattr(getattr(loader, "collate_fn", None), "unpin"):
+                loader.collate_fn.unpin()
             it = getattr(loader, "_iterator", None)
             if it is not None and hasattr(it, "_shutdown_workers"):
                 it._shutdown_workers()

@@ -17,14 +17,14 @@ from src.datasets.finetune import RankShardSampler, SharedBatchRing, plan_worker
 
 
 def synthetic_sample(size, seed):
-    """One (image [1, S, S] float32, label [1, S, S] uint8) pair."""
+    """One (image [1, S, S] float32, label [1, S, S] uint8) pair: U[0,1) noise and an axis-aligned ellipse."""
     g = torch.Generator().manual_seed(seed)
     img = torch.rand(1, size, size, generator=g)
     c = torch.rand(2, generator=g) * size * 0.5 + size * 0.25
     r = torch.rand(2, generator=g) * size * 0.2 + size * 0.08
-    yy = torch.arange(size, dtype=torch.float32)[:, None]
-    xx = torch.arange(size, dtype=torch.float32)[None, :]
-    mask = ((yy - c[0]) / r[0]) ** 2 + ((xx - c[1]) / r[1]) ** 2 <= 1
+    yy = torch.arange(size, dtype=torch.float32)
+    half = r[1] * torch.sqrt(torch.clamp(1 - ((yy - c[0]) / r[0]) ** 2, min=0))      # half-width of the ellipse on every row
+    mask = ((yy[None, :] - c[1]).abs() <= half[:, None]) & ((yy - c[0]).abs() <= r[0])[:, None]
     return img, mask[None].to(torch.uint8)
 
 
@@ -47,15 +47,38 @@ def as_model_input(images, labels, in_channels=3):
 
 
 class SyntheticSegmentation(Dataset):
-    def __init__(self, n, img_size, seed, prefix):
+    """n deterministic samples.  A sample costs ~0.4 ms of host time to generate (the noise draw above all) — 50 ms per 128-image batch per worker, more than the
+    GPU step — so the dataset keeps what it generated in SHARED memory allocated before the workers fork (the usual in-RAM cache of a small medical dataset: BUSI has
+    780 images): after the first epoch a sample is two views.  `cache_bytes` bounds it (default 4 GiB and a quarter of what /dev/shm has free); beyond it samples
+    are generated on every access."""
+
+    def __init__(self, n, img_size, seed, prefix, cache_bytes=4 << 30):
         self.n, self.img_size, self.seed, self.prefix = n, img_size, seed, prefix
+        self._img = self._lab = self._have = None
+        need = n * img_size * img_size * 5
+        try:
+            import shutil
+            room = shutil.disk_usage("/dev/shm").free // 4
+        except OSError:
+            room = 0
+        if 0 < need <= min(cache_bytes, room):
+            self._img = torch.empty(n, 1, img_size, img_size).share_memory_()          # pages are committed when a worker first writes them
+            self._lab = torch.empty(n, 1, img_size, img_size, dtype=torch.uint8).share_memory_()
+            self._have = torch.zeros(n, dtype=torch.bool).share_memory_()
 
     def __len__(self):
         return self.n
 
     def __getitem__(self, i):
+        name = f"{self.prefix}_{i:05d}.png"
+        if self._have is not None and bool(self._have[i]):
+            return self._img[i], self._lab[i], name
         img, lab = synthetic_sample(self.img_size, self.seed * 1000003 + i)
-        return img, lab, f"{self.prefix}_{i:05d}.png"
+        if self._have is not None:
+            self._img[i].copy_(img)
+            self._lab[i].copy_(lab)
+            self._have[i] = True                                   # set after the data: a reader that sees the flag sees the sample (one writer per index at a time is
+        return img, lab, name                                      # not guaranteed, but every writer writes the same bytes)
 
 
 class TensorSegmentation(Dataset):
@@ -167,6 +190,8 @@ class DataModule:
 
     def shutdown(self):
         for loader in self._loaders:
+            if hasattr(loader.collate_fn, "unpin"):
+                loader.collate_fn.unpin()                       # the ring's host registration must not outlive its mapping
             it = getattr(loader, "_iterator", None)
             if it is not None and hasattr(it, "_shutdown_workers"):
                 it._shutdown_workers()

@@ -197,11 +197,22 @@ def train(args):
     cur = torch.cuda.current_stream()
     dm.set_epoch(0)
     batches = iter(train_pf)
+    ab = os.environ.get("UIA_SEG_AB", "")                     # measurement knobs (tools/ab_clipseg_entry.sh); none is set in normal use
+    if "nogc" in ab:
+        import gc
+        gc.disable()
+    if "switch" in ab:
+        sys.setswitchinterval(0.05)
     for epoch in range(max_epoch):
         torch.cuda.synchronize()
-        t0, w0 = time.perf_counter(), train_pf.wait_s
+        t0, w0, enq = time.perf_counter(), train_pf.wait_s, 0.0
         n_it = 0
+        if "resident" in ab and epoch > 0:                      # the same device batch every iteration, the prefetcher idle: the loop's floor
+            first = first if epoch > 1 else next(batches)
+            train_pf.close()
+            batches = (first for _ in range(len(trainloader)))
         for images, labels, ready in batches:
+            t1 = time.perf_counter()
             cur.wait_event(ready)
             images, labels = as_model_input(images, labels, args.in_channels)
             # scheduler.step() follows optimizer.step() (:147-148): iteration i runs at the closed form's value for i
@@ -211,10 +222,13 @@ def train(args):
                 logged.append((iter_num, loss, cosine_lr(args.lr, args.lr_min, iter_num + 1, max_iters)))
             iter_num += 1
             n_it += 1
+            enq += time.perf_counter() - t1
+        t2 = time.perf_counter()
         torch.cuda.synchronize()
-        epoch_ms.append({"ms": (time.perf_counter() - t0) * 1e3, "updates": n_it, "loader_wait_ms": (train_pf.wait_s - w0) * 1e3})
+        epoch_ms.append({"ms": (time.perf_counter() - t0) * 1e3, "updates": n_it, "loader_wait_ms": (train_pf.wait_s - w0) * 1e3, "enqueue_ms": enq * 1e3,
+                         "drain_ms": (time.perf_counter() - t2) * 1e3})
         validate = (epoch > 0 and epoch % args.val_every == 0) or (epoch == max_epoch - 1)
-        if epoch + 1 < max_epoch:                                # the next epoch's first batches load while this one validates
+        if epoch + 1 < max_epoch and "resident" not in ab:       # the next epoch's first batches load while this one validates
             dm.set_epoch(epoch + 1)
             batches = iter(train_pf)
         if not validate:
