@@ -607,7 +607,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const UiaGemmParams& p, f32x4 
                         outv[hf] = r;
                     }
 #ifdef UIA_EPI_DIRECT
-                    // experiment build (tools/scratch/ab_direct.sh): the rounded values go to memory from the MFMA layout (a lane holds 16 consecutive columns of one row: two
+                    // experiment build (tools/attic/ab_direct.sh): the rounded values go to memory from the MFMA layout (a lane holds 16 consecutive columns of one row: two
                     // 16-byte stores), no bounce.  Measured SLOWER, round 5: 65 536 x 2304 x 768 1052 -> 998 TF/s on cfg 8, 1083 -> 1029 on cfg 27, the step 40.1 -> 40.5-40.7 ms
                     // (profiles/r05_f_quadv_ablation.txt): a store instruction of sixteen rows x four 16-byte pieces costs the CU's store path more than the bounce's LDS time.
                     {

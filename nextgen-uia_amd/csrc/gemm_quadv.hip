@@ -476,7 +476,7 @@ int uia_gemm_quadv_launch(hipStream_t stream, const UiaGemmParams& p, bool speci
         if (a_bytes >= ((size_t)1 << 32) || w_bytes >= ((size_t)1 << 32)) { uia_set_error("uia_gemm: tile cfg 27 addresses its operands through 32-bit buffer offsets (A %zu bytes, W %zu bytes)", a_bytes, w_bytes); return -1; }
     }
 #ifdef UIA_QUADV_ABLATIONS
-    // diagnostic build only (tools/scratch/quadv_ablate.sh builds a second library with -DUIA_QUADV_ABLATIONS): timing ablations of the K loop, selected by an
+    // diagnostic build only (tools/attic/quadv_ablate.sh builds a second library with -DUIA_QUADV_ABLATIONS): timing ablations of the K loop, selected by an
     // environment variable; the results are WRONG by construction, so the shipped library does not contain them
     static const int abl = [] { const char* e = getenv("UIA_QUADV_ABLATE"); return e ? atoi(e) : 0; }();
     if (abl) {                                             // timing ablations of the K loop (results are WRONG): tools/gemm_square_yardstick.py

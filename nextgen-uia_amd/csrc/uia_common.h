@@ -238,7 +238,7 @@ __device__ __forceinline__ float uia_dpp_row_mirror(float v) { return __builtin_
 // rows_*: all-reduce over the four rows of 16 lanes (lanes li, li + 16, li + 32, li + 48): the other row of the pair, then the other pair.
 // v_permlane16_swap a, b: rows 1 and 3 of a change places with rows 0 and 2 of b; v_permlane32_swap: the upper half of a with the lower half of b — with
 // a = b = v the two registers then hold the two partners of every lane.  Inline asm: the builtin of this hipcc (7.2) returns the first register for BOTH
-// results (tools/scratch/dpp_test.hip shows it); the s_nop pairs are the wait states the hazard pass would have placed around a VALU lane permute.
+// results (tools/attic/dpp_test.hip shows it); the s_nop pairs are the wait states the hazard pass would have placed around a VALU lane permute.
 __device__ __forceinline__ void uia_swap16(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b)); }
 __device__ __forceinline__ void uia_swap32(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b)); }
 __device__ __forceinline__ float rows_sum(float v) {

@@ -208,8 +208,9 @@ def train(args):
         t0, w0, enq = time.perf_counter(), train_pf.wait_s, 0.0
         n_it = 0
         if "resident" in ab and epoch > 0:                      # the same device batch every iteration, the prefetcher idle: the loop's floor
-            first = first if epoch > 1 else next(batches)
-            train_pf.close()
+            if epoch == 1:
+                first = next(iter(train_pf))
+                train_pf.close()
             batches = (first for _ in range(len(trainloader)))
         for images, labels, ready in batches:
             t1 = time.perf_counter()

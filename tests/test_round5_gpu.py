@@ -377,7 +377,7 @@ def test_forward_three_byte_handoff_between_adapter_and_block_equals_fp32_handof
     assert not any(r or o for r, o in masks[0])                       # fp32 hand-off: no three-byte operand anywhere in this tower
     assert sum(1 for r, o in masks[1] if o) == 2 and sum(1 for r, o in masks[1] if r) == 2     # adapters 0 and 1 write three bytes, blocks 1 and 2 read them; adapter 2 feeds the CLS head in fp32
     (f0, l0, g0), (f1, l1, g1) = outs
-    # the two hand-offs differ by 2^-16 per element at the boundary (tools/scratch/f3_probe.py: decode(hi, lo) against the fp32 rows 2.2e-5); behind three blocks of bf16 operands
+    # the two hand-offs differ by 2^-16 per element at the boundary (tools/attic/f3_probe.py: decode(hi, lo) against the fp32 rows 2.2e-5); behind three blocks of bf16 operands
     # that perturbation re-rounds some of them: the features move by bf16 noise (max 2-3e-3, rms 1e-4), the SAME size either mode has against the oracle (profiles/r05_d)
     assert float((f0 - f1).abs().max() / f0.abs().max()) < 6e-3 and float((f0 - f1).pow(2).mean().sqrt() / f0.abs().max()) < 1e-3 and abs(l0 - l1) < 2e-3 * max(1.0, abs(l0))
     # gradients: the same bars the bf16 step is held to against the oracle (whole vector: direction and L2; every tensor on the global gradient scale)

@@ -308,3 +308,58 @@ def test_two_ranks_on_two_gpus(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
     assert line["n_gpus"] == 2 and line["rccl_world"] == 2 and line["rccl_initialised"] is True and line["scaling"] == "weak" and line["value"] > 0
+
+
+# ------------------------------------------------------------------------------------------------ UniMed-CLIP (open_clip native layout)
+def test_native_open_clip_layout_equals_the_in_tree_clip_and_its_entry_point_runs(tmp_path, monkeypatch):
+    """src/third_party/open_clip/model.NativeCLIP (batch-first blocks, adapters behind BatchFirstMonaWrapper through the injector's case 2) against the OpenAI-layout
+    CLIP of src/third_party/openai_clip/model.py (sequence-first interface, pinned by the reference's own vectors in tests/test_golden_gpu.py) on the SAME weights and
+    adapters: features and adapter gradients must agree — the two layouts are views of the same batch-first storage.  Then the UniMed entry point end to end."""
+    from src.adapters import inject_mona_variant_to_clip, inject_mona_variant_to_open_clip
+    from src.third_party.open_clip.model import NativeCLIP
+    from src.third_party.openai_clip.model import CLIP
+    from uia_hip import functional as UF
+    UF.set_compute_dtype(torch.float32)
+    torch.manual_seed(3)
+    a = CLIP(64, 32, 2, 128, 8, 16, 100, 64, 2, 1).float()
+    b = NativeCLIP(embed_dim=64, image_size=32, vision_layers=2, vision_width=128, patch_size=8, context_length=16, vocab_size=100, width=64, heads=2, layers=1).float()
+    b.load_state_dict(a.state_dict())
+    for m in (a, b):
+        for p in m.parameters():
+            p.requires_grad_(False)
+    torch.manual_seed(5)
+    inject_mona_variant_to_clip(a, variant="hybrid", bottleneck_dim=64)
+    inject_mona_variant_to_open_clip(b, variant="hybrid", bottleneck_dim=64)
+    pa = {k: p for k, p in a.named_parameters() if "mona" in k}
+    pb = {k.replace(".mona.clip_mona.", ".mona."): p for k, p in b.named_parameters() if "mona" in k}
+    assert set(pa) == set(pb) and len(pa) > 20
+    g = torch.Generator().manual_seed(9)
+    with torch.no_grad():
+        for k in pa:
+            v = 0.05 * torch.randn(pa[k].shape, generator=g) + (1.0 if k.endswith(("norm.weight", "gammax")) else 0.0)
+            pa[k].copy_(v)
+            pb[k].copy_(v)
+    for m in (a, b):
+        for k, p in m.named_parameters():
+            p.requires_grad_("mona" in k)
+        m.to(dev()).eval()
+    x = torch.rand(6, 3, 32, 32, generator=g).to(dev())
+    dy = torch.randn(6, 64, generator=g).to(dev())
+    fa, fb = a.encode_image(x), b.encode_image(x)
+    (fa * dy).sum().backward()
+    (fb * dy).sum().backward()
+    assert float((fa - fb).abs().max()) <= 1e-5 * float(fa.abs().max())
+    for k in pa:
+        ga, gb = pa[k].grad, pb[k].grad
+        assert float((ga - gb).abs().max()) <= 1e-4 * max(float(ga.abs().max()), 1e-6), k
+    ids = torch.randint(1, 99, (6, 16)).to(dev())
+    assert float((a.encode_text(ids) - b.encode_text(ids)).abs().max()) == 0.0
+    # the entry point: reference CLI on the measured loop
+    from src.models.unimedclip import finetune as F
+    monkeypatch.chdir(tmp_path)
+    cfg = "dict(embed_dim=64, image_size=32, vision_layers=2, vision_width=128, patch_size=8, context_length=16, vocab_size=30522, width=64, heads=2, layers=1)"
+    out = F.main(["--synthetic", "--synthetic_train", "32", "--synthetic_val", "16", "--img_size", "32", "--batch_size", "16", "--epochs", "2", "--dtype", "bf16", "--exp", "um",
+                  "--model_config", cfg, "--num_workers", "0", "--lr", "2e-3"])
+    assert out["updates"] == 4 and math.isfinite(out["best_val"]) and math.isfinite(out["last_train"])
+    ck = torch.load(tmp_path / "runs" / "um" / "best_model.pth")
+    assert ck and all(".mona.clip_mona." in k for k in ck)

@@ -49,7 +49,7 @@ def _argparse_table(path):
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="the reference tree exists in the build container only")
 @pytest.mark.parametrize("entry", ["biomedclip/finetune.py", "biomedclip/segmentation.py", "biomedclip/zero_shot.py", "clipseg/segmentation.py", "metaclip/finetune.py",
-                                   "clip/finetune.py"])
+                                   "clip/finetune.py", "unimedclip/finetune.py"])
 def test_every_reference_flag_of_every_entry_point_is_there_with_its_default(entry):
     """The argparse tables of reference and build compared syntactically (flag set, default / action / choices expressions); `--device` is the one deliberate
     difference (decided without a HIP call, src/utils/tools.default_device)."""
@@ -249,3 +249,40 @@ def test_default_device_makes_no_hip_call(monkeypatch):
     monkeypatch.setattr(os.path, "exists", lambda p: False)
     monkeypatch.delenv("HIP_VISIBLE_DEVICES")
     assert tools.default_device() == "cpu"
+
+
+# ------------------------------------------------------------------------------------------------ UniMed-CLIP entry (VERDICT r05 missing #3)
+UNIMED_TOY = ("dict(embed_dim=64, image_size=32, vision_layers=2, vision_width=128, patch_size=8, context_length=16, vocab_size=30522, width=64, heads=2, layers=1)")
+
+
+def test_unimedclip_entry_point_flags_model_layout_and_checkpoint_rule(tmp_path):
+    """reference src/models/unimedclip/finetune.py:27-108: flags / defaults; open_clip's native layout (batch-first blocks under visual.transformer.resblocks, the
+    injector's case 2: adapters wrapped in BatchFirstMonaWrapper -> `...resblocks.{i}.mona.clip_mona.*`); ONLY visual.* and logit_scale are taken from the checkpoint,
+    `module.` prefixes stripped, the text tower stays as initialised."""
+    from src.models.unimedclip import finetune as F
+    a = F.get_args([])
+    want = dict(img_size=224, num_workers=8, strong_augs=False, weak_augs=False, version="ViT-B-16-quickgelu", ckpt="ckpt/unimed_clip_vit_b16.pt", mona_variant="noise_aware",
+                exp="unimedclip_finetune", in_channels=3, mona_bottleneck=64, mona_layers=None, temperature=0.07, seed=1, epochs=1000, batch_size=64, lr=1e-4, lr_min=1e-8,
+                weight_decay=0.01, beta1_adam=0.9, beta2_adam=0.95, patience=10)
+    for k, v in want.items():
+        assert getattr(a, k) == v, k
+    args = F.get_args(["--synthetic", "--model_config", UNIMED_TOY])
+    args.device = "cpu"
+    base, _ = F.prepare_model(args)
+    donor = {("module." + k): torch.full_like(v, 0.25) for k, v in base.state_dict().items() if "mona" not in k}
+    ck = tmp_path / "unimed.pt"
+    torch.save({"state_dict": donor}, ck)
+    args.ckpt = str(ck)
+    model, tok = F.prepare_model(args)
+    sd = model.state_dict()
+    assert float(sd["visual.conv1.weight"].mean()) == 0.25 and float(sd["visual.transformer.resblocks.1.mlp.c_fc.weight"].mean()) == 0.25 and float(sd["logit_scale"]) == 0.25
+    assert float(sd["token_embedding.weight"].abs().mean()) != 0.25 and float(sd["transformer.resblocks.0.ln_1.weight"].mean()) == 1.0      # text tower untouched
+    trainable = [k for k, p in model.named_parameters() if p.requires_grad]
+    assert trainable and all(".mona.clip_mona." in k and k.startswith("visual.transformer.resblocks.") for k in trainable)
+    assert not hasattr(model.visual, "trunk") and model.visual.grid_size == (4, 4) and model.visual.transformer.resblocks[0].batch_first
+    ids = tok(["breast ultrasound image", "x"])
+    assert tuple(ids.shape) == (2, 16) and int(ids[0, 0]) == 2
+    from src.third_party.open_clip.model import NATIVE_GEOMETRY, create_native_clip
+    with pytest.raises(NotImplementedError):
+        create_native_clip("RN50")
+    assert "ViT-B-16-quickgelu" in NATIVE_GEOMETRY

@@ -2,7 +2,7 @@
 # K-loop ablations of tile cfg 27 (results wrong by construction; timing only): 1 no barrier, 2 loads from sub-tiles 0/1 only, 4 no ds_write, 8 no fragment reads,
 # 16 no global loads, 20 = 4+16, 29 = MFMAs alone
 mkdir -p gpurun_out
-# needs the diagnostic library: bash tools/scratch/quadv_build_ablate.sh (before gpurun)
+# needs the diagnostic library: bash tools/attic/quadv_build_ablate.sh (before gpurun)
 export UIA_HIP_LIB=$GRAFT_REPO_ROOT/nextgen-uia_amd/uia_hip/libuia_hip_ablate.so
 for a in 0 1 2 4 8 16 20 29; do
   echo "== ablate $a" >> gpurun_out/quadv_ablate.txt

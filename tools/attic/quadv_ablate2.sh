@@ -1,7 +1,7 @@
 #!/bin/bash
 # tile-seam ablations of cfg 27: 32 = no epilogue, 61 = no epilogue and MFMAs alone in the K loop
 mkdir -p gpurun_out
-# needs the diagnostic library: bash tools/scratch/quadv_build_ablate.sh (before gpurun)
+# needs the diagnostic library: bash tools/attic/quadv_build_ablate.sh (before gpurun)
 export UIA_HIP_LIB=$GRAFT_REPO_ROOT/nextgen-uia_amd/uia_hip/libuia_hip_ablate.so
 for a in 0 32 61; do
   echo "== ablate $a" >> gpurun_out/quadv_ablate2.txt

@@ -1,7 +1,7 @@
 #!/bin/bash
 # one round of tiles on 72 CUs vs on 252 CUs: is the epilogue paced by each CU's own store path or by all CUs bursting together?  (cfg 27, full and without epilogue)
 mkdir -p gpurun_out
-# needs the diagnostic library: bash tools/scratch/quadv_build_ablate.sh (before gpurun)
+# needs the diagnostic library: bash tools/attic/quadv_build_ablate.sh (before gpurun)
 export UIA_HIP_LIB=$GRAFT_REPO_ROOT/nextgen-uia_amd/uia_hip/libuia_hip_ablate.so
 for a in 0 32; do
   echo "== ablate $a" >> gpurun_out/quadv_ablate3.txt
