@@ -32,7 +32,7 @@ for _p in (ROOT, os.path.join(ROOT, "nextgen-uia_amd")):
 # algorithmic work per image-caption pair: 69.95 GF image tower fwd+bwd (+Mona) + 45.90 GF text fwd
 GFLOP_PER_PAIR = 115.86
 PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
-TRAFFIC_FILE = "r05_traffic_pmc.json"   # tools/pmc_traffic.sh on the tree that is benchmarked; tests/test_host_logic.py checks that every instantiation is in it
+TRAFFIC_FILE = "r06_traffic_pmc.json"   # tools/pmc_traffic.sh on the tree that is benchmarked; tests/test_host_logic.py checks that every instantiation is in it
 
 
 def parse():

@@ -139,9 +139,11 @@ def test_clipseg_loop_matches_a_restatement_of_the_reference_loop(tmp_path, monk
     for k in names:
         # against the distance travelled: AdamW moves an element whose gradient is at rounding level by a whole lr in either direction, so a max-norm bar on the
         # weights themselves would measure those elements (2.1e-4 seen on one of 131 072 entries of fc2), not the loop
+        # (k_proj.bias: the softmax is invariant to a key bias — its gradient is rounding noise on both sides, and AdamW normalises noise to steps of +-lr: the
+        #  second term allows 2 % of the elements to differ by a whole lr)
         moved = float((P[k] - P0[k]).norm())
         err = float((got[k].detach().cpu() - P[k]).norm())
-        assert err <= 0.05 * moved + 1e-7, (k, err, moved)
+        assert err <= 0.05 * moved + 0.02 * args.lr * P[k].numel() ** 0.5, (k, err, moved)
 
 
 def test_biomedclip_segmentation_test_mode(tmp_path, monkeypatch):
@@ -360,6 +362,6 @@ def test_native_open_clip_layout_equals_the_in_tree_clip_and_its_entry_point_run
     cfg = "dict(embed_dim=64, image_size=32, vision_layers=2, vision_width=128, patch_size=8, context_length=16, vocab_size=30522, width=64, heads=2, layers=1)"
     out = F.main(["--synthetic", "--synthetic_train", "32", "--synthetic_val", "16", "--img_size", "32", "--batch_size", "16", "--epochs", "2", "--dtype", "bf16", "--exp", "um",
                   "--model_config", cfg, "--num_workers", "0", "--lr", "2e-3"])
-    assert out["updates"] == 4 and math.isfinite(out["best_val"]) and math.isfinite(out["last_train"])
+    assert out["iters"] == 4 and math.isfinite(out["best_val"]) and math.isfinite(out["last_train"])
     ck = torch.load(tmp_path / "runs" / "um" / "best_model.pth")
     assert ck and all(".mona.clip_mona." in k for k in ck)

@@ -19,7 +19,15 @@ from oracle import vit_ref, mona_ref
 SITES = ["A_qkv", "W_qkv", "O_qkv", "attn_P", "O_attn", "W_proj", "A_fc1", "W_fc1", "O_gelu", "W_fc2", "mona_u", "W_p1", "mona_t", "mona_d", "W_p2"]
 ON = set()
 rb = lambda t: t.bfloat16().float()
-R = lambda site, t: rb(t) if site in ON else t
+EXACT_W = set()          # data_ptr of frozen weights kept UNROUNDED (--exact-weight-blocks: what a bf16 hi + bf16 lo split of those weights would give, to 2^-16)
+
+
+def R(site, t):
+    if site not in ON or (site.startswith("W_") and t.data_ptr() in EXACT_W):
+        return t
+    return rb(t)
+
+
 _lin, _gelu, _attn = F.linear, F.gelu, vit_ref._attention
 KIND = {(2304, 768): "qkv", (768, 768): "proj", (3072, 768): "fc1", (768, 3072): "fc2", (64, 768): "p1", (768, 64): "p2"}
 IN_MONA = [False]
@@ -77,6 +85,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--stress", action="store_true")
+    ap.add_argument("--exact-weight-blocks", default="", help="round 6 (VERDICT r05 item 5): comma-separated lists of blocks whose frozen weights stay unrounded, ';' between "
+                    "experiments, e.g. '0,1,10,11;0,1,2,3;8,9,10,11' — prints max-norm / rms of the image features with every other site on, then exits")
     args = ap.parse_args()
     import importlib.util
     spec = importlib.util.spec_from_file_location("pabb", os.path.join(ROOT, "tools", "parity_at_bench_batch.py"))
@@ -100,6 +110,19 @@ def main():
     ON.update(SITES)
     e_all = rel(features(images, P), ref)
     print(f"batch {args.batch}{' (outlier stress)' if args.stress else ''}: every site on: image features rel {e_all:.2e}   (rms {float((features(images, P) - ref).pow(2).mean().sqrt() / ref.abs().max()):.2e})")
+    if args.exact_weight_blocks:
+        import re
+        for exp in args.exact_weight_blocks.split(";"):
+            blocks = {int(b) for b in exp.split(",") if b.strip() != ""}
+            EXACT_W.clear()
+            for k, v in P.items():
+                m = re.match(r"visual\.trunk\.blocks\.(\d+)\.(attn|mlp)\..*weight$", k)
+                if m and int(m.group(1)) in blocks and v.dim() == 2:
+                    EXACT_W.add(v.data_ptr())
+            f = features(images, P)
+            print(f"frozen weights of blocks {sorted(blocks)} unrounded ({len(EXACT_W)} matrices), every other site on: max-norm {rel(f, ref):.2e}   rms {float((f - ref).pow(2).mean().sqrt() / ref.abs().max()):.2e}")
+        EXACT_W.clear()
+        return
     print(f"{'site':10s} {'only this site':>16s} {'all but this site':>18s}")
     groups = [("A_qkv",), ("A_fc1",), ("W_qkv", "W_proj", "W_fc1", "W_fc2"), ("O_qkv",), ("attn_P",), ("O_attn",), ("O_gelu",), ("mona_u",), ("mona_t",), ("mona_d",), ("W_p1", "W_p2")]
     for grp in groups:
