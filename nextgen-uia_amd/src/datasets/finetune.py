@@ -6,6 +6,8 @@ batch contract: images float32 [B,3,S,S] in [0,1] WITHOUT mean/std normalisation
 `drop_last=True`.  `--synthetic` provides exactly that deterministically; real data can be supplied as a .pt file of
 {"images": uint8/float [N,3,S,S], "texts": [str]*N} via --data_pt.
 """
+import os
+
 import torch
 from torch.utils.data import DataLoader, Dataset
 
@@ -108,6 +110,8 @@ class SharedBatchRing:
     def pin(self):
         """hipHostRegister the ring (once, from the process that owns the GPU): host-to-device copies from a slot are then asynchronous DMA.  False when the runtime
         refuses: the consumer stages through its own pinned buffers instead."""
+        if self.pinned is None and os.environ.get("UIA_RING_NO_PIN"):      # measurement knob: host-to-device copies through the consumer's own pinned staging buffers
+            self.pinned = False
         if self.pinned is None:
             ok = True
             try:

@@ -39,8 +39,20 @@ def synthetic_batch(B, size, seed, device):
     return img.to(device), mask[:, None].float().to(device)
 
 
-def as_model_input(images, labels, in_channels=3):
-    """Device side of the batch contract: the grayscale channel repeated (reference :199-200), the mask as float32."""
+def as_model_input(images, labels, in_channels=3, bufs=None):
+    """Device side of the batch contract: the grayscale channel repeated (reference :199-200), the mask as float32.
+    bufs: a dict the caller keeps — the widened batch is written into the same two tensors every iteration (one copy kernel each, no allocation: the step's
+    working set stays where it was, as with a resident batch)."""
+    if bufs is not None:
+        key = (tuple(images.shape), in_channels, images.device)
+        if key not in bufs:
+            c = 3 if (images.shape[1] == 1 and in_channels == 3) else images.shape[1]
+            bufs[key] = (torch.empty((images.shape[0], c) + tuple(images.shape[2:]), dtype=torch.float32, device=images.device),
+                         torch.empty(labels.shape, dtype=torch.float32, device=labels.device))
+        im, lab = bufs[key]
+        im.copy_(images.expand_as(im) if images.shape[1] != im.shape[1] else images)
+        lab.copy_(labels)
+        return im, lab
     if images.shape[1] == 1 and in_channels == 3:
         images = images.expand(-1, 3, -1, -1).contiguous()
     return images.float(), labels.float()

@@ -195,6 +195,7 @@ def train(args):
     iter_num, best_val_dice, patience_counter = 0, 0.0, 0
     epoch_ms, logged = [], []
     cur = torch.cuda.current_stream()
+    bufs = {}                                                    # the widened training batch lives in the same two tensors every iteration
     dm.set_epoch(0)
     batches = iter(train_pf)
     ab = os.environ.get("UIA_SEG_AB", "")                     # measurement knobs (tools/ab_clipseg_entry.sh); none is set in normal use
@@ -203,6 +204,14 @@ def train(args):
         gc.disable()
     if "switch" in ab:
         sys.setswitchinterval(0.05)
+    sampler = None
+    if "power" in ab:                                            # board power / shader clock during the epochs (bench.py's sampler: amdgpu hwmon files, no HIP call)
+        sys.path.insert(0, str(Path(__file__).resolve().parents[4]))
+        sys.argv, _argv = ["bench.py"], sys.argv
+        import bench as _bench
+        sys.argv = _argv
+        sampler = _bench.PowerSampler(torch, torch.device(args.device))
+        sampler.start()
     for epoch in range(max_epoch):
         torch.cuda.synchronize()
         t0, w0, enq = time.perf_counter(), train_pf.wait_s, 0.0
@@ -215,7 +224,7 @@ def train(args):
         for images, labels, ready in batches:
             t1 = time.perf_counter()
             cur.wait_event(ready)
-            images, labels = as_model_input(images, labels, args.in_channels)
+            images, labels = as_model_input(images, labels, args.in_channels, bufs)
             # scheduler.step() follows optimizer.step() (:147-148): iteration i runs at the closed form's value for i
             loss, _ = segmentation_step(model, criterion, opt, images, labels, input_ids=_batch_prompt(prompt, cache, images.shape[0]),
                                         lr=cosine_lr(args.lr, args.lr_min, iter_num, max_iters))
@@ -291,6 +300,8 @@ def train(args):
         logging.warning("no validation improved on a mean Dice of 0.0: saving the last iterate as best_model.pth")
         torch.save({"decoder": model.decoder.state_dict()}, os.path.join(args.train_snapshot_path, "best_model.pth"))
     out = {"iters": iter_num, "best_val_dice": best_val_dice, "rank": rank, "world": world, "epochs": epoch_ms}
+    if sampler is not None:
+        out["power"] = sampler.stop()
     if args.stats_json and rank == 0:
         import json
         with open(args.stats_json, "w") as f:

@@ -168,10 +168,11 @@ class FlatAdapterOptimizer(FlatLayout):
         """The squared gradient norm of every guarded update, read WITHOUT a host sync (copied to pinned memory behind the update, examined one update
         late).  A non-finite norm behind finite losses means the backward itself diverged — or a three-byte gradient token (functional.publish_grad3)
         was read by something that is not its consumer: raise instead of training on NaN weights."""
-        prev = getattr(self, "_norm_poll", None)
-        if prev is not None:
+        pending = self.__dict__.setdefault("_norm_polls", [])
+        while len(pending) >= UF.POLL_LAG:                     # recorded UF.POLL_LAG updates ago: returns at once unless the host is that far ahead of the GPU
+            prev = pending.pop(0)
             t0 = time.perf_counter()
-            prev[1].synchronize()                              # recorded a whole update ago: returns at once unless the host is a full update ahead of the GPU
+            prev[1].synchronize()
             self.gpu_wait_s = getattr(self, "gpu_wait_s", 0.0) + time.perf_counter() - t0
             if float(prev[0][1]) != 0.0 and not math.isfinite(float(prev[0][0])):
                 raise FloatingPointError("uia_hip: the accumulated adapter gradient is non-finite although every accumulated loss was finite: the backward diverged "
@@ -180,7 +181,7 @@ class FlatAdapterOptimizer(FlatLayout):
         host.copy_(self.ws8[:2], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        self._norm_poll = (host, ev)
+        pending.append((host, ev))
 
     def read_guard(self):
         """One host sync: {updates, accumulated, skipped, updates_skipped, loss_sum, ok_log}; clears the loss sum and the log."""

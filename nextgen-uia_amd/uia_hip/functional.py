@@ -97,6 +97,11 @@ _FOLD_POLL = {}          # device index -> (pinned host word, event) of a read-b
 _FOLD_REPORTED = {}      # device index -> bits already reported
 
 
+POLL_LAG = max(1, int(os.environ.get("UIA_POLL_LAG", "2")))     # steps between a guard word's copy to pinned memory and its examination on the host (poll_ln_flag, engine._poll_norm): with 1
+                                                                # the host can never be more than ONE step ahead of the GPU, and any jitter of its enqueue time beyond the GPU's step time shows
+                                                                # as a bubble (round 6: the CLIPSeg CLI, 8.3 ms steps enqueued in 6-7 ms beside a loader thread)
+
+
 def reset_ln_flag(device=None):
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     key = dev.index if dev.index is not None else torch.cuda.current_device()
@@ -121,10 +126,11 @@ def poll_ln_flag(device=None, sync=False):
     if flag is None:
         return 0
     seen = 0
-    prev = _FOLD_POLL.pop(key, None)
-    if prev is not None:
+    pending = _FOLD_POLL.setdefault(key, [])
+    while pending and (sync or len(pending) >= POLL_LAG):       # the copy made POLL_LAG calls ago: the host may run that many steps ahead of the GPU before it waits here
+        prev = pending.pop(0)
         t0 = time.perf_counter()
-        prev[1].synchronize()                                   # long done: it was recorded a whole step ago (unless the host is that far ahead of the GPU)
+        prev[1].synchronize()
         _STATE["gpu_wait_s"] = _STATE.get("gpu_wait_s", 0.0) + time.perf_counter() - t0
         seen |= int(prev[0][0])
     host = torch.empty(1, dtype=torch.int32, pin_memory=True)
@@ -135,7 +141,7 @@ def poll_ln_flag(device=None, sync=False):
         ev.synchronize()
         seen |= int(host[0])
     else:
-        _FOLD_POLL[key] = (host, ev)
+        pending.append((host, ev))
     seen &= ~_FOLD_REPORTED.get(key, 0) | 2                       # a centring warning is given once; a range error every time it is seen
     _FOLD_REPORTED[key] = _FOLD_REPORTED.get(key, 0) | (seen & 1)
     if seen & 2:
