@@ -126,7 +126,7 @@ class FlatAdapterOptimizer(FlatLayout):
                             self.max_norm, self.steps, gs, self.ws)
         UF.WEIGHTS.bump()                                      # T copies of the adapter weights are stale now
         if UF.ln_fold_enabled(UF.compute_dtype()):             # guard of the folded LayerNorms: every folded layer of every step was checked on
-            UF.poll_ln_flag(self.device)                       # the device; this reads the verdict without a host sync (one step late)
+            UF.poll_ln_flag(self.device)                       # the device; this reads the verdict without a host sync (UF.POLL_LAG steps late)
 
     def grad_norm(self):
         """‖g‖₂ of the last update (before clipping; one host read)."""

@@ -119,7 +119,7 @@ def poll_ln_flag(device=None, sync=False):
             take over from the next forward;
       bit 1 (a non-finite or out-of-range partial sum): LnFoldRangeError — the step that produced it must not be trusted.
     sync=False (the training loops, once per step): no host synchronisation — the word is copied to pinned memory behind the step's
-    kernels and the copy of the PREVIOUS call is examined, so a bad step is reported one step late; sync=True waits for this one."""
+    kernels and the copy made POLL_LAG calls ago is examined, so a bad step is reported POLL_LAG (2) steps late; sync=True waits for this one."""
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     key = dev.index if dev.index is not None else torch.cuda.current_device()
     flag = ops._LN_FLAG.get(key)
