@@ -205,12 +205,9 @@ def train(args):
     if "switch" in ab:
         sys.setswitchinterval(0.05)
     sampler = None
-    if "power" in ab:                                            # board power / shader clock during the epochs (bench.py's sampler: amdgpu hwmon files, no HIP call)
-        sys.path.insert(0, str(Path(__file__).resolve().parents[4]))
-        sys.argv, _argv = ["bench.py"], sys.argv
-        import bench as _bench
-        sys.argv = _argv
-        sampler = _bench.PowerSampler(torch, torch.device(args.device))
+    if "power" in ab:                                            # board power / shader clock during the epochs (uia_hip.telemetry: amdgpu hwmon files, no HIP call)
+        from uia_hip.telemetry import PowerSampler
+        sampler = PowerSampler(torch, torch.device(args.device))
         sampler.start()
     for epoch in range(max_epoch):
         torch.cuda.synchronize()
