@@ -286,3 +286,22 @@ def test_unimedclip_entry_point_flags_model_layout_and_checkpoint_rule(tmp_path)
     with pytest.raises(NotImplementedError):
         create_native_clip("RN50")
     assert "ViT-B-16-quickgelu" in NATIVE_GEOMETRY
+
+
+def test_bench_help_and_telemetry_without_a_gpu():
+    """`python bench.py --help` must work (a bare percent sign in one help string made argparse raise until round 6), and the telemetry sampler must be inert where the
+    driver's hwmon files are absent (this container): no thread, no exception, None."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "--gpus" in r.stdout and "--steps" in r.stdout and "--warmup" in r.stdout, r.stderr[-500:]
+    from uia_hip.telemetry import PowerSampler
+
+    class _NoDevice:
+        class cuda:
+            @staticmethod
+            def get_device_properties(d):
+                raise RuntimeError("no GPU")
+    s = PowerSampler(_NoDevice, "cuda:0")
+    s.start()
+    assert s.stop() is None
