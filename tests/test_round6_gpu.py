@@ -365,3 +365,38 @@ def test_native_open_clip_layout_equals_the_in_tree_clip_and_its_entry_point_run
     assert out["iters"] == 4 and math.isfinite(out["best_val"]) and math.isfinite(out["last_train"])
     ck = torch.load(tmp_path / "runs" / "um" / "best_model.pth")
     assert ck and all(".mona.clip_mona." in k for k in ck)
+
+
+def test_clipseg_entry_point_on_a_data_file_with_its_own_split(tmp_path, monkeypatch):
+    """--data_pt: real data handed over as tensors (uint8 three-channel images are reduced to the one grayscale channel the reference's loader produces,
+    reference src/datasets/segmentation.py:175; masks binarised; the file's own train / val / test split and names are used) through the whole CLI: train, validate,
+    checkpoint, test(), results.csv — and under --in_channels 3 the model sees three identical channels."""
+    from src.datasets import segmentation as D
+    from src.models.clipseg import segmentation as S
+    monkeypatch.chdir(tmp_path)
+    g = torch.Generator().manual_seed(5)
+    n = 44
+    gray = torch.randint(0, 256, (n, 1, 64, 64), generator=g, dtype=torch.uint8)
+    yy, xx = torch.meshgrid(torch.arange(64), torch.arange(64), indexing="ij")
+    cx = torch.randint(16, 48, (n,), generator=g)
+    labels = (((yy[None] - 32) ** 2 + (xx[None] - cx[:, None, None]) ** 2) <= 100)[:, None].to(torch.uint8) * 255      # 0 / 255 masks as a PNG would hold them
+    blob = {"images": gray.repeat(1, 3, 1, 1), "labels": labels, "names": [f"case_{i:03d}.png" for i in range(n)],
+            "split": {"train": list(range(0, 24)), "val": list(range(24, 34)), "test": list(range(34, 44))}}
+    torch.save(blob, tmp_path / "data.pt")
+    args = S.get_args(["--dataset", "BUSI", "--data_pt", str(tmp_path / "data.pt"), "--img_size", "64", "--batch_size", "8", "--num_workers", "0"])
+    dm = D.DataModule(args, rank=0, world=1)
+    assert (len(dm.train_dataset), len(dm.val_dataset), len(dm.test_dataset)) == (24, 10, 10)
+    im, lab, name = dm.test_dataset[3]
+    assert name == "case_037.png" and tuple(im.shape) == (1, 64, 64) and im.dtype == torch.float32 and float(im.max()) <= 1.0 and lab.dtype == torch.uint8 and set(lab.unique().tolist()) <= {0, 1}
+    assert torch.equal(im[0], gray[37, 0].float() / 255.0) and torch.equal(lab[0].bool(), labels[37, 0] > 0)
+    x, y = D.as_model_input(im[None].to(dev()), lab[None].to(dev()), 3)
+    assert tuple(x.shape) == (1, 3, 64, 64) and torch.equal(x[0, 0], x[0, 2]) and y.dtype == torch.float32
+    with pytest.raises(FileNotFoundError):                       # no --synthetic: the backbone must come from --ckpt, as in the reference (clip.load raises for a missing file)
+        S.main(["--dataset", "BUSI", "--data_pt", str(tmp_path / "data.pt"), "--img_size", "64", "--batch_size", "8", "--epochs", "1", "--exp", "dp0", "--num_workers", "0"])
+    from src.third_party.openai_clip.model import CLIP
+    torch.manual_seed(2)
+    torch.save(CLIP(64, 64, 10, 128, 16, 77, 49408, 64, 1, 2).state_dict(), tmp_path / "clip.pt")       # a plain state dict; build_model() reads the geometry off it (reference model.py:417-465)
+    out = S.main(["--dataset", "BUSI", "--data_pt", str(tmp_path / "data.pt"), "--ckpt", str(tmp_path / "clip.pt"), "--img_size", "64", "--batch_size", "8", "--epochs", "2",
+                  "--lr", "1e-3", "--dtype", "bf16", "--exp", "dp", "--num_workers", "0"])
+    assert out["train"]["iters"] == 2 * 3 and math.isfinite(out["test"]["loss"]) and out["test"]["results_csv"].endswith("results.csv")
+    assert os.path.exists(tmp_path / "runs" / "dp" / "BUSI" / "train" / "best_model.pth")
