@@ -39,10 +39,13 @@ def synthetic_batch(B, size, seed, device):
     return img.to(device), mask[:, None].float().to(device)
 
 
-def as_model_input(images, labels, in_channels=3, bufs=None):
+def as_model_input(images, labels, in_channels=3, bufs=None, widen=True):
     """Device side of the batch contract: the grayscale channel repeated (reference :199-200), the mask as float32.
-    bufs: a dict the caller keeps — the widened batch is written into the same two tensors every iteration (one copy kernel each, no allocation: the step's
-    working set stays where it was, as with a resident batch)."""
+    widen=False: the one-channel batch goes to the towers as it is — their patch embedding takes it with the channel-summed kernel (UF.gray_conv_weight), which is
+    the same convolution; the segmentation loops use it (no 77 MB copy written per iteration).
+    bufs: a dict the caller keeps — a widened batch is written into the same two tensors every iteration (one copy kernel each, no allocation)."""
+    if not widen and images.shape[1] == 1 and in_channels == 3:
+        return images.float(), labels.float()
     if bufs is not None:
         key = (tuple(images.shape), in_channels, images.device)
         if key not in bufs:

@@ -116,7 +116,7 @@ def evaluate(model, loader_pf, args, accumulator):
     with torch.no_grad():
         for images, labels, ready in loader_pf:
             cur.wait_event(ready)
-            images, labels = as_model_input(images, labels, args.in_channels)
+            images, labels = as_model_input(images, labels, args.in_channels, widen=False)
             accumulator.update(model(images).detach(), labels.detach())
 
 
@@ -153,7 +153,7 @@ def train(args):
         t0, n_it = time.perf_counter(), 0
         for images, labels, ready in batches:
             cur.wait_event(ready)
-            images, labels = as_model_input(images, labels, args.in_channels, bufs)
+            images, labels = as_model_input(images, labels, args.in_channels, bufs, widen=False)
             loss, _ = segmentation_step(model, criterion, opt, images, labels, lr=cosine_lr(args.lr, args.lr_min, iter_num, max_iters))
             if iter_num % 10 == 0:
                 logged.append((iter_num, loss))

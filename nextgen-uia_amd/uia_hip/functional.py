@@ -1129,6 +1129,26 @@ def post_ln_layer(res, x_t, L, B, heads, P, keylen, eps=1e-12, cu_seqlens=None, 
     return _post_ln(s_o, P["output.LayerNorm.weight"], P["output.LayerNorm.bias"], eps, x_t, stats_buf=stats_buf), x_t
 
 
+_GRAY_W = {}
+
+
+def gray_conv_weight(conv_w):
+    """Patch-embedding weight for ONE-channel input: Σ_c W[:, c] — a convolution over three identical channels (the reference repeats the grayscale ultrasound
+    image, src/datasets/segmentation.py:199-200) is the convolution of the one channel with the summed kernel.  The segmentation loops hand the towers the
+    one-channel batch as it arrived from the host: a third of the bytes read, and no 77 MB widened copy written per iteration (round 6: rewriting the input
+    batch every iteration costs the step 4 % — it evicts the frozen weights from the 256 MB infinity cache that a resident batch leaves warm).  Cached per
+    (tensor, version); frozen weights only."""
+    if conv_w.requires_grad:
+        raise NotImplementedError("one-channel input through a TRAINABLE patch embedding: widen the batch instead (src.datasets.segmentation.as_model_input)")
+    key = id(conv_w)
+    hit = _GRAY_W.get(key)
+    sig = (conv_w._version, conv_w.data_ptr(), conv_w.dtype, conv_w.device)
+    if hit is None or hit[0] != sig or hit[2]() is not conv_w:
+        import weakref
+        hit = _GRAY_W[key] = (sig, conv_w.detach().float().sum(dim=1, keepdim=True).contiguous(), weakref.ref(conv_w))
+    return hit[1]
+
+
 class PatchEmbedFn(torch.autograd.Function):
     """images [B,3,H,W] → tokens [B, 1+gh*gw, D] fp32 (= cat(cls, conv(x)) + pos); frozen → no backward."""
 

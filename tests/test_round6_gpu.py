@@ -400,3 +400,41 @@ def test_clipseg_entry_point_on_a_data_file_with_its_own_split(tmp_path, monkeyp
                   "--lr", "1e-3", "--dtype", "bf16", "--exp", "dp", "--num_workers", "0"])
     assert out["train"]["iters"] == 2 * 3 and math.isfinite(out["test"]["loss"]) and out["test"]["results_csv"].endswith("results.csv")
     assert os.path.exists(tmp_path / "runs" / "dp" / "BUSI" / "train" / "best_model.pth")
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_one_channel_batches_equal_the_widened_ones(mode):
+    """The segmentation loops hand the towers the grayscale batch as ONE channel (reference src/datasets/segmentation.py:199-200 repeats it three times on the host):
+    the patch embedding then runs with the channel-summed kernel (UF.gray_conv_weight) — the same convolution.  CLIPSeg logits and a timm-trunk tower's features on
+    [B, 1, S, S] against the same batch widened to three channels: rounding-level in fp32, bf16-weight-rounding level in bf16."""
+    from src.third_party.biomedclip.model import create_biomedclip
+    from src.third_party.openai_clip.clipseg_adapter import CLIPSegAdapter
+    from src.third_party.openai_clip.model import CLIP
+    from uia_hip import functional as UF
+    UF.set_compute_dtype(torch.float32 if mode == "fp32" else torch.bfloat16)
+    tol = 2e-5 if mode == "fp32" else 1.5e-2        # bf16: bf16(w0 + w1 + w2) against bf16(w0), bf16(w1), bf16(w2) — two roundings of the same weights (7e-3 of max|logit| measured)
+    g = torch.Generator().manual_seed(3)
+    torch.manual_seed(1)
+    model = CLIPSegAdapter(CLIP(64, 64, 10, 128, 16, 77, 49408, 64, 1, 2).float())
+    model.freeze_clip_backbone()
+    model = model.to(dev()).eval()
+    gray = torch.rand(4, 1, 64, 64, generator=g).to(dev())
+    ids = torch.zeros(4, 77, dtype=torch.long)
+    ids[:, 0], ids[:, 1:6], ids[:, 6] = 49406, 1234, 49407
+    with torch.no_grad():
+        a = model(gray, input_ids=ids.to(dev())).float()
+        b = model(gray.repeat(1, 3, 1, 1), input_ids=ids.to(dev())).float()
+    assert tuple(a.shape) == (4, 2, 64, 64) and float((a - b).abs().max()) <= tol * float(b.abs().max())
+    cfg = dict(embed_dim=128, vision_cfg=dict(img_size=32, patch_size=8, embed_dim=128, depth=2, num_heads=2),
+               text_cfg=dict(vocab_size=30000, hidden_size=128, num_hidden_layers=1, num_attention_heads=2, intermediate_size=256, max_position_embeddings=64))
+    tower = create_biomedclip(config=cfg, seed=4)
+    for p in tower.parameters():
+        p.requires_grad_(False)
+    tower = tower.to(dev()).eval()
+    gray = torch.rand(6, 1, 32, 32, generator=g).to(dev())
+    with torch.no_grad():
+        fa, fb = tower.encode_image(gray).float(), tower.encode_image(gray.repeat(1, 3, 1, 1)).float()
+    assert float((fa - fb).abs().max()) <= tol * float(fb.abs().max())
+    tower.visual.trunk.patch_embed.proj.weight.requires_grad_(True)
+    with pytest.raises(NotImplementedError):
+        tower.encode_image(gray)
