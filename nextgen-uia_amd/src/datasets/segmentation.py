@@ -8,7 +8,8 @@ supplies them deterministically (U[0,1) grayscale images with a random-ellipse m
 {"images": [N, 1 or 3, S, S] uint8 / float, "labels": [N, 1, S, S], optional "names", optional "split": {"train": idx, "val": idx, "test": idx}}.
 
 Because the three channels are copies of one, a batch travels host -> device as ONE channel (float32) plus a uint8 mask — 32 MB instead of 103 MB at 128 images —
-through the same shared-memory slot ring the fine-tune loader uses, and `as_model_input` repeats the channel on the device (a 77 MB write at HBM rate).
+through the same shared-memory slot ring the fine-tune loader uses; the towers' patch embedding takes the one channel with the channel-summed kernel
+(uia_hip.functional.gray_conv_weight — the same convolution), `as_model_input(..., widen=True)` repeats the channel on the device for callers that want the reference's tensor.
 """
 import torch
 from torch.utils.data import DataLoader, Dataset
