@@ -127,10 +127,10 @@ def report_test(args, stats, saved_best, rank=0):
     if rank != 0:
         return None
     backup_folder = os.path.join(args.test_snapshot_path, f"{datetime.datetime.now().strftime('%Y_%m_%d_%H_%M_%S')}_iou={stats['iou_mean'] * 100:.2f}")
-    n = 1
+    base, n = backup_folder, 1
     while os.path.exists(backup_folder):                        # two tests within one second with the same IoU (the reference's os.makedirs raises there)
         n += 1
-        backup_folder = backup_folder.rsplit("__", 1)[0] + f"__{n}"
+        backup_folder = f"{base}__{n}"
     os.makedirs(backup_folder)
     csv_path = os.path.join(backup_folder, "results.csv")
     with open(csv_path, "w") as f:
