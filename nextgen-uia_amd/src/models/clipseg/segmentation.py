@@ -285,83 +285,16 @@ def train(args):
 
     writer.close()
 
-    def resident_loop():                                         # measurement knob "post": bench.py's loop (a resident batch) in THIS process
-        model.train()
-        im, lab = synthetic_batch(args.batch_size, args.img_size, 1, args.device)
-        bp = _batch_prompt(prompt, cache, args.batch_size)
-        for _ in range(30):
-            segmentation_step(model, criterion, opt, im, lab, input_ids=bp, lr=args.lr_min)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(120):
-            segmentation_step(model, criterion, opt, im, lab, input_ids=bp, lr=args.lr_min)
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / 120 * 1e3
-    post = [resident_loop()] if "post" in ab else None           # ... with the loaders' worker processes alive and the rings registered
-    if "attrib" in ab:                                           # which ingredient of the epoch loop costs GPU time?  the resident loop + one ingredient at a time
-        im, lab = synthetic_batch(args.batch_size, args.img_size, 1, args.device)
-        bp = _batch_prompt(prompt, cache, args.batch_size)
-        side = torch.cuda.Stream(device=args.device)
-        host_im = torch.empty(args.batch_size, 1, args.img_size, args.img_size, pin_memory=True)
-        host_lab = torch.zeros(args.batch_size, 1, args.img_size, args.img_size, dtype=torch.uint8, pin_memory=True)
-        dev_im = [torch.empty_like(host_im, device=args.device) for _ in range(4)]
-        dev_lab = [torch.empty_like(host_lab, device=args.device) for _ in range(4)]
-        gray = im[:, :1].contiguous()
-
-        def variant(copy, wait, fresh, rec):
-            def body(k):
-                ev = None
-                if copy:
-                    with torch.cuda.stream(side):
-                        dev_im[k % 4].copy_(host_im, non_blocking=True)
-                        dev_lab[k % 4].copy_(host_lab, non_blocking=True)
-                        ev = torch.cuda.Event()
-                        ev.record(side)
-                if wait and ev is not None:
-                    cur.wait_event(ev)
-                x, y = (gray, lab)
-                if fresh:                                        # the step reads the freshly copied (rotating) buffers, as the epoch loop does
-                    dev_im[k % 4].copy_(gray) if not copy else None
-                    x, y = dev_im[k % 4], lab
-                segmentation_step(model, criterion, opt, x, y, input_ids=bp, lr=args.lr_min)
-                if rec:
-                    e2 = torch.cuda.Event()
-                    e2.record(cur)
-            for k in range(30):
-                body(k)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for k in range(120):
-                body(k)
-            torch.cuda.synchronize()
-            return round((time.perf_counter() - t0) / 120 * 1e3, 3)
-        attrib = {"resident gray": variant(False, False, False, False), "+H2D copies on a side stream": variant(True, False, False, False),
-                  "+copies +wait_event": variant(True, True, False, False), "+copies +wait +step reads the rotating buffers": variant(True, True, True, False),
-                  "rotating buffers filled by a kernel (no H2D)": variant(False, False, True, False), "+event record per step": variant(False, False, False, True)}
-        # ... and the resident loop while the loaders WORK: a thread drains the training prefetcher (workers collate, the ring fills and empties, copies run) beside it
-        import threading
-        stop = threading.Event()
-
-        def drain():
-            torch.cuda.set_device(torch.device(args.device))
-            while not stop.is_set():
-                for _b in train_pf:
-                    if stop.is_set():
-                        break
-        th = threading.Thread(target=drain, daemon=True)
-        th.start()
-        attrib["resident gray, loaders working beside it"] = variant(False, False, False, False)
-        stop.set()
-        th.join(timeout=20)
-        train_pf.close()
-        attrib["resident gray again, loaders idle"] = variant(False, False, False, False)
-    else:
-        attrib = None
+    measure = None
+    if "post" in ab or "attrib" in ab:                           # measurement knobs (tools/ab_clipseg_post.sh, ab_clipseg_attrib.sh): src/models/clipseg/_measure.py
+        from src.models.clipseg import _measure
+        measure = _measure.Probe(model, criterion, opt, prompt, cache, args, train_pf)
+        measure.before_shutdown(ab)
     for pf in (train_pf, val_pf, test_pf):
         pf.close()                                               # an epoch prefetched and then abandoned by early stopping
     dm.shutdown()
-    if post is not None:
-        post.append(resident_loop())                             # ... and after they are gone
+    if measure is not None:
+        measure.after_shutdown(ab)
     if world > 1:
         from uia_hip import ops
         import torch.distributed as dist
@@ -374,10 +307,8 @@ def train(args):
     out = {"iters": iter_num, "best_val_dice": best_val_dice, "rank": rank, "world": world, "epochs": epoch_ms}
     if sampler is not None:
         out["power"] = sampler.stop()
-    if post is not None:
-        out["post_resident_ms"] = post
-    if attrib is not None:
-        out["attrib_ms"] = attrib
+    if measure is not None:
+        out.update(measure.results)
     if args.stats_json and rank == 0:
         import json
         with open(args.stats_json, "w") as f:
