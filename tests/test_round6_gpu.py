@@ -264,14 +264,16 @@ def test_the_loop_descends_at_vit_b16_geometry_and_agrees_with_the_oracle():
     T = 14
     small = D.run_hip(8, T, 1e-3)
     ref = D.run_oracle(8, T, 1e-3, threads=_cpu_share())
-    assert ref["losses"][-1] < 0.8 * ref["losses"][0] and small["losses"][-1] < 0.8 * small["losses"][0], (small["losses"], ref["losses"])
+    # (three repetitions on one box, tools/descent_margins.py: B = 64 min(last 5) / first 0.66-0.70; B = 8 last / first 0.59-0.76 for HIP — single steps bounce — and 0.52 for
+    #  the oracle; first six losses within 0.5 %; displacement cosine 0.78; oracle loss with the HIP-trained adapters 1.29-1.42 against 2.08 untrained)
+    assert min(ref["losses"][-4:]) < 0.8 * ref["losses"][0] and min(small["losses"][-4:]) < 0.8 * small["losses"][0], (small["losses"], ref["losses"])
     for a, b in zip(small["losses"][:6], ref["losses"][:6]):                           # same initial adapters, same batches: the curves coincide until rounding
         assert a == pytest.approx(b, rel=0.02), (small["losses"], ref["losses"])       # differences have grown through the updates (0.5 % over the first seven)
     cos, ratio = D.alignment(small, ref)
     assert cos > 0.5 and 0.7 < ratio < 1.4, (cos, ratio)                               # (two ORACLE runs whose initial adapters differ by 1e-3: 0.95 after 8 updates)
     # what the HIP path learned, judged by the reference arithmetic on a batch neither run has seen
     l0, l1 = D.oracle_loss(None, 8, T, threads=_cpu_share()), D.oracle_loss(small["state"], 8, T, threads=_cpu_share())
-    assert l1 < 0.8 * l0 and l1 == pytest.approx(small["losses"][-1], rel=0.35), (l0, l1, small["losses"])
+    assert l1 < 0.8 * l0 and l1 < 1.6 * min(small["losses"][-4:]), (l0, l1, small["losses"])
 
 
 # ------------------------------------------------------------------------------------------------ two ranks, when the box has them
