@@ -172,12 +172,14 @@ __global__ __launch_bounds__(64 * NW, NW >= 7 ? 4 : 1) void attn_fwd_bf16_kernel
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             if (4 * c < LTq) {
+                // (tiles at and past LT_MAX cannot hold a key of this instantiation — L <= 16·LT_MAX by dispatch: the last chunk of the 13-tile kernel is ONE tile,
+                //  not four of which three were computed, exponentiated and discarded: 13 tiles instead of 16 per query tile of a 197-token head, round 6)
                 if (c < interior) {
 #pragma unroll
-                    for (int t = 4 * c; t < 4 * c + 4; ++t) tile(t, std::false_type{});
+                    for (int t = 4 * c; t < 4 * c + 4; ++t) if (t < LT_MAX) tile(t, std::false_type{});
                 } else {
 #pragma unroll
-                    for (int t = 4 * c; t < 4 * c + 4; ++t) tile(t, std::true_type{});
+                    for (int t = 4 * c; t < 4 * c + 4; ++t) if (t < LT_MAX) tile(t, std::true_type{});
                 }
             } else {
 #pragma unroll
@@ -196,11 +198,15 @@ __global__ __launch_bounds__(64 * NW, NW >= 7 ? 4 : 1) void attn_fwd_bf16_kernel
             if (4 * c < LTq) {
 #pragma unroll
                 for (int t = 4 * c; t < 4 * c + 4; ++t)
+                    if (t < LT_MAX) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float e = __builtin_amdgcn_exp2f(fmaf(s[t][r], sc, -msc));      // exp2(-inf) = 0 for masked keys
-                        s[t][r] = e;
-                        sum += e;
+                        for (int r = 0; r < 4; ++r) {
+                            const float e = __builtin_amdgcn_exp2f(fmaf(s[t][r], sc, -msc));      // exp2(-inf) = 0 for masked keys
+                            s[t][r] = e;
+                            sum += e;
+                        }
+                    } else {
+                        s[t] = f32x4{0.f, 0.f, 0.f, 0.f};         // never a key: contributes 0 to the PV product's padded k-slots
                     }
             }
         }
