@@ -489,7 +489,7 @@ def main():
 
 
 def secondary_lines(args, device):
-    """BASELINE configs[3] and the per-GPU shape of configs[4] inside the default line (the driver runs only the default command): 10 timed steps
+    """BASELINE configs[3] and the per-GPU shape of configs[4] inside the default line (the driver runs only the default command): 15 timed steps
     each, no CPU leg, the same keys as `python bench.py --config clipseg|vitl_lora` prints, cut to what a reader needs."""
     import copy
     import gc
@@ -498,7 +498,7 @@ def secondary_lines(args, device):
     lines = {}
     for cfg, fn in (("clipseg", bench_clipseg), ("vitl_lora", bench_vitl_lora)):
         a = copy.copy(args)
-        a.config, a.batch, a.steps, a.warmup, a.no_cpu_baseline, a.overlap_text, a.streams = cfg, 128, 10, 3, True, False, 1
+        a.config, a.batch, a.steps, a.warmup, a.no_cpu_baseline, a.overlap_text, a.streams = cfg, 128, 15, 5, True, False, 1      # (10 + 3 until round 6: one 100 ms hiccup inside ten steps once read as 78.8 ms for a 67.7 ms step)
         UF.clear_t_copies()
         gc.collect()
         torch.cuda.empty_cache()
