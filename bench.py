@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--no-entry-point", action="store_true", help="skip the `entry_point` form: the fine-tune CLI (src/models/biomedclip/finetune.py --method mona --synthetic, bs 256, "
                     "one update per batch) run as a child process after the timed region, its steady-state ms per update printed beside the headline")
     ap.add_argument("--entry-steps", type=int, default=60, help="updates per epoch of the entry-point run (3 epochs; the first is warm-up)")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the two secondary lines (BASELINE configs[3] and the per-GPU shape of configs[4], 10 steps each, "
+    ap.add_argument("--no-secondary", action="store_true", help="skip the two secondary lines (BASELINE configs[3] and the per-GPU shape of configs[4], 15 steps each, "
                     "no CPU leg) that the default single-GPU run prints under `secondary`")
     ap.add_argument("--also-streams", type=int, default=1, help="after the timed region, time 5 more steps each of two other forms of the step (everything on one stream; the text tower on "
                     "valid tokens only) and report them beside the headline as `other_forms` (0 = skip)")
